@@ -1,0 +1,132 @@
+/*
+ * mpassit_amd.h -- C-ABI of the MI355X-native regrid engine that replaces the ESMF calls made by
+ * LarissaReames-NOAA/MPASSIT's hot path (interp.F90 + the ESMF_Mesh/Grid objects of model_grid.F90).
+ *
+ * Every entry point replaces one ESMF verb at the cited reference call sites.
+ * Conventions (mirroring the reference, utils.F90:16-33 / interp.F90:130-131):
+ *   - every function returns an int rc, 0 == MPG_SUCCESS (like ESMF_SUCCESS); on failure
+ *     mpg_last_error() returns a message; the caller decides to abort (the reference always does,
+ *     error_handler -> mpi_abort(999)).
+ *   - the caller owns all host buffers; the library owns device buffers and the opaque objects.
+ *   - one process drives one GPU (one "PET" per GPU, mpassit.F90:84-96); calls are synchronous at the
+ *     boundary unless the name ends in _dev and a stream is passed.
+ *   - all floating point data is float64 (ESMF_TYPEKIND_R8 everywhere, interp.F90:479), indices int32.
+ *   - there is NO CPU fallback: without a HIP device mpg_init fails and every other call returns
+ *     MPG_ERR_NOT_INITIALIZED.
+ */
+#ifndef MPASSIT_AMD_H
+#define MPASSIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpg_mesh_s *mpg_mesh;     /* replaces type(ESMF_Mesh)        model_grid.F90:72  */
+typedef struct mpg_grid_s *mpg_grid;     /* replaces type(ESMF_Grid)        model_grid.F90:73  */
+typedef struct mpg_handle_s *mpg_handle; /* replaces type(ESMF_RouteHandle) interp.F90:86,192  */
+
+enum {
+  MPG_SUCCESS = 0,
+  MPG_ERR_NOT_INITIALIZED = 1,
+  MPG_ERR_INVALID_ARG = 2,
+  MPG_ERR_HIP = 3,
+  MPG_ERR_UNSUPPORTED = 4,
+  MPG_ERR_OVERFLOW = 5
+};
+
+/* ESMF_REGRIDMETHOD_* (interp.F90:119,204,370,420) */
+enum { MPG_REGRIDMETHOD_BILINEAR = 0, MPG_REGRIDMETHOD_CONSERVE = 1, MPG_REGRIDMETHOD_NEAREST_STOD = 2 };
+/* ESMF_MESHLOC_* (input_data.F90:927,1116-1123) */
+enum { MPG_MESHLOC_ELEMENT = 0, MPG_MESHLOC_NODE = 1 };
+/* ESMF_STAGGERLOC_* (interp.F90:480,489,509; model_grid.F90:706-728) */
+enum { MPG_STAGGERLOC_CENTER = 0, MPG_STAGGERLOC_EDGE1 = 1, MPG_STAGGERLOC_EDGE2 = 2, MPG_STAGGERLOC_CORNER = 3 };
+/* memory order of a source field with an ungridded (level) dimension */
+enum {
+  MPG_LAYOUT_CELL_FAST = 0, /* [nlev][ncell]: how the reference holds fields, input_data.F90:653-655 */
+  MPG_LAYOUT_LEV_FAST = 1   /* [ncell][nlev]: MPAS file order, input_data.F90:630,645 (fused ingest) */
+};
+
+/* ---- runtime: ESMF_Initialize / ESMF_Finalize (mpassit.F90:84,140) ------------------------------ */
+int mpg_init(int device);
+int mpg_finalize(void);
+const char *mpg_last_error(void);
+/* "gfx950" etc.; buf may be NULL */
+int mpg_device_info(char *arch_buf, int buf_len, int *n_cu, int64_t *hbm_bytes);
+
+/* ---- ESMF_MeshCreate (model_grid.F90:488-497) ---------------------------------------------------
+ * Arrays exactly as read from the MPAS file (model_grid.F90:354-417): lat/lon in RADIANS, the
+ * deg conversion + (-180,180] wrap of :450-454,464-468 happens inside; verticesOnCell is
+ * [nCells][maxEdges], 1-based, 0-padded (:448,479).  Elements = cells, nodes = vertices. */
+int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell,
+                    const double *lonCell, const double *latVertex, const double *lonVertex,
+                    const int32_t *verticesOnCell, mpg_mesh *out);
+int mpg_mesh_destroy(mpg_mesh mesh); /* ESMF_MeshDestroy model_grid.F90:2154 */
+
+/* ---- ESMF_GridCreateNoPeriDim / 1PeriDim + GridAddCoord x4 (model_grid.F90:684-728,736-1038) ------
+ * nx, ny = mass (CENTER) point counts (i_target, j_target).  Coordinates in DEGREES, C order with i
+ * fastest: centre [ny][nx], corner [ny+1][nx+1], EDGE1 (U) [ny][nx+1], EDGE2 (V) [ny+1][nx].
+ * corner/edge arrays may be NULL when the corresponding stagger is never used. */
+int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, const double *lat_center,
+                    const double *lon_corner, const double *lat_corner, const double *lon_edge1,
+                    const double *lat_edge1, const double *lon_edge2, const double *lat_edge2,
+                    mpg_grid *out);
+int mpg_grid_destroy(mpg_grid grid); /* ESMF_GridDestroy model_grid.F90:2156 */
+
+/* ---- ESMF_Field[Bundle]RegridStore (interp.F90:123,207,226,241,259,277,334,353,372,394,421,437) ---
+ * srcTermProcessing=1, unmappedaction=IGNORE are implied.  Mesh -> Grid.  Handles are cached: the same
+ * (mesh, src_loc, grid, dst_stagger, method) returns the same handle (reference recomputes it up to
+ * 13x per run); each Store must be paired with one mpg_handle_release. */
+int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod,
+                     mpg_handle *out);
+/* Grid -> Grid on the same grid, CENTER -> EDGE1/EDGE2 bilinear (interp.F90:298,316). */
+int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod,
+                          mpg_handle *out);
+
+/* ---- ESMF_Field[Bundle]Regrid (interp.F90:134,219,236,251,268,286,307,325,344,363,382,404,431,443) --
+ * dst is fully overwritten: [nfields][nlev][ny_dst][nx_dst], unmapped points = 0.0 (zeroregion=TOTAL).
+ * src: nfields slabs of nlev*n_src doubles in `src_layout` order.  Host-pointer version copies
+ * H2D/D2H internally; the _dev version takes device pointers and a hipStream_t (NULL = default
+ * stream) and returns after enqueueing. */
+int mpg_regrid(mpg_handle rh, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host);
+int mpg_regrid_dev(mpg_handle rh, const double *src_dev, int src_layout, int nlev, int nfields,
+                   double *dst_dev, void *hip_stream);
+/* ESMF_FieldBundleRegridRelease (interp.F90:450,455,461) */
+int mpg_handle_release(mpg_handle rh);
+
+/* ---- rotate_winds_cgrid (interp.F90:689-749): in place on CENTER-stagger u, v [nlev][ny][nx] with
+ * cosalpha/sinalpha [ny][nx] (model_grid.F90:1154).  */
+int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const double *sina_host,
+                     double *u_host, double *v_host);
+int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const double *sina_dev,
+                         double *u_dev, double *v_dev, void *hip_stream);
+
+/* ---- introspection (tests, INTEGRATION.md, multi-GPU halo schedule) -------------------------------- */
+/* n_src: source points the handle indexes; n_dst = nx_dst*ny_dst; nnz_per_row: 3 bilinear(mesh),
+ * 4 bilinear(grid), 1 nearest, 0 = CSR (conservative); nnz = total stored weights. */
+int mpg_handle_info(mpg_handle rh, int64_t *n_src, int64_t *n_dst, int *nx_dst, int *ny_dst,
+                    int *nnz_per_row, int64_t *nnz);
+/* fixed-nnz handles: idx/w are [n_dst][nnz_per_row] (row-major, host); idx = -1 where unmapped */
+int mpg_handle_get_weights(mpg_handle rh, int32_t *idx_host, double *w_host);
+/* CSR handles: rowptr [n_dst+1], col/val [nnz] (host) */
+int mpg_handle_get_csr(mpg_handle rh, int64_t *rowptr_host, int32_t *col_host, double *val_host);
+/* dual (Delaunay) triangles of a mesh: tri_host [nVertices][3], 0-based cell ids or -1 */
+int mpg_mesh_get_triangles(mpg_mesh mesh, int32_t *tri_host);
+
+/* Multi-GPU (ESMF's per-Regrid source exchange): sorted unique source ids the handle
+ * references.  Call with ids_host == NULL to get the count.  mpg_handle_localize rewrites the handle's
+ * indices to positions in that list so that Regrid reads a compact [nlev][n_unique] halo buffer. */
+int mpg_handle_unique_sources(mpg_handle rh, int64_t *n_unique, int32_t *ids_host);
+int mpg_handle_localize(mpg_handle rh);
+/* dst[k][i] = src[k][ids[i]] (pack owned cells for the halo exchange); all device pointers */
+int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *ids_dev, int64_t n_ids,
+                 double *dst_dev, void *hip_stream);
+
+/* timing of the last Store phases in ms (search build, search, finalize); any pointer may be NULL */
+int mpg_handle_store_ms(mpg_handle rh, float *ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""ctypes binding of libmpassit_amd.so (the C-ABI of include/mpassit_amd.h).
+
+There is no CPU implementation behind this module: if the HIP library is missing, or no GPU is
+present at `init()`, every entry point raises.  Nothing here imports the test oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libmpassit_amd.so")
+
+# every symbol include/mpassit_amd.h declares (tests check they are all exported)
+SYMBOLS = [
+    "mpg_init", "mpg_finalize", "mpg_last_error", "mpg_device_info", "mpg_mesh_create", "mpg_mesh_destroy",
+    "mpg_grid_create", "mpg_grid_destroy", "mpg_regrid_store", "mpg_regrid_store_grid", "mpg_regrid",
+    "mpg_regrid_dev", "mpg_handle_release", "mpg_rotate_winds", "mpg_rotate_winds_dev", "mpg_handle_info",
+    "mpg_handle_get_weights", "mpg_handle_get_csr", "mpg_mesh_get_triangles", "mpg_handle_unique_sources",
+    "mpg_handle_localize", "mpg_pack_dev", "mpg_handle_store_ms",
+]
+
+MPG_SUCCESS = 0
+REGRIDMETHOD_BILINEAR, REGRIDMETHOD_CONSERVE, REGRIDMETHOD_NEAREST_STOD = 0, 1, 2
+MESHLOC_ELEMENT, MESHLOC_NODE = 0, 1
+STAGGERLOC_CENTER, STAGGERLOC_EDGE1, STAGGERLOC_EDGE2, STAGGERLOC_CORNER = 0, 1, 2, 3
+LAYOUT_CELL_FAST, LAYOUT_LEV_FAST = 0, 1
+
+_lib = None
+_initialized = False
+
+
+class MpgError(RuntimeError):
+    def __init__(self, rc, msg):
+        super().__init__("libmpassit_amd rc=%d: %s" % (rc, msg))
+        self.rc = rc
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                "%s not found: build the HIP extension first (python -m mpassit_amd.build); "
+                "mpassit_amd has no CPU fallback" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        L.mpg_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            if name != "mpg_last_error":
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != MPG_SUCCESS:
+        raise MpgError(rc, load().mpg_last_error().decode("utf-8", "replace"))
+
+
+def init(device=0):
+    """ESMF_Initialize equivalent (mpassit.F90:84).  Requires a HIP device."""
+    global _initialized
+    check(load().mpg_init(C.c_int(device)))
+    _initialized = True
+
+
+def finalize():
+    global _initialized
+    if _lib is not None:
+        check(_lib.mpg_finalize())
+    _initialized = False
+
+
+def device_info():
+    buf = C.create_string_buffer(64)
+    ncu, hbm = C.c_int(), C.c_int64()
+    check(load().mpg_device_info(buf, C.c_int(64), C.byref(ncu), C.byref(hbm)))
+    return buf.value.decode(), ncu.value, hbm.value

@@ -1,0 +1,60 @@
+// Device-side spherical geometry shared by the weight-generation kernels (float64 throughout).
+// Semantics follow SURVEY.md Appendix A (ESMF reference manual); the CPU oracle restates the same
+// mathematics independently in oracle/mpassit_oracle.c.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define MPG_TOL 1e-10  // "inside" tolerance on barycentric / parametric coordinates (App. A2)
+
+struct dv3 {
+  double x, y, z;
+};
+__device__ __forceinline__ dv3 mk3(double x, double y, double z) { return dv3{x, y, z}; }
+__device__ __forceinline__ dv3 operator-(dv3 a, dv3 b) { return dv3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ dv3 operator+(dv3 a, dv3 b) { return dv3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ dv3 operator*(dv3 a, double s) { return dv3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ double dot3(dv3 a, dv3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ dv3 cross3(dv3 a, dv3 b) {
+  return dv3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ dv3 ld3(const double *x, const double *y, const double *z, int64_t i) {
+  return dv3{x[i], y[i], z[i]};
+}
+// det[p,b,c] through differences from p (well conditioned for km-scale triangles on the unit sphere)
+__device__ __forceinline__ double det3_from(dv3 p, dv3 b, dv3 c) { return dot3(p, cross3(b - p, c - p)); }
+
+// A2: barycentric weights of P in planar triangle ABC seen from the origin.  Returns true when inside.
+__device__ __forceinline__ bool tri_weights(dv3 P, dv3 A, dv3 B, dv3 C, double tol, double *w) {
+  dv3 a = A - P, b = B - P, c = C - P;
+  double dA = dot3(P, cross3(b, c)), dB = dot3(P, cross3(c, a)), dC = dot3(P, cross3(a, b));
+  double S = dA + dB + dC;
+  if (!(S > 0.0)) return false;
+  w[0] = dA / S;
+  w[1] = dB / S;
+  w[2] = dC / S;
+  return w[0] >= -tol && w[1] >= -tol && w[2] >= -tol;
+}
+
+// A6: squared chord distance, evaluated as ((dx^2 + dy^2) + dz^2) WITHOUT fma so that host (oracle) and
+// device agree bit for bit and box lower bounds stay monotone.
+__device__ __forceinline__ double dist2_nofma(double px, double py, double pz, double cx, double cy, double cz) {
+#pragma clang fp contract(off)
+  double dx = px - cx, dy = py - cy, dz = pz - cz;
+  double a = dx * dx, b = dy * dy, c = dz * dz;
+  return (a + b) + c;
+}
+__device__ __forceinline__ double boxdist2_nofma(double px, double py, double pz, const double *bx) {
+#pragma clang fp contract(off)
+  double dx = fmax(fmax(bx[0] - px, px - bx[3]), 0.0);
+  double dy = fmax(fmax(bx[1] - py, py - bx[4]), 0.0);
+  double dz = fmax(fmax(bx[2] - pz, pz - bx[5]), 0.0);
+  double a = dx * dx, b = dy * dy, c = dz * dz;
+  return (a + b) + c;
+}
+
+// A5: signed spherical triangle area (Van Oosterom-Strackee), difference form
+__device__ __forceinline__ double sph_tri_area(dv3 a, dv3 b, dv3 c) {
+  double num = det3_from(a, b, c);
+  double den = 1.0 + dot3(a, b) + dot3(b, c) + dot3(c, a);
+  return 2.0 * atan2(num, den);
+}

@@ -1,0 +1,271 @@
+// Weight application ("Regrid") kernels -- the HBM-bound hot path.
+//
+// Replace ESMF_Field[Bundle]Regrid at interp.F90:134,219,236,251,268,286,307,325,344,363,382,404,431,
+// 443.  Semantics: dst(p,k) = sum_j w_pj * src(c_pj, k) for every level k of the
+// ungridded dimension, float64 accumulation; the destination is fully overwritten and unmapped points
+// are 0.0 (zeroregion=TOTAL + unmappedaction=IGNORE); nearest-neighbour is a pure copy (bit exact).
+//
+//   K2  k_apply3_cf    3-point gather, source cell-fastest [nlev][ncell] (reference memory order,
+//                       input_data.F90:653-655), destination [nlev][ny][nx]
+//   K2' k_apply3_lf    same from level-fastest [ncell][nlev] (MPAS file order, input_data.F90:630,645):
+//                       the reference's host transpose is fused away through an LDS tile transpose
+//   K3  k_apply1       nearest-neighbour copy
+//   K4  k_apply_csr    conservative (variable row length)
+//   K6  k_applyN<4>    4-point destagger (CENTER -> EDGE1/EDGE2)
+//   K7  k_rotate       rotate_winds_cgrid (interp.F90:737-748)
+//
+// Roofline: no reuse beyond the ~1.9 target points that share a source value, 5 flop per 36-60 B ->
+// HBM-bound; MFMA does not apply.  Design for CDNA4: 64 consecutive i per wave (512 B coalesced,
+// non-temporal stores so the write stream does not evict the source lines from L2), 2-D target tiles so
+// a workgroup's gather footprint is spatially compact, XCD-aware tile order so neighbouring tiles share
+// an L2, weights/indices SoA and read once per tile for all levels.
+#include "geom.h"
+#include "mpg_internal.h"
+
+static int g_lev_chunk = 0;  // 0 = all levels in one workgroup pass (tunable through MPG_LEV_CHUNK)
+static int g_tune_read = 0;
+
+// bijective XCD swizzle (cdna_hip_programming.md s5 "XCD swizzle must be bijective"): workgroups b and
+// b+8 share an XCD, so give each XCD one contiguous range of the linear work space.
+__device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
+  unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+#define A3_TX 64
+#define A3_RPT 4
+#define A3_TY (4 * A3_RPT)
+
+__global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                   const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                   int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk) {
+  int64_t P = (int64_t)nx * ny;
+  unsigned ntile = (unsigned)ntx * nty;
+  unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned tile = lin % ntile;
+  unsigned rest = lin / ntile;  // = field * nchunk + chunk
+  int chunk = rest % nchunk;
+  int fld = rest / nchunk;
+  int tx = tile % ntx, ty = tile / ntx;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int i = tx * A3_TX + lane;
+  int j0 = ty * A3_TY + wave * A3_RPT;
+  int k0 = chunk * lev_chunk, k1 = min(nlev, k0 + lev_chunk);
+
+  int32_t c[A3_RPT][3];
+  double ww[A3_RPT][3];
+  bool act[A3_RPT], mapped[A3_RPT];
+#pragma unroll
+  for (int r = 0; r < A3_RPT; ++r) {
+    int j = j0 + r;
+    act[r] = (i < nx) && (j < ny);
+    int64_t p = act[r] ? (int64_t)j * nx + i : 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      c[r][q] = idx[q * P + p];
+      ww[r][q] = w[q * P + p];
+    }
+    mapped[r] = c[r][0] >= 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
+  }
+  const double *s = src + ((int64_t)fld * nlev + k0) * nsrc;
+  double *d = dst + ((int64_t)fld * nlev + k0) * P + (int64_t)j0 * nx + i;
+  for (int k = k0; k < k1; ++k) {
+    double v[A3_RPT];
+#pragma unroll
+    for (int r = 0; r < A3_RPT; ++r) {
+      double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
+      v[r] = ww[r][0] * a + ww[r][1] * b + ww[r][2] * e;
+    }
+#pragma unroll
+    for (int r = 0; r < A3_RPT; ++r)
+      if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + (int64_t)r * nx);
+    s += nsrc;
+    d += P;
+  }
+}
+
+// Level-fastest source: one workgroup = 64 consecutive target points x all levels.
+// phase 1: wave w serves points 16w..16w+15, lanes = levels -> three coalesced row reads per point;
+// phase 2: lanes = points -> 512-B coalesced stores per level.  LDS tile [nlev][65] doubles.
+__global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                   const double *__restrict__ src, double *__restrict__ dst, int64_t P,
+                                                   int64_t nsrc, int nlev, int nblk) {
+  extern __shared__ double tile[];  // [nlev][65]
+  unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned blk = lin % nblk;
+  int fld = lin / nblk;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t p0 = (int64_t)blk * 64;
+  const double *sf = src + (int64_t)fld * nlev * nsrc;
+  for (int q = 0; q < 16; ++q) {
+    int pt = wave * 16 + q;
+    int64_t p = p0 + pt;
+    if (p >= P) break;
+    int32_t c0 = idx[p], c1 = idx[P + p], c2 = idx[2 * P + p];
+    double w0 = w[p], w1 = w[P + p], w2 = w[2 * P + p];
+    bool mapped = c0 >= 0;
+    c0 = max(c0, 0); c1 = max(c1, 0); c2 = max(c2, 0);
+    for (int k = lane; k < nlev; k += 64) {
+      double a = sf[(int64_t)c0 * nlev + k], b = sf[(int64_t)c1 * nlev + k], e = sf[(int64_t)c2 * nlev + k];
+      double v = w0 * a + w1 * b + w2 * e;
+      tile[k * 65 + pt] = mapped ? v : 0.0;
+    }
+  }
+  __syncthreads();
+  double *df = dst + (int64_t)fld * nlev * P;
+  int64_t p = p0 + lane;
+  if (p < P)
+    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + p);
+}
+
+// nearest neighbour: bit-exact copy
+__global__ __launch_bounds__(256) void k_apply1(const int32_t *__restrict__ idx, const double *__restrict__ src,
+                                                double *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast,
+                                                int nblk) {
+  unsigned blk = blockIdx.x % nblk;
+  int fld = blockIdx.x / nblk;
+  int64_t p = (int64_t)blk * 256 + threadIdx.x;
+  if (p >= P) return;
+  int32_t c = idx[p];
+  const double *sf = src + (int64_t)fld * nlev * nsrc;
+  double *df = dst + (int64_t)fld * nlev * P;
+  for (int k = 0; k < nlev; ++k) {
+    double v = 0.0;
+    if (c >= 0) v = lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c];
+    df[(int64_t)k * P + p] = v;
+  }
+}
+
+template <int NNZ>
+__global__ __launch_bounds__(256) void k_applyN(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                const double *__restrict__ src, double *__restrict__ dst, int64_t P,
+                                                int64_t nsrc, int nlev, int lev_fast, int nblk) {
+  unsigned blk = blockIdx.x % nblk;
+  int fld = blockIdx.x / nblk;
+  int64_t p = (int64_t)blk * 256 + threadIdx.x;
+  if (p >= P) return;
+  int32_t c[NNZ];
+  double ww[NNZ];
+#pragma unroll
+  for (int q = 0; q < NNZ; ++q) {
+    c[q] = idx[q * P + p];
+    ww[q] = w[q * P + p];
+  }
+  bool mapped = c[0] >= 0;
+  const double *sf = src + (int64_t)fld * nlev * nsrc;
+  double *df = dst + (int64_t)fld * nlev * P;
+  for (int k = 0; k < nlev; ++k) {
+    double acc = 0.0;
+    if (mapped) {
+#pragma unroll
+      for (int q = 0; q < NNZ; ++q) acc += ww[q] * (lev_fast ? sf[(int64_t)c[q] * nlev + k] : sf[(int64_t)k * nsrc + c[q]]);
+    }
+    df[(int64_t)k * P + p] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_apply_csr(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const double *__restrict__ val, const double *__restrict__ src,
+                                                   double *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast,
+                                                   int nblk) {
+  unsigned blk = blockIdx.x % nblk;
+  int fld = blockIdx.x / nblk;
+  int64_t p = (int64_t)blk * 256 + threadIdx.x;
+  if (p >= P) return;
+  int b = rowptr[p], e = rowptr[p + 1];
+  const double *sf = src + (int64_t)fld * nlev * nsrc;
+  double *df = dst + (int64_t)fld * nlev * P;
+  for (int k = 0; k < nlev; ++k) {
+    double acc = 0.0;
+    for (int q = b; q < e; ++q) {
+      int32_t c = col[q];
+      acc += val[q] * (lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]);
+    }
+    df[(int64_t)k * P + p] = acc;
+  }
+}
+
+// rotate_winds_cgrid (interp.F90:737-748); evaluated exactly as written (no FMA) -> bit-identical to the oracle
+__global__ __launch_bounds__(256) void k_rotate(int64_t npts, int nlev, const double *__restrict__ cosa,
+                                                const double *__restrict__ sina, double *__restrict__ u, double *__restrict__ v) {
+#pragma clang fp contract(off)
+  int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= npts) return;
+  double ca = cosa[p], sa = sina[p];
+  double tana = sa / ca;
+  double den = ca + sa * tana;
+  for (int k = 0; k < nlev; ++k) {
+    int64_t q = (int64_t)k * npts + p;
+    double uo = u[q], vo = v[q];
+    double t1 = vo * tana;
+    double un = (uo + t1) / den;
+    double t2 = un * sa;
+    double vn = (vo - t2) / ca;
+    u[q] = un;
+    v[q] = vn;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, int64_t nsrc, int nlev,
+                                              const int32_t *__restrict__ ids, int64_t nids, double *__restrict__ dst) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nids) return;
+  int32_t c = ids[i];
+  for (int k = 0; k < nlev; ++k) dst[(int64_t)k * nids + i] = src[(int64_t)k * nsrc + c];
+}
+
+int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s) {
+  if (!g_tune_read) {
+    g_tune_read = 1;
+    const char *e = getenv("MPG_LEV_CHUNK");
+    if (e) g_lev_chunk = atoi(e);
+  }
+  int64_t P = h->n_dst;
+  int lev_fast = layout == MPG_LAYOUT_LEV_FAST;
+  if (P == 0 || nlev == 0 || nfields == 0) return MPG_SUCCESS;
+  int nblk = (int)((P + 255) / 256);
+  if (h->kind == MPG_KIND_CSR) {
+    k_apply_csr<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->rowptr.p, h->col.p, h->val.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
+  } else if (h->nnz_per_row == 1) {
+    k_apply1<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
+  } else if (h->nnz_per_row == 4) {
+    k_applyN<4><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
+  } else if (h->nnz_per_row == 3) {
+    if (lev_fast) {
+      int nb64 = (int)((P + 63) / 64);
+      size_t lds = sizeof(double) * 65 * (size_t)nlev;
+      if (lds > 160 * 1024) {
+        mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
+        return MPG_ERR_UNSUPPORTED;
+      }
+      k_apply3_lf<<<(unsigned)nb64 * nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, nb64);
+    } else {
+      int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + A3_TY - 1) / A3_TY;
+      int lc = g_lev_chunk > 0 ? g_lev_chunk : nlev;
+      int nchunk = (nlev + lc - 1) / lc;
+      unsigned nwg = (unsigned)ntx * nty * nchunk * nfields;
+      k_apply3_cf<<<nwg, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk);
+    }
+  } else {
+    mpg_set_error("Regrid: unsupported handle");
+    return MPG_ERR_UNSUPPORTED;
+  }
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s) {
+  if (npts == 0 || nlev == 0) return MPG_SUCCESS;
+  k_rotate<<<(unsigned)((npts + 255) / 256), 256, 0, s>>>(npts, nlev, cosa, sina, u, v);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s) {
+  if (n_ids == 0 || nlev == 0) return MPG_SUCCESS;
+  k_pack<<<(unsigned)((n_ids + 255) / 256), 256, 0, s>>>(src, n_src, nlev, ids, n_ids, dst);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}

@@ -1,0 +1,64 @@
+// Source-halo support for the multi-GPU path (replaces the per-Regrid source exchange hidden in ESMF's
+// route handle): sorted unique source ids referenced by a handle, index compaction,
+// and the pack kernel lives in k_apply.hip.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "mpg_internal.h"
+
+__global__ __launch_bounds__(256) void k_mark(int64_t n, const int32_t *__restrict__ idx, int32_t *__restrict__ flag) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t c = idx[i];
+    if (c >= 0) flag[c] = 1;
+  }
+}
+__global__ __launch_bounds__(256) void k_compact(int64_t n, const int32_t *__restrict__ flag, const int32_t *__restrict__ pos,
+                                                 int32_t *__restrict__ ids) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (flag[i]) ids[pos[i]] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void k_remap(int64_t n, int32_t *__restrict__ idx, const int32_t *__restrict__ pos) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t c = idx[i];
+    if (c >= 0) idx[i] = pos[c];
+  }
+}
+
+int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap, hipStream_t s) {
+  int rc;
+  int64_t n = h->n_src;
+  int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
+  int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
+  DevBuf<int32_t> flag, pos, out;
+  if ((rc = flag.alloc((size_t)n + 1)) || (rc = pos.alloc((size_t)n + 1))) return rc;
+  MPG_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t) * (n + 1), s));
+  int gb = (int)((ni + 255) / 256);
+  if (gb > 8192) gb = 8192;
+  if (gb < 1) gb = 1;
+  k_mark<<<gb, 256, 0, s>>>(ni, ip, flag.p);
+  size_t tmp_bytes = 0;
+  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag.p, pos.p, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), s));
+  DevBuf<char> tmp;
+  if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
+  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, flag.p, pos.p, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), s));
+  int32_t nu = 0;
+  MPG_HIP(hipMemcpyAsync(&nu, pos.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  ids.resize((size_t)nu);
+  if ((rc = out.alloc((size_t)nu + 1))) return rc;
+  int gn = (int)((n + 255) / 256);
+  if (gn > 8192) gn = 8192;
+  k_compact<<<gn, 256, 0, s>>>(n, flag.p, pos.p, out.p);
+  if (nu) MPG_HIP(hipMemcpyAsync(ids.data(), out.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, s));
+  if (remap) {
+    k_remap<<<gb, 256, 0, s>>>(ni, ip, pos.p);
+    h->n_src = nu;
+    h->localized = true;
+  }
+  MPG_HIP(hipGetLastError());
+  MPG_HIP(hipStreamSynchronize(s));
+  flag.free(); pos.free(); out.free(); tmp.free();
+  return MPG_SUCCESS;
+}
+

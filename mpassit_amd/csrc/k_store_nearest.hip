@@ -1,0 +1,217 @@
+// K3 "build_nearest": nearest source-to-destination RegridStore.
+//
+// Replaces ESMF_FieldBundleRegridStore(regridmethod=NEAREST_STOD) at interp.F90:421 (and the soil
+// bundle at :437 by method fall-through).  Semantics (App. A6): every destination
+// point maps to argmin over ALL source cell centres of the 3-D chord distance, ties -> lowest cell
+// id; points outside the mesh footprint are mapped too.
+//
+// MI355X-native formulation: cell centres are sorted along a 63-bit Morton curve (rocPRIM radix sort,
+// set-up only), which makes an implicit 8-ary BVH: leaf = 8 consecutive sorted sites, each upper level
+// groups 8 nodes.  One thread per target point runs an exact branch-and-bound descent (nearest child
+// first).  Distances and box lower bounds are evaluated without FMA in a fixed order so the bound is
+// monotone in floating point and the argmin / tie-break is identical to the CPU oracle's.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "geom.h"
+#include "mpg_internal.h"
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
+  v &= 0x1fffffull;
+  v = (v | v << 32) & 0x1f00000000ffffull;
+  v = (v | v << 16) & 0x1f0000ff0000ffull;
+  v = (v | v << 8) & 0x100f00f00f00f00full;
+  v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+__global__ __launch_bounds__(256) void k_morton(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                const double *__restrict__ z, unsigned long long *__restrict__ key,
+                                                int32_t *__restrict__ id) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double sc = 2097151.0 * 0.5;  // (2^21 - 1) / 2
+  unsigned long long qx = (unsigned long long)fmin(fmax((x[i] + 1.0) * sc, 0.0), 2097151.0);
+  unsigned long long qy = (unsigned long long)fmin(fmax((y[i] + 1.0) * sc, 0.0), 2097151.0);
+  unsigned long long qz = (unsigned long long)fmin(fmax((z[i] + 1.0) * sc, 0.0), 2097151.0);
+  key[i] = spread21(qx) | (spread21(qy) << 1) | (spread21(qz) << 2);
+  id[i] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void k_gather_sites(int64_t n, const int32_t *__restrict__ id, const double *__restrict__ x,
+                                                      const double *__restrict__ y, const double *__restrict__ z,
+                                                      double *__restrict__ sx, double *__restrict__ sy, double *__restrict__ sz) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t c = id[i];
+  sx[i] = x[c];
+  sy[i] = y[c];
+  sz[i] = z[c];
+}
+__global__ __launch_bounds__(256) void k_bvh_leaf(int64_t n, int64_t nleaf, const double *__restrict__ sx,
+                                                  const double *__restrict__ sy, const double *__restrict__ sz,
+                                                  double *__restrict__ box) {
+  int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= nleaf) return;
+  double lo[3] = {2, 2, 2}, hi[3] = {-2, -2, -2};
+  int64_t e = min(n, (b + 1) * MPG_BVH_LEAF);
+  for (int64_t i = b * MPG_BVH_LEAF; i < e; ++i) {
+    lo[0] = fmin(lo[0], sx[i]); hi[0] = fmax(hi[0], sx[i]);
+    lo[1] = fmin(lo[1], sy[i]); hi[1] = fmax(hi[1], sy[i]);
+    lo[2] = fmin(lo[2], sz[i]); hi[2] = fmax(hi[2], sz[i]);
+  }
+  double *o = box + 6 * b;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+}
+__global__ __launch_bounds__(256) void k_bvh_up(int64_t nchild, int64_t nparent, const double *__restrict__ child,
+                                                double *__restrict__ parent) {
+  int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= nparent) return;
+  double lo[3] = {2, 2, 2}, hi[3] = {-2, -2, -2};
+  int64_t e = min(nchild, (b + 1) * MPG_BVH_FAN);
+  for (int64_t i = b * MPG_BVH_FAN; i < e; ++i) {
+    const double *c = child + 6 * i;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fmin(lo[k], c[k]);
+      hi[k] = fmax(hi[k], c[3 + k]);
+    }
+  }
+  double *o = parent + 6 * b;
+  o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+}
+
+int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s) {
+  SiteBvh &b = m->bvh;
+  if (b.built) return MPG_SUCCESS;
+  int rc;
+  int64_t n = m->nCells;
+  b.n = n;
+  DevBuf<unsigned long long> key_in, key_out;
+  DevBuf<int32_t> id_in;
+  if ((rc = key_in.alloc(n)) || (rc = key_out.alloc(n)) || (rc = id_in.alloc(n)) || (rc = b.sorted_id.alloc(n))) return rc;
+  if ((rc = b.sorted.alloc(n))) return rc;
+  unsigned nb = (unsigned)((n + 255) / 256);
+  k_morton<<<nb, 256, 0, s>>>(n, m->cell.x.p, m->cell.y.p, m->cell.z.p, key_in.p, id_in.p);
+  size_t tmp_bytes = 0;
+  MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
+  DevBuf<char> tmp;
+  if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
+  MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
+  k_gather_sites<<<nb, 256, 0, s>>>(n, b.sorted_id.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, b.sorted.x.p, b.sorted.y.p, b.sorted.z.p);
+  // level sizes
+  int nlev = 0;
+  int64_t total = 0, cnt = (n + MPG_BVH_LEAF - 1) / MPG_BVH_LEAF;
+  while (true) {
+    if (nlev >= MPG_BVH_MAXLEV) {
+      mpg_set_error("bvh: too many levels");
+      return MPG_ERR_OVERFLOW;
+    }
+    b.nnodes[nlev] = cnt;
+    b.off[nlev] = total;
+    total += cnt;
+    ++nlev;
+    if (cnt == 1) break;
+    cnt = (cnt + MPG_BVH_FAN - 1) / MPG_BVH_FAN;
+  }
+  b.off[nlev] = total;
+  b.nlev = nlev;
+  if ((rc = b.box.alloc(6 * (size_t)total))) return rc;
+  k_bvh_leaf<<<(unsigned)((b.nnodes[0] + 255) / 256), 256, 0, s>>>(n, b.nnodes[0], b.sorted.x.p, b.sorted.y.p, b.sorted.z.p, b.box.p);
+  for (int l = 1; l < nlev; ++l)
+    k_bvh_up<<<(unsigned)((b.nnodes[l] + 255) / 256), 256, 0, s>>>(b.nnodes[l - 1], b.nnodes[l], b.box.p + 6 * b.off[l - 1],
+                                                                  b.box.p + 6 * b.off[l]);
+  MPG_HIP(hipGetLastError());
+  MPG_HIP(hipStreamSynchronize(s));
+  key_in.free(); key_out.free(); id_in.free(); tmp.free();
+  b.built = true;
+  return MPG_SUCCESS;
+}
+
+#define NN_STACK 96
+__global__ __launch_bounds__(256) void k_nearest_query(int64_t P, const double *__restrict__ px, const double *__restrict__ py,
+                                                       const double *__restrict__ pz, SiteBvhView b, int32_t *__restrict__ out) {
+  int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double X = px[p], Y = py[p], Z = pz[p];
+  double best = INFINITY;
+  int32_t best_id = 0x7fffffff;
+  int stack[NN_STACK];
+  int sp = 0;
+  stack[sp++] = (b.nlev - 1) << 27;  // node < 2^27 per level
+  while (sp > 0) {
+    int e = stack[--sp];
+    int lev = e >> 27;
+    int64_t node = e & ((1 << 27) - 1);
+    double dbox = boxdist2_nofma(X, Y, Z, b.box + 6 * (b.off[lev] + node));
+    if (dbox > best) continue;  // equal bounds are explored: a tie with a lower id may hide inside
+    if (lev == 0) {
+      int64_t e1 = min(b.n, (node + 1) * MPG_BVH_LEAF);
+      for (int64_t i = node * MPG_BVH_LEAF; i < e1; ++i) {
+        double d = dist2_nofma(X, Y, Z, b.sx[i], b.sy[i], b.sz[i]);
+        int32_t id = b.sid[i];
+        if (d < best || (d == best && id < best_id)) {
+          best = d;
+          best_id = id;
+        }
+      }
+    } else {
+      // children sorted by decreasing bound so that the nearest is popped first
+      int64_t c0 = node * MPG_BVH_FAN, c1 = min(b.nnodes[lev - 1], c0 + MPG_BVH_FAN);
+      double cd[MPG_BVH_FAN];
+      int ci[MPG_BVH_FAN];
+      int nc = 0;
+      for (int64_t c = c0; c < c1; ++c) {
+        double d = boxdist2_nofma(X, Y, Z, b.box + 6 * (b.off[lev - 1] + c));
+        if (d > best) continue;
+        int k = nc++;
+        while (k > 0 && cd[k - 1] < d) {
+          cd[k] = cd[k - 1];
+          ci[k] = ci[k - 1];
+          --k;
+        }
+        cd[k] = d;
+        ci[k] = (int)(c - c0);
+      }
+      for (int k = 0; k < nc && sp < NN_STACK; ++k) stack[sp++] = ((lev - 1) << 27) | (int)(c0 + ci[k]);
+    }
+  }
+  out[p] = best_id;
+}
+
+int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s) {
+  int rc;
+  if ((rc = mpg_k_build_bvh(m, s))) return rc;
+  PointSet &pts = g->pts[stagger];
+  int npx = g->snx[stagger], npy = g->sny[stagger];
+  int64_t P = (int64_t)npx * npy;
+  if (pts.n != P) {
+    mpg_set_error("RegridStore: destination stagger %d has no coordinates", stagger);
+    return MPG_ERR_INVALID_ARG;
+  }
+  SiteBvh &b = m->bvh;
+  if (b.nnodes[0] >= (1 << 27)) {
+    mpg_set_error("mesh too large for the nearest-neighbour BVH");
+    return MPG_ERR_OVERFLOW;
+  }
+  h->kind = MPG_KIND_FIXED;
+  h->nnz_per_row = 1;
+  h->n_src = m->nCells;
+  h->n_dst = P;
+  h->nx_dst = npx;
+  h->ny_dst = npy;
+  h->nnz = P;
+  if ((rc = h->idx.alloc((size_t)P))) return rc;
+  SiteBvhView v;
+  v.n = b.n;
+  v.sx = b.sorted.x.p; v.sy = b.sorted.y.p; v.sz = b.sorted.z.p;
+  v.sid = b.sorted_id.p;
+  v.nlev = b.nlev;
+  for (int i = 0; i < MPG_BVH_MAXLEV; ++i) v.nnodes[i] = b.nnodes[i];
+  for (int i = 0; i <= MPG_BVH_MAXLEV; ++i) v.off[i] = b.off[i];
+  v.box = b.box.p;
+  k_nearest_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p);
+  MPG_HIP(hipGetLastError());
+  MPG_HIP(hipStreamSynchronize(s));
+  return MPG_SUCCESS;
+}

@@ -1,0 +1,418 @@
+// C-ABI entry points of libmpassit_amd.so (declared in include/mpassit_amd.h).
+// Thin glue: argument checks, object lifetime, handle cache, host<->device staging.  All arithmetic is
+// in the k_*.hip kernels; there is deliberately no CPU code path.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mpg_internal.h"
+
+static thread_local char g_err[1024] = "";
+static bool g_init = false;
+static int g_device = -1;
+static hipStream_t g_stream = nullptr;
+static std::map<HandleKey, mpg_handle_s *> g_cache;
+
+void mpg_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+bool mpg_is_initialized() { return g_init; }
+hipStream_t mpg_setup_stream() { return g_stream; }
+
+extern "C" {
+
+const char *mpg_last_error(void) { return g_err; }
+
+int mpg_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    mpg_set_error("mpg_init: no HIP device available (%s); this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return MPG_ERR_NOT_INITIALIZED;
+  }
+  MPG_ARG(device >= 0 && device < n, "mpg_init: device index out of range");
+  MPG_HIP(hipSetDevice(device));
+  if (!g_init) MPG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_device = device;
+  g_init = true;
+  return MPG_SUCCESS;
+}
+
+int mpg_finalize(void) {
+  if (!g_init) return MPG_SUCCESS;
+  (void)hipStreamSynchronize(g_stream);
+  (void)hipStreamDestroy(g_stream);
+  g_stream = nullptr;
+  g_init = false;
+  return MPG_SUCCESS;
+}
+
+int mpg_device_info(char *arch_buf, int buf_len, int *n_cu, int64_t *hbm_bytes) {
+  MPG_CHECK_INIT();
+  hipDeviceProp_t p;
+  MPG_HIP(hipGetDeviceProperties(&p, g_device));
+  if (arch_buf && buf_len > 0) {
+    strncpy(arch_buf, p.gcnArchName, (size_t)buf_len - 1);
+    arch_buf[buf_len - 1] = 0;
+  }
+  if (n_cu) *n_cu = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return MPG_SUCCESS;
+}
+
+// ---- mesh -----------------------------------------------------------------------------------------
+int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell, const double *lonCell,
+                    const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, mpg_mesh *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(out, "mpg_mesh_create: out is NULL");
+  MPG_ARG(nCells > 0 && nVertices > 0 && maxEdges >= 3, "mpg_mesh_create: nCells, nVertices must be > 0 and maxEdges >= 3");
+  MPG_ARG(nCells < 0x7fffffff && nVertices < 0x7fffffff, "mpg_mesh_create: sizes must fit int32 ids");
+  MPG_ARG(latCell && lonCell && latVertex && lonVertex && verticesOnCell, "mpg_mesh_create: NULL array");
+  mpg_mesh_s *m = new mpg_mesh_s();
+  m->nCells = nCells;
+  m->nVertices = nVertices;
+  m->maxEdges = maxEdges;
+  int rc;
+  hipStream_t s = g_stream;
+  if ((rc = mpg_k_mesh_coords(nCells, lonCell, latCell, m->cell, s)) || (rc = mpg_k_mesh_coords(nVertices, lonVertex, latVertex, m->vert, s)) ||
+      (rc = m->voc.alloc((size_t)nCells * maxEdges))) {
+    mpg_mesh_destroy(m);
+    return rc;
+  }
+  MPG_HIP(hipMemcpyAsync(m->voc.p, verticesOnCell, sizeof(int32_t) * (size_t)nCells * maxEdges, hipMemcpyHostToDevice, s));
+  if ((rc = mpg_k_dual_triangles(m, s))) {
+    mpg_mesh_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return MPG_SUCCESS;
+}
+
+// handles outlive neither their mesh nor their grid in the cache: a recycled address must never hit
+static void cache_purge(void *obj) {
+  for (auto it = g_cache.begin(); it != g_cache.end();) {
+    if (std::get<0>(it->first) == obj || std::get<2>(it->first) == obj) {
+      it->second->cached = false;
+      it = g_cache.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+int mpg_mesh_destroy(mpg_mesh m) {
+  if (!m) return MPG_SUCCESS;
+  cache_purge(m);
+  m->cell.free();
+  m->vert.free();
+  m->voc.free();
+  m->tri.free();
+  m->bvh.free();
+  delete m;
+  return MPG_SUCCESS;
+}
+
+int mpg_mesh_get_triangles(mpg_mesh m, int32_t *tri_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(m && tri_host, "mpg_mesh_get_triangles: NULL argument");
+  int64_t nV = m->nVertices;
+  std::vector<int32_t> tmp(3 * (size_t)nV);
+  MPG_HIP(hipMemcpy(tmp.data(), m->tri.p, sizeof(int32_t) * 3 * nV, hipMemcpyDeviceToHost));
+  for (int64_t v = 0; v < nV; ++v)
+    for (int k = 0; k < 3; ++k) tri_host[3 * v + k] = tmp[(size_t)k * nV + v];
+  return MPG_SUCCESS;
+}
+
+// ---- grid -----------------------------------------------------------------------------------------
+int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, const double *lat_center, const double *lon_corner,
+                    const double *lat_corner, const double *lon_edge1, const double *lat_edge1, const double *lon_edge2,
+                    const double *lat_edge2, mpg_grid *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(out, "mpg_grid_create: out is NULL");
+  MPG_ARG(nx > 0 && ny > 0, "mpg_grid_create: nx, ny must be > 0");
+  MPG_ARG(lon_center && lat_center, "mpg_grid_create: CENTER coordinates are mandatory");
+  MPG_ARG((int64_t)(nx + 1) * (ny + 1) < 0x7fffffff, "mpg_grid_create: grid too large for int32 ids");
+  mpg_grid_s *g = new mpg_grid_s();
+  g->nx = nx;
+  g->ny = ny;
+  g->periodic = periodic_i;
+  g->snx[MPG_STAGGERLOC_CENTER] = nx;     g->sny[MPG_STAGGERLOC_CENTER] = ny;
+  g->snx[MPG_STAGGERLOC_EDGE1] = nx + 1;  g->sny[MPG_STAGGERLOC_EDGE1] = ny;
+  g->snx[MPG_STAGGERLOC_EDGE2] = nx;      g->sny[MPG_STAGGERLOC_EDGE2] = ny + 1;
+  g->snx[MPG_STAGGERLOC_CORNER] = nx + 1; g->sny[MPG_STAGGERLOC_CORNER] = ny + 1;
+  const double *lon[4] = {lon_center, lon_edge1, lon_edge2, lon_corner};
+  const double *lat[4] = {lat_center, lat_edge1, lat_edge2, lat_corner};
+  for (int st = 0; st < 4; ++st) {
+    if (!lon[st] || !lat[st]) continue;
+    int rc = mpg_k_grid_coords((int64_t)g->snx[st] * g->sny[st], lon[st], lat[st], g->pts[st], g_stream);
+    if (rc) {
+      mpg_grid_destroy(g);
+      return rc;
+    }
+  }
+  *out = g;
+  return MPG_SUCCESS;
+}
+
+int mpg_grid_destroy(mpg_grid g) {
+  if (!g) return MPG_SUCCESS;
+  cache_purge(g);
+  for (int st = 0; st < 4; ++st) {
+    g->pts[st].free();
+    g->pyr[st].free();
+  }
+  g->cellpyr.free();
+  delete g;
+  return MPG_SUCCESS;
+}
+
+// ---- RegridStore ----------------------------------------------------------------------------------
+static void handle_free(mpg_handle_s *h) {
+  h->idx.free();
+  h->w.free();
+  h->rowptr.free();
+  h->col.free();
+  h->val.free();
+  delete h;
+}
+
+static int store_common(HandleKey key, mpg_handle *out, int (*build)(mpg_handle_s *, void *), void *ctx) {
+  auto it = g_cache.find(key);
+  if (it != g_cache.end()) {
+    it->second->refcount++;
+    *out = it->second;
+    return MPG_SUCCESS;
+  }
+  mpg_handle_s *h = new mpg_handle_s();
+  hipEvent_t e0, e1;
+  MPG_HIP(hipEventCreate(&e0));
+  MPG_HIP(hipEventCreate(&e1));
+  MPG_HIP(hipEventRecord(e0, g_stream));
+  int rc = build(h, ctx);
+  if (rc) {
+    handle_free(h);
+    return rc;
+  }
+  MPG_HIP(hipEventRecord(e1, g_stream));
+  MPG_HIP(hipEventSynchronize(e1));
+  MPG_HIP(hipEventElapsedTime(&h->store_ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  h->key = key;
+  h->cached = true;
+  g_cache[key] = h;
+  *out = h;
+  return MPG_SUCCESS;
+}
+
+struct StoreCtx {
+  mpg_mesh_s *m;
+  mpg_grid_s *g;
+  int stagger;
+  int method;
+};
+
+int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(src && dst && out, "mpg_regrid_store: NULL argument");
+  MPG_ARG(dst_staggerloc >= 0 && dst_staggerloc <= 2, "mpg_regrid_store: destination stagger must be CENTER, EDGE1 or EDGE2");
+  if (src_meshloc != MPG_MESHLOC_ELEMENT) {
+    mpg_set_error("mpg_regrid_store: node-located sources (vorticity, interp.F90:350-366) are not supported yet");
+    return MPG_ERR_UNSUPPORTED;
+  }
+  MPG_ARG(regridmethod >= 0 && regridmethod <= 2, "mpg_regrid_store: unknown regrid method");
+  if (regridmethod == MPG_REGRIDMETHOD_CONSERVE && dst_staggerloc != MPG_STAGGERLOC_CENTER) {
+    mpg_set_error("mpg_regrid_store: conservative regridding is defined on the CENTER stagger only");
+    return MPG_ERR_UNSUPPORTED;
+  }
+  StoreCtx ctx{src, dst, dst_staggerloc, regridmethod};
+  HandleKey key(src, src_meshloc, dst, dst_staggerloc, regridmethod);
+  return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
+    StoreCtx *x = (StoreCtx *)c;
+    h->method = x->method;
+    if (x->method == MPG_REGRIDMETHOD_BILINEAR) return mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, h, g_stream);
+    if (x->method == MPG_REGRIDMETHOD_NEAREST_STOD) return mpg_k_store_nearest(x->m, x->g, x->stagger, h, g_stream);
+    return mpg_k_store_conserve(x->m, x->g, h, g_stream);
+  }, &ctx);
+}
+
+int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(grid && out, "mpg_regrid_store_grid: NULL argument");
+  if (src_staggerloc != MPG_STAGGERLOC_CENTER || (dst_staggerloc != MPG_STAGGERLOC_EDGE1 && dst_staggerloc != MPG_STAGGERLOC_EDGE2) ||
+      regridmethod != MPG_REGRIDMETHOD_BILINEAR) {
+    mpg_set_error("mpg_regrid_store_grid: only bilinear CENTER -> EDGE1/EDGE2 is used by the reference (interp.F90:298,316)");
+    return MPG_ERR_UNSUPPORTED;
+  }
+  StoreCtx ctx{nullptr, grid, dst_staggerloc, regridmethod};
+  HandleKey key(grid, 100 + src_staggerloc, grid, dst_staggerloc, regridmethod);
+  return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
+    StoreCtx *x = (StoreCtx *)c;
+    h->method = x->method;
+    return mpg_k_store_grid_bilinear(x->g, x->stagger, h, g_stream);
+  }, &ctx);
+}
+
+int mpg_handle_release(mpg_handle h) {
+  if (!h) return MPG_SUCCESS;
+  if (--h->refcount > 0) return MPG_SUCCESS;
+  if (h->cached) g_cache.erase(h->key);
+  handle_free(h);
+  return MPG_SUCCESS;
+}
+
+// ---- Regrid ---------------------------------------------------------------------------------------
+int mpg_regrid_dev(mpg_handle h, const double *src_dev, int src_layout, int nlev, int nfields, double *dst_dev, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && src_dev && dst_dev, "mpg_regrid: NULL argument");
+  MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid: nlev and nfields must be >= 1");
+  MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid: bad src_layout");
+  return mpg_k_apply(h, src_dev, src_layout, nlev, nfields, dst_dev, (hipStream_t)hip_stream);
+}
+
+int mpg_regrid(mpg_handle h, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && src_host && dst_host, "mpg_regrid: NULL argument");
+  MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid: nlev and nfields must be >= 1");
+  size_t ns = (size_t)h->n_src * nlev * nfields, nd = (size_t)h->n_dst * nlev * nfields;
+  DevBuf<double> s, d;
+  int rc;
+  if ((rc = s.alloc(ns)) || (rc = d.alloc(nd))) {
+    s.free();
+    return rc;
+  }
+  MPG_HIP(hipMemcpyAsync(s.p, src_host, sizeof(double) * ns, hipMemcpyHostToDevice, g_stream));
+  rc = mpg_regrid_dev(h, s.p, src_layout, nlev, nfields, d.p, g_stream);
+  if (!rc) {
+    MPG_HIP(hipMemcpyAsync(dst_host, d.p, sizeof(double) * nd, hipMemcpyDeviceToHost, g_stream));
+    MPG_HIP(hipStreamSynchronize(g_stream));
+  }
+  s.free();
+  d.free();
+  return rc;
+}
+
+int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const double *sina_dev, double *u_dev, double *v_dev,
+                         void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(cosa_dev && sina_dev && u_dev && v_dev, "mpg_rotate_winds: NULL argument");
+  MPG_ARG(npts >= 0 && nlev >= 1, "mpg_rotate_winds: bad sizes");
+  return mpg_k_rotate(npts, nlev, cosa_dev, sina_dev, u_dev, v_dev, (hipStream_t)hip_stream);
+}
+
+int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const double *sina_host, double *u_host, double *v_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(cosa_host && sina_host && u_host && v_host, "mpg_rotate_winds: NULL argument");
+  MPG_ARG(npts >= 0 && nlev >= 1, "mpg_rotate_winds: bad sizes");
+  DevBuf<double> cs, uv;
+  int rc;
+  size_t n = (size_t)npts, nl = n * nlev;
+  if ((rc = cs.alloc(2 * n)) || (rc = uv.alloc(2 * nl))) {
+    cs.free();
+    return rc;
+  }
+  MPG_HIP(hipMemcpyAsync(cs.p, cosa_host, sizeof(double) * n, hipMemcpyHostToDevice, g_stream));
+  MPG_HIP(hipMemcpyAsync(cs.p + n, sina_host, sizeof(double) * n, hipMemcpyHostToDevice, g_stream));
+  MPG_HIP(hipMemcpyAsync(uv.p, u_host, sizeof(double) * nl, hipMemcpyHostToDevice, g_stream));
+  MPG_HIP(hipMemcpyAsync(uv.p + nl, v_host, sizeof(double) * nl, hipMemcpyHostToDevice, g_stream));
+  rc = mpg_k_rotate(npts, nlev, cs.p, cs.p + n, uv.p, uv.p + nl, g_stream);
+  if (!rc) {
+    MPG_HIP(hipMemcpyAsync(u_host, uv.p, sizeof(double) * nl, hipMemcpyDeviceToHost, g_stream));
+    MPG_HIP(hipMemcpyAsync(v_host, uv.p + nl, sizeof(double) * nl, hipMemcpyDeviceToHost, g_stream));
+    MPG_HIP(hipStreamSynchronize(g_stream));
+  }
+  cs.free();
+  uv.free();
+  return rc;
+}
+
+// ---- introspection ----------------------------------------------------------------------------------
+int mpg_handle_info(mpg_handle h, int64_t *n_src, int64_t *n_dst, int *nx_dst, int *ny_dst, int *nnz_per_row, int64_t *nnz) {
+  MPG_ARG(h, "mpg_handle_info: NULL handle");
+  if (n_src) *n_src = h->n_src;
+  if (n_dst) *n_dst = h->n_dst;
+  if (nx_dst) *nx_dst = h->nx_dst;
+  if (ny_dst) *ny_dst = h->ny_dst;
+  if (nnz_per_row) *nnz_per_row = h->nnz_per_row;
+  if (nnz) *nnz = h->nnz;
+  return MPG_SUCCESS;
+}
+
+int mpg_handle_store_ms(mpg_handle h, float *ms_total) {
+  MPG_ARG(h, "mpg_handle_store_ms: NULL handle");
+  if (ms_total) *ms_total = h->store_ms;
+  return MPG_SUCCESS;
+}
+
+int mpg_handle_get_weights(mpg_handle h, int32_t *idx_host, double *w_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && idx_host, "mpg_handle_get_weights: NULL argument");
+  MPG_ARG(h->kind == MPG_KIND_FIXED, "mpg_handle_get_weights: handle is CSR, use mpg_handle_get_csr");
+  int nz = h->nnz_per_row;
+  int64_t P = h->n_dst;
+  std::vector<int32_t> ti((size_t)nz * P);
+  MPG_HIP(hipMemcpy(ti.data(), h->idx.p, sizeof(int32_t) * nz * P, hipMemcpyDeviceToHost));
+  for (int64_t p = 0; p < P; ++p)
+    for (int q = 0; q < nz; ++q) idx_host[p * nz + q] = ti[(size_t)q * P + p];
+  if (w_host) {
+    if (h->w.p) {
+      std::vector<double> tw((size_t)nz * P);
+      MPG_HIP(hipMemcpy(tw.data(), h->w.p, sizeof(double) * nz * P, hipMemcpyDeviceToHost));
+      for (int64_t p = 0; p < P; ++p)
+        for (int q = 0; q < nz; ++q) w_host[p * nz + q] = tw[(size_t)q * P + p];
+    } else {
+      for (int64_t p = 0; p < P * nz; ++p) w_host[p] = idx_host[p] >= 0 ? 1.0 : 0.0;
+    }
+  }
+  return MPG_SUCCESS;
+}
+
+int mpg_handle_get_csr(mpg_handle h, int64_t *rowptr_host, int32_t *col_host, double *val_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && rowptr_host, "mpg_handle_get_csr: NULL argument");
+  MPG_ARG(h->kind == MPG_KIND_CSR, "mpg_handle_get_csr: handle is not CSR");
+  std::vector<int32_t> rp((size_t)h->n_dst + 1);
+  MPG_HIP(hipMemcpy(rp.data(), h->rowptr.p, sizeof(int32_t) * (h->n_dst + 1), hipMemcpyDeviceToHost));
+  for (int64_t p = 0; p <= h->n_dst; ++p) rowptr_host[p] = rp[p];
+  if (col_host) MPG_HIP(hipMemcpy(col_host, h->col.p, sizeof(int32_t) * h->nnz, hipMemcpyDeviceToHost));
+  if (val_host) MPG_HIP(hipMemcpy(val_host, h->val.p, sizeof(double) * h->nnz, hipMemcpyDeviceToHost));
+  return MPG_SUCCESS;
+}
+
+// ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------
+int mpg_handle_unique_sources(mpg_handle h, int64_t *n_unique, int32_t *ids_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && n_unique, "mpg_handle_unique_sources: NULL argument");
+  MPG_ARG(!h->localized, "mpg_handle_unique_sources: handle already localized");
+  std::vector<int32_t> ids;
+  int rc = mpg_k_unique_sources(h, ids, false, g_stream);
+  if (rc) return rc;
+  *n_unique = (int64_t)ids.size();
+  if (ids_host && !ids.empty()) memcpy(ids_host, ids.data(), sizeof(int32_t) * ids.size());
+  return MPG_SUCCESS;
+}
+
+int mpg_handle_localize(mpg_handle h) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h, "mpg_handle_localize: NULL handle");
+  MPG_ARG(!h->localized, "mpg_handle_localize: handle already localized");
+  // a localized handle no longer matches its cache key: detach it
+  if (h->cached) {
+    g_cache.erase(h->key);
+    h->cached = false;
+  }
+  std::vector<int32_t> ids;
+  return mpg_k_unique_sources(h, ids, true, g_stream);
+}
+
+int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *ids_dev, int64_t n_ids, double *dst_dev, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(src_dev && ids_dev && dst_dev, "mpg_pack_dev: NULL argument");
+  return mpg_k_pack(src_dev, n_src, nlev, ids_dev, n_ids, dst_dev, (hipStream_t)hip_stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// Internal declarations shared by the HIP translation units of libmpassit_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/mpassit_amd.h"
+
+#define MPG_WAVE 64
+
+void mpg_set_error(const char *fmt, ...);
+bool mpg_is_initialized();
+hipStream_t mpg_setup_stream();
+
+#define MPG_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      mpg_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MPG_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define MPG_CHECK_INIT()                                                               \
+  do {                                                                                 \
+    if (!mpg_is_initialized()) {                                                       \
+      mpg_set_error("mpg_init has not been called (or no HIP device): no CPU fallback"); \
+      return MPG_ERR_NOT_INITIALIZED;                                                  \
+    }                                                                                  \
+  } while (0)
+
+#define MPG_ARG(cond, msg)         \
+  do {                             \
+    if (!(cond)) {                 \
+      mpg_set_error("%s", msg);    \
+      return MPG_ERR_INVALID_ARG;  \
+    }                              \
+  } while (0)
+
+// RAII-less device buffer helper (explicit free keeps object lifetimes obvious)
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count;
+    if (count == 0) return MPG_SUCCESS;
+    MPG_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    return MPG_SUCCESS;
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// Point set on the unit sphere, SoA
+struct PointSet {
+  int64_t n = 0;
+  DevBuf<double> x, y, z;
+  int alloc(int64_t count) {
+    n = count;
+    int rc;
+    if ((rc = x.alloc(count))) return rc;
+    if ((rc = y.alloc(count))) return rc;
+    return z.alloc(count);
+  }
+  void free() { x.free(); y.free(); z.free(); n = 0; }
+};
+
+// AABB pyramid over a structured (nx x ny) point set: level 0 = blocks of B0 x B0 points, each upper
+// level merges 2x2 nodes.  box[level] is [nodes][6] = lo.xyz, hi.xyz.
+#define MPG_PYR_B0 4
+#define MPG_PYR_MAXLEV 16
+struct Pyramid {
+  int nlev = 0;
+  int nx[MPG_PYR_MAXLEV], ny[MPG_PYR_MAXLEV];
+  int64_t off[MPG_PYR_MAXLEV + 1];  // node offset of each level inside `box` (in nodes)
+  DevBuf<double> box;
+  bool built = false;
+  void free() { box.free(); built = false; nlev = 0; }
+};
+struct PyramidView {  // passed by value to kernels
+  int nlev;
+  int nx[MPG_PYR_MAXLEV], ny[MPG_PYR_MAXLEV];
+  int64_t off[MPG_PYR_MAXLEV + 1];
+  const double *box;
+};
+
+// Morton-sorted site BVH (leaf = 8 consecutive sorted sites, fan-out 8)
+#define MPG_BVH_LEAF 8
+#define MPG_BVH_FAN 8
+#define MPG_BVH_MAXLEV 12
+struct SiteBvh {
+  int64_t n = 0;
+  PointSet sorted;          // sites in Morton order
+  DevBuf<int32_t> sorted_id;  // original cell id of each sorted site
+  int nlev = 0;
+  int64_t nnodes[MPG_BVH_MAXLEV];
+  int64_t off[MPG_BVH_MAXLEV + 1];
+  DevBuf<double> box;  // [nodes][6]
+  bool built = false;
+  void free() { sorted.free(); sorted_id.free(); box.free(); built = false; }
+};
+struct SiteBvhView {
+  int64_t n;
+  const double *sx, *sy, *sz;
+  const int32_t *sid;
+  int nlev;
+  int64_t nnodes[MPG_BVH_MAXLEV];
+  int64_t off[MPG_BVH_MAXLEV + 1];
+  const double *box;
+};
+
+struct mpg_handle_s;
+typedef std::tuple<void *, int, void *, int, int> HandleKey;
+
+struct mpg_mesh_s {
+  int64_t nCells = 0, nVertices = 0;
+  int maxEdges = 0;
+  PointSet cell, vert;          // unit vectors of cell centres / vertices
+  DevBuf<int32_t> voc;          // [nCells][maxEdges] 1-based, 0-padded (as given)
+  DevBuf<int32_t> tri;          // [3][nVertices] dual triangles (cells), -1 = none; CCW
+  int64_t nTriValid = 0;
+  SiteBvh bvh;
+};
+
+struct mpg_grid_s {
+  int nx = 0, ny = 0, periodic = 0;
+  PointSet pts[4];  // indexed by MPG_STAGGERLOC_*
+  int snx[4], sny[4];
+  Pyramid pyr[4];   // point pyramids (per stagger), built lazily
+  Pyramid cellpyr;  // pyramid over CENTER cells bounded by CORNER points (conservative)
+};
+
+enum { MPG_KIND_FIXED = 0, MPG_KIND_CSR = 1 };
+struct mpg_handle_s {
+  int kind = MPG_KIND_FIXED;
+  int method = 0;
+  int nnz_per_row = 0;  // 3, 4, 1 or 0 (CSR)
+  int64_t n_src = 0, n_dst = 0;
+  int nx_dst = 0, ny_dst = 0;
+  DevBuf<int32_t> idx;  // [nnz_per_row][n_dst] SoA, -1 = unmapped
+  DevBuf<double> w;     // [nnz_per_row][n_dst] SoA (absent for nearest)
+  DevBuf<int32_t> rowptr;  // CSR [n_dst+1]
+  DevBuf<int32_t> col;
+  DevBuf<double> val;
+  int64_t nnz = 0;
+  int refcount = 1;
+  bool cached = false;
+  HandleKey key;
+  float store_ms = 0.f;
+  bool localized = false;
+};
+
+// ---- launchers implemented in the kernel TUs ---------------------------------------------------
+int mpg_k_mesh_coords(int64_t n, const double *lon_rad, const double *lat_rad, PointSet &out, hipStream_t s);
+int mpg_k_grid_coords(int64_t n, const double *lon_deg, const double *lat_deg, PointSet &out, hipStream_t s);
+int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s);
+int mpg_k_build_pyramid(const PointSet &pts, int nx, int ny, Pyramid &pyr, hipStream_t s);
+int mpg_k_build_cell_pyramid(const PointSet &corner, int nx, int ny, Pyramid &pyr, hipStream_t s);
+PyramidView mpg_pyr_view(const Pyramid &p);
+int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s);
+int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s);
+int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStream_t s);
+int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, hipStream_t s);
+int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s);
+int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s);
+int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
+int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
+int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap, hipStream_t s);

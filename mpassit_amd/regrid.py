@@ -1,0 +1,214 @@
+"""Host-side mirror of the ESMF verbs MPASSIT's hot path uses, bound to the HIP C-ABI.
+
+Names follow the reference's call sites so that tests read like the reference:
+  Mesh            <- ESMF_MeshCreate                 (model_grid.F90:488-497)
+  Grid            <- ESMF_GridCreate* + GridAddCoord (model_grid.F90:684-728,736-1038)
+  regrid_store    <- ESMF_Field[Bundle]RegridStore   (interp.F90:123,207,...,437)
+  RouteHandle.regrid      <- ESMF_Field[Bundle]Regrid (interp.F90:134,219,...,443)
+  RouteHandle.release     <- ESMF_FieldBundleRegridRelease (interp.F90:450-463)
+Host numpy arrays go through mpg_regrid (H2D + kernel + D2H); torch CUDA tensors go through
+mpg_regrid_dev on torch's current stream (device-resident fast path used by bench.py).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import (LAYOUT_CELL_FAST, LAYOUT_LEV_FAST, MESHLOC_ELEMENT, REGRIDMETHOD_BILINEAR, REGRIDMETHOD_CONSERVE,
+                   REGRIDMETHOD_NEAREST_STOD, STAGGERLOC_CENTER, STAGGERLOC_CORNER, STAGGERLOC_EDGE1, STAGGERLOC_EDGE2,
+                   check)
+
+__all__ = ["Mesh", "Grid", "RouteHandle", "regrid_store", "regrid_store_grid", "rotate_winds_cgrid",
+           "REGRIDMETHOD_BILINEAR", "REGRIDMETHOD_CONSERVE", "REGRIDMETHOD_NEAREST_STOD", "STAGGERLOC_CENTER",
+           "STAGGERLOC_EDGE1", "STAGGERLOC_EDGE2", "STAGGERLOC_CORNER", "LAYOUT_CELL_FAST", "LAYOUT_LEV_FAST"]
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Mesh:
+    """MPAS mesh as the reference hands it to ESMF: elements = cells, nodes = vertices.
+    lat/lon in radians (file convention), verticesOnCell [nCells][maxEdges] 1-based, 0-padded."""
+
+    def __init__(self, latCell, lonCell, latVertex, lonVertex, verticesOnCell):
+        latCell, lonCell, latVertex, lonVertex = map(_f64, (latCell, lonCell, latVertex, lonVertex))
+        voc = np.ascontiguousarray(verticesOnCell, dtype=np.int32)
+        if voc.ndim != 2 or voc.shape[0] != latCell.size:
+            raise ValueError("verticesOnCell must be [nCells][maxEdges]")
+        self.nCells, self.nVertices, self.maxEdges = int(latCell.size), int(latVertex.size), int(voc.shape[1])
+        self._h = C.c_void_p()
+        check(L.load().mpg_mesh_create(C.c_int64(self.nCells), C.c_int64(self.nVertices), C.c_int(self.maxEdges),
+                                       _ptr(latCell), _ptr(lonCell), _ptr(latVertex), _ptr(lonVertex), _ptr(voc),
+                                       C.byref(self._h)))
+
+    @classmethod
+    def from_mpas(cls, m):
+        return cls(m.latCell, m.lonCell, m.latVertex, m.lonVertex, m.verticesOnCell)
+
+    def triangles(self):
+        tri = np.empty((self.nVertices, 3), np.int32)
+        check(L.load().mpg_mesh_get_triangles(self._h, _ptr(tri)))
+        return tri
+
+    def destroy(self):
+        if self._h:
+            check(L.load().mpg_mesh_destroy(self._h))
+            self._h = C.c_void_p()
+
+
+class Grid:
+    """Structured target grid with its four staggers (degrees, arrays [nj][ni], i fastest)."""
+
+    def __init__(self, lon, lat, lon_corner=None, lat_corner=None, lon_u=None, lat_u=None, lon_v=None, lat_v=None,
+                 periodic=False):
+        lon, lat = _f64(lon), _f64(lat)
+        self.ny, self.nx = lat.shape
+        arrs = [None if a is None else _f64(a) for a in (lon_corner, lat_corner, lon_u, lat_u, lon_v, lat_v)]
+        shapes = [(self.ny + 1, self.nx + 1)] * 2 + [(self.ny, self.nx + 1)] * 2 + [(self.ny + 1, self.nx)] * 2
+        for a, s in zip(arrs, shapes):
+            if a is not None and a.shape != s:
+                raise ValueError("stagger coordinate array has shape %s, expected %s" % (a.shape, s))
+        self._h = C.c_void_p()
+        check(L.load().mpg_grid_create(C.c_int(self.nx), C.c_int(self.ny), C.c_int(int(periodic)), _ptr(lon), _ptr(lat),
+                                       *[_ptr(a) for a in arrs], C.byref(self._h)))
+
+    @classmethod
+    def from_target(cls, g, rows=None):
+        """From target_grid.TargetGrid; rows=(j0, j1) keeps only mass rows [j0, j1) (multi-GPU row shard,
+        mirrors the reference's regDecomp=(/1,npets/) split along j, model_grid.F90:693)."""
+        if rows is None:
+            return cls(g.lon, g.lat, g.lon_c, g.lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v, periodic=not g.is_regional)
+        j0, j1 = rows
+        return cls(g.lon[j0:j1], g.lat[j0:j1], g.lon_c[j0:j1 + 1], g.lat_c[j0:j1 + 1], g.lon_u[j0:j1], g.lat_u[j0:j1],
+                   g.lon_v[j0:j1 + 1], g.lat_v[j0:j1 + 1], periodic=not g.is_regional)
+
+    def stagger_shape(self, staggerloc):
+        return {STAGGERLOC_CENTER: (self.ny, self.nx), STAGGERLOC_EDGE1: (self.ny, self.nx + 1),
+                STAGGERLOC_EDGE2: (self.ny + 1, self.nx), STAGGERLOC_CORNER: (self.ny + 1, self.nx + 1)}[staggerloc]
+
+    def destroy(self):
+        if self._h:
+            check(L.load().mpg_grid_destroy(self._h))
+            self._h = C.c_void_p()
+
+
+class RouteHandle:
+    def __init__(self, h):
+        self._h = h
+        n_src, n_dst, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+        nx, ny, npr = C.c_int(), C.c_int(), C.c_int()
+        check(L.load().mpg_handle_info(h, C.byref(n_src), C.byref(n_dst), C.byref(nx), C.byref(ny), C.byref(npr), C.byref(nnz)))
+        self.n_src, self.n_dst, self.nx_dst, self.ny_dst = n_src.value, n_dst.value, nx.value, ny.value
+        self.nnz_per_row, self.nnz = npr.value, nnz.value
+
+    @property
+    def store_ms(self):
+        ms = C.c_float()
+        check(L.load().mpg_handle_store_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def _refresh(self):
+        self.__init__(self._h)
+
+    # -- ESMF_FieldRegrid / ESMF_FieldBundleRegrid ---------------------------------------------------
+    def regrid(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out=None):
+        """src: nfields slabs of nlev*n_src float64 (numpy on host or torch on the GPU).
+        Returns dst [nfields][nlev][ny_dst][nx_dst] (squeezing nfields == 1 and nlev == 1 is left to the caller)."""
+        shape = (nfields, nlev, self.ny_dst, self.nx_dst)
+        need = nfields * nlev * self.n_src
+        if _is_torch(src):
+            import torch
+            if not src.is_cuda or src.dtype != torch.float64 or not src.is_contiguous():
+                raise ValueError("device regrid needs a contiguous float64 CUDA tensor")
+            if src.numel() != need:
+                raise ValueError("source has %d elements, handle expects %d" % (src.numel(), need))
+            if out is None:
+                out = torch.empty(shape, dtype=torch.float64, device=src.device)
+            check(L.load().mpg_regrid_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(layout), C.c_int(nlev), C.c_int(nfields),
+                                          C.c_void_p(out.data_ptr()), _stream_ptr()))
+            return out
+        src = _f64(src)
+        if src.size != need:
+            raise ValueError("source has %d elements, handle expects %d" % (src.size, need))
+        if out is None:
+            out = np.empty(shape)
+        check(L.load().mpg_regrid(self._h, _ptr(src), C.c_int(layout), C.c_int(nlev), C.c_int(nfields), _ptr(out)))
+        return out
+
+    def weights(self):
+        """(idx [n_dst][nnz_per_row] int32 with -1 = unmapped, w [n_dst][nnz_per_row])."""
+        idx = np.empty((self.n_dst, self.nnz_per_row), np.int32)
+        w = np.empty((self.n_dst, self.nnz_per_row))
+        check(L.load().mpg_handle_get_weights(self._h, _ptr(idx), _ptr(w)))
+        return idx, w
+
+    def csr(self):
+        rowptr = np.empty(self.n_dst + 1, np.int64)
+        col, val = np.empty(self.nnz, np.int32), np.empty(self.nnz)
+        check(L.load().mpg_handle_get_csr(self._h, _ptr(rowptr), _ptr(col), _ptr(val)))
+        return rowptr, col, val
+
+    def unique_sources(self):
+        n = C.c_int64()
+        check(L.load().mpg_handle_unique_sources(self._h, C.byref(n), None))
+        ids = np.empty(n.value, np.int32)
+        if n.value:
+            check(L.load().mpg_handle_unique_sources(self._h, C.byref(n), _ptr(ids)))
+        return ids
+
+    def localize(self):
+        ids = self.unique_sources()
+        check(L.load().mpg_handle_localize(self._h))
+        self._refresh()
+        return ids
+
+    def release(self):
+        if self._h:
+            check(L.load().mpg_handle_release(self._h))
+            self._h = None
+
+
+def regrid_store(src_mesh, dst_grid, regridmethod=REGRIDMETHOD_BILINEAR, staggerloc=STAGGERLOC_CENTER,
+                 meshloc=MESHLOC_ELEMENT):
+    """ESMF_FieldRegridStore(mesh field -> grid field); srcTermProcessing=1, unmappedaction=IGNORE."""
+    h = C.c_void_p()
+    check(L.load().mpg_regrid_store(src_mesh._h, C.c_int(meshloc), dst_grid._h, C.c_int(staggerloc), C.c_int(regridmethod), C.byref(h)))
+    return RouteHandle(h)
+
+
+def regrid_store_grid(grid, dst_staggerloc, src_staggerloc=STAGGERLOC_CENTER, regridmethod=REGRIDMETHOD_BILINEAR):
+    """ESMF_FieldRegridStore(u_target_grid_nostag -> u_target_grid) (interp.F90:298,316)."""
+    h = C.c_void_p()
+    check(L.load().mpg_regrid_store_grid(grid._h, C.c_int(src_staggerloc), C.c_int(dst_staggerloc), C.c_int(regridmethod), C.byref(h)))
+    return RouteHandle(h)
+
+
+def rotate_winds_cgrid(cosa, sina, u, v):
+    """rotate_winds_cgrid (interp.F90:689-749), in place.  u, v: [nlev][ny][nx] (or [ny][nx]); numpy or torch."""
+    if _is_torch(u):
+        npts = cosa.numel()
+        nlev = u.numel() // npts
+        check(L.load().mpg_rotate_winds_dev(C.c_int64(npts), C.c_int(nlev), C.c_void_p(cosa.data_ptr()), C.c_void_p(sina.data_ptr()),
+                                            C.c_void_p(u.data_ptr()), C.c_void_p(v.data_ptr()), _stream_ptr()))
+        return u, v
+    cosa, sina = _f64(cosa), _f64(sina)
+    if not (u.flags.c_contiguous and v.flags.c_contiguous and u.dtype == np.float64 and v.dtype == np.float64):
+        raise ValueError("u, v must be contiguous float64 (rotated in place)")
+    npts = cosa.size
+    nlev = u.size // npts
+    check(L.load().mpg_rotate_winds(C.c_int64(npts), C.c_int(nlev), _ptr(cosa), _ptr(sina), _ptr(u), _ptr(v)))
+    return u, v

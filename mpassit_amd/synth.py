@@ -1,0 +1,180 @@
+"""Deterministic synthetic MPAS-like meshes and fields (seed 20240807).
+
+No MPAS files or NetCDF exist in the build environment, so tests and bench.py use:
+  * global quasi-uniform Voronoi meshes from `scipy.spatial.SphericalVoronoi` (real unstructured
+    connectivity: pentagons/hexagons/heptagons) for the small parity cases, and
+  * regional perturbed-hexagonal meshes laid out in a Lambert plane (O(N) to generate, exact
+    Voronoi vertices = spherical circumcentres) for the 655 362-cell / 3 M-cell bench workloads.
+Arrays follow the MPAS file conventions the reference reads (model_grid.F90:354-417): lat/lon in
+radians, lon in [0, 2pi), `verticesOnCell` [nCells][maxEdges] int32, 1-based, 0-padded.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+SEED = 20240807
+
+
+@dataclass
+class MpasMesh:
+    latCell: np.ndarray
+    lonCell: np.ndarray
+    latVertex: np.ndarray
+    lonVertex: np.ndarray
+    verticesOnCell: np.ndarray  # [nCells][maxEdges] int32, 1-based, 0 = pad
+
+    @property
+    def nCells(self):
+        return self.latCell.size
+
+    @property
+    def nVertices(self):
+        return self.latVertex.size
+
+    @property
+    def maxEdges(self):
+        return self.verticesOnCell.shape[1]
+
+
+def _xyz_to_latlon_rad(xyz):
+    lat = np.arcsin(np.clip(xyz[:, 2], -1.0, 1.0))
+    lon = np.arctan2(xyz[:, 1], xyz[:, 0])
+    lon = np.where(lon < 0.0, lon + 2.0 * np.pi, lon)
+    return lat, lon
+
+
+def latlon_rad_to_xyz(lat, lon):
+    cl = np.cos(lat)
+    return np.stack([cl * np.cos(lon), cl * np.sin(lon), np.sin(lat)], axis=-1)
+
+
+def global_voronoi_mesh(n_cells, seed=SEED, jitter=0.25, max_edges=None):
+    """Quasi-uniform global mesh: jittered spherical-Fibonacci generators + SphericalVoronoi."""
+    from scipy.spatial import SphericalVoronoi
+    rng = np.random.default_rng(seed)
+    k = np.arange(n_cells) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / n_cells)
+    theta = np.pi * (1.0 + 5.0 ** 0.5) * k
+    pts = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1)
+    h = np.sqrt(4.0 * np.pi / n_cells)
+    pts = pts + jitter * h * rng.uniform(-0.5, 0.5, pts.shape)
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    sv = SphericalVoronoi(pts, radius=1.0, center=np.zeros(3))
+    sv.sort_vertices_of_regions()
+    me = max(len(r) for r in sv.regions)
+    if max_edges is None:
+        max_edges = me
+    assert max_edges >= me
+    voc = np.zeros((n_cells, max_edges), np.int32)
+    for c, r in enumerate(sv.regions):
+        r = np.asarray(r, np.int32)
+        # CCW seen from outside (MPAS convention)
+        a, b, cc = sv.vertices[r[0]], sv.vertices[r[1]], sv.vertices[r[2]]
+        if np.dot(pts[c], np.cross(b - a, cc - a)) < 0:
+            r = r[::-1]
+        voc[c, :len(r)] = r + 1
+    latc, lonc = _xyz_to_latlon_rad(pts)
+    latv, lonv = _xyz_to_latlon_rad(sv.vertices)
+    return MpasMesh(latc, lonc, latv, lonv, voc)
+
+
+def regional_hex_mesh(proj, x0, y0, q_cells, r_cells, spacing, seed=SEED, jitter=0.12):
+    """Perturbed hexagonal mesh in the index plane of Lambert projection `proj`.
+
+    Cell (r, q) sits near x = x0 + (q + 0.5*(r%2))*spacing, y = y0 + r*spacing*sqrt(3)/2 (grid-index
+    units of `proj`); cell id = r*q_cells + q.  A ghost ring supplies the rim vertices so that every
+    kept cell has a complete 6-vertex polygon; vertices touched by < 3 kept cells exist but give no
+    dual triangle (regional rim).  Vertices are spherical circumcentres of the
+    lattice triangles, so polygons are the true Voronoi cells while the lattice stays Delaunay.
+    """
+    rng = np.random.default_rng(seed)
+    Q, R = q_cells + 2, r_cells + 2  # ghost lattice
+    rr, qq = np.meshgrid(np.arange(R), np.arange(Q), indexing="ij")
+    x = x0 + (qq - 1 + 0.5 * ((rr - 1) % 2)) * spacing
+    y = y0 + (rr - 1) * spacing * (3.0 ** 0.5 / 2.0)
+    x = x + jitter * spacing * rng.uniform(-1.0, 1.0, x.shape)
+    y = y + jitter * spacing * rng.uniform(-1.0, 1.0, y.shape)
+    lat_deg, lon_deg = proj.ij_to_latlon(x, y)
+    lat = np.deg2rad(lat_deg).ravel()
+    lon = np.deg2rad(lon_deg).ravel()
+    P = latlon_rad_to_xyz(lat, lon)  # ghost lattice points [R*Q][3]
+    gid = (rr * Q + qq)
+
+    # triangles between lattice rows g and g+1 (ghost indices); parity refers to the KEPT row index
+    # r = g-1, whose odd rows are shifted by +0.5 -> ghost row g is shifted iff (g-1)%2==1.
+    g = np.arange(R - 1)[:, None]
+    q = np.arange(Q - 1)[None, :]
+    shifted = ((g - 1) % 2 == 1)  # row g shifted
+    p00, p01 = gid[:-1, :-1], gid[:-1, 1:]  # (g,q), (g,q+1)
+    p10, p11 = gid[1:, :-1], gid[1:, 1:]    # (g+1,q), (g+1,q+1)
+    # row g not shifted:  up = (g,q),(g,q+1),(g+1,q);    down = (g,q+1),(g+1,q+1),(g+1,q)
+    # row g shifted:      up = (g,q),(g,q+1),(g+1,q+1);  down = (g,q),(g+1,q+1),(g+1,q)
+    up = np.stack([p00, p01, np.where(shifted, p11, p10)], axis=-1)
+    dn = np.stack([np.where(shifted, p00, p01), p11, p10], axis=-1)
+    tris = np.stack([up, dn], axis=2).reshape(-1, 3)  # tid = ((g*(Q-1))+q)*2 + type
+    A, B, C = P[tris[:, 0]], P[tris[:, 1]], P[tris[:, 2]]
+    n = np.cross(B - A, C - A)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n *= np.sign(np.einsum("ij,ij->i", n, A))[:, None]
+
+    def tid(gg, q_, typ):
+        return ((gg * (Q - 1)) + q_) * 2 + typ
+
+    # six triangles around kept cell (ghost coords g=r+1, q=qk+1), CCW from the E-NE one
+    gk, qk = np.meshgrid(np.arange(1, R - 1), np.arange(1, Q - 1), indexing="ij")
+    sh = ((gk - 1) % 2 == 1)
+    ring = np.stack([
+        tid(gk, qk, 0),
+        np.where(sh, tid(gk, qk, 1), tid(gk, qk - 1, 1)),
+        tid(gk, qk - 1, 0),
+        tid(gk - 1, qk - 1, 1),
+        np.where(sh, tid(gk - 1, qk, 0), tid(gk - 1, qk - 1, 0)),
+        tid(gk - 1, qk, 1),
+    ], axis=-1).reshape(-1, 6)
+    used = np.zeros(tris.shape[0], bool)
+    used[ring.ravel()] = True
+    newid = np.cumsum(used, dtype=np.int64)  # 1-based ids for used triangles
+    voc = newid[ring].astype(np.int32)
+    latv, lonv = _xyz_to_latlon_rad(n[used])
+    keep = gid[1:-1, 1:-1].ravel()
+    lonc = np.where(lon[keep] < 0.0, lon[keep] + 2.0 * np.pi, lon[keep])
+    return MpasMesh(lat[keep].copy(), lonc, latv, lonv, voc)
+
+
+def regional_mesh_for_lambert(proj, nx, ny, n_cells, margin=0.05, seed=SEED):
+    """~n_cells-cell hex mesh covering the (nx x ny)-point Lambert domain of `proj` plus `margin`."""
+    w, h = (nx - 1) * (1 + 2 * margin), (ny - 1) * (1 + 2 * margin)
+    # cell area = spacing^2*sqrt(3)/2
+    spacing = (w * h / (n_cells * (3.0 ** 0.5 / 2.0))) ** 0.5
+    q_cells = int(np.ceil(w / spacing)) + 1
+    r_cells = int(np.ceil(n_cells / q_cells))
+    x0 = 1.0 - margin * (nx - 1) - 0.25 * spacing
+    y0 = 1.0 - margin * (ny - 1) - ((r_cells - 1) * spacing * (3.0 ** 0.5 / 2.0) - h) / 2.0
+    return regional_hex_mesh(proj, x0, y0, q_cells, r_cells, spacing, seed=seed)
+
+
+def analytic_field(lat_rad, lon_rad, nlev, seed=SEED, cell_fast=True, dtype=np.float64):
+    """f(lat,lon,k) = a_k + b_k x + c_k y + d_k z + 0.1 sin(5 lon) cos(3 lat)  (SURVEY s8(d)).
+    Returns [nlev][n] (cell-fastest, as the reference holds fields, input_data.F90:653-655) or
+    [n][nlev] (level-fastest, MPAS file order)."""
+    rng = np.random.default_rng(seed)
+    co = rng.uniform(-1.0, 1.0, (nlev, 4))
+    xyz = latlon_rad_to_xyz(lat_rad, lon_rad)
+    wig = 0.1 * np.sin(5.0 * lon_rad) * np.cos(3.0 * lat_rad)
+    f = co[:, :1] + co[:, 1:] @ xyz.T + wig[None, :]
+    f = f.astype(dtype)
+    return np.ascontiguousarray(f if cell_fast else f.T)
+
+
+def category_field(n, nlev=1, seed=SEED, ncat=20):
+    """Integer-valued float64 field floor(1 + 19u) (land-use-like), [nlev][n]."""
+    rng = np.random.default_rng(seed + 1)
+    return np.floor(1.0 + (ncat - 1) * rng.uniform(0.0, 1.0, (nlev, n)))
+
+
+def snow_field(lat_rad, lon_rad, lat0=np.deg2rad(45.0), lon0=np.deg2rad(-100.0 % 360.0)):
+    """Non-negative smooth bump (snow-like), [1][n]."""
+    x = latlon_rad_to_xyz(lat_rad, lon_rad)
+    c = latlon_rad_to_xyz(np.array(lat0), np.array(lon0))
+    d2 = np.sum((x - c) ** 2, axis=-1)
+    return np.exp(-d2 / 0.02)[None, :]

@@ -1,0 +1,211 @@
+"""ctypes front-end of the CPU oracle (oracle/mpassit_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package (mpassit_amd/).  Parity status: see the header of
+mpassit_oracle.c ("parity unpinned" at the ESMF boundary; projection pinned by SURVEY App. E).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmpassit_oracle.so")
+_lib = None
+
+f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+M, U, V, CORNER = 1, 2, 3, 4  # stagger codes of orc_xytoll
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mpassit_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.orc_dual_triangles.restype = C.c_int64
+        L.orc_conserve.restype = C.c_int64
+        L.orc_sizeof_proj.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def mesh_coords_deg(lon_rad, lat_rad):
+    lon_rad, lat_rad = _c(lon_rad, np.float64), _c(lat_rad, np.float64)
+    lo, la = np.empty_like(lon_rad), np.empty_like(lat_rad)
+    lib().orc_mesh_coords_deg(C.c_int64(lon_rad.size), lon_rad.ctypes, lat_rad.ctypes, lo.ctypes, la.ctypes)
+    return lo, la
+
+
+def lonlat_deg_to_xyz(lon_deg, lat_deg):
+    lon_deg, lat_deg = _c(lon_deg, np.float64).ravel(), _c(lat_deg, np.float64).ravel()
+    xyz = np.empty((lon_deg.size, 3))
+    lib().orc_lonlat_deg_to_xyz(C.c_int64(lon_deg.size), lon_deg.ctypes, lat_deg.ctypes, xyz.ctypes)
+    return xyz
+
+
+def dual_triangles(voc, n_vertices, cell_xyz):
+    voc = _c(voc, np.int32)
+    n_cells, max_edges = voc.shape
+    tri = np.empty((n_vertices, 3), np.int32)
+    cell_xyz = _c(cell_xyz, np.float64)
+    n = lib().orc_dual_triangles(C.c_int64(n_cells), C.c_int64(n_vertices), C.c_int(max_edges), voc.ctypes,
+                                 cell_xyz.ctypes, tri.ctypes)
+    return tri, int(n)
+
+
+def bilinear_weights(cell_xyz, tri, pt_xyz):
+    cell_xyz, tri, pt_xyz = _c(cell_xyz, np.float64), _c(tri, np.int32), _c(pt_xyz, np.float64)
+    P = pt_xyz.shape[0]
+    idx, w = np.empty((P, 3), np.int32), np.empty((P, 3))
+    lib().orc_bilinear_weights(C.c_int64(cell_xyz.shape[0]), cell_xyz.ctypes, C.c_int64(tri.shape[0]), tri.ctypes,
+                               C.c_int64(P), pt_xyz.ctypes, idx.ctypes, w.ctypes)
+    return idx, w
+
+
+def nearest(cell_xyz, pt_xyz, brute=False):
+    cell_xyz, pt_xyz = _c(cell_xyz, np.float64), _c(pt_xyz, np.float64)
+    P = pt_xyz.shape[0]
+    idx = np.empty(P, np.int32)
+    fn = lib().orc_nearest_brute if brute else lib().orc_nearest
+    fn(C.c_int64(cell_xyz.shape[0]), cell_xyz.ctypes, C.c_int64(P), pt_xyz.ctypes, idx.ctypes)
+    return idx
+
+
+def conserve(voc, vert_xyz, nx, ny, corner_xyz):
+    """CSR (rowptr[nx*ny+1], col, val) of first-order conservative weights."""
+    voc, vert_xyz, corner_xyz = _c(voc, np.int32), _c(vert_xyz, np.float64), _c(corner_xyz, np.float64)
+    n_cells, max_edges = voc.shape
+    assert corner_xyz.shape[0] == (nx + 1) * (ny + 1)
+    rowptr = np.empty(nx * ny + 1, np.int64)
+    args = (C.c_int64(n_cells), C.c_int64(vert_xyz.shape[0]), C.c_int(max_edges), voc.ctypes, vert_xyz.ctypes,
+            C.c_int(nx), C.c_int(ny), corner_xyz.ctypes, rowptr.ctypes)
+    nnz = lib().orc_conserve(*args, None, None, C.c_int64(0))
+    col, val = np.empty(nnz, np.int32), np.empty(nnz)
+    lib().orc_conserve(*args, col.ctypes, val.ctypes, C.c_int64(nnz))
+    return rowptr, col, val
+
+
+def grid_bilinear(nx, ny, centre_xyz, stagger, dst_xyz):
+    centre_xyz, dst_xyz = _c(centre_xyz, np.float64), _c(dst_xyz, np.float64)
+    P = dst_xyz.shape[0]
+    idx, w = np.empty((P, 4), np.int32), np.empty((P, 4))
+    lib().orc_grid_bilinear(C.c_int(nx), C.c_int(ny), centre_xyz.ctypes, C.c_int(stagger), dst_xyz.ctypes,
+                            idx.ctypes, w.ctypes)
+    return idx, w
+
+
+def apply_fixed(idx, w, src, nlev, lev_fast=False):
+    idx, w, src = _c(idx, np.int32), _c(w, np.float64), _c(src, np.float64)
+    P, nnz = idx.shape
+    nsrc = src.size // nlev
+    dst = np.empty((nlev, P))
+    lib().orc_apply_fixed(C.c_int(nnz), C.c_int64(P), idx.ctypes, w.ctypes, C.c_int64(nsrc), C.c_int(nlev),
+                          C.c_int(int(lev_fast)), src.ctypes, dst.ctypes)
+    return dst
+
+
+def apply_nearest(idx, src, nlev, lev_fast=False):
+    idx, src = _c(idx, np.int32), _c(src, np.float64)
+    P = idx.size
+    nsrc = src.size // nlev
+    dst = np.empty((nlev, P))
+    lib().orc_apply_nearest(C.c_int64(P), idx.ctypes, C.c_int64(nsrc), C.c_int(nlev), C.c_int(int(lev_fast)),
+                            src.ctypes, dst.ctypes)
+    return dst
+
+
+def apply_csr(rowptr, col, val, src, nlev, lev_fast=False):
+    rowptr, col, val, src = _c(rowptr, np.int64), _c(col, np.int32), _c(val, np.float64), _c(src, np.float64)
+    P = rowptr.size - 1
+    nsrc = src.size // nlev
+    dst = np.empty((nlev, P))
+    lib().orc_apply_csr(C.c_int64(P), rowptr.ctypes, col.ctypes, val.ctypes, C.c_int64(nsrc), C.c_int(nlev),
+                        C.c_int(int(lev_fast)), src.ctypes, dst.ctypes)
+    return dst
+
+
+def apply3_mt(idx, w, src, nlev, dst=None):
+    """Threaded 3-point apply (cpu_baseline 'port'); src is cell-fastest [nlev][nsrc]."""
+    P = idx.shape[0]
+    nsrc = src.size // nlev
+    if dst is None:
+        dst = np.empty((nlev, P))
+    lib().orc_apply3_mt(C.c_int64(P), idx.ctypes, w.ctypes, C.c_int64(nsrc), C.c_int(nlev), src.ctypes, dst.ctypes)
+    return dst
+
+
+def rotate_winds(cosa, sina, u, v):
+    """In-place on copies; u, v are [nlev][npts]."""
+    cosa, sina = _c(cosa, np.float64).ravel(), _c(sina, np.float64).ravel()
+    u, v = np.array(u, np.float64, order="C"), np.array(v, np.float64, order="C")
+    nlev = u.size // cosa.size
+    lib().orc_rotate_winds(C.c_int64(cosa.size), C.c_int(nlev), cosa.ctypes, sina.ctypes, u.ctypes, v.ctypes)
+    return u, v
+
+
+class Proj:
+    def __init__(self):
+        self.buf = C.create_string_buffer(lib().orc_sizeof_proj())
+
+    @classmethod
+    def lambert(cls, truelat1, truelat2, stdlon, lat1, lon1, knowni, knownj, dx):
+        p = cls()
+        lib().orc_map_set_lc(p.buf, *(C.c_double(x) for x in (truelat1, truelat2, stdlon, lat1, lon1, knowni, knownj, dx)))
+        return p
+
+    @classmethod
+    def latlon(cls, lat1, lon1, knowni, knownj, latinc, loninc):
+        p = cls()
+        lib().orc_map_set_latlon(p.buf, *(C.c_double(x) for x in (lat1, lon1, knowni, knownj, latinc, loninc)))
+        return p
+
+    def fields(self):
+        names = ["code_pad", "lat1", "lon1", "knowni", "knownj", "dx", "stdlon", "truelat1", "truelat2", "hemi", "cone",
+                 "polei", "polej", "rsw", "rebydx", "latinc", "loninc"]
+        vals = np.frombuffer(self.buf.raw[:8 * len(names)], dtype=np.float64)
+        return dict(zip(names[1:], vals[1:]))
+
+    def xytoll(self, x, y, stagger=M):
+        la, lo = C.c_double(), C.c_double()
+        lib().orc_xytoll(self.buf, C.c_double(x), C.c_double(y), C.c_int(stagger), C.byref(la), C.byref(lo))
+        return la.value, lo.value
+
+    def latlon_to_ij(self, lat, lon):
+        i, j = C.c_double(), C.c_double()
+        lib().orc_latlon_to_ij_lc(self.buf, C.c_double(lat), C.c_double(lon), C.byref(i), C.byref(j))
+        return i.value, j.value
+
+    def lat_lon_fields(self, ni, nj, stagger):
+        lat, lon = np.empty((nj, ni)), np.empty((nj, ni))
+        lib().orc_lat_lon_fields(self.buf, C.c_int(ni), C.c_int(nj), C.c_int(stagger), lat.ctypes, lon.ctypes)
+        return lat, lon
+
+
+def get_rotang(xlat, xlon):
+    xlat, xlon = _c(xlat, np.float64), _c(xlon, np.float64)
+    nj, ni = xlat.shape
+    cosa, sina = np.empty_like(xlat), np.empty_like(xlat)
+    lib().orc_get_rotang(C.c_int(ni), C.c_int(nj), xlat.ctypes, xlon.ctypes, cosa.ctypes, sina.ctypes)
+    return cosa, sina
+
+
+def para_range(n1, n2, nprocs, irank):
+    a, b = C.c_int(), C.c_int()
+    lib().orc_para_range(C.c_int(n1), C.c_int(n2), C.c_int(nprocs), C.c_int(irank), C.byref(a), C.byref(b))
+    return a.value, b.value
