@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark: interpolated 3-D fields/s (nCells x nLev -> nx x ny) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one Regrid (ESMF_FieldBundleRegrid, interp.F90:251) of a bundle of F 3-D fields through a
+cached bilinear route handle, inputs and outputs resident in HBM.  Workload at every N: BASELINE.json's
+headline configuration, the 3.0 M-cell x 55-level regional mesh -> 1801x1061 Lambert grid (it fits one
+GPU); for N > 1 the same global problem is split by target rows with a source halo exchange over
+RCCL (strong scaling).  RegridStore (weight generation) is timed once and reported separately
+(`store_ms`): weights are data, built once per (mesh, grid) and reused for every field and time.
+
+Prints ONE JSON line on rank 0 (see the task contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec); ~6.3 TB/s achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4_3m_regional")
+    ap.add_argument("--fields", type=int, default=13, help="3-D fields per Regrid bundle (histlist_3d has 13 nz fields)")
+    ap.add_argument("--layout", default="cell_fast", choices=["cell_fast", "lev_fast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--calib", action="store_true", help="also launch a known-byte-count streaming kernel (PMC calibration)")
+    return ap.parse_args()
+
+
+def synth_fields_device(torch, lat, lon, nlev, nfields, out_rows, seed=20240807):
+    """f(lat,lon,k) = a_k + b_k x + c_k y + d_k z + 0.1 sin(5 lon) cos(3 lat), written in
+    place into out_rows [nfields*nlev][n] on the device."""
+    dev = out_rows.device
+    lat_t = torch.as_tensor(lat, device=dev)
+    lon_t = torch.as_tensor(lon, device=dev)
+    cl = torch.cos(lat_t)
+    x, y, z = cl * torch.cos(lon_t), cl * torch.sin(lon_t), torch.sin(lat_t)
+    wig = 0.1 * torch.sin(5.0 * lon_t) * torch.cos(3.0 * lat_t)
+    rng = np.random.default_rng(seed)
+    co = torch.as_tensor(rng.uniform(-1.0, 1.0, (nfields * nlev, 4)), device=dev)
+    for r in range(nfields * nlev):
+        out_rows[r].copy_(co[r, 0] + co[r, 1] * x + co[r, 2] * y + co[r, 3] * z + wig)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather_object(obj):
+        if world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    from mpassit_amd import _lib, dist as mdist, regrid as R, workloads
+    _lib.init(local_rank)
+    arch, n_cu, hbm = _lib.device_info()
+
+    t0 = time.time()
+    m, g, nlev, desc = workloads.workload(args.workload)
+    t_gen = time.time() - t0
+    F = args.fields
+    layout = R.LAYOUT_CELL_FAST if args.layout == "cell_fast" else R.LAYOUT_LEV_FAST
+    if layout == R.LAYOUT_LEV_FAST and world > 1:
+        raise SystemExit("lev_fast layout is single-GPU only")
+
+    sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object)
+    P_local = sr.rh.n_dst
+    local = sr.local_buffer(F, nlev, dev)
+    c0, c1 = sr.sched.own
+    if sr.sched.mode == "range":
+        own = sr.own_view(local)
+    else:
+        own = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
+    synth_fields_device(torch, m.latCell[c0:c1], m.lonCell[c0:c1], nlev, F, own)
+    src_for_kernel = local
+    if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
+        src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()
+    out = torch.empty((F, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+
+    ev = []
+
+    def one_step(record):
+        if world > 1:
+            sr.sched.exchange(own, local, pack_fn=sr._pack)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        sr.rh.regrid(src_for_kernel.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+        if record:
+            e1.record()
+            ev.append((e0, e1))
+
+    if args.calib:  # 1 GiB read / 1 GiB write, 8 B per lane fully coalesced: calibrates FETCH_SIZE / WRITE_SIZE
+        n_cal = 1 << 27
+        cal_src = torch.zeros(n_cal, dtype=torch.float64, device=dev)
+        cal_dst = torch.empty(n_cal, dtype=torch.float64, device=dev)
+        cal_ids = torch.arange(n_cal, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            _lib.check(_lib.load().mpg_pack_dev(ctypes.c_void_p(cal_src.data_ptr()), ctypes.c_int64(n_cal), ctypes.c_int(1),
+                                                ctypes.c_void_p(cal_ids.data_ptr()), ctypes.c_int64(n_cal),
+                                                ctypes.c_void_p(cal_dst.data_ptr()),
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        del cal_src, cal_dst, cal_ids
+
+    for _ in range(args.warmup):
+        one_step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+
+    # correctness guard inside the bench: constant field -> constant on mapped points (sum of weights = 1)
+    chk = torch.full((nlev, sr.sched.n_local), 2.5, dtype=torch.float64, device=dev)
+    if layout == R.LAYOUT_LEV_FAST:
+        chk = chk.t().contiguous()
+    o1 = sr.rh.regrid(chk.view(-1), nlev=nlev, nfields=1, layout=layout)
+    torch.cuda.synchronize()
+    bad = int(((o1 != 0.0) & ((o1 - 2.5).abs() > 1e-12)).sum().item())
+    n_unmapped = int((o1[0, 0] == 0.0).sum().item())
+    if bad:
+        raise SystemExit("bench self-check failed: %d points off" % bad)
+
+    # live streaming reference of THIS device (boxes differ by >10 %): plain 2 GiB -> 2 GiB device copy
+    cp_a = torch.empty(1 << 28, dtype=torch.float64, device=dev)
+    cp_b = torch.empty_like(cp_a)
+    cp_b.copy_(cp_a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        cp_b.copy_(cp_a)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * cp_a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del cp_a, cp_b
+
+    U = sr.n_needed
+    alg_bytes = F * nlev * 8.0 * (U + P_local) + P_local * 36.0  # U*L*e + P*L*e per field + P*36 once per launch
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_f%d_%s.json" % (args.workload, F, args.layout))
+    if world == 1 and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sr, src_for_kernel if layout == R.LAYOUT_CELL_FAST else local, nlev, args.cpu_seconds)
+
+    if rank == 0:
+        fields_per_s = F * args.steps / dt
+        rec = {
+            "metric": "interpolated 3-D fields/sec (nCells x nLev -> nx x ny)",
+            "value": fields_per_s, "unit": "fields/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (args.workload, desc), "fields_per_step": F, "nlev": nlev, "nCells": int(m.nCells),
+                       "target_points": int(g.nx * g.ny), "method": "bilinear", "src_layout": args.layout,
+                       "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
+                       "unmapped_points_rank0": n_unmapped},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "k_apply3_cf" if layout == R.LAYOUT_CELL_FAST else "k_apply3_lf",
+                         "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
+                         "device_copy_GBs": copy_gbs},
+            "cpu_baseline": cpu,
+            "store_ms": sr.store_ms,
+            "device": {"arch": arch, "cus": n_cu, "hbm_gib": round(hbm / 2 ** 30, 1), "name": torch.cuda.get_device_name(dev),
+                       "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))},
+            "setup_s": {"synthetic_mesh_and_grid": round(t_gen, 2)},
+        }
+        print(json.dumps(rec), flush=True)
+    sr.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sr, local_rows, nlev, seconds):
+    """Oracle ('port') apply loop on the host cores, one whole 3-D field of the same workload, same weights.
+    Test infrastructure used only as the reported CPU comparator; never on the product path."""
+    cores = len(os.sched_getaffinity(0))
+    try:  # honour the cgroup CPU quota of the box (e.g. 16 of 256 hardware threads)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    from oracle import oracle as o
+    o.build()
+    idx, w = sr.rh.weights()
+    src = local_rows.view(-1, local_rows.shape[-1])[:nlev].cpu().numpy()  # field 0: [nlev][n_local]
+    dst = np.empty((nlev, idx.shape[0]))
+    o.apply3_mt(idx, w, src, nlev, dst)  # warm-up / page-in
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        o.apply3_mt(idx, w, src, nlev, dst)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > seconds or reps >= 200:
+            break
+    return {"value": reps / el, "unit": "fields/s", "cores": cores, "kind": "port",
+            "sample": "%d full 3-D fields (%d levels, all %d target points) through the oracle's OpenMP apply loop, "
+                      "weights taken from the GPU handle; CPU restatement, not ESMF (ESMF unavailable)" % (reps, nlev, idx.shape[0])}
+
+
+if __name__ == "__main__":
+    main()

@@ -119,9 +119,18 @@ int mpg_mesh_get_triangles(mpg_mesh mesh, int32_t *tri_host);
  * indices to positions in that list so that Regrid reads a compact [nlev][n_unique] halo buffer. */
 int mpg_handle_unique_sources(mpg_handle rh, int64_t *n_unique, int32_t *ids_host);
 int mpg_handle_localize(mpg_handle rh);
+/* Halo in "range" form (spatially banded cell numbering): subtract `base` from every source index and
+ * declare the local source extent n_local, so that Regrid reads a [nlev][n_local] buffer holding the
+ * global cell range [base, base + n_local).  Fails if any referenced id falls outside that range. */
+int mpg_handle_rebase(mpg_handle rh, int64_t base, int64_t n_local);
 /* dst[k][i] = src[k][ids[i]] (pack owned cells for the halo exchange); all device pointers */
 int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *ids_dev, int64_t n_ids,
                  double *dst_dev, void *hip_stream);
+
+/* kernel-selection knobs for benchmarking (defaults are the tuned production values):
+ *   "lev_chunk"  levels per workgroup pass of the 3-point apply kernel (0 = all levels)
+ *   "a3_variant" index into the compiled (rows-per-thread, level-unroll, non-temporal) variants */
+int mpg_tune(const char *key, int value);
 
 /* timing of the last Store phases in ms (search build, search, finalize); any pointer may be NULL */
 int mpg_handle_store_ms(mpg_handle rh, float *ms_total);

@@ -15,7 +15,7 @@ SYMBOLS = [
     "mpg_grid_create", "mpg_grid_destroy", "mpg_regrid_store", "mpg_regrid_store_grid", "mpg_regrid",
     "mpg_regrid_dev", "mpg_handle_release", "mpg_rotate_winds", "mpg_rotate_winds_dev", "mpg_handle_info",
     "mpg_handle_get_weights", "mpg_handle_get_csr", "mpg_mesh_get_triangles", "mpg_handle_unique_sources",
-    "mpg_handle_localize", "mpg_pack_dev", "mpg_handle_store_ms",
+    "mpg_handle_localize", "mpg_handle_rebase", "mpg_pack_dev", "mpg_handle_store_ms", "mpg_tune",
 ]
 
 MPG_SUCCESS = 0
@@ -38,6 +38,13 @@ def load():
     """dlopen the HIP library; raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; when torch shares the process it
+        # must be loaded FIRST so that this library binds to the same runtime (two runtimes in one process
+        # leave the second one without a device).  C / Fortran callers have no torch and use /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(SO_PATH):
             raise ImportError(
                 "%s not found: build the HIP extension first (python -m mpassit_amd.build); "
@@ -75,3 +82,7 @@ def device_info():
     ncu, hbm = C.c_int(), C.c_int64()
     check(load().mpg_device_info(buf, C.c_int(64), C.byref(ncu), C.byref(hbm)))
     return buf.value.decode(), ncu.value, hbm.value
+
+
+def tune(key, value):
+    check(load().mpg_tune(key.encode(), C.c_int(int(value))))

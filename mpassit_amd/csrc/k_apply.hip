@@ -19,6 +19,8 @@
 // non-temporal stores so the write stream does not evict the source lines from L2), 2-D target tiles so
 // a workgroup's gather footprint is spatially compact, XCD-aware tile order so neighbouring tiles share
 // an L2, weights/indices SoA and read once per tile for all levels.
+#include <string.h>
+
 #include "geom.h"
 #include "mpg_internal.h"
 
@@ -33,12 +35,14 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
 }
 
 #define A3_TX 64
-#define A3_RPT 4
-#define A3_TY (4 * A3_RPT)
 
+// RPT = target rows per thread (tile = 64 x 4*RPT points per 256-thread workgroup), KU = level unroll,
+// NT = non-temporal destination stores.
+template <int RPT, int KU, bool NT>
 __global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                    const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
                                                    int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk) {
+  constexpr int TY = 4 * RPT;
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -49,14 +53,14 @@ __global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ i
   int tx = tile % ntx, ty = tile / ntx;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int i = tx * A3_TX + lane;
-  int j0 = ty * A3_TY + wave * A3_RPT;
+  int j0 = ty * TY + wave * RPT;
   int k0 = chunk * lev_chunk, k1 = min(nlev, k0 + lev_chunk);
 
-  int32_t c[A3_RPT][3];
-  double ww[A3_RPT][3];
-  bool act[A3_RPT], mapped[A3_RPT];
+  int32_t c[RPT][3];
+  double ww[RPT][3];
+  bool act[RPT], mapped[RPT];
 #pragma unroll
-  for (int r = 0; r < A3_RPT; ++r) {
+  for (int r = 0; r < RPT; ++r) {
     int j = j0 + r;
     act[r] = (i < nx) && (j < ny);
     int64_t p = act[r] ? (int64_t)j * nx + i : 0;
@@ -71,20 +75,53 @@ __global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ i
   }
   const double *s = src + ((int64_t)fld * nlev + k0) * nsrc;
   double *d = dst + ((int64_t)fld * nlev + k0) * P + (int64_t)j0 * nx + i;
-  for (int k = k0; k < k1; ++k) {
-    double v[A3_RPT];
+  int k = k0;
+  for (; k + KU <= k1; k += KU) {
+    double v[KU][RPT];
 #pragma unroll
-    for (int r = 0; r < A3_RPT; ++r) {
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const double *su = s + (int64_t)u * nsrc;
+        double a = su[c[r][0]], b = su[c[r][1]], e = su[c[r][2]];
+        v[u][r] = ww[r][0] * a + ww[r][1] * b + ww[r][2] * e;
+      }
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int r = 0; r < RPT; ++r)
+        if (act[r]) {
+          double o = mapped[r] ? v[u][r] : 0.0;
+          double *dp = d + (int64_t)u * P + (int64_t)r * nx;
+          if (NT) __builtin_nontemporal_store(o, dp); else *dp = o;
+        }
+    s += (int64_t)KU * nsrc;
+    d += (int64_t)KU * P;
+  }
+  for (; k < k1; ++k) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
       double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
-      v[r] = ww[r][0] * a + ww[r][1] * b + ww[r][2] * e;
+      double o = mapped[r] ? ww[r][0] * a + ww[r][1] * b + ww[r][2] * e : 0.0;
+      if (act[r]) {
+        double *dp = d + (int64_t)r * nx;
+        if (NT) __builtin_nontemporal_store(o, dp); else *dp = o;
+      }
     }
-#pragma unroll
-    for (int r = 0; r < A3_RPT; ++r)
-      if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + (int64_t)r * nx);
     s += nsrc;
     d += P;
   }
 }
+
+typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int);
+struct A3Variant { int rpt, ku, nt; apply3_fn fn; };
+static const A3Variant g_a3_variants[] = {
+    {4, 1, 1, k_apply3_cf<4, 1, true>},  {4, 2, 1, k_apply3_cf<4, 2, true>},  {2, 2, 1, k_apply3_cf<2, 2, true>},
+    {2, 4, 1, k_apply3_cf<2, 4, true>},  {8, 1, 1, k_apply3_cf<8, 1, true>},  {1, 4, 1, k_apply3_cf<1, 4, true>},
+    {4, 1, 0, k_apply3_cf<4, 1, false>}, {4, 2, 0, k_apply3_cf<4, 2, false>}, {1, 8, 1, k_apply3_cf<1, 8, true>},
+    {2, 1, 1, k_apply3_cf<2, 1, true>},  {8, 2, 1, k_apply3_cf<8, 2, true>},
+};
+static int g_a3_variant = 9;  // MPG_A3_VARIANT (tuned on MI355X: profiles/r01_sweep_apply.txt)
 
 // Level-fastest source: one workgroup = 64 consecutive target points x all levels.
 // phase 1: wave w serves points 16w..16w+15, lanes = levels -> three coalesced row reads per point;
@@ -216,11 +253,27 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
   for (int k = 0; k < nlev; ++k) dst[(int64_t)k * nids + i] = src[(int64_t)k * nsrc + c];
 }
 
+int mpg_k_tune(const char *key, int value) {
+  g_tune_read = 1;
+  if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }
+  if (!strcmp(key, "a3_variant")) {
+    if (value < 0 || value >= (int)(sizeof(g_a3_variants) / sizeof(g_a3_variants[0]))) return MPG_ERR_INVALID_ARG;
+    g_a3_variant = value;
+    return MPG_SUCCESS;
+  }
+  return MPG_ERR_INVALID_ARG;
+}
+
 int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s) {
   if (!g_tune_read) {
     g_tune_read = 1;
     const char *e = getenv("MPG_LEV_CHUNK");
     if (e) g_lev_chunk = atoi(e);
+    e = getenv("MPG_A3_VARIANT");
+    if (e) {
+      int v = atoi(e);
+      if (v >= 0 && v < (int)(sizeof(g_a3_variants) / sizeof(g_a3_variants[0]))) g_a3_variant = v;
+    }
   }
   int64_t P = h->n_dst;
   int lev_fast = layout == MPG_LAYOUT_LEV_FAST;
@@ -242,11 +295,13 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
       }
       k_apply3_lf<<<(unsigned)nb64 * nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, nb64);
     } else {
-      int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + A3_TY - 1) / A3_TY;
+      const A3Variant &av = g_a3_variants[g_a3_variant];
+      int tyv = 4 * av.rpt;
+      int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + tyv - 1) / tyv;
       int lc = g_lev_chunk > 0 ? g_lev_chunk : nlev;
       int nchunk = (nlev + lc - 1) / lc;
       unsigned nwg = (unsigned)ntx * nty * nchunk * nfields;
-      k_apply3_cf<<<nwg, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk);
+      av.fn<<<nwg, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk);
     }
   } else {
     mpg_set_error("Regrid: unsupported handle");

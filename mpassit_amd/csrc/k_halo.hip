@@ -62,3 +62,38 @@ int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap,
   return MPG_SUCCESS;
 }
 
+
+__global__ __launch_bounds__(256) void k_rebase(int64_t n, int32_t *__restrict__ idx, int32_t base, int32_t nlocal,
+                                                int32_t *__restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t c = idx[i];
+    if (c < 0) continue;
+    c -= base;
+    if (c < 0 || c >= nlocal) atomicAdd(bad, 1);
+    idx[i] = c;
+  }
+}
+
+int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s) {
+  int rc;
+  int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
+  int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
+  DevBuf<int32_t> bad;
+  if ((rc = bad.alloc(1))) return rc;
+  MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
+  int gb = (int)((ni + 255) / 256);
+  if (gb > 8192) gb = 8192;
+  if (gb < 1) gb = 1;
+  k_rebase<<<gb, 256, 0, s>>>(ni, ip, (int32_t)base, (int32_t)n_local, bad.p);
+  int32_t nb = 0;
+  MPG_HIP(hipMemcpyAsync(&nb, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  bad.free();
+  h->n_src = n_local;
+  h->localized = true;
+  if (nb) {
+    mpg_set_error("mpg_handle_rebase: %d source indices fall outside [base, base+n_local)", nb);
+    return MPG_ERR_INVALID_ARG;
+  }
+  return MPG_SUCCESS;
+}

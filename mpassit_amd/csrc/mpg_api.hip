@@ -409,6 +409,25 @@ int mpg_handle_localize(mpg_handle h) {
   return mpg_k_unique_sources(h, ids, true, g_stream);
 }
 
+int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h, "mpg_handle_rebase: NULL handle");
+  MPG_ARG(!h->localized, "mpg_handle_rebase: handle already localized");
+  MPG_ARG(base >= 0 && n_local > 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
+  if (h->cached) {
+    g_cache.erase(h->key);
+    h->cached = false;
+  }
+  return mpg_k_rebase(h, base, n_local, g_stream);
+}
+
+int mpg_tune(const char *key, int value) {
+  MPG_ARG(key, "mpg_tune: NULL key");
+  int rc = mpg_k_tune(key, value);
+  if (rc) mpg_set_error("mpg_tune: unknown key or value out of range: %s=%d", key, value);
+  return rc;
+}
+
 int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *ids_dev, int64_t n_ids, double *dst_dev, void *hip_stream) {
   MPG_CHECK_INIT();
   MPG_ARG(src_dev && ids_dev && dst_dev, "mpg_pack_dev: NULL argument");

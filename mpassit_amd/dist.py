@@ -1,0 +1,200 @@
+"""Multi-GPU path: target rows sharded over ranks, source-cell halo exchanged over RCCL/xGMI.
+
+One process per GPU (torch.distributed, backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+Decomposition mirrors the reference's two data-parallel splits:
+  * target grid split along j into contiguous row blocks (regDecomp=(/1,npets/), model_grid.F90:693),
+  * source cells split into contiguous id blocks by `para_range` (model_grid.F90:423-438,2428-2441).
+Every target point is owned by exactly one rank, so there is no reduction collective; the only data
+exchange is the source halo (ESMF hides it in the route handle): one all-to-all-v per
+field batch.  The schedule is computed once per handle ("geometry halo"), the values move per batch.
+
+Two halo forms:
+  range   : cell numbering is spatially banded (MPAS regional meshes ordered by rows, the synthetic
+            bench meshes): a rank's local source space is the contiguous global id range [g0, g1) that
+            covers its own block plus everything its rows reference; own data lives in place and only
+            the two thin side strips travel.
+  compact : arbitrary numbering: local source space = sorted unique referenced ids; every referenced
+            value is gathered (mpg_pack_dev) and sent, including the rank's own.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def para_range(n1, n2, nprocs, irank):
+    """model_grid.F90:2428-2441: inclusive 1-based block [ista, iend] of rank irank."""
+    iwork1, iwork2 = divmod(n2 - n1 + 1, nprocs)
+    ista = irank * iwork1 + n1 + min(irank, iwork2)
+    iend = ista + iwork1 - 1
+    if iwork2 > irank:
+        iend += 1
+    return ista, iend
+
+
+def row_block(ny, world, rank):
+    """0-based half-open mass-row block [j0, j1) of `rank`."""
+    a, b = para_range(1, ny, world, rank)
+    return a - 1, b
+
+
+def cell_block(n_cells, world, rank):
+    a, b = para_range(1, n_cells, world, rank)
+    return a - 1, b
+
+
+@dataclass
+class HaloSchedule:
+    """Who sends which source cells to whom.  Pure host logic + one torch.distributed exchange;
+    device-agnostic (CPU tensors under gloo, CUDA tensors under nccl)."""
+    rank: int
+    world: int
+    mode: str                      # "range" | "compact"
+    n_local: int                   # length of the local source index space
+    own: tuple                     # global [c0, c1) owned by this rank
+    base: int = 0                  # range mode: global id of local index 0
+    send_ids: list = field(default_factory=list)   # per peer: owned-slab offsets to send (np.int32) or (a, b) range
+    recv_pos: list = field(default_factory=list)   # per peer: (a, b) destination range in the local index space
+    own_pos: tuple = (0, 0)        # range mode: where the own block sits in the local index space
+
+    @staticmethod
+    def build(needed_ids, n_cells, rank, world, all_gather_object, range_slack=1.25):
+        """needed_ids: sorted unique global source ids this rank's rows reference."""
+        c0, c1 = cell_block(n_cells, world, rank)
+        needed_ids = np.asarray(needed_ids, np.int64)
+        lo = int(min(needed_ids[0], c0)) if needed_ids.size else c0
+        hi = int(max(needed_ids[-1] + 1, c1)) if needed_ids.size else c1
+        # banded numbering <=> the covering range is not much larger than what is actually used
+        used = np.union1d(needed_ids, np.arange(c0, c1)).size if (hi - lo) < 4 * (needed_ids.size + c1 - c0) else 0
+        want_range = used > 0 and (hi - lo) <= range_slack * used
+        votes = all_gather_object(bool(want_range))
+        mode = "range" if all(votes) else "compact"
+        blocks = [cell_block(n_cells, world, q) for q in range(world)]
+        if mode == "range":
+            spans = all_gather_object((lo, hi))
+            s = HaloSchedule(rank, world, mode, hi - lo, (c0, c1), base=lo, own_pos=(c0 - lo, c1 - lo))
+            for q in range(world):
+                if q == rank:
+                    s.send_ids.append((0, 0))
+                    s.recv_pos.append((0, 0))
+                    continue
+                qlo, qhi = spans[q]
+                a, b = max(qlo, c0), min(qhi, c1)          # what q wants from my block
+                s.send_ids.append((a - c0, b - c0) if b > a else (0, 0))
+                qc0, qc1 = blocks[q]
+                a, b = max(lo, qc0), min(hi, qc1)          # what I want from q's block
+                s.recv_pos.append((a - lo, b - lo) if b > a else (0, 0))
+            return s
+        lists = all_gather_object(needed_ids.astype(np.int32))
+        s = HaloSchedule(rank, world, mode, int(needed_ids.size), (c0, c1))
+        for q in range(world):
+            theirs = lists[q]
+            mine = theirs[(theirs >= c0) & (theirs < c1)]
+            s.send_ids.append((mine - c0).astype(np.int32))
+            qc0, qc1 = blocks[q]
+            a = int(np.searchsorted(needed_ids, qc0))
+            b = int(np.searchsorted(needed_ids, qc1))
+            s.recv_pos.append((a, b))
+        return s
+
+    def counts(self):
+        if self.mode == "range":
+            send = [b - a for a, b in self.send_ids]
+        else:
+            send = [int(x.size) for x in self.send_ids]
+        recv = [b - a for a, b in self.recv_pos]
+        return send, recv
+
+    def exchange(self, own_rows, local_rows, pack_fn=None):
+        """own_rows: tensor [R][n_own] of this rank's block (R = nfields*nlev rows);
+        local_rows: tensor [R][n_local], filled in place.  In range mode `own_rows` may be a view of
+        `local_rows` (own data already in place).  pack_fn(own_rows, ids) -> [R][len(ids)] gathers columns
+        (HIP pack kernel on the GPU, index_select in the CPU tests)."""
+        import torch
+        import torch.distributed as dist
+        R = own_rows.shape[0]
+        send_n, recv_n = self.counts()
+        parts = []
+        for q in range(self.world):
+            if send_n[q] == 0:
+                continue
+            if self.mode == "range":
+                a, b = self.send_ids[q]
+                parts.append(own_rows[:, a:b].reshape(-1))
+            else:
+                ids = self.send_ids[q]
+                if pack_fn is not None:
+                    parts.append(pack_fn(own_rows, ids).reshape(-1))
+                else:
+                    parts.append(own_rows[:, torch.as_tensor(ids, dtype=torch.long, device=own_rows.device)].reshape(-1))
+        sendbuf = torch.cat(parts) if parts else own_rows.new_empty(0)
+        recvbuf = own_rows.new_empty(R * sum(recv_n))
+        if self.world > 1:
+            dist.all_to_all_single(recvbuf, sendbuf, [R * n for n in recv_n], [R * n for n in send_n])
+        else:
+            recvbuf.copy_(sendbuf)
+        off = 0
+        for q in range(self.world):
+            n = recv_n[q]
+            if n == 0:
+                continue
+            a, b = self.recv_pos[q]
+            local_rows[:, a:b].copy_(recvbuf[off:off + R * n].view(R, n))
+            off += R * n
+        return local_rows
+
+
+class ShardedRegrid:
+    """Rank-local piece of a row-sharded Mesh -> Grid regrid on this rank's GPU."""
+
+    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object):
+        from . import regrid as R
+        self.rank, self.world = rank, world
+        self.j0, self.j1 = row_block(target.ny, world, rank)
+        self.mesh = R.Mesh.from_mpas(mpas_mesh)
+        self.grid = R.Grid.from_target(target, rows=(self.j0, self.j1))
+        self.rh = R.regrid_store(self.mesh, self.grid, regridmethod)
+        self.store_ms = self.rh.store_ms
+        needed = self.rh.unique_sources()
+        self.n_needed = int(needed.size)
+        self.sched = HaloSchedule.build(needed, mpas_mesh.nCells, rank, world, all_gather_object)
+        if self.sched.mode == "range":
+            self.rh.rebase(self.sched.base, self.sched.n_local)
+        else:
+            self.rh.localize()
+        self._ids_dev = {}
+
+    def _pack(self, own_rows, ids):
+        """HIP gather of owned columns (mpg_pack_dev)."""
+        import ctypes as C
+
+        import torch
+
+        from . import _lib as L
+        key = ids.ctypes.data
+        if key not in self._ids_dev:
+            self._ids_dev[key] = torch.as_tensor(ids, device=own_rows.device)
+        ids_d = self._ids_dev[key]
+        out = torch.empty((own_rows.shape[0], ids.size), dtype=own_rows.dtype, device=own_rows.device)
+        L.check(L.load().mpg_pack_dev(C.c_void_p(own_rows.data_ptr()), C.c_int64(own_rows.shape[1]), C.c_int(own_rows.shape[0]),
+                                      C.c_void_p(ids_d.data_ptr()), C.c_int64(ids.size), C.c_void_p(out.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    def local_buffer(self, nfields, nlev, device):
+        import torch
+        return torch.empty((nfields * nlev, self.sched.n_local), dtype=torch.float64, device=device)
+
+    def own_view(self, local_rows):
+        """Range mode: the slice of the local buffer that holds this rank's own cells (fill it in place)."""
+        a, b = self.sched.own_pos
+        return local_rows[:, a:b]
+
+    def step(self, own_rows, local_rows, nlev, nfields, out=None):
+        """Halo exchange + Regrid of one field batch.  Returns dst [nfields][nlev][rows][nx]."""
+        self.sched.exchange(own_rows, local_rows, pack_fn=self._pack if own_rows.is_cuda else None)
+        return self.rh.regrid(local_rows.view(-1), nlev=nlev, nfields=nfields, out=out)
+
+    def destroy(self):
+        self.rh.release()
+        self.mesh.destroy()
+        self.grid.destroy()

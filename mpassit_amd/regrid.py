@@ -176,6 +176,10 @@ class RouteHandle:
         self._refresh()
         return ids
 
+    def rebase(self, base, n_local):
+        check(L.load().mpg_handle_rebase(self._h, C.c_int64(base), C.c_int64(n_local)))
+        self._refresh()
+
     def release(self):
         if self._h:
             check(L.load().mpg_handle_release(self._h))

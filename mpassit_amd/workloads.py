@@ -1,0 +1,39 @@
+"""Named synthetic workloads (BASELINE.json `configs`) shared by bench.py, smoke() and the tests."""
+from . import synth
+from . import target_grid as tg
+
+README_LAMBERT = dict(dx=3000.0, dy=3000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+
+# parm/histlist_3d with wrf_mod_vars=.false.: 13 nz-fields (incl. uReconstructZonal/Meridional), 2 nzp1
+HISTLIST_3D_NZ = ["theta", "uReconstructZonal", "uReconstructMeridional", "qv", "qc", "qr", "qi", "qs", "qg", "ni", "nr",
+                  "pressure", "rho"]
+
+
+def conus_lambert_grid(nx=1801, ny=1061, **over):
+    """README.md:53-73 namelist: 1801x1061 (staggered) 3-km Lambert grid -> 1800x1060 mass points."""
+    p = dict(README_LAMBERT)
+    p.update(over)
+    return tg.define_target_grid_params("lambert", nx, ny, **p)
+
+
+def workload(name):
+    """-> (MpasMesh, TargetGrid, nlev, description)"""
+    if name == "c4_3m_regional":
+        g = conus_lambert_grid()
+        m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
+        return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1801x1061 Lambert (1800x1060 mass points)"
+    if name == "c2_655k_regional":
+        g = conus_lambert_grid()
+        m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 655_362)
+        return m, g, 55, "655 362-cell regional hex mesh x 55 levels -> 1801x1061 Lambert"
+    if name == "c1_65k_global":
+        g = tg.define_target_grid_params("lat-lon", 201, 201, dx=0.1, dy=0.1, ref_lat=30.0, ref_lon=-110.0, ref_x=1.0, ref_y=1.0,
+                                         stand_lon=-110.0)
+        m = synth.global_voronoi_mesh(65_536)
+        return m, g, 10, "65 536-cell global Voronoi mesh x 10 levels -> 200x200 0.1-degree lat-lon"
+    if name == "tiny":
+        g = tg.define_target_grid_params("lambert", 181, 107, dx=30000.0, dy=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
+                                         truelat2=38.5, stand_lon=-97.5)
+        m = synth.regional_mesh_for_lambert(g.proj, 181, 107, 30_000)
+        return m, g, 8, "30 k-cell regional hex mesh x 8 levels -> 181x107 30-km Lambert"
+    raise KeyError(name)
