@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference's `interp` module (interp.F90), driving the HIP C-ABI.
+
+Same entry points, same order of operations, same quirks:
+  interp_data        interp.F90:92-105
+  interp_diag_data   interp.F90:107-141   one bilinear bundle S/R, then U10/V10 rotation (Lambert only)
+  interp_hist_data   interp.F90:183-465   2d_patch -> hgt -> 3d_nz -> UMASS/VMASS -> rotate -> U/V
+                                          destagger -> 3d_nzp1 -> [3d_vert] -> 2d_cons -> 2d_nstd -> soil
+  rotate_winds_cgrid interp.F90:689-749
+Every `S/R` (RegridStore + Regrid) pair of the reference becomes regrid_store() (cached: identical
+5-tuples share one weight set, the reference recomputes it up to 13x) + RouteHandle.regrid().
+Fields are float64; 3-D fields are cell-fastest [nlev][nCells] as the reference holds them
+(input_data.F90:653-655) unless `layout=LAYOUT_LEV_FAST` ([nCells][nlev], MPAS file order).
+Arrays may be numpy (host path) or torch CUDA tensors (device-resident path).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import fields as F
+from . import regrid as R
+
+
+@dataclass
+class InputData:
+    """What `read_input_data` leaves in the ESMF bundles (input_data.F90:97-1144)."""
+    hgt: object = None                            # 'ter' on cells (model_grid.F90:396-399)
+    diag: dict = field(default_factory=dict)      # mpas name -> [nCells] or [nz][nCells] (refl10cm)
+    hist: dict = field(default_factory=dict)      # mpas name -> [nCells] | [nlev][nCells]
+    nz: int = 0
+    nzp1: int = 0
+    nsoil: int = 0
+    layout: int = R.LAYOUT_CELL_FAST
+
+
+@dataclass
+class InterpConfig:
+    """Subset of program_setup / model_grid module state the interp module reads."""
+    interp_diag: bool = True
+    interp_hist: bool = True
+    wrf_mod_vars: bool = False
+    proj_is_lambert: bool = True      # proj_code == PROJ_LC (interp.F90:138,291)
+    diag_list: list = field(default_factory=list)
+    hist_2d: list = field(default_factory=list)
+    hist_3d: list = field(default_factory=list)
+    hist_soil: list = field(default_factory=list)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _stack(arrs):
+    if _is_torch(arrs[0]):
+        import torch
+        return torch.stack([a.contiguous() for a in arrs]).contiguous()
+    return np.ascontiguousarray(np.stack(arrs))
+
+
+def _bundle_regrid(rh, arrs, nlev, layout):
+    """ESMF_FieldBundleRegrid: one weight set, nfields fields of equal level count."""
+    if not arrs:
+        return []
+    out = rh.regrid(_stack(arrs).reshape(-1), nlev=nlev, nfields=len(arrs), layout=layout)
+    return [out[i] for i in range(len(arrs))]
+
+
+def rotate_winds_cgrid(target, u, v):
+    """In place earth -> grid-relative rotation with cosalpha/sinalpha of the CENTER stagger."""
+    cosa, sina = target.cosa, target.sina
+    if _is_torch(u):
+        import torch
+        cosa = torch.as_tensor(np.ascontiguousarray(cosa), device=u.device)
+        sina = torch.as_tensor(np.ascontiguousarray(sina), device=u.device)
+    return R.rotate_winds_cgrid(cosa, sina, u, v)
+
+
+def interp_diag_data(mesh, grid, target, inp, cfg, out):
+    names = [n for n, _ in cfg.diag_list]
+    if not names:
+        return
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)          # interp.F90:123
+    two_d = [(n, t) for n, t in cfg.diag_list if inp.diag[n].ndim == 1]
+    three_d = [(n, t) for n, t in cfg.diag_list if inp.diag[n].ndim == 2]   # REFL_10CM, interp.F90:153-160
+    for (n, t), o in zip(two_d, _bundle_regrid(rh, [inp.diag[n] for n, _ in two_d], 1, R.LAYOUT_CELL_FAST)):
+        out[t] = o[0]
+    for (n, t), o in zip(three_d, _bundle_regrid(rh, [inp.diag[n] for n, _ in three_d], inp.nz, inp.layout)):
+        out[t] = o
+    rh.release()
+    iu, iv = F.diag_wind_indices(cfg.diag_list)
+    if iu is not None and iv is not None and cfg.proj_is_lambert:     # interp.F90:138-140
+        tu, tv = cfg.diag_list[iu][1], cfg.diag_list[iv][1]
+        rotate_winds_cgrid(target, out[tu], out[tv])
+
+
+def interp_hist_data(mesh, grid, target, inp, cfg, out):
+    h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars)
+    # `method` is only assigned inside `if (n_hist_fields_2d_patch>0)` in the reference (interp.F90:203-204) and
+    # undefined otherwise; this build always uses BILINEAR for the blocks below.
+    rh_patch = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)    # interp.F90:207 / :226 / :241 / ...
+    for (n, t), o in zip(h.patch_2d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.patch_2d], 1, R.LAYOUT_CELL_FAST)):
+        out[t] = o[0]
+    out["HGT"] = rh_patch.regrid(inp.hgt, nlev=1)[0, 0]              # interp.F90:226-238
+    for (n, t), o in zip(h.nz_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nz_3d], inp.nz, inp.layout)):
+        out[t] = o                                                    # interp.F90:240-254
+    if h.do_u_interp:
+        out["UMASS"] = rh_patch.regrid(inp.hist["uReconstructZonal"], nlev=inp.nz, layout=inp.layout)[0]      # :256-272
+    if h.do_v_interp:
+        out["VMASS"] = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout)[0]  # :274-289
+    if h.do_u_interp and h.do_v_interp and cfg.proj_is_lambert:
+        rotate_winds_cgrid(target, out["UMASS"], out["VMASS"])        # :291-293
+    if h.do_u_interp:
+        rh_u = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1)          # :295-311  UMASS(CENTER) -> U(EDGE1)
+        out["U"] = rh_u.regrid(out["UMASS"].reshape(-1), nlev=inp.nz)[0]
+        rh_u.release()
+    if h.do_v_interp:
+        rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2)          # :313-328  VMASS(CENTER) -> V(EDGE2)
+        out["V"] = rh_v.regrid(out["VMASS"].reshape(-1), nlev=inp.nz)[0]
+        rh_v.release()
+    for (n, t), o in zip(h.nzp1_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nzp1_3d], inp.nzp1, inp.layout)):
+        out[t] = o                                                    # :331-347
+    if h.vert_3d:
+        raise NotImplementedError("node-located bilinear (vorticity, interp.F90:350-366) is not built yet (SURVEY s8 a11)")
+    rh_cons = rh_nstd = None
+    if h.cons_2d:
+        rh_cons = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)  # :368-416 (bundle or per-field: same result)
+        for (n, t), o in zip(h.cons_2d, _bundle_regrid(rh_cons, [inp.hist[n] for n, _ in h.cons_2d], 1, R.LAYOUT_CELL_FAST)):
+            out[t] = o[0]
+    if h.nstd_2d:
+        rh_nstd = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)  # :418-434
+        for (n, t), o in zip(h.nstd_2d, _bundle_regrid(rh_nstd, [inp.hist[n] for n, _ in h.nstd_2d], 1, R.LAYOUT_CELL_FAST)):
+            out[t] = o[0]
+    if h.soil:
+        # soil bundle uses whichever method was set last (interp.F90:436-441)
+        rh_soil = {"nearest": rh_nstd, "conserve": rh_cons, "bilinear": rh_patch}[F.soil_method(h)]
+        for (n, t), o in zip(h.soil, _bundle_regrid(rh_soil, [inp.hist[n] for n, _ in h.soil], inp.nsoil, inp.layout)):
+            out[t] = o
+    rh_patch.release()                                                # :449-464
+    if rh_cons is not None:
+        rh_cons.release()
+    if rh_nstd is not None:
+        rh_nstd.release()
+
+
+def interp_data(mesh, grid, target, inp, cfg):
+    """-> dict target_name -> array ([ny][nx], [nlev][ny][nx]; U on EDGE1, V on EDGE2)."""
+    out = {}
+    if cfg.interp_diag:
+        interp_diag_data(mesh, grid, target, inp, cfg, out)
+    if cfg.interp_hist:
+        interp_hist_data(mesh, grid, target, inp, cfg, out)
+    return out
