@@ -57,5 +57,33 @@ def build(force=False, verbose=False):
     return SO
 
 
+FORTRAN_SRC = ["mpg_mod.F90", "host_mod.F90", "interp_mod.F90", "mpassit_driver.F90"]
+FLANG = os.environ.get("FLANG", "/opt/rocm/bin/amdflang")
+DRIVER = os.path.join(HERE, "fortran", "mpassit")
+
+
+def build_fortran(force=False):
+    """Fortran driver (reference surface: namelist + parm lists) linked against the C-ABI library."""
+    fdir = os.path.join(HERE, "fortran")
+    srcs = [os.path.join(fdir, f) for f in FORTRAN_SRC]
+    if not force and _newer(DRIVER, srcs + [SO]):
+        return DRIVER
+    mod = os.path.join(OBJDIR, "fmod")
+    os.makedirs(mod, exist_ok=True)
+    objs = []
+    for s in srcs:
+        o = os.path.join(mod, os.path.basename(s).replace(".F90", ".o"))
+        r = subprocess.run([FLANG, "-O2", "-fPIC", "-module-dir", mod, "-I", mod, "-c", s, "-o", o], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("amdflang failed on %s:\n%s" % (s, r.stderr[-6000:]))
+        objs.append(o)
+    r = subprocess.run([FLANG, "-o", DRIVER] + objs + ["-L" + HERE, "-lmpassit_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("linking the Fortran driver failed:\n%s" % r.stderr[-6000:])
+    return DRIVER
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_fortran(force="--force" in sys.argv))

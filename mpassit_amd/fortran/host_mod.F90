@@ -1,0 +1,337 @@
+!> Host-side support modules of the Fortran driver: namelist, variable lists, target-grid coordinates and
+!! a raw-binary stand-in for NetCDF (no NetCDF library exists in the build image; I/O is outside the hot
+!! path, SURVEY s8(f)).  All of it is a fresh restatement of what the reference computes on the host:
+!!   program_setup  <- program_setup.F90:87-249 (namelist &config :103-106, derived sizes :163-164,:238-240)
+!!   varlists       <- input_data.F90:1146-1194 (read_varlist), :840-911 (classification)
+!!   target_grid    <- model_grid.F90:644-1201,2188-2219,2450-2507 via llxy_module.F90:166-216 and
+!!                     module_map_utils.F90:1083-1233,1398-1428 (Lambert + lat-lon only)
+!! Reals are real(8) explicitly (the reference promotes with -r8 / -fdefault-real-8, CMakeLists.txt:80-82).
+
+module program_setup
+  implicit none
+  public
+  integer, parameter :: dp = kind(1.0d0)
+  real(dp), parameter :: NAN = 1.0e20_dp           ! misc_definitions_module.F90:12 ("unset" sentinel)
+  integer, parameter :: PROJ_LATLON = 0, PROJ_LC = 1  ! misc_definitions_module.F90:38-39
+  real(dp), parameter :: PI = 3.141592653589793_dp, RAD_PER_DEG = PI/180.0_dp, DEG_PER_RAD = 180.0_dp/PI
+  real(dp), parameter :: EARTH_RADIUS_M = 6370000.0_dp
+
+  character(len=500) :: grid_file_input_grid = "NULL", diag_file_input_grid = "NULL", hist_file_input_grid = "NULL"
+  character(len=500) :: file_target_grid = "NULL", output_file = "NULL", block_decomp_file = "NULL"
+  character(len=500) :: target_grid_type = "lambert"
+  logical :: interp_diag = .false., interp_hist = .false., wrf_mod_vars = .false., is_regional = .true.
+  logical :: interp_as_bundle = .true., esmf_log = .false.
+  integer :: i_target = 0, j_target = 0, proj_code = PROJ_LC
+  real(dp) :: truelat1 = NAN, truelat2 = NAN, stand_lon = NAN, ref_lat = NAN, ref_lon = NAN, ref_x = NAN, ref_y = NAN
+  real(dp) :: pole_lat = 90.0_dp, pole_lon = 0.0_dp
+  real(dp) :: dxkm, dykm, dlondeg, dlatdeg, known_lat, known_lon, known_x, known_y
+
+contains
+
+  subroutine fatal(msg, code)
+    character(len=*), intent(in) :: msg
+    integer, intent(in) :: code
+    print *, "- FATAL ERROR: "
+    write (*, '(A)') trim(msg)
+    print *, "- IOSTAT IS: ", code
+    error stop 999
+  end subroutine fatal
+
+  function upper(s) result(u)
+    character(len=*), intent(in) :: s
+    character(len=len(s)) :: u
+    integer :: i, c
+    u = s
+    do i = 1, len(s)
+      c = iachar(s(i:i))
+      if (c >= iachar('a') .and. c <= iachar('z')) u(i:i) = achar(c - 32)
+    end do
+  end function upper
+
+  subroutine read_setup_namelist(filename)
+    character(len=*), intent(in) :: filename
+    real(dp) :: dx, dy
+    integer :: nx, ny, ierr, u
+    character(len=500) :: kind
+    namelist /config/ grid_file_input_grid, diag_file_input_grid, hist_file_input_grid, file_target_grid, output_file, &
+      interp_diag, interp_hist, wrf_mod_vars, esmf_log, target_grid_type, nx, ny, dx, dy, ref_lat, ref_lon, ref_x, ref_y, &
+      truelat1, truelat2, stand_lon, is_regional, pole_lat, pole_lon, interp_as_bundle, block_decomp_file
+    dx = NAN; dy = NAN; nx = 0; ny = 0
+    open (newunit=u, file=trim(filename), status='old', iostat=ierr)
+    if (ierr /= 0) call fatal("OPENING SETUP NAMELIST.", ierr)
+    read (u, nml=config, iostat=ierr)
+    if (ierr /= 0) call fatal("READING SETUP NAMELIST.", ierr)
+    close (u)
+    kind = upper(trim(target_grid_type))
+    if (trim(kind) == 'FILE') call fatal("target_grid_type='file' needs NetCDF (not available in this build)", -1)
+    dxkm = dx; dykm = dy
+    known_lat = ref_lat; known_lon = ref_lon; known_x = ref_x; known_y = ref_y
+    i_target = nx - 1; j_target = ny - 1        ! namelist nx, ny are STAGGERED counts
+    if (trim(kind) == 'LAMBERT') then
+      proj_code = PROJ_LC
+      if (truelat2 == NAN) then
+        if (truelat1 == NAN) call fatal("No TRUELAT1 specified for Lambert conformal projection.", 3)
+        truelat2 = truelat1
+      end if
+    else if (trim(kind) == 'LAT-LON') then
+      proj_code = PROJ_LATLON
+      if (dx == NAN .and. dy == NAN) then
+        if (is_regional) call fatal("For lat-lon projection, if dx/dy are not specified a global grid is assumed.", 3)
+        dlondeg = 360.0_dp/i_target; dlatdeg = 180.0_dp/j_target
+        known_x = 1.0_dp; known_y = 1.0_dp
+        known_lon = stand_lon + dlondeg/2.0_dp; known_lat = -90.0_dp + dlatdeg/2.0_dp
+      else
+        if (.not. is_regional) call fatal("For lat-lon projection, if dx/dy are specified a regional grid is assumed.", 3)
+        dlatdeg = dy; dlondeg = dx
+        if (known_lat == NAN .or. known_lon == NAN) call fatal("lat-lon with dx/dy needs ref_lat, ref_lon", 3)
+      end if
+    else
+      call fatal('In namelist, invalid target_grid_type: this build supports "lambert" and "lat-lon".', 3)
+    end if
+    if (known_x == NAN .and. known_y == NAN) then
+      known_x = real(i_target + 1, dp)/2.0_dp; known_y = real(j_target + 1, dp)/2.0_dp
+    else if (known_x == NAN .or. known_y == NAN) then
+      call fatal("In namelist, neither or both of ref_x, ref_y must be specified.", 3)
+    end if
+  end subroutine read_setup_namelist
+end module program_setup
+
+!> Two-column variable lists (fixed names in the CWD: diaglist, histlist_2d, histlist_3d, histlist_soil).
+module varlists
+  use program_setup, only: fatal
+  implicit none
+  public
+contains
+  subroutine read_varlist(file, n, names, targets)
+    character(len=*), intent(in) :: file
+    integer, intent(out) :: n
+    character(len=50), allocatable, intent(out) :: names(:), targets(:)
+    integer :: u, istat, k
+    character(len=200) :: line
+    logical :: ex
+    inquire (file=trim(file), exist=ex)
+    if (.not. ex) call fatal("VARLIST FILE "//trim(file)//" not exist", 1)
+    open (newunit=u, file=trim(file), form='formatted', status='old', iostat=istat)
+    if (istat /= 0) call fatal("OPENING VARLIST FILE", istat)
+    n = 0
+    do
+      read (u, '(A)', iostat=istat) line
+      if (istat /= 0) exit
+      if (trim(line) == '') cycle
+      n = n + 1
+    end do
+    allocate (names(n), targets(n))
+    rewind (u)
+    k = 0
+    do while (k < n)
+      read (u, '(A)', iostat=istat) line
+      if (istat /= 0) call fatal("READING VARLIST FILE", istat)
+      if (trim(line) == '') cycle
+      k = k + 1
+      read (line, *, iostat=istat) names(k), targets(k)
+      if (istat /= 0) call fatal("READING VARLIST FILE", istat)
+    end do
+    close (u)
+  end subroutine read_varlist
+
+  logical function is_in(name, list)
+    character(len=*), intent(in) :: name, list(:)
+    integer :: i
+    is_in = .false.
+    do i = 1, size(list)
+      if (trim(name) == trim(list(i))) is_in = .true.
+    end do
+  end function is_in
+end module varlists
+
+!> Target-grid coordinates of the four staggers and the wind-rotation angle.
+module target_grid
+  use program_setup
+  implicit none
+  public
+  integer, parameter :: ST_M = 1, ST_U = 2, ST_V = 3, ST_CORNER = 6
+  real(dp) :: cone, polei, polej, rsw, rebydx, hemi
+  real(dp), allocatable :: lat_m(:, :), lon_m(:, :), lat_u(:, :), lon_u(:, :), lat_v(:, :), lon_v(:, :), lat_c(:, :), lon_c(:, :)
+  real(dp), allocatable :: cosa(:, :), sina(:, :)
+contains
+  subroutine set_projection()
+    real(dp) :: dl, arg, lon1, slon
+    if (proj_code /= PROJ_LC) return
+    hemi = 1.0_dp
+    if (truelat1 < 0.0_dp) hemi = -1.0_dp
+    rebydx = EARTH_RADIUS_M/dxkm
+    if (abs(truelat1 - truelat2) > 0.1_dp) then
+      cone = (log10(cos(truelat1*RAD_PER_DEG)) - log10(cos(truelat2*RAD_PER_DEG)))/ &
+             (log10(tan((45.0_dp - abs(truelat1)/2.0_dp)*RAD_PER_DEG)) - log10(tan((45.0_dp - abs(truelat2)/2.0_dp)*RAD_PER_DEG)))
+    else
+      cone = sin(abs(truelat1)*RAD_PER_DEG)
+    end if
+    lon1 = wrap180(known_lon); slon = wrap180(stand_lon)
+    dl = lon1 - slon
+    if (dl > 180.0_dp) dl = dl - 360.0_dp
+    if (dl < -180.0_dp) dl = dl + 360.0_dp
+    rsw = rebydx*cos(truelat1*RAD_PER_DEG)/cone* &
+          (tan((90.0_dp*hemi - known_lat)*RAD_PER_DEG/2.0_dp)/tan((90.0_dp*hemi - truelat1)*RAD_PER_DEG/2.0_dp))**cone
+    arg = cone*(dl*RAD_PER_DEG)
+    polei = hemi*known_x - hemi*rsw*sin(arg)
+    polej = hemi*known_y + rsw*cos(arg)
+  end subroutine set_projection
+
+  real(dp) function wrap180(x) result(y)
+    real(dp), intent(in) :: x
+    integer :: it
+    y = x
+    it = 0
+    do while (abs(y) > 180.0_dp .and. it < 10)
+      if (y < -180.0_dp) y = y + 360.0_dp
+      if (y > 180.0_dp) y = y - 360.0_dp
+      it = it + 1
+    end do
+  end function wrap180
+
+  subroutine ij_to_latlon(i, j, lat, lon)
+    real(dp), intent(in) :: i, j
+    real(dp), intent(out) :: lat, lon
+    real(dp) :: chi1, chi2, chi, xx, yy, r2, r, iw, span
+    if (proj_code == PROJ_LC) then
+      chi1 = (90.0_dp - hemi*truelat1)*RAD_PER_DEG
+      chi2 = (90.0_dp - hemi*truelat2)*RAD_PER_DEG
+      xx = hemi*i - polei
+      yy = polej - hemi*j
+      r2 = xx*xx + yy*yy
+      r = sqrt(r2)/rebydx
+      if (r2 == 0.0_dp) then
+        lat = hemi*90.0_dp; lon = wrap180(stand_lon)
+      else
+        lon = wrap180(stand_lon) + DEG_PER_RAD*atan2(hemi*xx, yy)/cone
+        lon = mod(lon + 360.0_dp, 360.0_dp)
+        if (chi1 == chi2) then
+          chi = 2.0_dp*atan((r/tan(chi1))**(1.0_dp/cone)*tan(chi1*0.5_dp))
+        else
+          chi = 2.0_dp*atan((r*cone/sin(chi1))**(1.0_dp/cone)*tan(chi1*0.5_dp))
+        end if
+        lat = (90.0_dp - chi*DEG_PER_RAD)*hemi
+      end if
+      if (lon > 180.0_dp) lon = lon - 360.0_dp
+      if (lon < -180.0_dp) lon = lon + 360.0_dp
+    else
+      span = real(nint(360.0_dp/dlondeg), dp)
+      iw = i
+      if (i < 0.5_dp) iw = i + span
+      if (i >= span + 0.5_dp) iw = i - span
+      lat = known_lat + (j - known_y)*dlatdeg
+      lon = wrap180(known_lon) + (iw - known_x)*dlondeg
+    end if
+  end subroutine ij_to_latlon
+
+  subroutine stagger_fields(ni, nj, stagger, lat, lon)
+    integer, intent(in) :: ni, nj, stagger
+    real(dp), allocatable, intent(out) :: lat(:, :), lon(:, :)
+    integer :: i, j
+    real(dp) :: x, y
+    allocate (lat(ni, nj), lon(ni, nj))
+    do j = 1, nj
+      do i = 1, ni
+        x = real(i, dp); y = real(j, dp)
+        if (stagger == ST_U) x = x - 0.5_dp
+        if (stagger == ST_V) y = y - 0.5_dp
+        if (stagger == ST_CORNER) then
+          x = x - 0.5_dp; y = y - 0.5_dp
+        end if
+        call ij_to_latlon(x, y, lat(i, j), lon(i, j))
+      end do
+    end do
+  end subroutine stagger_fields
+
+  subroutine define_target_grid_params()
+    integer :: i, j, jm, jp
+    real(dp) :: d_lon, alpha
+    call set_projection()
+    call stagger_fields(i_target, j_target, ST_M, lat_m, lon_m)
+    call stagger_fields(i_target, j_target + 1, ST_V, lat_v, lon_v)
+    call stagger_fields(i_target + 1, j_target, ST_U, lat_u, lon_u)
+    call stagger_fields(i_target + 1, j_target + 1, ST_CORNER, lat_c, lon_c)
+    if (proj_code == PROJ_LC) then
+      allocate (cosa(i_target, j_target), sina(i_target, j_target))
+      do j = 1, j_target
+        jm = max(j - 1, 1); jp = min(j + 1, j_target)
+        do i = 1, i_target
+          d_lon = lon_m(i, jp) - lon_m(i, jm)
+          if (d_lon > 180.0_dp) then
+            d_lon = d_lon - 360.0_dp
+          else if (d_lon < -180.0_dp) then
+            d_lon = d_lon + 360.0_dp
+          end if
+          alpha = atan2(-cos(lat_m(i, j)*RAD_PER_DEG)*(d_lon*RAD_PER_DEG), (lat_m(i, jp) - lat_m(i, jm))*RAD_PER_DEG)
+          sina(i, j) = sin(alpha); cosa(i, j) = cos(alpha)
+        end do
+      end do
+    end if
+  end subroutine define_target_grid_params
+end module target_grid
+
+!> Raw-binary named-array container ("MPGRAW1"), the NetCDF stand-in of this build.
+!! record = name(32 chars) | dtype int32 (0 = float64, 1 = int32) | ndim int32 | dims 3 x int64 (fastest first) | data
+module rawio
+  use, intrinsic :: iso_fortran_env, only: int32, int64, real64
+  use program_setup, only: fatal
+  implicit none
+  public
+contains
+  !> Positions the unit at the data of `name`; returns dims (unused = 1); found = .false. if absent.
+  subroutine raw_seek(u, name, dtype, ndim, dims, found)
+    integer, intent(in) :: u
+    character(len=*), intent(in) :: name
+    integer(int32), intent(out) :: dtype, ndim
+    integer(int64), intent(out) :: dims(3)
+    logical, intent(out) :: found
+    character(len=8) :: magic
+    character(len=32) :: nm
+    integer(int64) :: pos, nbytes
+    integer :: ios
+    found = .false.
+    read (u, pos=1, iostat=ios) magic
+    if (ios /= 0 .or. magic /= 'MPGRAW1 ') call fatal("not an MPGRAW1 file", ios)
+    pos = 9
+    do
+      read (u, pos=pos, iostat=ios) nm, dtype, ndim, dims
+      if (ios /= 0) return
+      pos = pos + 32 + 4 + 4 + 24
+      nbytes = dims(1)*dims(2)*dims(3)*merge(8_int64, 4_int64, dtype == 0)
+      if (trim(nm) == trim(name)) then
+        read (u, pos=pos - 1, iostat=ios) magic(1:1)   ! leave the unit positioned right before the data
+        found = .true.
+        return
+      end if
+      pos = pos + nbytes
+    end do
+  end subroutine raw_seek
+
+  subroutine raw_open_read(file, u)
+    character(len=*), intent(in) :: file
+    integer, intent(out) :: u
+    integer :: ios
+    open (newunit=u, file=trim(file), access='stream', form='unformatted', status='old', action='read', iostat=ios)
+    if (ios /= 0) call fatal("OPENING INPUT FILE "//trim(file), ios)
+  end subroutine raw_open_read
+
+  subroutine raw_open_write(file, u)
+    character(len=*), intent(in) :: file
+    integer, intent(out) :: u
+    integer :: ios
+    open (newunit=u, file=trim(file), access='stream', form='unformatted', status='replace', action='write', iostat=ios)
+    if (ios /= 0) call fatal("CREATING OUTPUT FILE "//trim(file), ios)
+    write (u) 'MPGRAW1 '
+  end subroutine raw_open_write
+
+  subroutine raw_write_f64(u, name, ndim, dims, data)
+    integer, intent(in) :: u, ndim
+    character(len=*), intent(in) :: name
+    integer(int64), intent(in) :: dims(3)
+    real(real64), intent(in) :: data(*)
+    character(len=32) :: nm
+    nm = name
+    write (u) nm, 0_int32, int(ndim, int32), dims
+    write (u) data(1:dims(1)*dims(2)*dims(3))
+  end subroutine raw_write_f64
+end module rawio

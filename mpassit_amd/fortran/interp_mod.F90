@@ -1,0 +1,171 @@
+!> Fortran mirror of the reference's `interp` module (interp.F90:92-749) on top of the HIP C-ABI.
+!! Same public entry point (interp_data), same order of operations and method fall-through; every ESMF
+!! Store/Regrid/Release becomes the mpg_* call named in mpg_mod.F90.  Field containers replace the ESMF
+!! field bundles of model_grid.F90:154-237.
+module model_data
+  use, intrinsic :: iso_c_binding
+  use program_setup, only: dp
+  implicit none
+  public
+  type field_t
+    character(len=50) :: name = "", tname = ""
+    integer :: nlev = 1
+    integer :: stagger = 0                      ! MPG_STAGGERLOC_* of the destination
+    real(dp), allocatable :: src(:)             ! MPAS file order: (nlev, nCells) level-fastest, or (nCells) for 2-D
+    real(dp), allocatable :: dst(:)             ! (nx, ny, nlev) i-fastest
+  end type field_t
+  type bundle_t
+    integer :: n = 0
+    type(field_t), allocatable :: f(:)
+  end type bundle_t
+
+  type(c_ptr) :: input_grid = c_null_ptr, target_grid_h = c_null_ptr   ! ESMF_Mesh / ESMF_Grid stand-ins
+  integer :: nCells_input = 0, nVert_input = 0, maxEdges_input = 0, nz_input = 0, nzp1_input = 0, nsoil_input = 0
+  type(bundle_t) :: diag_bundle, hist_2d_patch, hist_2d_cons, hist_2d_nstd, hist_3d_nz, hist_3d_nzp1, hist_soil
+  type(field_t) :: hgt, u_field, v_field, umass, vmass
+  integer :: do_u_interp = 0, do_v_interp = 0, u10_ind = 0, v10_ind = 0
+end module model_data
+
+module interp
+  use, intrinsic :: iso_c_binding
+  use mpg
+  use model_data
+  use program_setup, only: dp, interp_diag, interp_hist, proj_code, PROJ_LC, i_target, j_target
+  use target_grid, only: cosa, sina
+  implicit none
+  private
+  public :: interp_data
+
+contains
+
+  subroutine interp_data()
+    if (interp_diag) call interp_diag_data()
+    if (interp_hist) call interp_hist_data()
+  end subroutine interp_data
+
+  !> ESMF_FieldBundleRegrid: every field of the bundle through one route handle.
+  !! 3-D sources arrive in MPAS file order (level fastest): the GPU kernel fuses the transpose the reference
+  !! does on the host (input_data.F90:653-655).
+  subroutine regrid_bundle(rh, b)
+    type(c_ptr), intent(in) :: rh
+    type(bundle_t), intent(inout) :: b
+    integer :: i
+    do i = 1, b%n
+      call regrid_field(rh, b%f(i))
+    end do
+  end subroutine regrid_bundle
+
+  subroutine regrid_field(rh, f)
+    type(c_ptr), intent(in) :: rh
+    type(field_t), intent(inout) :: f
+    integer(c_int64_t) :: n_src, n_dst, nnz
+    integer(c_int) :: nxd, nyd, npr, layout
+    call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+    if (allocated(f%dst)) deallocate (f%dst)
+    allocate (f%dst(n_dst*f%nlev))
+    layout = MPG_LAYOUT_LEV_FAST
+    if (f%nlev == 1) layout = MPG_LAYOUT_CELL_FAST
+    call mpg_check(mpg_regrid(rh, f%src, layout, int(f%nlev, c_int), 1_c_int, f%dst), "IN FieldRegrid "//trim(f%name))
+  end subroutine regrid_field
+
+  subroutine interp_diag_data()
+    type(c_ptr) :: rh_patch
+    print *, "- CREATE DIAG BUNDLE REGRID ROUTEHANDLE"
+    call mpg_check(mpg_regrid_store(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, &
+                                    MPG_REGRIDMETHOD_BILINEAR, rh_patch), "IN FieldBundleRegridStore")
+    print *, "- REGRID DIAG FIELDS "
+    call regrid_bundle(rh_patch, diag_bundle)
+    call mpg_check(mpg_handle_release(rh_patch), "IN FieldRegridRelease")
+    if (u10_ind > 0 .and. v10_ind > 0 .and. proj_code == PROJ_LC) then
+      call rotate_winds_cgrid(diag_bundle%f(u10_ind), diag_bundle%f(v10_ind))
+    end if
+  end subroutine interp_diag_data
+
+  subroutine interp_hist_data()
+    type(c_ptr) :: rh_patch, rh_cons, rh_nstd, rh_stag, rh_soil
+    integer(c_int) :: method
+    logical :: have_cons, have_nstd
+    ! the reference leaves `method` undefined when no 2-D bilinear field is listed (interp.F90:203-204,
+    ! SURVEY App. C2); it is always BILINEAR here
+    method = MPG_REGRIDMETHOD_BILINEAR
+    print *, "- CREATE HIST BUNDLE PATCH REGRID ROUTEHANDLE"
+    call mpg_check(mpg_regrid_store(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, method, rh_patch), &
+                   "IN FieldBundleRegridStore")
+    if (hist_2d_patch%n > 0) call regrid_bundle(rh_patch, hist_2d_patch)
+    print *, "- PATCH REGRID HGT FIELD "
+    call regrid_field(rh_patch, hgt)
+    if (hist_3d_nz%n > 0) call regrid_bundle(rh_patch, hist_3d_nz)
+    if (do_u_interp == 1) call regrid_to(rh_patch, u_field, umass)
+    if (do_v_interp == 1) call regrid_to(rh_patch, v_field, vmass)
+    if (do_u_interp == 1 .and. do_v_interp == 1 .and. proj_code == PROJ_LC) call rotate_winds_cgrid(umass, vmass)
+    if (do_u_interp == 1) then          ! UMASS(CENTER) -> U(EDGE1), interp.F90:295-311
+      call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, method, rh_stag), &
+                     "IN FieldRegridStore")
+      call destagger(rh_stag, umass, u_field)
+      call mpg_check(mpg_handle_release(rh_stag), "IN FieldRegridRelease")
+    end if
+    if (do_v_interp == 1) then          ! VMASS(CENTER) -> V(EDGE2), interp.F90:313-328
+      call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE2, method, rh_stag), &
+                     "IN FieldRegridStore")
+      call destagger(rh_stag, vmass, v_field)
+      call mpg_check(mpg_handle_release(rh_stag), "IN FieldRegridRelease")
+    end if
+    if (hist_3d_nzp1%n > 0) call regrid_bundle(rh_patch, hist_3d_nzp1)
+    rh_soil = rh_patch
+    have_cons = hist_2d_cons%n > 0
+    have_nstd = hist_2d_nstd%n > 0
+    if (have_cons) then
+      print *, "- CREATE HIST BUNDLE CONSERVATIVE REGRID ROUTEHANDLE"
+      method = MPG_REGRIDMETHOD_CONSERVE
+      call mpg_check(mpg_regrid_store(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, method, rh_cons), &
+                     "IN FieldBundleRegridStore")
+      call regrid_bundle(rh_cons, hist_2d_cons)
+      rh_soil = rh_cons
+    end if
+    if (have_nstd) then
+      print *, "- CREATE HIST BUNDLE NSTD REGRID ROUTEHANDLE"
+      method = MPG_REGRIDMETHOD_NEAREST_STOD
+      call mpg_check(mpg_regrid_store(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, method, rh_nstd), &
+                     "IN FieldBundleRegridStore")
+      call regrid_bundle(rh_nstd, hist_2d_nstd)
+      rh_soil = rh_nstd
+    end if
+    ! soil: "whatever method is current" (interp.F90:436-447, SURVEY App. C3)
+    if (hist_soil%n > 0) call regrid_bundle(rh_soil, hist_soil)
+    print *, "- CALL FieldRegridRelease."
+    call mpg_check(mpg_handle_release(rh_patch), "IN FieldRegridRelease")
+    if (have_cons) call mpg_check(mpg_handle_release(rh_cons), "IN FieldRegridRelease")
+    if (have_nstd) call mpg_check(mpg_handle_release(rh_nstd), "IN FieldRegridRelease")
+  end subroutine interp_hist_data
+
+  !> mesh field `src` -> CENTER-stagger field `dst` (uReconstructZonal -> UMASS, interp.F90:256-289)
+  subroutine regrid_to(rh, src, dst)
+    type(c_ptr), intent(in) :: rh
+    type(field_t), intent(inout) :: src
+    type(field_t), intent(inout) :: dst
+    call regrid_field(rh, src)
+    dst%nlev = src%nlev
+    call move_alloc(src%dst, dst%dst)
+  end subroutine regrid_to
+
+  !> CENTER-stagger field -> EDGE stagger field through a Grid->Grid handle
+  subroutine destagger(rh, mass, stag)
+    type(c_ptr), intent(in) :: rh
+    type(field_t), intent(in) :: mass
+    type(field_t), intent(inout) :: stag
+    integer(c_int64_t) :: n_src, n_dst, nnz
+    integer(c_int) :: nxd, nyd, npr
+    call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+    if (allocated(stag%dst)) deallocate (stag%dst)
+    allocate (stag%dst(n_dst*mass%nlev))
+    call mpg_check(mpg_regrid(rh, mass%dst, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, stag%dst), "IN FieldRegrid")
+  end subroutine destagger
+
+  !> rotate_winds_cgrid (interp.F90:689-749) on the device
+  subroutine rotate_winds_cgrid(u, v)
+    type(field_t), intent(inout) :: u, v
+    call mpg_check(mpg_rotate_winds(int(i_target, c_int64_t)*int(j_target, c_int64_t), int(u%nlev, c_int), cosa, sina, u%dst, v%dst), &
+                   "IN rotate_winds_cgrid")
+  end subroutine rotate_winds_cgrid
+
+end module interp

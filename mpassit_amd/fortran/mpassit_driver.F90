@@ -1,0 +1,228 @@
+!> Thin Fortran driver with the reference's user surface (mpassit.F90:22-146): `mpassit <namelist>`
+!! (default fort.41), &config namelist, diaglist / histlist_2d / histlist_3d / histlist_soil in the CWD.
+!! Phases in the reference's order (mpassit.F90:105-137): namelist -> target grid -> input grid ->
+!! input data -> interp_data (HIP, through the C-ABI) -> write.  No MPI/ESMF: one process drives one GPU.
+!! File I/O uses the MPGRAW1 raw container because the image has no NetCDF (I/O is out of the hot path).
+program mpassit
+  use, intrinsic :: iso_c_binding
+  use, intrinsic :: iso_fortran_env, only: int32, int64
+  use mpg
+  use program_setup
+  use varlists
+  use target_grid
+  use rawio
+  use model_data
+  use interp
+  implicit none
+  character(len=500) :: nml_file
+  integer :: nargs
+
+  nargs = command_argument_count()
+  if (nargs >= 1) then
+    call get_command_argument(1, nml_file)
+  else
+    nml_file = "./fort.41"
+  end if
+  print *, "- READ SETUP NAMELIST"
+  call read_setup_namelist(trim(nml_file))
+  call mpg_check(mpg_init(0_c_int), "INITIALIZING GPU RUNTIME")
+  print *, "- DEFINE TARGET GRID"
+  call define_target_grid()
+  print *, "- DEFINE INPUT GRID"
+  call define_input_grid()
+  print *, "- READ INPUT DATA"
+  call read_input_data()
+  print *, "- INTERPOLATE DATA"
+  call interp_data()
+  print *, "- WRITE DATA"
+  call write_to_file()
+  call mpg_check(mpg_mesh_destroy(input_grid), "IN MeshDestroy")
+  call mpg_check(mpg_grid_destroy(target_grid_h), "IN GridDestroy")
+  call mpg_check(mpg_finalize(), "IN Finalize")
+  print *, "- DONE."
+
+contains
+
+  subroutine define_target_grid()
+    integer(c_int) :: periodic
+    call define_target_grid_params()
+    periodic = 0
+    if (.not. is_regional) periodic = 1
+    call mpg_check(mpg_grid_create(int(i_target, c_int), int(j_target, c_int), periodic, lon_m, lat_m, lon_c, lat_c, &
+                                   lon_u, lat_u, lon_v, lat_v, target_grid_h), "IN GridCreate")
+  end subroutine define_target_grid
+
+  subroutine read_f64(u, name, arr, dims, required)
+    integer, intent(in) :: u
+    character(len=*), intent(in) :: name
+    real(dp), allocatable, intent(out) :: arr(:)
+    integer(int64), intent(out) :: dims(3)
+    logical, intent(in) :: required
+    integer(int32) :: dtype, ndim
+    logical :: found
+    integer :: ios
+    call raw_seek(u, name, dtype, ndim, dims, found)
+    if (.not. found) then
+      if (required) call fatal("reading field id - "//trim(name), -1)
+      return
+    end if
+    if (dtype /= 0) call fatal("field "//trim(name)//" is not float64", -1)
+    allocate (arr(dims(1)*dims(2)*dims(3)))
+    read (u, iostat=ios) arr
+    if (ios /= 0) call fatal("reading field "//trim(name), ios)
+  end subroutine read_f64
+
+  subroutine define_input_grid()
+    integer :: u, ios
+    integer(int32) :: dtype, ndim
+    integer(int64) :: dims(3)
+    logical :: found
+    real(dp), allocatable :: latCell(:), lonCell(:), latVertex(:), lonVertex(:)
+    integer(c_int32_t), allocatable :: voc(:)
+    call raw_open_read(grid_file_input_grid, u)
+    call read_f64(u, "latCell", latCell, dims, .true.)
+    nCells_input = int(dims(1))
+    call read_f64(u, "lonCell", lonCell, dims, .true.)
+    call read_f64(u, "latVertex", latVertex, dims, .true.)
+    nVert_input = int(dims(1))
+    call read_f64(u, "lonVertex", lonVertex, dims, .true.)
+    call raw_seek(u, "verticesOnCell", dtype, ndim, dims, found)
+    if (.not. found .or. dtype /= 1) call fatal("reading verticesOnCell", -1)
+    maxEdges_input = int(dims(1))
+    allocate (voc(dims(1)*dims(2)))
+    read (u, iostat=ios) voc
+    if (ios /= 0) call fatal("reading verticesOnCell", ios)
+    call read_f64(u, "ter", hgt%src, dims, .true.)
+    hgt%name = "ter"; hgt%tname = "HGT"; hgt%nlev = 1
+    close (u)
+    print *, "- NUMBER OF CELLS ON INPUT GRID ", nCells_input
+    print *, "- NUMBER OF NODES ON INPUT GRID ", nVert_input
+    print *, "- CREATE MESH -"
+    call mpg_check(mpg_mesh_create(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &
+                                   latCell, lonCell, latVertex, lonVertex, voc, input_grid), "IN MeshCreate")
+  end subroutine define_input_grid
+
+  subroutine load_field(u, name, tname, f)
+    integer, intent(in) :: u
+    character(len=*), intent(in) :: name, tname
+    type(field_t), intent(out) :: f
+    integer(int64) :: dims(3)
+    f%name = name; f%tname = tname
+    call read_f64(u, name, f%src, dims, .true.)
+    if (dims(2) == 1) then
+      f%nlev = 1                 ! [nCells]
+    else
+      f%nlev = int(dims(1))      ! [nCells][nlev] in the file == Fortran (nlev, nCells)
+    end if
+  end subroutine load_field
+
+  subroutine append(b, f)
+    type(bundle_t), intent(inout) :: b
+    type(field_t), intent(in) :: f
+    type(field_t), allocatable :: tmp(:)
+    allocate (tmp(b%n + 1))
+    if (b%n > 0) tmp(1:b%n) = b%f(1:b%n)
+    tmp(b%n + 1) = f
+    call move_alloc(tmp, b%f)
+    b%n = b%n + 1
+  end subroutine append
+
+  subroutine read_input_data()
+    character(len=50), allocatable :: names(:), targets(:)
+    character(len=50) :: cons_vars(2), nstd_vars(4), nzp1_vars(2)
+    type(field_t) :: f
+    integer :: n, i, u
+    cons_vars = [character(len=50) :: 'snow', 'snowh']                       ! input_data.F90:840-842
+    nstd_vars = [character(len=50) :: 'ivgtyp', 'isltyp', 'xland', 'landmask']
+    nzp1_vars = [character(len=50) :: 'zgrid', 'w']
+    if (interp_diag) then
+      call read_varlist('diaglist', n, names, targets)
+      call raw_open_read(diag_file_input_grid, u)
+      do i = 1, n
+        call load_field(u, names(i), targets(i), f)
+        call append(diag_bundle, f)
+        if (trim(names(i)) == 'u10') u10_ind = i
+        if (trim(names(i)) == 'v10') v10_ind = i
+      end do
+      close (u)
+    end if
+    if (interp_hist) then
+      call raw_open_read(hist_file_input_grid, u)
+      call read_varlist('histlist_2d', n, names, targets)
+      do i = 1, n
+        call load_field(u, names(i), targets(i), f)
+        if (is_in(names(i), cons_vars)) then
+          call append(hist_2d_cons, f)
+        else if (is_in(names(i), nstd_vars)) then
+          call append(hist_2d_nstd, f)
+        else
+          call append(hist_2d_patch, f)
+        end if
+      end do
+      call read_varlist('histlist_3d', n, names, targets)
+      do i = 1, n
+        call load_field(u, names(i), targets(i), f)
+        if (wrf_mod_vars .and. trim(names(i)) == 'uReconstructZonal') then
+          do_u_interp = 1; u_field = f; umass%name = 'UMASS'; umass%tname = 'UMASS'
+        else if (wrf_mod_vars .and. trim(names(i)) == 'uReconstructMeridional') then
+          do_v_interp = 1; v_field = f; vmass%name = 'VMASS'; vmass%tname = 'VMASS'
+        else if (is_in(names(i), nzp1_vars)) then
+          call append(hist_3d_nzp1, f)
+        else if (trim(names(i)) == 'vorticity') then
+          call fatal("node-located bilinear (vorticity) is not supported by this build", -1)
+        else
+          call append(hist_3d_nz, f)
+        end if
+      end do
+      call read_varlist('histlist_soil', n, names, targets)
+      do i = 1, n
+        call load_field(u, names(i), targets(i), f)
+        call append(hist_soil, f)
+      end do
+      close (u)
+    end if
+  end subroutine read_input_data
+
+  subroutine put(u, f, ni, nj)
+    integer, intent(in) :: u, ni, nj
+    type(field_t), intent(in) :: f
+    integer(int64) :: dims(3)
+    if (.not. allocated(f%dst)) return
+    dims = [int(ni, int64), int(nj, int64), int(f%nlev, int64)]
+    call raw_write_f64(u, trim(f%tname), merge(2, 3, f%nlev == 1), dims, f%dst)
+  end subroutine put
+
+  subroutine put_bundle(u, b)
+    integer, intent(in) :: u
+    type(bundle_t), intent(in) :: b
+    integer :: i
+    do i = 1, b%n
+      call put(u, b%f(i), i_target, j_target)
+    end do
+  end subroutine put_bundle
+
+  subroutine write_to_file()
+    integer :: u
+    call raw_open_write(output_file, u)
+    if (interp_diag) call put_bundle(u, diag_bundle)
+    if (interp_hist) then
+      call put(u, hgt, i_target, j_target)
+      call put_bundle(u, hist_2d_patch)
+      call put_bundle(u, hist_2d_cons)
+      call put_bundle(u, hist_2d_nstd)
+      call put_bundle(u, hist_3d_nz)
+      call put_bundle(u, hist_3d_nzp1)
+      call put_bundle(u, hist_soil)
+      if (do_u_interp == 1) then
+        call put(u, umass, i_target, j_target)
+        call put(u, u_field, i_target + 1, j_target)
+      end if
+      if (do_v_interp == 1) then
+        call put(u, vmass, i_target, j_target)
+        call put(u, v_field, i_target, j_target + 1)
+      end if
+    end if
+    close (u)
+  end subroutine write_to_file
+
+end program mpassit

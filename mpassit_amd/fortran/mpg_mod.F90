@@ -1,0 +1,159 @@
+!> ISO_C_BINDING interface to libmpassit_amd.so (include/mpassit_amd.h) -- the thin Fortran<->HIP boundary
+!! named by BASELINE.json's north_star.  Each interface replaces one ESMF verb of the reference:
+!!   mpg_init / mpg_finalize       ESMF_Initialize / ESMF_Finalize          mpassit.F90:84,140
+!!   mpg_mesh_create               ESMF_MeshCreate                          model_grid.F90:488-497
+!!   mpg_grid_create               ESMF_GridCreate* + ESMF_GridAddCoord     model_grid.F90:684-728,736-1038
+!!   mpg_regrid_store[_grid]       ESMF_Field[Bundle]RegridStore            interp.F90:123,207,...,437
+!!   mpg_regrid                    ESMF_Field[Bundle]Regrid                 interp.F90:134,219,...,443
+!!   mpg_handle_release            ESMF_FieldBundleRegridRelease            interp.F90:450-463
+!!   mpg_rotate_winds              rotate_winds_cgrid                       interp.F90:689-749
+!! Array conventions line up with the reference without any transposition:
+!!   Fortran verticesOnCell(maxEdges,nCells) == C [nCells][maxEdges];  field(nCells,nz) == C [nz][nCells]
+!!   (cell-fastest, input_data.F90:653-655);  target lat(i,j) == C [ny][nx];  dst(i,j,k) == C [nz][ny][nx].
+module mpg
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  integer(c_int), parameter :: MPG_SUCCESS = 0
+  integer(c_int), parameter :: MPG_REGRIDMETHOD_BILINEAR = 0, MPG_REGRIDMETHOD_CONSERVE = 1, MPG_REGRIDMETHOD_NEAREST_STOD = 2
+  integer(c_int), parameter :: MPG_MESHLOC_ELEMENT = 0, MPG_MESHLOC_NODE = 1
+  integer(c_int), parameter :: MPG_STAGGERLOC_CENTER = 0, MPG_STAGGERLOC_EDGE1 = 1, MPG_STAGGERLOC_EDGE2 = 2, &
+                               MPG_STAGGERLOC_CORNER = 3
+  integer(c_int), parameter :: MPG_LAYOUT_CELL_FAST = 0, MPG_LAYOUT_LEV_FAST = 1
+
+  interface
+    function mpg_init(device) bind(C, name="mpg_init") result(rc)
+      import :: c_int
+      integer(c_int), value :: device
+      integer(c_int) :: rc
+    end function mpg_init
+
+    function mpg_finalize() bind(C, name="mpg_finalize") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function mpg_finalize
+
+    function mpg_last_error_c() bind(C, name="mpg_last_error") result(p)
+      import :: c_ptr
+      type(c_ptr) :: p
+    end function mpg_last_error_c
+
+    function mpg_mesh_create(nCells, nVertices, maxEdges, latCell, lonCell, latVertex, lonVertex, verticesOnCell, mesh) &
+        bind(C, name="mpg_mesh_create") result(rc)
+      import :: c_int, c_int64_t, c_int32_t, c_double, c_ptr
+      integer(c_int64_t), value :: nCells, nVertices
+      integer(c_int), value :: maxEdges
+      real(c_double), intent(in) :: latCell(*), lonCell(*), latVertex(*), lonVertex(*)
+      integer(c_int32_t), intent(in) :: verticesOnCell(*)
+      type(c_ptr), intent(out) :: mesh
+      integer(c_int) :: rc
+    end function mpg_mesh_create
+
+    function mpg_mesh_destroy(mesh) bind(C, name="mpg_mesh_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mesh
+      integer(c_int) :: rc
+    end function mpg_mesh_destroy
+
+    function mpg_grid_create(nx, ny, periodic_i, lon_center, lat_center, lon_corner, lat_corner, lon_edge1, lat_edge1, &
+                             lon_edge2, lat_edge2, grid) bind(C, name="mpg_grid_create") result(rc)
+      import :: c_int, c_double, c_ptr
+      integer(c_int), value :: nx, ny, periodic_i
+      real(c_double), intent(in) :: lon_center(*), lat_center(*), lon_corner(*), lat_corner(*)
+      real(c_double), intent(in) :: lon_edge1(*), lat_edge1(*), lon_edge2(*), lat_edge2(*)
+      type(c_ptr), intent(out) :: grid
+      integer(c_int) :: rc
+    end function mpg_grid_create
+
+    function mpg_grid_destroy(grid) bind(C, name="mpg_grid_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: grid
+      integer(c_int) :: rc
+    end function mpg_grid_destroy
+
+    function mpg_regrid_store(src, src_meshloc, dst, dst_staggerloc, regridmethod, rh) &
+        bind(C, name="mpg_regrid_store") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: src, dst
+      integer(c_int), value :: src_meshloc, dst_staggerloc, regridmethod
+      type(c_ptr), intent(out) :: rh
+      integer(c_int) :: rc
+    end function mpg_regrid_store
+
+    function mpg_regrid_store_grid(grid, src_staggerloc, dst_staggerloc, regridmethod, rh) &
+        bind(C, name="mpg_regrid_store_grid") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: grid
+      integer(c_int), value :: src_staggerloc, dst_staggerloc, regridmethod
+      type(c_ptr), intent(out) :: rh
+      integer(c_int) :: rc
+    end function mpg_regrid_store_grid
+
+    function mpg_regrid(rh, src, src_layout, nlev, nfields, dst) bind(C, name="mpg_regrid") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: rh
+      real(c_double), intent(in) :: src(*)
+      integer(c_int), value :: src_layout, nlev, nfields
+      real(c_double), intent(inout) :: dst(*)
+      integer(c_int) :: rc
+    end function mpg_regrid
+
+    function mpg_handle_release(rh) bind(C, name="mpg_handle_release") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: rh
+      integer(c_int) :: rc
+    end function mpg_handle_release
+
+    function mpg_rotate_winds(npts, nlev, cosa, sina, u, v) bind(C, name="mpg_rotate_winds") result(rc)
+      import :: c_int, c_int64_t, c_double
+      integer(c_int64_t), value :: npts
+      integer(c_int), value :: nlev
+      real(c_double), intent(in) :: cosa(*), sina(*)
+      real(c_double), intent(inout) :: u(*), v(*)
+      integer(c_int) :: rc
+    end function mpg_rotate_winds
+
+    function mpg_handle_info(rh, n_src, n_dst, nx_dst, ny_dst, nnz_per_row, nnz) bind(C, name="mpg_handle_info") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: rh
+      integer(c_int64_t), intent(out) :: n_src, n_dst, nnz
+      integer(c_int), intent(out) :: nx_dst, ny_dst, nnz_per_row
+      integer(c_int) :: rc
+    end function mpg_handle_info
+  end interface
+
+contains
+
+  !> Message of the last failing call (mpg_last_error).
+  function mpg_last_error() result(msg)
+    character(len=:), allocatable :: msg
+    character(kind=c_char), pointer :: s(:)
+    type(c_ptr) :: p
+    integer :: n
+    p = mpg_last_error_c()
+    msg = ""
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [1024])
+    n = 0
+    do while (n < 1024)
+      if (s(n + 1) == c_null_char) exit
+      n = n + 1
+    end do
+    allocate (character(len=n) :: msg)
+    if (n > 0) msg = transfer(s(1:n), msg)
+  end function mpg_last_error
+
+  !> Same contract as the reference's error_handler (utils.F90:16-33): print and abort with code 999 on any
+  !! non-zero rc -- every ESMF rc in interp.F90 is checked this way (e.g. :130-131).
+  subroutine mpg_check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    if (rc == MPG_SUCCESS) return
+    print *, "- FATAL ERROR: "
+    write (*, '(A)') trim(where)//": "//mpg_last_error()
+    print *, "- IOSTAT IS: ", rc
+    error stop 999
+  end subroutine mpg_check
+
+end module mpg
