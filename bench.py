@@ -69,11 +69,17 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("MPASSIT_DIST_BACKEND", "nccl")  # "gloo" = rehearsal on fewer GPUs than ranks
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def all_gather_object(obj):
         if world == 1:
@@ -83,7 +89,7 @@ def main():
         return out
 
     from mpassit_amd import _lib, dist as mdist, regrid as R, workloads
-    _lib.init(local_rank)
+    _lib.init(dev_index)
     arch, n_cu, hbm = _lib.device_info()
 
     t0 = time.time()
@@ -110,17 +116,47 @@ def main():
     torch.cuda.synchronize()
 
     ev = []
+    # N > 1: the halo exchange of batch s+1 runs on its own stream while batch s is regridded (two source buffers);
+    # every step still performs exactly one exchange and one Regrid.
+    pipe = None
+    if world > 1:
+        local2 = local.clone()
+        bufs = [local, local2]
+        owns = [own, sr.own_view(local2)] if sr.sched.mode == "range" else [own, own]
+        halo_stream = torch.cuda.Stream(device=dev)
+        pipe = {"n": 0, "halo_done": [None, None], "comp_done": [None, None]}
+
+        def exchange_into(b):
+            with torch.cuda.stream(halo_stream):
+                if pipe["comp_done"][b] is not None:
+                    halo_stream.wait_event(pipe["comp_done"][b])   # the Regrid that last read this buffer
+                sr.sched.exchange(owns[b], bufs[b], pack_fn=sr._pack)
+                e = torch.cuda.Event()
+                e.record(halo_stream)
+                pipe["halo_done"][b] = e
+        halo_stream.wait_stream(torch.cuda.current_stream())
+        exchange_into(0)
 
     def one_step(record):
         if world > 1:
-            sr.sched.exchange(own, local, pack_fn=sr._pack)
+            b = pipe["n"] % 2
+            exchange_into(1 - b)                                   # next batch's halo, overlapped
+            torch.cuda.current_stream().wait_event(pipe["halo_done"][b])
+            src_t = bufs[b]
+        else:
+            src_t = src_for_kernel
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        sr.rh.regrid(src_for_kernel.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+        sr.rh.regrid(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
         if record:
             e1.record()
             ev.append((e0, e1))
+        if world > 1:
+            e = torch.cuda.Event()
+            e.record()
+            pipe["comp_done"][b] = e
+            pipe["n"] += 1
 
     if args.calib:  # 1 GiB read / 1 GiB write, 8 B per lane fully coalesced: calibrates FETCH_SIZE / WRITE_SIZE
         n_cal = 1 << 27
@@ -148,7 +184,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")

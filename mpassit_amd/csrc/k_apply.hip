@@ -36,20 +36,23 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
 
 #define A3_TX 64
 
-// RPT = target rows per thread (tile = 64 x 4*RPT points per 256-thread workgroup), KU = level unroll,
-// NT = non-temporal destination stores.
-template <int RPT, int KU, bool NT>
-__global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
-                                                   const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
-                                                   int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk) {
-  constexpr int TY = 4 * RPT;
+// RPT = target rows per thread, WAVES = waves per workgroup (tile = 64 x WAVES*RPT target points), SYNC = keep the
+// workgroup's waves in level lock-step with a barrier so that lines shared between neighbouring rows are
+// still in L1/L2 when the next wave asks for them.  Each workgroup serves `fpw` fields of its tile back to back,
+// so indices and weights are read once per tile instead of once per field.  Destination stores are non-temporal.
+template <int RPT, int WAVES, bool SYNC>
+__global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                          const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                          int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk,
+                                                          int nfields, int fpw) {
+  constexpr int TY = WAVES * RPT;
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tile = lin % ntile;
-  unsigned rest = lin / ntile;  // = field * nchunk + chunk
+  unsigned rest = lin / ntile;  // = field group * nchunk + chunk
   int chunk = rest % nchunk;
-  int fld = rest / nchunk;
+  int f0 = (rest / nchunk) * fpw, f1 = min(nfields, f0 + fpw);
   int tx = tile % ntx, ty = tile / ntx;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int i = tx * A3_TX + lane;
@@ -73,89 +76,110 @@ __global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ i
 #pragma unroll
     for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
   }
-  const double *s = src + ((int64_t)fld * nlev + k0) * nsrc;
-  double *d = dst + ((int64_t)fld * nlev + k0) * P + (int64_t)j0 * nx + i;
-  int k = k0;
-  for (; k + KU <= k1; k += KU) {
-    double v[KU][RPT];
-#pragma unroll
-    for (int u = 0; u < KU; ++u)
+  for (int f = f0; f < f1; ++f) {
+    const double *s = src + ((int64_t)f * nlev + k0) * nsrc;
+    double *d = dst + ((int64_t)f * nlev + k0) * P + (int64_t)j0 * nx + i;
+    for (int k = k0; k < k1; ++k) {
+      if (SYNC) __syncthreads();
+      double v[RPT];
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        const double *su = s + (int64_t)u * nsrc;
-        double a = su[c[r][0]], b = su[c[r][1]], e = su[c[r][2]];
-        v[u][r] = ww[r][0] * a + ww[r][1] * b + ww[r][2] * e;
+        double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
+        v[r] = ww[r][0] * a + ww[r][1] * b + ww[r][2] * e;
       }
-#pragma unroll
-    for (int u = 0; u < KU; ++u)
 #pragma unroll
       for (int r = 0; r < RPT; ++r)
-        if (act[r]) {
-          double o = mapped[r] ? v[u][r] : 0.0;
-          double *dp = d + (int64_t)u * P + (int64_t)r * nx;
-          if (NT) __builtin_nontemporal_store(o, dp); else *dp = o;
-        }
-    s += (int64_t)KU * nsrc;
-    d += (int64_t)KU * P;
-  }
-  for (; k < k1; ++k) {
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-      double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
-      double o = mapped[r] ? ww[r][0] * a + ww[r][1] * b + ww[r][2] * e : 0.0;
-      if (act[r]) {
-        double *dp = d + (int64_t)r * nx;
-        if (NT) __builtin_nontemporal_store(o, dp); else *dp = o;
-      }
+        if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + (int64_t)r * nx);
+      s += nsrc;
+      d += P;
     }
-    s += nsrc;
-    d += P;
   }
 }
 
-typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int);
-struct A3Variant { int rpt, ku, nt; apply3_fn fn; };
+typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int, int, int);
+struct A3Variant { int rpt, waves, sync; apply3_fn fn; };
 static const A3Variant g_a3_variants[] = {
-    {4, 1, 1, k_apply3_cf<4, 1, true>},  {4, 2, 1, k_apply3_cf<4, 2, true>},  {2, 2, 1, k_apply3_cf<2, 2, true>},
-    {2, 4, 1, k_apply3_cf<2, 4, true>},  {8, 1, 1, k_apply3_cf<8, 1, true>},  {1, 4, 1, k_apply3_cf<1, 4, true>},
-    {4, 1, 0, k_apply3_cf<4, 1, false>}, {4, 2, 0, k_apply3_cf<4, 2, false>}, {1, 8, 1, k_apply3_cf<1, 8, true>},
-    {2, 1, 1, k_apply3_cf<2, 1, true>},  {8, 2, 1, k_apply3_cf<8, 2, true>},
+    {2, 4, 0, k_apply3_cf<2, 4, false>},  {2, 4, 1, k_apply3_cf<2, 4, true>},   {2, 8, 0, k_apply3_cf<2, 8, false>},
+    {2, 8, 1, k_apply3_cf<2, 8, true>},   {2, 16, 0, k_apply3_cf<2, 16, false>}, {2, 16, 1, k_apply3_cf<2, 16, true>},
+    {1, 8, 1, k_apply3_cf<1, 8, true>},   {1, 16, 1, k_apply3_cf<1, 16, true>},  {4, 4, 0, k_apply3_cf<4, 4, false>},
+    {4, 8, 1, k_apply3_cf<4, 8, true>},   {1, 4, 0, k_apply3_cf<1, 4, false>},   {1, 16, 0, k_apply3_cf<1, 16, false>},
+    {4, 4, 1, k_apply3_cf<4, 4, true>},
 };
-static int g_a3_variant = 9;  // MPG_A3_VARIANT (tuned on MI355X: profiles/r01_sweep_apply.txt)
+static int g_a3_variant = 1;  // "a3_variant" knob (tuned on MI355X: profiles/r01_sweep_apply*.txt)
+static int g_fpw = 1;         // "fields_per_wg" knob (0 = all fields in one workgroup pass)
 
-// Level-fastest source: one workgroup = 64 consecutive target points x all levels.
-// phase 1: wave w serves points 16w..16w+15, lanes = levels -> three coalesced row reads per point;
-// phase 2: lanes = points -> 512-B coalesced stores per level.  LDS tile [nlev][65] doubles.
+// Level-fastest source ([ncell][nlev], MPAS file order): the reference transposes on the host
+// (input_data.F90:653-655); here the transpose is fused through LDS.  One workgroup = a TXL x (64/TXL) tile of 64
+// target points x all levels (2-D so that the points of a tile share source rows).
+// phase 0: the tile's 64 x 3 indices/weights are staged in LDS (coalesced);
+// phase 1: wave w serves points 16w..16w+15, lanes = levels: the cell id is wave-uniform (readfirstlane -> scalar
+//          row base), so each gather is one coalesced nlev*8-byte row read; 4 points (12 loads) in flight;
+// phase 2: lanes = points: TXL*8-byte contiguous non-temporal stores per level.
+// LDS tile [nlev][65] doubles (row pad 1: conflict-free ds_write_b64 column writes).
+template <int TXL>
 __global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ idx, const double *__restrict__ w,
-                                                   const double *__restrict__ src, double *__restrict__ dst, int64_t P,
-                                                   int64_t nsrc, int nlev, int nblk) {
-  extern __shared__ double tile[];  // [nlev][65]
+                                                   const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                   int64_t nsrc, int nlev, int ntx, int nty) {
+  constexpr int TYL = 64 / TXL;
+  extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
+  double *sw = tile + (size_t)nlev * 65;
+  int32_t *sidx = (int32_t *)(sw + 192);
+  int64_t P = (int64_t)nx * ny;
+  unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  unsigned blk = lin % nblk;
-  int fld = lin / nblk;
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int64_t p0 = (int64_t)blk * 64;
+  unsigned tl = lin % ntile;
+  int fld = lin / ntile;
+  int tx = tl % ntx, ty = tl / ntx;
+  int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 192) {
+    int pt = t & 63, q = t >> 6;
+    int i = tx * TXL + (pt % TXL), j = ty * TYL + (pt / TXL);
+    bool in = i < nx && j < ny;
+    int64_t p = in ? (int64_t)j * nx + i : 0;
+    int32_t c = idx[q * P + p];
+    sidx[q * 64 + pt] = in ? c : -1;
+    sw[q * 64 + pt] = w[q * P + p];
+  }
+  __syncthreads();
   const double *sf = src + (int64_t)fld * nlev * nsrc;
-  for (int q = 0; q < 16; ++q) {
-    int pt = wave * 16 + q;
-    int64_t p = p0 + pt;
-    if (p >= P) break;
-    int32_t c0 = idx[p], c1 = idx[P + p], c2 = idx[2 * P + p];
-    double w0 = w[p], w1 = w[P + p], w2 = w[2 * P + p];
-    bool mapped = c0 >= 0;
-    c0 = max(c0, 0); c1 = max(c1, 0); c2 = max(c2, 0);
-    for (int k = lane; k < nlev; k += 64) {
-      double a = sf[(int64_t)c0 * nlev + k], b = sf[(int64_t)c1 * nlev + k], e = sf[(int64_t)c2 * nlev + k];
-      double v = w0 * a + w1 * b + w2 * e;
-      tile[k * 65 + pt] = mapped ? v : 0.0;
+  for (int kb = 0; kb < nlev; kb += 64) {
+    int k = kb + lane;
+    bool kact = k < nlev;
+    int kk = kact ? k : 0;
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int pt = wave * 16 + q0 + u;
+        int32_t c0 = __builtin_amdgcn_readfirstlane(sidx[pt]);
+        int32_t c1 = __builtin_amdgcn_readfirstlane(sidx[64 + pt]);
+        int32_t c2 = __builtin_amdgcn_readfirstlane(sidx[128 + pt]);
+        double w0 = sw[pt], w1 = sw[64 + pt], w2 = sw[128 + pt];
+        bool m = c0 >= 0;
+        c0 = max(c0, 0); c1 = max(c1, 0); c2 = max(c2, 0);
+        const double *r0 = sf + (int64_t)c0 * nlev, *r1 = sf + (int64_t)c1 * nlev, *r2 = sf + (int64_t)c2 * nlev;
+        double a = r0[kk], b = r1[kk], e = r2[kk];
+        v[u] = m ? w0 * a + w1 * b + w2 * e : 0.0;
+      }
+      if (kact) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tile[k * 65 + wave * 16 + q0 + u] = v[u];
+      }
     }
   }
   __syncthreads();
   double *df = dst + (int64_t)fld * nlev * P;
-  int64_t p = p0 + lane;
-  if (p < P)
+  int i = tx * TXL + (lane % TXL), j = ty * TYL + (lane / TXL);
+  if (i < nx && j < ny) {
+    int64_t p = (int64_t)j * nx + i;
     for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + p);
+  }
 }
+typedef void (*apply3lf_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int);
+struct LfVariant { int txl; apply3lf_fn fn; };
+static const LfVariant g_lf_variants[] = {{16, k_apply3_lf<16>}, {32, k_apply3_lf<32>}, {64, k_apply3_lf<64>}, {8, k_apply3_lf<8>}};
+static int g_lf_variant = 2;  // "lf_variant" knob (64 x 1 tiles: tuned on MI355X)
 
 // nearest neighbour: bit-exact copy
 __global__ __launch_bounds__(256) void k_apply1(const int32_t *__restrict__ idx, const double *__restrict__ src,
@@ -256,6 +280,12 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
 int mpg_k_tune(const char *key, int value) {
   g_tune_read = 1;
   if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }
+  if (!strcmp(key, "fields_per_wg")) { g_fpw = value; return MPG_SUCCESS; }
+  if (!strcmp(key, "lf_variant")) {
+    if (value < 0 || value >= (int)(sizeof(g_lf_variants) / sizeof(g_lf_variants[0]))) return MPG_ERR_INVALID_ARG;
+    g_lf_variant = value;
+    return MPG_SUCCESS;
+  }
   if (!strcmp(key, "a3_variant")) {
     if (value < 0 || value >= (int)(sizeof(g_a3_variants) / sizeof(g_a3_variants[0]))) return MPG_ERR_INVALID_ARG;
     g_a3_variant = value;
@@ -287,21 +317,27 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
     k_applyN<4><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
   } else if (h->nnz_per_row == 3) {
     if (lev_fast) {
-      int nb64 = (int)((P + 63) / 64);
-      size_t lds = sizeof(double) * 65 * (size_t)nlev;
+      const LfVariant &lv = g_lf_variants[g_lf_variant];
+      int tyl = 64 / lv.txl;
+      int ntx = (h->nx_dst + lv.txl - 1) / lv.txl, nty = (h->ny_dst + tyl - 1) / tyl;
+      size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
       if (lds > 160 * 1024) {
         mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
         return MPG_ERR_UNSUPPORTED;
       }
-      k_apply3_lf<<<(unsigned)nb64 * nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, nb64);
+      if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)lv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lv.fn<<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty);
     } else {
       const A3Variant &av = g_a3_variants[g_a3_variant];
-      int tyv = 4 * av.rpt;
+      int tyv = av.waves * av.rpt;
       int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + tyv - 1) / tyv;
       int lc = g_lev_chunk > 0 ? g_lev_chunk : nlev;
       int nchunk = (nlev + lc - 1) / lc;
-      unsigned nwg = (unsigned)ntx * nty * nchunk * nfields;
-      av.fn<<<nwg, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk);
+      int fpw = g_fpw > 0 ? (g_fpw < nfields ? g_fpw : nfields) : nfields;
+      int ngroups = (nfields + fpw - 1) / fpw;
+      unsigned nwg = (unsigned)ntx * nty * nchunk * ngroups;
+      av.fn<<<nwg, 64 * av.waves, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk,
+                                          nfields, fpw);
     }
   } else {
     mpg_set_error("Regrid: unsupported handle");

@@ -57,19 +57,41 @@ class HaloSchedule:
     own_pos: tuple = (0, 0)        # range mode: where the own block sits in the local index space
 
     @staticmethod
-    def build(needed_ids, n_cells, rank, world, all_gather_object, range_slack=1.25):
-        """needed_ids: sorted unique global source ids this rank's rows reference."""
-        c0, c1 = cell_block(n_cells, world, rank)
+    def build(needed_ids, n_cells, rank, world, all_gather_object, ownership="aligned", range_slack=1.25):
+        """needed_ids: sorted unique global source ids this rank's rows reference.
+
+        ownership = "para_range": source cells owned in equal contiguous id blocks exactly like the reference's
+        default partition (model_grid.F90:427); the exchange then moves whatever the geometry dictates.
+        ownership = "aligned" (default, banded numbering only): the id boundaries between ranks are placed in
+        the middle of the overlap of neighbouring ranks' needed ranges, i.e. the source partition follows the
+        target-row partition and only a thin strip (the triangles straddling a row-block boundary) travels;
+        cells nobody references are owned by nobody and never loaded."""
         needed_ids = np.asarray(needed_ids, np.int64)
-        lo = int(min(needed_ids[0], c0)) if needed_ids.size else c0
-        hi = int(max(needed_ids[-1] + 1, c1)) if needed_ids.size else c1
-        # banded numbering <=> the covering range is not much larger than what is actually used
-        used = np.union1d(needed_ids, np.arange(c0, c1)).size if (hi - lo) < 4 * (needed_ids.size + c1 - c0) else 0
-        want_range = used > 0 and (hi - lo) <= range_slack * used
-        votes = all_gather_object(bool(want_range))
-        mode = "range" if all(votes) else "compact"
-        blocks = [cell_block(n_cells, world, q) for q in range(world)]
+        pr = cell_block(n_cells, world, rank)
+        nlo = int(needed_ids[0]) if needed_ids.size else pr[0]
+        nhi = int(needed_ids[-1] + 1) if needed_ids.size else pr[0]
+        # banded numbering <=> the covering range of the needed ids is not much larger than their count
+        want_range = needed_ids.size > 0 and (nhi - nlo) <= range_slack * needed_ids.size
+        votes = all_gather_object((bool(want_range), nlo, nhi))
+        mode = "range" if all(v[0] for v in votes) else "compact"
+        if mode == "range" and ownership == "aligned":
+            los, his = [v[1] for v in votes], [v[2] for v in votes]
+            if any(los[q] < los[q - 1] or his[q] < his[q - 1] for q in range(1, world)):
+                ownership = "para_range"     # row blocks do not map to increasing id ranges
+        if mode == "range" and ownership == "aligned":
+            bnd = [los[0]]
+            for q in range(1, world):
+                b = (los[q] + his[q - 1]) // 2 if los[q] < his[q - 1] else los[q]
+                bnd.append(max(b, bnd[-1]))
+            bnd.append(max(his[-1], bnd[-1]))
+            blocks = [(bnd[q], bnd[q + 1]) for q in range(world)]
+        else:
+            blocks = [cell_block(n_cells, world, q) for q in range(world)]
+        c0, c1 = blocks[rank]
         if mode == "range":
+            lo, hi = min(nlo, c0), max(nhi, c1)
+            if not needed_ids.size:
+                lo, hi = c0, c1
             spans = all_gather_object((lo, hi))
             s = HaloSchedule(rank, world, mode, hi - lo, (c0, c1), base=lo, own_pos=(c0 - lo, c1 - lo))
             for q in range(world):
@@ -129,7 +151,13 @@ class HaloSchedule:
         sendbuf = torch.cat(parts) if parts else own_rows.new_empty(0)
         recvbuf = own_rows.new_empty(R * sum(recv_n))
         if self.world > 1:
-            dist.all_to_all_single(recvbuf, sendbuf, [R * n for n in recv_n], [R * n for n in send_n])
+            if sendbuf.is_cuda and dist.get_backend() == "gloo":
+                # rehearsal transport (gloo moves host memory); the production transport is RCCL on device memory
+                rb = torch.empty(recvbuf.shape, dtype=recvbuf.dtype)
+                dist.all_to_all_single(rb, sendbuf.cpu(), [R * n for n in recv_n], [R * n for n in send_n])
+                recvbuf.copy_(rb)
+            else:
+                dist.all_to_all_single(recvbuf, sendbuf, [R * n for n in recv_n], [R * n for n in send_n])
         else:
             recvbuf.copy_(sendbuf)
         off = 0
@@ -146,7 +174,7 @@ class HaloSchedule:
 class ShardedRegrid:
     """Rank-local piece of a row-sharded Mesh -> Grid regrid on this rank's GPU."""
 
-    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object):
+    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object, ownership="aligned"):
         from . import regrid as R
         self.rank, self.world = rank, world
         self.j0, self.j1 = row_block(target.ny, world, rank)
@@ -156,7 +184,7 @@ class ShardedRegrid:
         self.store_ms = self.rh.store_ms
         needed = self.rh.unique_sources()
         self.n_needed = int(needed.size)
-        self.sched = HaloSchedule.build(needed, mpas_mesh.nCells, rank, world, all_gather_object)
+        self.sched = HaloSchedule.build(needed, mpas_mesh.nCells, rank, world, all_gather_object, ownership=ownership)
         if self.sched.mode == "range":
             self.rh.rebase(self.sched.base, self.sched.n_local)
         else:

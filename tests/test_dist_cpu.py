@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shuffle, q):
+def _worker(rank, world, port, shuffle, ownership, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -46,11 +46,13 @@ def _worker(rank, world, port, shuffle, q):
             out = [None] * world
             dist.all_gather_object(out, obj)
             return out
-        sched = mdist.HaloSchedule.build(needed, m.nCells, rank, world, ago)
+        sched = mdist.HaloSchedule.build(needed, m.nCells, rank, world, ago, ownership=ownership)
         assert sched.mode == ("compact" if shuffle else "range")
         nlev = 3
         full = synth.analytic_field(m.latCell, m.lonCell, nlev)[:, perm]     # field in the (possibly shuffled) numbering
         c0, c1 = sched.own
+        if ownership == "para_range" or shuffle:
+            assert (c0, c1) == mdist.cell_block(m.nCells, world, rank)
         local = torch.full((nlev, sched.n_local), float("nan"), dtype=torch.float64)
         if sched.mode == "range":
             a, b = sched.own_pos
@@ -66,17 +68,18 @@ def _worker(rank, world, port, shuffle, q):
         assert not np.isnan(got).any()
         assert np.array_equal(got, want)
         send_n, recv_n = sched.counts()
-        q.put((rank, sched.mode, sum(send_n), sum(recv_n), j1 - j0, int(got.shape[1])))
+        q.put((rank, sched.mode, sum(send_n), sum(recv_n), j1 - j0, int(got.shape[1]), c0, c1))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shuffle", [(2, False), (2, True), (3, False)])
-def test_row_sharded_halo_exchange(world, shuffle):
+@pytest.mark.parametrize("world,shuffle,ownership", [(2, False, "aligned"), (2, True, "aligned"), (3, False, "aligned"),
+                                                    (3, False, "para_range")])
+def test_row_sharded_halo_exchange(world, shuffle, ownership):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shuffle, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shuffle, ownership, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -86,6 +89,10 @@ def test_row_sharded_halo_exchange(world, shuffle):
     assert sum(r[4] for r in res) == 40               # every target row owned exactly once
     assert sum(r[2] for r in res) == sum(r[3] for r in res)   # everything sent is received
     assert sum(r[2] for r in res) > 0                 # neighbouring bands really exchange a halo strip
+    assert all(res[i][7] == res[i + 1][6] for i in range(world - 1))     # ownership blocks tile the id space
+    if ownership == "aligned" and not shuffle:
+        # source partition follows the target rows: only a thin strip travels (a few lattice rows of ~70 cells)
+        assert sum(r[2] for r in res) < 0.25 * 4000
 
 
 def test_row_and_cell_blocks():

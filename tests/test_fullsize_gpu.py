@@ -1,0 +1,105 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle would need minutes
+there): partition of unity, exact reproduction of constants, linearity, closed-form answer for Cartesian-linear
+fields, nearest-neighbour optimality on a sample and value-set preservation, conservative row sums /
+non-negativity, equality of the two source layouts, determinism of repeated Stores."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c4(gpu_lib):
+    import torch
+    from mpassit_amd import regrid as R, workloads
+    m, g, nlev, _ = workloads.workload("c4_3m_regional")
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    yield dict(m=m, g=g, mesh=mesh, grid=grid, nlev=nlev, torch=torch)
+    mesh.destroy()
+    grid.destroy()
+
+
+def _xyz(lat, lon):
+    cl = np.cos(lat)
+    return np.stack([cl * np.cos(lon), cl * np.sin(lon), np.sin(lat)], axis=-1)
+
+
+def test_c4_bilinear_properties(c4):
+    from mpassit_amd import regrid as R
+    torch, m, g = c4["torch"], c4["m"], c4["g"]
+    rh = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_BILINEAR)
+    assert rh.n_dst == 1800 * 1060 and rh.n_src == m.nCells
+    idx, w = rh.weights()
+    mapped = idx[:, 0] >= 0
+    assert mapped.all()                                   # the 3 M-cell mesh covers the whole Lambert domain
+    assert np.abs(w.sum(1) - 1).max() < 1e-13 and w.min() > -1e-10
+    # closed form: f = a.X  ->  t*(a.P), t = det[A,B,C]/S, on every one of the 1.9 M points
+    cx = _xyz(m.latCell, np.where(m.lonCell > np.pi, m.lonCell - 2 * np.pi, m.lonCell))
+    px = _xyz(np.deg2rad(g.lat).ravel(), np.deg2rad(g.lon).ravel())
+    a = np.array([0.3, -0.7, 0.5])
+    src = torch.as_tensor(np.stack([cx @ a, np.full(m.nCells, 7.25)]), device="cuda")       # 2 "levels"
+    out = rh.regrid(src.view(-1), nlev=2).cpu().numpy().reshape(2, -1)
+    A, B, C = cx[idx[:, 0]], cx[idx[:, 1]], cx[idx[:, 2]]
+    n = np.cross(B - A, C - A)                     # difference form: well conditioned for 3-km triangles
+    t = np.einsum("ij,ij->i", A, n) / np.einsum("ij,ij->i", n, px)
+    assert np.abs(out[0] - t * (px @ a)).max() < 1e-12
+    assert np.abs(out[1] - 7.25).max() < 1e-13           # constants are reproduced (sum w = 1)
+    # linearity over a 55-level bundle + both source layouts agree
+    L = c4["nlev"]
+    x = torch.randn((2, L, m.nCells), dtype=torch.float64, device="cuda")
+    y = rh.regrid(x.view(-1), nlev=L, nfields=2)
+    z = rh.regrid((2.0 * x[0] - 3.0 * x[1]).contiguous().view(-1), nlev=L)
+    assert float((z[0] - (2.0 * y[0] - 3.0 * y[1])).abs().max()) < 1e-12
+    ylf = rh.regrid(x.permute(0, 2, 1).contiguous().view(-1), nlev=L, nfields=2, layout=R.LAYOUT_LEV_FAST)
+    assert float((ylf - y).abs().max()) < 1e-13
+    # min/max principle: convex weights (up to the 1e-10 edge tolerance)
+    assert float(y.max()) <= float(x.max()) + 1e-9 and float(y.min()) >= float(x.min()) - 1e-9
+    print("store_ms bilinear C4:", rh.store_ms)
+    rh.release()
+    # determinism: a fresh Store gives the identical handle contents
+    rh2 = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_BILINEAR)
+    idx2, w2 = rh2.weights()
+    assert np.array_equal(idx, idx2) and np.array_equal(w, w2)
+    rh2.release()
+
+
+def test_c4_nearest_properties(c4):
+    from mpassit_amd import regrid as R, synth
+    torch, m, g = c4["torch"], c4["m"], c4["g"]
+    rh = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_NEAREST_STOD)
+    idx, _ = rh.weights()
+    idx = idx[:, 0]
+    assert idx.min() >= 0 and idx.max() < m.nCells
+    cx = _xyz(m.latCell, m.lonCell)
+    px = _xyz(np.deg2rad(g.lat).ravel(), np.deg2rad(g.lon).ravel())
+    rng = np.random.default_rng(0)
+    sample = rng.choice(px.shape[0], 40, replace=False)
+    for p in sample:                                       # brute force over all 3 M cells
+        d = ((cx - px[p]) ** 2).sum(1)
+        assert d[idx[p]] <= d.min() * (1 + 1e-12)
+    cat = synth.category_field(m.nCells, nlev=2)
+    out = rh.regrid(torch.as_tensor(cat, device="cuda").view(-1), nlev=2).cpu().numpy().reshape(2, -1)
+    assert np.array_equal(out, cat[:, idx])                # bit-exact copy, integer categories preserved
+    print("store_ms nearest C4:", rh.store_ms)
+    rh.release()
+
+
+def test_c4_conservative_properties(c4):
+    from mpassit_amd import regrid as R
+    torch, m, g = c4["torch"], c4["m"], c4["g"]
+    rh = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_CONSERVE)
+    rp, col, val = rh.csr()
+    P = g.nx * g.ny
+    assert val.min() > 0 and col.min() >= 0 and col.max() < m.nCells
+    rows = np.repeat(np.arange(P), np.diff(rp))
+    rowsum = np.bincount(rows, weights=val, minlength=P)
+    assert np.abs(rowsum - 1).max() < 1e-9                 # every destination cell fully covered by the mesh
+    assert (np.diff(rp) >= 1).all() and np.diff(rp).max() < 32
+    for p in np.random.default_rng(1).choice(P, 1000, replace=False):   # rows sorted by source id, no duplicates
+        c = col[rp[p]:rp[p + 1]]
+        assert (np.diff(c) > 0).all()
+    const = torch.full((m.nCells,), 4.5, dtype=torch.float64, device="cuda")
+    out = rh.regrid(const, nlev=1).cpu().numpy().ravel()
+    assert np.abs(out - 4.5).max() < 1e-8
+    print("store_ms conserve C4:", rh.store_ms, "nnz/row", len(col) / P)
+    rh.release()

@@ -16,8 +16,10 @@ def main():
     ap.add_argument("--workload", default="c4_3m_regional")
     ap.add_argument("--fields", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10")
-    ap.add_argument("--chunks", default="0,11")
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10,11,12")
+    ap.add_argument("--chunks", default="0")
+    ap.add_argument("--fpw", default="1,0")
+    ap.add_argument("--lf", default="", help="comma list of lev_fast variants: sweeps the level-fastest kernel instead")
     args = ap.parse_args()
     import torch
     from mpassit_amd import _lib, regrid as R, workloads
@@ -30,24 +32,33 @@ def main():
     src = torch.randn((F, nlev, m.nCells), dtype=torch.float64, device="cuda")
     out = torch.empty((F, nlev, g.ny, g.nx), dtype=torch.float64, device="cuda")
     alg = F * nlev * 8.0 * (U + g.nx * g.ny) + g.nx * g.ny * 36.0
-    combos = [(int(v), int(c)) for v in args.variants.split(",") for c in args.chunks.split(",")]
+    combos = [(int(v), int(c), int(f)) for v in args.variants.split(",") for c in args.chunks.split(",") for f in args.fpw.split(",")]
+    layout = R.LAYOUT_CELL_FAST
+    if args.lf:
+        combos = [(int(v), 0, 1) for v in args.lf.split(",")]
+        layout = R.LAYOUT_LEV_FAST
+        src = src.permute(0, 2, 1).contiguous()
     times = {c: [] for c in combos}
     for rnd in range(args.rounds + 1):
-        for v, c in combos:
-            _lib.tune("a3_variant", v)
-            _lib.tune("lev_chunk", c)
+        for v, c, fp in combos:
+            if args.lf:
+                _lib.tune("lf_variant", v)
+            else:
+                _lib.tune("a3_variant", v)
+                _lib.tune("lev_chunk", c)
+                _lib.tune("fields_per_wg", fp)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                rh.regrid(src.view(-1), nlev=nlev, nfields=F, out=out)
+                rh.regrid(src.view(-1), nlev=nlev, nfields=F, out=out, layout=layout)
             e1.record()
             torch.cuda.synchronize()
             if rnd > 0:
-                times[(v, c)].append(e0.elapsed_time(e1) / 3)
+                times[(v, c, fp)].append(e0.elapsed_time(e1) / 3)
     res = []
-    for (v, c), ts in times.items():
+    for (v, c, fp), ts in times.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
-        res.append(dict(variant=v, lev_chunk=c, ms_med=med, ms_min=mn, GBs_med=alg / med / 1e6, fields_per_s=F / med * 1e3))
+        res.append(dict(variant=v, lev_chunk=c, fpw=fp, ms_med=med, ms_min=mn, GBs_med=alg / med / 1e6, fields_per_s=F / med * 1e3))
     res.sort(key=lambda r: r["ms_med"])
     for r in res:
         print(json.dumps(r))
