@@ -44,7 +44,7 @@ template <int RPT, int WAVES, bool SYNC>
 __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                           const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
                                                           int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk,
-                                                          int nfields, int fpw) {
+                                                          int nfields, int fpw, int tgroup) {
   constexpr int TY = WAVES * RPT;
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
@@ -53,7 +53,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   unsigned rest = lin / ntile;  // = field group * nchunk + chunk
   int chunk = rest % nchunk;
   int f0 = (rest / nchunk) * fpw, f1 = min(nfields, f0 + fpw);
-  int tx = tile % ntx, ty = tile / ntx;
+  // tiles are walked in bands of `tgroup` tile rows, column by column inside a band: workgroups dispatched back to
+  // back are vertical neighbours (they share footprint rows), horizontal neighbours follow `tgroup` slots later
+  int band = tile / (ntx * tgroup), rem = tile % (ntx * tgroup);
+  int bh = min(tgroup, nty - band * tgroup);   // rows in this (possibly last, shorter) band
+  int tx = rem / bh, ty = band * tgroup + rem % bh;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int i = tx * A3_TX + lane;
   int j0 = ty * TY + wave * RPT;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   }
 }
 
-typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int, int, int);
+typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int, int, int, int);
 struct A3Variant { int rpt, waves, sync; apply3_fn fn; };
 static const A3Variant g_a3_variants[] = {
     {2, 4, 0, k_apply3_cf<2, 4, false>},  {2, 4, 1, k_apply3_cf<2, 4, true>},   {2, 8, 0, k_apply3_cf<2, 8, false>},
@@ -107,6 +111,7 @@ static const A3Variant g_a3_variants[] = {
 };
 static int g_a3_variant = 1;  // "a3_variant" knob (tuned on MI355X: profiles/r01_sweep_apply*.txt)
 static int g_fpw = 1;         // "fields_per_wg" knob (0 = all fields in one workgroup pass)
+static int g_tgroup = 1;      // "tile_group" knob: tile rows per band (1 = plain row-major tile order)
 
 // Level-fastest source ([ncell][nlev], MPAS file order): the reference transposes on the host
 // (input_data.F90:653-655); here the transpose is fused through LDS.  One workgroup = a TXL x (64/TXL) tile of 64
@@ -281,6 +286,7 @@ int mpg_k_tune(const char *key, int value) {
   g_tune_read = 1;
   if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }
   if (!strcmp(key, "fields_per_wg")) { g_fpw = value; return MPG_SUCCESS; }
+  if (!strcmp(key, "tile_group")) { g_tgroup = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_variant")) {
     if (value < 0 || value >= (int)(sizeof(g_lf_variants) / sizeof(g_lf_variants[0]))) return MPG_ERR_INVALID_ARG;
     g_lf_variant = value;
@@ -337,7 +343,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
       int ngroups = (nfields + fpw - 1) / fpw;
       unsigned nwg = (unsigned)ntx * nty * nchunk * ngroups;
       av.fn<<<nwg, 64 * av.waves, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk,
-                                          nfields, fpw);
+                                          nfields, fpw, g_tgroup < nty ? g_tgroup : nty);
     }
   } else {
     mpg_set_error("Regrid: unsupported handle");

@@ -102,8 +102,61 @@ __global__ __launch_bounds__(256) void k_fill_i32(int64_t n, int32_t v, int32_t 
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = v;
 }
 
-int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s) {
+// Node-located sources (vorticity; interp.F90:350-366): the Voronoi polygons carry values at their
+// corners.  ESMF triangulates polygons with > 4 sides in an undocumented order; this build uses the fan from the
+// first listed vertex (triangle k of cell c = (v0, v_{k+1}, v_{k+2}), id = c*(maxEdges-2)+k) and the same
+// rasteriser as the element-located case, with vertex coordinates as the source points.
+__global__ __launch_bounds__(256) void k_fan_triangles(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
+                                                       const double *__restrict__ vx, const double *__restrict__ vy,
+                                                       const double *__restrict__ vz, int32_t *__restrict__ ftri) {
+  int nf = maxEdges - 2;
+  int64_t nFan = nCells * nf;
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= nFan) return;
+  int64_t c = t / nf;
+  int k = (int)(t % nf);
+  // k-th fan triangle uses the 1st, (k+2)-th and (k+3)-th non-zero entries of the cell's row
+  int32_t a = -1, b = -1, d = -1;
+  int n = 0;
+  for (int j = 0; j < maxEdges; ++j) {
+    int32_t x = voc[c * maxEdges + j];
+    if (x <= 0) continue;
+    if (n == 0) a = x - 1;
+    if (n == k + 1) b = x - 1;
+    if (n == k + 2) d = x - 1;
+    ++n;
+  }
+  if (d >= 0) {
+    double det = det3_from(dv3{vx[a], vy[a], vz[a]}, dv3{vx[b], vy[b], vz[b]}, dv3{vx[d], vy[d], vz[d]});
+    if (det == 0.0) a = b = d = -1;
+    if (det < 0.0) { int32_t x = b; b = d; d = x; }
+  } else {
+    a = b = d = -1;
+  }
+  ftri[t] = a;
+  ftri[nFan + t] = b;
+  ftri[2 * nFan + t] = d;
+}
+
+int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int meshloc, mpg_handle_s *h, hipStream_t s) {
   int rc;
+  const int32_t *trip = m->tri.p;
+  int64_t nT = m->nVertices;
+  const PointSet *sp = &m->cell;
+  if (meshloc == MPG_MESHLOC_NODE) {
+    nT = m->nCells * (int64_t)(m->maxEdges - 2);
+    if (nT >= 0x7fffffff) {
+      mpg_set_error("mesh too large for the node-located fan triangulation");
+      return MPG_ERR_OVERFLOW;
+    }
+    if (!m->fan.p) {
+      if ((rc = m->fan.alloc(3 * (size_t)nT))) return rc;
+      k_fan_triangles<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p,
+                                                                  m->vert.z.p, m->fan.p);
+    }
+    trip = m->fan.p;
+    sp = &m->vert;
+  }
   PointSet &pts = g->pts[stagger];
   int npx = g->snx[stagger], npy = g->sny[stagger];
   int64_t P = (int64_t)npx * npy;
@@ -118,7 +171,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_han
   }
   h->kind = MPG_KIND_FIXED;
   h->nnz_per_row = 3;
-  h->n_src = m->nCells;
+  h->n_src = sp->n;
   h->n_dst = P;
   h->nx_dst = npx;
   h->ny_dst = npy;
@@ -130,12 +183,11 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_han
   int fb = (int)((P + 255) / 256);
   if (fb > 8192) fb = 8192;
   k_fill_i32<<<fb, 256, 0, s>>>(P, 0x7fffffff, owner.p);
-  int64_t nT = m->nVertices;
-  k_tri_raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, m->tri.p, nT, m->cell.x.p, m->cell.y.p, m->cell.z.p,
+  k_tri_raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sp->x.p, sp->y.p, sp->z.p,
                                                            mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p,
                                                            pts.z.p, owner.p);
-  k_tri_finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, m->tri.p, nT, m->cell.x.p, m->cell.y.p,
-                                                            m->cell.z.p, pts.x.p, pts.y.p, pts.z.p, h->idx.p, h->w.p);
+  k_tri_finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sp->x.p, sp->y.p, sp->z.p, pts.x.p, pts.y.p,
+                                                            pts.z.p, h->idx.p, h->w.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
   owner.free();

@@ -111,6 +111,7 @@ int mpg_mesh_destroy(mpg_mesh m) {
   m->vert.free();
   m->voc.free();
   m->tri.free();
+  m->fan.free();
   m->bvh.free();
   delete m;
   return MPG_SUCCESS;
@@ -214,14 +215,16 @@ struct StoreCtx {
   mpg_grid_s *g;
   int stagger;
   int method;
+  int meshloc;
 };
 
 int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod, mpg_handle *out) {
   MPG_CHECK_INIT();
   MPG_ARG(src && dst && out, "mpg_regrid_store: NULL argument");
   MPG_ARG(dst_staggerloc >= 0 && dst_staggerloc <= 2, "mpg_regrid_store: destination stagger must be CENTER, EDGE1 or EDGE2");
-  if (src_meshloc != MPG_MESHLOC_ELEMENT) {
-    mpg_set_error("mpg_regrid_store: node-located sources (vorticity, interp.F90:350-366) are not supported yet");
+  MPG_ARG(src_meshloc == MPG_MESHLOC_ELEMENT || src_meshloc == MPG_MESHLOC_NODE, "mpg_regrid_store: unknown mesh location");
+  if (src_meshloc == MPG_MESHLOC_NODE && regridmethod != MPG_REGRIDMETHOD_BILINEAR) {
+    mpg_set_error("mpg_regrid_store: node-located sources are only regridded bilinearly by the reference (interp.F90:350-366)");
     return MPG_ERR_UNSUPPORTED;
   }
   MPG_ARG(regridmethod >= 0 && regridmethod <= 2, "mpg_regrid_store: unknown regrid method");
@@ -229,12 +232,12 @@ int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_stagge
     mpg_set_error("mpg_regrid_store: conservative regridding is defined on the CENTER stagger only");
     return MPG_ERR_UNSUPPORTED;
   }
-  StoreCtx ctx{src, dst, dst_staggerloc, regridmethod};
+  StoreCtx ctx{src, dst, dst_staggerloc, regridmethod, src_meshloc};
   HandleKey key(src, src_meshloc, dst, dst_staggerloc, regridmethod);
   return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
     StoreCtx *x = (StoreCtx *)c;
     h->method = x->method;
-    if (x->method == MPG_REGRIDMETHOD_BILINEAR) return mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, h, g_stream);
+    if (x->method == MPG_REGRIDMETHOD_BILINEAR) return mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, x->meshloc, h, g_stream);
     if (x->method == MPG_REGRIDMETHOD_NEAREST_STOD) return mpg_k_store_nearest(x->m, x->g, x->stagger, h, g_stream);
     return mpg_k_store_conserve(x->m, x->g, h, g_stream);
   }, &ctx);
@@ -248,7 +251,7 @@ int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc,
     mpg_set_error("mpg_regrid_store_grid: only bilinear CENTER -> EDGE1/EDGE2 is used by the reference (interp.F90:298,316)");
     return MPG_ERR_UNSUPPORTED;
   }
-  StoreCtx ctx{nullptr, grid, dst_staggerloc, regridmethod};
+  StoreCtx ctx{nullptr, grid, dst_staggerloc, regridmethod, 0};
   HandleKey key(grid, 100 + src_staggerloc, grid, dst_staggerloc, regridmethod);
   return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
     StoreCtx *x = (StoreCtx *)c;

@@ -126,6 +126,7 @@ struct mpg_mesh_s {
   DevBuf<int32_t> voc;          // [nCells][maxEdges] 1-based, 0-padded (as given)
   DevBuf<int32_t> tri;          // [3][nVertices] dual triangles (cells), -1 = none; CCW
   int64_t nTriValid = 0;
+  DevBuf<int32_t> fan;          // [3][nCells*(maxEdges-2)] fan triangles of the Voronoi polygons (vertex ids), lazily
   SiteBvh bvh;
 };
 
@@ -164,7 +165,7 @@ int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s);
 int mpg_k_build_pyramid(const PointSet &pts, int nx, int ny, Pyramid &pyr, hipStream_t s);
 int mpg_k_build_cell_pyramid(const PointSet &corner, int nx, int ny, Pyramid &pyr, hipStream_t s);
 PyramidView mpg_pyr_view(const Pyramid &p);
-int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s);
+int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int meshloc, mpg_handle_s *h, hipStream_t s);
 int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s);
 int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStream_t s);
 int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, hipStream_t s);

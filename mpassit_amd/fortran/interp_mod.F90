@@ -21,7 +21,7 @@ module model_data
 
   type(c_ptr) :: input_grid = c_null_ptr, target_grid_h = c_null_ptr   ! ESMF_Mesh / ESMF_Grid stand-ins
   integer :: nCells_input = 0, nVert_input = 0, maxEdges_input = 0, nz_input = 0, nzp1_input = 0, nsoil_input = 0
-  type(bundle_t) :: diag_bundle, hist_2d_patch, hist_2d_cons, hist_2d_nstd, hist_3d_nz, hist_3d_nzp1, hist_soil
+  type(bundle_t) :: diag_bundle, hist_2d_patch, hist_2d_cons, hist_2d_nstd, hist_3d_nz, hist_3d_nzp1, hist_3d_vert, hist_soil
   type(field_t) :: hgt, u_field, v_field, umass, vmass
   integer :: do_u_interp = 0, do_v_interp = 0, u10_ind = 0, v10_ind = 0
 end module model_data
@@ -111,6 +111,13 @@ contains
       call mpg_check(mpg_handle_release(rh_stag), "IN FieldRegridRelease")
     end if
     if (hist_3d_nzp1%n > 0) call regrid_bundle(rh_patch, hist_3d_nzp1)
+    if (hist_3d_vert%n > 0) then        ! node-located sources (vorticity), interp.F90:350-366
+      print *, "- CREATE HIST BUNDLE VERT BILINEAR REGRID ROUTEHANDLE"
+      call mpg_check(mpg_regrid_store(input_grid, MPG_MESHLOC_NODE, target_grid_h, MPG_STAGGERLOC_CENTER, method, rh_stag), &
+                     "IN FieldBundleRegridStore")
+      call regrid_bundle(rh_stag, hist_3d_vert)
+      call mpg_check(mpg_handle_release(rh_stag), "IN FieldRegridRelease")
+    end if
     rh_soil = rh_patch
     have_cons = hist_2d_cons%n > 0
     have_nstd = hist_2d_nstd%n > 0

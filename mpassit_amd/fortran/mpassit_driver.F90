@@ -169,7 +169,7 @@ contains
         else if (is_in(names(i), nzp1_vars)) then
           call append(hist_3d_nzp1, f)
         else if (trim(names(i)) == 'vorticity') then
-          call fatal("node-located bilinear (vorticity) is not supported by this build", -1)
+          call append(hist_3d_vert, f)
         else
           call append(hist_3d_nz, f)
         end if
@@ -212,6 +212,7 @@ contains
       call put_bundle(u, hist_2d_nstd)
       call put_bundle(u, hist_3d_nz)
       call put_bundle(u, hist_3d_nzp1)
+      call put_bundle(u, hist_3d_vert)
       call put_bundle(u, hist_soil)
       if (do_u_interp == 1) then
         call put(u, umass, i_target, j_target)

@@ -118,8 +118,11 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out):
         rh_v.release()
     for (n, t), o in zip(h.nzp1_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nzp1_3d], inp.nzp1, inp.layout)):
         out[t] = o                                                    # :331-347
-    if h.vert_3d:
-        raise NotImplementedError("node-located bilinear (vorticity, interp.F90:350-366) is not built yet (SURVEY s8 a11)")
+    if h.vert_3d:                                                     # :350-366 node-located sources (vorticity)
+        rh_vert = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)
+        for (n, t), o in zip(h.vert_3d, _bundle_regrid(rh_vert, [inp.hist[n] for n, _ in h.vert_3d], inp.nz, inp.layout)):
+            out[t] = o
+        rh_vert.release()
     rh_cons = rh_nstd = None
     if h.cons_2d:
         rh_cons = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)  # :368-416 (bundle or per-field: same result)

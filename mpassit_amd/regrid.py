@@ -14,11 +14,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from ._lib import (LAYOUT_CELL_FAST, LAYOUT_LEV_FAST, MESHLOC_ELEMENT, REGRIDMETHOD_BILINEAR, REGRIDMETHOD_CONSERVE,
+from ._lib import (LAYOUT_CELL_FAST, LAYOUT_LEV_FAST, MESHLOC_ELEMENT, MESHLOC_NODE, REGRIDMETHOD_BILINEAR, REGRIDMETHOD_CONSERVE,
                    REGRIDMETHOD_NEAREST_STOD, STAGGERLOC_CENTER, STAGGERLOC_CORNER, STAGGERLOC_EDGE1, STAGGERLOC_EDGE2,
                    check)
 
-__all__ = ["Mesh", "Grid", "RouteHandle", "regrid_store", "regrid_store_grid", "rotate_winds_cgrid",
+__all__ = ["MESHLOC_ELEMENT", "MESHLOC_NODE", "Mesh", "Grid", "RouteHandle", "regrid_store", "regrid_store_grid", "rotate_winds_cgrid",
            "REGRIDMETHOD_BILINEAR", "REGRIDMETHOD_CONSERVE", "REGRIDMETHOD_NEAREST_STOD", "STAGGERLOC_CENTER",
            "STAGGERLOC_EDGE1", "STAGGERLOC_EDGE2", "STAGGERLOC_CORNER", "LAYOUT_CELL_FAST", "LAYOUT_LEV_FAST"]
 

@@ -107,6 +107,33 @@ int64_t orc_dual_triangles(int64_t nCells, int64_t nVertices, int maxEdges, cons
 }
 
 /* ------------------------------------------------------------------------------------------
+ * A3. Bilinear, source on nodes (vorticity; interp.F90:350-366, input_data.F90:1116-1123).  The original
+ * mesh is used: Voronoi polygons with values at their corners.  ESMF triangulates polygons with more than 4
+ * sides internally in an undocumented order [ESMF-doc] => IMPLEMENTATION-DEFINED; this restatement (and the
+ * GPU) use the fan from the first listed vertex: triangle k of cell c = (v0, v_{k+1}, v_{k+2}),
+ * id = c*(maxEdges-2)+k, lowest id wins on shared edges.  ftri[3*id+..] = 0-based vertex ids or -1.
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_fan_triangles(int64_t nCells, int maxEdges, const int32_t *voc, const double *vert_xyz, int32_t *ftri) {
+  int nf = maxEdges - 2;
+  int64_t nvalid = 0;
+  for (int64_t t = 0; t < 3 * nCells * nf; ++t) ftri[t] = -1;
+  for (int64_t c = 0; c < nCells; ++c) {
+    int32_t v[64]; int n = 0;
+    for (int j = 0; j < maxEdges && n < 64; ++j) { int32_t x = voc[c * maxEdges + j]; if (x > 0) v[n++] = x - 1; }
+    for (int k = 0; k + 2 < n; ++k) {
+      int64_t t = c * nf + k;
+      int32_t a = v[0], b = v[k + 1], d = v[k + 2];
+      double det = det3_from(v3load(vert_xyz, a), v3load(vert_xyz, b), v3load(vert_xyz, d));
+      if (det == 0) continue;
+      if (det < 0) { int32_t x = b; b = d; d = x; }
+      ftri[3 * t] = a; ftri[3 * t + 1] = b; ftri[3 * t + 2] = d;
+      nvalid++;
+    }
+  }
+  return nvalid;
+}
+
+/* ------------------------------------------------------------------------------------------
  * 3-D box hash: every item registers in each grid cell of [-1,1]^3 its (inflated) AABB touches.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {

@@ -36,6 +36,7 @@ def lib():
         L = C.CDLL(_SO)
         L.orc_dual_triangles.restype = C.c_int64
         L.orc_conserve.restype = C.c_int64
+        L.orc_fan_triangles.restype = C.c_int64
         L.orc_sizeof_proj.restype = C.c_int
         _lib = L
     return _lib
@@ -67,6 +68,15 @@ def dual_triangles(voc, n_vertices, cell_xyz):
     n = lib().orc_dual_triangles(C.c_int64(n_cells), C.c_int64(n_vertices), C.c_int(max_edges), voc.ctypes,
                                  cell_xyz.ctypes, tri.ctypes)
     return tri, int(n)
+
+
+def fan_triangles(voc, vert_xyz):
+    """Fan triangulation of the Voronoi polygons (node-located bilinear, App. A3): [nCells*(maxEdges-2)][3] vertex ids."""
+    voc, vert_xyz = _c(voc, np.int32), _c(vert_xyz, np.float64)
+    n_cells, max_edges = voc.shape
+    ftri = np.empty((n_cells * (max_edges - 2), 3), np.int32)
+    n = lib().orc_fan_triangles(C.c_int64(n_cells), C.c_int(max_edges), voc.ctypes, vert_xyz.ctypes, ftri.ctypes)
+    return ftri, int(n)
 
 
 def bilinear_weights(cell_xyz, tri, pt_xyz):

@@ -215,3 +215,27 @@ def test_rotation_identity(oracle, conus_grid_30km):
     assert np.abs(un - (u * g.cosa + v * g.sina)).max() < 1e-12      # interp.F90:741-742 == rotation by alpha
     assert np.abs(vn - (v * g.cosa - u * g.sina)).max() < 1e-12
     assert np.abs(g.cosa ** 2 + g.sina ** 2 - 1).max() < 1e-14
+
+
+def test_node_located_bilinear_fan(oracle, global_mesh, conus_grid_30km):
+    """App. A3 (vorticity): values on Voronoi vertices, fan triangulation from the first listed vertex."""
+    m, g = global_mesh, conus_grid_30km
+    _, vxyz = mesh_xyz(oracle, m)
+    ftri, nvalid = oracle.fan_triangles(m.verticesOnCell, vxyz)
+    ne = (m.verticesOnCell > 0).sum(1)
+    assert nvalid == (ne - 2).sum()                       # an n-gon gives n-2 fan triangles
+    pxyz = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
+    idx, w = oracle.bilinear_weights(vxyz, ftri, pxyz)
+    assert (idx >= 0).all() and np.abs(w.sum(1) - 1).max() < 1e-13
+    # the three vertices belong to the Voronoi cell of the nearest cell centre (polygon containment)
+    cxyz, _ = mesh_xyz(oracle, m)
+    near = oracle.nearest(cxyz, pxyz)
+    cell_verts = m.verticesOnCell[near] - 1
+    inside = np.array([(np.isin(idx[p], cell_verts[p])).all() for p in range(len(idx))])
+    assert inside.mean() > 0.999                          # shared-edge ties may pick the neighbouring polygon
+    a = np.array([0.2, 0.5, -0.4])
+    got = oracle.apply_fixed(idx, w, (vxyz @ a)[None, :], 1)[0]
+    A, B, C = vxyz[idx[:, 0]], vxyz[idx[:, 1]], vxyz[idx[:, 2]]
+    n = np.cross(B - A, C - A)
+    t = np.einsum("ij,ij->i", A, n) / np.einsum("ij,ij->i", n, pxyz)
+    assert np.abs(got - t * (pxyz @ a)).max() < 1e-13

@@ -216,3 +216,69 @@ def test_errors_are_loud(gpu_lib):
     from mpassit_amd._lib import MpgError
     with pytest.raises(MpgError):
         R.Mesh(np.zeros(4), np.zeros(4), np.zeros(4), np.zeros(4), np.zeros((4, 2), np.int32))  # maxEdges < 3
+
+
+def test_global_latlon_target(gpu_lib, oracle, global_mesh):
+    """BASELINE config 5 in miniature: global mesh -> global lat-lon grid (is_regional=.false.), poles and the
+    date line included; bilinear, nearest and conservative against the oracle, plus global conservation."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    m = global_mesh
+    g = tg.define_target_grid_params("lat-lon", 73, 37, stand_lon=-180.0, is_regional=False)   # 72 x 36, 5 degrees
+    assert g.lat_c[0, 0] == -90.0 and g.lat_c[-1, 0] == 90.0
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    cxyz, vxyz = mesh_xyz(oracle, m)
+    tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    pxyz = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
+    src = synth.analytic_field(m.latCell, m.lonCell, 3)
+    # bilinear: the closed sphere has no hull -> every point mapped
+    idx_o, w_o = oracle.bilinear_weights(cxyz, tri, pxyz)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    idx_g, w_g = rh.weights()
+    assert (idx_g >= 0).all() and (idx_o >= 0).all()
+    assert rel_err(rh.regrid(src, nlev=3).reshape(3, -1), oracle.apply_fixed(idx_o, w_o, src, 3)) < 1e-12
+    rh.release()
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+    assert np.array_equal(rh.weights()[0][:, 0], oracle.nearest(cxyz, pxyz))
+    rh.release()
+    # conservative: 5-degree cells hold ~dozens of source cells each; polar cells degenerate to triangles
+    pc = oracle.lonlat_deg_to_xyz(g.lon_c, g.lat_c)
+    rp_o, col_o, val_o = oracle.conserve(m.verticesOnCell, vxyz, g.nx, g.ny, pc)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    rp_g, col_g, val_g = rh.csr()
+    P = g.nx * g.ny
+    rows = np.repeat(np.arange(P), np.diff(rp_g))
+    assert np.abs(np.bincount(rows, weights=val_g, minlength=P) - 1).max() < 1e-9
+    snow = synth.snow_field(m.latCell, m.lonCell)
+    got = rh.regrid(snow, nlev=1).reshape(-1)
+    assert rel_err(got, oracle.apply_csr(rp_o, col_o, val_o, snow, 1)[0]) < 1e-10
+    # global -> global: sum_j A_j w_ij = A_i for every source cell, hence the global integral is conserved
+    lat_e = np.deg2rad(g.lat_c[:, 0])
+    A_dst = np.repeat(np.deg2rad(5.0) * (np.sin(lat_e[1:]) - np.sin(lat_e[:-1])), g.nx)
+    assert abs(A_dst.sum() - 4 * np.pi) < 1e-12
+    A_src = np.bincount(col_g, weights=val_g * A_dst[rows], minlength=m.nCells)
+    assert abs(A_src.sum() - 4 * np.pi) < 1e-9
+    assert abs((got * A_dst).sum() - (snow[0] * A_src).sum()) < 1e-12
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+@pytest.mark.parametrize("case", ["glob", "regi"])
+def test_node_located_bilinear(case, request, oracle):
+    """vorticity path (interp.F90:350-366): MESHLOC_NODE bilinear with the documented fan triangulation."""
+    from mpassit_amd import regrid as R
+    c = request.getfixturevalue(case)
+    m, g = c["m"], c["g"]
+    ftri, _ = oracle.fan_triangles(m.verticesOnCell, c["vxyz"])
+    pxyz = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
+    idx_o, w_o = oracle.bilinear_weights(c["vxyz"], ftri, pxyz)
+    rh = R.regrid_store(c["mesh"], c["grid"], R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)
+    assert rh.n_src == m.nVertices
+    idx_g, w_g = rh.weights()
+    assert np.array_equal(idx_o[:, 0] >= 0, idx_g[:, 0] >= 0)
+    same = (idx_o == idx_g).all(1)
+    assert same.mean() > 0.999 and np.abs(w_o[same] - w_g[same]).max() < 1e-11
+    vort = np.random.default_rng(9).standard_normal((4, m.nVertices))
+    got = rh.regrid(vort, nlev=4).reshape(4, -1)
+    assert rel_err(got, oracle.apply_fixed(idx_o, w_o, vort, 4)) < 1e-12
+    rh.release()

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10,11,12")
     ap.add_argument("--chunks", default="0")
     ap.add_argument("--fpw", default="1,0")
+    ap.add_argument("--tgroup", default="1")
     ap.add_argument("--lf", default="", help="comma list of lev_fast variants: sweeps the level-fastest kernel instead")
     args = ap.parse_args()
     import torch
@@ -32,7 +33,8 @@ def main():
     src = torch.randn((F, nlev, m.nCells), dtype=torch.float64, device="cuda")
     out = torch.empty((F, nlev, g.ny, g.nx), dtype=torch.float64, device="cuda")
     alg = F * nlev * 8.0 * (U + g.nx * g.ny) + g.nx * g.ny * 36.0
-    combos = [(int(v), int(c), int(f)) for v in args.variants.split(",") for c in args.chunks.split(",") for f in args.fpw.split(",")]
+    combos = [(int(v), int(c), int(f) + 1000 * int(g)) for v in args.variants.split(",") for c in args.chunks.split(",")
+              for f in args.fpw.split(",") for g in args.tgroup.split(",")]
     layout = R.LAYOUT_CELL_FAST
     if args.lf:
         combos = [(int(v), 0, 1) for v in args.lf.split(",")]
@@ -46,7 +48,8 @@ def main():
             else:
                 _lib.tune("a3_variant", v)
                 _lib.tune("lev_chunk", c)
-                _lib.tune("fields_per_wg", fp)
+                _lib.tune("fields_per_wg", fp % 1000)
+                _lib.tune("tile_group", max(1, fp // 1000))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
