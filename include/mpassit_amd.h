@@ -92,6 +92,14 @@ int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc,
 int mpg_regrid(mpg_handle rh, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host);
 int mpg_regrid_dev(mpg_handle rh, const double *src_dev, int src_layout, int nlev, int nfields,
                    double *dst_dev, void *hip_stream);
+/* Fused ingest/egress Regrid (the callers either side of the hot path): the source may be
+ * float32 (MPAS history variables are single precision; the reference widens them at read, input_data.F90:630-655)
+ * and the destination float32 (every output variable is NF90_FLOAT, write_data.F90:779).  The arithmetic stays
+ * float64 and  dst = (dst type)( regrid(src) * scale + offset )  reproduces the writer's post-ops (T - 300,
+ * write_data.F90:1343; PHB * 9.81, :1418), so float32 results are bit-identical to the reference's file contents.
+ * src_f32 / dst_f32: 0 = float64, 1 = float32.  Device pointers, stream as in mpg_regrid_dev. */
+int mpg_regrid_typed_dev(mpg_handle rh, const void *src_dev, int src_f32, int src_layout, int nlev, int nfields,
+                         void *dst_dev, int dst_f32, double scale, double offset, void *hip_stream);
 /* ESMF_FieldBundleRegridRelease (interp.F90:450,455,461) */
 int mpg_handle_release(mpg_handle rh);
 

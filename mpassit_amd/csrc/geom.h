@@ -52,6 +52,12 @@ __device__ __forceinline__ double boxdist2_nofma(double px, double py, double pz
   return (a + b) + c;
 }
 
+// A7: the 3-term weighted sum of every bilinear Regrid kernel, with the FMA pattern pinned so that all kernel
+// variants (cell-fast, level-fast, typed) produce bit-identical results
+__device__ __forceinline__ double wsum3(double w0, double a, double w1, double b, double w2, double e) {
+  return fma(w2, e, fma(w1, b, w0 * a));
+}
+
 // A5: signed spherical triangle area (Van Oosterom-Strackee), difference form
 __device__ __forceinline__ double sph_tri_area(dv3 a, dv3 b, dv3 c) {
   double num = det3_from(a, b, c);

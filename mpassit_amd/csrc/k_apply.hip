@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
-        v[r] = ww[r][0] * a + ww[r][1] * b + ww[r][2] * e;
+        v[r] = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
       }
 #pragma unroll
       for (int r = 0; r < RPT; ++r)
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ i
         c0 = max(c0, 0); c1 = max(c1, 0); c2 = max(c2, 0);
         const double *r0 = sf + (int64_t)c0 * nlev, *r1 = sf + (int64_t)c1 * nlev, *r2 = sf + (int64_t)c2 * nlev;
         double a = r0[kk], b = r1[kk], e = r2[kk];
-        v[u] = m ? w0 * a + w1 * b + w2 * e : 0.0;
+        v[u] = m ? wsum3(w0, a, w1, b, w2, e) : 0.0;
       }
       if (kact) {
 #pragma unroll
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_applyN(const int32_t *__restrict__ idx,
     double acc = 0.0;
     if (mapped) {
 #pragma unroll
-      for (int q = 0; q < NNZ; ++q) acc += ww[q] * (lev_fast ? sf[(int64_t)c[q] * nlev + k] : sf[(int64_t)k * nsrc + c[q]]);
+      for (int q = 0; q < NNZ; ++q) acc = fma(ww[q], (lev_fast ? sf[(int64_t)c[q] * nlev + k] : sf[(int64_t)k * nsrc + c[q]]), acc);
     }
     df[(int64_t)k * P + p] = acc;
   }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_apply_csr(const int32_t *__restrict__ r
     double acc = 0.0;
     for (int q = b; q < e; ++q) {
       int32_t c = col[q];
-      acc += val[q] * (lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]);
+      acc = fma(val[q], (lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]), acc);
     }
     df[(int64_t)k * P + p] = acc;
   }

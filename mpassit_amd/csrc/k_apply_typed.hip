@@ -1,0 +1,200 @@
+// Fused ingest / egress variants of the Regrid kernels (the callers either side of the
+// hot path).  The reference widens the single-precision MPAS history variables to float64 when it reads them
+// (nf90_get_var into real(8) buffers, input_data.F90:630-655), regrids in float64 and narrows every output
+// variable back to float32 when it writes (all NF90_FLOAT, write_data.F90:779), after two scalar post-ops:
+// T - 300 (write_data.F90:1343) and PHB * 9.81 (:1418).  These kernels read float32 or float64 sources, do the
+// identical float64 arithmetic and store float32 or float64 with an affine epilogue:
+//     dst = (TD)( regrid(src) * scale + offset )
+// so the float32 results are bit-identical to what the reference's writer would put in the file, while the
+// HBM traffic per 3-D field drops from 8+8 to 4+4 bytes per source/destination element.
+// Same structure as k_apply3_cf<2,4,true> / k_apply3_lf<64> in k_apply.hip.
+#include "geom.h"
+#include "mpg_internal.h"
+
+__device__ __forceinline__ unsigned xcd_remap_t(unsigned lin, unsigned n) {
+  unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                     const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                     int nlev, int ntx, int nty, double scale, double offset) {
+  constexpr int RPT = 2, TY = 4 * RPT;
+  int64_t P = (int64_t)nx * ny;
+  unsigned ntile = (unsigned)ntx * nty;
+  unsigned lin = xcd_remap_t(blockIdx.x, gridDim.x);
+  unsigned tile = lin % ntile;
+  int fld = lin / ntile;
+  int tx = tile % ntx, ty = tile / ntx;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int i = tx * 64 + lane;
+  int j0 = ty * TY + wave * RPT;
+  int32_t c[RPT][3];
+  double ww[RPT][3];
+  bool act[RPT], mapped[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    int j = j0 + r;
+    act[r] = (i < nx) && (j < ny);
+    int64_t p = act[r] ? (int64_t)j * nx + i : 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      c[r][q] = idx[q * P + p];
+      ww[r][q] = w[q * P + p];
+    }
+    mapped[r] = c[r][0] >= 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
+  }
+  const TS *s = src + (int64_t)fld * nlev * nsrc;
+  TD *d = dst + (int64_t)fld * nlev * P + (int64_t)j0 * nx + i;
+  for (int k = 0; k < nlev; ++k) {
+    __syncthreads();
+    double v[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      double a = (double)s[c[r][0]], b = (double)s[c[r][1]], e = (double)s[c[r][2]];
+      v[r] = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      if (act[r]) __builtin_nontemporal_store((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), d + (int64_t)r * nx);
+    s += nsrc;
+    d += P;
+  }
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                     const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                     int nlev, int ntx, int nty, double scale, double offset) {
+  extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
+  double *sw = tile + (size_t)nlev * 65;
+  int32_t *sidx = (int32_t *)(sw + 192);
+  int64_t P = (int64_t)nx * ny;
+  unsigned ntile = (unsigned)ntx * nty;
+  unsigned lin = xcd_remap_t(blockIdx.x, gridDim.x);
+  unsigned tl = lin % ntile;
+  int fld = lin / ntile;
+  int tx = tl % ntx, ty = tl / ntx;
+  int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 192) {
+    int pt = t & 63, q = t >> 6;
+    int i = tx * 64 + pt, j = ty;
+    bool in = i < nx && j < ny;
+    int64_t p = in ? (int64_t)j * nx + i : 0;
+    int32_t c = idx[q * P + p];
+    sidx[q * 64 + pt] = in ? c : -1;
+    sw[q * 64 + pt] = w[q * P + p];
+  }
+  __syncthreads();
+  const TS *sf = src + (int64_t)fld * nlev * nsrc;
+  for (int kb = 0; kb < nlev; kb += 64) {
+    int k = kb + lane;
+    bool kact = k < nlev;
+    int kk = kact ? k : 0;
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += 4) {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int pt = wave * 16 + q0 + u;
+        int32_t c0 = __builtin_amdgcn_readfirstlane(sidx[pt]);
+        int32_t c1 = __builtin_amdgcn_readfirstlane(sidx[64 + pt]);
+        int32_t c2 = __builtin_amdgcn_readfirstlane(sidx[128 + pt]);
+        double w0 = sw[pt], w1 = sw[64 + pt], w2 = sw[128 + pt];
+        bool m = c0 >= 0;
+        c0 = max(c0, 0); c1 = max(c1, 0); c2 = max(c2, 0);
+        const TS *r0 = sf + (int64_t)c0 * nlev, *r1 = sf + (int64_t)c1 * nlev, *r2 = sf + (int64_t)c2 * nlev;
+        double a = (double)r0[kk], b = (double)r1[kk], e = (double)r2[kk];
+        v[u] = fma(m ? wsum3(w0, a, w1, b, w2, e) : 0.0, scale, offset);
+      }
+      if (kact) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tile[k * 65 + wave * 16 + q0 + u] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  TD *df = dst + (int64_t)fld * nlev * P;
+  int i = tx * 64 + lane, j = ty;
+  if (i < nx && j < ny) {
+    int64_t p = (int64_t)j * nx + i;
+    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store((TD)tile[k * 65 + lane], df + (int64_t)k * P + p);
+  }
+}
+
+// nearest (NNZ = 1, weights implicit), 4-point destagger (NNZ = 4) and CSR (NNZ = 0): one thread per target point
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void k_apply_generic_t(int nnz_per_row, const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                         const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ val, const TS *__restrict__ src,
+                                                         TD *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast, int nblk,
+                                                         double scale, double offset) {
+  unsigned blk = blockIdx.x % nblk;
+  int fld = blockIdx.x / nblk;
+  int64_t p = (int64_t)blk * 256 + threadIdx.x;
+  if (p >= P) return;
+  const TS *sf = src + (int64_t)fld * nlev * nsrc;
+  TD *df = dst + (int64_t)fld * nlev * P;
+  for (int k = 0; k < nlev; ++k) {
+    double acc = 0.0;
+    if (nnz_per_row == 0) {
+      for (int q = rowptr[p]; q < rowptr[p + 1]; ++q) {
+        int32_t c = col[q];
+        acc = fma(val[q], (double)(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]), acc);
+      }
+    } else if (nnz_per_row == 1) {
+      int32_t c = idx[p];
+      if (c >= 0) acc = (double)(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]);
+    } else if (idx[p] >= 0) {
+      for (int q = 0; q < nnz_per_row; ++q) {
+        int32_t c = idx[q * P + p];
+        acc = fma(w[q * P + p], (double)(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]), acc);
+      }
+    }
+    df[(int64_t)k * P + p] = (TD)fma(acc, scale, offset);
+  }
+}
+
+template <typename TS, typename TD>
+static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, int nfields, void *dst, double scale, double offset,
+                        hipStream_t s) {
+  int64_t P = h->n_dst;
+  int lev_fast = layout == MPG_LAYOUT_LEV_FAST;
+  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3) {
+    if (lev_fast) {
+      int ntx = (h->nx_dst + 63) / 64, nty = h->ny_dst;
+      size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
+      if (lds > 160 * 1024) {
+        mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
+        return MPG_ERR_UNSUPPORTED;
+      }
+      if (lds > 48 * 1024)
+        MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      k_apply3_lf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
+                                                                           h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+    } else {
+      int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 7) / 8;
+      k_apply3_cf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, 0, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
+                                                                         h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+    }
+  } else {
+    int nblk = (int)((P + 255) / 256);
+    k_apply_generic_t<TS, TD><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->kind == MPG_KIND_CSR ? 0 : h->nnz_per_row, h->idx.p, h->w.p,
+                                                                      h->rowptr.p, h->col.p, h->val.p, (const TS *)src, (TD *)dst, P,
+                                                                      h->n_src, nlev, lev_fast, nblk, scale, offset);
+  }
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
+                      double scale, double offset, hipStream_t s) {
+  if (h->n_dst == 0 || nlev == 0 || nfields == 0) return MPG_SUCCESS;
+  if (src_f32 && dst_f32) return launch_typed<float, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  if (src_f32) return launch_typed<float, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  if (dst_f32) return launch_typed<double, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  return launch_typed<double, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+}

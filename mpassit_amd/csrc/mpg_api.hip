@@ -277,6 +277,16 @@ int mpg_regrid_dev(mpg_handle h, const double *src_dev, int src_layout, int nlev
   return mpg_k_apply(h, src_dev, src_layout, nlev, nfields, dst_dev, (hipStream_t)hip_stream);
 }
 
+int mpg_regrid_typed_dev(mpg_handle h, const void *src_dev, int src_f32, int src_layout, int nlev, int nfields, void *dst_dev,
+                         int dst_f32, double scale, double offset, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && src_dev && dst_dev, "mpg_regrid_typed: NULL argument");
+  MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid_typed: nlev and nfields must be >= 1");
+  MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid_typed: bad src_layout");
+  MPG_ARG((src_f32 == 0 || src_f32 == 1) && (dst_f32 == 0 || dst_f32 == 1), "mpg_regrid_typed: src_f32/dst_f32 must be 0 or 1");
+  return mpg_k_apply_typed(h, src_dev, src_f32, src_layout, nlev, nfields, dst_dev, dst_f32, scale, offset, (hipStream_t)hip_stream);
+}
+
 int mpg_regrid(mpg_handle h, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host) {
   MPG_CHECK_INIT();
   MPG_ARG(h && src_host && dst_host, "mpg_regrid: NULL argument");

@@ -149,6 +149,22 @@ class RouteHandle:
         check(L.load().mpg_regrid(self._h, _ptr(src), C.c_int(layout), C.c_int(nlev), C.c_int(nfields), _ptr(out)))
         return out
 
+    def regrid_typed(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offset=0.0, out=None):
+        """Fused ingest/egress Regrid on device tensors: float32 or float64 source (as in the MPAS file), float32 or
+        float64 destination (as in the output file), float64 arithmetic, dst = cast(regrid(src)*scale + offset)."""
+        import torch
+        if not (src.is_cuda and src.is_contiguous() and src.dtype in (torch.float32, torch.float64)):
+            raise ValueError("regrid_typed needs a contiguous float32/float64 CUDA tensor")
+        if src.numel() != nfields * nlev * self.n_src:
+            raise ValueError("source has %d elements, handle expects %d" % (src.numel(), nfields * nlev * self.n_src))
+        out_dtype = out_dtype or src.dtype
+        if out is None:
+            out = torch.empty((nfields, nlev, self.ny_dst, self.nx_dst), dtype=out_dtype, device=src.device)
+        check(L.load().mpg_regrid_typed_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(int(src.dtype == torch.float32)), C.c_int(layout),
+                                            C.c_int(nlev), C.c_int(nfields), C.c_void_p(out.data_ptr()),
+                                            C.c_int(int(out.dtype == torch.float32)), C.c_double(scale), C.c_double(offset), _stream_ptr()))
+        return out
+
     def weights(self):
         """(idx [n_dst][nnz_per_row] int32 with -1 = unmapped, w [n_dst][nnz_per_row])."""
         idx = np.empty((self.n_dst, self.nnz_per_row), np.int32)
