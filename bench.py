@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--workload", default="c4_3m_regional")
     ap.add_argument("--fields", type=int, default=13, help="3-D fields per Regrid bundle (histlist_3d has 13 nz fields)")
     ap.add_argument("--layout", default="cell_fast", choices=["cell_fast", "lev_fast"])
+    ap.add_argument("--io", default="f64", choices=["f64", "f32"], help="field element type in HBM; f64 = reference-faithful headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--calib", action="store_true", help="also launch a known-byte-count streaming kernel (PMC calibration)")
@@ -112,7 +113,13 @@ def main():
     src_for_kernel = local
     if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
         src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()
-    out = torch.empty((F, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dtype=torch.float64, device=dev)
+    io32 = args.io == "f32"
+    if io32:  # fused ingest/egress variant: float32 in HBM on both sides, float64 arithmetic (not the headline)
+        if world > 1:
+            raise SystemExit("--io f32 is single-GPU only")
+        src_for_kernel = src_for_kernel.float()
+        del local
+    out = torch.empty((F, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dtype=torch.float32 if io32 else torch.float64, device=dev)
     torch.cuda.synchronize()
 
     ev = []
@@ -148,7 +155,10 @@ def main():
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        sr.rh.regrid(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+        if io32:
+            sr.rh.regrid_typed(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+        else:
+            sr.rh.regrid(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
         if record:
             e1.record()
             ev.append((e0, e1))
@@ -214,15 +224,16 @@ def main():
     del cp_a, cp_b
 
     U = sr.n_needed
-    alg_bytes = F * nlev * 8.0 * (U + P_local) + P_local * 36.0  # U*L*e + P*L*e per field + P*36 once per launch
+    esz = 4.0 if io32 else 8.0  # element size of the field values in HBM (float64 = reference-faithful headline)
+    alg_bytes = F * nlev * esz * (U + P_local) + P_local * 36.0  # U*L*e + P*L*e per field + P*36 once per launch
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s_f%d_%s.json" % (args.workload, F, args.layout))
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_f%d_%s%s.json" % (args.workload, F, args.layout, "_io32" if io32 else ""))
     if world == 1 and os.path.exists(tpath):
         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not io32:
         cpu = cpu_baseline(sr, src_for_kernel if layout == R.LAYOUT_CELL_FAST else local, nlev, args.cpu_seconds)
 
     if rank == 0:
@@ -234,6 +245,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %s" % (args.workload, desc), "fields_per_step": F, "nlev": nlev, "nCells": int(m.nCells),
                        "target_points": int(g.nx * g.ny), "method": "bilinear", "src_layout": args.layout,
+                       "io_dtype": "f32 (fused ingest/egress, f64 arithmetic)" if io32 else "f64",
                        "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
                        "unmapped_points_rank0": n_unmapped},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
