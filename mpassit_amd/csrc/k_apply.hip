@@ -121,11 +121,14 @@ static int g_tgroup = 1;      // "tile_group" knob: tile rows per band (1 = plai
 //          row base), so each gather is one coalesced nlev*8-byte row read; 4 points (12 loads) in flight;
 // phase 2: lanes = points: TXL*8-byte contiguous non-temporal stores per level.
 // LDS tile [nlev][65] doubles (row pad 1: conflict-free ds_write_b64 column writes).
-template <int TXL>
-__global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ idx, const double *__restrict__ w,
-                                                   const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
-                                                   int64_t nsrc, int nlev, int ntx, int nty) {
-  constexpr int TYL = 64 / TXL;
+// WAVES = waves per workgroup (64/WAVES points per wave), BATCH = points whose 3 row loads are issued before the
+// wave waits (memory-level parallelism per wave = 3*BATCH loads of nlev*8 bytes).
+template <int TXL, int WAVES, int BATCH>
+__global__ __launch_bounds__(64 * WAVES) void k_apply3_lf(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                          const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                          int64_t nsrc, int nlev, int ntx, int nty, int nfields, int fpw) {
+  constexpr int TYL = 64 / TXL, PPW = 64 / WAVES;
+  static_assert(PPW % BATCH == 0, "batch must divide the points per wave");
   extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
   double *sw = tile + (size_t)nlev * 65;
   int32_t *sidx = (int32_t *)(sw + 192);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ i
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tl = lin % ntile;
-  int fld = lin / ntile;
+  int f0 = (lin / ntile) * fpw, f1 = min(nfields, f0 + fpw);
   int tx = tl % ntx, ty = tl / ntx;
   int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 192) {
@@ -146,17 +149,21 @@ __global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ i
     sw[q * 64 + pt] = w[q * P + p];
   }
   __syncthreads();
+  int oi = tx * TXL + (lane % TXL), oj = ty * TYL + (lane / TXL);
+  bool oact = oi < nx && oj < ny;
+  int64_t op = oact ? (int64_t)oj * nx + oi : 0;
+ for (int fld = f0; fld < f1; ++fld) {   // the tile's indices/weights stay staged in LDS for all its fields
   const double *sf = src + (int64_t)fld * nlev * nsrc;
   for (int kb = 0; kb < nlev; kb += 64) {
     int k = kb + lane;
     bool kact = k < nlev;
     int kk = kact ? k : 0;
 #pragma unroll
-    for (int q0 = 0; q0 < 16; q0 += 4) {
-      double v[4];
+    for (int q0 = 0; q0 < PPW; q0 += BATCH) {
+      double v[BATCH];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int pt = wave * 16 + q0 + u;
+      for (int u = 0; u < BATCH; ++u) {
+        int pt = wave * PPW + q0 + u;
         int32_t c0 = __builtin_amdgcn_readfirstlane(sidx[pt]);
         int32_t c1 = __builtin_amdgcn_readfirstlane(sidx[64 + pt]);
         int32_t c2 = __builtin_amdgcn_readfirstlane(sidx[128 + pt]);
@@ -169,22 +176,26 @@ __global__ __launch_bounds__(256) void k_apply3_lf(const int32_t *__restrict__ i
       }
       if (kact) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) tile[k * 65 + wave * 16 + q0 + u] = v[u];
+        for (int u = 0; u < BATCH; ++u) tile[k * 65 + wave * PPW + q0 + u] = v[u];
       }
     }
   }
   __syncthreads();
   double *df = dst + (int64_t)fld * nlev * P;
-  int i = tx * TXL + (lane % TXL), j = ty * TYL + (lane / TXL);
-  if (i < nx && j < ny) {
-    int64_t p = (int64_t)j * nx + i;
-    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + p);
-  }
+  if (oact)
+    for (int k = wave; k < nlev; k += WAVES) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + op);
+  __syncthreads();   // the tile is rewritten by the next field
+ }
 }
-typedef void (*apply3lf_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int);
-struct LfVariant { int txl; apply3lf_fn fn; };
-static const LfVariant g_lf_variants[] = {{16, k_apply3_lf<16>}, {32, k_apply3_lf<32>}, {64, k_apply3_lf<64>}, {8, k_apply3_lf<8>}};
-static int g_lf_variant = 2;  // "lf_variant" knob (64 x 1 tiles: tuned on MI355X)
+typedef void (*apply3lf_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int);
+struct LfVariant { int txl, waves; apply3lf_fn fn; };
+static const LfVariant g_lf_variants[] = {
+    {64, 4, k_apply3_lf<64, 4, 4>},  {64, 4, k_apply3_lf<64, 4, 8>},  {64, 4, k_apply3_lf<64, 4, 16>}, {64, 8, k_apply3_lf<64, 8, 8>},
+    {64, 8, k_apply3_lf<64, 8, 4>},  {64, 16, k_apply3_lf<64, 16, 4>}, {64, 16, k_apply3_lf<64, 16, 2>}, {32, 8, k_apply3_lf<32, 8, 8>},
+    {64, 2, k_apply3_lf<64, 2, 16>}, {64, 2, k_apply3_lf<64, 2, 8>},
+};
+static int g_lf_variant = 4;  // "lf_variant" knob (8 waves x 8 points, 4 points in flight: tuned on MI355X)
+static int g_lf_fpw = 1;      // "lf_fields_per_wg" knob (looping fields inside a workgroup measured slower)
 
 // nearest neighbour: bit-exact copy
 __global__ __launch_bounds__(256) void k_apply1(const int32_t *__restrict__ idx, const double *__restrict__ src,
@@ -287,6 +298,7 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }
   if (!strcmp(key, "fields_per_wg")) { g_fpw = value; return MPG_SUCCESS; }
   if (!strcmp(key, "tile_group")) { g_tgroup = value < 1 ? 1 : value; return MPG_SUCCESS; }
+  if (!strcmp(key, "lf_fields_per_wg")) { g_lf_fpw = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_variant")) {
     if (value < 0 || value >= (int)(sizeof(g_lf_variants) / sizeof(g_lf_variants[0]))) return MPG_ERR_INVALID_ARG;
     g_lf_variant = value;
@@ -332,7 +344,10 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
         return MPG_ERR_UNSUPPORTED;
       }
       if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)lv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      lv.fn<<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty);
+      int fpw = g_lf_fpw < nfields ? g_lf_fpw : nfields;
+      int ngroups = (nfields + fpw - 1) / fpw;
+      lv.fn<<<(unsigned)ntx * nty * ngroups, 64 * lv.waves, lds, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
+                                                                     nfields, fpw);
     } else {
       const A3Variant &av = g_a3_variants[g_a3_variant];
       int tyv = av.waves * av.rpt;

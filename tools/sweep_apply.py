@@ -37,7 +37,7 @@ def main():
               for f in args.fpw.split(",") for g in args.tgroup.split(",")]
     layout = R.LAYOUT_CELL_FAST
     if args.lf:
-        combos = [(int(v), 0, 1) for v in args.lf.split(",")]
+        combos = [(int(v), 0, int(f)) for v in args.lf.split(",") for f in args.fpw.split(",")]
         layout = R.LAYOUT_LEV_FAST
         src = src.permute(0, 2, 1).contiguous()
     times = {c: [] for c in combos}
@@ -45,6 +45,7 @@ def main():
         for v, c, fp in combos:
             if args.lf:
                 _lib.tune("lf_variant", v)
+                _lib.tune("lf_fields_per_wg", max(1, fp))
             else:
                 _lib.tune("a3_variant", v)
                 _lib.tune("lev_chunk", c)
