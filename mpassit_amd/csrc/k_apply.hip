@@ -326,6 +326,10 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
   int64_t P = h->n_dst;
   int lev_fast = layout == MPG_LAYOUT_LEV_FAST;
   if (P == 0 || nlev == 0 || nfields == 0) return MPG_SUCCESS;
+  if (h->n_src == 0) {  // nothing is mapped (e.g. a row shard entirely outside the mesh): zero-filled destination
+    MPG_HIP(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)P * nlev * nfields, s));
+    return MPG_SUCCESS;
+  }
   int nblk = (int)((P + 255) / 256);
   if (h->kind == MPG_KIND_CSR) {
     k_apply_csr<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->rowptr.p, h->col.p, h->val.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);

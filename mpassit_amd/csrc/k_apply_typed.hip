@@ -193,6 +193,14 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
 int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
                       double scale, double offset, hipStream_t s) {
   if (h->n_dst == 0 || nlev == 0 || nfields == 0) return MPG_SUCCESS;
+  if (h->n_src == 0) {  // nothing mapped: the destination is the epilogue of 0.0
+    if (offset != 0.0) {
+      mpg_set_error("mpg_regrid_typed: handle without sources and a non-zero offset is not supported");
+      return MPG_ERR_UNSUPPORTED;
+    }
+    MPG_HIP(hipMemsetAsync(dst, 0, (dst_f32 ? 4 : 8) * (size_t)h->n_dst * nlev * nfields, s));
+    return MPG_SUCCESS;
+  }
   if (src_f32 && dst_f32) return launch_typed<float, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
   if (src_f32) return launch_typed<float, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
   if (dst_f32) return launch_typed<double, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);

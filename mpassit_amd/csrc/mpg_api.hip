@@ -271,7 +271,7 @@ int mpg_handle_release(mpg_handle h) {
 // ---- Regrid ---------------------------------------------------------------------------------------
 int mpg_regrid_dev(mpg_handle h, const double *src_dev, int src_layout, int nlev, int nfields, double *dst_dev, void *hip_stream) {
   MPG_CHECK_INIT();
-  MPG_ARG(h && src_dev && dst_dev, "mpg_regrid: NULL argument");
+  MPG_ARG(h && dst_dev && (src_dev || h->n_src == 0), "mpg_regrid: NULL argument");
   MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid: nlev and nfields must be >= 1");
   MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid: bad src_layout");
   return mpg_k_apply(h, src_dev, src_layout, nlev, nfields, dst_dev, (hipStream_t)hip_stream);
@@ -280,7 +280,7 @@ int mpg_regrid_dev(mpg_handle h, const double *src_dev, int src_layout, int nlev
 int mpg_regrid_typed_dev(mpg_handle h, const void *src_dev, int src_f32, int src_layout, int nlev, int nfields, void *dst_dev,
                          int dst_f32, double scale, double offset, void *hip_stream) {
   MPG_CHECK_INIT();
-  MPG_ARG(h && src_dev && dst_dev, "mpg_regrid_typed: NULL argument");
+  MPG_ARG(h && dst_dev && (src_dev || h->n_src == 0), "mpg_regrid_typed: NULL argument");
   MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid_typed: nlev and nfields must be >= 1");
   MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid_typed: bad src_layout");
   MPG_ARG((src_f32 == 0 || src_f32 == 1) && (dst_f32 == 0 || dst_f32 == 1), "mpg_regrid_typed: src_f32/dst_f32 must be 0 or 1");
@@ -426,7 +426,7 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
   MPG_CHECK_INIT();
   MPG_ARG(h, "mpg_handle_rebase: NULL handle");
   MPG_ARG(!h->localized, "mpg_handle_rebase: handle already localized");
-  MPG_ARG(base >= 0 && n_local > 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
+  MPG_ARG(base >= 0 && n_local >= 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
   if (h->cached) {
     g_cache.erase(h->key);
     h->cached = false;

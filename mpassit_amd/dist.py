@@ -71,11 +71,17 @@ class HaloSchedule:
         nlo = int(needed_ids[0]) if needed_ids.size else pr[0]
         nhi = int(needed_ids[-1] + 1) if needed_ids.size else pr[0]
         # banded numbering <=> the covering range of the needed ids is not much larger than their count
-        want_range = needed_ids.size > 0 and (nhi - nlo) <= range_slack * needed_ids.size
-        votes = all_gather_object((bool(want_range), nlo, nhi))
+        empty = needed_ids.size == 0          # e.g. a row shard that lies entirely outside the mesh footprint
+        want_range = empty or (nhi - nlo) <= range_slack * needed_ids.size
+        votes = all_gather_object((bool(want_range), nlo, nhi, bool(empty)))
         mode = "range" if all(v[0] for v in votes) else "compact"
         if mode == "range" and ownership == "aligned":
             los, his = [v[1] for v in votes], [v[2] for v in votes]
+            prev = min([v[1] for v in votes if not v[3]], default=0)
+            for q in range(world):            # ranks that need nothing own an empty block right after their predecessor
+                if votes[q][3]:
+                    los[q] = his[q] = prev
+                prev = his[q]
             if any(los[q] < los[q - 1] or his[q] < his[q - 1] for q in range(1, world)):
                 ownership = "para_range"     # row blocks do not map to increasing id ranges
         if mode == "range" and ownership == "aligned":

@@ -22,7 +22,7 @@ def _free_port():
 
 def _worker(rank, world, port, shuffle, ownership, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=90))
     try:
         from mpassit_amd import dist as mdist, synth, target_grid as tg
         from oracle import oracle as o

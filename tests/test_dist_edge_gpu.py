@@ -1,0 +1,85 @@
+"""Row-sharded path, edge case: a rank whose target rows lie entirely outside the mesh footprint (nothing mapped,
+empty halo, zero-filled output) next to ranks that do real work; 3 ranks on one card over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    from mpassit_amd import synth, target_grid as tg
+    g = tg.define_target_grid_params("lambert", 121, 91, dx=30000.0, dy=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
+                                     truelat2=38.5, stand_lon=-97.5)
+    # mesh covers only the lower ~55 % of the target rows: the top third of the rows (rank 2 of 3) sees no mesh at all
+    m = synth.regional_mesh_for_lambert(g.proj, 121, 50, 12000, margin=0.0)
+    return m, g
+
+
+def _rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=90))
+    try:
+        from mpassit_amd import _lib, dist as mdist, regrid as R, synth
+        _lib.init(0)
+        m, g = _case()
+
+        def ago(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, ago)
+        nlev = 3
+        full = synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5)
+        c0, c1 = sr.sched.own
+        local = sr.local_buffer(1, nlev, "cuda")
+        local.fill_(float("nan"))
+        own = sr.own_view(local)
+        own.copy_(torch.as_tensor(np.ascontiguousarray(full[:, c0:c1])))
+        sr.sched.exchange(own, local, pack_fn=sr._pack)
+        out = sr.rh.regrid(local.view(-1), nlev=nlev)
+        torch.cuda.synchronize()
+        q.put((rank, sr.j0, sr.j1, out.cpu().numpy(), sr.sched.mode, sr.n_needed, sr.sched.n_local))
+        sr.destroy()
+        _lib.finalize()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_without_sources(gpu_lib):
+    import torch.multiprocessing as mp
+    from mpassit_amd import regrid as R, synth
+    m, g = _case()
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    want = rh.regrid(synth.analytic_field(m.latCell, m.lonCell, 3, seed=5), nlev=3)
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(3)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[2][5] == 0 and res[2][6] == 0            # the top shard references no source cell at all
+    assert (res[2][3] == 0.0).all()                      # ... and is zero-filled like the reference's unmapped points
+    assert all(r[4] == "range" for r in res)
+    got = np.concatenate([r[3] for r in res], axis=2)
+    assert np.array_equal(got, want)

@@ -132,7 +132,7 @@ def _rank_main(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=90))
     try:
         from mpassit_amd import _lib, dist as mdist, regrid as R, synth, workloads
         _lib.init(0)
