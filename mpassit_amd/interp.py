@@ -60,6 +60,10 @@ def _bundle_regrid(rh, arrs, nlev, layout):
     """ESMF_FieldBundleRegrid: one weight set, nfields fields of equal level count."""
     if not arrs:
         return []
+    if _is_torch(arrs[0]):
+        # device-resident fields live in separate tensors: regrid them one by one through the shared handle
+        # (identical to the bundle call, SURVEY App. A7) instead of stacking gigabytes into a temporary
+        return [rh.regrid(a.contiguous().reshape(-1), nlev=nlev, layout=layout)[0] for a in arrs]
     out = rh.regrid(_stack(arrs).reshape(-1), nlev=nlev, nfields=len(arrs), layout=layout)
     return [out[i] for i in range(len(arrs))]
 

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Whole-job run of the hot path (`interp_data`: every RegridStore + Regrid + rotation + destaggering of a run)
+on the BASELINE.json configurations, device-resident synthetic inputs, reference default variable lists.
+
+  python tools/run_config.py --config 2     # 655 362-cell mesh, full histlist_2d + histlist_3d, bilinear + nearest
+  python tools/run_config.py --config 3     # + conservative snow fields + histlist_soil
+  python tools/run_config.py --config 4     # 3.0 M-cell mesh, full diag + hist field set
+
+Prints one JSON line: wall time of the whole sequence (Stores included, handle cache cold), 3-D fields per second
+and a per-phase breakdown.  This is a job-level illustration next to bench.py's Regrid-only headline."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+HIST_2D = [("xland", "XLAND"), ("skintemp", "TSK"), ("snow", "SNOW"), ("snowh", "SNOWH"), ("sst", "SST")]
+HIST_3D = [("zgrid", "PHB"), ("w", "W"), ("theta", "T"), ("uReconstructZonal", "U"), ("uReconstructMeridional", "V"), ("qv", "QVAPOR"),
+           ("qc", "QCLOUD"), ("qr", "QRAIN"), ("qi", "QICE"), ("qs", "QSNOW"), ("qg", "QGRAUP"), ("ni", "QNICE"), ("nr", "QNRAIN"),
+           ("pressure", "P_HYD"), ("rho", "MUB")]
+SOIL = [("tslb", "TSLB"), ("smois", "SMOIS"), ("sh2o", "SH2O")]
+DIAG = [("rainc", "RAINC"), ("rainnc", "RAINNC"), ("snowncv", "SNOWNCV"), ("rainncv", "RAINNCV"), ("graupelncv", "GRAUPELNCV"),
+        ("prec_acc_c", "PREC_ACC_C"), ("prec_acc_nc", "PREC_ACC_NC"), ("snow_acc_nc", "SNOW_ACC_NC"), ("refl10cm", "REFL_10CM"),
+        ("refl10cm_max", "COMPOSITE_REFL_10CM"), ("refl10cm_1km", "REFL_10CM_1KM"), ("refl10cm_1km_max", "REFL_10CM_1KM_MAX"),
+        ("u10", "U10"), ("v10", "V10"), ("q2", "Q2"), ("t2m", "T2"), ("th2m", "TH2"), ("updraft_helicity_max", "UP_HELI_MAX"),
+        ("w_velocity_max", "W_UP_MAX"), ("surface_pressure", "PSFC")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4])
+    ap.add_argument("--wrf-mod-vars", action="store_true", default=True)
+    args = ap.parse_args()
+    import torch
+    from mpassit_amd import _lib, interp as I, regrid as R, workloads
+    _lib.init(0)
+    wl = "c4_3m_regional" if args.config == 4 else "c2_655k_regional"
+    m, g, nz, desc = workloads.workload(wl)
+    nsoil = 4
+    dev = "cuda"
+    rng = torch.Generator(device=dev)
+    rng.manual_seed(20240807)
+
+    def f2():
+        return torch.rand(m.nCells, dtype=torch.float64, device=dev, generator=rng)
+
+    def f3(L):
+        return torch.rand((L, m.nCells), dtype=torch.float64, device=dev, generator=rng)
+    h2 = [p for p in HIST_2D if args.config >= 3 or p[0] not in ("snow", "snowh")]
+    soil = SOIL if args.config >= 3 else []
+    diag = DIAG if args.config == 4 else []
+    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil, hgt=f2())
+    for n, _ in h2:
+        inp.hist[n] = torch.floor(f2() * 3) if n == "xland" else f2()
+    for n, _ in HIST_3D:
+        inp.hist[n] = f3(nz + 1 if n in ("zgrid", "w") else nz)
+    for n, _ in soil:
+        inp.hist[n] = f3(nsoil)
+    for n, _ in diag:
+        inp.diag[n] = f3(nz) if n == "refl10cm" else f2()
+    cfg = I.InterpConfig(interp_diag=bool(diag), wrf_mod_vars=args.wrf_mod_vars, diag_list=diag, hist_2d=h2, hist_3d=HIST_3D, hist_soil=soil)
+    t0 = time.perf_counter()
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    torch.cuda.synchronize()
+    t_geom = time.perf_counter() - t0
+    times = []
+    for rep in range(3):   # rep 0: cold handle cache (Stores included); later reps: a second time level of the same run
+        handles = []
+        if rep > 0:   # keep the weight sets alive like a multi-time-level driver would
+            handles = [R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR), R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD),
+                       R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1), R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2)]
+            if args.config >= 3:
+                handles.append(R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = I.interp_data(mesh, grid, g, inp, cfg)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        for h in handles:
+            h.release()
+    n3d = sum(1 for v in out.values() if v.ndim == 3 and v.shape[0] >= nz)
+    rec = {"config": args.config, "workload": desc, "outputs": len(out), "fields_3d": n3d,
+           "geometry_ingest_s": t_geom, "job_s_cold": times[0], "job_s_warm": min(times[1:]),
+           "fields_3d_per_s_cold": n3d / times[0], "fields_3d_per_s_warm": n3d / min(times[1:])}
+    print(json.dumps(rec))
+    mesh.destroy()
+    grid.destroy()
+
+
+if __name__ == "__main__":
+    main()
