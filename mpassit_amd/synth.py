@@ -153,6 +153,16 @@ def regional_mesh_for_lambert(proj, nx, ny, n_cells, margin=0.05, seed=SEED):
     return regional_hex_mesh(proj, x0, y0, q_cells, r_cells, spacing, seed=seed)
 
 
+def shuffle_cells(m, seed=SEED, block=1):
+    """Renumber the cells of a mesh: random permutation of blocks of `block` consecutive cells (block=1: fully random).
+    Real MPAS meshes are not necessarily numbered along rows; this is the worst case for gather locality."""
+    rng = np.random.default_rng(seed + 7)
+    nb = (m.nCells + block - 1) // block
+    order = rng.permutation(nb)
+    perm = np.concatenate([np.arange(b * block, min((b + 1) * block, m.nCells)) for b in order])  # new id i holds old cell perm[i]
+    return MpasMesh(m.latCell[perm], m.lonCell[perm], m.latVertex, m.lonVertex, m.verticesOnCell[perm])
+
+
 def analytic_field(lat_rad, lon_rad, nlev, seed=SEED, cell_fast=True, dtype=np.float64):
     """f(lat,lon,k) = a_k + b_k x + c_k y + d_k z + 0.1 sin(5 lon) cos(3 lat)  (SURVEY s8(d)).
     Returns [nlev][n] (cell-fastest, as the reference holds fields, input_data.F90:653-655) or

@@ -31,6 +31,11 @@ def workload(name):
                                          stand_lon=-110.0)
         m = synth.global_voronoi_mesh(65_536)
         return m, g, 10, "65 536-cell global Voronoi mesh x 10 levels -> 200x200 0.1-degree lat-lon"
+    if name.startswith("c4_3m_shuffled"):  # same mesh, cells renumbered at random (optionally in blocks: c4_3m_shuffled_b64)
+        g = conus_lambert_grid()
+        m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
+        block = int(name.split("_b")[1]) if "_b" in name else 1
+        return synth.shuffle_cells(m, block=block), g, 55, "3.0 M-cell regional mesh, cells renumbered at random (blocks of %d)" % block
     if name == "tiny":
         g = tg.define_target_grid_params("lambert", 181, 107, dx=30000.0, dy=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
                                          truelat2=38.5, stand_lon=-97.5)
