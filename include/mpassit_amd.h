@@ -110,6 +110,14 @@ int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const doub
 int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const double *sina_dev,
                          double *u_dev, double *v_dev, void *hip_stream);
 
+/* ---- bring-your-own weights: the factorList / factorIndexList form of ESMF_FieldRegridStore (and of an
+ * ESMF_RegridWeightGen file: S, col, row).  Builds a route handle that applies externally computed weights with the
+ * same Regrid kernels, e.g. to compare this library's weight generation with ESMF's on a site that has ESMF.
+ * col = source index, row = destination index (j*nx_dst + i), both 1-based as in ESMF; any entry order (order
+ * inside a destination row is kept = summation order).  Destination points without entries regrid to 0.0. */
+int mpg_handle_from_weights(int64_t n_src, int nx_dst, int ny_dst, int64_t nnz, const int32_t *row_host,
+                            const int32_t *col_host, const double *S_host, mpg_handle *out);
+
 /* ---- introspection (tests, INTEGRATION.md, multi-GPU halo schedule) -------------------------------- */
 /* n_src: source points the handle indexes; n_dst = nx_dst*ny_dst; nnz_per_row: 3 bilinear(mesh),
  * 4 bilinear(grid), 1 nearest, 0 = CSR (conservative); nnz = total stored weights. */

@@ -344,6 +344,80 @@ int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const doub
 }
 
 // ---- introspection ----------------------------------------------------------------------------------
+int mpg_handle_from_weights(int64_t n_src, int nx_dst, int ny_dst, int64_t nnz, const int32_t *row_host, const int32_t *col_host,
+                            const double *S_host, mpg_handle *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(out && (nnz == 0 || (row_host && col_host && S_host)), "mpg_handle_from_weights: NULL argument");
+  MPG_ARG(n_src > 0 && n_src < 0x7fffffff && nx_dst > 0 && ny_dst > 0 && nnz >= 0 && nnz < 0x7fffffff,
+          "mpg_handle_from_weights: bad sizes");
+  int64_t P = (int64_t)nx_dst * ny_dst;
+  std::vector<int32_t> rowptr((size_t)P + 1, 0);
+  for (int64_t q = 0; q < nnz; ++q) {
+    if (row_host[q] < 1 || row_host[q] > P || col_host[q] < 1 || col_host[q] > n_src) {
+      mpg_set_error("mpg_handle_from_weights: entry %lld has row %d / col %d outside [1, n_dst] / [1, n_src]", (long long)q,
+                    row_host[q], col_host[q]);
+      return MPG_ERR_INVALID_ARG;
+    }
+    rowptr[(size_t)row_host[q]]++;   // count into slot row (1-based) -> exclusive scan below
+  }
+  int maxlen = 0, minlen_nonempty = 1 << 30;
+  for (int64_t p = 0; p < P; ++p) {
+    int len = rowptr[(size_t)p + 1];
+    if (len > maxlen) maxlen = len;
+    if (len > 0 && len < minlen_nonempty) minlen_nonempty = len;
+    rowptr[(size_t)p + 1] += rowptr[(size_t)p];
+  }
+  std::vector<int32_t> col((size_t)nnz + 1);
+  std::vector<double> val((size_t)nnz + 1);
+  {
+    std::vector<int32_t> cur(rowptr.begin(), rowptr.end() - 1);
+    for (int64_t q = 0; q < nnz; ++q) {   // stable: keeps the caller's order inside a row
+      int32_t r = row_host[q] - 1;
+      col[(size_t)cur[r]] = col_host[q] - 1;
+      val[(size_t)cur[r]++] = S_host[q];
+    }
+  }
+  mpg_handle_s *h = new mpg_handle_s();
+  h->n_src = n_src;
+  h->n_dst = P;
+  h->nx_dst = nx_dst;
+  h->ny_dst = ny_dst;
+  h->nnz = nnz;
+  h->method = -1;
+  int rc = MPG_SUCCESS;
+  if (maxlen == 3 && minlen_nonempty == 3) {
+    // every mapped destination has exactly 3 sources (bilinear on triangles): the fast fixed-3 layout
+    h->kind = MPG_KIND_FIXED;
+    h->nnz_per_row = 3;
+    std::vector<int32_t> idx(3 * (size_t)P, -1);
+    std::vector<double> w(3 * (size_t)P, 0.0);
+    for (int64_t p = 0; p < P; ++p)
+      if (rowptr[(size_t)p + 1] > rowptr[(size_t)p])
+        for (int k = 0; k < 3; ++k) {
+          idx[(size_t)k * P + p] = col[(size_t)rowptr[(size_t)p] + k];
+          w[(size_t)k * P + p] = val[(size_t)rowptr[(size_t)p] + k];
+        }
+    if (!(rc = h->idx.alloc(3 * (size_t)P)) && !(rc = h->w.alloc(3 * (size_t)P))) {
+      MPG_HIP(hipMemcpy(h->idx.p, idx.data(), sizeof(int32_t) * 3 * P, hipMemcpyHostToDevice));
+      MPG_HIP(hipMemcpy(h->w.p, w.data(), sizeof(double) * 3 * P, hipMemcpyHostToDevice));
+    }
+  } else {
+    h->kind = MPG_KIND_CSR;
+    h->nnz_per_row = 0;
+    if (!(rc = h->rowptr.alloc((size_t)P + 1)) && !(rc = h->col.alloc((size_t)nnz + 1)) && !(rc = h->val.alloc((size_t)nnz + 1))) {
+      MPG_HIP(hipMemcpy(h->rowptr.p, rowptr.data(), sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice));
+      MPG_HIP(hipMemcpy(h->col.p, col.data(), sizeof(int32_t) * (nnz + 1), hipMemcpyHostToDevice));
+      MPG_HIP(hipMemcpy(h->val.p, val.data(), sizeof(double) * (nnz + 1), hipMemcpyHostToDevice));
+    }
+  }
+  if (rc) {
+    handle_free(h);
+    return rc;
+  }
+  *out = h;
+  return MPG_SUCCESS;
+}
+
 int mpg_handle_info(mpg_handle h, int64_t *n_src, int64_t *n_dst, int *nx_dst, int *ny_dst, int *nnz_per_row, int64_t *nnz) {
   MPG_ARG(h, "mpg_handle_info: NULL handle");
   if (n_src) *n_src = h->n_src;

@@ -165,6 +165,32 @@ class RouteHandle:
                                             C.c_int(int(out.dtype == torch.float32)), C.c_double(scale), C.c_double(offset), _stream_ptr()))
         return out
 
+    @classmethod
+    def from_weights(cls, n_src, nx_dst, ny_dst, row, col, S):
+        """Route handle from externally computed weights in ESMF's factorList / factorIndexList form (1-based
+        row = destination j*nx+i, col = source), e.g. the S/row/col of an ESMF_RegridWeightGen file."""
+        row = np.ascontiguousarray(row, np.int32)
+        col = np.ascontiguousarray(col, np.int32)
+        S = _f64(S)
+        if not (row.size == col.size == S.size):
+            raise ValueError("row, col and S must have the same length")
+        h = C.c_void_p()
+        check(L.load().mpg_handle_from_weights(C.c_int64(n_src), C.c_int(nx_dst), C.c_int(ny_dst), C.c_int64(S.size), _ptr(row), _ptr(col),
+                                               _ptr(S), C.byref(h)))
+        return cls(h)
+
+    def to_esmf_weights(self):
+        """(row, col, S), 1-based, unmapped destination points omitted: what ESMF would return as factorIndexList /
+        factorList for the same regrid (nearest: S = 1)."""
+        if self.nnz_per_row == 0:
+            rowptr, col, val = self.csr()
+            row = np.repeat(np.arange(1, self.n_dst + 1, dtype=np.int32), np.diff(rowptr).astype(np.int64))
+            return row, (col + 1).astype(np.int32), val
+        idx, w = self.weights()
+        keep = idx >= 0
+        row = np.broadcast_to(np.arange(1, self.n_dst + 1, dtype=np.int32)[:, None], idx.shape)[keep]
+        return np.ascontiguousarray(row), (idx[keep] + 1).astype(np.int32), np.ascontiguousarray(w[keep])
+
     def weights(self):
         """(idx [n_dst][nnz_per_row] int32 with -1 = unmapped, w [n_dst][nnz_per_row])."""
         idx = np.empty((self.n_dst, self.nnz_per_row), np.int32)

@@ -78,6 +78,44 @@ def global_voronoi_mesh(n_cells, seed=SEED, jitter=0.25, max_edges=None):
     return MpasMesh(latc, lonc, latv, lonv, voc)
 
 
+def variable_resolution_mesh(n_cells, lat0_deg=38.5, lon0_deg=-97.5, ratio=8.0, radius_deg=25.0, seed=SEED):
+    """Global variable-resolution Voronoi mesh (like the MPAS 60-3 km / 15-3 km meshes): generator density is
+    `ratio`^2 times higher inside a cap of `radius_deg` around (lat0, lon0) than far away, with a smooth transition.
+    Cells are random (Poisson-like) points thinned by the density function -- irregular pentagons..octagons, strongly
+    varying triangle sizes: a stress test for the search structures."""
+    from scipy.spatial import SphericalVoronoi
+    rng = np.random.default_rng(seed + 3)
+    c = latlon_rad_to_xyz(np.deg2rad(lat0_deg), np.deg2rad(lon0_deg))
+    pts = np.empty((0, 3))
+    while pts.shape[0] < n_cells:
+        cand = rng.standard_normal((4 * n_cells, 3))
+        cand /= np.linalg.norm(cand, axis=1, keepdims=True)
+        ang = np.degrees(np.arccos(np.clip(cand @ c, -1, 1)))
+        # spacing grows from 1 (inside) to `ratio` (outside) over one more radius; density ~ 1/spacing^2
+        spacing = 1.0 + (ratio - 1.0) * np.clip((ang - radius_deg) / radius_deg, 0.0, 1.0)
+        keep = rng.uniform(size=cand.shape[0]) < 1.0 / spacing ** 2
+        pts = np.concatenate([pts, cand[keep]])
+    pts = pts[:n_cells]
+    # two Lloyd-like relaxations towards the region centroids make the cells less ragged (still far from uniform)
+    for _ in range(2):
+        sv = SphericalVoronoi(pts, radius=1.0, center=np.zeros(3))
+        cen = np.stack([sv.vertices[r].mean(axis=0) for r in sv.regions])
+        pts = cen / np.linalg.norm(cen, axis=1, keepdims=True)
+    sv = SphericalVoronoi(pts, radius=1.0, center=np.zeros(3))
+    sv.sort_vertices_of_regions()
+    me = max(len(r) for r in sv.regions)
+    voc = np.zeros((n_cells, me), np.int32)
+    for i, r in enumerate(sv.regions):
+        r = np.asarray(r, np.int32)
+        a, b, cc = sv.vertices[r[0]], sv.vertices[r[1]], sv.vertices[r[2]]
+        if np.dot(pts[i], np.cross(b - a, cc - a)) < 0:
+            r = r[::-1]
+        voc[i, :len(r)] = r + 1
+    latc, lonc = _xyz_to_latlon_rad(pts)
+    latv, lonv = _xyz_to_latlon_rad(sv.vertices)
+    return MpasMesh(latc, lonc, latv, lonv, voc)
+
+
 def regional_hex_mesh(proj, x0, y0, q_cells, r_cells, spacing, seed=SEED, jitter=0.12):
     """Perturbed hexagonal mesh in the index plane of Lambert projection `proj`.
 
