@@ -24,8 +24,7 @@
 #include "geom.h"
 #include "mpg_internal.h"
 
-static int g_lev_chunk = 0;  // 0 = all levels in one workgroup pass (tunable through MPG_LEV_CHUNK)
-static int g_tune_read = 0;
+static int g_lev_chunk = 0;  // "lev_chunk" knob: 0 = all levels in one workgroup pass
 
 // bijective XCD swizzle (cdna_hip_programming.md s5 "XCD swizzle must be bijective"): workgroups b and
 // b+8 share an XCD, so give each XCD one contiguous range of the linear work space.
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
 }
 
 int mpg_k_tune(const char *key, int value) {
-  g_tune_read = 1;
+
   if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }
   if (!strcmp(key, "fields_per_wg")) { g_fpw = value; return MPG_SUCCESS; }
   if (!strcmp(key, "tile_group")) { g_tgroup = value < 1 ? 1 : value; return MPG_SUCCESS; }
@@ -313,16 +312,6 @@ int mpg_k_tune(const char *key, int value) {
 }
 
 int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s) {
-  if (!g_tune_read) {
-    g_tune_read = 1;
-    const char *e = getenv("MPG_LEV_CHUNK");
-    if (e) g_lev_chunk = atoi(e);
-    e = getenv("MPG_A3_VARIANT");
-    if (e) {
-      int v = atoi(e);
-      if (v >= 0 && v < (int)(sizeof(g_a3_variants) / sizeof(g_a3_variants[0]))) g_a3_variant = v;
-    }
-  }
   int64_t P = h->n_dst;
   int lev_fast = layout == MPG_LAYOUT_LEV_FAST;
   if (P == 0 || nlev == 0 || nfields == 0) return MPG_SUCCESS;
