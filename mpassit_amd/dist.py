@@ -232,3 +232,80 @@ class ShardedRegrid:
         self.rh.release()
         self.mesh.destroy()
         self.grid.destroy()
+
+
+class ShardedInterp:
+    """The whole `interp_data` sequence (interp.F90:92-465) on a row shard of the target grid.
+
+    Mirrors the reference's own data distribution for this step: every rank holds the full source fields (the
+    reference reads every variable whole on every rank, input_data.F90:645) and owns a block of target rows; all
+    Mesh -> Grid regrids are embarrassingly parallel.  The only neighbour dependence is the CENTER -> EDGE1/EDGE2
+    destaggering of the rotated winds: a U/V point of a rank's first or last row needs the mass row just outside its
+    block, so UMASS / VMASS exchange ONE halo row with each neighbour (P2P) and the stagger weights are built on the
+    block extended by those rows.  Results are bit-identical to the single-GPU run.
+    Ownership of staggered rows: rank r returns U rows [j0, j1) and V rows [j0, j1), the last rank also V row ny."""
+
+    def __init__(self, mpas_mesh, target, rank, world):
+        import copy
+
+        from . import regrid as R
+        self.rank, self.world, self.ny = rank, world, target.ny
+        self.j0, self.j1 = row_block(target.ny, world, rank)
+        self.e0, self.e1 = max(self.j0 - 1, 0), min(self.j1 + 1, target.ny)
+        self.mesh = R.Mesh.from_mpas(mpas_mesh)
+        self.grid = R.Grid.from_target(target, rows=(self.j0, self.j1))
+        self.grid_ext = R.Grid.from_target(target, rows=(self.e0, self.e1))
+        self.target = copy.copy(target)               # rotation angles of the own rows
+        if target.cosa is not None:
+            self.target.cosa = np.ascontiguousarray(target.cosa[self.j0:self.j1])
+            self.target.sina = np.ascontiguousarray(target.sina[self.j0:self.j1])
+
+    def _halo_rows(self, mass):
+        """mass [nz][rows][nx] of the own block -> [nz][e1-e0][nx] with the neighbours' boundary rows attached."""
+        import torch
+        import torch.distributed as dist
+        lo, hi = self.j0 - self.e0, self.e1 - self.j1          # halo rows below / above (0 or 1)
+        is_t = type(mass).__module__.startswith("torch")
+        m = mass if is_t else torch.from_numpy(np.ascontiguousarray(mass))
+        stage_cpu = m.is_cuda and self.world > 1 and dist.get_backend() == "gloo"
+        ext = m.new_empty((m.shape[0], self.e1 - self.e0, m.shape[2]))
+        ext[:, lo:lo + (self.j1 - self.j0)] = m
+        if self.world > 1:
+            ops, bufs = [], []
+
+            def tr(x):
+                return x.cpu() if stage_cpu else x
+            if hi:   # my last row goes up, their first row comes down
+                s, r = tr(m[:, -1].contiguous()), tr(m.new_empty((m.shape[0], m.shape[2])))
+                ops += [dist.P2POp(dist.isend, s, self.rank + 1), dist.P2POp(dist.irecv, r, self.rank + 1)]
+                bufs.append((r, ext.shape[1] - 1))
+            if lo:
+                s, r = tr(m[:, 0].contiguous()), tr(m.new_empty((m.shape[0], m.shape[2])))
+                ops += [dist.P2POp(dist.isend, s, self.rank - 1), dist.P2POp(dist.irecv, r, self.rank - 1)]
+                bufs.append((r, 0))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            for r, row in bufs:
+                ext[:, row] = r.to(ext.device)
+        return ext if is_t else ext.numpy()
+
+    def _destagger(self, grid, staggerloc, mass, nz):
+        from . import regrid as R
+        ext = self._halo_rows(mass)
+        rh = R.regrid_store_grid(self.grid_ext, staggerloc)
+        full = rh.regrid(ext.reshape(-1), nlev=nz)[0]              # [nz][ext rows (+1 for EDGE2)][nx (+1 for EDGE1)]
+        rh.release()
+        off = self.j0 - self.e0
+        nrows = self.j1 - self.j0
+        if staggerloc == R.STAGGERLOC_EDGE2 and self.j1 == self.ny:
+            nrows += 1                                              # the last rank also owns the top V row
+        return full[:, off:off + nrows]
+
+    def interp_data(self, inp, cfg):
+        from . import interp as I
+        return I.interp_data(self.mesh, self.grid, self.target, inp, cfg, destagger=self._destagger)
+
+    def destroy(self):
+        self.mesh.destroy()
+        self.grid.destroy()
+        self.grid_ext.destroy()

@@ -96,7 +96,15 @@ def interp_diag_data(mesh, grid, target, inp, cfg, out):
         rotate_winds_cgrid(target, out[tu], out[tv])
 
 
-def interp_hist_data(mesh, grid, target, inp, cfg, out):
+def _destagger_local(grid, staggerloc, mass, nz):
+    """Grid -> Grid bilinear S/R on one grid (ESMF_FieldRegridStore + ESMF_FieldRegrid, interp.F90:298-309,316-327)."""
+    rh = R.regrid_store_grid(grid, staggerloc)
+    res = rh.regrid(mass.reshape(-1), nlev=nz)[0]
+    rh.release()
+    return res
+
+
+def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
     h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars)
     # `method` is only assigned inside `if (n_hist_fields_2d_patch>0)` in the reference (interp.F90:203-204) and
     # undefined otherwise (SURVEY App. C2); this build always uses BILINEAR for the blocks below.
@@ -112,14 +120,11 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out):
         out["VMASS"] = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout)[0]  # :274-289
     if h.do_u_interp and h.do_v_interp and cfg.proj_is_lambert:
         rotate_winds_cgrid(target, out["UMASS"], out["VMASS"])        # :291-293
+    destagger = destagger or _destagger_local
     if h.do_u_interp:
-        rh_u = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1)          # :295-311  UMASS(CENTER) -> U(EDGE1)
-        out["U"] = rh_u.regrid(out["UMASS"].reshape(-1), nlev=inp.nz)[0]
-        rh_u.release()
+        out["U"] = destagger(grid, R.STAGGERLOC_EDGE1, out["UMASS"], inp.nz)   # :295-311  UMASS(CENTER) -> U(EDGE1)
     if h.do_v_interp:
-        rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2)          # :313-328  VMASS(CENTER) -> V(EDGE2)
-        out["V"] = rh_v.regrid(out["VMASS"].reshape(-1), nlev=inp.nz)[0]
-        rh_v.release()
+        out["V"] = destagger(grid, R.STAGGERLOC_EDGE2, out["VMASS"], inp.nz)   # :313-328  VMASS(CENTER) -> V(EDGE2)
     for (n, t), o in zip(h.nzp1_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nzp1_3d], inp.nzp1, inp.layout)):
         out[t] = o                                                    # :331-347
     if h.vert_3d:                                                     # :350-366 node-located sources (vorticity)
@@ -148,11 +153,12 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out):
         rh_nstd.release()
 
 
-def interp_data(mesh, grid, target, inp, cfg):
-    """-> dict target_name -> array ([ny][nx], [nlev][ny][nx]; U on EDGE1, V on EDGE2)."""
+def interp_data(mesh, grid, target, inp, cfg, destagger=None):
+    """-> dict target_name -> array ([ny][nx], [nlev][ny][nx]; U on EDGE1, V on EDGE2).
+    `destagger` lets the row-sharded driver (dist.ShardedInterp) supply the CENTER -> EDGE step with its row halo."""
     out = {}
     if cfg.interp_diag:
         interp_diag_data(mesh, grid, target, inp, cfg, out)
     if cfg.interp_hist:
-        interp_hist_data(mesh, grid, target, inp, cfg, out)
+        interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=destagger)
     return out
