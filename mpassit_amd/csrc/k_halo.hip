@@ -30,7 +30,7 @@ int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap,
   int64_t n = h->n_src;
   int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
   int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
-  DevBuf<int32_t> flag, pos, out;
+  TmpBuf<int32_t> flag, pos, out;
   if ((rc = flag.alloc((size_t)n + 1)) || (rc = pos.alloc((size_t)n + 1))) return rc;
   MPG_HIP(hipMemsetAsync(flag.p, 0, sizeof(int32_t) * (n + 1), s));
   int gb = (int)((ni + 255) / 256);
@@ -39,7 +39,7 @@ int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap,
   k_mark<<<gb, 256, 0, s>>>(ni, ip, flag.p);
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag.p, pos.p, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), s));
-  DevBuf<char> tmp;
+  TmpBuf<char> tmp;
   if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, flag.p, pos.p, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), s));
   int32_t nu = 0;
@@ -78,7 +78,7 @@ int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s) 
   int rc;
   int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
   int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
-  DevBuf<int32_t> bad;
+  TmpBuf<int32_t> bad;
   if ((rc = bad.alloc(1))) return rc;
   MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
   int gb = (int)((ni + 255) / 256);

@@ -178,7 +178,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   h->nnz = 3 * P;
   if ((rc = h->idx.alloc(3 * (size_t)P))) return rc;
   if ((rc = h->w.alloc(3 * (size_t)P))) return rc;
-  DevBuf<int32_t> owner;
+  TmpBuf<int32_t> owner;
   if ((rc = owner.alloc((size_t)P))) return rc;
   int fb = (int)((P + 255) / 256);
   if (fb > 8192) fb = 8192;

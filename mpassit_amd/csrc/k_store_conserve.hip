@@ -188,7 +188,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   h->n_dst = P;
   h->nx_dst = nx;
   h->ny_dst = ny;
-  DevBuf<int32_t> count;
+  TmpBuf<int32_t> count;
   if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1))) return rc;
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
   unsigned nb = (unsigned)((m->nCells + 127) / 128);
@@ -198,7 +198,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipGetLastError());
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
-  DevBuf<char> tmp;
+  TmpBuf<char> tmp;
   if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
   int32_t nnz = 0;

@@ -87,15 +87,15 @@ int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s) {
   int rc;
   int64_t n = m->nCells;
   b.n = n;
-  DevBuf<unsigned long long> key_in, key_out;
-  DevBuf<int32_t> id_in;
+  TmpBuf<unsigned long long> key_in, key_out;
+  TmpBuf<int32_t> id_in;
   if ((rc = key_in.alloc(n)) || (rc = key_out.alloc(n)) || (rc = id_in.alloc(n)) || (rc = b.sorted_id.alloc(n))) return rc;
   if ((rc = b.sorted.alloc(n))) return rc;
   unsigned nb = (unsigned)((n + 255) / 256);
   k_morton<<<nb, 256, 0, s>>>(n, m->cell.x.p, m->cell.y.p, m->cell.z.p, key_in.p, id_in.p);
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
-  DevBuf<char> tmp;
+  TmpBuf<char> tmp;
   if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
   MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
   k_gather_sites<<<nb, 256, 0, s>>>(n, b.sorted_id.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, b.sorted.x.p, b.sorted.y.p, b.sorted.z.p);

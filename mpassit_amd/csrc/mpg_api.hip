@@ -292,7 +292,7 @@ int mpg_regrid(mpg_handle h, const double *src_host, int src_layout, int nlev, i
   MPG_ARG(h && src_host && dst_host, "mpg_regrid: NULL argument");
   MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid: nlev and nfields must be >= 1");
   size_t ns = (size_t)h->n_src * nlev * nfields, nd = (size_t)h->n_dst * nlev * nfields;
-  DevBuf<double> s, d;
+  TmpBuf<double> s, d;
   int rc;
   if ((rc = s.alloc(ns)) || (rc = d.alloc(nd))) {
     s.free();
@@ -321,7 +321,7 @@ int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const doub
   MPG_CHECK_INIT();
   MPG_ARG(cosa_host && sina_host && u_host && v_host, "mpg_rotate_winds: NULL argument");
   MPG_ARG(npts >= 0 && nlev >= 1, "mpg_rotate_winds: bad sizes");
-  DevBuf<double> cs, uv;
+  TmpBuf<double> cs, uv;
   int rc;
   size_t n = (size_t)npts, nl = n * nlev;
   if ((rc = cs.alloc(2 * n)) || (rc = uv.alloc(2 * nl))) {

@@ -58,6 +58,16 @@ struct DevBuf {
   }
 };
 
+// Scoped temporary: freed when it goes out of scope, so early error returns (MPG_HIP) cannot leak device memory.
+// Long-lived members of meshes / grids / handles stay plain DevBuf and are freed by their owner.
+template <typename T>
+struct TmpBuf : DevBuf<T> {
+  TmpBuf() = default;
+  TmpBuf(const TmpBuf &) = delete;
+  TmpBuf &operator=(const TmpBuf &) = delete;
+  ~TmpBuf() { this->free(); }
+};
+
 // Point set on the unit sphere, SoA
 struct PointSet {
   int64_t n = 0;
