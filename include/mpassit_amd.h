@@ -67,7 +67,16 @@ int mpg_mesh_destroy(mpg_mesh mesh); /* ESMF_MeshDestroy model_grid.F90:2154 */
 /* ---- ESMF_GridCreateNoPeriDim / 1PeriDim + GridAddCoord x4 (model_grid.F90:684-728,736-1038) ------
  * nx, ny = mass (CENTER) point counts (i_target, j_target).  Coordinates in DEGREES, C order with i
  * fastest: centre [ny][nx], corner [ny+1][nx+1], EDGE1 (U) [ny][nx+1], EDGE2 (V) [ny+1][nx].
- * corner/edge arrays may be NULL when the corresponding stagger is never used. */
+ * corner/edge arrays may be NULL when the corresponding stagger is never used.
+ * periodic_i = 0: ESMF_GridCreateNoPeriDim (regional, model_grid.F90:699).
+ * periodic_i = MPG_GRID_PERIODIC_I (1): ESMF_GridCreate1PeriDim(periodicDim=1, poleDim=2, MONOPOLE at both
+ *   ends, model_grid.F90:685-694): CENTER column nx-1 neighbours column 0, and each j end is closed by a pole
+ *   node at lat -/+90 whose value is the mean of the first / last CENTER row.  Array shapes are the same as
+ *   in the regional case; the extra EDGE1 / CORNER column (index nx) duplicates column 0 one period later
+ *   (ESMF's periodic staggers hold only the first nx columns).  Only Grid -> Grid RegridStore reads the flag.
+ * OR in MPG_GRID_NO_SOUTH_POLE / MPG_GRID_NO_NORTH_POLE for a row block of a periodic grid that does not
+ *   touch that pole (multi-GPU row sharding). */
+enum { MPG_GRID_PERIODIC_I = 1, MPG_GRID_NO_SOUTH_POLE = 2, MPG_GRID_NO_NORTH_POLE = 4 };
 int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, const double *lat_center,
                     const double *lon_corner, const double *lat_corner, const double *lon_edge1,
                     const double *lat_edge1, const double *lon_edge2, const double *lat_edge2,
@@ -127,6 +136,14 @@ int mpg_handle_info(mpg_handle rh, int64_t *n_src, int64_t *n_dst, int *nx_dst, 
 int mpg_handle_get_weights(mpg_handle rh, int32_t *idx_host, double *w_host);
 /* CSR handles: rowptr [n_dst+1], col/val [nnz] (host) */
 int mpg_handle_get_csr(mpg_handle rh, int64_t *rowptr_host, int32_t *col_host, double *val_host);
+/* Pole terms of a Grid -> Grid handle on a periodic (monopole) grid.  Destination points inside a pole cap
+ * (triangle pole / A / B of the first or last CENTER row) carry, besides the A and B entries reported by
+ * mpg_handle_get_weights, a weight on the pole node; the pole's value is the mean of the `row_len` sources
+ * starting at `src_row_start`, i.e. ESMF's factor list holds row_len entries of w_pole/row_len for it.
+ * mpg_handle_pole_count: n_points = 0 for every other handle.  mpg_handle_get_pole: arrays [n_points] (host);
+ * entries with w_pole == 0 are destination points of the two candidate rows that are not in a cap. */
+int mpg_handle_pole_count(mpg_handle rh, int64_t *n_points, int *row_len);
+int mpg_handle_get_pole(mpg_handle rh, int32_t *dst_id_host, int32_t *src_row_start_host, double *w_pole_host);
 /* dual (Delaunay) triangles of a mesh: tri_host [nVertices][3], 0-based cell ids or -1 */
 int mpg_mesh_get_triangles(mpg_mesh mesh, int32_t *tri_host);
 

@@ -15,7 +15,8 @@ SYMBOLS = [
     "mpg_grid_create", "mpg_grid_destroy", "mpg_regrid_store", "mpg_regrid_store_grid", "mpg_regrid",
     "mpg_regrid_dev", "mpg_regrid_typed_dev", "mpg_handle_release", "mpg_rotate_winds", "mpg_rotate_winds_dev", "mpg_handle_info",
     "mpg_handle_from_weights", "mpg_handle_get_weights", "mpg_handle_get_csr", "mpg_mesh_get_triangles", "mpg_handle_unique_sources",
-    "mpg_handle_localize", "mpg_handle_rebase", "mpg_pack_dev", "mpg_handle_store_ms", "mpg_tune",
+    "mpg_handle_localize", "mpg_handle_rebase", "mpg_pack_dev", "mpg_handle_store_ms", "mpg_tune", "mpg_handle_pole_count",
+    "mpg_handle_get_pole",
 ]
 
 MPG_SUCCESS = 0
@@ -23,6 +24,7 @@ REGRIDMETHOD_BILINEAR, REGRIDMETHOD_CONSERVE, REGRIDMETHOD_NEAREST_STOD = 0, 1, 
 MESHLOC_ELEMENT, MESHLOC_NODE = 0, 1
 STAGGERLOC_CENTER, STAGGERLOC_EDGE1, STAGGERLOC_EDGE2, STAGGERLOC_CORNER = 0, 1, 2, 3
 LAYOUT_CELL_FAST, LAYOUT_LEV_FAST = 0, 1
+GRID_PERIODIC_I, GRID_NO_SOUTH_POLE, GRID_NO_NORTH_POLE = 1, 2, 4
 
 _lib = None
 _initialized = False

@@ -358,6 +358,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
     return MPG_ERR_UNSUPPORTED;
   }
   MPG_HIP(hipGetLastError());
+  if (h->n_pole) return mpg_k_pole_fix(h, src, 0, layout, nlev, nfields, dst, 0, 1.0, 0.0, s);
   return MPG_SUCCESS;
 }
 

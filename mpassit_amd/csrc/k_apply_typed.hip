@@ -201,8 +201,11 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
     MPG_HIP(hipMemsetAsync(dst, 0, (dst_f32 ? 4 : 8) * (size_t)h->n_dst * nlev * nfields, s));
     return MPG_SUCCESS;
   }
-  if (src_f32 && dst_f32) return launch_typed<float, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
-  if (src_f32) return launch_typed<float, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
-  if (dst_f32) return launch_typed<double, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
-  return launch_typed<double, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  int rc;
+  if (src_f32 && dst_f32) rc = launch_typed<float, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  else if (src_f32) rc = launch_typed<float, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  else if (dst_f32) rc = launch_typed<double, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  else rc = launch_typed<double, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);
+  if (rc == MPG_SUCCESS && h->n_pole) rc = mpg_k_pole_fix(h, src, src_f32, layout, nlev, nfields, dst, dst_f32, scale, offset, s);
+  return rc;
 }

@@ -45,6 +45,10 @@ __device__ double clip_area(int ns, const dv3 *src, const dv3 *quad) {
   for (int i = 0; i < ns; ++i) a[i] = src[i];
   dv3 *cur = a, *nxt = b;
   for (int e = 0; e < 4 && n >= 3; ++e) {
+    // a collapsed side (the two CORNER points of a lat-lon cell at a pole, equal up to the rounding of cos(90))
+    // bounds nothing, and the direction of its great circle is noise: skip it
+    dv3 side = quad[(e + 1) & 3] - quad[e];
+    if (dot3(side, side) < 1e-24) continue;
     dv3 nrm = cross3(quad[e], quad[(e + 1) & 3]);
     n = clip_halfspace(n, cur, nrm, nxt);
     dv3 *t = cur; cur = nxt; nxt = t;

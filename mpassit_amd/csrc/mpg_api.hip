@@ -136,6 +136,8 @@ int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, co
   MPG_ARG(out, "mpg_grid_create: out is NULL");
   MPG_ARG(nx > 0 && ny > 0, "mpg_grid_create: nx, ny must be > 0");
   MPG_ARG(lon_center && lat_center, "mpg_grid_create: CENTER coordinates are mandatory");
+  MPG_ARG(periodic_i >= 0 && periodic_i < 8 && ((periodic_i & MPG_GRID_PERIODIC_I) || !periodic_i),
+          "mpg_grid_create: periodic_i must be 0 or MPG_GRID_PERIODIC_I [| MPG_GRID_NO_SOUTH_POLE | MPG_GRID_NO_NORTH_POLE]");
   MPG_ARG((int64_t)(nx + 1) * (ny + 1) < 0x7fffffff, "mpg_grid_create: grid too large for int32 ids");
   mpg_grid_s *g = new mpg_grid_s();
   g->nx = nx;
@@ -178,6 +180,9 @@ static void handle_free(mpg_handle_s *h) {
   h->rowptr.free();
   h->col.free();
   h->val.free();
+  h->pole_dst.free();
+  h->pole_src0.free();
+  h->pole_w.free();
   delete h;
 }
 
@@ -470,11 +475,29 @@ int mpg_handle_get_csr(mpg_handle h, int64_t *rowptr_host, int32_t *col_host, do
   return MPG_SUCCESS;
 }
 
+int mpg_handle_pole_count(mpg_handle h, int64_t *n_points, int *row_len) {
+  MPG_ARG(h, "mpg_handle_pole_count: NULL handle");
+  if (n_points) *n_points = h->n_pole;
+  if (row_len) *row_len = h->pole_len;
+  return MPG_SUCCESS;
+}
+
+int mpg_handle_get_pole(mpg_handle h, int32_t *dst_id_host, int32_t *src_row_start_host, double *w_pole_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h, "mpg_handle_get_pole: NULL handle");
+  if (h->n_pole == 0) return MPG_SUCCESS;
+  if (dst_id_host) MPG_HIP(hipMemcpy(dst_id_host, h->pole_dst.p, sizeof(int32_t) * h->n_pole, hipMemcpyDeviceToHost));
+  if (src_row_start_host) MPG_HIP(hipMemcpy(src_row_start_host, h->pole_src0.p, sizeof(int32_t) * h->n_pole, hipMemcpyDeviceToHost));
+  if (w_pole_host) MPG_HIP(hipMemcpy(w_pole_host, h->pole_w.p, sizeof(double) * h->n_pole, hipMemcpyDeviceToHost));
+  return MPG_SUCCESS;
+}
+
 // ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------
 int mpg_handle_unique_sources(mpg_handle h, int64_t *n_unique, int32_t *ids_host) {
   MPG_CHECK_INIT();
   MPG_ARG(h && n_unique, "mpg_handle_unique_sources: NULL argument");
   MPG_ARG(!h->localized, "mpg_handle_unique_sources: handle already localized");
+  MPG_ARG(h->n_pole == 0, "mpg_handle_unique_sources: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
   std::vector<int32_t> ids;
   int rc = mpg_k_unique_sources(h, ids, false, g_stream);
   if (rc) return rc;
@@ -487,6 +510,7 @@ int mpg_handle_localize(mpg_handle h) {
   MPG_CHECK_INIT();
   MPG_ARG(h, "mpg_handle_localize: NULL handle");
   MPG_ARG(!h->localized, "mpg_handle_localize: handle already localized");
+  MPG_ARG(h->n_pole == 0, "mpg_handle_localize: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
   // a localized handle no longer matches its cache key: detach it
   if (h->cached) {
     g_cache.erase(h->key);
@@ -500,6 +524,7 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
   MPG_CHECK_INIT();
   MPG_ARG(h, "mpg_handle_rebase: NULL handle");
   MPG_ARG(!h->localized, "mpg_handle_rebase: handle already localized");
+  MPG_ARG(h->n_pole == 0, "mpg_handle_rebase: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
   MPG_ARG(base >= 0 && n_local >= 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
   if (h->cached) {
     g_cache.erase(h->key);

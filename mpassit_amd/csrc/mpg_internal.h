@@ -166,6 +166,12 @@ struct mpg_handle_s {
   HandleKey key;
   float store_ms = 0.f;
   bool localized = false;
+  // pole caps of a periodic (monopole) source grid: destination point pole_dst[q] adds pole_w[q] * mean of the
+  // pole_len sources starting at pole_src0[q].  Dense over the candidate rows, pole_w == 0 where not in a cap.
+  int64_t n_pole = 0;
+  int pole_len = 0;
+  DevBuf<int32_t> pole_dst, pole_src0;
+  DevBuf<double> pole_w;
 };
 
 // ---- launchers implemented in the kernel TUs ---------------------------------------------------
@@ -183,6 +189,8 @@ int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s);
 int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
                       double scale, double offset, hipStream_t s);
+int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
+                   double scale, double offset, hipStream_t s);
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);

@@ -89,12 +89,17 @@ class Grid:
     @classmethod
     def from_target(cls, g, rows=None):
         """From target_grid.TargetGrid; rows=(j0, j1) keeps only mass rows [j0, j1) (multi-GPU row shard,
-        mirrors the reference's regDecomp=(/1,npets/) split along j, model_grid.F90:693)."""
+        mirrors the reference's regDecomp=(/1,npets/) split along j, model_grid.F90:693).  A global grid
+        (is_regional=.false.) is periodic in i with monopole caps (model_grid.F90:685-694); a row block keeps only
+        the caps it touches."""
+        flags = 0 if g.is_regional else L.GRID_PERIODIC_I
         if rows is None:
-            return cls(g.lon, g.lat, g.lon_c, g.lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v, periodic=not g.is_regional)
+            return cls(g.lon, g.lat, g.lon_c, g.lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v, periodic=flags)
         j0, j1 = rows
+        if flags:
+            flags |= (L.GRID_NO_SOUTH_POLE if j0 > 0 else 0) | (L.GRID_NO_NORTH_POLE if j1 < g.ny else 0)
         return cls(g.lon[j0:j1], g.lat[j0:j1], g.lon_c[j0:j1 + 1], g.lat_c[j0:j1 + 1], g.lon_u[j0:j1], g.lat_u[j0:j1],
-                   g.lon_v[j0:j1 + 1], g.lat_v[j0:j1 + 1], periodic=not g.is_regional)
+                   g.lon_v[j0:j1 + 1], g.lat_v[j0:j1 + 1], periodic=flags)
 
     def stagger_shape(self, staggerloc):
         return {STAGGERLOC_CENTER: (self.ny, self.nx), STAGGERLOC_EDGE1: (self.ny, self.nx + 1),
@@ -189,7 +194,27 @@ class RouteHandle:
         idx, w = self.weights()
         keep = idx >= 0
         row = np.broadcast_to(np.arange(1, self.n_dst + 1, dtype=np.int32)[:, None], idx.shape)[keep]
-        return np.ascontiguousarray(row), (idx[keep] + 1).astype(np.int32), np.ascontiguousarray(w[keep])
+        row, col, S = np.ascontiguousarray(row), (idx[keep] + 1).astype(np.int32), np.ascontiguousarray(w[keep])
+        dst, src0, wp, row_len = self.pole()
+        if len(dst):
+            # a pole node's value is the mean of one CENTER row: row_len factors of w_pole / row_len each
+            nz = wp != 0.0
+            prow = np.repeat(dst[nz] + 1, row_len).astype(np.int32)
+            pcol = (src0[nz][:, None] + np.arange(1, row_len + 1, dtype=np.int32)[None, :]).reshape(-1).astype(np.int32)
+            row, col, S = np.concatenate([row, prow]), np.concatenate([col, pcol]), np.concatenate([S, np.repeat(wp[nz] / row_len, row_len)])
+            keep = S != 0.0                                      # the cap points' zero-weight filler slots
+            row, col, S = row[keep], col[keep], S[keep]
+        return row, col, S
+
+    def pole(self):
+        """Pole terms of a Grid -> Grid handle on a periodic grid: (dst_id, src_row_start, w_pole, row_len);
+        empty arrays for every other handle (mpg_handle_get_pole)."""
+        n, row_len = C.c_int64(), C.c_int()
+        check(L.load().mpg_handle_pole_count(self._h, C.byref(n), C.byref(row_len)))
+        dst, src0, wp = np.empty(n.value, np.int32), np.empty(n.value, np.int32), np.empty(n.value)
+        if n.value:
+            check(L.load().mpg_handle_get_pole(self._h, _ptr(dst), _ptr(src0), _ptr(wp)))
+        return dst, src0, wp, row_len.value
 
     def weights(self):
         """(idx [n_dst][nnz_per_row] int32 with -1 = unmapped, w [n_dst][nnz_per_row])."""

@@ -78,6 +78,79 @@ def global_voronoi_mesh(n_cells, seed=SEED, jitter=0.25, max_edges=None):
     return MpasMesh(latc, lonc, latv, lonv, voc)
 
 
+def _morton_order(xyz, bits=10):
+    """Permutation that sorts unit vectors along a 3-D Morton curve (locality-preserving numbering)."""
+    q = np.clip(((xyz + 1.0) * 0.5 * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    code = np.zeros(xyz.shape[0], np.int64)
+    for b in range(bits):
+        for d in range(3):
+            code |= ((q[:, d] >> b) & 1) << (3 * b + d)
+    return np.argsort(code, kind="stable")
+
+
+def icosahedral_mesh(level, order="morton"):
+    """Global quasi-uniform mesh by `level` bisections of the icosahedron, the construction behind the MPAS x1 meshes:
+    10*4^level + 2 cells (level 6: 40 962, 8: 655 362, 9: 2 621 442), 12 pentagons, hexagons elsewhere; the Voronoi
+    vertices are the circumcentres of the bisection triangles.  O(N log N) numpy, no scipy.
+    order="morton": cells and vertices renumbered along a space-filling curve (production meshes are reordered for
+    locality too); order="native": bisection order (each level's midpoints appended), which is close to random."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    verts = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                      [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    verts /= np.linalg.norm(verts, axis=1, keepdims=True)
+    faces = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                      [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+                      [8, 6, 7], [9, 8, 1]], np.int64)
+    for _ in range(level):
+        nv, nf = verts.shape[0], faces.shape[0]
+        e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+        key = np.minimum(e[:, 0], e[:, 1]) * nv + np.maximum(e[:, 0], e[:, 1])
+        uk, inv = np.unique(key, return_inverse=True)
+        mid = verts[uk // nv] + verts[uk % nv]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        m = inv.reshape(-1) + nv
+        m01, m12, m20 = m[:nf], m[nf:2 * nf], m[2 * nf:]
+        v0, v1, v2 = faces[:, 0], faces[:, 1], faces[:, 2]
+        faces = np.concatenate([np.stack([v0, m01, m20], 1), np.stack([v1, m12, m01], 1), np.stack([v2, m20, m12], 1),
+                                np.stack([m01, m12, m20], 1)])
+        verts = np.concatenate([verts, mid])
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    n = np.cross(b - a, c - a)
+    flip = np.einsum("ij,ij->i", n, a + b + c) < 0.0          # counter-clockwise seen from outside
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    n[flip] *= -1.0
+    cc = n / np.linalg.norm(n, axis=1, keepdims=True)          # spherical circumcentres = Voronoi vertices
+    del a, b, c, n
+    if order == "morton":
+        pc = _morton_order(verts)
+        rank = np.empty_like(pc)
+        rank[pc] = np.arange(pc.size)
+        verts, faces = verts[pc], rank[faces]
+        pt = _morton_order(cc)
+        cc, faces = cc[pt], faces[pt]
+    elif order != "native":
+        raise ValueError("order must be 'morton' or 'native'")
+    # verticesOnCell: the triangles around each cell sorted by azimuth in the cell's tangent plane (CCW)
+    nc, nt = verts.shape[0], faces.shape[0]
+    cell = faces.reshape(-1)
+    tri = np.repeat(np.arange(nt, dtype=np.int64), 3)
+    p = verts[cell]
+    ref = np.where((np.abs(p[:, 2]) < 0.9)[:, None], np.array([0.0, 0.0, 1.0]), np.array([1.0, 0.0, 0.0]))
+    e1 = ref - np.einsum("ij,ij->i", ref, p)[:, None] * p
+    e2 = np.cross(p, e1)
+    d = cc[tri] - p
+    ang = np.arctan2(np.einsum("ij,ij->i", d, e2), np.einsum("ij,ij->i", d, e1))
+    del p, ref, e1, e2, d
+    o = np.lexsort((ang, cell))
+    cell, tri = cell[o], tri[o]
+    start = np.concatenate([[0], np.cumsum(np.bincount(cell, minlength=nc))])
+    voc = np.zeros((nc, 6), np.int32)
+    voc[cell, np.arange(cell.size) - start[cell]] = tri + 1
+    latc, lonc = _xyz_to_latlon_rad(verts)
+    latv, lonv = _xyz_to_latlon_rad(cc)
+    return MpasMesh(latc, lonc, latv, lonv, voc)
+
+
 def variable_resolution_mesh(n_cells, lat0_deg=38.5, lon0_deg=-97.5, ratio=8.0, radius_deg=25.0, seed=SEED):
     """Global variable-resolution Voronoi mesh (like the MPAS 60-3 km / 15-3 km meshes): generator density is
     `ratio`^2 times higher inside a cap of `radius_deg` around (lat0, lon0) than far away, with a smooth transition.

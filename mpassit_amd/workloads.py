@@ -31,6 +31,14 @@ def workload(name):
                                          stand_lon=-110.0)
         m = synth.global_voronoi_mesh(65_536)
         return m, g, 10, "65 536-cell global Voronoi mesh x 10 levels -> 200x200 0.1-degree lat-lon"
+    if name in ("c5_global_latlon", "c5_small"):
+        # BASELINE config 5: global mesh -> global lat-lon grid (is_regional=.false.: 360/nx x 180/ny degrees, periodic in i,
+        # poles closed, program_setup.F90:197-217 / model_grid.F90:684-696)
+        level, nx, ny = (9, 3601, 1801) if name == "c5_global_latlon" else (6, 361, 181)
+        g = tg.define_target_grid_params("lat-lon", nx, ny, stand_lon=0.0, is_regional=False)
+        m = synth.icosahedral_mesh(level)
+        return m, g, 55, "%d-cell global icosahedral mesh x 55 levels -> %dx%d global lat-lon (%dx%d mass points)" % (
+            m.nCells, nx, ny, nx - 1, ny - 1)
     if name.startswith("c4_3m_shuffled"):  # same mesh, cells renumbered at random (optionally in blocks: c4_3m_shuffled_b64)
         g = conus_lambert_grid()
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)

@@ -369,6 +369,9 @@ static double clip_area(int ns, const v3 *src, const v3 *quad) {
   memcpy(bufA, src, sizeof(v3) * (size_t)ns);
   v3 *cur = bufA, *nxt = bufB;
   for (int e = 0; e < 4 && n >= 3; ++e) {
+    /* collapsed side (both CORNER points of a lat-lon cell at a pole): bounds nothing, direction is noise */
+    v3 side = v3sub(quad[(e + 1) & 3], quad[e]);
+    if (v3dot(side, side) < 1e-24) continue;
     v3 nrm = v3cross(quad[e], quad[(e + 1) & 3]);
     n = clip_halfspace(n, cur, nrm, nxt);
     v3 *t = cur; cur = nxt; nxt = t;
@@ -487,9 +490,17 @@ static int quad_solve(v3 P, v3 A, v3 B, v3 C, v3 D, double *xi, double *eta) {
   return lam > 0;
 }
 
-void orc_grid_bilinear(int nx, int ny, const double *centre_xyz, int stagger, const double *dst_xyz,
-                       int32_t *idx, double *w) {
+/* flags = 0: ESMF_GridCreateNoPeriDim.  flags & 1: ESMF_GridCreate1PeriDim(periodicDim=1, poleDim=2, MONOPOLE)
+ * (model_grid.F90:685-694): the CENTER columns wrap, and each j end is closed by a pole node at lat -/+90 whose
+ * value is the mean of the first / last CENTER row; a destination point in the cap triangle (pole, A, B) gets
+ * planar barycentric weights (A2) on A, B and the pole.  flags & 2 / & 4: no south / north cap (row block of a
+ * periodic grid).  pole_w [2][nxd] (south candidate row j = 0, north candidate row j = nyd-1) receives the pole
+ * weight, pole_src0 the first source of the averaged row; both may be NULL when flags == 0. */
+void orc_grid_bilinear_p(int nx, int ny, int flags, const double *centre_xyz, int stagger, const double *dst_xyz,
+                         int32_t *idx, double *w, int32_t *pole_src0, double *pole_w) {
   int nxd = stagger == 1 ? nx + 1 : nx, nyd = stagger == 2 ? ny + 1 : ny;
+  int per = flags & 1;
+  if (per) for (int q = 0; q < 2 * nxd; ++q) { pole_src0[q] = 0; pole_w[q] = 0.0; }
   for (int j = 0; j < nyd; ++j) for (int i = 0; i < nxd; ++i) {
     int64_t p = (int64_t)j * nxd + i;
     v3 P = v3load(dst_xyz, p);
@@ -499,8 +510,10 @@ void orc_grid_bilinear(int nx, int ny, const double *centre_xyz, int stagger, co
     int found = 0;
     for (int bb = 0; bb < ncb && !found; ++bb) for (int aa = 0; aa < nca && !found; ++aa) {
       int a = ca[aa], b = cb[bb];
-      if (a < 0 || b < 0 || a + 1 >= nx || b + 1 >= ny) continue;
-      int64_t iA = (int64_t)b * nx + a, iB = iA + 1, iC = iA + nx + 1, iD = iA + nx;
+      if (per) a = (a + nx) % nx;
+      if (a < 0 || b < 0 || b + 1 >= ny || (!per && a + 1 >= nx)) continue;
+      int a1 = a + 1 == nx ? 0 : a + 1;
+      int64_t iA = (int64_t)b * nx + a, iB = (int64_t)b * nx + a1, iC = iB + nx, iD = iA + nx;
       double xi, eta;
       if (!quad_solve(P, v3load(centre_xyz, iA), v3load(centre_xyz, iB), v3load(centre_xyz, iC), v3load(centre_xyz, iD), &xi, &eta)) continue;
       if (xi < -ORC_TOL || xi > 1 + ORC_TOL || eta < -ORC_TOL || eta > 1 + ORC_TOL) continue;
@@ -509,7 +522,31 @@ void orc_grid_bilinear(int nx, int ny, const double *centre_xyz, int stagger, co
       found = 1;
     }
     if (!found) for (int k = 0; k < 4; ++k) { idx[4 * p + k] = -1; w[4 * p + k] = 0; }
+    if (per && !found)
+      for (int bb = 0; bb < ncb && !found; ++bb) for (int aa = 0; aa < nca && !found; ++aa) {
+        int b = cb[bb];
+        int south = b == -1 && !(flags & 2), north = b == ny - 1 && !(flags & 4);
+        if (!south && !north) continue;
+        int a = (ca[aa] + nx) % nx, a1 = a + 1 == nx ? 0 : a + 1;
+        int64_t row0 = south ? 0 : (int64_t)(ny - 1) * nx;
+        v3 A = v3load(centre_xyz, row0 + a), B = v3load(centre_xyz, row0 + a1);
+        v3 N = {0, 0, 1}, S = {0, 0, -1};
+        double t[3];
+        /* counter-clockwise seen from outside: (A, B, N) / (B, A, S) */
+        int in = north ? tri_weights(P, A, B, N, ORC_TOL, t) : tri_weights(P, B, A, S, ORC_TOL, t);
+        if (!in) continue;
+        idx[4 * p] = (int32_t)(row0 + a); idx[4 * p + 1] = (int32_t)(row0 + a1);
+        w[4 * p] = north ? t[0] : t[1]; w[4 * p + 1] = north ? t[1] : t[0];
+        int64_t q = (j == 0 ? 0 : nxd) + i;
+        pole_src0[q] = (int32_t)row0;
+        pole_w[q] = t[2];
+        found = 1;
+      }
   }
+}
+void orc_grid_bilinear(int nx, int ny, const double *centre_xyz, int stagger, const double *dst_xyz,
+                       int32_t *idx, double *w) {
+  orc_grid_bilinear_p(nx, ny, 0, centre_xyz, stagger, dst_xyz, idx, w, 0, 0);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -120,6 +120,32 @@ def grid_bilinear(nx, ny, centre_xyz, stagger, dst_xyz):
     return idx, w
 
 
+def grid_bilinear_periodic(nx, ny, flags, centre_xyz, stagger, dst_xyz):
+    """Grid -> Grid bilinear on a 1PeriDim / monopole grid -> (idx [P][4], w [P][4], pole_src0 [2][nxd], pole_w [2][nxd])."""
+    centre_xyz, dst_xyz = _c(centre_xyz, np.float64), _c(dst_xyz, np.float64)
+    P = dst_xyz.shape[0]
+    nxd = nx + 1 if stagger == 1 else nx
+    idx, w = np.empty((P, 4), np.int32), np.empty((P, 4))
+    pole_src0, pole_w = np.zeros((2, nxd), np.int32), np.zeros((2, nxd))
+    lib().orc_grid_bilinear_p(C.c_int(nx), C.c_int(ny), C.c_int(flags), centre_xyz.ctypes, C.c_int(stagger), dst_xyz.ctypes,
+                              idx.ctypes, w.ctypes, pole_src0.ctypes, pole_w.ctypes)
+    return idx, w, pole_src0, pole_w
+
+
+def apply_grid_periodic(nx, idx, w, pole_src0, pole_w, src, nlev):
+    """A7 for a monopole handle: the 4-point sum plus w_pole * mean(CENTER row), src [nlev][nsrc] -> [nlev][P]."""
+    out = apply_fixed(idx, w, src, nlev)
+    src = np.asarray(src, np.float64).reshape(nlev, -1)
+    nxd = pole_w.shape[1]
+    P = idx.shape[0]
+    for slot, p0 in ((0, 0), (1, P - nxd)):
+        for i in range(nxd):
+            if pole_w[slot, i] != 0.0:
+                s0 = int(pole_src0[slot, i])
+                out[:, p0 + i] += pole_w[slot, i] * src[:, s0:s0 + nx].mean(axis=1)
+    return out
+
+
 def apply_fixed(idx, w, src, nlev, lev_fast=False):
     idx, w, src = _c(idx, np.int32), _c(w, np.float64), _c(src, np.float64)
     P, nnz = idx.shape

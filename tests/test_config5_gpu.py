@@ -1,0 +1,124 @@
+"""BASELINE config 5 at full size: 2 621 442-cell global icosahedral mesh -> 3600 x 1800 global lat-lon grid
+(is_regional=.false.), wrf_mod_vars staggered winds.  The oracle would need many minutes here, so parity goes
+through properties only a GLOBAL remap offers: every target point is mapped (poles and date line included), the
+conservative remap preserves the global integral, the pole rows of V are zonal means, U wraps around the seam."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c5(gpu_lib):
+    import torch
+    from mpassit_amd import regrid as R, workloads
+    m, g, nlev, _ = workloads.workload("c5_global_latlon")
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    yield dict(m=m, g=g, mesh=mesh, grid=grid, nlev=nlev, torch=torch)
+    mesh.destroy()
+    grid.destroy()
+
+
+def _xyz(lat, lon):
+    cl = np.cos(lat)
+    return np.stack([cl * np.cos(lon), cl * np.sin(lon), np.sin(lat)], axis=-1)
+
+
+def _tri_area(a, b, c):
+    """Spherical triangle area (Van Oosterom-Strackee), difference form for small triangles."""
+    num = np.einsum("ij,ij->i", a, np.cross(b - a, c - a))
+    den = 1.0 + np.einsum("ij,ij->i", a, b) + np.einsum("ij,ij->i", b, c) + np.einsum("ij,ij->i", c, a)
+    return 2.0 * np.arctan2(num, den)
+
+
+def test_c5_bilinear_and_nearest(c5):
+    from mpassit_amd import regrid as R
+    torch, m, g = c5["torch"], c5["m"], c5["g"]
+    assert (g.nx, g.ny) == (3600, 1800) and m.nCells == 2_621_442
+    rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_BILINEAR)
+    idx, w = rh.weights()
+    assert (idx >= 0).all()                                # a closed sphere has no unmapped point
+    assert np.abs(w.sum(1) - 1).max() < 1e-13 and w.min() > -1e-10
+    cx = _xyz(m.latCell, np.where(m.lonCell > np.pi, m.lonCell - 2 * np.pi, m.lonCell))
+    px = _xyz(np.deg2rad(g.lat).ravel(), np.deg2rad(g.lon).ravel())
+    a = np.array([0.3, -0.7, 0.5])
+    src = torch.as_tensor(np.stack([cx @ a, np.full(m.nCells, 7.25)]), device="cuda")
+    out = rh.regrid(src.view(-1), nlev=2).cpu().numpy().reshape(2, -1)
+    A, B, C = cx[idx[:, 0]], cx[idx[:, 1]], cx[idx[:, 2]]
+    n = np.cross(B - A, C - A)
+    t = np.einsum("ij,ij->i", A, n) / np.einsum("ij,ij->i", n, px)       # closed form, SURVEY App. E
+    assert np.abs(out[0] - t * (px @ a)).max() < 1e-12
+    assert np.abs(out[1] - 7.25).max() < 1e-13
+    print("store_ms bilinear C5:", rh.store_ms)
+    rh.release()
+    rn = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_NEAREST_STOD)
+    near = rn.weights()[0][:, 0]
+    assert near.min() >= 0
+    # the nearest cell is a corner of the containing Delaunay triangle or beats all three of them
+    d_near = ((cx[near] - px) ** 2).sum(1)
+    d_tri = np.minimum(np.minimum(((A - px) ** 2).sum(1), ((B - px) ** 2).sum(1)), ((C - px) ** 2).sum(1))
+    assert (d_near <= d_tri * (1 + 1e-12)).all()
+    for p in np.random.default_rng(5).choice(px.shape[0], 25, replace=False):   # brute force over all cells
+        d = ((cx - px[p]) ** 2).sum(1)
+        assert d[near[p]] <= d.min() * (1 + 1e-12)
+    print("store_ms nearest C5:", rn.store_ms)
+    rn.release()
+
+
+def test_c5_conservative_global_integral(c5):
+    from mpassit_amd import regrid as R, synth
+    torch, m, g = c5["torch"], c5["m"], c5["g"]
+    rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_CONSERVE)
+    rp, col, val = rh.csr()
+    P = g.nx * g.ny
+    rows = np.repeat(np.arange(P), np.diff(rp))
+    rowsum = np.bincount(rows, weights=val, minlength=P)
+    assert val.min() > 0 and np.abs(rowsum - 1).max() < 1e-9            # every target cell fully covered
+    # areas of the target cells (great-circle quads between the CORNER points, as the clipper sees them)
+    cor = _xyz(np.deg2rad(g.lat_c), np.deg2rad(g.lon_c))
+    c00, c10, c11, c01 = (cor[:-1, :-1].reshape(-1, 3), cor[:-1, 1:].reshape(-1, 3), cor[1:, 1:].reshape(-1, 3),
+                          cor[1:, :-1].reshape(-1, 3))
+    a_dst = _tri_area(c00, c10, c11) + _tri_area(c00, c11, c01)
+    assert abs(a_dst.sum() - 4 * np.pi) < 1e-9
+    # column sums: sum_d A_d w_ds = A_s, the area of source cell s (every source cell lies inside the global grid)
+    a_src = np.bincount(col, weights=val * a_dst[rows], minlength=m.nCells)
+    assert abs(a_src.sum() - 4 * np.pi) < 1e-8
+    vx = _xyz(m.latVertex, m.lonVertex)
+    voc = m.verticesOnCell
+    v0 = vx[voc[:, 0] - 1]
+    poly = np.zeros(m.nCells)
+    for k in range(1, voc.shape[1] - 1):
+        ok = voc[:, k + 1] > 0
+        poly[ok] += _tri_area(v0[ok], vx[voc[ok, k] - 1], vx[voc[ok, k + 1] - 1])
+    assert np.abs(a_src / poly - 1).max() < 1e-7
+    # hence the global integral of a remapped field is preserved
+    f = synth.snow_field(m.latCell, m.lonCell) + 1.0
+    out = rh.regrid(torch.as_tensor(f, device="cuda"), nlev=1).cpu().numpy().ravel()
+    assert abs((out * a_dst).sum() / (f * poly).sum() - 1) < 1e-9
+    print("store_ms conserve C5:", rh.store_ms, "nnz/row", len(col) / P)
+    rh.release()
+
+
+def test_c5_staggered_winds(c5):
+    """wrf_mod_vars: UMASS/VMASS on CENTER -> U on EDGE1, V on EDGE2 of the periodic grid (interp.F90:295-328)."""
+    from mpassit_amd import regrid as R
+    torch, g = c5["torch"], c5["g"]
+    nlev = 4
+    lat, lon = np.deg2rad(g.lat), np.deg2rad(g.lon)
+    mass = np.stack([10.0 * (k + 1) * np.cos(lat) * np.sin(lon + 0.3 * k) + 2.0 * np.sin(lat) for k in range(nlev)])
+    src = torch.as_tensor(mass, device="cuda")
+    ru = R.regrid_store_grid(c5["grid"], R.STAGGERLOC_EDGE1)
+    u = ru.regrid(src.view(-1), nlev=nlev)[0].cpu().numpy()
+    assert u.shape == (nlev, g.ny, g.nx + 1)
+    assert np.array_equal(u[:, :, 0], u[:, :, -1])
+    np.testing.assert_allclose(u[:, :, :-1], 0.5 * (np.roll(mass, 1, axis=2) + mass), atol=1e-4)
+    ru.release()
+    rv = R.regrid_store_grid(c5["grid"], R.STAGGERLOC_EDGE2)
+    v = rv.regrid(src.view(-1), nlev=nlev)[0].cpu().numpy()
+    assert v.shape == (nlev, g.ny + 1, g.nx)
+    np.testing.assert_allclose(v[:, 0], np.broadcast_to(mass[:, 0].mean(axis=1)[:, None], v[:, 0].shape), atol=1e-12)
+    np.testing.assert_allclose(v[:, -1], np.broadcast_to(mass[:, -1].mean(axis=1)[:, None], v[:, -1].shape), atol=1e-12)
+    np.testing.assert_allclose(v[:, 1:-1], 0.5 * (mass[:, :-1] + mass[:, 1:]), atol=1e-5)
+    one = rv.regrid(torch.full((g.nx * g.ny,), 3.5, dtype=torch.float64, device="cuda"), nlev=1)
+    assert float((one - 3.5).abs().max()) < 1e-13
+    rv.release()
