@@ -239,3 +239,63 @@ def test_node_located_bilinear_fan(oracle, global_mesh, conus_grid_30km):
     n = np.cross(B - A, C - A)
     t = np.einsum("ij,ij->i", A, n) / np.einsum("ij,ij->i", n, pxyz)
     assert np.abs(got - t * (pxyz @ a)).max() < 1e-13
+
+
+def test_icosahedral_mesh_is_a_valid_mpas_mesh(oracle):
+    """synth.icosahedral_mesh: 10*4^L+2 cells, 12 pentagons, every Voronoi vertex has 3 cells, polygons CCW and tiling."""
+    from mpassit_amd import synth
+    for order in ("morton", "native"):
+        m = synth.icosahedral_mesh(4, order=order)
+        assert m.nCells == 10 * 4 ** 4 + 2 and m.nVertices == 20 * 4 ** 4 and m.maxEdges == 6
+        nedge = (m.verticesOnCell > 0).sum(1)
+        assert (nedge == 5).sum() == 12 and (nedge == 6).sum() == m.nCells - 12
+        cxyz, vxyz = mesh_xyz(oracle, m)
+        tri, nvalid = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+        assert nvalid == m.nVertices and (tri >= 0).all()
+        # each cell's polygon: counter-clockwise fan areas, together the whole sphere
+        total = 0.0
+        for c in range(m.nCells):
+            v = vxyz[m.verticesOnCell[c, :nedge[c]] - 1]
+            for k in range(1, len(v) - 1):
+                num = np.dot(v[0], np.cross(v[k] - v[0], v[k + 1] - v[0]))
+                assert num > 0
+                total += 2 * np.arctan2(num, 1 + v[0] @ v[k] + v[k] @ v[k + 1] + v[k + 1] @ v[0])
+        assert abs(total - 4 * np.pi) < 1e-10
+    # Morton numbering keeps neighbours close in index space, bisection order does not
+    near = synth.icosahedral_mesh(5)
+    far = synth.icosahedral_mesh(5, order="native")
+
+    def spread(mm):
+        v = mm.verticesOnCell[:, :5].astype(np.int64)
+        return np.median(v.max(1) - v.min(1))
+    assert spread(near) * 5 < spread(far)
+
+
+def test_grid_to_grid_bilinear_periodic_monopole(oracle):
+    """1PeriDim + MONOPOLE restatement (model_grid.F90:685-694): nothing unmapped on the closed sphere, weights (pole
+    share included) sum to one, V at a pole is the zonal mean, row blocks keep only their own caps."""
+    from mpassit_amd import target_grid as tg
+    t = tg.define_target_grid_params("lat-lon", nx=37, ny=19, stand_lon=0.0, is_regional=False)   # 36 x 18, 10 degrees
+    cen = oracle.lonlat_deg_to_xyz(t.lon, t.lat)
+    for st, lon, lat in ((1, t.lon_u, t.lat_u), (2, t.lon_v, t.lat_v)):
+        idx, w, src0, wp = oracle.grid_bilinear_periodic(t.nx, t.ny, 1, cen, st, oracle.lonlat_deg_to_xyz(lon, lat))
+        nxd = lon.shape[1]
+        total = w.sum(1)
+        total[:nxd] += wp[0]
+        total[-nxd:] += wp[1]
+        assert (idx[:, 0] >= 0).all() and np.abs(total - 1).max() < 1e-13
+        f = np.cos(np.deg2rad(t.lat)) * np.sin(np.deg2rad(t.lon)) + 2.0 + np.sin(np.deg2rad(t.lat))
+        out = oracle.apply_grid_periodic(t.nx, idx, w, src0, wp, f.reshape(1, -1), 1).reshape(lon.shape)
+        if st == 2:
+            assert np.allclose(wp, 1.0, atol=1e-12) and (src0[1] == (t.ny - 1) * t.nx).all() and (src0[0] == 0).all()
+            assert np.allclose(out[0], f[0].mean()) and np.allclose(out[-1], f[-1].mean())
+        else:
+            assert (wp == 0).all() and np.array_equal(out[:, 0], out[:, -1])
+        # non-periodic reading of the same grid leaves the seam column / pole rows unmapped
+        idx0, _ = oracle.grid_bilinear(t.nx, t.ny, cen, st, oracle.lonlat_deg_to_xyz(lon, lat))
+        assert (idx0[:, 0] < 0).sum() == (2 * t.ny if st == 1 else 2 * t.nx)
+    # a southern row block: south cap only
+    rows = slice(0, 9)
+    idx, w, src0, wp = oracle.grid_bilinear_periodic(t.nx, 9, 1 | 4, oracle.lonlat_deg_to_xyz(t.lon[rows], t.lat[rows]), 2,
+                                                     oracle.lonlat_deg_to_xyz(t.lon_v[0:10], t.lat_v[0:10]))
+    assert np.allclose(wp[0], 1.0, atol=1e-12) and (wp[1] == 0).all() and (idx[-t.nx:, 0] < 0).all()
