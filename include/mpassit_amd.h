@@ -119,6 +119,19 @@ int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const doub
 int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const double *sina_dev,
                          double *u_dev, double *v_dev, void *hip_stream);
 
+/* ---- output epilogues: what write_data.F90 computes on rank 0 between ESMF_FieldGather and nf90_put_var, done on
+ * the device-resident regridded fields so that only final float32 arrays leave the GPU.
+ * Every output variable is NF90_FLOAT (write_data.F90:312-980) while the fields are float64: the cast below is the
+ * conversion nf90_put_var applies (round to nearest).  Device pointers; hip_stream as in mpg_regrid_dev.
+ *   mpg_post_cast_dev        dst = (float)(src*scale + offset): plain fields (scale 1, offset 0), T - 300 (:1339-1347,
+ *                            the `continue` in that loop is a no-op statement, so every point is shifted), PHB*9.81 (:1418)
+ *   mpg_post_layer_mean_dev  Z_C(k) = 0.5*(PHB(k+1) + PHB(k)), src [nlevp1][n_pts] -> dst [nlevp1-1][n_pts] (:1406-1415)
+ *   mpg_post_ptop_dev        P_TOP from P_HYD [nlev][n_pts]: min(maxval(P_HYD), 0.8*P_HYD(top) over columns whose top
+ *                            value is >= 10) (:1362-1371); float64 result returned to the host, blocks on the stream */
+int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream);
+int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream);
+int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream);
+
 /* ---- bring-your-own weights: the factorList / factorIndexList form of ESMF_FieldRegridStore (and of an
  * ESMF_RegridWeightGen file: S, col, row).  Builds a route handle that applies externally computed weights with the
  * same Regrid kernels, e.g. to compare this library's weight generation with ESMF's on a site that has ESMF.

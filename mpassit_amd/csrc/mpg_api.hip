@@ -546,4 +546,24 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
   return mpg_k_pack(src_dev, n_src, nlev, ids_dev, n_ids, dst_dev, (hipStream_t)hip_stream);
 }
 
+// ---- output epilogues (kernels in k_post.hip) ------------------------------------------------------------
+int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(n >= 0 && (n == 0 || (src_dev && dst_dev)), "mpg_post_cast_dev: NULL argument");
+  return mpg_k_post_cast(src_dev, n, scale, offset, dst_dev, (hipStream_t)hip_stream);
+}
+
+int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(nlevp1 >= 2 && n_pts >= 0, "mpg_post_layer_mean_dev: needs at least two levels");
+  MPG_ARG(n_pts == 0 || (src_dev && dst_dev), "mpg_post_layer_mean_dev: NULL argument");
+  return mpg_k_post_layer_mean(src_dev, nlevp1, n_pts, dst_dev, (hipStream_t)hip_stream);
+}
+
+int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(p_hyd_dev && ptop_host && nlev >= 1 && n_pts >= 1, "mpg_post_ptop_dev: bad argument");
+  return mpg_k_post_ptop(p_hyd_dev, nlev, n_pts, ptop_host, (hipStream_t)hip_stream);
+}
+
 }  // extern "C"

@@ -191,6 +191,9 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
                       double scale, double offset, hipStream_t s);
 int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
                    double scale, double offset, hipStream_t s);
+int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, hipStream_t s);
+int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, hipStream_t s);
+int mpg_k_post_ptop(const double *src, int nlev, int64_t P, double *ptop_host, hipStream_t s);
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);

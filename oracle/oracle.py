@@ -245,3 +245,33 @@ def para_range(n1, n2, nprocs, irank):
     a, b = C.c_int(), C.c_int()
     lib().orc_para_range(C.c_int(n1), C.c_int(n2), C.c_int(nprocs), C.c_int(irank), C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+# ---- output post-ops of write_target_data (write_data.F90:1339-1475), numpy restatement -----------------------
+def post_cast(x, scale=1.0, offset=0.0):
+    """float64 -> NF90_FLOAT as nf90_put_var converts it; T - 300 (:1343) and PHB*9.81 (:1418) are one float64
+    operation each before the conversion."""
+    x = np.asarray(x, np.float64)
+    if scale != 1.0:
+        x = x * scale
+    if offset != 0.0:
+        x = x + offset
+    return x.astype(np.float32)
+
+
+def post_layer_mean(phb):
+    """Z_C(k-1) = 0.5*(PHB(k) + PHB(k-1)), k = 2..nzp1 (write_data.F90:1406-1412)."""
+    phb = np.asarray(phb, np.float64)
+    return (0.5 * (phb[1:] + phb[:-1])).astype(np.float32)
+
+
+def post_ptop(p_hyd):
+    """write_data.F90:1362-1371: start from maxval(P_HYD); every column whose top value is >= 10 lowers it to
+    min(0.8*top, current)."""
+    p_hyd = np.asarray(p_hyd, np.float64)
+    top = p_hyd[-1].ravel()
+    cand = top[top >= 10.0] * 0.80
+    v = p_hyd.max()
+    if cand.size:
+        v = min(v, cand.min())
+    return np.float32(v)
