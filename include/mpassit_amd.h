@@ -83,6 +83,32 @@ int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, co
                     mpg_grid *out);
 int mpg_grid_destroy(mpg_grid grid); /* ESMF_GridDestroy model_grid.F90:2156 */
 
+/* ---- target grid straight from the projection, on the device -------------------------
+ * Replaces the host loops of define_target_grid_params (model_grid.F90:736-1038): get_lat_lon_fields x4 staggers
+ * (:2188-2219 -> xytoll, llxy_module.F90:166-216 -> ij_to_latlon, module_map_utils.F90:629-679, Lambert :1160-1233,
+ * lat-lon :1398-1428), get_rotang (:2450-2507) and get_map_factor (:2229-2365).  The fields of mpg_proj are the
+ * arguments of push_source_projection / map_set (model_grid.F90:676-678); the derived constants (cone, rsw, pole
+ * i/j; set_lc, module_map_utils.F90:1083-1121) are computed inside.  nx, ny = mass point counts (i_target,
+ * j_target); stagger shapes as in mpg_grid_create.  The grid keeps lon/lat (degrees), cos/sin(alpha) and the map
+ * factors on the device; the getters copy them to the host (XLAT/XLONG/MAPFAC/SINALPHA/COSALPHA of the output file,
+ * write_data.F90:1003-1140).
+ * Map factors: PROJ_LC as get_map_factor; PROJ_LATLON has no branch there (the reference writes unset memory) and
+ * returns 1.0 here.  cos/sin(alpha) exist for PROJ_LC only (model_grid.F90:1113), as in the reference. */
+enum { MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1 }; /* misc_definitions_module.F90:38-39 */
+typedef struct mpg_proj {
+  int code;
+  double known_lat, known_lon, known_x, known_y; /* lat1, lon1, knowni, knownj */
+  double dx_m;                                   /* PROJ_LC: grid spacing in metres */
+  double stand_lon, truelat1, truelat2;          /* PROJ_LC */
+  double dlat_deg, dlon_deg;                     /* PROJ_LATLON: latinc, loninc */
+} mpg_proj;
+int mpg_grid_create_proj(const mpg_proj *proj, int nx, int ny, int periodic_i, mpg_grid *out);
+int mpg_grid_get_coords(mpg_grid grid, int staggerloc, double *lon_host, double *lat_host);
+int mpg_grid_get_rotang(mpg_grid grid, double *cosa_host, double *sina_host);
+int mpg_grid_get_mapfac(mpg_grid grid, int staggerloc, double *mapfac_host);
+/* device pointers owned by the grid ([ny][nx], CENTER), for mpg_rotate_winds_dev */
+int mpg_grid_rotang_dev(mpg_grid grid, const double **cosa_dev, const double **sina_dev);
+
 /* ---- ESMF_Field[Bundle]RegridStore (interp.F90:123,207,226,241,259,277,334,353,372,394,421,437) ---
  * srcTermProcessing=1, unmappedaction=IGNORE are implied.  Mesh -> Grid.  Handles are cached: the same
  * (mesh, src_loc, grid, dst_stagger, method) returns the same handle (reference recomputes it up to

@@ -1,0 +1,205 @@
+// Target grid straight from the projection.
+//
+// The reference fills four staggered lat/lon arrays, three map-factor arrays and cos/sin(alpha) with host loops
+// (define_target_grid_params, model_grid.F90:736-1038) before the hot path can start; on a 1800 x 1060 grid the
+// numpy mirror of those loops costs ~20x the whole interpolation job.  Here one kernel per stagger evaluates
+//   get_lat_lon_fields (model_grid.F90:2188-2219): xytoll(real(i-0.5)+0.5, real(j-0.5)+0.5, stagger)
+//   xytoll             (llxy_module.F90:166-216):   U: x-0.5, V: y-0.5, CORNER: both
+//   ij_to_latlon       (module_map_utils.F90:629-679; Lambert :1160-1233, lat-lon :1398-1428)
+// and writes lon/lat (degrees), the unit vector every Store kernel works with, and the map factor
+// (get_map_factor, model_grid.F90:2229-2365); a second kernel does get_rotang (:2450-2507) on the CENTER points.
+// Pure ALU + transcendental work, a few MB written once: nowhere near any roofline, it only has to be off the host.
+// Floating point: contraction is switched off so the arithmetic is the reference's operation for operation; the
+// device libm (atan2/pow/tan/...) may differ from the host's in the last bit, the parity test allows 1e-12 degrees.
+#include <math.h>
+#include <string.h>
+
+#include "geom.h"
+#include "mpg_internal.h"
+
+#define TG_PI 3.141592653589793  // constants_module.F90:8
+#define TG_RAD_PER_DEG (TG_PI / 180.0)
+#define TG_DEG_PER_RAD (180.0 / TG_PI)
+#define TG_EARTH_RADIUS_M 6370000.0  // constants_module.F90:25
+
+__device__ __forceinline__ void ij_to_latlon(const ProjDev &p, double i, double j, double *lat_out, double *lon_out) {
+#pragma clang fp contract(off)
+  if (p.code == MPG_PROJ_LC) {
+    double chi1 = (90.0 - p.hemi * p.truelat1) * TG_RAD_PER_DEG;
+    double chi2 = (90.0 - p.hemi * p.truelat2) * TG_RAD_PER_DEG;
+    double xx = p.hemi * i - p.polei;
+    double yy = p.polej - p.hemi * j;
+    double r2 = xx * xx + yy * yy;
+    double r = sqrt(r2) / p.rebydx;
+    double lat, lon;
+    if (r2 == 0.0) {
+      lat = p.hemi * 90.0;
+      lon = p.stdlon;
+    } else {
+      lon = p.stdlon + TG_DEG_PER_RAD * atan2(p.hemi * xx, yy) / p.cone;
+      lon = fmod(lon + 360.0, 360.0);
+      double chi;
+      if (chi1 == chi2) chi = 2.0 * atan(pow(r / tan(chi1), 1.0 / p.cone) * tan(chi1 * 0.5));
+      else chi = 2.0 * atan(pow(r * p.cone / sin(chi1), 1.0 / p.cone) * tan(chi1 * 0.5));
+      lat = (90.0 - chi * TG_DEG_PER_RAD) * p.hemi;
+    }
+    if (lon > 180.0) lon -= 360.0;
+    if (lon < -180.0) lon += 360.0;
+    *lat_out = lat;
+    *lon_out = lon;
+  } else {
+    double span = (double)(p.nxmax - p.nxmin + 1);
+    double iw = i;
+    if (i < p.nxmin - 0.5) iw = i + span;
+    if (i >= p.nxmax + 0.5) iw = i - span;
+    *lat_out = p.lat1 + (j - p.knownj) * p.latinc;
+    *lon_out = p.lon1 + (iw - p.knowni) * p.loninc;
+  }
+}
+
+__device__ __forceinline__ double map_factor(const ProjDev &p, double lat) {
+#pragma clang fp contract(off)
+  if (p.code != MPG_PROJ_LC) return 1.0;  // PROJ_LATLON: no branch in get_map_factor
+  double colat = TG_RAD_PER_DEG * (90.0 - lat);
+  if (p.truelat1 != p.truelat2) {
+    double colat1 = TG_RAD_PER_DEG * (90.0 - p.truelat1), colat2 = TG_RAD_PER_DEG * (90.0 - p.truelat2);
+    double n = (log(sin(colat1)) - log(sin(colat2))) / (log(tan(colat1 / 2.0)) - log(tan(colat2 / 2.0)));
+    return sin(colat2) / sin(colat) * pow(tan(colat / 2.0) / tan(colat2 / 2.0), n);
+  }
+  double colat0 = TG_RAD_PER_DEG * (90.0 - p.truelat1);
+  return sin(colat0) / sin(colat) * pow(tan(colat / 2.0) / tan(colat0 / 2.0), cos(colat0));
+}
+
+// stagger: MPG_STAGGERLOC_*; snx x sny points of that stagger
+__global__ __launch_bounds__(256) void k_target_points(ProjDev p, int stagger, int snx, int sny, double *__restrict__ lon,
+                                                       double *__restrict__ lat, double *__restrict__ x, double *__restrict__ y,
+                                                       double *__restrict__ z, double *__restrict__ mapfac) {
+  int64_t n = (int64_t)snx * sny;
+  int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  double la, lo;
+  {
+#pragma clang fp contract(off)
+    double fi = (double)(q % snx + 1), fj = (double)(q / snx + 1);
+    double xi = (fi - 0.5) + 0.5, yj = (fj - 0.5) + 0.5;  // get_lat_lon_fields with sub_x = sub_y = 1
+    if (stagger == MPG_STAGGERLOC_EDGE1 || stagger == MPG_STAGGERLOC_CORNER) xi -= 0.5;
+    if (stagger == MPG_STAGGERLOC_EDGE2 || stagger == MPG_STAGGERLOC_CORNER) yj -= 0.5;
+    ij_to_latlon(p, xi, yj, &la, &lo);
+  }
+  lon[q] = lo;
+  lat[q] = la;
+  // same conversion as k_grid_coords (k_setup.hip): the Stores see identical unit vectors for identical degrees
+  const double d2r = 3.141592653589793 / 180.0;
+  double sl, cl, so, co;
+  sincos(la * d2r, &sl, &cl);
+  sincos(lo * d2r, &so, &co);
+  x[q] = cl * co;
+  y[q] = cl * so;
+  z[q] = sl;
+  if (mapfac) mapfac[q] = map_factor(p, la);
+}
+
+// get_rotang: centred differences in j, one-sided on the first / last row
+__global__ __launch_bounds__(256) void k_rotang(int nx, int ny, const double *__restrict__ lon, const double *__restrict__ lat,
+                                                double *__restrict__ cosa, double *__restrict__ sina) {
+#pragma clang fp contract(off)
+  int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= (int64_t)nx * ny) return;
+  int j = (int)(q / nx);
+  int64_t jm = j > 0 ? q - nx : q, jp = j < ny - 1 ? q + nx : q;
+  double d_lon = lon[jp] - lon[jm];
+  if (d_lon > 180.0) d_lon -= 360.0;
+  else if (d_lon < -180.0) d_lon += 360.0;
+  double alpha = atan2(-cos(lat[q] * TG_RAD_PER_DEG) * (d_lon * TG_RAD_PER_DEG), (lat[jp] - lat[jm]) * TG_RAD_PER_DEG);
+  sina[q] = sin(alpha);
+  cosa[q] = cos(alpha);
+}
+
+static double wrap180(double x) {
+  for (int it = 0; fabs(x) > 180.0 && it < 10; ++it) {
+    if (x < -180.0) x += 360.0;
+    if (x > 180.0) x -= 360.0;
+  }
+  return x;
+}
+
+// map_set / set_lc / lc_cone (module_map_utils.F90:1083-1157) on the host: a handful of scalars
+static int derive(const mpg_proj *in, ProjDev *p) {
+  memset(p, 0, sizeof(*p));
+  p->code = in->code;
+  p->lat1 = in->known_lat;
+  p->lon1 = wrap180(in->known_lon);
+  p->knowni = in->known_x;
+  p->knownj = in->known_y;
+  p->hemi = 1.0;
+  if (in->code == MPG_PROJ_LC) {
+    if (!(in->dx_m > 0.0) || fabs(in->truelat1) > 90.0) {
+      mpg_set_error("mpg_grid_create_proj: Lambert needs dx_m > 0 and |truelat1| <= 90");
+      return MPG_ERR_INVALID_ARG;
+    }
+    p->stdlon = wrap180(in->stand_lon);
+    p->truelat1 = in->truelat1;
+    p->truelat2 = fabs(in->truelat2) > 90.0 ? in->truelat1 : in->truelat2;
+    p->hemi = in->truelat1 < 0.0 ? -1.0 : 1.0;
+    p->rebydx = TG_EARTH_RADIUS_M / in->dx_m;
+    if (fabs(p->truelat1 - p->truelat2) > 0.1) {
+      double cone = log10(cos(p->truelat1 * TG_RAD_PER_DEG)) - log10(cos(p->truelat2 * TG_RAD_PER_DEG));
+      cone = cone / (log10(tan((45.0 - fabs(p->truelat1) / 2.0) * TG_RAD_PER_DEG)) -
+                     log10(tan((45.0 - fabs(p->truelat2) / 2.0) * TG_RAD_PER_DEG)));
+      p->cone = cone;
+    } else {
+      p->cone = sin(fabs(p->truelat1) * TG_RAD_PER_DEG);
+    }
+    double deltalon1 = p->lon1 - p->stdlon;
+    if (deltalon1 > 180.0) deltalon1 -= 360.0;
+    if (deltalon1 < -180.0) deltalon1 += 360.0;
+    double ctl1r = cos(p->truelat1 * TG_RAD_PER_DEG);
+    double rsw = p->rebydx * ctl1r / p->cone *
+                 pow(tan((90.0 * p->hemi - p->lat1) * TG_RAD_PER_DEG / 2.0) / tan((90.0 * p->hemi - p->truelat1) * TG_RAD_PER_DEG / 2.0),
+                     p->cone);
+    double arg = p->cone * (deltalon1 * TG_RAD_PER_DEG);
+    p->polei = p->hemi * p->knowni - p->hemi * rsw * sin(arg);
+    p->polej = p->hemi * p->knownj + rsw * cos(arg);
+  } else if (in->code == MPG_PROJ_LATLON) {
+    if (in->dlat_deg == 0.0 || !(in->dlon_deg > 0.0)) {
+      mpg_set_error("mpg_grid_create_proj: lat-lon needs dlat_deg != 0 and dlon_deg > 0");
+      return MPG_ERR_INVALID_ARG;
+    }
+    p->latinc = in->dlat_deg;
+    p->loninc = in->dlon_deg;
+    p->nxmin = 1;
+    p->nxmax = (int)nearbyint(360.0 / in->dlon_deg);
+  } else {
+    mpg_set_error("mpg_grid_create_proj: projection code %d not supported (PROJ_LC, PROJ_LATLON)", in->code);
+    return MPG_ERR_UNSUPPORTED;
+  }
+  return MPG_SUCCESS;
+}
+
+int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s) {
+  ProjDev p;
+  int rc = derive(proj, &p);
+  if (rc) return rc;
+  g->from_proj = true;
+  g->proj_code = p.code;
+  for (int st = 0; st < 4; ++st) {
+    int64_t n = (int64_t)g->snx[st] * g->sny[st];
+    if ((rc = g->pts[st].alloc(n)) || (rc = g->lon[st].alloc(n)) || (rc = g->lat[st].alloc(n))) return rc;
+    double *mf = nullptr;
+    if (st != MPG_STAGGERLOC_CORNER) {
+      if ((rc = g->mapfac[st].alloc(n))) return rc;
+      mf = g->mapfac[st].p;
+    }
+    k_target_points<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(p, st, g->snx[st], g->sny[st], g->lon[st].p, g->lat[st].p,
+                                                              g->pts[st].x.p, g->pts[st].y.p, g->pts[st].z.p, mf);
+    MPG_HIP(hipGetLastError());
+  }
+  if (p.code == MPG_PROJ_LC) {  // model_grid.F90:1113
+    int64_t n = (int64_t)g->nx * g->ny;
+    if ((rc = g->cosa.alloc(n)) || (rc = g->sina.alloc(n))) return rc;
+    k_rotang<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->nx, g->ny, g->lon[0].p, g->lat[0].p, g->cosa.p, g->sina.p);
+    MPG_HIP(hipGetLastError());
+  }
+  MPG_HIP(hipStreamSynchronize(s));
+  return MPG_SUCCESS;
+}

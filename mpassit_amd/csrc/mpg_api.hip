@@ -169,7 +169,92 @@ int mpg_grid_destroy(mpg_grid g) {
     g->pyr[st].free();
   }
   g->cellpyr.free();
+  for (int st = 0; st < 4; ++st) {
+    g->lon[st].free();
+    g->lat[st].free();
+  }
+  for (int st = 0; st < 3; ++st) g->mapfac[st].free();
+  g->cosa.free();
+  g->sina.free();
   delete g;
+  return MPG_SUCCESS;
+}
+
+static void grid_shape(mpg_grid_s *g, int nx, int ny, int periodic_i) {
+  g->nx = nx;
+  g->ny = ny;
+  g->periodic = periodic_i;
+  g->snx[MPG_STAGGERLOC_CENTER] = nx;     g->sny[MPG_STAGGERLOC_CENTER] = ny;
+  g->snx[MPG_STAGGERLOC_EDGE1] = nx + 1;  g->sny[MPG_STAGGERLOC_EDGE1] = ny;
+  g->snx[MPG_STAGGERLOC_EDGE2] = nx;      g->sny[MPG_STAGGERLOC_EDGE2] = ny + 1;
+  g->snx[MPG_STAGGERLOC_CORNER] = nx + 1; g->sny[MPG_STAGGERLOC_CORNER] = ny + 1;
+}
+
+int mpg_grid_create_proj(const mpg_proj *proj, int nx, int ny, int periodic_i, mpg_grid *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(proj && out, "mpg_grid_create_proj: NULL argument");
+  MPG_ARG(nx > 0 && ny > 0, "mpg_grid_create_proj: nx, ny must be > 0");
+  MPG_ARG((int64_t)(nx + 1) * (ny + 1) < 0x7fffffff, "mpg_grid_create_proj: grid too large for int32 ids");
+  MPG_ARG(periodic_i >= 0 && periodic_i < 8 && ((periodic_i & MPG_GRID_PERIODIC_I) || !periodic_i),
+          "mpg_grid_create_proj: periodic_i must be 0 or MPG_GRID_PERIODIC_I [| MPG_GRID_NO_SOUTH_POLE | MPG_GRID_NO_NORTH_POLE]");
+  mpg_grid_s *g = new mpg_grid_s();
+  grid_shape(g, nx, ny, periodic_i);
+  int rc = mpg_k_target_grid(proj, g, g_stream);
+  if (rc) {
+    mpg_grid_destroy(g);
+    return rc;
+  }
+  *out = g;
+  return MPG_SUCCESS;
+}
+
+#define MPG_PROJ_GRID(g, what)                                                                  \
+  do {                                                                                          \
+    MPG_ARG(g, what ": NULL grid");                                                             \
+    if (!(g)->from_proj) {                                                                      \
+      mpg_set_error(what ": the grid was created from caller arrays (mpg_grid_create), which the caller still holds"); \
+      return MPG_ERR_UNSUPPORTED;                                                               \
+    }                                                                                           \
+  } while (0)
+
+int mpg_grid_get_coords(mpg_grid g, int staggerloc, double *lon_host, double *lat_host) {
+  MPG_CHECK_INIT();
+  MPG_PROJ_GRID(g, "mpg_grid_get_coords");
+  MPG_ARG(staggerloc >= 0 && staggerloc < 4, "mpg_grid_get_coords: bad staggerloc");
+  size_t bytes = sizeof(double) * (size_t)g->snx[staggerloc] * g->sny[staggerloc];
+  if (lon_host) MPG_HIP(hipMemcpy(lon_host, g->lon[staggerloc].p, bytes, hipMemcpyDeviceToHost));
+  if (lat_host) MPG_HIP(hipMemcpy(lat_host, g->lat[staggerloc].p, bytes, hipMemcpyDeviceToHost));
+  return MPG_SUCCESS;
+}
+
+int mpg_grid_get_mapfac(mpg_grid g, int staggerloc, double *mapfac_host) {
+  MPG_CHECK_INIT();
+  MPG_PROJ_GRID(g, "mpg_grid_get_mapfac");
+  MPG_ARG(staggerloc >= 0 && staggerloc < 3 && mapfac_host, "mpg_grid_get_mapfac: CENTER, EDGE1 or EDGE2 and a buffer");
+  MPG_HIP(hipMemcpy(mapfac_host, g->mapfac[staggerloc].p, sizeof(double) * (size_t)g->snx[staggerloc] * g->sny[staggerloc],
+                    hipMemcpyDeviceToHost));
+  return MPG_SUCCESS;
+}
+
+int mpg_grid_rotang_dev(mpg_grid g, const double **cosa_dev, const double **sina_dev) {
+  MPG_CHECK_INIT();
+  MPG_PROJ_GRID(g, "mpg_grid_rotang_dev");
+  if (!g->cosa.p) {
+    mpg_set_error("mpg_grid_rotang_dev: cos/sin(alpha) exist for PROJ_LC grids only (model_grid.F90:1113)");
+    return MPG_ERR_UNSUPPORTED;
+  }
+  if (cosa_dev) *cosa_dev = g->cosa.p;
+  if (sina_dev) *sina_dev = g->sina.p;
+  return MPG_SUCCESS;
+}
+
+int mpg_grid_get_rotang(mpg_grid g, double *cosa_host, double *sina_host) {
+  const double *c, *s;
+  int rc = mpg_grid_rotang_dev(g, &c, &s);
+  if (rc) return rc;
+  size_t bytes = sizeof(double) * (size_t)g->nx * g->ny;
+  if (cosa_host) MPG_HIP(hipMemcpy(cosa_host, c, bytes, hipMemcpyDeviceToHost));
+  if (sina_host) MPG_HIP(hipMemcpy(sina_host, s, bytes, hipMemcpyDeviceToHost));
   return MPG_SUCCESS;
 }
 

@@ -146,6 +146,19 @@ struct mpg_grid_s {
   int snx[4], sny[4];
   Pyramid pyr[4];   // point pyramids (per stagger), built lazily
   Pyramid cellpyr;  // pyramid over CENTER cells bounded by CORNER points (conservative)
+  // grids created from a projection (mpg_grid_create_proj) also keep what the output file needs
+  bool from_proj = false;
+  int proj_code = 0;
+  DevBuf<double> lon[4], lat[4];  // degrees, per stagger
+  DevBuf<double> mapfac[3];       // CENTER, EDGE1, EDGE2
+  DevBuf<double> cosa, sina;      // CENTER, PROJ_LC only
+};
+
+// projection constants handed to the kernels by value (proj_info subset, module_map_utils.F90:140-192)
+struct ProjDev {
+  int code;
+  double hemi, truelat1, truelat2, stdlon, cone, polei, polej, rebydx, lat1, lon1, knowni, knownj, latinc, loninc;
+  int nxmin, nxmax;
 };
 
 enum { MPG_KIND_FIXED = 0, MPG_KIND_CSR = 1 };
@@ -177,6 +190,7 @@ struct mpg_handle_s {
 // ---- launchers implemented in the kernel TUs ---------------------------------------------------
 int mpg_k_mesh_coords(int64_t n, const double *lon_rad, const double *lat_rad, PointSet &out, hipStream_t s);
 int mpg_k_grid_coords(int64_t n, const double *lon_deg, const double *lat_deg, PointSet &out, hipStream_t s);
+int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s);
 int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s);
 int mpg_k_build_pyramid(const PointSet &pts, int nx, int ny, Pyramid &pyr, hipStream_t s);
 int mpg_k_build_cell_pyramid(const PointSet &corner, int nx, int ny, Pyramid &pyr, hipStream_t s);

@@ -70,6 +70,13 @@ class Mesh:
             self._h = C.c_void_p()
 
 
+class _Proj(C.Structure):
+    """struct mpg_proj (include/mpassit_amd.h)."""
+    _fields_ = [("code", C.c_int), ("known_lat", C.c_double), ("known_lon", C.c_double), ("known_x", C.c_double),
+                ("known_y", C.c_double), ("dx_m", C.c_double), ("stand_lon", C.c_double), ("truelat1", C.c_double),
+                ("truelat2", C.c_double), ("dlat_deg", C.c_double), ("dlon_deg", C.c_double)]
+
+
 class Grid:
     """Structured target grid with its four staggers (degrees, arrays [nj][ni], i fastest)."""
 
@@ -100,6 +107,41 @@ class Grid:
             flags |= (L.GRID_NO_SOUTH_POLE if j0 > 0 else 0) | (L.GRID_NO_NORTH_POLE if j1 < g.ny else 0)
         return cls(g.lon[j0:j1], g.lat[j0:j1], g.lon_c[j0:j1 + 1], g.lat_c[j0:j1 + 1], g.lon_u[j0:j1], g.lat_u[j0:j1],
                    g.lon_v[j0:j1 + 1], g.lat_v[j0:j1 + 1], periodic=flags)
+
+    @classmethod
+    def from_proj(cls, g, fill_target=True):
+        """Device-side target grid (mpg_grid_create_proj): all four staggers, map factors and cos/sin(alpha) are
+        computed on the GPU from the projection of target_grid.TargetGrid `g` (built with arrays=False or not).
+        fill_target: copy cos/sin(alpha) back into `g` (interp's wind rotation reads them from there)."""
+        p = g.proj
+        c = _Proj(code=p.code, known_lat=p.lat1, known_lon=p.lon1, known_x=p.knowni, known_y=p.knownj, dx_m=p.dx,
+                  stand_lon=p.stdlon, truelat1=p.truelat1, truelat2=p.truelat2, dlat_deg=p.latinc, dlon_deg=p.loninc)
+        self = cls.__new__(cls)
+        self.nx, self.ny = g.nx, g.ny
+        self._h = C.c_void_p()
+        check(L.load().mpg_grid_create_proj(C.byref(c), C.c_int(g.nx), C.c_int(g.ny),
+                                            C.c_int(0 if g.is_regional else L.GRID_PERIODIC_I), C.byref(self._h)))
+        if fill_target and p.code == 1:
+            g.cosa, g.sina = self.rotang()
+        return self
+
+    def coords(self, staggerloc):
+        """(lon, lat) in degrees of a projection-built grid, [nj][ni] of that stagger (XLONG/XLAT[_U,_V] of the file)."""
+        lon, lat = np.empty(self.stagger_shape(staggerloc)), np.empty(self.stagger_shape(staggerloc))
+        check(L.load().mpg_grid_get_coords(self._h, C.c_int(staggerloc), _ptr(lon), _ptr(lat)))
+        return lon, lat
+
+    def rotang(self):
+        """(cosalpha, sinalpha) [ny][nx] (get_rotang, model_grid.F90:2450-2507); Lambert grids only."""
+        cosa, sina = np.empty((self.ny, self.nx)), np.empty((self.ny, self.nx))
+        check(L.load().mpg_grid_get_rotang(self._h, _ptr(cosa), _ptr(sina)))
+        return cosa, sina
+
+    def mapfac(self, staggerloc):
+        """MAPFAC_M / _U / _V (get_map_factor, model_grid.F90:2229-2365)."""
+        mf = np.empty(self.stagger_shape(staggerloc))
+        check(L.load().mpg_grid_get_mapfac(self._h, C.c_int(staggerloc), _ptr(mf)))
+        return mf
 
     def stagger_shape(self, staggerloc):
         return {STAGGERLOC_CENTER: (self.ny, self.nx), STAGGERLOC_EDGE1: (self.ny, self.nx + 1),

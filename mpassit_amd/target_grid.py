@@ -193,9 +193,11 @@ class TargetGrid:
 
 
 def define_target_grid_params(target_grid_type, nx, ny, dx=NAN, dy=NAN, ref_lat=NAN, ref_lon=NAN, ref_x=NAN, ref_y=NAN,
-                              truelat1=NAN, truelat2=NAN, stand_lon=NAN, is_regional=True):
+                              truelat1=NAN, truelat2=NAN, stand_lon=NAN, is_regional=True, arrays=True):
     """Namelist (&config, program_setup.F90:103-106) -> TargetGrid.  nx, ny are the namelist's
-    STAGGERED counts: the mass grid is (nx-1) x (ny-1) (program_setup.F90:163-164)."""
+    STAGGERED counts: the mass grid is (nx-1) x (ny-1) (program_setup.F90:163-164).
+    arrays=False stops after the namelist checks and the projection set-up: the coordinate arrays are then
+    produced on the device by `regrid.Grid.from_proj(target)`."""
     i_target, j_target = nx - 1, ny - 1
     kind = target_grid_type.upper()
     known_x, known_y, known_lat, known_lon = ref_x, ref_y, ref_lat, ref_lon
@@ -229,6 +231,8 @@ def define_target_grid_params(target_grid_type, nx, ny, dx=NAN, dy=NAN, ref_lat=
     else:
         proj = Proj.latlon(known_lat, known_lon, known_x, known_y, dlatdeg, dlondeg)
     g = TargetGrid(i_target, j_target, proj, is_regional)
+    if not arrays:      # coordinates are generated on the device (regrid.Grid.from_proj -> mpg_grid_create_proj)
+        return g
     g.lat, g.lon = proj.lat_lon_fields(i_target, j_target, M)
     g.lat_v, g.lon_v = proj.lat_lon_fields(i_target, j_target + 1, V)
     g.lat_u, g.lon_u = proj.lat_lon_fields(i_target + 1, j_target, U)

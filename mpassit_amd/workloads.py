@@ -16,8 +16,14 @@ def conus_lambert_grid(nx=1801, ny=1061, **over):
     return tg.define_target_grid_params("lambert", nx, ny, **p)
 
 
-def workload(name):
-    """-> (MpasMesh, TargetGrid, nlev, description)"""
+def workload(name, arrays=True):
+    """-> (MpasMesh, TargetGrid, nlev, description).  arrays=False: the TargetGrid carries only the projection
+    (coordinates are then generated on the device, regrid.Grid.from_proj); regional Lambert workloads only."""
+    if not arrays:
+        m, g, nlev, desc = workload(name)
+        if g.proj.code != tg.PROJ_LC or name == "tiny":
+            raise KeyError("arrays=False is wired for the CONUS Lambert workloads")
+        return m, conus_lambert_grid(arrays=False), nlev, desc
     if name == "c4_3m_regional":
         g = conus_lambert_grid()
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)

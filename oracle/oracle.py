@@ -275,3 +275,19 @@ def post_ptop(p_hyd):
     if cand.size:
         v = min(v, cand.min())
     return np.float32(v)
+
+
+def map_factor(lat_deg, proj_code, truelat1, truelat2):
+    """get_map_factor (model_grid.F90:2229-2365) for PROJ_LC (= 1); PROJ_LATLON (= 0) has no branch in the reference
+    (the arrays stay unset there), the product returns 1.0."""
+    lat_deg = np.asarray(lat_deg, np.float64)
+    if proj_code != 1:
+        return np.ones_like(lat_deg)
+    rad = 3.141592653589793 / 180.0
+    colat = rad * (90.0 - lat_deg)
+    if truelat1 != truelat2:
+        c1, c2 = rad * (90.0 - truelat1), rad * (90.0 - truelat2)
+        n = (np.log(np.sin(c1)) - np.log(np.sin(c2))) / (np.log(np.tan(c1 / 2.0)) - np.log(np.tan(c2 / 2.0)))
+        return np.sin(c2) / np.sin(colat) * (np.tan(colat / 2.0) / np.tan(c2 / 2.0)) ** n
+    c0 = rad * (90.0 - truelat1)
+    return np.sin(c0) / np.sin(colat) * (np.tan(colat / 2.0) / np.tan(c0 / 2.0)) ** np.cos(c0)
