@@ -39,12 +39,19 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
 // workgroup's waves in level lock-step with a barrier so that lines shared between neighbouring rows are
 // still in L1/L2 when the next wave asks for them.  Each workgroup serves `fpw` fields of its tile back to back,
 // so indices and weights are read once per tile instead of once per field.  Destination stores are non-temporal.
-template <int RPT, int WAVES, bool SYNC>
+// WX = target points a wave spans in i (64: one row of 64; 16: a 16 x 4 patch, i.e. four 128-byte store segments per
+// instruction).  Compact patches keep the gather footprint of ONE load instruction inside few cache lines when the
+// source cells are numbered along a space-filling curve (production MPAS meshes, synth.icosahedral_mesh) instead of
+// row by row; the tile stays 64 wide.
+template <int RPT, int WAVES, bool SYNC, int WX = 64>
 __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                           const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
                                                           int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk,
                                                           int nfields, int fpw, int tgroup) {
-  constexpr int TY = WAVES * RPT;
+  constexpr int WH = 64 / WX;           // rows a wave spans per instruction
+  constexpr int CG = A3_TX / WX;        // waves side by side in a tile
+  static_assert(WAVES % CG == 0, "waves must fill whole tile rows");
+  constexpr int TY = (WAVES / CG) * WH * RPT;
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -58,8 +65,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   int bh = min(tgroup, nty - band * tgroup);   // rows in this (possibly last, shorter) band
   int tx = rem / bh, ty = band * tgroup + rem % bh;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int i = tx * A3_TX + lane;
-  int j0 = ty * TY + wave * RPT;
+  int i = tx * A3_TX + (wave % CG) * WX + (lane % WX);
+  int j0 = ty * TY + (wave / CG) * (WH * RPT) + lane / WX;   // thread rows: j0, j0 + WH, ...
   int k0 = chunk * lev_chunk, k1 = min(nlev, k0 + lev_chunk);
 
   int32_t c[RPT][3];
@@ -67,7 +74,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   bool act[RPT], mapped[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
-    int j = j0 + r;
+    int j = j0 + r * WH;
     act[r] = (i < nx) && (j < ny);
     int64_t p = act[r] ? (int64_t)j * nx + i : 0;
 #pragma unroll
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
       }
 #pragma unroll
       for (int r = 0; r < RPT; ++r)
-        if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + (int64_t)r * nx);
+        if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + (int64_t)r * WH * nx);
       s += nsrc;
       d += P;
     }
@@ -100,14 +107,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
 }
 
 typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int, int, int, int);
-struct A3Variant { int rpt, waves, sync; apply3_fn fn; };
+struct A3Variant { int rpt, waves, sync, wx; apply3_fn fn; };
 static const A3Variant g_a3_variants[] = {
-    {2, 4, 0, k_apply3_cf<2, 4, false>},  {2, 4, 1, k_apply3_cf<2, 4, true>},   {2, 8, 0, k_apply3_cf<2, 8, false>},
-    {2, 8, 1, k_apply3_cf<2, 8, true>},   {2, 16, 0, k_apply3_cf<2, 16, false>}, {2, 16, 1, k_apply3_cf<2, 16, true>},
-    {1, 8, 1, k_apply3_cf<1, 8, true>},   {1, 16, 1, k_apply3_cf<1, 16, true>},  {4, 4, 0, k_apply3_cf<4, 4, false>},
-    {4, 8, 1, k_apply3_cf<4, 8, true>},   {1, 4, 0, k_apply3_cf<1, 4, false>},   {1, 16, 0, k_apply3_cf<1, 16, false>},
-    {4, 4, 1, k_apply3_cf<4, 4, true>},
+    {2, 4, 0, 64, k_apply3_cf<2, 4, false>},  {2, 4, 1, 64, k_apply3_cf<2, 4, true>},   {2, 8, 0, 64, k_apply3_cf<2, 8, false>},
+    {2, 8, 1, 64, k_apply3_cf<2, 8, true>},   {2, 16, 0, 64, k_apply3_cf<2, 16, false>}, {2, 16, 1, 64, k_apply3_cf<2, 16, true>},
+    {1, 8, 1, 64, k_apply3_cf<1, 8, true>},   {1, 16, 1, 64, k_apply3_cf<1, 16, true>},  {4, 4, 0, 64, k_apply3_cf<4, 4, false>},
+    {4, 8, 1, 64, k_apply3_cf<4, 8, true>},   {1, 4, 0, 64, k_apply3_cf<1, 4, false>},   {1, 16, 0, 64, k_apply3_cf<1, 16, false>},
+    {4, 4, 1, 64, k_apply3_cf<4, 4, true>},
+    // 13..: compact wave patches (16 x 4 and 32 x 2 points per instruction)
+    {2, 4, 1, 16, k_apply3_cf<2, 4, true, 16>},  {2, 4, 0, 16, k_apply3_cf<2, 4, false, 16>}, {2, 8, 1, 16, k_apply3_cf<2, 8, true, 16>},
+    {1, 8, 1, 16, k_apply3_cf<1, 8, true, 16>},  {4, 4, 1, 16, k_apply3_cf<4, 4, true, 16>},  {2, 4, 1, 32, k_apply3_cf<2, 4, true, 32>},
+    {2, 8, 1, 32, k_apply3_cf<2, 8, true, 32>},  {1, 8, 1, 32, k_apply3_cf<1, 8, true, 32>},
 };
+static inline int a3_tile_rows(const A3Variant &v) { return (v.waves / (64 / v.wx)) * (64 / v.wx) * v.rpt; }
 static int g_a3_variant = 1;  // "a3_variant" knob (tuned on MI355X: profiles/r01_sweep_apply*.txt)
 static int g_fpw = 1;         // "fields_per_wg" knob (0 = all fields in one workgroup pass)
 static int g_tgroup = 1;      // "tile_group" knob: tile rows per band (1 = plain row-major tile order)
@@ -193,7 +205,8 @@ static const LfVariant g_lf_variants[] = {
     {64, 8, k_apply3_lf<64, 8, 4>},  {64, 16, k_apply3_lf<64, 16, 4>}, {64, 16, k_apply3_lf<64, 16, 2>}, {32, 8, k_apply3_lf<32, 8, 8>},
     {64, 2, k_apply3_lf<64, 2, 16>}, {64, 2, k_apply3_lf<64, 2, 8>},
 };
-static int g_lf_variant = 4;  // "lf_variant" knob (8 waves x 8 points, 4 points in flight: tuned on MI355X)
+#define LF_DEFAULT_ROW_GATHER 4  // 8 waves x 8 points, 4 points in flight: tuned on MI355X
+static int g_lf_variant = -1;    // "lf_variant" knob: -1 = per-handle choice between row-gather #4 and the LDS-staged kernel
 static int g_lf_fpw = 1;      // "lf_fields_per_wg" knob (looping fields inside a workgroup measured slower)
 
 // nearest neighbour: bit-exact copy
@@ -298,7 +311,11 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "fields_per_wg")) { g_fpw = value; return MPG_SUCCESS; }
   if (!strcmp(key, "tile_group")) { g_tgroup = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_fields_per_wg")) { g_lf_fpw = value < 1 ? 1 : value; return MPG_SUCCESS; }
-  if (!strcmp(key, "lf_variant")) {
+  if (!strcmp(key, "lf_variant")) {  // 0.. : k_apply3_lf variants; 100.. : LDS-staged unique-cell variants (k_apply_lfu.hip)
+    if (value == -1 || (value >= 100 && value < 100 + mpg_lfu_num_variants())) {
+      g_lf_variant = value;
+      return MPG_SUCCESS;
+    }
     if (value < 0 || value >= (int)(sizeof(g_lf_variants) / sizeof(g_lf_variants[0]))) return MPG_ERR_INVALID_ARG;
     g_lf_variant = value;
     return MPG_SUCCESS;
@@ -327,8 +344,17 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
   } else if (h->nnz_per_row == 4) {
     k_applyN<4><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
   } else if (h->nnz_per_row == 3) {
-    if (lev_fast) {
-      const LfVariant &lv = g_lf_variants[g_lf_variant];
+    int lfv = g_lf_variant;
+    if (lev_fast && lfv < 0) {  // auto: per handle, by the reuse statistic of its tile lists (k_apply_lfu.hip)
+      int pick, rc = mpg_lfu_auto(h, s, &pick);
+      if (rc) return rc;
+      lfv = pick >= 0 ? 100 + pick : LF_DEFAULT_ROW_GATHER;
+    }
+    if (lev_fast && lfv >= 100) {
+      int rc = mpg_k_apply3_lfu(h, lfv - 100, src, nlev, nfields, dst, s);
+      if (rc) return rc;
+    } else if (lev_fast) {
+      const LfVariant &lv = g_lf_variants[lfv];
       int tyl = 64 / lv.txl;
       int ntx = (h->nx_dst + lv.txl - 1) / lv.txl, nty = (h->ny_dst + tyl - 1) / tyl;
       size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
@@ -343,7 +369,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
                                                                      nfields, fpw);
     } else {
       const A3Variant &av = g_a3_variants[g_a3_variant];
-      int tyv = av.waves * av.rpt;
+      int tyv = a3_tile_rows(av);
       int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + tyv - 1) / tyv;
       int lc = g_lev_chunk > 0 ? g_lev_chunk : nlev;
       int nchunk = (nlev + lc - 1) / lc;

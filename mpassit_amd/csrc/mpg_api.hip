@@ -268,6 +268,9 @@ static void handle_free(mpg_handle_s *h) {
   h->pole_dst.free();
   h->pole_src0.free();
   h->pole_w.free();
+  h->ut_ptr.free();
+  h->ut_cells.free();
+  h->lidx.free();
   delete h;
 }
 
@@ -577,6 +580,15 @@ int mpg_handle_get_pole(mpg_handle h, int32_t *dst_id_host, int32_t *src_row_sta
   return MPG_SUCCESS;
 }
 
+// the tile lists of the LDS-staged level-fast kernel hold source ids: re-indexing a handle drops them
+static void lf_invalidate(mpg_handle_s *h) {
+  h->ut_ptr.free();
+  h->ut_cells.free();
+  h->lidx.free();
+  h->ut_rpt = 0;
+  h->lf_choice = 0;
+}
+
 // ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------
 int mpg_handle_unique_sources(mpg_handle h, int64_t *n_unique, int32_t *ids_host) {
   MPG_CHECK_INIT();
@@ -602,6 +614,7 @@ int mpg_handle_localize(mpg_handle h) {
     h->cached = false;
   }
   std::vector<int32_t> ids;
+  lf_invalidate(h);
   return mpg_k_unique_sources(h, ids, true, g_stream);
 }
 
@@ -615,6 +628,7 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
     g_cache.erase(h->key);
     h->cached = false;
   }
+  lf_invalidate(h);
   return mpg_k_rebase(h, base, n_local, g_stream);
 }
 

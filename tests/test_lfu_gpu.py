@@ -1,0 +1,56 @@
+"""LDS-staged level-fast Regrid (k_apply_lfu.hip): every variant must reproduce the cell-fast kernel bit for bit
+(same wsum3 arithmetic, only the data path differs) on meshes with unmapped rims, global meshes with Morton or
+bisection numbering, randomly renumbered cells, ragged tile edges and several fields."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LFU = list(range(100, 112))      # 100-105 two-phase, 106-111 software-pipelined
+
+
+def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    rng = np.random.default_rng(seed)
+    src = rng.normal(size=(nfields, nlev, m.nCells))
+    want = rh.regrid(src.reshape(-1), nlev=nlev, nfields=nfields)
+    src_lf = np.ascontiguousarray(src.transpose(0, 2, 1))
+    try:
+        for v in LFU:
+            gpu_lib.tune("lf_variant", v)
+            got = rh.regrid(src_lf.reshape(-1), nlev=nlev, nfields=nfields, layout=R.LAYOUT_LEV_FAST)
+            assert np.array_equal(got, want), "lf_variant %d differs" % v
+        gpu_lib.tune("lf_variant", -1)                      # the default: per-handle choice
+        got = rh.regrid(src_lf.reshape(-1), nlev=nlev, nfields=nfields, layout=R.LAYOUT_LEV_FAST)
+        assert np.array_equal(got, want)
+        rh.rebase(0, m.nCells)                               # re-indexing drops the tile lists; they are rebuilt on demand
+        got = rh.regrid(src_lf.reshape(-1), nlev=nlev, nfields=nfields, layout=R.LAYOUT_LEV_FAST)
+        assert np.array_equal(got, want)
+    finally:
+        gpu_lib.tune("lf_variant", -1)
+    unmapped = int((rh.weights()[0][:, 0] < 0).sum())
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+    return unmapped
+
+
+def test_regional_mesh_with_unmapped_rim(gpu_lib, regional_case):
+    from mpassit_amd import regrid as R
+    m, g = regional_case
+    assert _check(R, gpu_lib, m, g, nlev=13) > 0            # 13 levels: ragged last level chunk for every LC
+
+
+def test_global_meshes_and_numberings(gpu_lib):
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    g = T.define_target_grid_params("lat-lon", nx=331, ny=167, stand_lon=0.0, is_regional=False)   # 330 x 166: ragged tiles
+    for m in (synth.icosahedral_mesh(5), synth.icosahedral_mesh(5, order="native"),
+              synth.shuffle_cells(synth.icosahedral_mesh(4), seed=5)):
+        assert _check(R, gpu_lib, m, g, nlev=55, nfields=1) == 0
+
+
+def test_tiny_workload_many_fields(gpu_lib):
+    from mpassit_amd import regrid as R, workloads
+    m, g, nlev, _ = workloads.workload("tiny")
+    _check(R, gpu_lib, m, g, nlev=nlev, nfields=5)
