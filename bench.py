@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--calib", action="store_true", help="also launch a known-byte-count streaming kernel (PMC calibration)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="kernel knob for experiments (mpg_tune), e.g. a3_variant=12; the default run sets none")
     return ap.parse_args()
 
 
@@ -91,6 +93,9 @@ def main():
 
     from mpassit_amd import _lib, dist as mdist, regrid as R, workloads
     _lib.init(dev_index)
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.tune(k, int(v))
     arch, n_cu, hbm = _lib.device_info()
 
     t0 = time.time()

@@ -1,48 +1,50 @@
 // K2'' k_apply3_lfu: 3-point Regrid from the level-fastest source ([ncell][nlev], MPAS file order) with the tile's
 // UNIQUE source cells staged through LDS.
 //
-// Why: k_apply3_lf reads three source rows per target point; neighbouring target points share cells (1.4-2.5 points
-// per cell on the BASELINE configs), so the same row crosses the L2 -> CU path several times and the kernel ends up
-// bound there, not by HBM (4.6 TB/s on C4, 2.9 TB/s on the 6.5 M-point global target).  Here every
-// tile of 64 x 4*RPT target points carries the sorted list of the cells its points reference (built once per handle,
-// on the device) and each point keeps three 16-bit positions in that list.  Per chunk of LC levels the workgroup
-// loads each unique row ONCE (LC consecutive doubles = one 64/128-byte segment per row, lanes along the levels),
-// parks it in LDS ([row][LC+1]: odd stride, conflict-free for the column reads) and every thread combines its points
-// from LDS; stores are 512-byte non-temporal row segments per level as in the other kernels.
-// HBM traffic per tile = unique rows (+ the one-cell halo ring shared with the neighbour tiles) + the destination:
-// independent of how the mesh numbers its cells.  Arithmetic = wsum3, bit-identical to the other variants.
+// Why: k_apply3_lf reads three source rows per target point; neighbouring target points share cells (1.4-2.9 points
+// per cell on the BASELINE configs), so the same row crosses the L2 -> CU path several times and that kernel ends up
+// latency/issue bound, not HBM bound (2.6-2.8 TB/s on the 655 k-cell and global configs).  Here every tile of
+// TXU x TY target points (256*RPT points) carries the sorted list of the cells its points reference (built once per
+// handle, on the device) and each point keeps three 16-bit positions in that list.  Per chunk of LC levels the
+// workgroup loads each unique row ONCE (LC consecutive doubles = one 64/128-byte segment per row, lanes along the
+// levels), parks it in LDS ([row][LC+1]: odd stride, conflict-free column reads) and every thread combines its
+// points from LDS; stores are >= 128-byte non-temporal row segments per level as in the other kernels.  The
+// pipelined form fetches chunk c+1 into registers while chunk c is combined and stored.
+// HBM traffic per tile = unique rows (+ the one-cell ring shared with the neighbour tiles) + the destination,
+// independent of how the mesh numbers its cells; compact tiles (32 x 8, 16 x 16) keep the ring small.
+// Arithmetic = wsum3, bit-identical to the other variants.
 #include <limits.h>
 #include <string.h>
 
 #include "geom.h"
 #include "mpg_internal.h"
 
-#define LFU_TX 64
 #define LFU_THREADS 256
+#define LFU_SORT 2048   // sort buffer: 3 ids x (at most) 512 points, padded to a power of two
 
 __device__ __forceinline__ unsigned lfu_xcd_remap(unsigned lin, unsigned n) {
   unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// ---- per-tile unique cell lists -------------------------------------------------------------------------
-// One workgroup per tile: the 3*NP cell ids are sorted in LDS (bitonic), duplicates dropped, and each point's three
-// ids are replaced by their rank in the tile's list.  FILL = false only counts (-> scan -> FILL = true).
-template <int RPT, bool FILL>
-__global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__restrict__ idx, int nx, int ny, int ntx,
+// ---- per-tile unique cell lists (set-up, runtime tile shape) --------------------------------------------------
+// One workgroup per tile of txu x tyu points: the 3*np cell ids are sorted in LDS (bitonic), duplicates dropped,
+// and each point's three ids are replaced by their rank in the tile's list.  FILL = false only counts.
+template <bool FILL>
+__global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__restrict__ idx, int nx, int ny, int txu, int tyu, int ntx,
                                                            int32_t *__restrict__ ut_count, const int32_t *__restrict__ ut_ptr,
                                                            int32_t *__restrict__ ut_cells, uint16_t *__restrict__ lidx) {
-  constexpr int TY = 4 * RPT, NP = LFU_TX * TY, NK = 3 * NP;
-  constexpr int SB = NK <= 1024 ? 1024 : (NK <= 2048 ? 2048 : 4096);
+  constexpr int SB = LFU_SORT, PER = SB / LFU_THREADS;
   __shared__ int32_t keys[SB];
   __shared__ int32_t part[LFU_THREADS + 1];
+  const int np = txu * tyu, nk = 3 * np;
   const int64_t P = (int64_t)nx * ny;
   const int tile = blockIdx.x, tx = tile % ntx, ty = tile / ntx, t = threadIdx.x;
   for (int e = t; e < SB; e += LFU_THREADS) {
     int32_t key = INT_MAX;
-    if (e < NK) {
-      int q = e / NP, pt = e % NP;
-      int i = tx * LFU_TX + pt % LFU_TX, j = ty * TY + pt / LFU_TX;
+    if (e < nk) {
+      int q = e / np, pt = e % np;
+      int i = tx * txu + pt % txu, j = ty * tyu + pt / txu;
       if (i < nx && j < ny) {
         int32_t c = idx[q * P + (int64_t)j * nx + i];
         if (c >= 0) key = c;
@@ -66,14 +68,14 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
       }
       __syncthreads();
     }
-  // unique count: thread t owns the contiguous slice [t*PER, (t+1)*PER)
-  constexpr int PER = SB / LFU_THREADS;
-  int cnt = 0;
+  // thread t owns the contiguous slice [t*PER, (t+1)*PER): collect its first occurrences
+  int32_t mine[PER];
+  int nm = 0;
   for (int e = t * PER; e < (t + 1) * PER; ++e) {
     int32_t v = keys[e];
-    if (v != INT_MAX && (e == 0 || keys[e - 1] != v)) ++cnt;
+    if (v != INT_MAX && (e == 0 || keys[e - 1] != v)) mine[nm++] = v;
   }
-  part[t + 1] = cnt;
+  part[t + 1] = nm;
   if (t == 0) part[0] = 0;
   __syncthreads();
   if (t == 0)
@@ -84,22 +86,14 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
     if (t == 0) ut_count[tile] = total;
     return;
   }
-  // compact in place is unsafe (readers of keys[e-1]): collect this thread's uniques first, then write
-  int32_t mine[PER];
-  int nm = 0;
-  for (int e = t * PER; e < (t + 1) * PER; ++e) {
-    int32_t v = keys[e];
-    if (v != INT_MAX && (e == 0 || keys[e - 1] != v)) mine[nm++] = v;
-  }
-  __syncthreads();
-  const int base = part[t];
+  const int base = part[t];   // every read of keys[] happened before the barriers above: compact in place
   for (int q = 0; q < nm; ++q) {
     keys[base + q] = mine[q];
     ut_cells[ut_ptr[tile] + base + q] = mine[q];
   }
   __syncthreads();
-  for (int pt = t; pt < NP; pt += LFU_THREADS) {
-    int i = tx * LFU_TX + pt % LFU_TX, j = ty * TY + pt / LFU_TX;
+  for (int pt = t; pt < np; pt += LFU_THREADS) {
+    int i = tx * txu + pt % txu, j = ty * tyu + pt / txu;
     if (i >= nx || j >= ny) continue;
     int64_t p = (int64_t)j * nx + i;
 #pragma unroll
@@ -121,49 +115,59 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
 }
 
 // ---- Regrid ---------------------------------------------------------------------------------------------
-template <int RPT, int LC>
+// Thread t serves points pt = t + 256*r (r < RPT) of the tile in row-major order: a wave covers 64 consecutive
+// points = 64/TXU rows of TXU points (512-, 256- or 128-byte store segments).
+template <int TXU, int RPT>
+struct LfuPoints {
+  int l[RPT][3];
+  double ww[RPT][3];
+  bool act[RPT], mapped[RPT];
+  int64_t off[RPT];  // j*nx + i
+  __device__ __forceinline__ void load(const uint16_t *__restrict__ lidx, const double *__restrict__ w, int nx, int ny, int tx, int ty, int LS) {
+    constexpr int TY = LFU_THREADS * RPT / TXU;
+    const int64_t P = (int64_t)nx * ny;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      int pt = (int)threadIdx.x + LFU_THREADS * r;
+      int i = tx * TXU + pt % TXU, j = ty * TY + pt / TXU;
+      act[r] = i < nx && j < ny;
+      off[r] = act[r] ? (int64_t)j * nx + i : 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        l[r][q] = lidx[q * P + off[r]];
+        ww[r][q] = w[q * P + off[r]];
+      }
+      mapped[r] = l[r][0] != 0xFFFF;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) l[r][q] = mapped[r] ? l[r][q] * LS : 0;
+    }
+  }
+};
+
+// two-phase form (load chunk, barrier, combine, barrier): the reference implementation of the scheme
+template <int TXU, int RPT, int LC>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                             const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                             const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
                                                             int64_t nsrc, int nlev, int ntx, int nty, int nfields, int ut_max) {
-  constexpr int TY = 4 * RPT, LS = LC + 1, RPP = LFU_THREADS / LC;  // RPP = rows loaded per pass
-  extern __shared__ double lds[];           // rows [ut_max][LS] | cell ids [ut_max]
+  constexpr int LS = LC + 1, RPP = LFU_THREADS / LC;  // RPP = rows loaded per pass
+  extern __shared__ double lds[];                     // rows [ut_max][LS] | cell ids [ut_max]
   int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
-  const int tx = tile % ntx, ty = tile / ntx;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   for (int r = t; r < nU; r += LFU_THREADS) cells[r] = ut_cells[u0 + r];
-
-  const int i = tx * LFU_TX + lane;
-  const int j0 = ty * TY + wave * RPT;
-  int l[RPT][3];
-  double ww[RPT][3];
-  bool act[RPT], mapped[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    int j = j0 + r;
-    act[r] = i < nx && j < ny;
-    int64_t p = act[r] ? (int64_t)j * nx + i : 0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      l[r][q] = lidx[q * P + p];
-      ww[r][q] = w[q * P + p];
-    }
-    mapped[r] = l[r][0] != 0xFFFF;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) l[r][q] = mapped[r] ? l[r][q] * LS : 0;
-  }
+  LfuPoints<TXU, RPT> pts;
+  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, LS);
   const double *sf = src + (int64_t)f * nlev * nsrc;
-  double *df = dst + (int64_t)f * nlev * P + (int64_t)j0 * nx + i;
+  double *df = dst + (int64_t)f * nlev * P;
   const int lrow = t / LC, llev = t % LC;
   __syncthreads();  // cells[] visible
   for (int k0 = 0; k0 < nlev; k0 += LC) {
-    // phase 1: every unique row's LC levels -> LDS, 4 loads in flight per thread
     const bool lev_ok = k0 + llev < nlev;
     for (int rb = lrow; rb < nU; rb += 4 * RPP) {
       double v[4];
@@ -179,14 +183,13 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__res
       }
     }
     __syncthreads();
-    // phase 2: combine from LDS, lanes = consecutive i
     const int kn = min(LC, nlev - k0);
     for (int kk = 0; kk < kn; ++kk) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        double a = lds[l[r][0] + kk], b = lds[l[r][1] + kk], e = lds[l[r][2] + kk];
-        double val = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
-        if (act[r]) __builtin_nontemporal_store(mapped[r] ? val : 0.0, df + (int64_t)(k0 + kk) * P + (int64_t)r * nx);
+        double a = lds[pts.l[r][0] + kk], b = lds[pts.l[r][1] + kk], e = lds[pts.l[r][2] + kk];
+        double val = wsum3(pts.ww[r][0], a, pts.ww[r][1], b, pts.ww[r][2], e);
+        if (pts.act[r]) __builtin_nontemporal_store(pts.mapped[r] ? val : 0.0, df + (int64_t)(k0 + kk) * P + pts.off[r]);
       }
     }
     __syncthreads();
@@ -196,12 +199,12 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__res
 // Software-pipelined form: the rows of level chunk c+1 are fetched into registers (NPF per thread) while chunk c is
 // combined from LDS and stored, so the global-load latency hides behind the LDS/ALU/store phase instead of sitting
 // between two barriers.  Tiles with more than NPF * (256/LC) unique rows load the surplus rows synchronously.
-template <int RPT, int LC, int NPF>
+template <int TXU, int RPT, int LC, int NPF>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                               const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
                                                               int64_t nsrc, int nlev, int ntx, int nty, int nfields, int ut_max) {
-  constexpr int TY = 4 * RPT, LS = LC + 1, RPP = LFU_THREADS / LC;
+  constexpr int LS = LC + 1, RPP = LFU_THREADS / LC;
   extern __shared__ double lds[];
   int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
   const int64_t P = (int64_t)nx * ny;
@@ -209,32 +212,13 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
   const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
-  const int tx = tile % ntx, ty = tile / ntx;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   for (int r = t; r < nU; r += LFU_THREADS) cells[r] = ut_cells[u0 + r];
-
-  const int i = tx * LFU_TX + lane;
-  const int j0 = ty * TY + wave * RPT;
-  int l[RPT][3];
-  double ww[RPT][3];
-  bool act[RPT], mapped[RPT];
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) {
-    int j = j0 + r;
-    act[r] = i < nx && j < ny;
-    int64_t p = act[r] ? (int64_t)j * nx + i : 0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      l[r][q] = lidx[q * P + p];
-      ww[r][q] = w[q * P + p];
-    }
-    mapped[r] = l[r][0] != 0xFFFF;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) l[r][q] = mapped[r] ? l[r][q] * LS : 0;
-  }
+  LfuPoints<TXU, RPT> pts;
+  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, LS);
   const double *sf = src + (int64_t)f * nlev * nsrc;
-  double *df = dst + (int64_t)f * nlev * P + (int64_t)j0 * nx + i;
+  double *df = dst + (int64_t)f * nlev * P;
   const int lrow = t / LC, llev = t % LC;
   __syncthreads();  // cells[] visible
   // this thread's rows: element offsets of (cell, level llev) inside the field, -1 = none
@@ -264,9 +248,9 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
     for (int kk = 0; kk < kn; ++kk) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        double a = lds[l[r][0] + kk], b = lds[l[r][1] + kk], e = lds[l[r][2] + kk];
-        double val = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
-        if (act[r]) __builtin_nontemporal_store(mapped[r] ? val : 0.0, df + (int64_t)(k0 + kk) * P + (int64_t)r * nx);
+        double a = lds[pts.l[r][0] + kk], b = lds[pts.l[r][1] + kk], e = lds[pts.l[r][2] + kk];
+        double val = wsum3(pts.ww[r][0], a, pts.ww[r][1], b, pts.ww[r][2], e);
+        if (pts.act[r]) __builtin_nontemporal_store(pts.mapped[r] ? val : 0.0, df + (int64_t)(k0 + kk) * P + pts.off[r]);
       }
     }
     __syncthreads();
@@ -275,31 +259,40 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
 
 typedef void (*lfu_fn)(const int32_t *, const int32_t *, const uint16_t *, const double *, const double *, double *, int, int, int64_t,
                        int, int, int, int, int);
-struct LfuVariant { int rpt, lc; lfu_fn fn; };
+struct LfuVariant { int txu, rpt, lc; lfu_fn fn; };
 static const LfuVariant g_lfu_variants[] = {
-    {1, 8, k_apply3_lfu<1, 8>}, {1, 16, k_apply3_lfu<1, 16>}, {2, 8, k_apply3_lfu<2, 8>}, {2, 16, k_apply3_lfu<2, 16>},
-    {1, 4, k_apply3_lfu<1, 4>}, {2, 4, k_apply3_lfu<2, 4>},
-    // 6..: software-pipelined
-    {1, 8, k_apply3_lfu_p<1, 8, 8>}, {1, 16, k_apply3_lfu_p<1, 16, 12>}, {2, 8, k_apply3_lfu_p<2, 8, 16>},
-    {2, 16, k_apply3_lfu_p<2, 16, 16>}, {1, 8, k_apply3_lfu_p<1, 8, 12>}, {1, 16, k_apply3_lfu_p<1, 16, 16>},
+    // 0-5: two-phase, 64-wide tiles
+    {64, 1, 8, k_apply3_lfu<64, 1, 8>},   {64, 1, 16, k_apply3_lfu<64, 1, 16>}, {64, 2, 8, k_apply3_lfu<64, 2, 8>},
+    {64, 2, 16, k_apply3_lfu<64, 2, 16>}, {64, 1, 4, k_apply3_lfu<64, 1, 4>},   {64, 2, 4, k_apply3_lfu<64, 2, 4>},
+    // 6-11: software-pipelined, 64-wide tiles
+    {64, 1, 8, k_apply3_lfu_p<64, 1, 8, 8>},    {64, 1, 16, k_apply3_lfu_p<64, 1, 16, 12>}, {64, 2, 8, k_apply3_lfu_p<64, 2, 8, 16>},
+    {64, 2, 16, k_apply3_lfu_p<64, 2, 16, 16>}, {64, 1, 8, k_apply3_lfu_p<64, 1, 8, 12>},   {64, 1, 16, k_apply3_lfu_p<64, 1, 16, 16>},
+    // 12-19: software-pipelined, compact tiles (32 x 8, 16 x 16, 32 x 16, 16 x 32 points)
+    {32, 1, 16, k_apply3_lfu_p<32, 1, 16, 16>}, {16, 1, 16, k_apply3_lfu_p<16, 1, 16, 16>}, {32, 1, 8, k_apply3_lfu_p<32, 1, 8, 8>},
+    {16, 1, 8, k_apply3_lfu_p<16, 1, 8, 8>},    {32, 2, 16, k_apply3_lfu_p<32, 2, 16, 16>}, {16, 2, 16, k_apply3_lfu_p<16, 2, 16, 16>},
+    {32, 1, 16, k_apply3_lfu_p<32, 1, 16, 12>}, {32, 1, 32, k_apply3_lfu_p<32, 1, 32, 16>},
 };
 int mpg_lfu_num_variants() { return (int)(sizeof(g_lfu_variants) / sizeof(g_lfu_variants[0])); }
 
-static int lfu_build(mpg_handle_s *h, int rpt, hipStream_t s) {
-  if (h->ut_rpt == rpt) return MPG_SUCCESS;
+static int lfu_build(mpg_handle_s *h, int txu, int rpt, hipStream_t s) {
+  const int key = txu * 16 + rpt;
+  if (h->ut_rpt == key) return MPG_SUCCESS;
   int rc;
   h->ut_ptr.free();
   h->ut_cells.free();
   h->ut_rpt = 0;
-  const int ty = 4 * rpt;
-  const int ntx = (h->nx_dst + LFU_TX - 1) / LFU_TX, nty = (h->ny_dst + ty - 1) / ty;
+  const int tyu = LFU_THREADS * rpt / txu;
+  if (3 * txu * tyu > LFU_SORT) {
+    mpg_set_error("staged Regrid: tile of %d x %d points exceeds the sort buffer", txu, tyu);
+    return MPG_ERR_UNSUPPORTED;
+  }
+  const int ntx = (h->nx_dst + txu - 1) / txu, nty = (h->ny_dst + tyu - 1) / tyu;
   const int64_t ntile = (int64_t)ntx * nty;
   TmpBuf<int32_t> count;
   if ((rc = count.alloc(ntile + 1)) || (rc = h->ut_ptr.alloc(ntile + 1))) return rc;
   if (!h->lidx.p && (rc = h->lidx.alloc(3 * (size_t)h->n_dst))) return rc;
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (ntile + 1), s));
-  if (rpt == 1) k_lfu_build<1, false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, ntx, count.p, nullptr, nullptr, nullptr);
-  else k_lfu_build<2, false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, ntx, count.p, nullptr, nullptr, nullptr);
+  k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, count.p, nullptr, nullptr, nullptr);
   MPG_HIP(hipGetLastError());
   std::vector<int32_t> hc((size_t)ntile + 1), hp((size_t)ntile + 1);
   MPG_HIP(hipMemcpyAsync(hc.data(), count.p, sizeof(int32_t) * (ntile + 1), hipMemcpyDeviceToHost, s));
@@ -318,28 +311,30 @@ static int lfu_build(mpg_handle_s *h, int rpt, hipStream_t s) {
   }
   MPG_HIP(hipMemcpyAsync(h->ut_ptr.p, hp.data(), sizeof(int32_t) * (ntile + 1), hipMemcpyHostToDevice, s));
   if ((rc = h->ut_cells.alloc((size_t)tot + 1))) return rc;
-  if (rpt == 1) k_lfu_build<1, true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p, h->lidx.p);
-  else k_lfu_build<2, true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p, h->lidx.p);
+  k_lfu_build<true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p,
+                                                           h->lidx.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
-  h->ut_rpt = rpt;
+  h->ut_rpt = key;
   h->ut_max = mx;
   h->ut_total = tot;
   return MPG_SUCCESS;
 }
 
 // Which level-fast kernel serves this handle?  Measured on MI355X (profiles/r01_sweep_lfu.txt), 4 fields x 55 levels:
-//   target points per source cell   row-gather k_apply3_lf   LDS-staged (variant 11)
+//   target points per source cell   row-gather k_apply3_lf   LDS-staged
 //   1.4  (C4, 3 M cells)            4.76 TB/s                3.3 TB/s
-//   2.9  (C2, 655 k cells)          2.61 TB/s                4.53 TB/s
-//   2.5  (C5, global lat-lon)       2.80 TB/s                4.72 TB/s
+//   2.9  (C2, 655 k cells)          2.61 TB/s                4.5 TB/s
+//   2.5  (C5, global lat-lon)       2.80 TB/s                4.7 TB/s
 // Staging pays when a staged row is referenced often enough; the statistic that separates the cases is
-// reuse = 3 * n_dst / sum(unique cells per tile): 2.5 on C4, 5-6 on C2 / C5.
-#define LFU_AUTO_VARIANT 11
+// reuse = 3 * n_dst / sum(unique cells per tile): ~2.5 on C4, 5-6 on C2 / C5.
+static int g_lfu_auto_variant = 11;
 #define LFU_AUTO_MIN_REUSE 3.5f
+void mpg_lfu_set_auto_variant(int v) { g_lfu_auto_variant = v; }
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
+  const LfuVariant &v = g_lfu_variants[g_lfu_auto_variant];
   if (h->lf_choice == 0) {
-    int rc = lfu_build(h, g_lfu_variants[LFU_AUTO_VARIANT].rpt, s);
+    int rc = lfu_build(h, v.txu, v.rpt, s);
     if (rc) return rc;
     h->lf_reuse = h->ut_total > 0 ? 3.0f * (float)h->n_dst / (float)h->ut_total : 0.f;
     h->lf_choice = h->lf_reuse >= LFU_AUTO_MIN_REUSE ? 1 : -1;
@@ -350,16 +345,16 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
       h->ut_rpt = 0;
     }
   }
-  *lfu_variant = h->lf_choice > 0 ? LFU_AUTO_VARIANT : -1;
+  *lfu_variant = h->lf_choice > 0 ? g_lfu_auto_variant : -1;
   return MPG_SUCCESS;
 }
 
 int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
   const LfuVariant &v = g_lfu_variants[variant];
-  int rc = lfu_build(h, v.rpt, s);
+  int rc = lfu_build(h, v.txu, v.rpt, s);
   if (rc) return rc;
-  const int ty = 4 * v.rpt;
-  const int ntx = (h->nx_dst + LFU_TX - 1) / LFU_TX, nty = (h->ny_dst + ty - 1) / ty;
+  const int tyu = LFU_THREADS * v.rpt / v.txu;
+  const int ntx = (h->nx_dst + v.txu - 1) / v.txu, nty = (h->ny_dst + tyu - 1) / tyu;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;  // unmapped points read row 0
   size_t lds = sizeof(double) * um * (v.lc + 1) + sizeof(int32_t) * um + 16;
   if (lds > 160 * 1024) {

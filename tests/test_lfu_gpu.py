@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LFU = list(range(100, 112))      # 100-105 two-phase, 106-111 software-pipelined
+LFU = list(range(100, 120))      # 100-105 two-phase, 106-111 software-pipelined, 112-119 compact tiles
 
 
 def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
