@@ -1,0 +1,70 @@
+/* mpassit_ncio.h -- NetCDF CLASSIC container I/O for the host side of the hot path (no libnetcdf in the build image).
+ *
+ * Stands in for the nf90_* calls on either side of the interpolation:
+ *   input   nf90_open / nf90_inq_dimid / nf90_inquire_dimension / nf90_inq_varid / nf90_get_var
+ *           (model_grid.F90:287-417 grid file, input_data.F90:145-812 diag / hist files)
+ *   output  nf90_create / nf90_def_dim / nf90_def_var / nf90_put_att / nf90_enddef / nf90_put_var / nf90_close
+ *           (write_data.F90:173-1498)
+ * Formats: CDF-1 (classic), CDF-2 (64-bit offset), CDF-5 (64-bit data) -- the on-disk layout published in the
+ * NetCDF User's Guide ("File Format Specification") and the PnetCDF CDF-5 note; big-endian data, 4-byte padding,
+ * record variables interleaved per record.  NetCDF-4 files are HDF5 containers (the reference creates its output
+ * with NF90_NETCDF4, write_data.F90:173) and are NOT handled: ncio_open reports them as such, and the writer emits
+ * CDF-5 / CDF-2, which every NetCDF tool reads and `nccopy -k nc4` converts.  Host code, no GPU involved.
+ * All functions return 0 on success or a negative NCIO_E* code; ncio_strerror() explains the last failure. */
+#ifndef MPASSIT_NCIO_H
+#define MPASSIT_NCIO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ncio_file ncio_file;
+
+enum { NCIO_BYTE = 1, NCIO_CHAR = 2, NCIO_SHORT = 3, NCIO_INT = 4, NCIO_FLOAT = 5, NCIO_DOUBLE = 6,
+       NCIO_UBYTE = 7, NCIO_USHORT = 8, NCIO_UINT = 9, NCIO_INT64 = 10, NCIO_UINT64 = 11 };
+enum { NCIO_EIO = -1, NCIO_EFORMAT = -2, NCIO_EHDF5 = -3, NCIO_ENOTFOUND = -4, NCIO_EINVAL = -5, NCIO_ERANGE = -6,
+       NCIO_EMODE = -7, NCIO_ENOMEM = -8 };
+#define NCIO_MAX_DIMS 8
+#define NCIO_GLOBAL (-1)
+
+const char *ncio_strerror(void);
+
+/* ---- reading ------------------------------------------------------------------------------------------------ */
+int ncio_open(const char *path, ncio_file **out);
+int ncio_format(ncio_file *f);                  /* 1, 2 or 5 */
+int64_t ncio_numrecs(ncio_file *f);
+int ncio_ndims(ncio_file *f);
+int ncio_nvars(ncio_file *f);
+int ncio_inq_dim(ncio_file *f, const char *name, int64_t *len, int *is_unlimited);
+int ncio_inq_dim_by_id(ncio_file *f, int dimid, char *name_buf, int buf_len, int64_t *len, int *is_unlimited);
+int ncio_inq_varid(ncio_file *f, const char *name, int *varid);
+/* shape: dimension lengths, slowest first as stored (the record dimension reports the current number of records) */
+int ncio_inq_var(ncio_file *f, int varid, char *name_buf, int buf_len, int *type, int *ndims, int64_t *shape, int *dimids,
+                 int *is_record);
+/* One whole non-record variable, or record `rec` (0-based) of a record variable, converted to mem_type
+ * (NCIO_INT, NCIO_FLOAT, NCIO_DOUBLE, NCIO_INT64, or the variable's own type for BYTE/CHAR/SHORT) in host byte order.
+ * buf must hold the variable's (record's) element count. */
+int ncio_get_var(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf);
+/* attributes: varid = NCIO_GLOBAL for global ones.  Text: copied NUL-terminated (truncated to buf_len-1).
+ * Numeric: converted to double, up to max_n values; *n receives the stored count. */
+int ncio_get_att_text(ncio_file *f, int varid, const char *name, char *buf, int buf_len);
+int ncio_get_att_double(ncio_file *f, int varid, const char *name, double *vals, int max_n, int *n);
+
+/* ---- writing ------------------------------------------------------------------------------------------------ */
+int ncio_create(const char *path, int format /* 1, 2 or 5 */, ncio_file **out);
+int ncio_def_dim(ncio_file *f, const char *name, int64_t len /* 0 = unlimited (one per file) */, int *dimid);
+int ncio_def_var(ncio_file *f, const char *name, int type, int ndims, const int *dimids, int *varid);
+int ncio_put_att_text(ncio_file *f, int varid, const char *name, const char *text);
+int ncio_put_att_int(ncio_file *f, int varid, const char *name, const int32_t *vals, int n);
+int ncio_put_att_float(ncio_file *f, int varid, const char *name, const float *vals, int n);
+int ncio_put_att_double(ncio_file *f, int varid, const char *name, const double *vals, int n);
+int ncio_enddef(ncio_file *f);                  /* lays the file out; data calls only after this */
+/* whole variable / one record from host memory of mem_type (converted to the variable's type and byte-swapped) */
+int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void *buf);
+
+int ncio_close(ncio_file *f);                   /* writer: fills numrecs, flushes */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

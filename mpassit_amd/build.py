@@ -57,6 +57,20 @@ def build(force=False, verbose=False):
     return SO
 
 
+NCIO_SRC = os.path.join(HERE, "hostio", "ncclassic.c")
+NCIO_SO = os.path.join(HERE, "hostio", "libmpassit_ncio.so")
+
+
+def build_ncio(force=False):
+    """Host-side NetCDF classic I/O (plain C, gcc): mpassit_amd/hostio/libmpassit_ncio.so."""
+    hdr = os.path.join(HERE, "..", "include", "mpassit_ncio.h")
+    if force or not _newer(NCIO_SO, [NCIO_SRC, hdr]):
+        r = subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-o", NCIO_SO, NCIO_SRC], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gcc failed:\n%s" % r.stderr[-4000:])
+    return NCIO_SO
+
+
 FORTRAN_SRC = ["mpg_mod.F90", "host_mod.F90", "interp_mod.F90", "mpassit_driver.F90"]
 FLANG = os.environ.get("FLANG", "/opt/rocm/bin/amdflang")
 DRIVER = os.path.join(HERE, "fortran", "mpassit")

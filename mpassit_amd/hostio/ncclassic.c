@@ -1,0 +1,591 @@
+/* NetCDF classic (CDF-1 / CDF-2 / CDF-5) reader and writer -- see include/mpassit_ncio.h.
+ *
+ * Written from the published on-disk grammar (NetCDF User's Guide, "File Format Specification"; CDF-5: PnetCDF
+ * "CDF-5 file format"); not derived from libnetcdf sources.  Layout:
+ *   header  = magic numrecs dim_list gatt_list var_list
+ *   magic   = 'C' 'D' 'F' VERSION(1|2|5)
+ *   NON_NEG = 4 bytes (CDF-1/2) | 8 bytes (CDF-5); begin offsets are 4 bytes in CDF-1, 8 bytes in CDF-2/5
+ *   lists   = ABSENT (ZERO NON_NEG(0)) | TAG(0x0A dim, 0x0B var, 0x0C att) NON_NEG(nelems) elements
+ *   name    = NON_NEG(len) bytes padded to 4;  att = name type NON_NEG(n) values padded to 4
+ *   var     = name NON_NEG(ndims) dimid* vatt_list type vsize begin     (dimid = NON_NEG)
+ *   data    = non-record variables (each padded to 4), then numrecs records = one slab of every record variable
+ * All numbers big-endian.  Host is assumed little-endian (x86-64, the only host of an MI355X node).           */
+#define _FILE_OFFSET_BITS 64
+#include "../../include/mpassit_ncio.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#define TAG_DIM 0x0A
+#define TAG_VAR 0x0B
+#define TAG_ATT 0x0C
+#define CHUNK (1 << 18) /* elements converted per I/O chunk */
+
+typedef struct { char *name; int64_t len; } dim_t;
+typedef struct { char *name; int type; int64_t n; void *data; /* host order */ } att_t;
+typedef struct {
+  char *name;
+  int ndims, dimids[NCIO_MAX_DIMS];
+  int natts;
+  att_t *atts;
+  int type, is_rec;
+  int64_t vsize, begin, count; /* count = elements per record (record var) or in total */
+} var_t;
+struct ncio_file {
+  FILE *fp;
+  int writing, defmode, format;
+  int64_t numrecs, recsize;
+  int ndims, nvars, ngatts, recdim;
+  dim_t *dims;
+  var_t *vars;
+  att_t *gatts;
+  int64_t data_end; /* writer: end of the non-record section / start of records */
+  int64_t rec_start;
+};
+
+static __thread char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+const char *ncio_strerror(void) { return g_err; }
+
+static int tsize(int t) {
+  static const int s[12] = {0, 1, 1, 2, 4, 4, 8, 1, 2, 4, 8, 8};
+  return (t >= 1 && t <= 11) ? s[t] : 0;
+}
+static int64_t pad4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+static uint16_t bs16(uint16_t v) { return (uint16_t)((v >> 8) | (v << 8)); }
+static uint32_t bs32(uint32_t v) { return __builtin_bswap32(v); }
+static uint64_t bs64(uint64_t v) { return __builtin_bswap64(v); }
+static void swap_buf(void *p, int64_t n, int size) {
+  if (size == 2) { uint16_t *q = (uint16_t *)p; for (int64_t i = 0; i < n; ++i) q[i] = bs16(q[i]); }
+  else if (size == 4) { uint32_t *q = (uint32_t *)p; for (int64_t i = 0; i < n; ++i) q[i] = bs32(q[i]); }
+  else if (size == 8) { uint64_t *q = (uint64_t *)p; for (int64_t i = 0; i < n; ++i) q[i] = bs64(q[i]); }
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* header reading                                                                                               */
+typedef struct { FILE *fp; int fmt; int bad; } rd_t;
+static uint32_t rd_u32(rd_t *r) {
+  uint32_t v = 0;
+  if (fread(&v, 4, 1, r->fp) != 1) r->bad = 1;
+  return bs32(v);
+}
+static int64_t rd_u64(rd_t *r) {
+  uint64_t v = 0;
+  if (fread(&v, 8, 1, r->fp) != 1) r->bad = 1;
+  return (int64_t)bs64(v);
+}
+static int64_t rd_nonneg(rd_t *r) { return r->fmt == 5 ? rd_u64(r) : (int64_t)rd_u32(r); }
+static char *rd_name(rd_t *r) {
+  int64_t n = rd_nonneg(r);
+  if (r->bad || n < 0 || n > 4096) { r->bad = 1; return NULL; }
+  char *s = (char *)calloc((size_t)pad4(n) + 1, 1);
+  if (!s) { r->bad = 1; return NULL; }
+  if (pad4(n) && fread(s, 1, (size_t)pad4(n), r->fp) != (size_t)pad4(n)) r->bad = 1;
+  s[n] = 0;
+  return s;
+}
+static int rd_atts(rd_t *r, int *natts, att_t **atts) {
+  uint32_t tag = rd_u32(r);
+  int64_t n = rd_nonneg(r);
+  *natts = 0;
+  *atts = NULL;
+  if (r->bad) return -1;
+  if (tag == 0 && n == 0) return 0;
+  if (tag != TAG_ATT || n < 0 || n > 100000) { r->bad = 1; return -1; }
+  *atts = (att_t *)calloc((size_t)n, sizeof(att_t));
+  *natts = (int)n;
+  for (int64_t a = 0; a < n && !r->bad; ++a) {
+    att_t *t = &(*atts)[a];
+    t->name = rd_name(r);
+    t->type = (int)rd_u32(r);
+    t->n = rd_nonneg(r);
+    int sz = tsize(t->type);
+    if (r->bad || !sz || t->n < 0) { r->bad = 1; break; }
+    int64_t bytes = pad4(t->n * sz);
+    t->data = calloc((size_t)bytes + 1, 1);
+    if (bytes && fread(t->data, 1, (size_t)bytes, r->fp) != (size_t)bytes) r->bad = 1;
+    swap_buf(t->data, t->n, sz);
+  }
+  return r->bad ? -1 : 0;
+}
+
+static void free_atts(int n, att_t *a) {
+  for (int i = 0; i < n; ++i) { free(a[i].name); free(a[i].data); }
+  free(a);
+}
+static void free_file(ncio_file *f) {
+  if (!f) return;
+  for (int i = 0; i < f->ndims; ++i) free(f->dims[i].name);
+  free(f->dims);
+  free_atts(f->ngatts, f->gatts);
+  for (int i = 0; i < f->nvars; ++i) { free(f->vars[i].name); free_atts(f->vars[i].natts, f->vars[i].atts); }
+  free(f->vars);
+  if (f->fp) fclose(f->fp);
+  free(f);
+}
+
+static void finish_layout_info(ncio_file *f) { /* per-variable element counts, record flags, record size */
+  int nrec = 0;
+  f->recsize = 0;
+  for (int v = 0; v < f->nvars; ++v) {
+    var_t *x = &f->vars[v];
+    x->is_rec = x->ndims > 0 && x->dimids[0] == f->recdim;
+    x->count = 1;
+    for (int d = x->is_rec ? 1 : 0; d < x->ndims; ++d) x->count *= f->dims[x->dimids[d]].len;
+    if (x->is_rec) { ++nrec; f->recsize += pad4(x->count * tsize(x->type)); } /* not the header's vsize: CDF-1/2 cap it */
+  }
+  if (nrec == 1) /* a lone record variable is stored without record padding */
+    for (int v = 0; v < f->nvars; ++v)
+      if (f->vars[v].is_rec) f->recsize = f->vars[v].count * tsize(f->vars[v].type);
+}
+
+int ncio_open(const char *path, ncio_file **out) {
+  if (!path || !out) return fail(NCIO_EINVAL, "ncio_open: NULL argument");
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return fail(NCIO_EIO, "ncio_open: cannot open %s", path);
+  unsigned char m[8] = {0};
+  if (fread(m, 1, 4, fp) != 4) { fclose(fp); return fail(NCIO_EFORMAT, "ncio_open: %s is too short to be a NetCDF file", path); }
+  if (m[0] == 0x89 && m[1] == 'H' && m[2] == 'D' && m[3] == 'F') {
+    fclose(fp);
+    return fail(NCIO_EHDF5, "ncio_open: %s is a NetCDF-4/HDF5 file; this build reads the classic formats only "
+                            "(convert with `nccopy -k cdf5 in.nc out.nc`)", path);
+  }
+  if (m[0] != 'C' || m[1] != 'D' || m[2] != 'F' || (m[3] != 1 && m[3] != 2 && m[3] != 5)) {
+    fclose(fp);
+    return fail(NCIO_EFORMAT, "ncio_open: %s is not a NetCDF classic file (magic %02x %02x %02x %02x)", path, m[0], m[1], m[2], m[3]);
+  }
+  ncio_file *f = (ncio_file *)calloc(1, sizeof(*f));
+  if (!f) { fclose(fp); return fail(NCIO_ENOMEM, "out of memory"); }
+  f->fp = fp;
+  f->format = m[3];
+  f->recdim = -1;
+  rd_t r = {fp, f->format, 0};
+  f->numrecs = rd_nonneg(&r);
+  if (f->format != 5 && f->numrecs == 0xFFFFFFFFll) f->numrecs = 0; /* STREAMING marker */
+  uint32_t tag = rd_u32(&r);
+  int64_t n = rd_nonneg(&r);
+  if (!r.bad && !(tag == 0 && n == 0)) {
+    if (tag != TAG_DIM || n < 0 || n > 100000) r.bad = 1;
+    else {
+      f->dims = (dim_t *)calloc((size_t)n, sizeof(dim_t));
+      f->ndims = (int)n;
+      for (int d = 0; d < f->ndims && !r.bad; ++d) {
+        f->dims[d].name = rd_name(&r);
+        f->dims[d].len = rd_nonneg(&r);
+        if (f->dims[d].len == 0) f->recdim = d;
+      }
+    }
+  }
+  if (!r.bad) rd_atts(&r, &f->ngatts, &f->gatts);
+  if (!r.bad) {
+    tag = rd_u32(&r);
+    n = rd_nonneg(&r);
+    if (!(tag == 0 && n == 0)) {
+      if (tag != TAG_VAR || n < 0 || n > 1000000) r.bad = 1;
+      else {
+        f->vars = (var_t *)calloc((size_t)n, sizeof(var_t));
+        f->nvars = (int)n;
+        for (int v = 0; v < f->nvars && !r.bad; ++v) {
+          var_t *x = &f->vars[v];
+          x->name = rd_name(&r);
+          int64_t nd = rd_nonneg(&r);
+          if (nd < 0 || nd > NCIO_MAX_DIMS) { r.bad = 1; break; }
+          x->ndims = (int)nd;
+          for (int d = 0; d < x->ndims; ++d) {
+            int64_t id = rd_nonneg(&r);
+            if (id < 0 || id >= f->ndims) r.bad = 1;
+            x->dimids[d] = (int)id;
+          }
+          if (r.bad) break;
+          rd_atts(&r, &x->natts, &x->atts);
+          x->type = (int)rd_u32(&r);
+          x->vsize = rd_nonneg(&r);
+          x->begin = f->format == 1 ? (int64_t)rd_u32(&r) : rd_u64(&r);
+          if (!tsize(x->type)) r.bad = 1;
+        }
+      }
+    }
+  }
+  if (r.bad) { free_file(f); return fail(NCIO_EFORMAT, "ncio_open: %s has a damaged or truncated header", path); }
+  if (f->recdim >= 0) f->dims[f->recdim].len = 0;
+  finish_layout_info(f);
+  *out = f;
+  return 0;
+}
+
+int ncio_format(ncio_file *f) { return f ? f->format : NCIO_EINVAL; }
+int64_t ncio_numrecs(ncio_file *f) { return f ? f->numrecs : NCIO_EINVAL; }
+int ncio_ndims(ncio_file *f) { return f ? f->ndims : NCIO_EINVAL; }
+int ncio_nvars(ncio_file *f) { return f ? f->nvars : NCIO_EINVAL; }
+
+static void copy_name(char *buf, int len, const char *s) {
+  if (buf && len > 0) { strncpy(buf, s, (size_t)len - 1); buf[len - 1] = 0; }
+}
+int ncio_inq_dim_by_id(ncio_file *f, int dimid, char *name_buf, int buf_len, int64_t *len, int *is_unlimited) {
+  if (!f || dimid < 0 || dimid >= f->ndims) return fail(NCIO_EINVAL, "ncio_inq_dim_by_id: bad dimension id %d", dimid);
+  copy_name(name_buf, buf_len, f->dims[dimid].name);
+  if (len) *len = dimid == f->recdim ? f->numrecs : f->dims[dimid].len;
+  if (is_unlimited) *is_unlimited = dimid == f->recdim;
+  return 0;
+}
+int ncio_inq_dim(ncio_file *f, const char *name, int64_t *len, int *is_unlimited) {
+  if (!f || !name) return fail(NCIO_EINVAL, "ncio_inq_dim: NULL argument");
+  for (int d = 0; d < f->ndims; ++d)
+    if (!strcmp(f->dims[d].name, name)) return ncio_inq_dim_by_id(f, d, NULL, 0, len, is_unlimited);
+  return fail(NCIO_ENOTFOUND, "dimension %s not found", name);
+}
+int ncio_inq_varid(ncio_file *f, const char *name, int *varid) {
+  if (!f || !name || !varid) return fail(NCIO_EINVAL, "ncio_inq_varid: NULL argument");
+  for (int v = 0; v < f->nvars; ++v)
+    if (!strcmp(f->vars[v].name, name)) { *varid = v; return 0; }
+  return fail(NCIO_ENOTFOUND, "variable %s not found", name);
+}
+int ncio_inq_var(ncio_file *f, int varid, char *name_buf, int buf_len, int *type, int *ndims, int64_t *shape, int *dimids, int *is_record) {
+  if (!f || varid < 0 || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_inq_var: bad variable id %d", varid);
+  var_t *x = &f->vars[varid];
+  copy_name(name_buf, buf_len, x->name);
+  if (type) *type = x->type;
+  if (ndims) *ndims = x->ndims;
+  for (int d = 0; d < x->ndims; ++d) {
+    if (shape) shape[d] = x->dimids[d] == f->recdim ? f->numrecs : f->dims[x->dimids[d]].len;
+    if (dimids) dimids[d] = x->dimids[d];
+  }
+  if (is_record) *is_record = x->is_rec;
+  return 0;
+}
+
+/* ---- element conversion ------------------------------------------------------------------------------------- */
+#define CONV_LOOP(ST, DT) { const ST *s_ = (const ST *)src; DT *d_ = (DT *)dst; for (int64_t i_ = 0; i_ < n; ++i_) d_[i_] = (DT)s_[i_]; } break
+#define CONV_FROM(ST)                      \
+  switch (dt) {                            \
+    case NCIO_BYTE: CONV_LOOP(ST, int8_t); \
+    case NCIO_CHAR: CONV_LOOP(ST, char);   \
+    case NCIO_UBYTE: CONV_LOOP(ST, uint8_t); \
+    case NCIO_SHORT: CONV_LOOP(ST, int16_t); \
+    case NCIO_USHORT: CONV_LOOP(ST, uint16_t); \
+    case NCIO_INT: CONV_LOOP(ST, int32_t); \
+    case NCIO_UINT: CONV_LOOP(ST, uint32_t); \
+    case NCIO_FLOAT: CONV_LOOP(ST, float); \
+    case NCIO_DOUBLE: CONV_LOOP(ST, double); \
+    case NCIO_INT64: CONV_LOOP(ST, int64_t); \
+    case NCIO_UINT64: CONV_LOOP(ST, uint64_t); \
+    default: return -1;                    \
+  }
+/* host-order src of type st -> host-order dst of type dt */
+static int convert(int st, const void *src, int dt, void *dst, int64_t n) {
+  if (st == dt) { memcpy(dst, src, (size_t)(n * tsize(st))); return 0; }
+  switch (st) {
+    case NCIO_BYTE: CONV_FROM(int8_t); break;
+    case NCIO_CHAR: CONV_FROM(char); break;
+    case NCIO_UBYTE: CONV_FROM(uint8_t); break;
+    case NCIO_SHORT: CONV_FROM(int16_t); break;
+    case NCIO_USHORT: CONV_FROM(uint16_t); break;
+    case NCIO_INT: CONV_FROM(int32_t); break;
+    case NCIO_UINT: CONV_FROM(uint32_t); break;
+    case NCIO_FLOAT: CONV_FROM(float); break;
+    case NCIO_DOUBLE: CONV_FROM(double); break;
+    case NCIO_INT64: CONV_FROM(int64_t); break;
+    case NCIO_UINT64: CONV_FROM(uint64_t); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+static int var_offset(ncio_file *f, var_t *x, int64_t rec, int64_t *off, const char *who) {
+  if (x->is_rec) {
+    if (rec < 0 || (!f->writing && rec >= f->numrecs)) return fail(NCIO_ERANGE, "%s: record %lld of %s out of range (%lld records)", who,
+                                                                  (long long)rec, x->name, (long long)f->numrecs);
+    *off = x->begin + rec * f->recsize;
+  } else {
+    *off = x->begin;
+  }
+  return 0;
+}
+
+int ncio_get_var(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf) {
+  if (!f || f->writing) return fail(NCIO_EMODE, "ncio_get_var: file not open for reading");
+  if (varid < 0 || varid >= f->nvars || !buf || !tsize(mem_type)) return fail(NCIO_EINVAL, "ncio_get_var: bad argument");
+  var_t *x = &f->vars[varid];
+  int64_t off;
+  int rc = var_offset(f, x, rec, &off, "ncio_get_var");
+  if (rc) return rc;
+  const int fs = tsize(x->type), ms = tsize(mem_type);
+  if (fseeko(f->fp, (off_t)off, SEEK_SET)) return fail(NCIO_EIO, "ncio_get_var: seek failed for %s", x->name);
+  void *tmp = malloc((size_t)CHUNK * 8);
+  if (!tmp) return fail(NCIO_ENOMEM, "out of memory");
+  for (int64_t done = 0; done < x->count; done += CHUNK) {
+    int64_t n = x->count - done < CHUNK ? x->count - done : CHUNK;
+    if (fread(tmp, (size_t)fs, (size_t)n, f->fp) != (size_t)n) { free(tmp); return fail(NCIO_EIO, "ncio_get_var: short read of %s", x->name); }
+    swap_buf(tmp, n, fs);
+    if (convert(x->type, tmp, mem_type, (char *)buf + done * ms, n)) { free(tmp); return fail(NCIO_EINVAL, "ncio_get_var: unsupported conversion"); }
+  }
+  free(tmp);
+  return 0;
+}
+
+static att_t *find_att(ncio_file *f, int varid, const char *name) {
+  int n = varid == NCIO_GLOBAL ? f->ngatts : f->vars[varid].natts;
+  att_t *a = varid == NCIO_GLOBAL ? f->gatts : f->vars[varid].atts;
+  for (int i = 0; i < n; ++i)
+    if (!strcmp(a[i].name, name)) return &a[i];
+  return NULL;
+}
+int ncio_get_att_text(ncio_file *f, int varid, const char *name, char *buf, int buf_len) {
+  if (!f || !name || !buf || buf_len < 1 || varid < NCIO_GLOBAL || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_get_att_text: bad argument");
+  att_t *a = find_att(f, varid, name);
+  if (!a) return fail(NCIO_ENOTFOUND, "attribute %s not found", name);
+  if (a->type != NCIO_CHAR) return fail(NCIO_EINVAL, "attribute %s is not text", name);
+  int64_t n = a->n < buf_len - 1 ? a->n : buf_len - 1;
+  memcpy(buf, a->data, (size_t)n);
+  buf[n] = 0;
+  return 0;
+}
+int ncio_get_att_double(ncio_file *f, int varid, const char *name, double *vals, int max_n, int *n) {
+  if (!f || !name || varid < NCIO_GLOBAL || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_get_att_double: bad argument");
+  att_t *a = find_att(f, varid, name);
+  if (!a) return fail(NCIO_ENOTFOUND, "attribute %s not found", name);
+  if (a->type == NCIO_CHAR) return fail(NCIO_EINVAL, "attribute %s is text", name);
+  if (n) *n = (int)a->n;
+  int64_t m = a->n < max_n ? a->n : max_n;
+  if (vals && m > 0 && convert(a->type, a->data, NCIO_DOUBLE, vals, m)) return fail(NCIO_EINVAL, "attribute %s: unsupported type", name);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+/* writing                                                                                                      */
+int ncio_create(const char *path, int format, ncio_file **out) {
+  if (!path || !out || (format != 1 && format != 2 && format != 5)) return fail(NCIO_EINVAL, "ncio_create: format must be 1, 2 or 5");
+  FILE *fp = fopen(path, "wb+");
+  if (!fp) return fail(NCIO_EIO, "ncio_create: cannot create %s", path);
+  ncio_file *f = (ncio_file *)calloc(1, sizeof(*f));
+  if (!f) { fclose(fp); return fail(NCIO_ENOMEM, "out of memory"); }
+  f->fp = fp;
+  f->writing = f->defmode = 1;
+  f->format = format;
+  f->recdim = -1;
+  *out = f;
+  return 0;
+}
+static int need_def(ncio_file *f, const char *who) {
+  if (!f || !f->writing || !f->defmode) return fail(NCIO_EMODE, "%s: file is not in define mode", who);
+  return 0;
+}
+int ncio_def_dim(ncio_file *f, const char *name, int64_t len, int *dimid) {
+  int rc = need_def(f, "ncio_def_dim");
+  if (rc) return rc;
+  if (!name || len < 0) return fail(NCIO_EINVAL, "ncio_def_dim: bad argument");
+  if (len == 0 && f->recdim >= 0) return fail(NCIO_EINVAL, "ncio_def_dim: only one unlimited dimension per file");
+  if (f->format != 5 && len > 0xFFFFFFFFll) return fail(NCIO_ERANGE, "ncio_def_dim: %s too long for CDF-%d", name, f->format);
+  f->dims = (dim_t *)realloc(f->dims, sizeof(dim_t) * (size_t)(f->ndims + 1));
+  f->dims[f->ndims].name = strdup(name);
+  f->dims[f->ndims].len = len;
+  if (len == 0) f->recdim = f->ndims;
+  if (dimid) *dimid = f->ndims;
+  f->ndims++;
+  return 0;
+}
+int ncio_def_var(ncio_file *f, const char *name, int type, int ndims, const int *dimids, int *varid) {
+  int rc = need_def(f, "ncio_def_var");
+  if (rc) return rc;
+  if (!name || !tsize(type) || ndims < 0 || ndims > NCIO_MAX_DIMS || (ndims && !dimids)) return fail(NCIO_EINVAL, "ncio_def_var: bad argument");
+  if (f->format != 5 && type > NCIO_DOUBLE) return fail(NCIO_EINVAL, "ncio_def_var: type %d needs CDF-5", type);
+  f->vars = (var_t *)realloc(f->vars, sizeof(var_t) * (size_t)(f->nvars + 1));
+  var_t *x = &f->vars[f->nvars];
+  memset(x, 0, sizeof(*x));
+  x->name = strdup(name);
+  x->type = type;
+  x->ndims = ndims;
+  for (int d = 0; d < ndims; ++d) {
+    if (dimids[d] < 0 || dimids[d] >= f->ndims) return fail(NCIO_EINVAL, "ncio_def_var: %s uses an undefined dimension", name);
+    if (d > 0 && dimids[d] == f->recdim) return fail(NCIO_EINVAL, "ncio_def_var: the unlimited dimension must come first (%s)", name);
+    x->dimids[d] = dimids[d];
+  }
+  if (varid) *varid = f->nvars;
+  f->nvars++;
+  return 0;
+}
+static int put_att(ncio_file *f, int varid, const char *name, int type, const void *vals, int64_t n) {
+  int rc = need_def(f, "ncio_put_att");
+  if (rc) return rc;
+  if (!name || varid < NCIO_GLOBAL || varid >= f->nvars || n < 0 || (n && !vals)) return fail(NCIO_EINVAL, "ncio_put_att: bad argument");
+  int *cnt = varid == NCIO_GLOBAL ? &f->ngatts : &f->vars[varid].natts;
+  att_t **arr = varid == NCIO_GLOBAL ? &f->gatts : &f->vars[varid].atts;
+  att_t *a = find_att(f, varid, name);
+  if (a) free(a->data);
+  else {
+    *arr = (att_t *)realloc(*arr, sizeof(att_t) * (size_t)(*cnt + 1));
+    a = &(*arr)[*cnt];
+    a->name = strdup(name);
+    (*cnt)++;
+  }
+  a->type = type;
+  a->n = n;
+  a->data = calloc((size_t)pad4(n * tsize(type)) + 1, 1);
+  if (n) memcpy(a->data, vals, (size_t)(n * tsize(type)));
+  return 0;
+}
+int ncio_put_att_text(ncio_file *f, int varid, const char *name, const char *text) {
+  return put_att(f, varid, name, NCIO_CHAR, text ? text : "", text ? (int64_t)strlen(text) : 0);
+}
+int ncio_put_att_int(ncio_file *f, int varid, const char *name, const int32_t *vals, int n) { return put_att(f, varid, name, NCIO_INT, vals, n); }
+int ncio_put_att_float(ncio_file *f, int varid, const char *name, const float *vals, int n) { return put_att(f, varid, name, NCIO_FLOAT, vals, n); }
+int ncio_put_att_double(ncio_file *f, int varid, const char *name, const double *vals, int n) { return put_att(f, varid, name, NCIO_DOUBLE, vals, n); }
+
+/* header serialisation into a growable buffer */
+typedef struct { unsigned char *p; size_t n, cap; int fmt; } wb_t;
+static void wb_raw(wb_t *w, const void *src, size_t n) {
+  if (w->n + n > w->cap) { w->cap = (w->n + n) * 2 + 1024; w->p = (unsigned char *)realloc(w->p, w->cap); }
+  memcpy(w->p + w->n, src, n);
+  w->n += n;
+}
+static void wb_u32(wb_t *w, uint32_t v) { v = bs32(v); wb_raw(w, &v, 4); }
+static void wb_u64(wb_t *w, uint64_t v) { v = bs64(v); wb_raw(w, &v, 8); }
+static void wb_nonneg(wb_t *w, int64_t v) { if (w->fmt == 5) wb_u64(w, (uint64_t)v); else wb_u32(w, (uint32_t)v); }
+static void wb_name(wb_t *w, const char *s) {
+  size_t n = strlen(s);
+  static const char zero[4] = {0, 0, 0, 0};
+  wb_nonneg(w, (int64_t)n);
+  wb_raw(w, s, n);
+  wb_raw(w, zero, (size_t)(pad4((int64_t)n) - (int64_t)n));
+}
+static void wb_atts(wb_t *w, int n, att_t *a) {
+  if (n == 0) { wb_u32(w, 0); wb_nonneg(w, 0); return; }
+  wb_u32(w, TAG_ATT);
+  wb_nonneg(w, n);
+  for (int i = 0; i < n; ++i) {
+    wb_name(w, a[i].name);
+    wb_u32(w, (uint32_t)a[i].type);
+    wb_nonneg(w, a[i].n);
+    int sz = tsize(a[i].type);
+    int64_t bytes = pad4(a[i].n * sz);
+    unsigned char *tmp = (unsigned char *)calloc((size_t)bytes + 1, 1);
+    memcpy(tmp, a[i].data, (size_t)(a[i].n * sz));
+    swap_buf(tmp, a[i].n, sz);
+    wb_raw(w, tmp, (size_t)bytes);
+    free(tmp);
+  }
+}
+static void serialise(ncio_file *f, wb_t *w) {
+  unsigned char magic[4] = {'C', 'D', 'F', (unsigned char)f->format};
+  w->n = 0;
+  wb_raw(w, magic, 4);
+  wb_nonneg(w, f->numrecs);
+  if (f->ndims == 0) { wb_u32(w, 0); wb_nonneg(w, 0); }
+  else {
+    wb_u32(w, TAG_DIM);
+    wb_nonneg(w, f->ndims);
+    for (int d = 0; d < f->ndims; ++d) { wb_name(w, f->dims[d].name); wb_nonneg(w, f->dims[d].len); }
+  }
+  wb_atts(w, f->ngatts, f->gatts);
+  if (f->nvars == 0) { wb_u32(w, 0); wb_nonneg(w, 0); }
+  else {
+    wb_u32(w, TAG_VAR);
+    wb_nonneg(w, f->nvars);
+    for (int v = 0; v < f->nvars; ++v) {
+      var_t *x = &f->vars[v];
+      wb_name(w, x->name);
+      wb_nonneg(w, x->ndims);
+      for (int d = 0; d < x->ndims; ++d) wb_nonneg(w, x->dimids[d]);
+      wb_atts(w, x->natts, x->atts);
+      wb_u32(w, (uint32_t)x->type);
+      int64_t vs = x->vsize;
+      if (f->format != 5 && vs > 0xFFFFFFFCll) vs = 0xFFFFFFFFll; /* "too big to represent" marker of CDF-1/2 */
+      wb_nonneg(w, vs);
+      if (f->format == 1) wb_u32(w, (uint32_t)x->begin);
+      else wb_u64(w, (uint64_t)x->begin);
+    }
+  }
+}
+
+int ncio_enddef(ncio_file *f) {
+  int rc = need_def(f, "ncio_enddef");
+  if (rc) return rc;
+  int nrec = 0;
+  for (int v = 0; v < f->nvars; ++v) {
+    var_t *x = &f->vars[v];
+    x->is_rec = x->ndims > 0 && x->dimids[0] == f->recdim;
+    x->count = 1;
+    for (int d = x->is_rec ? 1 : 0; d < x->ndims; ++d) x->count *= f->dims[x->dimids[d]].len;
+    x->vsize = pad4(x->count * tsize(x->type));
+    nrec += x->is_rec;
+  }
+  wb_t w = {NULL, 0, 0, f->format};
+  serialise(f, &w); /* sizes do not depend on the begin values */
+  int64_t off = pad4((int64_t)w.n);
+  for (int v = 0; v < f->nvars; ++v)
+    if (!f->vars[v].is_rec) { f->vars[v].begin = off; off += f->vars[v].vsize; }
+  f->rec_start = off;
+  f->recsize = 0;
+  for (int v = 0; v < f->nvars; ++v)
+    if (f->vars[v].is_rec) { f->vars[v].begin = off; off += f->vars[v].vsize; f->recsize += f->vars[v].vsize; }
+  if (nrec == 1) { /* keep records 4-byte aligned: declare the lone record variable's padded size as the record size */
+    for (int v = 0; v < f->nvars; ++v)
+      if (f->vars[v].is_rec && (f->vars[v].count * tsize(f->vars[v].type)) % 4) {
+        free(w.p);
+        return fail(NCIO_EINVAL, "ncio_enddef: a single record variable of %d-byte elements with an odd record size is not supported; "
+                                 "add a second record variable", tsize(f->vars[v].type));
+      }
+  }
+  if (f->format == 1 && off > 0x7FFFFFFFll) { free(w.p); return fail(NCIO_ERANGE, "ncio_enddef: layout exceeds CDF-1 offsets; use format 2 or 5"); }
+  if (f->format != 5)
+    for (int v = 0; v < f->nvars; ++v)
+      if (f->vars[v].vsize > 0xFFFFFFFCll && !(v == f->nvars - 1 || f->vars[v].is_rec))
+        { free(w.p); return fail(NCIO_ERANGE, "ncio_enddef: variable %s exceeds 4 GiB; use format 5", f->vars[v].name); }
+  serialise(f, &w);
+  if (fseeko(f->fp, 0, SEEK_SET) || fwrite(w.p, 1, w.n, f->fp) != w.n) { free(w.p); return fail(NCIO_EIO, "ncio_enddef: header write failed"); }
+  free(w.p);
+  f->defmode = 0;
+  f->data_end = f->rec_start;
+  return 0;
+}
+
+int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void *buf) {
+  if (!f || !f->writing || f->defmode) return fail(NCIO_EMODE, "ncio_put_var: call ncio_enddef first");
+  if (varid < 0 || varid >= f->nvars || !buf || !tsize(mem_type)) return fail(NCIO_EINVAL, "ncio_put_var: bad argument");
+  var_t *x = &f->vars[varid];
+  int64_t off;
+  int rc = var_offset(f, x, rec, &off, "ncio_put_var");
+  if (rc) return rc;
+  const int fs = tsize(x->type), ms = tsize(mem_type);
+  if (fseeko(f->fp, (off_t)off, SEEK_SET)) return fail(NCIO_EIO, "ncio_put_var: seek failed for %s", x->name);
+  void *tmp = malloc((size_t)CHUNK * 8);
+  if (!tmp) return fail(NCIO_ENOMEM, "out of memory");
+  for (int64_t done = 0; done < x->count; done += CHUNK) {
+    int64_t n = x->count - done < CHUNK ? x->count - done : CHUNK;
+    if (convert(mem_type, (const char *)buf + done * ms, x->type, tmp, n)) { free(tmp); return fail(NCIO_EINVAL, "ncio_put_var: unsupported conversion"); }
+    swap_buf(tmp, n, fs);
+    if (fwrite(tmp, (size_t)fs, (size_t)n, f->fp) != (size_t)n) { free(tmp); return fail(NCIO_EIO, "ncio_put_var: short write of %s", x->name); }
+  }
+  free(tmp);
+  if (x->is_rec && rec + 1 > f->numrecs) f->numrecs = rec + 1;
+  return 0;
+}
+
+int ncio_close(ncio_file *f) {
+  if (!f) return 0;
+  int rc = 0;
+  if (f->writing) {
+    if (f->defmode) rc = ncio_enddef(f);
+    if (!rc) {
+      /* numrecs sits right after the magic; unwritten space reads as zeros */
+      wb_t w = {NULL, 0, 0, f->format};
+      wb_nonneg(&w, f->numrecs);
+      if (fseeko(f->fp, 4, SEEK_SET) || fwrite(w.p, 1, w.n, f->fp) != w.n) rc = fail(NCIO_EIO, "ncio_close: cannot update numrecs");
+      free(w.p);
+      int64_t end = f->rec_start + f->numrecs * f->recsize;
+      fflush(f->fp);
+      if (!rc && ftruncate(fileno(f->fp), (off_t)end)) rc = fail(NCIO_EIO, "ncio_close: cannot size the file");
+    }
+  }
+  free_file(f);
+  return rc;
+}

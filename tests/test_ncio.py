@@ -1,0 +1,144 @@
+"""Host-side NetCDF classic I/O (hostio/ncclassic.c) cross-checked against an independent implementation of the same
+format: scipy.io.netcdf_file (CDF-1 / CDF-2).  CDF-5 has no second reader in the image: round trip + header bytes."""
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+
+@pytest.fixture(scope="module")
+def ncio():
+    from mpassit_amd import build, ncio
+    build.build_ncio()
+    return ncio
+
+
+def _payload(rng):
+    return dict(latCell=rng.uniform(-1.5, 1.5, 17), voc=rng.integers(0, 40, (17, 6)).astype(np.int32),
+                theta=rng.normal(300, 20, (3, 17, 5)).astype(np.float32), flag=rng.integers(-100, 100, 9).astype(np.int16),
+                xtime=[b"2024-08-07_00:00:00", b"2024-08-07_01:00:00", b"2024-08-07_02:00:00"])
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_written_files_are_read_by_scipy(ncio, tmp_path, fmt):
+    rng = np.random.default_rng(fmt)
+    d = _payload(rng)
+    path = tmp_path / ("w%d.nc" % fmt)
+    with ncio.Writer(path, format=fmt) as w:
+        for name, n in (("Time", None), ("nCells", 17), ("maxEdges", 6), ("nVertLevels", 5), ("StrLen", 19), ("nine", 9)):
+            w.def_dim(name, n)
+        w.put_att("title", "ncio test")
+        w.put_att("sphere_radius", 6371229.0)
+        w.put_att("levels", np.array([1, 2, 3]))
+        w.def_var("latCell", ncio.DOUBLE, ("nCells",), units="rad", long_name="latitude")
+        w.def_var("verticesOnCell", ncio.INT, ("nCells", "maxEdges"))
+        w.def_var("theta", ncio.FLOAT, ("Time", "nCells", "nVertLevels"), scale=np.float32(2.5))
+        w.def_var("flag", ncio.SHORT, ("nine",))
+        w.def_var("xtime", ncio.CHAR, ("Time", "StrLen"))
+        w.put("latCell", d["latCell"])
+        w.put("verticesOnCell", d["voc"])
+        w.put("flag", d["flag"])
+        for r in range(3):
+            w.put("theta", d["theta"][r].astype(np.float64), rec=r)      # float64 in memory -> NC_FLOAT on disk
+            w.put("xtime", d["xtime"][r], rec=r)
+    f = netcdf_file(str(path), "r", mmap=False)
+    assert f.version_byte == fmt
+    assert f.dimensions["nCells"] == 17 and f.dimensions["Time"] is None
+    assert f.title == b"ncio test" and f.sphere_radius == 6371229.0 and list(f.levels) == [1, 2, 3]
+    assert np.array_equal(f.variables["latCell"][:], d["latCell"]) and f.variables["latCell"].units == b"rad"
+    assert np.array_equal(f.variables["verticesOnCell"][:], d["voc"])
+    assert f.variables["theta"].shape == (3, 17, 5) and np.array_equal(f.variables["theta"][:], d["theta"])
+    assert f.variables["theta"].scale == np.float32(2.5)
+    assert np.array_equal(f.variables["flag"][:], d["flag"])
+    assert [b"".join(row) for row in f.variables["xtime"][:]] == d["xtime"]
+    f.close()
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_scipy_files_are_read(ncio, tmp_path, fmt):
+    rng = np.random.default_rng(10 + fmt)
+    d = _payload(rng)
+    path = tmp_path / ("s%d.nc" % fmt)
+    f = netcdf_file(str(path), "w", version=fmt)
+    f.createDimension("Time", None)
+    f.createDimension("nCells", 17)
+    f.createDimension("maxEdges", 6)
+    f.createDimension("nVertLevels", 5)
+    f.createDimension("StrLen", 19)
+    f.on_a_sphere = "YES"
+    f.sphere_radius = 6371229.0
+    v = f.createVariable("latCell", "d", ("nCells",))
+    v[:] = d["latCell"]
+    v.units = "rad"
+    f.createVariable("verticesOnCell", "i", ("nCells", "maxEdges"))[:] = d["voc"]
+    th = f.createVariable("theta", "f", ("Time", "nCells", "nVertLevels"))
+    xt = f.createVariable("xtime", "c", ("Time", "StrLen"))
+    for r in range(3):
+        th[r] = d["theta"][r]
+        xt[r] = np.frombuffer(d["xtime"][r], "S1")
+    f.close()
+    with ncio.Reader(path) as r:
+        assert r.format == fmt and r.numrecs == 3 and r.unlimited == "Time"
+        assert r.dims == {"Time": 3, "nCells": 17, "maxEdges": 6, "nVertLevels": 5, "StrLen": 19}
+        assert r.vars["theta"]["shape"] == (3, 17, 5) and r.vars["theta"]["dims"] == ("Time", "nCells", "nVertLevels")
+        assert r.vars["theta"]["record"] and not r.vars["latCell"]["record"]
+        assert np.array_equal(r.get("latCell"), d["latCell"])
+        assert np.array_equal(r.get("verticesOnCell"), d["voc"])
+        assert np.array_equal(r.get("theta"), d["theta"])
+        assert np.array_equal(r.get("theta", rec=1, dtype=np.float64), d["theta"][1].astype(np.float64))   # widened on read
+        assert r.get("xtime", rec=2).tobytes() == d["xtime"][2]
+        assert r.att("on_a_sphere") == "YES" and r.att("sphere_radius")[0] == 6371229.0 and r.att("units", var="latCell") == "rad"
+        with pytest.raises(ncio.NcioError):
+            r.get("theta", rec=3)
+        with pytest.raises(KeyError):
+            r.get("nope")
+
+
+def test_cdf5_round_trip_and_header(ncio, tmp_path):
+    rng = np.random.default_rng(5)
+    path = tmp_path / "c5.nc"
+    big = rng.integers(-2 ** 60, 2 ** 60, 11)
+    th = rng.normal(size=(2, 7, 3))
+    with ncio.Writer(path, format=5) as w:
+        w.def_dim("Time", None)
+        w.def_dim("n", 11)
+        w.def_dim("c", 7)
+        w.def_dim("l", 3)
+        w.def_var("ids", ncio.INT64, ("n",))
+        w.def_var("theta", ncio.DOUBLE, ("Time", "c", "l"))
+        w.def_var("t2", ncio.FLOAT, ("Time", "c"))
+        w.put("ids", big)
+        for r in range(2):
+            w.put("theta", th[r], rec=r)
+            w.put("t2", th[r, :, 0], rec=r)
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"CDF\x05" and int.from_bytes(raw[4:12], "big") == 2          # 8-byte numrecs
+    with ncio.Reader(path) as r:
+        assert r.format == 5 and r.numrecs == 2
+        assert np.array_equal(r.get("ids"), big) and np.array_equal(r.get("theta"), th)
+        assert np.array_equal(r.get("t2"), th[:, :, 0].astype(np.float32))
+    assert len(raw) % 4 == 0
+
+
+def test_errors_are_explicit(ncio, tmp_path):
+    h5 = tmp_path / "h5.nc"
+    h5.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    with pytest.raises(ncio.NcioError, match="NetCDF-4/HDF5"):
+        ncio.Reader(h5)
+    junk = tmp_path / "junk.nc"
+    junk.write_bytes(b"not a netcdf file")
+    with pytest.raises(ncio.NcioError, match="not a NetCDF classic"):
+        ncio.Reader(junk)
+    cut = tmp_path / "cut.nc"
+    cut.write_bytes(b"CDF\x02\0\0\0\0\0\0\0\x0a\0\0\0\x05")
+    with pytest.raises(ncio.NcioError, match="damaged"):
+        ncio.Reader(cut)
+    with ncio.Writer(tmp_path / "w.nc", format=2) as w:
+        w.def_dim("n", 4)
+        w.def_var("a", ncio.FLOAT, ("n",))
+        with pytest.raises(ValueError):
+            w.put("a", np.zeros(5))
+        with pytest.raises(ncio.NcioError):
+            w.def_dim("late", 3)                      # define mode is over after the first put
+        w.put("a", np.arange(4.0))
+    with pytest.raises(ncio.NcioError):
+        ncio.Writer(tmp_path / "x.nc", format=3)
