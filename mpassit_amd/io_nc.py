@@ -1,0 +1,239 @@
+"""File surface around the hot path: MPAS grid / history / diagnostics files in, WRF-style file out.
+
+Mirrors the nf90 calls of the reference with the classic-format library of this repo (ncio, include/mpassit_ncio.h):
+  read_grid          model_grid.F90:287-417     dimensions + lat/lon of cells and vertices, verticesOnCell, ter, zs
+  read_input_data    input_data.F90:316-812     every listed variable, first Time record, file order kept:
+                                                 3-D fields stay [nCells][nVertLevels] (MPG_LAYOUT_LEV_FAST), the host
+                                                 transpose of :653-655 is not done
+  write_target_data  write_data.F90:173-1498    dimensions, global attributes, grid variables, fields after the
+                                                 post-ops of post.output_fields; NF90_FLOAT everywhere
+Differences, all forced by the build image (no libnetcdf / HDF5): files are NetCDF CLASSIC (CDF-5 by default, CDF-2 on
+request), not NetCDF-4; input files in NetCDF-4 have to be converted (`nccopy -k cdf5`) -- ncio says so when it meets
+one.  `write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
+import numpy as np
+
+from . import fields as F
+from . import interp as I
+from . import ncio
+from . import regrid as R
+from . import synth
+
+DATESTRLEN = 19
+
+
+# ---- synthetic inputs in MPAS layout -----------------------------------------------------------------------------
+def write_mpas_files(grid_path, hist_path, mesh, ter, zs, hist, nz, nsoil, diag_path=None, diag=None, xtime="2024-08-07_00:00:00",
+                     fmt=5):
+    """mesh: synth.MpasMesh; hist / diag: name -> [nCells] | [nCells][L] arrays (file order), written as float32 with a
+    leading Time record like MPAS history files.  Grid variables go to grid_path (static file), fields to hist_path."""
+    nc, nv, me = mesh.nCells, mesh.nVertices, mesh.maxEdges
+    with ncio.Writer(grid_path, format=fmt) as w:
+        for name, n in (("Time", None), ("nCells", nc), ("nVertices", nv), ("maxEdges", me), ("nSoilLevels", nsoil), ("StrLen", 64)):
+            w.def_dim(name, n)
+        w.put_att("on_a_sphere", "YES")
+        w.put_att("sphere_radius", 6371229.0)
+        for name in ("latCell", "lonCell"):
+            w.def_var(name, ncio.DOUBLE, ("nCells",), units="rad")
+        for name in ("latVertex", "lonVertex"):
+            w.def_var(name, ncio.DOUBLE, ("nVertices",), units="rad")
+        w.def_var("verticesOnCell", ncio.INT, ("nCells", "maxEdges"))
+        w.def_var("nEdgesOnCell", ncio.INT, ("nCells",))
+        w.def_var("ter", ncio.DOUBLE, ("nCells",), units="m", long_name="terrain height")
+        w.def_var("zs", ncio.FLOAT, ("Time", "nSoilLevels"), units="m")
+        w.put("latCell", mesh.latCell)
+        w.put("lonCell", mesh.lonCell)
+        w.put("latVertex", mesh.latVertex)
+        w.put("lonVertex", mesh.lonVertex)
+        w.put("verticesOnCell", mesh.verticesOnCell)
+        w.put("nEdgesOnCell", (mesh.verticesOnCell > 0).sum(1).astype(np.int32))
+        w.put("ter", ter)
+        w.put("zs", np.asarray(zs, np.float32), rec=0)
+
+    def fields_file(path, flds):
+        with ncio.Writer(path, format=fmt) as w:
+            w.def_dim("Time", None)
+            w.def_dim("nCells", nc)
+            w.def_dim("nVertLevels", nz)
+            w.def_dim("nVertLevelsP1", nz + 1)
+            w.def_dim("nSoilLevels", nsoil)
+            w.def_dim("StrLen", 64)
+            w.put_att("config_start_time", xtime)
+            w.put_att("config_dt", 20.0)
+            w.def_var("xtime", ncio.CHAR, ("Time", "StrLen"))
+            levdim = {nz: "nVertLevels", nz + 1: "nVertLevelsP1", nsoil: "nSoilLevels"}
+            for name, a in flds.items():
+                a = np.asarray(a)
+                dims = ("Time", "nCells") if a.ndim == 1 else ("Time", "nCells", levdim[a.shape[1]])
+                w.def_var(name, ncio.FLOAT, dims, units="-", long_name=name)
+            w.put("xtime", xtime.encode().ljust(64), rec=0)
+            for name, a in flds.items():
+                w.put(name, np.asarray(a, np.float32), rec=0)
+    fields_file(hist_path, hist)
+    if diag_path is not None:
+        fields_file(diag_path, diag or {})
+
+
+# ---- input -----------------------------------------------------------------------------------------------------
+def read_grid(path):
+    """-> (synth.MpasMesh, ter [nCells] float64, zs [nsoil] float64).  model_grid.F90:287-417."""
+    with ncio.Reader(path) as r:
+        for d in ("nCells", "nVertices", "maxEdges"):
+            if d not in r.dims:
+                raise ValueError("%s: dimension %s missing -- not an MPAS grid file" % (path, d))
+        mesh = synth.MpasMesh(r.get("latCell", dtype=np.float64), r.get("lonCell", dtype=np.float64),
+                              r.get("latVertex", dtype=np.float64), r.get("lonVertex", dtype=np.float64),
+                              np.ascontiguousarray(r.get("verticesOnCell", dtype=np.int32)))
+        ter = r.get("ter", dtype=np.float64) if "ter" in r.vars else None
+        zs = None
+        if "zs" in r.vars:
+            zs = r.get("zs", rec=0, dtype=np.float64) if r.vars["zs"]["record"] else r.get("zs", dtype=np.float64)
+    return mesh, ter, zs
+
+
+def _read_field(r, name):
+    v = r.vars[name]
+    return r.get(name, rec=0, dtype=np.float64) if v["record"] else r.get(name, dtype=np.float64)   # widened like nf90_get_var -> r8
+
+
+def read_input_data(hist_path, cfg, ter, diag_path=None):
+    """-> (interp.InputData with layout = LEV_FAST, attrs dict name -> (units, long_name), valid time string).
+    Every variable of the lists is read whole, first Time record (input_data.F90:316-812)."""
+    inp = I.InputData(hgt=ter, layout=R.LAYOUT_LEV_FAST)
+    attrs = {}
+    valid = ""
+
+    def take(r, names, store):
+        for n in names:
+            if n not in r.vars:
+                raise KeyError("variable %s not in %s" % (n, r_path))
+            store[n] = _read_field(r, n)
+            try:
+                attrs[n] = (r.att("units", var=n), r.att("long_name", var=n))
+            except ncio.NcioError:
+                attrs[n] = ("-", n)
+    if cfg.interp_hist:
+        r_path = hist_path
+        with ncio.Reader(hist_path) as r:
+            inp.nz = r.dims.get("nVertLevels", 0)
+            inp.nzp1 = r.dims.get("nVertLevelsP1", inp.nz + 1)
+            inp.nsoil = r.dims.get("nSoilLevels", 0)
+            take(r, [n for n, _ in cfg.hist_2d + cfg.hist_3d + cfg.hist_soil], inp.hist)
+            if "xtime" in r.vars:
+                valid = r.get("xtime", rec=0).tobytes().decode().strip()[:DATESTRLEN]
+    if cfg.interp_diag and diag_path is not None:
+        r_path = diag_path
+        with ncio.Reader(diag_path) as r:
+            inp.nz = inp.nz or r.dims.get("nVertLevels", 0)
+            take(r, [n for n, _ in cfg.diag_list], inp.diag)
+    return inp, attrs, valid
+
+
+# ---- output ----------------------------------------------------------------------------------------------------
+_GRID_VARS = [  # name, stagger key, dims, description, units   (write_data.F90:312-476)
+    ("XLONG", "M", ("west_east", "south_north"), "LONGITUDE, WEST IS NEGATIVE", "degree_east"),
+    ("XLONG_U", "U", ("west_east_stag", "south_north"), "LONGITUDE, WEST IS NEGATIVE", "degree_east"),
+    ("XLONG_V", "V", ("west_east", "south_north_stag"), "LONGITUDE, WEST IS NEGATIVE", "degree_east"),
+    ("XLAT", "M", ("west_east", "south_north"), "LATITUDE, SOUTH IS NEGATIVE", "degree_north"),
+    ("XLAT_U", "U", ("west_east_stag", "south_north"), "LATITUDE, SOUTH IS NEGATIVE", "degree_north"),
+    ("XLAT_V", "V", ("west_east", "south_north_stag"), "LATITUDE, SOUTH IS NEGATIVE", "degree_north"),
+    ("MAPFAC_M", "M", ("west_east", "south_north"), "Map scale factor on mass grid", ""),
+    ("MAPFAC_U", "U", ("west_east_stag", "south_north"), "Map scale factor on u-grid", ""),
+    ("MAPFAC_V", "V", ("west_east", "south_north_stag"), "Map scale factor on v-grid", ""),
+]
+
+
+def _np(x):
+    return x.cpu().numpy() if type(x).__module__.startswith("torch") else np.asarray(x)
+
+
+def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time="0000-00-00_00:00:00", start_time=None,
+                      zs=None, namelist=None, fmt=5):
+    """res: post.output_fields() result (float32 arrays, [L][ny][nx] C order = Fortran (i, j, L)).  grid: a
+    regrid.Grid built with Grid.from_proj (coordinates / map factors / rotation come from the device).
+    namelist: dict with dx, ref_lat, ref_lon, truelat1, truelat2, stand_lon for the global attributes."""
+    nl = dict(dx=0.0, ref_lat=0.0, ref_lon=0.0, truelat1=0.0, truelat2=0.0, stand_lon=0.0, pole_lat=90.0, pole_lon=0.0)
+    nl.update(namelist or {})
+    nx, ny = target.nx, target.ny
+    start_time = start_time or valid_time
+    with ncio.Writer(path, format=fmt) as w:
+        for name, n in (("Time", None), ("west_east", nx), ("west_east_stag", nx + 1), ("south_north", ny), ("south_north_stag", ny + 1),
+                        ("bottom_top", nz), ("bottom_top_stag", nzp1), ("soil_layers_stag", max(nsoil, 1)), ("StrLen", DATESTRLEN)):
+            w.def_dim(name, n)                                                        # write_data.F90:177-194
+        ga = [("WEST-EAST_GRID_DIMENSION", nx + 1), ("SOUTH-NORTH_GRID_DIMENSION", ny + 1), ("BOTTOM-TOP_GRID_DIMENSION", nz + 1),
+              ("SIMULATION_START_DATE", start_time), ("START_DATE", start_time), ("DX", np.float32(nl["dx"])), ("DY", np.float32(nl["dx"])),
+              ("CEN_LAT", np.float32(nl["ref_lat"])), ("CEN_LON", np.float32(nl["ref_lon"])), ("TRUELAT1", np.float32(nl["truelat1"])),
+              ("TRUELAT2", np.float32(nl["truelat2"])), ("MOAD_CEN_LAT", np.float32(nl["ref_lat"])), ("STAND_LON", np.float32(nl["stand_lon"])),
+              ("POLE_LAT", np.float32(nl["pole_lat"])), ("POLE_LON", np.float32(nl["pole_lon"])), ("MAP_PROJ", int(target.proj.code)),
+              ("MAP_PROJ_CHAR", "Lambert Conformal" if target.proj.code == 1 else "Cylindrical Equidistant"),
+              ("I_PARENT_START", 1), ("J_PARENT_START", 1), ("WEST-EAST_PATCH_END_UNSTAG", nx), ("WEST-EAST_PATCH_END_STAG", nx + 1),
+              ("SOUTH-NORTH_PATCH_END_UNSTAG", ny), ("SOUTH-NORTH_PATCH_END_STAG", ny + 1), ("BOTTOM-TOP_PATCH_END_UNSTAG", nz),
+              ("BOTTOM-TOP_PATCH_END_STAG", nz + 1)]
+        for k, v in ga:                                                               # :196-308
+            w.put_att(k, v)
+        stag = {"M": (R.STAGGERLOC_CENTER, ""), "U": (R.STAGGERLOC_EDGE1, "X"), "V": (R.STAGGERLOC_EDGE2, "Y")}
+        for name, st, dims, desc, units in _GRID_VARS:
+            w.def_var(name, ncio.FLOAT, ("Time",) + dims[::-1], description=desc, units=units, MemoryOrder="XY ", stagger=stag[st][1],
+                      FieldType=104)
+        lc = target.proj.code == 1
+        if lc:                                                                        # :446-476
+            for name in ("SINALPHA", "COSALPHA"):
+                w.def_var(name, ncio.FLOAT, ("Time", "south_north", "west_east"), description="Local %s of map rotation" %
+                          ("sine" if name[0] == "S" else "cosine"), units="", MemoryOrder="XY ", stagger="", FieldType=104)
+        w.def_var("ZS", ncio.FLOAT, ("Time", "soil_layers_stag"), description="DEPTHS OF CENTERS OF SOIL LAYERS", units="m", MemoryOrder="X")
+        w.def_var("Times", ncio.CHAR, ("Time", "StrLen"))
+        dimsets = {(ny, nx): ("south_north", "west_east"), (nz, ny, nx): ("bottom_top", "south_north", "west_east"),
+                   (nz, ny, nx + 1): ("bottom_top", "south_north", "west_east_stag"),
+                   (nz, ny + 1, nx): ("bottom_top", "south_north_stag", "west_east"),
+                   (nzp1, ny, nx): ("bottom_top_stag", "south_north", "west_east")}
+        if nsoil and nsoil not in (nz, nzp1):
+            dimsets[(nsoil, ny, nx)] = ("soil_layers_stag", "south_north", "west_east")
+        arrays = {}
+        for name, a in res.items():
+            if name == "P_TOP":
+                w.def_var("P_TOP", ncio.FLOAT, ("Time",), description="PRESSURE TOP OF THE MODEL", units="Pa")
+                continue
+            a = _np(a)
+            arrays[name] = a
+            dims = dimsets[tuple(a.shape)]
+            if name == "Z_C":                                                         # declared on bottom_top_stag, nz levels written (:479, :1413)
+                dims = ("bottom_top_stag",) + dims[1:]
+            w.def_var(name, ncio.FLOAT, ("Time",) + dims, MemoryOrder="XYZ" if a.ndim == 3 else "XY ", coordinates="XLONG XLAT XTIME",
+                      stagger="X" if a.shape[-1] == nx + 1 else ("Y" if a.shape[-2] == ny + 1 else ""), FieldType=104)
+        # ---- data (:1003-1475) ----
+        for name, st, dims, _, _ in _GRID_VARS:
+            lon, lat = grid.coords(stag[st][0])
+            w.put(name, grid.mapfac(stag[st][0]) if name.startswith("MAPFAC") else (lon if "LONG" in name else lat), rec=0)
+        if lc:
+            cosa, sina = grid.rotang()
+            w.put("SINALPHA", sina, rec=0)
+            w.put("COSALPHA", cosa, rec=0)
+        w.put("ZS", np.zeros(max(nsoil, 1), np.float32) if zs is None else np.asarray(zs, np.float32), rec=0)
+        w.put("Times", valid_time.encode()[:DATESTRLEN].ljust(DATESTRLEN), rec=0)
+        for name, a in arrays.items():
+            if name == "Z_C":
+                pad = np.zeros((nzp1,) + a.shape[1:], np.float32)
+                pad[:nz] = a
+                a = pad
+            w.put(name, a, rec=0)
+        if "P_TOP" in res:
+            w.put("P_TOP", np.array([res["P_TOP"]], np.float32), rec=0)
+
+
+def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=None, fmt=5):
+    """mpassit.F90's main sequence on files: read grid + data, regrid on the GPU, post-ops, write.  Returns the
+    dictionary that went to the file (float32, post.output_fields order)."""
+    from . import post
+    mpas, ter, zs = read_grid(grid_path)
+    inp, _, valid = read_input_data(hist_path, cfg, ter, diag_path=diag_path)
+    mesh = R.Mesh.from_mpas(mpas)
+    grid = R.Grid.from_proj(target)
+    out = I.interp_data(mesh, grid, target, inp, cfg)
+    res = post.output_fields(out, cfg)
+    write_target_data(out_path, target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00", zs=zs,
+                      namelist=namelist, fmt=fmt)
+    mesh.destroy()
+    grid.destroy()
+    return res
+
+
+__all__ = ["write_mpas_files", "read_grid", "read_input_data", "write_target_data", "run", "F"]

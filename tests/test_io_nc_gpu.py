@@ -1,0 +1,79 @@
+"""File-to-file run (mpassit.F90's main sequence): synthetic MPAS grid/history/diag files -> GPU regrid -> post-ops ->
+WRF-style output file, read back with an independent NetCDF reader (scipy) and compared with the in-memory pipeline."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_file_to_file_run_matches_the_in_memory_pipeline(gpu_lib, tmp_path):
+    from scipy.io import netcdf_file
+
+    from mpassit_amd import build, interp as I, io_nc, ncio, post, regrid as R, synth, target_grid as T, workloads
+    build.build_ncio()
+    m, _, nz, _ = workloads.workload("tiny")
+    nsoil = 4
+    rng = np.random.default_rng(17)
+    f32 = lambda a: np.asarray(a, np.float32)           # noqa: E731  history files are single precision
+    hist = {"xland": f32(np.floor(rng.uniform(1, 3, m.nCells))), "skintemp": f32(rng.uniform(250, 320, m.nCells)),
+            "snow": f32(synth.snow_field(m.latCell, m.lonCell)[0]),
+            "zgrid": f32(np.sort(rng.uniform(0, 2.0e4, (m.nCells, nz + 1)), axis=1)), "theta": f32(rng.uniform(280, 500, (m.nCells, nz))),
+            "uReconstructZonal": f32(rng.normal(0, 10, (m.nCells, nz))), "uReconstructMeridional": f32(rng.normal(0, 10, (m.nCells, nz))),
+            "pressure": f32(-np.sort(-rng.uniform(2.0e3, 1.0e5, (m.nCells, nz)), axis=1)), "rho": f32(rng.uniform(0.1, 1.2, (m.nCells, nz))),
+            "tslb": f32(rng.uniform(260, 300, (m.nCells, nsoil)))}
+    diag = {"t2m": f32(rng.uniform(250, 310, m.nCells)), "u10": f32(rng.normal(0, 8, m.nCells)), "v10": f32(rng.normal(0, 8, m.nCells)),
+            "refl10cm": f32(rng.uniform(-30, 60, (m.nCells, nz)))}
+    ter = rng.uniform(0, 3000, m.nCells)
+    zs = [0.05, 0.25, 0.7, 1.5]
+    gpath, hpath, dpath, opath = (tmp_path / n for n in ("grid.nc", "hist.nc", "diag.nc", "out.nc"))
+    io_nc.write_mpas_files(gpath, hpath, m, ter, zs, hist, nz, nsoil, diag_path=dpath, diag=diag, xtime="2024-08-07_06:00:00")
+    cfg = I.InterpConfig(interp_diag=True, wrf_mod_vars=True,
+                         diag_list=[("t2m", "T2"), ("u10", "U10"), ("v10", "V10"), ("refl10cm", "REFL_10CM")],
+                         hist_2d=[("xland", "XLAND"), ("skintemp", "TSK"), ("snow", "SNOW")],
+                         hist_3d=[("zgrid", "PHB"), ("theta", "T"), ("uReconstructZonal", "U"), ("uReconstructMeridional", "V"),
+                                  ("pressure", "P_HYD"), ("rho", "MUB")], hist_soil=[("tslb", "TSLB")])
+    nml = dict(dx=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+    target = T.define_target_grid_params("lambert", 181, 107, dy=30000.0, arrays=False, **nml)
+    res = io_nc.run(gpath, hpath, opath, target, cfg, diag_path=dpath, namelist=nml, fmt=2)
+
+    # the same job without files: float32 inputs widened, cell-fast layout, host-array target grid
+    host = T.define_target_grid_params("lambert", 181, 107, dy=30000.0, **nml)
+    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil, hgt=ter)
+    inp.hist = {k: np.ascontiguousarray(v.astype(np.float64).T) for k, v in hist.items()}
+    inp.diag = {k: np.ascontiguousarray(v.astype(np.float64).T) for k, v in diag.items()}
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(host)
+    want = post.output_fields(I.interp_data(mesh, grid, host, inp, cfg), cfg)
+    assert list(res) == list(want)
+
+    f = netcdf_file(str(opath), "r", mmap=False)                      # independent reader of the classic format
+    assert f.version_byte == 2 and f.dimensions["west_east"] == 180 and f.dimensions["south_north_stag"] == 107
+    assert f.dimensions["bottom_top"] == nz and f.dimensions["Time"] is None and f.MAP_PROJ == 1
+    assert abs(f.TRUELAT1 - 38.5) < 1e-6 and f.variables["XLAT"].units == b"degree_north"
+    assert b"".join(f.variables["Times"][0]) == b"2024-08-07_06:00:00"
+    np.testing.assert_allclose(f.variables["XLAT"][0], host.lat, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f.variables["XLONG_U"][0], host.lon_u, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f.variables["COSALPHA"][0], host.cosa, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(f.variables["ZS"][0], zs, rtol=1e-6)
+    mf = f.variables["MAPFAC_M"][0]
+    assert 0.9 < mf.min() and mf.max() < 1.2 and abs(mf[53, 90] - 1.0) < 1e-3          # ~1 at the true latitude
+    for name, w in want.items():
+        got = f.variables[name][0]
+        if name == "P_TOP":
+            assert got == w
+            continue
+        if name == "Z_C":
+            assert got.shape == (nz + 1, host.ny, host.nx) and not got[nz].any()
+            got = got[:nz]
+        assert got.dtype.kind == "f" and got.dtype.itemsize == 4 and got.shape == w.shape      # NC_FLOAT (big-endian on disk)
+        # device-generated vs host-generated grid coordinates differ in the last bits -> float32-level agreement
+        np.testing.assert_allclose(got, w, rtol=2e-6, atol=2e-6 * max(1.0, float(np.abs(w).max())), err_msg=name)
+    assert f.variables["U"].shape == (1, nz, host.ny, host.nx + 1) and f.variables["V"].shape == (1, nz, host.ny + 1, host.nx)
+    f.close()
+
+    # CDF-5 output is read back by this repo's reader
+    res5 = io_nc.run(gpath, hpath, tmp_path / "out5.nc", target, cfg, diag_path=dpath, namelist=nml, fmt=5)
+    with ncio.Reader(tmp_path / "out5.nc") as r:
+        assert r.format == 5
+        assert np.array_equal(r.get("T", rec=0), res5["T"]) and np.array_equal(r.get("TSLB", rec=0), res5["TSLB"])
+    mesh.destroy()
+    grid.destroy()
