@@ -71,7 +71,7 @@ def build_ncio(force=False):
     return NCIO_SO
 
 
-FORTRAN_SRC = ["mpg_mod.F90", "host_mod.F90", "interp_mod.F90", "mpassit_driver.F90"]
+FORTRAN_SRC = ["mpg_mod.F90", "ncio_mod.F90", "host_mod.F90", "interp_mod.F90", "ncfiles_mod.F90", "mpassit_driver.F90"]
 FLANG = os.environ.get("FLANG", "/opt/rocm/bin/amdflang")
 DRIVER = os.path.join(HERE, "fortran", "mpassit")
 
@@ -80,7 +80,8 @@ def build_fortran(force=False):
     """Fortran driver (reference surface: namelist + parm lists) linked against the C-ABI library."""
     fdir = os.path.join(HERE, "fortran")
     srcs = [os.path.join(fdir, f) for f in FORTRAN_SRC]
-    if not force and _newer(DRIVER, srcs + [SO]):
+    build_ncio()
+    if not force and _newer(DRIVER, srcs + [SO, NCIO_SO]):
         return DRIVER
     mod = os.path.join(OBJDIR, "fmod")
     os.makedirs(mod, exist_ok=True)
@@ -91,7 +92,8 @@ def build_fortran(force=False):
         if r.returncode != 0:
             raise RuntimeError("amdflang failed on %s:\n%s" % (s, r.stderr[-6000:]))
         objs.append(o)
-    r = subprocess.run([FLANG, "-o", DRIVER] + objs + ["-L" + HERE, "-lmpassit_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib"],
+    r = subprocess.run([FLANG, "-o", DRIVER] + objs + ["-L" + HERE, "-lmpassit_amd", "-L" + os.path.join(HERE, "hostio"), "-lmpassit_ncio", "-Wl,-rpath," + HERE,
+                        "-Wl,-rpath," + os.path.join(HERE, "hostio"), "-Wl,-rpath,/opt/rocm/lib"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("linking the Fortran driver failed:\n%s" % r.stderr[-6000:])

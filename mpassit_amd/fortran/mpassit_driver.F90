@@ -2,7 +2,9 @@
 !! (default fort.41), &config namelist, diaglist / histlist_2d / histlist_3d / histlist_soil in the CWD.
 !! Phases in the reference's order (mpassit.F90:105-137): namelist -> target grid -> input grid ->
 !! input data -> interp_data (HIP, through the C-ABI) -> write.  No MPI/ESMF: one process drives one GPU.
-!! File I/O uses the MPGRAW1 raw container because the image has no NetCDF (I/O is out of the hot path).
+!! File I/O: NetCDF classic files (CDF-1/2/5, through ncio: the image has no libnetcdf, so NetCDF-4 is not read) are
+!! recognised by their magic; anything else is taken as the MPGRAW1 raw container.  An output_file ending in ".nc" is
+!! written as CDF-5 with the reference's dimension / variable names and post-ops (ncfiles_mod.F90).
 program mpassit
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: int32, int64
@@ -13,8 +15,13 @@ program mpassit
   use rawio
   use model_data
   use interp
+  use ncio
+  use ncfiles
   implicit none
   character(len=500) :: nml_file
+  character(len=19) :: valid_time = "0000-00-00_00:00:00"
+  logical :: nc_in = .false.
+  type(c_ptr) :: nf_in = c_null_ptr
   integer :: nargs
 
   nargs = command_argument_count()
@@ -79,6 +86,14 @@ contains
     logical :: found
     real(dp), allocatable :: latCell(:), lonCell(:), latVertex(:), lonVertex(:)
     integer(c_int32_t), allocatable :: voc(:)
+    if (nc_is_netcdf(grid_file_input_grid)) then
+      call nc_read_grid(grid_file_input_grid, latCell, lonCell, latVertex, lonVertex, voc)
+      print *, "- NUMBER OF CELLS ON INPUT GRID ", nCells_input
+      print *, "- CREATE MESH -"
+      call mpg_check(mpg_mesh_create(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &
+                                     latCell, lonCell, latVertex, lonVertex, voc, input_grid), "IN MeshCreate")
+      return
+    end if
     call raw_open_read(grid_file_input_grid, u)
     call read_f64(u, "latCell", latCell, dims, .true.)
     nCells_input = int(dims(1))
@@ -107,6 +122,10 @@ contains
     character(len=*), intent(in) :: name, tname
     type(field_t), intent(out) :: f
     integer(int64) :: dims(3)
+    if (nc_in) then
+      call nc_load_field(nf_in, name, tname, f)
+      return
+    end if
     f%name = name; f%tname = tname
     call read_f64(u, name, f%src, dims, .true.)
     if (dims(2) == 1) then
@@ -137,17 +156,17 @@ contains
     nzp1_vars = [character(len=50) :: 'zgrid', 'w']
     if (interp_diag) then
       call read_varlist('diaglist', n, names, targets)
-      call raw_open_read(diag_file_input_grid, u)
+      call open_in(diag_file_input_grid, u)
       do i = 1, n
         call load_field(u, names(i), targets(i), f)
         call append(diag_bundle, f)
         if (trim(names(i)) == 'u10') u10_ind = i
         if (trim(names(i)) == 'v10') v10_ind = i
       end do
-      close (u)
+      call close_in(u)
     end if
     if (interp_hist) then
-      call raw_open_read(hist_file_input_grid, u)
+      call open_in(hist_file_input_grid, u)
       call read_varlist('histlist_2d', n, names, targets)
       do i = 1, n
         call load_field(u, names(i), targets(i), f)
@@ -179,9 +198,38 @@ contains
         call load_field(u, names(i), targets(i), f)
         call append(hist_soil, f)
       end do
-      close (u)
+      call close_in(u)
     end if
   end subroutine read_input_data
+
+  subroutine open_in(file, u)
+    character(len=*), intent(in) :: file
+    integer, intent(out) :: u
+    integer(c_int) :: id, rc
+    integer(c_int8_t) :: tb(64)
+    nc_in = nc_is_netcdf(file)
+    u = -1
+    if (nc_in) then
+      call ncio_check(ncio_open(file, nf_in), "opening "//trim(file))
+      if (ncio_inq_varid(nf_in, "xtime", id) == 0) then
+        tb = 32_c_int8_t
+        rc = ncio_get_var(nf_in, id, 0_c_int64_t, NCIO_CHAR, tb)
+        if (rc == 0) valid_time = transfer(tb(1:19), valid_time)
+      end if
+    else
+      call raw_open_read(file, u)
+    end if
+  end subroutine open_in
+
+  subroutine close_in(u)
+    integer, intent(in) :: u
+    if (nc_in) then
+      call ncio_check(ncio_close(nf_in), "closing input file")
+      nc_in = .false.
+    else
+      close (u)
+    end if
+  end subroutine close_in
 
   subroutine put(u, f, ni, nj)
     integer, intent(in) :: u, ni, nj
@@ -202,7 +250,14 @@ contains
   end subroutine put_bundle
 
   subroutine write_to_file()
-    integer :: u
+    integer :: u, l
+    l = len_trim(output_file)
+    if (l > 3) then
+      if (output_file(l - 2:l) == ".nc") then
+        call nc_write_target(trim(output_file), valid_time)
+        return
+      end if
+    end if
     call raw_open_write(output_file, u)
     if (interp_diag) call put_bundle(u, diag_bundle)
     if (interp_hist) then

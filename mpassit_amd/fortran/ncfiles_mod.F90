@@ -1,0 +1,294 @@
+!> NetCDF (classic formats) file surface of the Fortran driver, through ncio (ncio_mod.F90):
+!!   nc_read_grid     model_grid.F90:287-417   dimensions, lat/lon of cells and vertices, verticesOnCell, ter
+!!   nc_load_field    input_data.F90:316-812   one listed variable, first Time record, file order (level fastest)
+!!   nc_write_target  write_data.F90:173-1498  dimensions, global attributes, grid variables, every target field with
+!!                                             the writer's post-ops (T-300 :1343, MU/PH/P = 0 :1354,:1427,:1466,
+!!                                             P_TOP :1362-1371, PB, Z_C :1406-1415, PHB*9.81 :1418), NF90_FLOAT
+!! The output is CDF-5 (the reference writes NetCDF-4, which needs HDF5: not in this image).
+module ncfiles
+  use, intrinsic :: iso_c_binding
+  use, intrinsic :: iso_fortran_env, only: int64
+  use ncio
+  use program_setup
+  use target_grid
+  use model_data
+  implicit none
+  private
+  public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target
+
+  type(c_ptr) :: nf_out = c_null_ptr
+  integer(c_int) :: d_time, d_we, d_wes, d_sn, d_sns, d_bt, d_bts, d_soil, d_str
+
+contains
+
+  logical function nc_is_netcdf(file)
+    character(len=*), intent(in) :: file
+    character(len=3) :: magic
+    integer :: u, ios
+    nc_is_netcdf = .false.
+    open (newunit=u, file=trim(file), access='stream', form='unformatted', status='old', iostat=ios)
+    if (ios /= 0) return
+    read (u, iostat=ios) magic
+    close (u)
+    nc_is_netcdf = ios == 0 .and. magic == 'CDF'
+  end function nc_is_netcdf
+
+  subroutine get_f64(nf, name, arr, n)
+    type(c_ptr), intent(in) :: nf
+    character(len=*), intent(in) :: name
+    integer(int64), intent(in) :: n
+    real(dp), allocatable, intent(out) :: arr(:)
+    integer(c_int) :: id
+    call ncio_check(ncio_inq_varid(nf, name, id), "reading field id - "//trim(name))
+    allocate (arr(n))
+    call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, arr), "reading field - "//trim(name))
+  end subroutine get_f64
+
+  subroutine nc_read_grid(file, latCell, lonCell, latVertex, lonVertex, voc)
+    character(len=*), intent(in) :: file
+    real(dp), allocatable, intent(out) :: latCell(:), lonCell(:), latVertex(:), lonVertex(:)
+    integer(c_int32_t), allocatable, intent(out) :: voc(:)
+    type(c_ptr) :: nf
+    integer(c_int64_t) :: nc, nv, me
+    integer(c_int) :: id
+    call ncio_check(ncio_open(file, nf), "opening grid file")
+    call ncio_check(ncio_inq_dim(nf, "nCells", nc), "reading nCells")
+    call ncio_check(ncio_inq_dim(nf, "nVertices", nv), "reading nVertices")
+    call ncio_check(ncio_inq_dim(nf, "maxEdges", me), "reading maxEdges")
+    nCells_input = int(nc); nVert_input = int(nv); maxEdges_input = int(me)
+    call get_f64(nf, "latCell", latCell, nc)
+    call get_f64(nf, "lonCell", lonCell, nc)
+    call get_f64(nf, "latVertex", latVertex, nv)
+    call get_f64(nf, "lonVertex", lonVertex, nv)
+    call ncio_check(ncio_inq_varid(nf, "verticesOnCell", id), "reading verticesOnCell id")
+    allocate (voc(nc*me))
+    call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_INT, voc), "reading verticesOnCell")
+    call get_f64(nf, "ter", hgt%src, nc)
+    hgt%name = "ter"; hgt%tname = "HGT"; hgt%nlev = 1
+    call ncio_check(ncio_close(nf), "closing grid file")
+  end subroutine nc_read_grid
+
+  subroutine nc_load_field(nf, name, tname, f)
+    type(c_ptr), intent(in) :: nf
+    character(len=*), intent(in) :: name, tname
+    type(field_t), intent(out) :: f
+    integer(c_int) :: id, xtype, ndims, isrec, dimids(8)
+    integer(c_int64_t) :: shp(8), n
+    character(kind=c_char) :: nbuf(64)
+    integer :: d0
+    f%name = name; f%tname = tname
+    call ncio_check(ncio_inq_varid(nf, name, id), "reading field id - "//trim(name))
+    call ncio_check(ncio_inq_var(nf, id, nbuf, 64_c_int, xtype, ndims, shp, dimids, isrec), "inquiring "//trim(name))
+    d0 = merge(2, 1, isrec /= 0)                  ! skip the Time dimension
+    if (ndims - d0 + 1 == 1) then
+      f%nlev = 1                                 ! (nCells)
+      n = shp(d0)
+    else
+      f%nlev = int(shp(d0 + 1))                  ! file order [nCells][nlev] == Fortran (nlev, nCells)
+      n = shp(d0)*shp(d0 + 1)
+    end if
+    allocate (f%src(n))
+    call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, f%src), "reading field - "//trim(name))
+  end subroutine nc_load_field
+
+  ! ---- output ---------------------------------------------------------------------------------------------------
+  subroutine def_field(name, nlev, stag, id)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: nlev, stag            ! stag: 0 mass, 1 U (west_east_stag), 2 V (south_north_stag)
+    integer(c_int), intent(out) :: id
+    integer(c_int) :: dx, dy, dz
+    dx = merge(d_wes, d_we, stag == 1)
+    dy = merge(d_sns, d_sn, stag == 2)
+    if (nlev == 1) then
+      call ncio_check(ncio_def_var(nf_out, name, NCIO_FLOAT, [d_time, dy, dx], id), "DEFINING "//trim(name))
+      call ncio_check(ncio_put_att_text(nf_out, id, "MemoryOrder", "XY "), "DEFINING MEMORYORDER")
+    else
+      if (nlev == nz_input) then
+        dz = d_bt
+      else if (nlev == nzp1_input) then
+        dz = d_bts
+      else
+        dz = d_soil
+      end if
+      call ncio_check(ncio_def_var(nf_out, name, NCIO_FLOAT, [d_time, dz, dy, dx], id), "DEFINING "//trim(name))
+      call ncio_check(ncio_put_att_text(nf_out, id, "MemoryOrder", "XYZ"), "DEFINING MEMORYORDER")
+    end if
+    call ncio_check(ncio_put_att_text(nf_out, id, "coordinates", "XLONG XLAT XTIME"), "DEFINING COORD")
+    call ncio_check(ncio_put_att_text(nf_out, id, "stagger", merge("X", merge("Y", " ", stag == 2), stag == 1)), "DEFINING STAGGER")
+    call ncio_check(ncio_put_att_int(nf_out, id, "FieldType", 104), "DEFINING FieldType")
+  end subroutine def_field
+
+  subroutine put_r8(id, a)
+    integer(c_int), intent(in) :: id
+    real(dp), intent(in) :: a(*)
+    call ncio_check(ncio_put_var(nf_out, id, 0_c_int64_t, NCIO_DOUBLE, a), "WRITING RECORD")
+  end subroutine put_r8
+
+  subroutine nc_write_target(file, valid_time)
+    character(len=*), intent(in) :: file, valid_time
+    integer, parameter :: MAXV = 512
+    integer(c_int) :: ids(MAXV), id_extra(8), id_grid(8), id_times, id_ptop
+    integer :: nv, i, k, npts
+    type(field_t), allocatable :: fl(:)
+    real(dp), allocatable :: tmp(:)
+    real(dp) :: ptop
+    character(len=19) :: tstr
+    integer(c_int8_t) :: tbytes(19)
+    logical :: have_ptop
+    ! nz / nzp1 / nsoil from what was read
+    if (do_u_interp == 1) nz_input = u_field%nlev
+    if (nz_input == 0 .and. hist_3d_nz%n > 0) nz_input = hist_3d_nz%f(1)%nlev
+    if (nz_input == 0 .and. diag_bundle%n > 0) nz_input = maxval(diag_bundle%f(1:diag_bundle%n)%nlev)
+    nz_input = max(nz_input, 1)
+    nzp1_input = nz_input + 1
+    if (hist_soil%n > 0) nsoil_input = hist_soil%f(1)%nlev
+    nsoil_input = max(nsoil_input, 1)
+    call ncio_check(ncio_create(file, 5, nf_out), "CREATING FILE "//trim(file))
+    call ncio_check(ncio_def_dim(nf_out, "Time", 0, d_time), "DEFINING Time")                    ! write_data.F90:177-194
+    call ncio_check(ncio_def_dim(nf_out, "west_east", i_target, d_we), "DEFINING west_east")
+    call ncio_check(ncio_def_dim(nf_out, "west_east_stag", i_target + 1, d_wes), "DEFINING west_east_stag")
+    call ncio_check(ncio_def_dim(nf_out, "south_north", j_target, d_sn), "DEFINING south_north")
+    call ncio_check(ncio_def_dim(nf_out, "south_north_stag", j_target + 1, d_sns), "DEFINING south_north_stag")
+    call ncio_check(ncio_def_dim(nf_out, "bottom_top", nz_input, d_bt), "DEFINING bottom_top")
+    call ncio_check(ncio_def_dim(nf_out, "bottom_top_stag", nzp1_input, d_bts), "DEFINING bottom_top_stag")
+    call ncio_check(ncio_def_dim(nf_out, "soil_layers_stag", nsoil_input, d_soil), "DEFINING soil_layers_stag")
+    call ncio_check(ncio_def_dim(nf_out, "StrLen", 19, d_str), "DEFINING StrLen")
+    call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "WEST-EAST_GRID_DIMENSION", i_target + 1), "GLOBAL ATT")   ! :196-308
+    call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "SOUTH-NORTH_GRID_DIMENSION", j_target + 1), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "BOTTOM-TOP_GRID_DIMENSION", nz_input + 1), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_text(nf_out, NCIO_GLOBAL, "START_DATE", valid_time), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DX", dxkm*1000.0_dp), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DY", dxkm*1000.0_dp), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "CEN_LAT", ref_lat), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "CEN_LON", ref_lon), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "TRUELAT1", truelat1), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "TRUELAT2", truelat2), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "STAND_LON", stand_lon), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "MAP_PROJ", proj_code), "GLOBAL ATT")
+    ! grid variables (:312-476): XLONG, XLAT on the three staggers, SINALPHA / COSALPHA for Lambert
+    call def_field("XLONG", 1, 0, id_grid(1)); call def_field("XLAT", 1, 0, id_grid(2))
+    call def_field("XLONG_U", 1, 1, id_grid(3)); call def_field("XLAT_U", 1, 1, id_grid(4))
+    call def_field("XLONG_V", 1, 2, id_grid(5)); call def_field("XLAT_V", 1, 2, id_grid(6))
+    if (proj_code == PROJ_LC) then
+      call def_field("SINALPHA", 1, 0, id_grid(7)); call def_field("COSALPHA", 1, 0, id_grid(8))
+    end if
+    call ncio_check(ncio_def_var(nf_out, "Times", NCIO_CHAR, [d_time, d_str], id_times), "DEFINING Times")
+    ! target fields in the writer's order (:1150-1475)
+    call collect(fl, nv)
+    if (nv > MAXV) call fatal("too many output variables", nv)
+    have_ptop = .false.
+    id_extra = -1
+    do i = 1, nv
+      call def_field(trim(fl(i)%tname), fl(i)%nlev, fl(i)%stagger, ids(i))
+      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'MUB') call def_field("MU", fl(i)%nlev, 0, id_extra(1))
+      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'P_HYD') then
+        call ncio_check(ncio_def_var(nf_out, "P_TOP", NCIO_FLOAT, [d_time], id_ptop), "DEFINING P_TOP")
+        call def_field("PB", fl(i)%nlev, 0, id_extra(2))
+        have_ptop = .true.
+      end if
+      if (trim(fl(i)%tname) == 'PHB') then
+        call def_field("Z_C", nzp1_input, 0, id_extra(3))                                        ! on bottom_top_stag (:479)
+        if (wrf_mod_vars) call def_field("PH", fl(i)%nlev, 0, id_extra(4))
+      end if
+    end do
+    if (wrf_mod_vars .and. hist_3d_nz%n > 0) call def_field("P", nz_input, 0, id_extra(5))
+    call ncio_check(ncio_enddef(nf_out), "ENDDEF")
+    ! ---- data ----
+    call put_r8(id_grid(1), lon_m); call put_r8(id_grid(2), lat_m)
+    call put_r8(id_grid(3), lon_u); call put_r8(id_grid(4), lat_u)
+    call put_r8(id_grid(5), lon_v); call put_r8(id_grid(6), lat_v)
+    if (proj_code == PROJ_LC) then
+      call put_r8(id_grid(7), sina); call put_r8(id_grid(8), cosa)
+    end if
+    tstr = valid_time
+    tbytes = transfer(tstr, tbytes)
+    call ncio_check(ncio_put_var(nf_out, id_times, 0_c_int64_t, NCIO_CHAR, tbytes), "WRITING Times")
+    npts = i_target*j_target
+    do i = 1, nv
+      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'T') then
+        tmp = fl(i)%dst - 300.0_dp                                                               ! :1339-1347
+        call put_r8(ids(i), tmp)
+      else if (trim(fl(i)%tname) == 'PHB') then
+        if (allocated(tmp)) deallocate (tmp)
+        allocate (tmp(npts*nzp1_input))
+        tmp = 0.0_dp
+        do k = 2, fl(i)%nlev                                                                     ! :1406-1412
+          tmp((k - 2)*npts + 1:(k - 1)*npts) = 0.5_dp*(fl(i)%dst((k - 1)*npts + 1:k*npts) + fl(i)%dst((k - 2)*npts + 1:(k - 1)*npts))
+        end do
+        call put_r8(id_extra(3), tmp)
+        tmp = fl(i)%dst*9.81_dp                                                                  ! :1418
+        call put_r8(ids(i), tmp(1:size(fl(i)%dst)))
+        if (wrf_mod_vars) then
+          tmp = 0.0_dp
+          call put_r8(id_extra(4), tmp)
+        end if
+        deallocate (tmp)
+      else
+        call put_r8(ids(i), fl(i)%dst)
+      end if
+      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'MUB') then
+        if (allocated(tmp)) deallocate (tmp)
+        allocate (tmp(size(fl(i)%dst))); tmp = 0.0_dp
+        call put_r8(id_extra(1), tmp)
+        deallocate (tmp)
+      end if
+      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'P_HYD') then                                  ! :1362-1379
+        ptop = maxval(fl(i)%dst)
+        do k = (fl(i)%nlev - 1)*npts + 1, fl(i)%nlev*npts
+          if (fl(i)%dst(k) >= 10.0_dp) ptop = min(fl(i)%dst(k)*0.80_dp, ptop)
+        end do
+        call ncio_check(ncio_put_var(nf_out, id_ptop, 0_c_int64_t, NCIO_DOUBLE, [ptop]), "WRITING P_TOP")
+        call put_r8(id_extra(2), fl(i)%dst)
+      end if
+    end do
+    if (id_extra(5) >= 0) then
+      if (allocated(tmp)) deallocate (tmp)
+      allocate (tmp(npts*nz_input)); tmp = 0.0_dp
+      call put_r8(id_extra(5), tmp)
+    end if
+    call ncio_check(ncio_close(nf_out), "CLOSING FILE")
+  end subroutine nc_write_target
+
+  !> every target field in the order write_target_data emits them
+  subroutine collect(fl, nv)
+    type(field_t), allocatable, intent(out) :: fl(:)
+    integer, intent(out) :: nv
+    integer :: cap
+    cap = 8 + diag_bundle%n + hist_2d_patch%n + hist_2d_cons%n + hist_2d_nstd%n + hist_3d_nz%n + hist_3d_nzp1%n + hist_3d_vert%n + hist_soil%n
+    allocate (fl(cap))
+    nv = 0
+    if (interp_hist) then
+      call add(hgt, 0)
+      if (do_u_interp == 1) call add(u_field, 1)
+      if (do_v_interp == 1) call add(v_field, 2)
+    end if
+    if (interp_diag) call add_bundle(diag_bundle, 1)          ! 2-D diag fields first (:584)
+    if (interp_hist) then
+      call add_bundle(hist_2d_cons, 0); call add_bundle(hist_2d_patch, 0); call add_bundle(hist_2d_nstd, 0)
+    end if
+    if (interp_diag) call add_bundle(diag_bundle, 2)          ! then the 3-D diag fields (:604)
+    if (interp_hist) then
+      call add_bundle(hist_soil, 0); call add_bundle(hist_3d_nz, 0); call add_bundle(hist_3d_nzp1, 0); call add_bundle(hist_3d_vert, 0)
+    end if
+  contains
+    subroutine add(f, stag)
+      type(field_t), intent(in) :: f
+      integer, intent(in) :: stag
+      if (.not. allocated(f%dst)) return
+      nv = nv + 1
+      fl(nv)%name = f%name; fl(nv)%tname = f%tname; fl(nv)%nlev = f%nlev
+      fl(nv)%dst = f%dst
+      fl(nv)%stagger = stag
+    end subroutine add
+    subroutine add_bundle(b, sel)
+      type(bundle_t), intent(in) :: b
+      integer, intent(in) :: sel                 ! 0 all, 1 only 2-D, 2 only 3-D
+      integer :: q
+      do q = 1, b%n
+        if (sel == 1 .and. b%f(q)%nlev /= 1) cycle
+        if (sel == 2 .and. b%f(q)%nlev == 1) cycle
+        call add(b%f(q), 0)
+      end do
+    end subroutine add_bundle
+  end subroutine collect
+end module ncfiles
