@@ -240,3 +240,69 @@ def define_target_grid_params(target_grid_type, nx, ny, dx=NAN, dy=NAN, ref_lat=
     if proj.code == PROJ_LC:
         g.cosa, g.sina = get_rotang(g.lat, g.lon)
     return g
+
+
+def get_cell_corners(lat, lon, dx):
+    """CORNER-stagger coordinates of a file-defined target grid, exactly as get_cell_corners computes them
+    (model_grid.F90:1902-1972): every corner is the great-circle destination point at distance sqrt(dx^2/2) from a
+    mass point, with the bearings AS WRITTEN there -- 135 degrees for the (i, j) block, 225 on the extra column
+    (from column i_target), 45 on the extra row (from row j_target), 315 at the far corner -- and its own constants
+    pi = 3.14159265359, R = 6370000.  lat, lon: [nj][ni] degrees -> ([nj+1][ni+1], [nj+1][ni+1])."""
+    pi, R = 3.14159265359, 6370000.0
+    nj, ni = lat.shape
+    d = np.sqrt((dx ** 2.0) / 2.0)
+
+    def dest(la, lo, bearing_deg):
+        lat1, lon1 = la * (pi / 180.0), lo * (pi / 180.0)
+        brng = bearing_deg * (pi / 180.0)
+        lat2 = np.arcsin(np.sin(lat1) * np.cos(d / R) + np.cos(lat1) * np.sin(d / R) * np.cos(brng))
+        lon2 = lon1 + np.arctan2(np.sin(brng) * np.sin(d / R) * np.cos(lat1), np.cos(d / R) - np.sin(lat1) * np.sin(lat2))
+        return lat2 * 180.0 / pi, lon2 * 180.0 / pi
+    latc, lonc = np.empty((nj + 1, ni + 1)), np.empty((nj + 1, ni + 1))
+    latc[:nj, :ni], lonc[:nj, :ni] = dest(lat, lon, 135.0)
+    latc[:nj, ni], lonc[:nj, ni] = dest(lat[:, ni - 1], lon[:, ni - 1], 225.0)
+    latc[nj, :ni], lonc[nj, :ni] = dest(lat[nj - 1, :], lon[nj - 1, :], 45.0)
+    latc[nj, ni], lonc[nj, ni] = dest(lat[nj - 1, ni - 1], lon[nj - 1, ni - 1], 315.0)
+    return latc, lonc
+
+
+def define_target_grid_file(path):
+    """target_grid_type = 'file' (define_target_grid_file, model_grid.F90:1203-1888): the grid comes from a WRF
+    geo_em / wrfinput style file -- dimensions west_east / south_north, global attributes DX, CEN_LAT, CEN_LON,
+    TRUELAT1/2, MOAD_CEN_LAT, STAND_LON, POLE_LAT/LON, MAP_PROJ, variables XLONG|XLONG_M, XLAT|XLAT_M, XLONG_U, XLAT_U,
+    XLONG_V, XLAT_V, MAPFAC_M/U/V, SINALPHA / COSALPHA (Lambert), HGT|HGT_M; corners from get_cell_corners.
+    Classic-format files only (ncio).  -> TargetGrid with host arrays (use regrid.Grid.from_target)."""
+    from . import ncio
+    with ncio.Reader(path) as r:
+        ni, nj = r.dims["west_east"], r.dims["south_north"]
+
+        def var(*names):
+            for n in names:
+                if n in r.vars:
+                    v = r.vars[n]
+                    return r.get(n, rec=0, dtype=np.float64) if v["record"] else r.get(n, dtype=np.float64)
+            raise KeyError("%s: none of %s found" % (path, "/".join(names)))
+
+        def att(name, default=NAN):
+            try:
+                return float(r.att(name)[0])
+            except ncio.NcioError:
+                return default
+        dx = att("DX")
+        code = int(att("MAP_PROJ", PROJ_LC))
+        proj = Proj(code, dx=dx, stdlon=att("STAND_LON"), truelat1=att("TRUELAT1"), truelat2=att("TRUELAT2"))
+        g = TargetGrid(ni, nj, proj, True)
+        g.lon, g.lat = var("XLONG", "XLONG_M"), var("XLAT", "XLAT_M")
+        g.lon_u, g.lat_u = var("XLONG_U"), var("XLAT_U")
+        g.lon_v, g.lat_v = var("XLONG_V"), var("XLAT_V")
+        g.lat_c, g.lon_c = get_cell_corners(g.lat, g.lon, dx)
+        for k, names in (("mapfac_m", ("MAPFAC_M",)), ("mapfac_u", ("MAPFAC_U",)), ("mapfac_v", ("MAPFAC_V",)), ("hgt", ("HGT", "HGT_M"))):
+            try:
+                g.extra[k] = var(*names)
+            except KeyError:
+                pass
+        if code == PROJ_LC:
+            g.sina, g.cosa = var("SINALPHA"), var("COSALPHA")
+        g.extra.update(ref_lat=att("MOAD_CEN_LAT", att("CEN_LAT")), ref_lon=att("CEN_LON"), pole_lat=att("POLE_LAT", 90.0),
+                       pole_lon=att("POLE_LON", 0.0))
+    return g

@@ -291,3 +291,29 @@ def map_factor(lat_deg, proj_code, truelat1, truelat2):
         return np.sin(c2) / np.sin(colat) * (np.tan(colat / 2.0) / np.tan(c2 / 2.0)) ** n
     c0 = rad * (90.0 - truelat1)
     return np.sin(c0) / np.sin(colat) * (np.tan(colat / 2.0) / np.tan(c0 / 2.0)) ** np.cos(c0)
+
+
+def cell_corners(lat, lon, dx):
+    """get_cell_corners (model_grid.F90:1902-1972), scalar loops in the reference's order of tests: far corner (bearing
+    315 from (i_target, j_target)), extra column (225 from column i_target), extra row (45 from row j_target), all other
+    points 135 from (i, j); d = sqrt(dx**2/2), pi = 3.14159265359, R = 6370000."""
+    import math
+    pi, R = 3.14159265359, 6370000.0
+    nj, ni = lat.shape
+    d = math.sqrt((dx ** 2.0) / 2.0)
+    latc, lonc = np.empty((nj + 1, ni + 1)), np.empty((nj + 1, ni + 1))
+    for j in range(nj + 1):
+        for i in range(ni + 1):
+            if j == nj and i == ni:
+                sj, si, b = nj - 1, ni - 1, 315.0
+            elif i == ni:
+                sj, si, b = j, ni - 1, 225.0
+            elif j == nj:
+                sj, si, b = nj - 1, i, 45.0
+            else:
+                sj, si, b = j, i, 135.0
+            lat1, lon1, brng = lat[sj, si] * (pi / 180.0), lon[sj, si] * (pi / 180.0), b * (pi / 180.0)
+            lat2 = math.asin(math.sin(lat1) * math.cos(d / R) + math.cos(lat1) * math.sin(d / R) * math.cos(brng))
+            lon2 = lon1 + math.atan2(math.sin(brng) * math.sin(d / R) * math.cos(lat1), math.cos(d / R) - math.sin(lat1) * math.sin(lat2))
+            latc[j, i], lonc[j, i] = lat2 * 180.0 / pi, lon2 * 180.0 / pi
+    return latc, lonc

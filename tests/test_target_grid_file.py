@@ -1,0 +1,78 @@
+"""target_grid_type = 'file' (define_target_grid_file, model_grid.F90:1203-1888): grid from a WRF geo_em / wrfinput style
+file, CORNER stagger from get_cell_corners (:1902-1972) with its bearings and constants exactly as written."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def geo_file(tmp_path_factory):
+    from mpassit_amd import build, ncio, target_grid as T
+    build.build_ncio()
+    nml = dict(dx=30000.0, dy=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+    g = T.define_target_grid_params("lambert", 41, 31, **nml)
+    path = tmp_path_factory.mktemp("geo") / "geo_em.d01.nc"
+    with ncio.Writer(path, format=2) as w:
+        for name, n in (("Time", None), ("west_east", g.nx), ("south_north", g.ny), ("west_east_stag", g.nx + 1), ("south_north_stag", g.ny + 1)):
+            w.def_dim(name, n)
+        for k, v in (("DX", np.float32(30000.0)), ("DY", np.float32(30000.0)), ("CEN_LAT", np.float32(38.5)), ("CEN_LON", np.float32(-97.5)),
+                     ("TRUELAT1", np.float32(38.5)), ("TRUELAT2", np.float32(38.5)), ("MOAD_CEN_LAT", np.float32(38.5)),
+                     ("STAND_LON", np.float32(-97.5)), ("POLE_LAT", np.float32(90.0)), ("POLE_LON", np.float32(0.0)), ("MAP_PROJ", 1)):
+            w.put_att(k, v)
+        dims = {"M": ("Time", "south_north", "west_east"), "U": ("Time", "south_north", "west_east_stag"),
+                "V": ("Time", "south_north_stag", "west_east")}
+        data = {"XLAT_M": (g.lat, "M"), "XLONG_M": (g.lon, "M"), "XLAT_U": (g.lat_u, "U"), "XLONG_U": (g.lon_u, "U"),
+                "XLAT_V": (g.lat_v, "V"), "XLONG_V": (g.lon_v, "V"), "SINALPHA": (g.sina, "M"), "COSALPHA": (g.cosa, "M"),
+                "MAPFAC_M": (np.ones_like(g.lat), "M"), "MAPFAC_U": (np.ones_like(g.lat_u), "U"), "MAPFAC_V": (np.ones_like(g.lat_v), "V"),
+                "HGT_M": (np.full_like(g.lat, 123.0), "M")}
+        for name, (_, st) in data.items():
+            w.def_var(name, ncio.FLOAT, dims[st])
+        for name, (a, _) in data.items():
+            w.put(name, a, rec=0)
+    return path, g
+
+
+def test_file_target_grid_and_cell_corners(oracle, geo_file):
+    from mpassit_amd import target_grid as T
+    path, g = geo_file
+    t = T.define_target_grid_file(path)
+    assert (t.nx, t.ny) == (g.nx, g.ny) and t.proj.code == T.PROJ_LC and t.proj.dx == 30000.0 and t.is_regional
+    for a, b in ((t.lat, g.lat), (t.lon, g.lon), (t.lat_u, g.lat_u), (t.lon_v, g.lon_v), (t.cosa, g.cosa), (t.sina, g.sina)):
+        assert a.dtype == np.float64 and np.array_equal(a, b.astype(np.float32).astype(np.float64))     # NF90_FLOAT widened
+    assert t.extra["hgt"][3, 4] == 123.0 and t.extra["ref_lat"] == 38.5
+    latc, lonc = oracle.cell_corners(t.lat, t.lon, 30000.0)
+    assert t.lat_c.shape == (g.ny + 1, g.nx + 1)
+    np.testing.assert_allclose(t.lat_c, latc, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(t.lon_c, lonc, rtol=0, atol=1e-12)
+    # the routine as written: bearing 135 puts the (i, j) "sw" corner south-EAST of mass point (i, j); the extra column
+    # (bearing 225 from the last column) lies south-west of it, i.e. west of the corner before it
+    assert (t.lat_c[:-1, :-1] < t.lat).all() and (t.lon_c[:-1, :-1] > t.lon).all()
+    assert (t.lon_c[:-1, -1] < t.lon[:, -1]).all() and (t.lat_c[-1, :-1] > t.lat[-1]).all()
+    d = 6370000.0 * np.arccos(np.clip(np.sin(np.deg2rad(t.lat)) * np.sin(np.deg2rad(t.lat_c[:-1, :-1])) +
+                                      np.cos(np.deg2rad(t.lat)) * np.cos(np.deg2rad(t.lat_c[:-1, :-1])) *
+                                      np.cos(np.deg2rad(t.lon_c[:-1, :-1] - t.lon)), -1, 1))
+    np.testing.assert_allclose(d, 30000.0 / np.sqrt(2.0), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_regrid_onto_a_file_defined_grid(oracle, gpu_lib, geo_file):
+    from conftest import mesh_xyz
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    path, g = geo_file
+    t = T.define_target_grid_file(path)
+    m = synth.regional_mesh_for_lambert(g.proj, 41, 31, 4000, margin=0.3)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(t)
+    cxyz, vxyz = mesh_xyz(oracle, m)
+    tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    f = synth.analytic_field(m.latCell, m.lonCell, 3)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    idx, w = oracle.bilinear_weights(cxyz, tri, oracle.lonlat_deg_to_xyz(t.lon, t.lat))
+    np.testing.assert_allclose(rh.regrid(f, nlev=3).reshape(3, -1), oracle.apply_fixed(idx, w, f, 3), rtol=1e-11, atol=1e-11)
+    rh.release()
+    # conservative onto the corners the reference would build (overlapping / gapped quads and all)
+    rc = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    rp, col, val = oracle.conserve(m.verticesOnCell, vxyz, t.nx, t.ny, oracle.lonlat_deg_to_xyz(t.lon_c, t.lat_c))
+    snow = synth.snow_field(m.latCell, m.lonCell) + 1.0
+    np.testing.assert_allclose(rc.regrid(snow, nlev=1).reshape(-1), oracle.apply_csr(rp, col, val, snow, 1)[0], rtol=1e-10, atol=1e-12)
+    rc.release()
+    mesh.destroy()
+    grid.destroy()
