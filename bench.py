@@ -254,7 +254,8 @@ def main():
                        "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
                        "unmapped_points_rank0": n_unmapped},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_apply3_cf" if layout == R.LAYOUT_CELL_FAST else "k_apply3_lf",
+                         "traffic": traffic, "kernel": ("k_apply3_cfu_p" if not any(t.startswith("a3_staged=-2") for t in args.tune) else "k_apply3_cf")
+                         if layout == R.LAYOUT_CELL_FAST else "k_apply3_lf / k_apply3_lfu_p (per handle)",
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
                          "device_copy_GBs": copy_gbs},
             "cpu_baseline": cpu,

@@ -121,6 +121,8 @@ static const A3Variant g_a3_variants[] = {
 };
 static inline int a3_tile_rows(const A3Variant &v) { return (v.waves / (64 / v.wx)) * (64 / v.wx) * v.rpt; }
 static int g_a3_variant = 1;  // "a3_variant" knob (tuned on MI355X: profiles/r01_sweep_apply*.txt)
+static int g_a3_staged = 1;   // "a3_staged" knob: -2 lane-gather only, -1 per-handle choice, >= 0 LDS-staged variant (default:
+                              // <64 x 8 points, 4 levels per chunk>, never slower than the lane-gather kernel on C2/C4/C5)
 static int g_fpw = 1;         // "fields_per_wg" knob (0 = all fields in one workgroup pass)
 static int g_tgroup = 1;      // "tile_group" knob: tile rows per band (1 = plain row-major tile order)
 
@@ -320,6 +322,11 @@ int mpg_k_tune(const char *key, int value) {
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "a3_staged")) {
+    if (value < -2 || value >= mpg_cfu_num_variants()) return MPG_ERR_INVALID_ARG;
+    g_a3_staged = value;
+    return MPG_SUCCESS;
+  }
   if (!strcmp(key, "a3_variant")) {
     if (value < 0 || value >= (int)(sizeof(g_a3_variants) / sizeof(g_a3_variants[0]))) return MPG_ERR_INVALID_ARG;
     g_a3_variant = value;
@@ -368,6 +375,14 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
       lv.fn<<<(unsigned)ntx * nty * ngroups, 64 * lv.waves, lds, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
                                                                      nfields, fpw);
     } else {
+      // cell-fast.  g_a3_staged: -2 = lane-gather kernel only, -1 = per-handle choice by the reuse statistic of the tile
+      // lists, >= 0 = that LDS-staged variant (k_apply_lfu.hip)
+      int staged = g_a3_staged;
+      if (staged == -1) {
+        int rc = mpg_cfu_auto(h, s, &staged);
+        if (rc) return rc;
+      }
+      if (staged >= 0) return mpg_k_apply3_cfu(h, staged, src, nlev, nfields, dst, s);
       const A3Variant &av = g_a3_variants[g_a3_variant];
       int tyv = a3_tile_rows(av);
       int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + tyv - 1) / tyv;

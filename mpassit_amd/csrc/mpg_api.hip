@@ -587,6 +587,7 @@ static void lf_invalidate(mpg_handle_s *h) {
   h->lidx.free();
   h->ut_rpt = 0;
   h->lf_choice = 0;
+  h->cf_choice = 0;
 }
 
 // ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------

@@ -189,6 +189,7 @@ struct mpg_handle_s {
   int ut_rpt = 0, ut_max = 0;
   int64_t ut_total = 0;
   int lf_choice = 0;      // level-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 row-gather
+  int cf_choice = 0;      // cell-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 lane-gather
   float lf_reuse = 0.f;   // 3 * n_dst / (sum of the tiles' unique cells): references per staged row
   DevBuf<int32_t> ut_ptr, ut_cells;
   DevBuf<uint16_t> lidx;  // [3][n_dst] positions in the tile's list, 0xFFFF = unmapped
@@ -212,6 +213,9 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
                       double scale, double offset, hipStream_t s);
 int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_lfu_num_variants();
+int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
+int mpg_cfu_num_variants();
+int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant);  // -> variant index or -1 (use k_apply3_cf)
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant);  // -> variant index or -1 (use the row-gather kernel)
 int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
                    double scale, double offset, hipStream_t s);

@@ -7,6 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 LFU = list(range(100, 120))      # 100-105 two-phase, 106-111 software-pipelined, 112-119 compact tiles
+A3_STAGED_DEFAULT = 1            # library default of the "a3_staged" knob
 
 
 def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
@@ -27,8 +28,14 @@ def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
         rh.rebase(0, m.nCells)                               # re-indexing drops the tile lists; they are rebuilt on demand
         got = rh.regrid(src_lf.reshape(-1), nlev=nlev, nfields=nfields, layout=R.LAYOUT_LEV_FAST)
         assert np.array_equal(got, want)
+        # cell-fast staged variants (a3_staged 0..9) and the per-handle choice (-1) against the lane-gather kernel (-2)
+        for v in list(range(10)) + [-1]:
+            gpu_lib.tune("a3_staged", v)
+            got = rh.regrid(src.reshape(-1), nlev=nlev, nfields=nfields)
+            assert np.array_equal(got, want), "a3_staged %d differs" % v
     finally:
         gpu_lib.tune("lf_variant", -1)
+        gpu_lib.tune("a3_staged", A3_STAGED_DEFAULT)
     unmapped = int((rh.weights()[0][:, 0] < 0).sum())
     rh.release()
     mesh.destroy()

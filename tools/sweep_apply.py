@@ -47,7 +47,8 @@ def main():
                 _lib.tune("lf_variant", v)
                 _lib.tune("lf_fields_per_wg", max(1, fp))
             else:
-                _lib.tune("a3_variant", v)
+                _lib.tune("a3_staged", v - 100 if v >= 100 else -2)      # 100.. = LDS-staged cell-fast variants
+                _lib.tune("a3_variant", v if v < 100 else 1)
                 _lib.tune("lev_chunk", c)
                 _lib.tune("fields_per_wg", fp % 1000)
                 _lib.tune("tile_group", max(1, fp // 1000))
