@@ -307,6 +307,8 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
   for (int k = 0; k < nlev; ++k) dst[(int64_t)k * nids + i] = src[(int64_t)k * nsrc + c];
 }
 
+int mpg_a3_staged() { return g_a3_staged; }
+
 int mpg_k_tune(const char *key, int value) {
 
   if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }

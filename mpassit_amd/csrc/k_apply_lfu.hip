@@ -446,6 +446,101 @@ int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
   return MPG_SUCCESS;
 }
 
+// Typed form of the staged cell-fast kernel (mpg_regrid_typed_dev): float32 or float64 source as the MPAS file stores
+// it, float64 arithmetic (wsum3), dst = (TD)(value * scale + offset) -- the writer's T - 300 / PHB * 9.81 / NF90_FLOAT
+// conversion fused in.  Fixed shape <64 x 8 points, 4 levels per chunk, 12 prefetch registers> = the f64 default.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
+                                                              const uint16_t *__restrict__ lidx, const double *__restrict__ w,
+                                                              const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                              int nlev, int ntx, int nty, int nfields, int ut_max, double scale,
+                                                              double offset) {
+  constexpr int TXU = 64, RPT = 2, LC = 4, NPF = 12, UPT = NPF / LC;
+  extern __shared__ double lds[];  // [LC][nup]
+  const int nup = ut_max;
+  const int64_t P = (int64_t)nx * ny;
+  const unsigned ntile = (unsigned)ntx * nty;
+  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tile = lin % ntile;
+  const int f = lin / ntile;
+  const int t = threadIdx.x;
+  const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
+  LfuPoints<TXU, RPT> pts;
+  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, 1);
+  const TS *sf = src + (int64_t)f * nlev * nsrc;
+  TD *df = dst + (int64_t)f * nlev * P;
+  int32_t cell[UPT];
+#pragma unroll
+  for (int u = 0; u < UPT; ++u) {
+    int q = t + LFU_THREADS * u;
+    cell[u] = q < nU ? ut_cells[u0 + q] : -1;
+  }
+  TS pf[NPF];
+#pragma unroll
+  for (int lv = 0; lv < LC; ++lv)
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) pf[lv * UPT + u] = (cell[u] >= 0 && lv < nlev) ? sf[(int64_t)lv * nsrc + cell[u]] : (TS)0;
+  for (int k0 = 0; k0 < nlev; k0 += LC) {
+#pragma unroll
+    for (int lv = 0; lv < LC; ++lv)
+#pragma unroll
+      for (int u = 0; u < UPT; ++u)
+        if (cell[u] >= 0) lds[lv * nup + t + LFU_THREADS * u] = (double)pf[lv * UPT + u];
+    for (int q = t + LFU_THREADS * UPT; q < nU; q += LFU_THREADS) {
+      int32_t c = ut_cells[u0 + q];
+      for (int lv = 0; lv < LC; ++lv) lds[lv * nup + q] = (k0 + lv < nlev) ? (double)sf[(int64_t)(k0 + lv) * nsrc + c] : 0.0;
+    }
+    __syncthreads();
+    const int kn1 = k0 + LC;
+    if (kn1 < nlev) {
+#pragma unroll
+      for (int lv = 0; lv < LC; ++lv)
+#pragma unroll
+        for (int u = 0; u < UPT; ++u)
+          pf[lv * UPT + u] = (cell[u] >= 0 && kn1 + lv < nlev) ? sf[(int64_t)(kn1 + lv) * nsrc + cell[u]] : (TS)0;
+    }
+    const int kn = min(LC, nlev - k0);
+    for (int kk = 0; kk < kn; ++kk) {
+      const double *row = lds + kk * nup;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        double a = row[pts.l[r][0]], b = row[pts.l[r][1]], e = row[pts.l[r][2]];
+        double val = pts.mapped[r] ? wsum3(pts.ww[r][0], a, pts.ww[r][1], b, pts.ww[r][2], e) : 0.0;
+        if (pts.act[r]) __builtin_nontemporal_store((TD)fma(val, scale, offset), df + (int64_t)(k0 + kk) * P + pts.off[r]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TS, typename TD>
+static int launch_cfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
+  const int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 7) / 8;
+  const size_t um = h->ut_max > 0 ? h->ut_max : 1;
+  size_t lds = sizeof(double) * um * 4 + 16;
+  if (lds > 160 * 1024) {
+    mpg_set_error("Regrid(CELL_FAST, staged): %d unique cells per tile exceed the LDS", h->ut_max);
+    return MPG_ERR_UNSUPPORTED;
+  }
+  if (lds > 48 * 1024)
+    MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_cfu_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_apply3_cfu_t<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
+                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
+                                                                                nfields, (int)um, scale, offset);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
+                           double offset, hipStream_t s) {
+  int rc = lfu_build(h, 64, 2, s);
+  if (rc) return rc;
+  if (src_f32 && dst_f32) return launch_cfu_t<float, float>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (src_f32) return launch_cfu_t<float, double>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (dst_f32) return launch_cfu_t<double, float>(h, src, nlev, nfields, dst, scale, offset, s);
+  return launch_cfu_t<double, double>(h, src, nlev, nfields, dst, scale, offset, s);
+}
+
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
   const LfuVariant &v = g_cfu_variants[variant];
   int rc = lfu_build(h, v.txu, v.rpt, s);

@@ -215,6 +215,9 @@ int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
 int mpg_lfu_num_variants();
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_cfu_num_variants();
+int mpg_a3_staged();  // current "a3_staged" knob
+int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
+                           double offset, hipStream_t s);
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant);  // -> variant index or -1 (use k_apply3_cf)
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant);  // -> variant index or -1 (use the row-gather kernel)
 int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
