@@ -7,10 +7,13 @@
 // (i,j) (model_grid.F90:784-794,959-984).  Uncovered destination cells stay 0.
 //
 // MI355X-native formulation: source polygons are rasterised onto the destination cells through an
-// AABB pyramid over the CORNER points (same machinery as the bilinear rasteriser).  Pass 1 counts the
-// overlaps per destination cell, a rocPRIM scan turns counts into CSR row offsets, pass 2 recomputes
-// and fills, pass 3 sorts every (short) row by source id so the stored matrix and the summation order
-// are deterministic.  Clipping = Sutherland-Hodgman against the 4 great-circle half-spaces.
+// AABB pyramid over the CORNER points (same machinery as the bilinear rasteriser).  ONE clipping pass: every
+// source cell writes its overlaps to a private 16-slot list and bumps the destination cells' counters; a
+// rocPRIM scan turns the counters into CSR row offsets, a scatter pass moves the lists into place (source
+// cells with more than 16 overlaps -- polar cells under lat-lon slivers -- are clipped again, writing in
+// place), and every (short) row is sorted by source id so the stored matrix and the summation order are
+// deterministic.  Destination cell areas are computed once per Store, not per overlap.
+// Clipping = Sutherland-Hodgman against the 4 great-circle half-spaces.
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -21,6 +24,7 @@
 #define CONS_MAXV 12   // max source polygon vertices handled (MPAS maxEdges is 6..10)
 #define CONS_BUF (CONS_MAXV + 6)
 #define CONS_STACK 64
+#define CONS_QUEUE 2048  // breadth-first node queue of the cooperative passes
 
 __device__ int clip_halfspace(int n, const dv3 *in, dv3 nrm, dv3 *out) {
   int m = 0;
@@ -59,17 +63,28 @@ __device__ double clip_area(int ns, const dv3 *src, const dv3 *quad) {
   return s > 0.0 ? s : 0.0;
 }
 
-// FILL = false: count[p]++ ; FILL = true: write (col, val) at rowptr[p] + cursor[p]++
-template <bool FILL>
+// One clipping pass.  MODE 0 ("pairs"): every overlap (dst cell, area ratio) of source cell c goes to the cell's private
+// slot list tmp_dst/tmp_val[c*CONS_CAP ..] (cnt_src[c] counts ALL overlaps, also those beyond the capacity) and count[p]
+// is bumped; a rocPRIM scan turns count into CSR row offsets and k_conserve_scatter moves the lists into place.
+// MODE 1 ("overflow fill"): only the source cells whose overlaps did not fit (cnt_src[c] > CONS_CAP: e.g. a polar cell
+// under thousands of lat-lon slivers) are clipped a second time and write straight to rowptr[p] + cursor[p]++.
+#define CONS_CAP 16
+template <int MODE>
 __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
                                                          const double *__restrict__ vx, const double *__restrict__ vy,
                                                          const double *__restrict__ vz, PyramidView pyr, int nx, int ny,
                                                          const double *__restrict__ qx, const double *__restrict__ qy,
-                                                         const double *__restrict__ qz, int32_t *__restrict__ count,
-                                                         const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
-                                                         double *__restrict__ val) {
-  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+                                                         const double *__restrict__ qz, const double *__restrict__ qarea,
+                                                         int32_t *__restrict__ count, const int32_t *__restrict__ rowptr,
+                                                         int32_t *__restrict__ col, double *__restrict__ val,
+                                                         int32_t *__restrict__ cnt_src, int32_t *__restrict__ tmp_dst,
+                                                         double *__restrict__ tmp_val, int32_t *__restrict__ ovf,
+                                                         int32_t *__restrict__ n_ovf) {
+  // MODE 0: one thread per source cell.  MODE 1: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]); its threads
+  // share the cell's subtrees of the pyramid, so a polar cell under thousands of slivers is clipped by 128 lanes at once.
+  int64_t c = MODE != 0 ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
+  int found = 0;
   dv3 poly[CONS_MAXV];
   int n = 0;
   for (int j = 0; j < maxEdges && n < CONS_MAXV; ++j) {
@@ -98,8 +113,43 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
 
   int nxc = nx + 1;
   int stack[CONS_STACK];
+  // Seeds of the depth-first walk.  MODE 0: the root.  Cooperative modes: the workgroup first expands the pyramid
+  // breadth-first in LDS (one node per thread and level) down to 8 x 8-cell nodes, then every thread walks its share.
+  __shared__ int q_nodes[2][CONS_QUEUE];
+  __shared__ int q_n[2], q_over;
+  int seed_lev = pyr.nlev - 1, nseed = 1, cur = 0;
+  if (MODE != 0) {
+    if (threadIdx.x == 0) { q_nodes[0][0] = 0; q_n[0] = 1; q_over = 0; }
+    __syncthreads();
+    while (seed_lev > 1) {
+      const int nq = q_n[cur];
+      if (threadIdx.x == 0) q_n[cur ^ 1] = 0;
+      __syncthreads();
+      const int cnx = pyr.nx[seed_lev - 1], cny = pyr.ny[seed_lev - 1], pnx = pyr.nx[seed_lev];
+      for (int k = threadIdx.x; k < nq; k += blockDim.x) {
+        int node = q_nodes[cur][k], bi = node % pnx, bj = node / pnx;
+        for (int ch = 0; ch < 4; ++ch) {
+          int ci = 2 * bi + (ch & 1), cj = 2 * bj + (ch >> 1);
+          if (ci >= cnx || cj >= cny) continue;
+          const double *bx = pyr.box + 6 * (pyr.off[seed_lev - 1] + cj * cnx + ci);
+          if (bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]) continue;
+          int slot = atomicAdd(&q_n[cur ^ 1], 1);
+          if (slot < CONS_QUEUE) q_nodes[cur ^ 1][slot] = cj * cnx + ci;
+          else q_over = 1;
+        }
+      }
+      __syncthreads();
+      if (q_over) break;       // next level does not fit the queue: walk from the current one (correct, less parallel)
+      cur ^= 1;
+      --seed_lev;
+      __syncthreads();
+    }
+    nseed = q_n[cur];
+  }
+  for (int sk = MODE != 0 ? (int)threadIdx.x : 0; sk < nseed; sk += MODE != 0 ? (int)blockDim.x : 1) {
+  const int seed = MODE != 0 ? q_nodes[cur][sk] : 0;
   int sp = 0;
-  stack[sp++] = (pyr.nlev - 1) << 26;
+  stack[sp++] = (seed_lev << 26) | seed;
   while (sp > 0) {
     int e = stack[--sp];
     int lev = e >> 26, node = e & ((1 << 26) - 1);
@@ -127,14 +177,25 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
           }
           double qp = 2.0 * qe2 + 1e-9;
           if (ql[0] - qp > hi[0] || qh[0] + qp < lo[0] || ql[1] - qp > hi[1] || qh[1] + qp < lo[1] || ql[2] - qp > hi[2] || qh[2] + qp < lo[2]) continue;
-          double aq = sph_tri_area(q[0], q[1], q[2]) + sph_tri_area(q[0], q[2], q[3]);
+          int64_t p = (int64_t)j * nx + i;
+          double aq = qarea[p];   // signed area of the destination quad, computed once per grid (k_cell_areas)
           if (aq < 0.0) { dv3 t = q[1]; q[1] = q[3]; q[3] = t; aq = -aq; }
           if (!(aq > 0.0)) continue;
           double ar = clip_area(n, poly, q);
           if (ar > 1e-14 * aq) {
-            int64_t p = (int64_t)j * nx + i;
-            int slot = atomicAdd(&count[p], 1);
-            if (FILL) {
+            if (MODE == 0) {
+              if (found == CONS_CAP) {  // does not fit: hand the whole cell to the cooperative passes and stop here
+                cnt_src[c] = CONS_CAP + 1;
+                ovf[atomicAdd(n_ovf, 1)] = (int32_t)c;
+                return;
+              }
+              tmp_dst[c * CONS_CAP + found] = (int32_t)p;
+              tmp_val[c * CONS_CAP + found] = ar / aq;
+              ++found;
+            } else if (MODE == 2) {
+              atomicAdd(&count[p], 1);
+            } else {
+              int slot = atomicAdd(&count[p], 1);
               col[rowptr[p] + slot] = (int32_t)c;
               val[rowptr[p] + slot] = ar / aq;
             }
@@ -150,6 +211,47 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
           if (ci < cnx && cj < cny && sp < CONS_STACK) stack[sp++] = ((lev - 1) << 26) | (cj * cnx + ci);
         }
     }
+  }
+  }
+  if (MODE == 0) cnt_src[c] = found;
+}
+
+// signed area of every destination cell (corner order i,j -> i+1,j -> i+1,j+1 -> i,j+1), once per grid
+__global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double *__restrict__ qx, const double *__restrict__ qy,
+                                                    const double *__restrict__ qz, double *__restrict__ qarea) {
+  int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= (int64_t)nx * ny) return;
+  int i = (int)(p % nx), j = (int)(p / nx), nxc = nx + 1;
+  int64_t k00 = (int64_t)j * nxc + i;
+  dv3 q0 = dv3{qx[k00], qy[k00], qz[k00]}, q1 = dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
+      q2 = dv3{qx[k00 + nxc + 1], qy[k00 + nxc + 1], qz[k00 + nxc + 1]}, q3 = dv3{qx[k00 + nxc], qy[k00 + nxc], qz[k00 + nxc]};
+  qarea[p] = sph_tri_area(q0, q1, q2) + sph_tri_area(q0, q2, q3);
+}
+
+// row lengths from the private lists (source cells that fitted)
+__global__ __launch_bounds__(256) void k_conserve_count_lists(int64_t nCells, const int32_t *__restrict__ cnt_src,
+                                                              const int32_t *__restrict__ tmp_dst, int32_t *__restrict__ count) {
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nCells) return;
+  int n = cnt_src[c];
+  if (n > CONS_CAP) return;
+  for (int e = 0; e < n; ++e) atomicAdd(&count[tmp_dst[c * CONS_CAP + e]], 1);
+}
+
+// the private lists of the source cells that fitted -> CSR slots (cursor = the zeroed count array)
+__global__ __launch_bounds__(256) void k_conserve_scatter(int64_t nCells, const int32_t *__restrict__ cnt_src,
+                                                          const int32_t *__restrict__ tmp_dst, const double *__restrict__ tmp_val,
+                                                          const int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor,
+                                                          int32_t *__restrict__ col, double *__restrict__ val) {
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nCells) return;
+  int n = cnt_src[c];
+  if (n > CONS_CAP) return;  // handled by the overflow fill pass
+  for (int e = 0; e < n; ++e) {
+    int32_t p = tmp_dst[c * CONS_CAP + e];
+    int slot = atomicAdd(&cursor[p], 1);
+    col[rowptr[p] + slot] = (int32_t)c;
+    val[rowptr[p] + slot] = tmp_val[c * CONS_CAP + e];
   }
 }
 
@@ -192,13 +294,30 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   h->n_dst = P;
   h->nx_dst = nx;
   h->ny_dst = ny;
-  TmpBuf<int32_t> count;
-  if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1))) return rc;
+  TmpBuf<int32_t> count, cnt_src, tmp_dst, ovf, n_ovf;
+  TmpBuf<double> tmp_val, qarea;
+  if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P)) ||
+      (rc = cnt_src.alloc((size_t)m->nCells)) || (rc = tmp_dst.alloc((size_t)m->nCells * CONS_CAP)) ||
+      (rc = tmp_val.alloc((size_t)m->nCells * CONS_CAP)) || (rc = ovf.alloc((size_t)m->nCells)) || (rc = n_ovf.alloc(1)))
+    return rc;
+  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, sizeof(int32_t), s));
+  MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)m->nCells, s));  // degenerate cells leave early
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
   unsigned nb = (unsigned)((m->nCells + 127) / 128);
   PyramidView pv = mpg_pyr_view(g->cellpyr);
-  k_conserve_raster<false><<<nb, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                            cor.x.p, cor.y.p, cor.z.p, count.p, nullptr, nullptr, nullptr);
+  k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p);
+  k_conserve_raster<0><<<nb, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
+                                        cor.y.p, cor.z.p, qarea.p, count.p, nullptr, nullptr, nullptr, cnt_src.p, tmp_dst.p, tmp_val.p, ovf.p,
+                                        n_ovf.p);
+  MPG_HIP(hipGetLastError());
+  int32_t novf = 0;
+  MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  k_conserve_count_lists<<<(unsigned)((m->nCells + 255) / 256), 256, 0, s>>>(m->nCells, cnt_src.p, tmp_dst.p, count.p);
+  MPG_HIP(hipStreamSynchronize(s));
+  if (novf > 0)  // MODE 2: cooperative count of the overflowed cells
+    k_conserve_raster<2><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
+                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, count.p, nullptr, nullptr, nullptr, cnt_src.p,
+                                                       nullptr, nullptr, ovf.p, nullptr);
   MPG_HIP(hipGetLastError());
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
@@ -215,12 +334,15 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   h->nnz = nnz;
   if ((rc = h->col.alloc((size_t)nnz + 1)) || (rc = h->val.alloc((size_t)nnz + 1))) return rc;
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
-  k_conserve_raster<true><<<nb, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                           cor.x.p, cor.y.p, cor.z.p, count.p, h->rowptr.p, h->col.p, h->val.p);
+  k_conserve_scatter<<<(unsigned)((m->nCells + 255) / 256), 256, 0, s>>>(m->nCells, cnt_src.p, tmp_dst.p, tmp_val.p, h->rowptr.p, count.p, h->col.p,
+                                                                        h->val.p);
+  // the few source cells with more than CONS_CAP overlaps are clipped again, one workgroup each, writing in place
+  if (novf > 0)
+    k_conserve_raster<1><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
+                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, count.p, h->rowptr.p, h->col.p, h->val.p,
+                                                       cnt_src.p, nullptr, nullptr, ovf.p, nullptr);
   k_csr_sort_rows<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, h->rowptr.p, h->col.p, h->val.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
-  count.free();
-  tmp.free();
   return MPG_SUCCESS;
 }
