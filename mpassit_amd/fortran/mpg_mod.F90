@@ -21,6 +21,16 @@ module mpg
   integer(c_int), parameter :: MPG_STAGGERLOC_CENTER = 0, MPG_STAGGERLOC_EDGE1 = 1, MPG_STAGGERLOC_EDGE2 = 2, &
                                MPG_STAGGERLOC_CORNER = 3
   integer(c_int), parameter :: MPG_LAYOUT_CELL_FAST = 0, MPG_LAYOUT_LEV_FAST = 1
+  integer(c_int), parameter :: MPG_GRID_PERIODIC_I = 1, MPG_GRID_NO_SOUTH_POLE = 2, MPG_GRID_NO_NORTH_POLE = 4
+  integer(c_int), parameter :: MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1
+  !> struct mpg_proj (include/mpassit_amd.h): the arguments of push_source_projection (model_grid.F90:676-678)
+  type, bind(C) :: mpg_proj
+    integer(c_int) :: code
+    real(c_double) :: known_lat, known_lon, known_x, known_y
+    real(c_double) :: dx_m
+    real(c_double) :: stand_lon, truelat1, truelat2
+    real(c_double) :: dlat_deg, dlon_deg
+  end type mpg_proj
 
   interface
     function mpg_init(device) bind(C, name="mpg_init") result(rc)
@@ -121,6 +131,38 @@ module mpg
       integer(c_int), intent(out) :: nx_dst, ny_dst, nnz_per_row
       integer(c_int) :: rc
     end function mpg_handle_info
+
+    !> Target grid straight from the projection (define_target_grid_params' host loops on the GPU, model_grid.F90:736-1038).
+    function mpg_grid_create_proj(proj, nx, ny, periodic_i, grid) bind(C, name="mpg_grid_create_proj") result(rc)
+      import :: c_int, c_ptr, mpg_proj
+      type(mpg_proj), intent(in) :: proj
+      integer(c_int), value :: nx, ny, periodic_i
+      type(c_ptr), intent(out) :: grid
+      integer(c_int) :: rc
+    end function mpg_grid_create_proj
+
+    function mpg_grid_get_coords(grid, staggerloc, lon, lat) bind(C, name="mpg_grid_get_coords") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: grid
+      integer(c_int), value :: staggerloc
+      real(c_double), intent(out) :: lon(*), lat(*)
+      integer(c_int) :: rc
+    end function mpg_grid_get_coords
+
+    function mpg_grid_get_rotang(grid, cosa, sina) bind(C, name="mpg_grid_get_rotang") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: grid
+      real(c_double), intent(out) :: cosa(*), sina(*)
+      integer(c_int) :: rc
+    end function mpg_grid_get_rotang
+
+    function mpg_grid_get_mapfac(grid, staggerloc, mapfac) bind(C, name="mpg_grid_get_mapfac") result(rc)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: grid
+      integer(c_int), value :: staggerloc
+      real(c_double), intent(out) :: mapfac(*)
+      integer(c_int) :: rc
+    end function mpg_grid_get_mapfac
   end interface
 
 contains
