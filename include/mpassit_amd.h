@@ -135,6 +135,13 @@ int mpg_regrid_dev(mpg_handle rh, const double *src_dev, int src_layout, int nle
  * src_f32 / dst_f32: 0 = float64, 1 = float32.  Device pointers, stream as in mpg_regrid_dev. */
 int mpg_regrid_typed_dev(mpg_handle rh, const void *src_dev, int src_f32, int src_layout, int nlev, int nfields,
                          void *dst_dev, int dst_f32, double scale, double offset, void *hip_stream);
+/* The same on HOST buffers (pageable memory: Fortran allocatables, numpy arrays), for hosts that keep the reference's
+ * file -> host array -> regrid -> host array -> file shape and are therefore bound by the PCIe link: float32 sources
+ * and results cross the link as they are stored in the files (half the bytes of the float64 route), and the field is cut
+ * into chunks whose upload, kernel and download overlap (full duplex, a helper thread downloads while the caller
+ * uploads).  Blocks until dst_host is complete. */
+int mpg_regrid_typed(mpg_handle rh, const void *src_host, int src_f32, int src_layout, int nlev, int nfields,
+                     void *dst_host, int dst_f32, double scale, double offset);
 /* ESMF_FieldBundleRegridRelease (interp.F90:450,455,461) */
 int mpg_handle_release(mpg_handle rh);
 

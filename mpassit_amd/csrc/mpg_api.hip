@@ -21,6 +21,7 @@ void mpg_set_error(const char *fmt, ...) {
 }
 bool mpg_is_initialized() { return g_init; }
 hipStream_t mpg_setup_stream() { return g_stream; }
+int mpg_device_index() { return g_device; }
 
 extern "C" {
 
@@ -384,22 +385,9 @@ int mpg_regrid(mpg_handle h, const double *src_host, int src_layout, int nlev, i
   MPG_CHECK_INIT();
   MPG_ARG(h && src_host && dst_host, "mpg_regrid: NULL argument");
   MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid: nlev and nfields must be >= 1");
-  size_t ns = (size_t)h->n_src * nlev * nfields, nd = (size_t)h->n_dst * nlev * nfields;
-  TmpBuf<double> s, d;
-  int rc;
-  if ((rc = s.alloc(ns)) || (rc = d.alloc(nd))) {
-    s.free();
-    return rc;
-  }
-  MPG_HIP(hipMemcpyAsync(s.p, src_host, sizeof(double) * ns, hipMemcpyHostToDevice, g_stream));
-  rc = mpg_regrid_dev(h, s.p, src_layout, nlev, nfields, d.p, g_stream);
-  if (!rc) {
-    MPG_HIP(hipMemcpyAsync(dst_host, d.p, sizeof(double) * nd, hipMemcpyDeviceToHost, g_stream));
-    MPG_HIP(hipStreamSynchronize(g_stream));
-  }
-  s.free();
-  d.free();
-  return rc;
+  // float64 in, float64 out through the chunked upload / kernel / download pipeline (mpg_hostpipe.hip); same kernels and
+  // the same bits as mpg_regrid_dev
+  return mpg_regrid_typed(h, src_host, 0, src_layout, nlev, nfields, dst_host, 0, 1.0, 0.0);
 }
 
 int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const double *sina_dev, double *u_dev, double *v_dev,

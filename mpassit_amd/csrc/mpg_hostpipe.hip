@@ -1,0 +1,111 @@
+// mpg_regrid_typed: the host-pointer Regrid with fused ingest / egress, pipelined over PCIe.
+//
+// The reference's data path per field is file -> host array -> (ESMF) -> host array -> file.  A host that keeps that
+// shape (the Fortran driver, io_nc.py) is bound by the PCIe link, not by the kernel (C4: 1.32 GB up + 0.84 GB down per
+// float64 field at ~55 GB/s = 39 ms, against 0.37 ms of kernel time).  Two levers, both here:
+//   * element types: float32 sources as the MPAS file stores them and float32 results as the output file stores them
+//     cross the link (half the bytes); the arithmetic stays float64 on the device (mpg_regrid_typed_dev semantics,
+//     including the writer's scale / offset epilogue);
+//   * full duplex: the field is cut into chunks of levels (cell-fast) or fields; the calling thread uploads chunk c+1
+//     and launches its kernel while a helper thread downloads chunk c-1, three device slots in flight, so upload and
+//     download overlap instead of alternating.
+// Caller buffers are ordinary pageable memory (Fortran allocatables, numpy arrays); hipMemcpy stages them itself.
+// (Page-locking them for the call with hipHostRegister was measured: +5 % at best, not worth touching caller memory.)
+#include <atomic>
+#include <thread>
+
+#include "mpg_internal.h"
+
+namespace {
+struct Chunk {
+  size_t src_off, src_n, dst_off, dst_n;  // elements
+  int nlev, nfields;
+};
+constexpr int NSLOT = 3;
+}  // namespace
+
+int mpg_device_index();  // mpg_api.hip
+
+extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32, int src_layout, int nlev, int nfields, void *dst_host,
+                                int dst_f32, double scale, double offset) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && dst_host && (src_host || h->n_src == 0), "mpg_regrid_typed: NULL argument");
+  MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid_typed: nlev and nfields must be >= 1");
+  MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid_typed: bad src_layout");
+  MPG_ARG((src_f32 == 0 || src_f32 == 1) && (dst_f32 == 0 || dst_f32 == 1), "mpg_regrid_typed: src_f32/dst_f32 must be 0 or 1");
+  const size_t es = src_f32 ? 4 : 8, ed = dst_f32 ? 4 : 8;
+  const size_t ns = (size_t)h->n_src, P = (size_t)h->n_dst;
+  // chunk plan: ~96 MB of source per chunk
+  std::vector<Chunk> plan;
+  if (src_layout == MPG_LAYOUT_CELL_FAST) {
+    int lch = ns ? (int)((96u << 20) / (ns * es)) : nlev;
+    lch = lch < 1 ? 1 : (lch > nlev ? nlev : lch);
+    for (int f = 0; f < nfields; ++f)
+      for (int l0 = 0; l0 < nlev; l0 += lch) {
+        int l1 = l0 + lch < nlev ? l0 + lch : nlev;
+        plan.push_back({((size_t)f * nlev + l0) * ns, (size_t)(l1 - l0) * ns, ((size_t)f * nlev + l0) * P, (size_t)(l1 - l0) * P, l1 - l0, 1});
+      }
+  } else {
+    for (int f = 0; f < nfields; ++f) plan.push_back({(size_t)f * nlev * ns, (size_t)nlev * ns, (size_t)f * nlev * P, (size_t)nlev * P, nlev, 1});
+  }
+  size_t max_s = 0, max_d = 0;
+  for (const Chunk &c : plan) {
+    max_s = c.src_n > max_s ? c.src_n : max_s;
+    max_d = c.dst_n > max_d ? c.dst_n : max_d;
+  }
+  const int nslot = (int)plan.size() < NSLOT ? (int)plan.size() : NSLOT;
+  TmpBuf<char> dsrc[NSLOT], ddst[NSLOT];
+  int rc;
+  for (int q = 0; q < nslot; ++q)
+    if ((rc = dsrc[q].alloc(max_s * es + 16)) || (rc = ddst[q].alloc(max_d * ed + 16))) return rc;
+  hipStream_t s_up, s_k;
+  MPG_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+  MPG_HIP(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+  std::vector<hipEvent_t> up(plan.size()), done(plan.size());
+  for (size_t c = 0; c < plan.size(); ++c) {
+    MPG_HIP(hipEventCreateWithFlags(&up[c], hipEventDisableTiming));
+    MPG_HIP(hipEventCreateWithFlags(&done[c], hipEventDisableTiming));
+  }
+  std::atomic<int> produced{0}, consumed{0}, err{0};
+  const int dev = mpg_device_index();
+  std::thread down([&]() {
+    if (hipSetDevice(dev) != hipSuccess) { err = MPG_ERR_HIP; return; }
+    for (size_t c = 0; c < plan.size(); ++c) {
+      while (produced.load(std::memory_order_acquire) <= (int)c) {
+        if (err.load()) return;
+        std::this_thread::yield();
+      }
+      if (hipEventSynchronize(done[c]) != hipSuccess ||
+          hipMemcpy((char *)dst_host + plan[c].dst_off * ed, ddst[c % nslot].p, plan[c].dst_n * ed, hipMemcpyDeviceToHost) != hipSuccess) {
+        err = MPG_ERR_HIP;
+        return;
+      }
+      consumed.store((int)c + 1, std::memory_order_release);
+    }
+  });
+  rc = MPG_SUCCESS;
+  for (size_t c = 0; c < plan.size() && !rc && !err.load(); ++c) {
+    const int q = (int)(c % nslot);
+    while ((int)c >= nslot && consumed.load(std::memory_order_acquire) <= (int)c - nslot && !err.load()) std::this_thread::yield();
+    if (plan[c].src_n &&
+        hipMemcpyAsync(dsrc[q].p, (const char *)src_host + plan[c].src_off * es, plan[c].src_n * es, hipMemcpyHostToDevice, s_up) != hipSuccess)
+      rc = MPG_ERR_HIP;
+    if (!rc && (hipEventRecord(up[c], s_up) != hipSuccess || hipStreamWaitEvent(s_k, up[c], 0) != hipSuccess)) rc = MPG_ERR_HIP;
+    if (!rc) rc = mpg_k_apply_typed(h, dsrc[q].p, src_f32, src_layout, plan[c].nlev, plan[c].nfields, ddst[q].p, dst_f32, scale, offset, s_k);
+    if (!rc && hipEventRecord(done[c], s_k) != hipSuccess) rc = MPG_ERR_HIP;
+    if (!rc) produced.store((int)c + 1, std::memory_order_release);
+  }
+  if (rc) err = rc;
+  down.join();
+  if (!rc && err.load()) rc = err.load();
+  (void)hipStreamSynchronize(s_k);
+  (void)hipStreamSynchronize(s_up);
+  for (size_t c = 0; c < plan.size(); ++c) {
+    (void)hipEventDestroy(up[c]);
+    (void)hipEventDestroy(done[c]);
+  }
+  (void)hipStreamDestroy(s_up);
+  (void)hipStreamDestroy(s_k);
+  if (rc == MPG_ERR_HIP) mpg_set_error("mpg_regrid_typed: a HIP call of the transfer pipeline failed: %s", hipGetErrorString(hipGetLastError()));
+  return rc;
+}

@@ -212,6 +212,22 @@ class RouteHandle:
                                             C.c_int(int(out.dtype == torch.float32)), C.c_double(scale), C.c_double(offset), _stream_ptr()))
         return out
 
+    def regrid_typed_host(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offset=0.0, out=None):
+        """The same on numpy arrays (mpg_regrid_typed): float32 / float64 host buffers cross PCIe as they are, chunks of
+        levels are uploaded, regridded and downloaded concurrently.  Returns [nfields][nlev][ny][nx] of out_dtype."""
+        src = np.ascontiguousarray(src)
+        if src.dtype not in (np.float32, np.float64):
+            src = src.astype(np.float64)
+        if src.size != nfields * nlev * self.n_src:
+            raise ValueError("source has %d elements, handle expects %d" % (src.size, nfields * nlev * self.n_src))
+        out_dtype = np.dtype(out_dtype or src.dtype)
+        if out is None:
+            out = np.empty((nfields, nlev, self.ny_dst, self.nx_dst), out_dtype)
+        check(L.load().mpg_regrid_typed(self._h, src.ctypes.data_as(C.c_void_p), C.c_int(int(src.dtype == np.float32)), C.c_int(layout),
+                                        C.c_int(nlev), C.c_int(nfields), out.ctypes.data_as(C.c_void_p),
+                                        C.c_int(int(out.dtype == np.float32)), C.c_double(scale), C.c_double(offset)))
+        return out
+
     @classmethod
     def from_weights(cls, n_src, nx_dst, ny_dst, row, col, S):
         """Route handle from externally computed weights in ESMF's factorList / factorIndexList form (1-based
