@@ -20,7 +20,7 @@
 #include "mpg_internal.h"
 
 #define LFU_THREADS 256
-#define LFU_SORT 2048   // sort buffer: 3 ids x (at most) 512 points, padded to a power of two
+#define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two
 
 __device__ __forceinline__ unsigned lfu_xcd_remap(unsigned lin, unsigned n) {
   unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
@@ -335,6 +335,8 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     {64, 1, 4, k_apply3_cfu_p<64, 1, 4, 4>},   {64, 1, 8, k_apply3_cfu_p<64, 1, 8, 8>},   {64, 1, 8, k_apply3_cfu_p<64, 1, 8, 16>},
     {32, 2, 4, k_apply3_cfu_p<32, 2, 4, 8>},   {32, 1, 8, k_apply3_cfu_p<32, 1, 8, 8>},   {64, 2, 2, k_apply3_cfu_p<64, 2, 2, 4>},
     {64, 2, 16, k_apply3_cfu_p<64, 2, 16, 32>},
+    // 10-12: 64 x 16-point tiles (smaller one-cell ring per point, more registers)
+    {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16>},  {64, 4, 2, k_apply3_cfu_p<64, 4, 2, 8>},   {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 20>},
 };
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 static const LfuVariant g_lfu_variants[] = {
