@@ -384,6 +384,11 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
         int rc = mpg_cfu_auto(h, s, &staged);
         if (rc) return rc;
       }
+      else if (staged >= 0) {
+        int fits, rc = mpg_cfu_fits(h, staged, s, &fits);
+        if (rc) return rc;
+        if (!fits) staged = -2;  // hardly any cell shared inside a tile: the lane-gather kernel serves this handle
+      }
       if (staged >= 0) return mpg_k_apply3_cfu(h, staged, src, nlev, nfields, dst, s);
       const A3Variant &av = g_a3_variants[g_a3_variant];
       int tyv = a3_tile_rows(av);

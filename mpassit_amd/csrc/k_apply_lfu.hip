@@ -339,6 +339,9 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16>},  {64, 4, 2, k_apply3_cfu_p<64, 4, 2, 8>},   {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 20>},
 };
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
+// unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
+static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20};
+static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * LFU_THREADS; }
 static const LfuVariant g_lfu_variants[] = {
     // 0-5: two-phase, 64-wide tiles
     {64, 1, 8, k_apply3_lfu<64, 1, 8>},   {64, 1, 16, k_apply3_lfu<64, 1, 16>}, {64, 2, 8, k_apply3_lfu<64, 2, 8>},
@@ -432,11 +435,12 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
 static int g_cfu_auto_variant = 0;
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
   const LfuVariant &v = g_cfu_variants[g_cfu_auto_variant];
-  if (h->cf_choice == 0) {
+  if (h->cf_choice == 0 || h->cf_for != -1) {
+    h->cf_for = -1;
     int rc = lfu_build(h, v.txu, v.rpt, s);
     if (rc) return rc;
     float reuse = h->ut_total > 0 ? 3.0f * (float)h->n_dst / (float)h->ut_total : 0.f;
-    h->cf_choice = reuse >= LFU_AUTO_MIN_REUSE ? 1 : -1;
+    h->cf_choice = (reuse >= LFU_AUTO_MIN_REUSE && h->ut_max <= cfu_capacity(g_cfu_auto_variant)) ? 1 : -1;
     if (h->cf_choice < 0 && h->lf_choice <= 0) {
       h->ut_ptr.free();
       h->ut_cells.free();
@@ -537,10 +541,32 @@ int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nl
                            double offset, hipStream_t s) {
   int rc = lfu_build(h, 64, 2, s);
   if (rc) return rc;
+  if (h->ut_max > 768) return MPG_ERR_UNSUPPORTED;  // caller falls back to the lane-gather typed kernel
   if (src_f32 && dst_f32) return launch_cfu_t<float, float>(h, src, nlev, nfields, dst, scale, offset, s);
   if (src_f32) return launch_cfu_t<float, double>(h, src, nlev, nfields, dst, scale, offset, s);
   if (dst_f32) return launch_cfu_t<double, float>(h, src, nlev, nfields, dst, scale, offset, s);
   return launch_cfu_t<double, double>(h, src, nlev, nfields, dst, scale, offset, s);
+}
+
+// Does the explicit staged variant suit this handle?  Tiles whose points share almost no cells (a fine mesh under a coarse
+// grid: up to 3 cells per point) overflow the register-resident part of the list; the lane-gather kernel is the right tool
+// there.  The decision is cached in the handle (cf_choice) so the lists are built once.
+int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits) {
+  if (h->cf_choice == 0 || h->cf_for != variant) {
+    h->cf_for = variant;
+    const LfuVariant &v = g_cfu_variants[variant];
+    int rc = lfu_build(h, v.txu, v.rpt, s);
+    if (rc) return rc;
+    h->cf_choice = h->ut_max <= cfu_capacity(variant) ? 1 : -1;
+    if (h->cf_choice < 0 && h->lf_choice <= 0) {
+      h->ut_ptr.free();
+      h->ut_cells.free();
+      h->lidx.free();
+      h->ut_rpt = 0;
+    }
+  }
+  *fits = h->cf_choice > 0;
+  return MPG_SUCCESS;
 }
 
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {

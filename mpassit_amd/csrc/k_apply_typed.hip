@@ -201,8 +201,12 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
     MPG_HIP(hipMemsetAsync(dst, 0, (dst_f32 ? 4 : 8) * (size_t)h->n_dst * nlev * nfields, s));
     return MPG_SUCCESS;
   }
-  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_CELL_FAST && mpg_a3_staged() != -2)
-    return mpg_k_apply3_cfu_typed(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);  // LDS-staged (k_apply_lfu.hip)
+  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_CELL_FAST && mpg_a3_staged() != -2 && !(h->cf_choice < 0 && h->cf_for == 1)) {
+    int rc = mpg_k_apply3_cfu_typed(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);  // LDS-staged (k_apply_lfu.hip)
+    if (rc != MPG_ERR_UNSUPPORTED) return rc;
+    h->cf_choice = -1;  // tile lists too long for the staged kernel: lane-gather from now on
+    h->cf_for = 1;
+  }
   int rc;
   if (src_f32 && dst_f32) rc = launch_typed<float, float>(h, src, layout, nlev, nfields, dst, scale, offset, s);
   else if (src_f32) rc = launch_typed<float, double>(h, src, layout, nlev, nfields, dst, scale, offset, s);

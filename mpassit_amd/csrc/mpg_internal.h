@@ -190,6 +190,7 @@ struct mpg_handle_s {
   int64_t ut_total = 0;
   int lf_choice = 0;      // level-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 row-gather
   int cf_choice = 0;      // cell-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 lane-gather
+  int cf_for = -99;       // "a3_staged" knob value the choice was made for
   float lf_reuse = 0.f;   // 3 * n_dst / (sum of the tiles' unique cells): references per staged row
   DevBuf<int32_t> ut_ptr, ut_cells;
   DevBuf<uint16_t> lidx;  // [3][n_dst] positions in the tile's list, 0xFFFF = unmapped
@@ -216,6 +217,7 @@ int mpg_lfu_num_variants();
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_cfu_num_variants();
 int mpg_a3_staged();  // current "a3_staged" knob
+int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits);
 int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
                            double offset, hipStream_t s);
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant);  // -> variant index or -1 (use k_apply3_cf)

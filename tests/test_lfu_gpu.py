@@ -61,3 +61,14 @@ def test_tiny_workload_many_fields(gpu_lib):
     from mpassit_amd import regrid as R, workloads
     m, g, nlev, _ = workloads.workload("tiny")
     _check(R, gpu_lib, m, g, nlev=nlev, nfields=5)
+
+
+def test_fine_mesh_under_a_coarse_grid_falls_back(gpu_lib):
+    """Downscaling direction (30 k-cell mesh -> 18 x 10 grid): neighbouring target points share no cells, a tile's list
+    holds up to three cells per point and exceeds what the staged kernel keeps in registers -> the library serves the
+    handle with the lane-gather kernel; results are the same either way."""
+    from mpassit_amd import regrid as R, target_grid as T, workloads
+    m, _, nlev, _ = workloads.workload("tiny")
+    g = T.define_target_grid_params("lambert", 19, 11, dx=300000.0, dy=300000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
+                                    truelat2=38.5, stand_lon=-97.5)
+    assert _check(R, gpu_lib, m, g, nlev=nlev, nfields=2) >= 0
