@@ -58,14 +58,26 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
   int rc;
   for (int q = 0; q < nslot; ++q)
     if ((rc = dsrc[q].alloc(max_s * es + 16)) || (rc = ddst[q].alloc(max_d * ed + 16))) return rc;
-  hipStream_t s_up, s_k;
-  MPG_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
-  MPG_HIP(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
-  std::vector<hipEvent_t> up(plan.size()), done(plan.size());
+  struct Res {  // streams and events of one call, released on every exit path
+    hipStream_t s_up = nullptr, s_k = nullptr;
+    std::vector<hipEvent_t> up, done;
+    ~Res() {
+      for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+      if (s_up) (void)hipStreamDestroy(s_up);
+      if (s_k) (void)hipStreamDestroy(s_k);
+    }
+  } res;
+  MPG_HIP(hipStreamCreateWithFlags(&res.s_up, hipStreamNonBlocking));
+  MPG_HIP(hipStreamCreateWithFlags(&res.s_k, hipStreamNonBlocking));
+  res.up.assign(plan.size(), nullptr);
+  res.done.assign(plan.size(), nullptr);
   for (size_t c = 0; c < plan.size(); ++c) {
-    MPG_HIP(hipEventCreateWithFlags(&up[c], hipEventDisableTiming));
-    MPG_HIP(hipEventCreateWithFlags(&done[c], hipEventDisableTiming));
+    MPG_HIP(hipEventCreateWithFlags(&res.up[c], hipEventDisableTiming));
+    MPG_HIP(hipEventCreateWithFlags(&res.done[c], hipEventDisableTiming));
   }
+  hipStream_t s_up = res.s_up, s_k = res.s_k;
+  std::vector<hipEvent_t> &up = res.up, &done = res.done;
   std::atomic<int> produced{0}, consumed{0}, err{0};
   const int dev = mpg_device_index();
   std::thread down([&]() {
@@ -100,12 +112,6 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
   if (!rc && err.load()) rc = err.load();
   (void)hipStreamSynchronize(s_k);
   (void)hipStreamSynchronize(s_up);
-  for (size_t c = 0; c < plan.size(); ++c) {
-    (void)hipEventDestroy(up[c]);
-    (void)hipEventDestroy(done[c]);
-  }
-  (void)hipStreamDestroy(s_up);
-  (void)hipStreamDestroy(s_k);
   if (rc == MPG_ERR_HIP) mpg_set_error("mpg_regrid_typed: a HIP call of the transfer pipeline failed: %s", hipGetErrorString(hipGetLastError()));
   return rc;
 }
