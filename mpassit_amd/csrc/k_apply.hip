@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
 }
 
 int mpg_a3_staged() { return g_a3_staged; }
+int mpg_lf_variant() { return g_lf_variant; }
 
 int mpg_k_tune(const char *key, int value) {
 

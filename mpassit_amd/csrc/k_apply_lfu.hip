@@ -537,6 +537,93 @@ static int launch_cfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields,
   return MPG_SUCCESS;
 }
 
+// Typed form of the staged LEVEL-fast kernel: float32 rows as the MPAS history file stores them ([nCells][nVertLevels],
+// 220 bytes per cell at 55 levels) or float64 rows, float64 arithmetic, dst = (TD)(value * scale + offset).  This is the
+// path of a file-order, single-precision ingest with single-precision output.  Fixed shape <64 x 4 points, 16 levels per
+// chunk, 16 prefetch registers> = the float64 auto variant.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
+                                                              const uint16_t *__restrict__ lidx, const double *__restrict__ w,
+                                                              const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                              int nlev, int ntx, int nty, int nfields, int ut_max, double scale,
+                                                              double offset) {
+  constexpr int TXU = 64, RPT = 1, LC = 16, NPF = 16, LS = LC + 1, RPP = LFU_THREADS / LC;
+  extern __shared__ double lds[];
+  int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
+  const int64_t P = (int64_t)nx * ny;
+  const unsigned ntile = (unsigned)ntx * nty;
+  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tile = lin % ntile;
+  const int f = lin / ntile;
+  const int t = threadIdx.x;
+  const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
+  for (int r = t; r < nU; r += LFU_THREADS) cells[r] = ut_cells[u0 + r];
+  LfuPoints<TXU, RPT> pts;
+  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, LS);
+  const TS *sf = src + (int64_t)f * nlev * nsrc;
+  TD *df = dst + (int64_t)f * nlev * P;
+  const int lrow = t / LC, llev = t % LC;
+  __syncthreads();
+  int64_t roff[NPF];
+#pragma unroll
+  for (int u = 0; u < NPF; ++u) {
+    int row = lrow + u * RPP;
+    roff[u] = row < nU ? (int64_t)cells[row] * nlev + llev : -1;
+  }
+  TS pf[NPF];
+#pragma unroll
+  for (int u = 0; u < NPF; ++u) pf[u] = (roff[u] >= 0 && llev < nlev) ? sf[roff[u]] : (TS)0;
+  for (int k0 = 0; k0 < nlev; k0 += LC) {
+#pragma unroll
+    for (int u = 0; u < NPF; ++u)
+      if (roff[u] >= 0) lds[(lrow + u * RPP) * LS + llev] = (double)pf[u];
+    for (int row = lrow + NPF * RPP; row < nU; row += RPP)
+      lds[row * LS + llev] = (k0 + llev < nlev) ? (double)sf[(int64_t)cells[row] * nlev + k0 + llev] : 0.0;
+    __syncthreads();
+    const int kn1 = k0 + LC;
+    if (kn1 < nlev) {
+      const bool ok = kn1 + llev < nlev;
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) pf[u] = (roff[u] >= 0 && ok) ? sf[roff[u] + kn1] : (TS)0;
+    }
+    const int kn = min(LC, nlev - k0);
+    for (int kk = 0; kk < kn; ++kk) {
+      double a = lds[pts.l[0][0] + kk], b = lds[pts.l[0][1] + kk], e = lds[pts.l[0][2] + kk];
+      double val = pts.mapped[0] ? wsum3(pts.ww[0][0], a, pts.ww[0][1], b, pts.ww[0][2], e) : 0.0;
+      if (pts.act[0]) __builtin_nontemporal_store((TD)fma(val, scale, offset), df + (int64_t)(k0 + kk) * P + pts.off[0]);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TS, typename TD>
+static int launch_lfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
+  const int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 3) / 4;
+  const size_t um = h->ut_max > 0 ? h->ut_max : 1;
+  size_t lds = sizeof(double) * um * 17 + sizeof(int32_t) * um + 16;
+  if (lds > 160 * 1024) return MPG_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024)
+    MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lfu_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_apply3_lfu_t<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
+                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
+                                                                                nfields, (int)um, scale, offset);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+// -> MPG_ERR_UNSUPPORTED when the row-gather kernel is the better choice for this handle (caller falls back)
+int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
+                           double offset, hipStream_t s) {
+  int pick, rc = mpg_lfu_auto(h, s, &pick);
+  if (rc) return rc;
+  if (pick < 0) return MPG_ERR_UNSUPPORTED;
+  if ((rc = lfu_build(h, 64, 1, s))) return rc;
+  if (src_f32 && dst_f32) return launch_lfu_t<float, float>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (src_f32) return launch_lfu_t<float, double>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (dst_f32) return launch_lfu_t<double, float>(h, src, nlev, nfields, dst, scale, offset, s);
+  return launch_lfu_t<double, double>(h, src, nlev, nfields, dst, scale, offset, s);
+}
+
 int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
                            double offset, hipStream_t s) {
   int rc = lfu_build(h, 64, 2, s);
