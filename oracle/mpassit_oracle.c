@@ -413,7 +413,8 @@ int64_t orc_conserve(int64_t nCells, int64_t nVertices, int maxEdges, const int3
   if (nd > 0) { qsort(diam, (size_t)nd, sizeof(double), cmp_double); g = 1.5 * diam[nd / 2]; }
   boxhash h; bh_build(&h, nCells, lo, hi, valid, g);
   int64_t nnz = 0;
-  int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * 65536);
+  const int64_t cand_cap = nCells + 1 > 65536 ? nCells + 1 : 65536;
+  int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * (size_t)cand_cap);
   int nxc = nx + 1;
   for (int j = 0; j < ny; ++j) for (int i = 0; i < nx; ++i) {
     int64_t p = (int64_t)j * nx + i;
@@ -432,16 +433,27 @@ int64_t orc_conserve(int64_t nCells, int64_t nVertices, int maxEdges, const int3
     double pad = 2.0 * e2 + 1e-9;
     int a0 = bh_cell(&h, l[0] - pad), a1 = bh_cell(&h, u[0] + pad), b0 = bh_cell(&h, l[1] - pad), b1 = bh_cell(&h, u[1] + pad),
         c0 = bh_cell(&h, l[2] - pad), c1 = bh_cell(&h, u[2] + pad);
-    int nc = 0;
-    for (int a = a0; a <= a1; ++a) for (int b = b0; b <= b1; ++b) for (int c = c0; c <= c1; ++c) {
+    int64_t nc = 0;
+    int overflow = (int64_t)(a1 - a0 + 1) * (b1 - b0 + 1) * (c1 - c0 + 1) > 4096;  /* huge destination cell: scan every source cell */
+    for (int a = a0; a <= a1 && !overflow; ++a) for (int b = b0; b <= b1 && !overflow; ++b) for (int c = c0; c <= c1 && !overflow; ++c) {
       uint32_t k = bh_hash(&h, a, b, c);
-      for (int64_t t = h.start[k]; t < h.start[k + 1] && nc < 65536; ++t) cand[nc++] = h.items[t];
+      for (int64_t t = h.start[k]; t < h.start[k + 1]; ++t) {
+        if (nc >= cand_cap) { overflow = 1; break; }
+        cand[nc++] = h.items[t];
+      }
     }
-    for (int64_t t = 0; t < h.nbig && nc < 65536; ++t) cand[nc++] = h.big[t];
-    /* sort + unique */
-    for (int a = 1; a < nc; ++a) { int32_t key = cand[a]; int b = a - 1; while (b >= 0 && cand[b] > key) { cand[b + 1] = cand[b]; --b; } cand[b + 1] = key; }
+    for (int64_t t = 0; t < h.nbig && !overflow; ++t) {
+      if (nc >= cand_cap) { overflow = 1; break; }
+      cand[nc++] = h.big[t];
+    }
+    if (overflow) {  /* never truncate the candidate set */
+      nc = 0;
+      for (int64_t c = 0; c < nCells; ++c) if (valid[c]) cand[nc++] = (int32_t)c;
+    } else {  /* sort + unique */
+      for (int64_t a = 1; a < nc; ++a) { int32_t key = cand[a]; int64_t b = a - 1; while (b >= 0 && cand[b] > key) { cand[b + 1] = cand[b]; --b; } cand[b + 1] = key; }
+    }
     int32_t last = -1;
-    for (int a = 0; a < nc; ++a) {
+    for (int64_t a = 0; a < nc; ++a) {
       int32_t c = cand[a];
       if (c == last) continue;
       last = c;
