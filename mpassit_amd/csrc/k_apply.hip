@@ -317,7 +317,7 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "tile_group")) { g_tgroup = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_fields_per_wg")) { g_lf_fpw = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_variant")) {  // 0.. : k_apply3_lf variants; 100.. : LDS-staged unique-cell variants (k_apply_lfu.hip)
-    if (value == -1 || (value >= 100 && value < 100 + mpg_lfu_num_variants())) {
+    if (value == -1 || value == 200 || (value >= 100 && value < 100 + mpg_lfu_num_variants())) {  // 200: rows-resident kernel
       g_lf_variant = value;
       return MPG_SUCCESS;
     }
@@ -359,6 +359,11 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
       int pick, rc = mpg_lfu_auto(h, s, &pick);
       if (rc) return rc;
       lfv = pick >= 0 ? 100 + pick : LF_DEFAULT_ROW_GATHER;
+    }
+    if (lev_fast && lfv == 200) {
+      int rc = mpg_k_apply3_lfr(h, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, s);
+      if (rc != MPG_ERR_UNSUPPORTED) return rc;
+      lfv = LF_DEFAULT_ROW_GATHER;  // rows of a tile do not fit the LDS
     }
     if (lev_fast && lfv >= 100) {
       int rc = mpg_k_apply3_lfu(h, lfv - 100, src, nlev, nfields, dst, s);

@@ -356,14 +356,17 @@ static const LfuVariant g_lfu_variants[] = {
 };
 int mpg_lfu_num_variants() { return (int)(sizeof(g_lfu_variants) / sizeof(g_lfu_variants[0])); }
 
-static int lfu_build(mpg_handle_s *h, int txu, int rpt, hipStream_t s) {
-  const int key = txu * 16 + rpt;
+static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s);
+static int lfu_build(mpg_handle_s *h, int txu, int rpt, hipStream_t s) { return lfu_build_shape(h, txu, LFU_THREADS * rpt / txu, s); }
+
+// tile lists for tiles of txu x tyu target points (cached in the handle, keyed by the shape)
+static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
+  const int key = txu * 1024 + tyu;
   if (h->ut_rpt == key) return MPG_SUCCESS;
   int rc;
   h->ut_ptr.free();
   h->ut_cells.free();
   h->ut_rpt = 0;
-  const int tyu = LFU_THREADS * rpt / txu;
   if (3 * txu * tyu > LFU_SORT) {
     mpg_set_error("staged Regrid: tile of %d x %d points exceeds the sort buffer", txu, tyu);
     return MPG_ERR_UNSUPPORTED;
@@ -609,6 +612,92 @@ static int launch_lfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields,
                                                                                 nfields, (int)um, scale, offset);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
+}
+
+// ---- level-fast, whole rows resident ("lfr") -------------------------------------------------------------------
+// For handles with little sharing between target points (C4: 1.4 points per cell) chunking the levels costs more than
+// it saves (every 128-byte line is touched by two chunks).  Here a tile of 32 x 4 target points keeps the COMPLETE
+// rows of its unique cells in LDS: each row is fetched once, as one contiguous wave-wide load (lanes = levels), then
+// 256 threads combine: thread = (point, level parity), so a wave still stores 64 consecutive points of one level
+// (two 256-byte row segments).  LDS holds the source element type (float32 rows stay float32; widened when read).
+template <typename TS, typename TD>
+__global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfr(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
+                                                            const uint16_t *__restrict__ lidx, const double *__restrict__ w,
+                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                            int nlev, int nlp, int ntx, int nty, int nfields, double scale, double offset) {
+  constexpr int TXU = 32, TYU = 4, NP = TXU * TYU;
+  extern __shared__ double lds_raw[];
+  TS *rows = (TS *)lds_raw;  // [nU][nlp]
+  const int64_t P = (int64_t)nx * ny;
+  const unsigned ntile = (unsigned)ntx * nty;
+  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tile = lin % ntile;
+  const int f = lin / ntile;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
+  const TS *sf = src + (int64_t)f * nlev * nsrc;
+  // phase 1: wave w fetches rows w, w+4, ...: 4 rows in flight per wave and iteration
+  for (int rb = wave; rb < nU; rb += 16) {
+    TS v[4];
+    int c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int row = rb + 4 * u;
+      c[u] = row < nU ? ut_cells[u0 + row] : -1;
+    }
+    for (int l0 = 0; l0 < nlev; l0 += 64) {
+      const bool ok = l0 + lane < nlev;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = (c[u] >= 0 && ok) ? sf[(int64_t)c[u] * nlev + l0 + lane] : (TS)0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c[u] >= 0 && ok) rows[(rb + 4 * u) * nlp + l0 + lane] = v[u];
+    }
+  }
+  // this thread's point
+  const int pt = t % NP, par = t / NP;
+  const int i = (tile % ntx) * TXU + pt % TXU, j = (tile / ntx) * TYU + pt / TXU;
+  const bool act = i < nx && j < ny;
+  const int64_t p = act ? (int64_t)j * nx + i : 0;
+  int l0 = lidx[p], l1 = lidx[P + p], l2 = lidx[2 * P + p];
+  const double w0 = w[p], w1 = w[P + p], w2 = w[2 * P + p];
+  const bool mapped = l0 != 0xFFFF;
+  l0 = mapped ? l0 * nlp : 0;
+  l1 = mapped ? l1 * nlp : 0;
+  l2 = mapped ? l2 * nlp : 0;
+  __syncthreads();
+  TD *df = dst + (int64_t)f * nlev * P + p;
+  if (act)
+    for (int k = par; k < nlev; k += 2) {
+      double val = mapped ? wsum3(w0, (double)rows[l0 + k], w1, (double)rows[l1 + k], w2, (double)rows[l2 + k]) : 0.0;
+      __builtin_nontemporal_store((TD)fma(val, scale, offset), df + (int64_t)k * P);
+    }
+}
+
+template <typename TS, typename TD>
+static int launch_lfr(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
+  const int ntx = (h->nx_dst + 31) / 32, nty = (h->ny_dst + 3) / 4;
+  const int nlp = nlev | 1;  // odd row stride: conflict-free column reads
+  const size_t um = h->ut_max > 0 ? h->ut_max : 1;
+  size_t lds = sizeof(TS) * um * nlp + 16;
+  if (lds > 80 * 1024) return MPG_ERR_UNSUPPORTED;  // fewer than two workgroups per CU: not worth it
+  if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lfr<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  k_apply3_lfr<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
+                                                                              (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, nlp, ntx, nty, nfields,
+                                                                              scale, offset);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+// explicit entry (lf_variant 200): rows-resident kernel for any element types
+int mpg_k_apply3_lfr(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale, double offset,
+                     hipStream_t s) {
+  int rc = lfu_build_shape(h, 32, 4, s);
+  if (rc) return rc;
+  if (src_f32 && dst_f32) return launch_lfr<float, float>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (src_f32) return launch_lfr<float, double>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (dst_f32) return launch_lfr<double, float>(h, src, nlev, nfields, dst, scale, offset, s);
+  return launch_lfr<double, double>(h, src, nlev, nfields, dst, scale, offset, s);
 }
 
 // -> MPG_ERR_UNSUPPORTED when the row-gather kernel is the better choice for this handle (caller falls back)

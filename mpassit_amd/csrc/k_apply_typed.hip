@@ -207,6 +207,10 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
     h->cf_choice = -1;  // tile lists too long for the staged kernel: lane-gather from now on
     h->cf_for = 1;
   }
+  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() == 200) {
+    int rc = mpg_k_apply3_lfr(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
+    if (rc != MPG_ERR_UNSUPPORTED) return rc;
+  }
   if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() == -1) {
     int rc = mpg_k_apply3_lfu_typed(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);  // staged, when it pays
     if (rc != MPG_ERR_UNSUPPORTED) return rc;
