@@ -121,8 +121,7 @@ static const A3Variant g_a3_variants[] = {
 };
 static inline int a3_tile_rows(const A3Variant &v) { return (v.waves / (64 / v.wx)) * (64 / v.wx) * v.rpt; }
 static int g_a3_variant = 1;  // "a3_variant" knob (tuned on MI355X: profiles/r01_sweep_apply*.txt)
-static int g_a3_staged = 1;   // "a3_staged" knob: -2 lane-gather only, -1 per-handle choice, >= 0 LDS-staged variant (default:
-                              // <64 x 8 points, 4 levels per chunk>, never slower than the lane-gather kernel on C2/C4/C5)
+static int g_a3_staged = -1;  // "a3_staged" knob: -2 lane-gather only, -1 per-handle choice (default), >= 0 that LDS-staged variant
 static int g_fpw = 1;         // "fields_per_wg" knob (0 = all fields in one workgroup pass)
 static int g_tgroup = 1;      // "tile_group" knob: tile rows per band (1 = plain row-major tile order)
 

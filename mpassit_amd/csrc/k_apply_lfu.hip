@@ -435,15 +435,26 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
 }
 
 // cell-fast: same statistic (measured: C2 reuse 5+ -> staged 1.5x faster; C4 reuse 2.5 -> k_apply3_cf is at the HBM limit)
-static int g_cfu_auto_variant = 0;
+// Per-handle choice (a3_staged = -1, the default), measured on MI355X (profiles/r01_sweep_cfu.txt, clean re-run):
+//   tiles of 64 x 16 points (variant 10) when cells are shared a lot (reuse >= 3.5) and the lists fit: C2 0.82 ms,
+//     C5 3.07 ms per 4 fields (64 x 8 tiles: 0.87 / 3.30; lane-gather 1.50 / 4.91);
+//   else tiles of 64 x 8 points (variant 1) when the lists fit: C4 1.57 ms (lane-gather 1.61);
+//   else the lane-gather kernel (fine mesh under a coarse grid).
+// cf_choice holds variant + 1, or -1 for the lane-gather kernel.
+#define CFU_WIDE 10
+#define CFU_BASE 1
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
-  const LfuVariant &v = g_cfu_variants[g_cfu_auto_variant];
   if (h->cf_choice == 0 || h->cf_for != -1) {
     h->cf_for = -1;
-    int rc = lfu_build(h, v.txu, v.rpt, s);
+    int rc = lfu_build(h, g_cfu_variants[CFU_WIDE].txu, g_cfu_variants[CFU_WIDE].rpt, s);
     if (rc) return rc;
     float reuse = h->ut_total > 0 ? 3.0f * (float)h->n_dst / (float)h->ut_total : 0.f;
-    h->cf_choice = (reuse >= LFU_AUTO_MIN_REUSE && h->ut_max <= cfu_capacity(g_cfu_auto_variant)) ? 1 : -1;
+    if (reuse >= LFU_AUTO_MIN_REUSE && h->ut_max <= cfu_capacity(CFU_WIDE)) {
+      h->cf_choice = CFU_WIDE + 1;
+    } else {
+      if ((rc = lfu_build(h, g_cfu_variants[CFU_BASE].txu, g_cfu_variants[CFU_BASE].rpt, s))) return rc;
+      h->cf_choice = h->ut_max <= cfu_capacity(CFU_BASE) ? CFU_BASE + 1 : -1;
+    }
     if (h->cf_choice < 0 && h->lf_choice <= 0) {
       h->ut_ptr.free();
       h->ut_cells.free();
@@ -451,7 +462,7 @@ int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
       h->ut_rpt = 0;
     }
   }
-  *cfu_variant = h->cf_choice > 0 ? g_cfu_auto_variant : -1;
+  *cfu_variant = h->cf_choice > 0 ? h->cf_choice - 1 : -1;
   return MPG_SUCCESS;
 }
 
@@ -733,7 +744,7 @@ int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits) {
     const LfuVariant &v = g_cfu_variants[variant];
     int rc = lfu_build(h, v.txu, v.rpt, s);
     if (rc) return rc;
-    h->cf_choice = h->ut_max <= cfu_capacity(variant) ? 1 : -1;
+    h->cf_choice = h->ut_max <= cfu_capacity(variant) ? variant + 1 : -1;
     if (h->cf_choice < 0 && h->lf_choice <= 0) {
       h->ut_ptr.free();
       h->ut_cells.free();

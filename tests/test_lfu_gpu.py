@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 LFU = list(range(100, 120)) + [200]   # 100-105 two-phase, 106-111 pipelined, 112-119 compact tiles, 200 rows-resident
-A3_STAGED_DEFAULT = 1            # library default of the "a3_staged" knob
+A3_STAGED_DEFAULT = -1           # library default of the "a3_staged" knob (per-handle choice)
 
 
 def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
