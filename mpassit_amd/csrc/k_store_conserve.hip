@@ -75,7 +75,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          const double *__restrict__ vz, PyramidView pyr, int nx, int ny,
                                                          const double *__restrict__ qx, const double *__restrict__ qy,
                                                          const double *__restrict__ qz, const double *__restrict__ qarea,
-                                                         int32_t *__restrict__ count, const int32_t *__restrict__ rowptr,
+                                                         const double *__restrict__ qsph, int32_t *__restrict__ count,
+                                                         const int32_t *__restrict__ rowptr,
                                                          int32_t *__restrict__ col, double *__restrict__ val,
                                                          int32_t *__restrict__ cnt_src, int32_t *__restrict__ tmp_dst,
                                                          double *__restrict__ tmp_val, int32_t *__restrict__ ovf,
@@ -163,6 +164,15 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
       int i1 = min(i0 + MPG_PYR_B0, nx), j1 = min(j0 + MPG_PYR_B0, ny);
       for (int j = j0; j < j1; ++j)
         for (int i = i0; i < i1; ++i) {
+          // bounding sphere of the destination cell (k_cell_areas) against the source polygon's padded box: 4 loads decide
+          // most candidates of a 4 x 4 leaf block before the 12 corner coordinates are touched
+          const int64_t pc = (int64_t)j * nx + i, PP = (int64_t)nx * ny;
+          {
+            double sx = qsph[pc], sy = qsph[PP + pc], sz = qsph[2 * PP + pc], r2 = qsph[3 * PP + pc];
+            double ddx = fmax(fmax(lo[0] - sx, sx - hi[0]), 0.0), ddy = fmax(fmax(lo[1] - sy, sy - hi[1]), 0.0),
+                   ddz = fmax(fmax(lo[2] - sz, sz - hi[2]), 0.0);
+            if (ddx * ddx + ddy * ddy + ddz * ddz > r2) continue;
+          }
           int64_t k00 = (int64_t)j * nxc + i;
           dv3 q[4] = {dv3{qx[k00], qy[k00], qz[k00]}, dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
                       dv3{qx[k00 + nxc + 1], qy[k00 + nxc + 1], qz[k00 + nxc + 1]}, dv3{qx[k00 + nxc], qy[k00 + nxc], qz[k00 + nxc]}};
@@ -218,7 +228,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
 
 // signed area of every destination cell (corner order i,j -> i+1,j -> i+1,j+1 -> i,j+1), once per grid
 __global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double *__restrict__ qx, const double *__restrict__ qy,
-                                                    const double *__restrict__ qz, double *__restrict__ qarea) {
+                                                    const double *__restrict__ qz, double *__restrict__ qarea,
+                                                    double *__restrict__ qsph /* [4][P]: centre xyz, radius^2 */) {
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (p >= (int64_t)nx * ny) return;
   int i = (int)(p % nx), j = (int)(p / nx), nxc = nx + 1;
@@ -226,6 +237,21 @@ __global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double
   dv3 q0 = dv3{qx[k00], qy[k00], qz[k00]}, q1 = dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
       q2 = dv3{qx[k00 + nxc + 1], qy[k00 + nxc + 1], qz[k00 + nxc + 1]}, q3 = dv3{qx[k00 + nxc], qy[k00 + nxc], qz[k00 + nxc]};
   qarea[p] = sph_tri_area(q0, q1, q2) + sph_tri_area(q0, q2, q3);
+  // bounding sphere: centre = normalised corner mean; the farthest point of a great-circle side from a point of the
+  // sphere is one of its end points, so the largest corner distance bounds the whole cell
+  dv3 cen = (q0 + q1) + (q2 + q3);
+  double nn = sqrt(dot3(cen, cen));
+  cen = nn > 0.0 ? cen * (1.0 / nn) : q0;
+  double r2 = 0.0;
+  dv3 d = q0 - cen; r2 = fmax(r2, dot3(d, d));
+  d = q1 - cen; r2 = fmax(r2, dot3(d, d));
+  d = q2 - cen; r2 = fmax(r2, dot3(d, d));
+  d = q3 - cen; r2 = fmax(r2, dot3(d, d));
+  const int64_t P = (int64_t)nx * ny;
+  qsph[p] = cen.x;
+  qsph[P + p] = cen.y;
+  qsph[2 * P + p] = cen.z;
+  qsph[3 * P + p] = r2 * (1.0 + 1e-9) + 1e-18;
 }
 
 // row lengths from the private lists (source cells that fitted)
@@ -295,8 +321,8 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   h->nx_dst = nx;
   h->ny_dst = ny;
   TmpBuf<int32_t> count, cnt_src, tmp_dst, ovf, n_ovf;
-  TmpBuf<double> tmp_val, qarea;
-  if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P)) ||
+  TmpBuf<double> tmp_val, qarea, qsph;
+  if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P)) || (rc = qsph.alloc(4 * (size_t)P)) ||
       (rc = cnt_src.alloc((size_t)m->nCells)) || (rc = tmp_dst.alloc((size_t)m->nCells * CONS_CAP)) ||
       (rc = tmp_val.alloc((size_t)m->nCells * CONS_CAP)) || (rc = ovf.alloc((size_t)m->nCells)) || (rc = n_ovf.alloc(1)))
     return rc;
@@ -305,9 +331,9 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
   unsigned nb = (unsigned)((m->nCells + 127) / 128);
   PyramidView pv = mpg_pyr_view(g->cellpyr);
-  k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p);
+  k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
   k_conserve_raster<0><<<nb, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
-                                        cor.y.p, cor.z.p, qarea.p, count.p, nullptr, nullptr, nullptr, cnt_src.p, tmp_dst.p, tmp_val.p, ovf.p,
+                                        cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, nullptr, nullptr, nullptr, cnt_src.p, tmp_dst.p, tmp_val.p, ovf.p,
                                         n_ovf.p);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
@@ -316,7 +342,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipStreamSynchronize(s));
   if (novf > 0)  // MODE 2: cooperative count of the overflowed cells
     k_conserve_raster<2><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, count.p, nullptr, nullptr, nullptr, cnt_src.p,
+                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, nullptr, nullptr, nullptr, cnt_src.p,
                                                        nullptr, nullptr, ovf.p, nullptr);
   MPG_HIP(hipGetLastError());
   size_t tmp_bytes = 0;
@@ -339,7 +365,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // the few source cells with more than CONS_CAP overlaps are clipped again, one workgroup each, writing in place
   if (novf > 0)
     k_conserve_raster<1><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, count.p, h->rowptr.p, h->col.p, h->val.p,
+                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, h->rowptr.p, h->col.p, h->val.p,
                                                        cnt_src.p, nullptr, nullptr, ovf.p, nullptr);
   k_csr_sort_rows<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, h->rowptr.p, h->col.p, h->val.p);
   MPG_HIP(hipGetLastError());
