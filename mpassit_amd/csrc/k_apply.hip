@@ -6,9 +6,12 @@
 // are 0.0 (zeroregion=TOTAL + unmappedaction=IGNORE); nearest-neighbour is a pure copy (bit exact).
 //
 //   K2  k_apply3_cf    3-point gather, source cell-fastest [nlev][ncell] (reference memory order,
-//                       input_data.F90:653-655), destination [nlev][ny][nx]
+//                       input_data.F90:653-655), destination [nlev][ny][nx]: the lane-gather form; the default
+//                       for cell-fast sources is the LDS-staged k_apply3_cfu_p of k_apply_lfu.hip (chosen per
+//                       handle in mpg_k_apply below), this one serves handles whose tiles share no cells
 //   K2' k_apply3_lf    same from level-fastest [ncell][nlev] (MPAS file order, input_data.F90:630,645):
-//                       the reference's host transpose is fused away through an LDS tile transpose
+//                       the reference's host transpose is fused away through an LDS tile transpose; the
+//                       row-gather form, used when target points share few cells (else k_apply3_lfu_p)
 //   K3  k_apply1       nearest-neighbour copy
 //   K4  k_apply_csr    conservative (variable row length)
 //   K6  k_applyN<4>    4-point destagger (CENTER -> EDGE1/EDGE2)
