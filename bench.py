@@ -241,6 +241,24 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not io32:
         cpu = cpu_baseline(sr, src_for_kernel if layout == R.LAYOUT_CELL_FAST else local, nlev, args.cpu_seconds)
 
+    # "report two timings" -- kernel-only above, and end to end through the PCIe link (one 3-D field from
+    # pageable host memory to pageable host memory: upload, Regrid, download; never `value`)
+    e2e = None
+    if rank == 0 and world == 1 and layout == R.LAYOUT_CELL_FAST and not io32 and not args.no_cpu_baseline:
+        e2e = {}
+        for name, dt_np in (("f64", np.float64), ("f32", np.float32)):
+            hs = np.random.default_rng(1).standard_normal((nlev, sr.sched.n_local)).astype(dt_np)
+            ho = np.empty((1, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dt_np)
+            sr.rh.regrid_typed_host(hs, nlev=nlev, out=ho)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                sr.rh.regrid_typed_host(hs, nlev=nlev, out=ho)
+                ts.append(time.perf_counter() - t0)
+            e2e[name + "_fields_per_s"] = 1.0 / min(ts)
+        e2e["what"] = ("one 3-D field, host -> device -> host through mpg_regrid_typed (chunked upload / kernel / download), f64 or f32 on "
+                       "both sides of the link, float64 arithmetic; pageable host buffers")
+
     if rank == 0:
         fields_per_s = F * args.steps / dt
         rec = {
@@ -259,6 +277,7 @@ def main():
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
                          "device_copy_GBs": copy_gbs},
             "cpu_baseline": cpu,
+            "end_to_end_pcie": e2e,
             "store_ms": sr.store_ms,
             "device": {"arch": arch, "cus": n_cu, "hbm_gib": round(hbm / 2 ** 30, 1), "name": torch.cuda.get_device_name(dev),
                        "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))},
