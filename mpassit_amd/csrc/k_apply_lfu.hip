@@ -337,10 +337,12 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     {64, 2, 16, k_apply3_cfu_p<64, 2, 16, 32>},
     // 10-12: 64 x 16-point tiles (smaller one-cell ring per point, more registers)
     {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16>},  {64, 4, 2, k_apply3_cfu_p<64, 4, 2, 8>},   {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 20>},
+    // 13: 64 x 8 tiles with room for 1024 unique cells per tile (C4 needs 756 of the 768 that variant 1 holds)
+    {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 16>},
 };
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
-static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20};
+static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16};
 static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * LFU_THREADS; }
 static const LfuVariant g_lfu_variants[] = {
     // 0-5: two-phase, 64-wide tiles
@@ -438,11 +440,12 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
 // Per-handle choice (a3_staged = -1, the default), measured on MI355X (profiles/r01_sweep_cfu.txt, clean re-run):
 //   tiles of 64 x 16 points (variant 10) when cells are shared a lot (reuse >= 3.5) and the lists fit: C2 0.82 ms,
 //     C5 3.07 ms per 4 fields (64 x 8 tiles: 0.87 / 3.30; lane-gather 1.50 / 4.91);
-//   else tiles of 64 x 8 points (variant 1) when the lists fit: C4 1.57 ms (lane-gather 1.61);
+//   else tiles of 64 x 8 points (variant 13: room for 1024 cells per tile, C4 needs 756) when the lists fit: C4 1.57 ms
+//     (lane-gather 1.61);
 //   else the lane-gather kernel (fine mesh under a coarse grid).
 // cf_choice holds variant + 1, or -1 for the lane-gather kernel.
 #define CFU_WIDE 10
-#define CFU_BASE 1
+#define CFU_BASE 13
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
   if (h->cf_choice == 0 || h->cf_for != -1) {
     h->cf_for = -1;
@@ -468,14 +471,14 @@ int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
 
 // Typed form of the staged cell-fast kernel (mpg_regrid_typed_dev): float32 or float64 source as the MPAS file stores
 // it, float64 arithmetic (wsum3), dst = (TD)(value * scale + offset) -- the writer's T - 300 / PHB * 9.81 / NF90_FLOAT
-// conversion fused in.  Fixed shape <64 x 8 points, 4 levels per chunk, 12 prefetch registers> = the f64 default.
+// conversion fused in.  Fixed shape <64 x 8 points, 4 levels per chunk, 16 prefetch registers> = the f64 base variant.
 template <typename TS, typename TD>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                               const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
                                                               int nlev, int ntx, int nty, int nfields, int ut_max, double scale,
                                                               double offset) {
-  constexpr int TXU = 64, RPT = 2, LC = 4, NPF = 12, UPT = NPF / LC;
+  constexpr int TXU = 64, RPT = 2, LC = 4, NPF = 16, UPT = NPF / LC;
   extern __shared__ double lds[];  // [LC][nup]
   const int nup = ut_max;
   const int64_t P = (int64_t)nx * ny;
@@ -728,7 +731,7 @@ int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nl
                            double offset, hipStream_t s) {
   int rc = lfu_build(h, 64, 2, s);
   if (rc) return rc;
-  if (h->ut_max > 768) return MPG_ERR_UNSUPPORTED;  // caller falls back to the lane-gather typed kernel
+  if (h->ut_max > 1024) return MPG_ERR_UNSUPPORTED;  // caller falls back to the lane-gather typed kernel
   if (src_f32 && dst_f32) return launch_cfu_t<float, float>(h, src, nlev, nfields, dst, scale, offset, s);
   if (src_f32) return launch_cfu_t<float, double>(h, src, nlev, nfields, dst, scale, offset, s);
   if (dst_f32) return launch_cfu_t<double, float>(h, src, nlev, nfields, dst, scale, offset, s);
