@@ -272,8 +272,7 @@ def main():
                        "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
                        "unmapped_points_rank0": n_unmapped},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": ("k_apply3_cfu_p" if not any(t.startswith("a3_staged=-2") for t in args.tune) else "k_apply3_cf")
-                         if layout == R.LAYOUT_CELL_FAST else "k_apply3_lf / k_apply3_lfu_p (per handle)",
+                         "traffic": traffic, "kernel": kernel_label(sr.rh, layout, R),
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
                          "device_copy_GBs": copy_gbs},
             "cpu_baseline": cpu,
@@ -287,6 +286,14 @@ def main():
     sr.destroy()
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_label(rh, layout, R):
+    """Name of the Regrid kernel the library picked for this handle (mpg_handle_kernel_choice)."""
+    cf, lf, mu = rh.kernel_choice()
+    if layout == R.LAYOUT_CELL_FAST:
+        return "k_apply3_cfu_p (staged variant %d, <= %d cells per tile)" % (cf - 1, mu) if cf > 0 else "k_apply3_cf (lane-gather)"
+    return "k_apply3_lfu_p (staged, <= %d cells per tile)" % mu if lf > 0 else "k_apply3_lf (row-gather)"
 
 
 def cpu_baseline(sr, local_rows, nlev, seconds):

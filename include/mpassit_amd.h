@@ -182,6 +182,10 @@ int mpg_handle_info(mpg_handle rh, int64_t *n_src, int64_t *n_dst, int *nx_dst, 
 int mpg_handle_get_weights(mpg_handle rh, int32_t *idx_host, double *w_host);
 /* CSR handles: rowptr [n_dst+1], col/val [nnz] (host) */
 int mpg_handle_get_csr(mpg_handle rh, int64_t *rowptr_host, int32_t *col_host, double *val_host);
+/* Which Regrid kernel serves a 3-point (bilinear) handle, decided when its tile lists are built on the first Regrid:
+ * cell_fast_kernel / lev_fast_kernel: 0 = not decided yet (layout not used so far), -1 = lane- / row-gather kernel,
+ * > 0 = LDS-staged variant index + 1;  max_unique = largest number of distinct source cells one tile references. */
+int mpg_handle_kernel_choice(mpg_handle rh, int *cell_fast_kernel, int *lev_fast_kernel, int *max_unique);
 /* Pole terms of a Grid -> Grid handle on a periodic (monopole) grid.  Destination points inside a pole cap
  * (triangle pole / A / B of the first or last CENTER row) carry, besides the A and B entries reported by
  * mpg_handle_get_weights, a weight on the pole node; the pole's value is the mean of the `row_len` sources

@@ -551,6 +551,14 @@ int mpg_handle_get_csr(mpg_handle h, int64_t *rowptr_host, int32_t *col_host, do
   return MPG_SUCCESS;
 }
 
+int mpg_handle_kernel_choice(mpg_handle h, int *cell_fast_kernel, int *lev_fast_kernel, int *max_unique) {
+  MPG_ARG(h, "mpg_handle_kernel_choice: NULL handle");
+  if (cell_fast_kernel) *cell_fast_kernel = h->cf_choice;
+  if (lev_fast_kernel) *lev_fast_kernel = h->lf_choice;
+  if (max_unique) *max_unique = h->ut_max;
+  return MPG_SUCCESS;
+}
+
 int mpg_handle_pole_count(mpg_handle h, int64_t *n_points, int *row_len) {
   MPG_ARG(h, "mpg_handle_pole_count: NULL handle");
   if (n_points) *n_points = h->n_pole;

@@ -264,6 +264,12 @@ class RouteHandle:
             row, col, S = row[keep], col[keep], S[keep]
         return row, col, S
 
+    def kernel_choice(self):
+        """(cell_fast, lev_fast, max_unique): which Regrid kernel serves this handle (mpg_handle_kernel_choice)."""
+        cf, lf, mu = C.c_int(), C.c_int(), C.c_int()
+        check(L.load().mpg_handle_kernel_choice(self._h, C.byref(cf), C.byref(lf), C.byref(mu)))
+        return cf.value, lf.value, mu.value
+
     def pole(self):
         """Pole terms of a Grid -> Grid handle on a periodic grid: (dst_id, src_row_start, w_pole, row_len);
         empty arrays for every other handle (mpg_handle_get_pole)."""
