@@ -161,6 +161,9 @@ int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const d
  *   mpg_post_layer_mean_dev  Z_C(k) = 0.5*(PHB(k+1) + PHB(k)), src [nlevp1][n_pts] -> dst [nlevp1-1][n_pts] (:1406-1415)
  *   mpg_post_ptop_dev        P_TOP from P_HYD [nlev][n_pts]: min(maxval(P_HYD), 0.8*P_HYD(top) over columns whose top
  *                            value is >= 10) (:1362-1371); float64 result returned to the host, blocks on the stream */
+/* In-place byte swap of n elements of elem_size 2, 4 or 8 bytes on the device: NetCDF classic data is big-endian, so a
+ * variable can be moved file <-> GPU as raw bytes (ncio_var_extent) and turned around at HBM speed. */
+int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream);
 int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream);
 int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream);
 int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream);

@@ -62,6 +62,13 @@ int ncio_enddef(ncio_file *f);                  /* lays the file out; data calls
 /* whole variable / one record from host memory of mem_type (converted to the variable's type and byte-swapped) */
 int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void *buf);
 
+/* ---- raw access (device-side ingest / egress) ---------------------------------------------------------------------
+ * Byte range of a whole non-record variable, or of record `rec` of a record variable, inside the file: big-endian
+ * elements of the variable's type, exactly as stored.  A caller can mmap / pread that range, move it to the GPU
+ * untouched and swap bytes there (mpg_bswap_dev), or write GPU-produced big-endian bytes into it.  On a file being
+ * written (after ncio_enddef) the range of record `rec` is made to exist (the file is extended, numrecs follows). */
+int ncio_var_extent(ncio_file *f, int varid, int64_t rec, int64_t *offset, int64_t *nbytes);
+
 int ncio_close(ncio_file *f);                   /* writer: fills numrecs, flushes */
 
 #ifdef __cplusplus

@@ -86,6 +86,34 @@ __global__ __launch_bounds__(256) void k_post_ptop(const double *__restrict__ sr
   }
 }
 
+// in-place byte swap of n elements of 2, 4 or 8 bytes: NetCDF classic files are big-endian, so a variable can travel
+// file -> device (and device -> file) as raw bytes and be turned around here at HBM speed instead of on a host core
+template <typename T>
+__global__ __launch_bounds__(256) void k_bswap(T *__restrict__ p, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    T v = p[i];
+    if (sizeof(T) == 2) v = (T)(((v & 0xff) << 8) | ((v >> 8) & 0xff));
+    else if (sizeof(T) == 4) v = (T)__builtin_bswap32((unsigned)v);
+    else v = (T)__builtin_bswap64((unsigned long long)v);
+    p[i] = v;
+  }
+}
+
+int mpg_k_bswap(void *buf, int64_t n, int elem_size, hipStream_t s) {
+  if (n == 0) return MPG_SUCCESS;
+  unsigned nb = (unsigned)((n + 255) / 256);
+  if (nb > 65536) nb = 65536;
+  if (elem_size == 2) k_bswap<uint16_t><<<nb, 256, 0, s>>>((uint16_t *)buf, n);
+  else if (elem_size == 4) k_bswap<uint32_t><<<nb, 256, 0, s>>>((uint32_t *)buf, n);
+  else if (elem_size == 8) k_bswap<unsigned long long><<<nb, 256, 0, s>>>((unsigned long long *)buf, n);
+  else {
+    mpg_set_error("mpg_bswap_dev: element size must be 2, 4 or 8");
+    return MPG_ERR_INVALID_ARG;
+  }
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
 int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, hipStream_t s) {
   if (n == 0) return MPG_SUCCESS;
   int64_t nthr = (n + 1) / 2;

@@ -643,6 +643,12 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
 }
 
 // ---- output epilogues (kernels in k_post.hip) ------------------------------------------------------------
+int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(n >= 0 && (n == 0 || buf_dev), "mpg_bswap_dev: NULL argument");
+  return mpg_k_bswap(buf_dev, n, elem_size, (hipStream_t)hip_stream);
+}
+
 int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream) {
   MPG_CHECK_INIT();
   MPG_ARG(n >= 0 && (n == 0 || (src_dev && dst_dev)), "mpg_post_cast_dev: NULL argument");

@@ -229,6 +229,7 @@ int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant);  // -> varia
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant);  // -> variant index or -1 (use the row-gather kernel)
 int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
                    double scale, double offset, hipStream_t s);
+int mpg_k_bswap(void *buf, int64_t n, int elem_size, hipStream_t s);
 int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, hipStream_t s);
 int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, hipStream_t s);
 int mpg_k_post_ptop(const double *src, int nlev, int64_t P, double *ptop_host, hipStream_t s);

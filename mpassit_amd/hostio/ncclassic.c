@@ -570,6 +570,27 @@ int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void 
   return 0;
 }
 
+int ncio_var_extent(ncio_file *f, int varid, int64_t rec, int64_t *offset, int64_t *nbytes) {
+  if (!f || varid < 0 || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_var_extent: bad argument");
+  if (f->writing && f->defmode) return fail(NCIO_EMODE, "ncio_var_extent: call ncio_enddef first");
+  var_t *x = &f->vars[varid];
+  int64_t off;
+  int rc = var_offset(f, x, rec, &off, "ncio_var_extent");
+  if (rc) return rc;
+  const int64_t nb = x->count * tsize(x->type);
+  if (f->writing) { /* make the range exist so that it can be mapped and written in place */
+    if (x->is_rec && rec + 1 > f->numrecs) f->numrecs = rec + 1;
+    int64_t end = f->rec_start + f->numrecs * f->recsize;
+    if (end < off + nb) end = off + nb;
+    fflush(f->fp);
+    off_t cur = lseek(fileno(f->fp), 0, SEEK_END);
+    if (cur < (off_t)end && ftruncate(fileno(f->fp), (off_t)end)) return fail(NCIO_EIO, "ncio_var_extent: cannot extend the file");
+  }
+  if (offset) *offset = off;
+  if (nbytes) *nbytes = nb;
+  return 0;
+}
+
 int ncio_close(ncio_file *f) {
   if (!f) return 0;
   int rc = 0;

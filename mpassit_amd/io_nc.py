@@ -10,8 +10,11 @@ Mirrors the nf90 calls of the reference with the classic-format library of this 
 Differences, all forced by the build image (no libnetcdf / HDF5): files are NetCDF CLASSIC (CDF-5 by default, CDF-2 on
 request), not NetCDF-4; input files in NetCDF-4 have to be converted (`nccopy -k cdf5`) -- ncio says so when it meets
 one.  `write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
+import os
+
 import numpy as np
 
+from . import _lib as L
 from . import fields as F
 from . import interp as I
 from . import ncio
@@ -95,10 +98,112 @@ def _read_field(r, name):
     return r.get(name, rec=0, dtype=np.float64) if v["record"] else r.get(name, dtype=np.float64)   # widened like nf90_get_var -> r8
 
 
-def read_input_data(hist_path, cfg, ter, diag_path=None):
+_RAW_TYPES = {ncio.FLOAT: ("float32", 4), ncio.DOUBLE: ("float64", 8)}
+
+
+def bswap_(t):
+    """In-place byte swap of a CUDA tensor's elements (mpg_bswap_dev): big-endian file order <-> host order."""
+    import ctypes as C
+    import torch
+    L.check(L.load().mpg_bswap_dev(C.c_void_p(t.data_ptr()), C.c_int64(t.numel()), C.c_int(t.element_size()),
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return t
+
+
+_IO_THREADS = 4
+_IO_CHUNK = 32 << 20
+_io_state = None
+
+
+def _io():
+    """A few pinned staging buffers + worker threads, created on first use: the GPU moves pinned chunks by DMA at PCIe
+    speed while the threads do the page-cache side (pread / pwrite are kernel copies that one core cannot do at that
+    speed, and they release the GIL)."""
+    import torch
+    global _io_state
+    if _io_state is None:
+        from concurrent.futures import ThreadPoolExecutor
+        bufs = [torch.empty(_IO_CHUNK, dtype=torch.uint8).pin_memory() for _ in range(2 * _IO_THREADS)]
+        _io_state = (ThreadPoolExecutor(_IO_THREADS), bufs)
+    return _io_state
+
+
+def _file_to_dev(path, offset, dev):
+    """bytes [offset, offset + dev.numel()) of the file -> the 1-D uint8 CUDA tensor `dev`."""
+    import torch
+    pool, bufs = _io()
+    n, nb = dev.numel(), len(bufs)
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        chunks = [(lo, min(n, lo + _IO_CHUNK)) for lo in range(0, n, _IO_CHUNK)]
+        free = [None] * nb                                          # event after which buffer k may be overwritten
+        reads = {}
+
+        def start(c):
+            k = c % nb
+            if free[k] is not None:
+                free[k].synchronize()
+            lo, hi = chunks[c]
+            reads[c] = pool.submit(os.preadv, fd, [memoryview(bufs[k].numpy())[:hi - lo]], offset + lo)
+        for c in range(min(nb, len(chunks))):
+            start(c)
+        for c, (lo, hi) in enumerate(chunks):
+            if reads.pop(c).result() != hi - lo:
+                raise IOError("%s: short read" % path)
+            k = c % nb
+            dev[lo:hi].copy_(bufs[k][:hi - lo], non_blocking=True)
+            free[k] = torch.cuda.Event()
+            free[k].record()
+            if c + nb < len(chunks):
+                start(c + nb)
+        torch.cuda.current_stream().synchronize()
+    finally:
+        os.close(fd)
+
+
+def _dev_to_file(path, offset, dev):
+    """the 1-D uint8 CUDA tensor `dev` -> bytes [offset, ...) of the file (which already has that size)."""
+    pool, bufs = _io()
+    n, nb = dev.numel(), len(bufs)
+    fd = os.open(path, os.O_WRONLY)
+    try:
+        busy = [None] * nb
+        for c, lo in enumerate(range(0, n, _IO_CHUNK)):
+            hi, k = min(n, lo + _IO_CHUNK), c % nb
+            if busy[k] is not None and busy[k].result() < 0:
+                raise IOError("%s: write failed" % path)
+            bufs[k][:hi - lo].copy_(dev[lo:hi])                      # blocking DMA into pinned memory
+            busy[k] = pool.submit(os.pwrite, fd, memoryview(bufs[k].numpy())[:hi - lo], offset + lo)
+        for f in busy:
+            if f is not None:
+                f.result()
+    finally:
+        os.close(fd)
+
+
+def _read_field_dev(r, name, device):
+    """The variable's bytes go file mapping -> GPU as stored (no host conversion pass, NF90_FLOAT stays 4 bytes on the
+    bus) and are turned to host byte order there; Regrid widens float32 in its loads."""
+    import torch
+    v = r.vars[name]
+    if v["type"] not in _RAW_TYPES:
+        return torch.as_tensor(_read_field(r, name), device=device)
+    off, nb = r.extent(name, rec=0)
+    t = torch.empty(nb, dtype=torch.uint8, device=device)
+    _file_to_dev(r.path, off, t)
+    shape = [int(n) for n in v["shape"]][1 if v["record"] else 0:]
+    return bswap_(t.view(getattr(torch, _RAW_TYPES[v["type"]][0]))).reshape(shape)
+
+
+def read_input_data(hist_path, cfg, ter, diag_path=None, device=None):
     """-> (interp.InputData with layout = LEV_FAST, attrs dict name -> (units, long_name), valid time string).
-    Every variable of the lists is read whole, first Time record (input_data.F90:316-812)."""
+    Every variable of the lists is read whole, first Time record (input_data.F90:316-812).
+    device="cuda": fields become CUDA tensors of the file's own float type, moved as raw big-endian bytes and swapped
+    on the GPU (device-side ingest)."""
     inp = I.InputData(hgt=ter, layout=R.LAYOUT_LEV_FAST)
+    if device is not None and ter is not None:
+        import torch
+        inp.hgt = torch.as_tensor(np.ascontiguousarray(ter, np.float64), device=device)
     attrs = {}
     valid = ""
 
@@ -106,7 +211,7 @@ def read_input_data(hist_path, cfg, ter, diag_path=None):
         for n in names:
             if n not in r.vars:
                 raise KeyError("variable %s not in %s" % (n, r_path))
-            store[n] = _read_field(r, n)
+            store[n] = _read_field(r, n) if device is None else _read_field_dev(r, n, device)
             try:
                 attrs[n] = (r.att("units", var=n), r.att("long_name", var=n))
             except ncio.NcioError:
@@ -144,6 +249,23 @@ _GRID_VARS = [  # name, stagger key, dims, description, units   (write_data.F90:
 
 def _np(x):
     return x.cpu().numpy() if type(x).__module__.startswith("torch") else np.asarray(x)
+
+
+def _is_dev(x):
+    return type(x).__module__.startswith("torch") and x.is_cuda
+
+
+def _put_dev(w, name, a):
+    """float32 CUDA tensor -> the variable's bytes in the file mapping: swapped to big-endian on the GPU (on a copy,
+    the caller keeps its tensor), one device -> mapping copy, no host conversion pass."""
+    import torch
+    a = a.contiguous()
+    off, _ = w.extent(name, rec=0)                        # makes the record exist: a file being created reads as zeros
+    if a.numel() and not bool(a.view(torch.int32).any()):
+        return                                            # all-zero bit patterns (MU, PH, P of wrf_mod_vars): nothing to store
+    be = bswap_(a.clone()).view(torch.uint8).reshape(-1)
+    torch.cuda.current_stream().synchronize()
+    _dev_to_file(w.path, off, be)                         # Z_C: nz of the declared nzp1 levels, the rest stays zero
 
 
 def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time="0000-00-00_00:00:00", start_time=None,
@@ -192,7 +314,8 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
             if name == "P_TOP":
                 w.def_var("P_TOP", ncio.FLOAT, ("Time",), description="PRESSURE TOP OF THE MODEL", units="Pa")
                 continue
-            a = _np(a)
+            if not (_is_dev(a) and str(a.dtype) == "torch.float32"):
+                a = _np(a)
             arrays[name] = a
             dims = dimsets[tuple(a.shape)]
             if name == "Z_C":                                                         # declared on bottom_top_stag, nz levels written (:479, :1413)
@@ -210,6 +333,9 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
         w.put("ZS", np.zeros(max(nsoil, 1), np.float32) if zs is None else np.asarray(zs, np.float32), rec=0)
         w.put("Times", valid_time.encode()[:DATESTRLEN].ljust(DATESTRLEN), rec=0)
         for name, a in arrays.items():
+            if _is_dev(a):
+                _put_dev(w, name, a)
+                continue
             if name == "Z_C":
                 pad = np.zeros((nzp1,) + a.shape[1:], np.float32)
                 pad[:nz] = a
@@ -219,18 +345,36 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
             w.put("P_TOP", np.array([res["P_TOP"]], np.float32), rec=0)
 
 
-def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=None, fmt=5):
+def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=None, fmt=5, device_io=False, timings=None):
     """mpassit.F90's main sequence on files: read grid + data, regrid on the GPU, post-ops, write.  Returns the
-    dictionary that went to the file (float32, post.output_fields order)."""
+    dictionary that went to the file (float32, post.output_fields order).
+    device_io: variables travel file <-> GPU as raw big-endian bytes and every field stays device resident in between
+    (same file, bit for bit, as the host-array path).  timings: dict that receives the wall seconds of each stage."""
+    import time
     from . import post
+
+    def lap(key, t0):
+        if timings is not None:
+            if device_io:
+                import torch
+                torch.cuda.synchronize()
+            timings[key] = timings.get(key, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+    t = time.perf_counter()
     mpas, ter, zs = read_grid(grid_path)
-    inp, _, valid = read_input_data(hist_path, cfg, ter, diag_path=diag_path)
+    t = lap("read_grid", t)
+    inp, _, valid = read_input_data(hist_path, cfg, ter, diag_path=diag_path, device="cuda" if device_io else None)
+    t = lap("read_input_data", t)
     mesh = R.Mesh.from_mpas(mpas)
     grid = R.Grid.from_proj(target)
+    t = lap("mesh_grid_create", t)
     out = I.interp_data(mesh, grid, target, inp, cfg)
+    t = lap("interp_data", t)
     res = post.output_fields(out, cfg)
+    t = lap("post_ops", t)
     write_target_data(out_path, target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00", zs=zs,
                       namelist=namelist, fmt=fmt)
+    t = lap("write_target_data", t)
     mesh.destroy()
     grid.destroy()
     return res

@@ -46,6 +46,7 @@ def _check(rc):
 class Reader:
     def __init__(self, path):
         self._h = C.c_void_p()
+        self.path = str(path)
         _check(lib().ncio_open(str(path).encode(), C.byref(self._h)))
         self.format = lib().ncio_format(self._h)
         self.numrecs = lib().ncio_numrecs(self._h)
@@ -86,6 +87,18 @@ class Reader:
             return np.stack(out) if out else np.empty((0,) + shape, _NP[mem])
         return out[0]
 
+    def raw(self, name, rec=0):
+        """Read-only memory map of the bytes of a variable (of record `rec`) exactly as stored: big-endian elements of
+        the variable's type (ncio_var_extent).  Meant for device-side ingest: upload untouched, swap on the GPU."""
+        off, nb = self.extent(name, rec)
+        return np.memmap(self.path, dtype=np.uint8, mode="r", offset=off, shape=(nb,))
+
+    def extent(self, name, rec=0):
+        """(offset, nbytes) of the variable's (record's) bytes in the file (ncio_var_extent)."""
+        off, nb = C.c_int64(), C.c_int64()
+        _check(lib().ncio_var_extent(self._h, self.vars[name]["id"], C.c_int64(rec), C.byref(off), C.byref(nb)))
+        return off.value, nb.value
+
     def att(self, name, var=None):
         vid = GLOBAL if var is None else self.vars[var]["id"]
         buf = C.create_string_buffer(4096)
@@ -113,6 +126,7 @@ class Writer:
 
     def __init__(self, path, format=5):
         self._h = C.c_void_p()
+        self.path = str(path)
         _check(lib().ncio_create(str(path).encode(), format, C.byref(self._h)))
         self._dims, self._dimlen, self._vars, self._defining = {}, {}, {}, True
 
@@ -168,6 +182,19 @@ class Writer:
         if a.size != count:
             raise ValueError("%s: %d elements given, the variable (record) holds %d" % (name, a.size, count))
         _check(lib().ncio_put_var(self._h, vid, C.c_int64(rec), mem, a.ctypes.data_as(C.c_void_p)))
+
+    def raw(self, name, rec=0):
+        """Writable memory map of the bytes of a variable (of record `rec`): the caller stores big-endian elements of the
+        variable's type itself (device-side egress: swap on the GPU, copy straight into the file mapping)."""
+        off, nb = self.extent(name, rec)
+        return np.memmap(self.path, dtype=np.uint8, mode="r+", offset=off, shape=(nb,))
+
+    def extent(self, name, rec=0):
+        """(offset, nbytes) of the variable's (record's) bytes; the file is extended so that the range exists."""
+        self.enddef()
+        off, nb = C.c_int64(), C.c_int64()
+        _check(lib().ncio_var_extent(self._h, self._vars[name][0], C.c_int64(rec), C.byref(off), C.byref(nb)))
+        return off.value, nb.value
 
     def close(self):
         if self._h:

@@ -179,8 +179,12 @@ class RouteHandle:
         need = nfields * nlev * self.n_src
         if _is_torch(src):
             import torch
+            if src.is_cuda and src.dtype == torch.float32 and src.is_contiguous():
+                # a field still in the file's NF90_FLOAT type: widened inside the kernel's loads (same result as
+                # widening first, nf90_get_var -> r8 in input_data.F90), float64 out
+                return self.regrid_typed(src, nlev=nlev, nfields=nfields, layout=layout, out_dtype=torch.float64, out=out)
             if not src.is_cuda or src.dtype != torch.float64 or not src.is_contiguous():
-                raise ValueError("device regrid needs a contiguous float64 CUDA tensor")
+                raise ValueError("device regrid needs a contiguous float32/float64 CUDA tensor")
             if src.numel() != need:
                 raise ValueError("source has %d elements, handle expects %d" % (src.numel(), need))
             if out is None:
@@ -188,6 +192,8 @@ class RouteHandle:
             check(L.load().mpg_regrid_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(layout), C.c_int(nlev), C.c_int(nfields),
                                           C.c_void_p(out.data_ptr()), _stream_ptr()))
             return out
+        if isinstance(src, np.ndarray) and src.dtype == np.float32:
+            return self.regrid_typed_host(src, nlev=nlev, nfields=nfields, layout=layout, out_dtype=np.float64, out=out)
         src = _f64(src)
         if src.size != need:
             raise ValueError("source has %d elements, handle expects %d" % (src.size, need))

@@ -75,5 +75,32 @@ def test_file_to_file_run_matches_the_in_memory_pipeline(gpu_lib, tmp_path):
     with ncio.Reader(tmp_path / "out5.nc") as r:
         assert r.format == 5
         assert np.array_equal(r.get("T", rec=0), res5["T"]) and np.array_equal(r.get("TSLB", rec=0), res5["TSLB"])
+
+    # device-side ingest / egress: variables cross as raw big-endian bytes, swapped on the GPU, fields device resident
+    # in between -> the very same file, byte for byte
+    import torch
+    resd = io_nc.run(gpath, hpath, tmp_path / "out5d.nc", target, cfg, diag_path=dpath, namelist=nml, fmt=5, device_io=True)
+    assert list(resd) == list(res5)
+    assert all(isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 for k, v in resd.items() if k != "P_TOP")
+    assert (tmp_path / "out5d.nc").read_bytes() == (tmp_path / "out5.nc").read_bytes()
+    inp_d, _, _ = io_nc.read_input_data(hpath, cfg, ter, diag_path=dpath, device="cuda")
+    assert inp_d.hist["theta"].dtype == torch.float32 and tuple(inp_d.hist["theta"].shape) == (m.nCells, nz)
+    assert np.array_equal(inp_d.hist["theta"].cpu().numpy(), hist["theta"]) and np.array_equal(inp_d.diag["u10"].cpu().numpy(), diag["u10"])
     mesh.destroy()
     grid.destroy()
+
+
+@pytest.mark.parametrize("dtype", ["int16", "float32", "float64"])
+def test_device_byte_swap_matches_numpy(gpu_lib, dtype):
+    import torch
+
+    from mpassit_amd import io_nc
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 255, 65537 * 3 + 1):
+        a = (rng.standard_normal(n) * 1000).astype(dtype)
+        t = torch.as_tensor(a, device="cuda")
+        io_nc.bswap_(t)
+        torch.cuda.synchronize()
+        assert t.cpu().numpy().tobytes() == a.byteswap().tobytes()
+        io_nc.bswap_(t)
+        assert np.array_equal(t.cpu().numpy(), a)
