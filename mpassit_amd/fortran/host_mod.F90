@@ -144,128 +144,45 @@ contains
   end function is_in
 end module varlists
 
-!> Target-grid coordinates of the four staggers and the wind-rotation angle.
+!> Target grid of a `lambert` / `lat-lon` namelist (define_target_grid_params, model_grid.F90:736-1038): the four
+!! staggers, cos/sin(alpha) and the map factors are evaluated on the GPU from the projection scalars
+!! (mpg_grid_create_proj); the host keeps copies of what the output file carries (write_data.F90:1003-1140).
 module target_grid
+  use, intrinsic :: iso_c_binding
   use program_setup
+  use mpg
   implicit none
   public
-  integer, parameter :: ST_M = 1, ST_U = 2, ST_V = 3, ST_CORNER = 6
-  real(dp) :: cone, polei, polej, rsw, rebydx, hemi
-  real(dp), allocatable :: lat_m(:, :), lon_m(:, :), lat_u(:, :), lon_u(:, :), lat_v(:, :), lon_v(:, :), lat_c(:, :), lon_c(:, :)
-  real(dp), allocatable :: cosa(:, :), sina(:, :)
+  real(dp), allocatable :: lat_m(:, :), lon_m(:, :), lat_u(:, :), lon_u(:, :), lat_v(:, :), lon_v(:, :)
+  real(dp), allocatable :: cosa(:, :), sina(:, :), mapfac_m(:, :), mapfac_u(:, :), mapfac_v(:, :)
 contains
-  subroutine set_projection()
-    real(dp) :: dl, arg, lon1, slon
-    if (proj_code /= PROJ_LC) return
-    hemi = 1.0_dp
-    if (truelat1 < 0.0_dp) hemi = -1.0_dp
-    rebydx = EARTH_RADIUS_M/dxkm
-    if (abs(truelat1 - truelat2) > 0.1_dp) then
-      cone = (log10(cos(truelat1*RAD_PER_DEG)) - log10(cos(truelat2*RAD_PER_DEG)))/ &
-             (log10(tan((45.0_dp - abs(truelat1)/2.0_dp)*RAD_PER_DEG)) - log10(tan((45.0_dp - abs(truelat2)/2.0_dp)*RAD_PER_DEG)))
-    else
-      cone = sin(abs(truelat1)*RAD_PER_DEG)
-    end if
-    lon1 = wrap180(known_lon); slon = wrap180(stand_lon)
-    dl = lon1 - slon
-    if (dl > 180.0_dp) dl = dl - 360.0_dp
-    if (dl < -180.0_dp) dl = dl + 360.0_dp
-    rsw = rebydx*cos(truelat1*RAD_PER_DEG)/cone* &
-          (tan((90.0_dp*hemi - known_lat)*RAD_PER_DEG/2.0_dp)/tan((90.0_dp*hemi - truelat1)*RAD_PER_DEG/2.0_dp))**cone
-    arg = cone*(dl*RAD_PER_DEG)
-    polei = hemi*known_x - hemi*rsw*sin(arg)
-    polej = hemi*known_y + rsw*cos(arg)
-  end subroutine set_projection
-
-  real(dp) function wrap180(x) result(y)
-    real(dp), intent(in) :: x
-    integer :: it
-    y = x
-    it = 0
-    do while (abs(y) > 180.0_dp .and. it < 10)
-      if (y < -180.0_dp) y = y + 360.0_dp
-      if (y > 180.0_dp) y = y - 360.0_dp
-      it = it + 1
-    end do
-  end function wrap180
-
-  subroutine ij_to_latlon(i, j, lat, lon)
-    real(dp), intent(in) :: i, j
-    real(dp), intent(out) :: lat, lon
-    real(dp) :: chi1, chi2, chi, xx, yy, r2, r, iw, span
+  subroutine define_target_grid_params(grid_h)
+    type(c_ptr), intent(out) :: grid_h
+    type(mpg_proj) :: p
+    integer(c_int) :: flags
+    p%code = int(proj_code, c_int)                           ! the arguments of map_set (model_grid.F90:676-678)
+    p%known_lat = known_lat; p%known_lon = known_lon; p%known_x = known_x; p%known_y = known_y
+    p%dx_m = 0.0_dp; p%stand_lon = 0.0_dp; p%truelat1 = 0.0_dp; p%truelat2 = 0.0_dp; p%dlat_deg = 0.0_dp; p%dlon_deg = 0.0_dp
     if (proj_code == PROJ_LC) then
-      chi1 = (90.0_dp - hemi*truelat1)*RAD_PER_DEG
-      chi2 = (90.0_dp - hemi*truelat2)*RAD_PER_DEG
-      xx = hemi*i - polei
-      yy = polej - hemi*j
-      r2 = xx*xx + yy*yy
-      r = sqrt(r2)/rebydx
-      if (r2 == 0.0_dp) then
-        lat = hemi*90.0_dp; lon = wrap180(stand_lon)
-      else
-        lon = wrap180(stand_lon) + DEG_PER_RAD*atan2(hemi*xx, yy)/cone
-        lon = mod(lon + 360.0_dp, 360.0_dp)
-        if (chi1 == chi2) then
-          chi = 2.0_dp*atan((r/tan(chi1))**(1.0_dp/cone)*tan(chi1*0.5_dp))
-        else
-          chi = 2.0_dp*atan((r*cone/sin(chi1))**(1.0_dp/cone)*tan(chi1*0.5_dp))
-        end if
-        lat = (90.0_dp - chi*DEG_PER_RAD)*hemi
-      end if
-      if (lon > 180.0_dp) lon = lon - 360.0_dp
-      if (lon < -180.0_dp) lon = lon + 360.0_dp
+      p%dx_m = dxkm; p%stand_lon = stand_lon; p%truelat1 = truelat1; p%truelat2 = truelat2
     else
-      span = real(nint(360.0_dp/dlondeg), dp)
-      iw = i
-      if (i < 0.5_dp) iw = i + span
-      if (i >= span + 0.5_dp) iw = i - span
-      lat = known_lat + (j - known_y)*dlatdeg
-      lon = wrap180(known_lon) + (iw - known_x)*dlondeg
+      p%dlat_deg = dlatdeg; p%dlon_deg = dlondeg
     end if
-  end subroutine ij_to_latlon
-
-  subroutine stagger_fields(ni, nj, stagger, lat, lon)
-    integer, intent(in) :: ni, nj, stagger
-    real(dp), allocatable, intent(out) :: lat(:, :), lon(:, :)
-    integer :: i, j
-    real(dp) :: x, y
-    allocate (lat(ni, nj), lon(ni, nj))
-    do j = 1, nj
-      do i = 1, ni
-        x = real(i, dp); y = real(j, dp)
-        if (stagger == ST_U) x = x - 0.5_dp
-        if (stagger == ST_V) y = y - 0.5_dp
-        if (stagger == ST_CORNER) then
-          x = x - 0.5_dp; y = y - 0.5_dp
-        end if
-        call ij_to_latlon(x, y, lat(i, j), lon(i, j))
-      end do
-    end do
-  end subroutine stagger_fields
-
-  subroutine define_target_grid_params()
-    integer :: i, j, jm, jp
-    real(dp) :: d_lon, alpha
-    call set_projection()
-    call stagger_fields(i_target, j_target, ST_M, lat_m, lon_m)
-    call stagger_fields(i_target, j_target + 1, ST_V, lat_v, lon_v)
-    call stagger_fields(i_target + 1, j_target, ST_U, lat_u, lon_u)
-    call stagger_fields(i_target + 1, j_target + 1, ST_CORNER, lat_c, lon_c)
-    if (proj_code == PROJ_LC) then
+    flags = 0
+    if (.not. is_regional) flags = MPG_GRID_PERIODIC_I       ! ESMF_GridCreate1PeriDim (model_grid.F90:685-694)
+    call mpg_check(mpg_grid_create_proj(p, int(i_target, c_int), int(j_target, c_int), flags, grid_h), "IN GridCreate")
+    allocate (lat_m(i_target, j_target), lon_m(i_target, j_target), mapfac_m(i_target, j_target))
+    allocate (lat_u(i_target + 1, j_target), lon_u(i_target + 1, j_target), mapfac_u(i_target + 1, j_target))
+    allocate (lat_v(i_target, j_target + 1), lon_v(i_target, j_target + 1), mapfac_v(i_target, j_target + 1))
+    call mpg_check(mpg_grid_get_coords(grid_h, MPG_STAGGERLOC_CENTER, lon_m, lat_m), "IN GridGetCoord")
+    call mpg_check(mpg_grid_get_coords(grid_h, MPG_STAGGERLOC_EDGE1, lon_u, lat_u), "IN GridGetCoord")
+    call mpg_check(mpg_grid_get_coords(grid_h, MPG_STAGGERLOC_EDGE2, lon_v, lat_v), "IN GridGetCoord")
+    call mpg_check(mpg_grid_get_mapfac(grid_h, MPG_STAGGERLOC_CENTER, mapfac_m), "IN get_map_factor")
+    call mpg_check(mpg_grid_get_mapfac(grid_h, MPG_STAGGERLOC_EDGE1, mapfac_u), "IN get_map_factor")
+    call mpg_check(mpg_grid_get_mapfac(grid_h, MPG_STAGGERLOC_EDGE2, mapfac_v), "IN get_map_factor")
+    if (proj_code == PROJ_LC) then                           ! get_rotang only runs for Lambert (model_grid.F90:1113)
       allocate (cosa(i_target, j_target), sina(i_target, j_target))
-      do j = 1, j_target
-        jm = max(j - 1, 1); jp = min(j + 1, j_target)
-        do i = 1, i_target
-          d_lon = lon_m(i, jp) - lon_m(i, jm)
-          if (d_lon > 180.0_dp) then
-            d_lon = d_lon - 360.0_dp
-          else if (d_lon < -180.0_dp) then
-            d_lon = d_lon + 360.0_dp
-          end if
-          alpha = atan2(-cos(lat_m(i, j)*RAD_PER_DEG)*(d_lon*RAD_PER_DEG), (lat_m(i, jp) - lat_m(i, jm))*RAD_PER_DEG)
-          sina(i, j) = sin(alpha); cosa(i, j) = cos(alpha)
-        end do
-      end do
+      call mpg_check(mpg_grid_get_rotang(grid_h, cosa, sina), "IN get_rotang")
     end if
   end subroutine define_target_grid_params
 end module target_grid

@@ -12,6 +12,8 @@ module model_data
     integer :: nlev = 1
     integer :: stagger = 0                      ! MPG_STAGGERLOC_* of the destination
     real(dp), allocatable :: src(:)             ! MPAS file order: (nlev, nCells) level-fastest, or (nCells) for 2-D
+    real(c_float), allocatable :: src4(:)       ! the same when the file variable is NF90_FLOAT (kept single: half the
+                                                ! host memory and PCIe bytes; the Regrid kernel widens in its loads)
     real(dp), allocatable :: dst(:)             ! (nx, ny, nlev) i-fastest
   end type field_t
   type bundle_t
@@ -21,9 +23,24 @@ module model_data
 
   type(c_ptr) :: input_grid = c_null_ptr, target_grid_h = c_null_ptr   ! ESMF_Mesh / ESMF_Grid stand-ins
   integer :: nCells_input = 0, nVert_input = 0, maxEdges_input = 0, nz_input = 0, nzp1_input = 0, nsoil_input = 0
-  type(bundle_t) :: diag_bundle, hist_2d_patch, hist_2d_cons, hist_2d_nstd, hist_3d_nz, hist_3d_nzp1, hist_3d_vert, hist_soil
-  type(field_t) :: hgt, u_field, v_field, umass, vmass
+  type(bundle_t), target :: diag_bundle, hist_2d_patch, hist_2d_cons, hist_2d_nstd, hist_3d_nz, hist_3d_nzp1, hist_3d_vert, hist_soil
+  type(field_t), target :: hgt, u_field, v_field, umass, vmass
+  real(dp), allocatable :: zs_input(:)          ! soil layer depths of the grid file (ZS of the output, write_data.F90:1130)
   integer :: do_u_interp = 0, do_v_interp = 0, u10_ind = 0, v10_ind = 0
+
+contains
+
+  !> a -> b without copying the arrays; a is left empty
+  subroutine move_field(a, b)
+    type(field_t), intent(inout) :: a, b
+    b%name = a%name; b%tname = a%tname; b%nlev = a%nlev; b%stagger = a%stagger
+    if (allocated(b%src)) deallocate (b%src)
+    if (allocated(b%src4)) deallocate (b%src4)
+    if (allocated(b%dst)) deallocate (b%dst)
+    if (allocated(a%src)) call move_alloc(a%src, b%src)
+    if (allocated(a%src4)) call move_alloc(a%src4, b%src4)
+    if (allocated(a%dst)) call move_alloc(a%dst, b%dst)
+  end subroutine move_field
 end module model_data
 
 module interp
@@ -57,7 +74,7 @@ contains
 
   subroutine regrid_field(rh, f)
     type(c_ptr), intent(in) :: rh
-    type(field_t), intent(inout) :: f
+    type(field_t), intent(inout), target :: f
     integer(c_int64_t) :: n_src, n_dst, nnz
     integer(c_int) :: nxd, nyd, npr, layout
     call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
@@ -65,7 +82,12 @@ contains
     allocate (f%dst(n_dst*f%nlev))
     layout = MPG_LAYOUT_LEV_FAST
     if (f%nlev == 1) layout = MPG_LAYOUT_CELL_FAST
-    call mpg_check(mpg_regrid(rh, f%src, layout, int(f%nlev, c_int), 1_c_int, f%dst), "IN FieldRegrid "//trim(f%name))
+    if (allocated(f%src4)) then
+      call mpg_check(mpg_regrid_typed(rh, c_loc(f%src4), 1_c_int, layout, int(f%nlev, c_int), 1_c_int, c_loc(f%dst), 0_c_int, &
+                                      1.0_c_double, 0.0_c_double), "IN FieldRegrid "//trim(f%name))
+    else
+      call mpg_check(mpg_regrid(rh, f%src, layout, int(f%nlev, c_int), 1_c_int, f%dst), "IN FieldRegrid "//trim(f%name))
+    end if
   end subroutine regrid_field
 
   subroutine interp_diag_data()

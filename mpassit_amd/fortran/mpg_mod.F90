@@ -109,6 +109,17 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid
 
+    !> Regrid on host buffers of the files' own types: src_f32 / dst_f32 = 1 for real(c_float) arrays (MPAS history
+    !! variables are NF90_FLOAT), 0 for real(c_double); float64 arithmetic, dst = regrid(src)*scale + offset.
+    function mpg_regrid_typed(rh, src, src_f32, src_layout, nlev, nfields, dst, dst_f32, scale, offset) &
+      bind(C, name="mpg_regrid_typed") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: rh, src, dst
+      integer(c_int), value :: src_f32, src_layout, nlev, nfields, dst_f32
+      real(c_double), value :: scale, offset
+      integer(c_int) :: rc
+    end function mpg_regrid_typed
+
     function mpg_handle_release(rh) bind(C, name="mpg_handle_release") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: rh

@@ -4,7 +4,7 @@
 !!   nc_write_target  write_data.F90:173-1498  dimensions, global attributes, grid variables, every target field with
 !!                                             the writer's post-ops (T-300 :1343, MU/PH/P = 0 :1354,:1427,:1466,
 !!                                             P_TOP :1362-1371, PB, Z_C :1406-1415, PHB*9.81 :1418), NF90_FLOAT
-!! The output is CDF-5 (the reference writes NetCDF-4, which needs HDF5: not in this image).
+!! The output is CDF-5 (the reference writes NetCDF-4, an HDF5 container: no libnetcdf in this image, DESIGN.md s7).
 module ncfiles
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: int64
@@ -16,6 +16,9 @@ module ncfiles
   private
   public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target
 
+  type fref
+    type(field_t), pointer :: p => null()
+  end type fref
   type(c_ptr) :: nf_out = c_null_ptr
   integer(c_int) :: d_time, d_we, d_wes, d_sn, d_sns, d_bt, d_bts, d_soil, d_str
 
@@ -49,7 +52,7 @@ contains
     real(dp), allocatable, intent(out) :: latCell(:), lonCell(:), latVertex(:), lonVertex(:)
     integer(c_int32_t), allocatable, intent(out) :: voc(:)
     type(c_ptr) :: nf
-    integer(c_int64_t) :: nc, nv, me
+    integer(c_int64_t) :: nc, nv, me, ns
     integer(c_int) :: id
     call ncio_check(ncio_open(file, nf), "opening grid file")
     call ncio_check(ncio_inq_dim(nf, "nCells", nc), "reading nCells")
@@ -65,6 +68,7 @@ contains
     call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_INT, voc), "reading verticesOnCell")
     call get_f64(nf, "ter", hgt%src, nc)
     hgt%name = "ter"; hgt%tname = "HGT"; hgt%nlev = 1
+    if (ncio_inq_varid(nf, "zs", id) == 0 .and. ncio_inq_dim(nf, "nSoilLevels", ns) == 0) call get_f64(nf, "zs", zs_input, ns)
     call ncio_check(ncio_close(nf), "closing grid file")
   end subroutine nc_read_grid
 
@@ -87,8 +91,13 @@ contains
       f%nlev = int(shp(d0 + 1))                  ! file order [nCells][nlev] == Fortran (nlev, nCells)
       n = shp(d0)*shp(d0 + 1)
     end if
-    allocate (f%src(n))
-    call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, f%src), "reading field - "//trim(name))
+    if (xtype == NCIO_FLOAT) then                 ! stays single precision: the Regrid widens it on the GPU
+      allocate (f%src4(n))
+      call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_FLOAT, f%src4), "reading field - "//trim(name))
+    else
+      allocate (f%src(n))
+      call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, f%src), "reading field - "//trim(name))
+    end if
   end subroutine nc_load_field
 
   ! ---- output ---------------------------------------------------------------------------------------------------
@@ -127,9 +136,10 @@ contains
   subroutine nc_write_target(file, valid_time)
     character(len=*), intent(in) :: file, valid_time
     integer, parameter :: MAXV = 512
-    integer(c_int) :: ids(MAXV), id_extra(8), id_grid(8), id_times, id_ptop
+    integer(c_int) :: ids(MAXV), id_extra(8), id_grid(8), id_mf(3), id_zs, id_times, id_ptop
+    real(dp), allocatable :: zs(:)
     integer :: nv, i, k, npts
-    type(field_t), allocatable :: fl(:)
+    type(fref), allocatable :: fl(:)
     real(dp), allocatable :: tmp(:)
     real(dp) :: ptop
     character(len=19) :: tstr
@@ -172,6 +182,8 @@ contains
     if (proj_code == PROJ_LC) then
       call def_field("SINALPHA", 1, 0, id_grid(7)); call def_field("COSALPHA", 1, 0, id_grid(8))
     end if
+    call def_field("MAPFAC_M", 1, 0, id_mf(1)); call def_field("MAPFAC_U", 1, 1, id_mf(2)); call def_field("MAPFAC_V", 1, 2, id_mf(3))
+    call ncio_check(ncio_def_var(nf_out, "ZS", NCIO_FLOAT, [d_time, d_soil], id_zs), "DEFINING ZS")
     call ncio_check(ncio_def_var(nf_out, "Times", NCIO_CHAR, [d_time, d_str], id_times), "DEFINING Times")
     ! target fields in the writer's order (:1150-1475)
     call collect(fl, nv)
@@ -179,16 +191,16 @@ contains
     have_ptop = .false.
     id_extra = -1
     do i = 1, nv
-      call def_field(trim(fl(i)%tname), fl(i)%nlev, fl(i)%stagger, ids(i))
-      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'MUB') call def_field("MU", fl(i)%nlev, 0, id_extra(1))
-      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'P_HYD') then
+      call def_field(trim(fl(i)%p%tname), fl(i)%p%nlev, fl(i)%p%stagger, ids(i))
+      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'MUB') call def_field("MU", fl(i)%p%nlev, 0, id_extra(1))
+      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'P_HYD') then
         call ncio_check(ncio_def_var(nf_out, "P_TOP", NCIO_FLOAT, [d_time], id_ptop), "DEFINING P_TOP")
-        call def_field("PB", fl(i)%nlev, 0, id_extra(2))
+        call def_field("PB", fl(i)%p%nlev, 0, id_extra(2))
         have_ptop = .true.
       end if
-      if (trim(fl(i)%tname) == 'PHB') then
+      if (trim(fl(i)%p%tname) == 'PHB') then
         call def_field("Z_C", nzp1_input, 0, id_extra(3))                                        ! on bottom_top_stag (:479)
-        if (wrf_mod_vars) call def_field("PH", fl(i)%nlev, 0, id_extra(4))
+        if (wrf_mod_vars) call def_field("PH", fl(i)%p%nlev, 0, id_extra(4))
       end if
     end do
     if (wrf_mod_vars .and. hist_3d_nz%n > 0) call def_field("P", nz_input, 0, id_extra(5))
@@ -200,45 +212,49 @@ contains
     if (proj_code == PROJ_LC) then
       call put_r8(id_grid(7), sina); call put_r8(id_grid(8), cosa)
     end if
+    call put_r8(id_mf(1), mapfac_m); call put_r8(id_mf(2), mapfac_u); call put_r8(id_mf(3), mapfac_v)
+    allocate (zs(nsoil_input)); zs = 0.0_dp
+    if (allocated(zs_input)) zs(1:min(size(zs_input), nsoil_input)) = zs_input(1:min(size(zs_input), nsoil_input))
+    call put_r8(id_zs, zs)
     tstr = valid_time
     tbytes = transfer(tstr, tbytes)
     call ncio_check(ncio_put_var(nf_out, id_times, 0_c_int64_t, NCIO_CHAR, tbytes), "WRITING Times")
     npts = i_target*j_target
     do i = 1, nv
-      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'T') then
-        tmp = fl(i)%dst - 300.0_dp                                                               ! :1339-1347
+      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'T') then
+        tmp = fl(i)%p%dst - 300.0_dp                                                               ! :1339-1347
         call put_r8(ids(i), tmp)
-      else if (trim(fl(i)%tname) == 'PHB') then
+      else if (trim(fl(i)%p%tname) == 'PHB') then
         if (allocated(tmp)) deallocate (tmp)
         allocate (tmp(npts*nzp1_input))
         tmp = 0.0_dp
-        do k = 2, fl(i)%nlev                                                                     ! :1406-1412
-          tmp((k - 2)*npts + 1:(k - 1)*npts) = 0.5_dp*(fl(i)%dst((k - 1)*npts + 1:k*npts) + fl(i)%dst((k - 2)*npts + 1:(k - 1)*npts))
+        do k = 2, fl(i)%p%nlev                                                                     ! :1406-1412
+          tmp((k - 2)*npts + 1:(k - 1)*npts) = 0.5_dp*(fl(i)%p%dst((k - 1)*npts + 1:k*npts) + fl(i)%p%dst((k - 2)*npts + 1:(k - 1)*npts))
         end do
         call put_r8(id_extra(3), tmp)
-        tmp = fl(i)%dst*9.81_dp                                                                  ! :1418
-        call put_r8(ids(i), tmp(1:size(fl(i)%dst)))
+        tmp = fl(i)%p%dst*9.81_dp                                                                  ! :1418
+        call put_r8(ids(i), tmp(1:size(fl(i)%p%dst)))
         if (wrf_mod_vars) then
           tmp = 0.0_dp
           call put_r8(id_extra(4), tmp)
         end if
         deallocate (tmp)
       else
-        call put_r8(ids(i), fl(i)%dst)
+        call put_r8(ids(i), fl(i)%p%dst)
       end if
-      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'MUB') then
+      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'MUB') then
         if (allocated(tmp)) deallocate (tmp)
-        allocate (tmp(size(fl(i)%dst))); tmp = 0.0_dp
+        allocate (tmp(size(fl(i)%p%dst))); tmp = 0.0_dp
         call put_r8(id_extra(1), tmp)
         deallocate (tmp)
       end if
-      if (wrf_mod_vars .and. trim(fl(i)%tname) == 'P_HYD') then                                  ! :1362-1379
-        ptop = maxval(fl(i)%dst)
-        do k = (fl(i)%nlev - 1)*npts + 1, fl(i)%nlev*npts
-          if (fl(i)%dst(k) >= 10.0_dp) ptop = min(fl(i)%dst(k)*0.80_dp, ptop)
+      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'P_HYD') then                                  ! :1362-1379
+        ptop = maxval(fl(i)%p%dst)
+        do k = (fl(i)%p%nlev - 1)*npts + 1, fl(i)%p%nlev*npts
+          if (fl(i)%p%dst(k) >= 10.0_dp) ptop = min(fl(i)%p%dst(k)*0.80_dp, ptop)
         end do
         call ncio_check(ncio_put_var(nf_out, id_ptop, 0_c_int64_t, NCIO_DOUBLE, [ptop]), "WRITING P_TOP")
-        call put_r8(id_extra(2), fl(i)%dst)
+        call put_r8(id_extra(2), fl(i)%p%dst)
       end if
     end do
     if (id_extra(5) >= 0) then
@@ -249,9 +265,9 @@ contains
     call ncio_check(ncio_close(nf_out), "CLOSING FILE")
   end subroutine nc_write_target
 
-  !> every target field in the order write_target_data emits them
+  !> every target field in the order write_target_data emits them (references, no copies)
   subroutine collect(fl, nv)
-    type(field_t), allocatable, intent(out) :: fl(:)
+    type(fref), allocatable, intent(out) :: fl(:)
     integer, intent(out) :: nv
     integer :: cap
     cap = 8 + diag_bundle%n + hist_2d_patch%n + hist_2d_cons%n + hist_2d_nstd%n + hist_3d_nz%n + hist_3d_nzp1%n + hist_3d_vert%n + hist_soil%n
@@ -272,16 +288,15 @@ contains
     end if
   contains
     subroutine add(f, stag)
-      type(field_t), intent(in) :: f
+      type(field_t), intent(inout), target :: f
       integer, intent(in) :: stag
       if (.not. allocated(f%dst)) return
       nv = nv + 1
-      fl(nv)%name = f%name; fl(nv)%tname = f%tname; fl(nv)%nlev = f%nlev
-      fl(nv)%dst = f%dst
-      fl(nv)%stagger = stag
+      f%stagger = stag
+      fl(nv)%p => f
     end subroutine add
     subroutine add_bundle(b, sel)
-      type(bundle_t), intent(in) :: b
+      type(bundle_t), intent(inout), target :: b
       integer, intent(in) :: sel                 ! 0 all, 1 only 2-D, 2 only 3-D
       integer :: q
       do q = 1, b%n

@@ -7,7 +7,7 @@ Mirrors the nf90 calls of the reference with the classic-format library of this 
                                                  transpose of :653-655 is not done
   write_target_data  write_data.F90:173-1498    dimensions, global attributes, grid variables, fields after the
                                                  post-ops of post.output_fields; NF90_FLOAT everywhere
-Differences, all forced by the build image (no libnetcdf / HDF5): files are NetCDF CLASSIC (CDF-5 by default, CDF-2 on
+Differences, all forced by the build image (no libnetcdf): files are NetCDF CLASSIC (CDF-5 by default, CDF-2 on
 request), not NetCDF-4; input files in NetCDF-4 have to be converted (`nccopy -k cdf5`) -- ncio says so when it meets
 one.  `write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
 import os

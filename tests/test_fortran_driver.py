@@ -104,16 +104,13 @@ def test_driver_matches_python_mirror(tmp_path, gpu_lib, regional_case):
     got = rawio.read(os.path.join(d, "out.raw"))
     inp = I.InputData(nz=6, nzp1=7, nsoil=4, hgt=ter, layout=R.LAYOUT_LEV_FAST, hist=hist, diag=diag)
     cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
-    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
-    want = I.interp_data(mesh, grid, g, inp, cfg)
+    import copy
+    gd = copy.copy(g)            # both hosts evaluate the projection on the device (mpg_grid_create_proj)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(gd)
+    want = I.interp_data(mesh, grid, gd, inp, cfg)
     mesh.destroy()
     grid.destroy()
     assert set(want) == set(got)
     for k, w in want.items():
         assert got[k].shape == w.shape, k
-        if k in ("XLAND", "TSLB", "SMOIS", "SH2O"):
-            assert np.array_equal(got[k], w), k                  # nearest: bit exact
-        else:
-            # the two hosts (flang runtime vs numpy) differ in the last ulp of pow/atan of the projection, which the
-            # area ratios of the conservative weights amplify to ~1e-12; far inside the 1e-6 north_star tolerance
-            assert np.abs(got[k] - w).max() <= 1e-10 * max(1.0, np.abs(w).max()), k
+        assert np.array_equal(got[k], w), k                      # same kernels on the same grid and inputs: bit exact

@@ -1,7 +1,7 @@
 """The Fortran driver on NetCDF files: `mpassit namelist.input` reads an MPAS grid / history / diag file set (classic
 format, written here with this repo's writer), regrids on the GPU through the ISO_C_BINDING boundary and writes a
 WRF-style CDF-5 file with the reference's post-ops; the result must equal the Python mirror (io_nc + post) bit for bit
-in float32 (same device kernels, same float64 -> float32 conversion) up to the hosts' projection libm differences."""
+in float32 (same device kernels, same device-built target grid, same float64 -> float32 conversion)."""
 import os
 import subprocess
 
@@ -53,8 +53,11 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
     cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
     inp, _, valid = io_nc.read_input_data(os.path.join(d, "hist.nc"), cfg, ter, diag_path=os.path.join(d, "diag.nc"))
     assert valid == "2024-08-07_12:00:00"
-    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
-    want = post.output_fields(I.interp_data(mesh, grid, g, inp, cfg), cfg)
+    import copy
+    gd = copy.copy(g)                                                   # both hosts build the target grid on the device
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(gd)
+    want = post.output_fields(I.interp_data(mesh, grid, gd, inp, cfg), cfg)
+    mapfac_u = grid.mapfac(R.STAGGERLOC_EDGE1)
     mesh.destroy()
     grid.destroy()
     with ncio.Reader(os.path.join(d, "out.nc")) as f:
@@ -75,11 +78,9 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
                 assert got.shape[0] == nz + 1 and not got[nz].any()
                 got = got[:nz]
             assert got.shape == w.shape and got.dtype == np.float32, k
-            if k in ("XLAND", "TSLB", "SMOIS", "SH2O", "MU", "PH", "P"):
-                assert np.array_equal(got, w), k                        # nearest copies and zero fields: bit exact
-            else:
-                tol = 2e-7 * max(1.0, float(np.abs(w).max()))           # one float32 ulp: the hosts' libm differs in the
-                assert np.abs(got - w).max() <= tol, k                  # projection's last bit (test_fortran_driver.py)
+            assert np.array_equal(got, w), k                            # same kernels, same grid, same casts: bit exact
+        assert np.array_equal(f.get("MAPFAC_U", rec=0), mapfac_u.astype(np.float32))
+        np.testing.assert_allclose(f.get("ZS", rec=0), [0.05, 0.25, 0.7, 1.5], rtol=1e-6)
         assert f.vars["U"]["dims"] == ("Time", "bottom_top", "south_north", "west_east_stag")
         assert f.vars["V"]["dims"] == ("Time", "bottom_top", "south_north_stag", "west_east")
         assert f.vars["TSLB"]["dims"][1] == "soil_layers_stag" and f.vars["PHB"]["dims"][1] == "bottom_top_stag"
