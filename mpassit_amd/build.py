@@ -65,7 +65,7 @@ def build_ncio(force=False):
     """Host-side NetCDF classic I/O (plain C, gcc): mpassit_amd/hostio/libmpassit_ncio.so."""
     hdr = os.path.join(HERE, "..", "include", "mpassit_ncio.h")
     if force or not _newer(NCIO_SO, [NCIO_SRC, hdr]):
-        r = subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-o", NCIO_SO, NCIO_SRC], capture_output=True, text=True)
+        r = subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-pthread", "-o", NCIO_SO, NCIO_SRC], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("gcc failed:\n%s" % r.stderr[-4000:])
     return NCIO_SO

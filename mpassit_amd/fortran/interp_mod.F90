@@ -15,6 +15,7 @@ module model_data
     real(c_float), allocatable :: src4(:)       ! the same when the file variable is NF90_FLOAT (kept single: half the
                                                 ! host memory and PCIe bytes; the Regrid kernel widens in its loads)
     real(dp), allocatable :: dst(:)             ! (nx, ny, nlev) i-fastest
+    real(c_float), allocatable :: dst4(:)       ! the same as the NF90_FLOAT the output file holds (f32_out), instead of dst
   end type field_t
   type bundle_t
     integer :: n = 0
@@ -27,8 +28,20 @@ module model_data
   type(field_t), target :: hgt, u_field, v_field, umass, vmass
   real(dp), allocatable :: zs_input(:)          ! soil layer depths of the grid file (ZS of the output, write_data.F90:1130)
   integer :: do_u_interp = 0, do_v_interp = 0, u10_ind = 0, v10_ind = 0
+  !> the output is a NetCDF file (every variable NF90_FLOAT, write_data.F90:587-980): fields nothing else needs in
+  !! float64 come back from the Regrid as float32 with the writer's affine post-op fused (T - 300, write_data.F90:1343)
+  logical :: f32_out = .false.
 
 contains
+
+  !> fields the host still works on in float64 after the Regrid: rotated winds (interp.F90:138-140,291-293),
+  !! PHB (Z_C and PHB*9.81, write_data.F90:1406-1418), P_HYD (P_TOP, :1362-1371)
+  logical function keeps_r8(f)
+    type(field_t), intent(in) :: f
+    keeps_r8 = .not. f32_out .or. trim(f%name) == 'u10' .or. trim(f%name) == 'v10' .or. &
+               trim(f%name) == 'uReconstructZonal' .or. trim(f%name) == 'uReconstructMeridional' .or. &
+               trim(f%tname) == 'PHB' .or. trim(f%tname) == 'P_HYD'
+  end function keeps_r8
 
   !> a -> b without copying the arrays; a is left empty
   subroutine move_field(a, b)
@@ -37,9 +50,11 @@ contains
     if (allocated(b%src)) deallocate (b%src)
     if (allocated(b%src4)) deallocate (b%src4)
     if (allocated(b%dst)) deallocate (b%dst)
+    if (allocated(b%dst4)) deallocate (b%dst4)
     if (allocated(a%src)) call move_alloc(a%src, b%src)
     if (allocated(a%src4)) call move_alloc(a%src4, b%src4)
     if (allocated(a%dst)) call move_alloc(a%dst, b%dst)
+    if (allocated(a%dst4)) call move_alloc(a%dst4, b%dst4)
   end subroutine move_field
 end module model_data
 
@@ -47,7 +62,7 @@ module interp
   use, intrinsic :: iso_c_binding
   use mpg
   use model_data
-  use program_setup, only: dp, interp_diag, interp_hist, proj_code, PROJ_LC, i_target, j_target
+  use program_setup, only: dp, interp_diag, interp_hist, proj_code, PROJ_LC, i_target, j_target, wrf_mod_vars
   use target_grid, only: cosa, sina
   implicit none
   private
@@ -76,17 +91,29 @@ contains
     type(c_ptr), intent(in) :: rh
     type(field_t), intent(inout), target :: f
     integer(c_int64_t) :: n_src, n_dst, nnz
-    integer(c_int) :: nxd, nyd, npr, layout
+    integer(c_int) :: nxd, nyd, npr, layout, src_f32
+    type(c_ptr) :: sp
+    real(c_double) :: offset
     call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
     if (allocated(f%dst)) deallocate (f%dst)
-    allocate (f%dst(n_dst*f%nlev))
+    if (allocated(f%dst4)) deallocate (f%dst4)
     layout = MPG_LAYOUT_LEV_FAST
     if (f%nlev == 1) layout = MPG_LAYOUT_CELL_FAST
     if (allocated(f%src4)) then
-      call mpg_check(mpg_regrid_typed(rh, c_loc(f%src4), 1_c_int, layout, int(f%nlev, c_int), 1_c_int, c_loc(f%dst), 0_c_int, &
+      sp = c_loc(f%src4); src_f32 = 1
+    else
+      sp = c_loc(f%src); src_f32 = 0
+    end if
+    if (keeps_r8(f)) then
+      allocate (f%dst(n_dst*f%nlev))
+      call mpg_check(mpg_regrid_typed(rh, sp, src_f32, layout, int(f%nlev, c_int), 1_c_int, c_loc(f%dst), 0_c_int, &
                                       1.0_c_double, 0.0_c_double), "IN FieldRegrid "//trim(f%name))
     else
-      call mpg_check(mpg_regrid(rh, f%src, layout, int(f%nlev, c_int), 1_c_int, f%dst), "IN FieldRegrid "//trim(f%name))
+      offset = 0.0_c_double
+      if (wrf_mod_vars .and. trim(f%tname) == 'T') offset = -300.0_c_double
+      allocate (f%dst4(n_dst*f%nlev))
+      call mpg_check(mpg_regrid_typed(rh, sp, src_f32, layout, int(f%nlev, c_int), 1_c_int, c_loc(f%dst4), 1_c_int, &
+                                      1.0_c_double, offset), "IN FieldRegrid "//trim(f%name))
     end if
   end subroutine regrid_field
 
@@ -180,14 +207,21 @@ contains
   !> CENTER-stagger field -> EDGE stagger field through a Grid->Grid handle
   subroutine destagger(rh, mass, stag)
     type(c_ptr), intent(in) :: rh
-    type(field_t), intent(in) :: mass
-    type(field_t), intent(inout) :: stag
+    type(field_t), intent(in), target :: mass
+    type(field_t), intent(inout), target :: stag
     integer(c_int64_t) :: n_src, n_dst, nnz
     integer(c_int) :: nxd, nyd, npr
     call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
     if (allocated(stag%dst)) deallocate (stag%dst)
-    allocate (stag%dst(n_dst*mass%nlev))
-    call mpg_check(mpg_regrid(rh, mass%dst, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, stag%dst), "IN FieldRegrid")
+    if (allocated(stag%dst4)) deallocate (stag%dst4)
+    if (f32_out) then
+      allocate (stag%dst4(n_dst*mass%nlev))
+      call mpg_check(mpg_regrid_typed(rh, c_loc(mass%dst), 0_c_int, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, &
+                                      c_loc(stag%dst4), 1_c_int, 1.0_c_double, 0.0_c_double), "IN FieldRegrid")
+    else
+      allocate (stag%dst(n_dst*mass%nlev))
+      call mpg_check(mpg_regrid(rh, mass%dst, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, stag%dst), "IN FieldRegrid")
+    end if
   end subroutine destagger
 
   !> rotate_winds_cgrid (interp.F90:689-749) on the device

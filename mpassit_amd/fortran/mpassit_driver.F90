@@ -43,6 +43,7 @@ program mpassit
   print *, "- DEFINE INPUT GRID"
   call define_input_grid()
   call lap("DEFINE INPUT GRID")
+  f32_out = is_nc_name(output_file)
   print *, "- READ INPUT DATA"
   call read_input_data()
   call lap("READ INPUT DATA")
@@ -266,14 +267,19 @@ contains
     end do
   end subroutine put_bundle
 
+  logical function is_nc_name(file)
+    character(len=*), intent(in) :: file
+    integer :: l
+    l = len_trim(file)
+    is_nc_name = .false.
+    if (l > 3) is_nc_name = file(l - 2:l) == ".nc"
+  end function is_nc_name
+
   subroutine write_to_file()
-    integer :: u, l
-    l = len_trim(output_file)
-    if (l > 3) then
-      if (output_file(l - 2:l) == ".nc") then
-        call nc_write_target(trim(output_file), valid_time)
-        return
-      end if
+    integer :: u
+    if (is_nc_name(output_file)) then
+      call nc_write_target(trim(output_file), valid_time)
+      return
     end if
     call raw_open_write(output_file, u)
     if (interp_diag) call put_bundle(u, diag_bundle)

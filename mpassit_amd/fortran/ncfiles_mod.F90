@@ -20,6 +20,7 @@ module ncfiles
     type(field_t), pointer :: p => null()
   end type fref
   type(c_ptr) :: nf_out = c_null_ptr
+  real(dp) :: put_seconds = 0.0_dp             ! wall time inside ncio_put_var (the rest of WRITE DATA is host post-ops)
   integer(c_int) :: d_time, d_we, d_wes, d_sn, d_sns, d_bt, d_bts, d_soil, d_str
 
 contains
@@ -130,8 +131,30 @@ contains
   subroutine put_r8(id, a)
     integer(c_int), intent(in) :: id
     real(dp), intent(in) :: a(*)
+    integer(int64) :: c0, c1, cr
+    call system_clock(c0, cr)
     call ncio_check(ncio_put_var(nf_out, id, 0_c_int64_t, NCIO_DOUBLE, a), "WRITING RECORD")
+    call system_clock(c1)
+    put_seconds = put_seconds + real(c1 - c0, dp)/real(cr, dp)
   end subroutine put_r8
+
+  !> an all-zero variable (MU, PH, P of wrf_mod_vars: write_data.F90:1354,1427,1466): the record is made to exist
+  !! and left as it is in the file just created -- zeros -- instead of converting and writing a gigabyte of them
+  subroutine put_zero(id)
+    integer(c_int), intent(in) :: id
+    integer(c_int64_t) :: off, nb
+    call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
+  end subroutine put_zero
+
+  subroutine put_r4(id, a)
+    integer(c_int), intent(in) :: id
+    real(c_float), intent(in) :: a(*)
+    integer(int64) :: c0, c1, cr
+    call system_clock(c0, cr)
+    call ncio_check(ncio_put_var(nf_out, id, 0_c_int64_t, NCIO_FLOAT, a), "WRITING RECORD")
+    call system_clock(c1)
+    put_seconds = put_seconds + real(c1 - c0, dp)/real(cr, dp)
+  end subroutine put_r4
 
   subroutine nc_write_target(file, valid_time)
     character(len=*), intent(in) :: file, valid_time
@@ -221,7 +244,9 @@ contains
     call ncio_check(ncio_put_var(nf_out, id_times, 0_c_int64_t, NCIO_CHAR, tbytes), "WRITING Times")
     npts = i_target*j_target
     do i = 1, nv
-      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'T') then
+      if (allocated(fl(i)%p%dst4)) then                                                          ! came back as NF90_FLOAT, post-op fused
+        call put_r4(ids(i), fl(i)%p%dst4)
+      else if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'T') then
         tmp = fl(i)%p%dst - 300.0_dp                                                               ! :1339-1347
         call put_r8(ids(i), tmp)
       else if (trim(fl(i)%p%tname) == 'PHB') then
@@ -234,20 +259,12 @@ contains
         call put_r8(id_extra(3), tmp)
         tmp = fl(i)%p%dst*9.81_dp                                                                  ! :1418
         call put_r8(ids(i), tmp(1:size(fl(i)%p%dst)))
-        if (wrf_mod_vars) then
-          tmp = 0.0_dp
-          call put_r8(id_extra(4), tmp)
-        end if
+        if (wrf_mod_vars) call put_zero(id_extra(4))
         deallocate (tmp)
       else
         call put_r8(ids(i), fl(i)%p%dst)
       end if
-      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'MUB') then
-        if (allocated(tmp)) deallocate (tmp)
-        allocate (tmp(size(fl(i)%p%dst))); tmp = 0.0_dp
-        call put_r8(id_extra(1), tmp)
-        deallocate (tmp)
-      end if
+      if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'MUB') call put_zero(id_extra(1))
       if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'P_HYD') then                                  ! :1362-1379
         ptop = maxval(fl(i)%p%dst)
         do k = (fl(i)%p%nlev - 1)*npts + 1, fl(i)%p%nlev*npts
@@ -257,12 +274,9 @@ contains
         call put_r8(id_extra(2), fl(i)%p%dst)
       end if
     end do
-    if (id_extra(5) >= 0) then
-      if (allocated(tmp)) deallocate (tmp)
-      allocate (tmp(npts*nz_input)); tmp = 0.0_dp
-      call put_r8(id_extra(5), tmp)
-    end if
+    if (id_extra(5) >= 0) call put_zero(id_extra(5))
     call ncio_check(ncio_close(nf_out), "CLOSING FILE")
+    print '(a,f9.3,a)', "   [WRITE DATA: of which inside ncio_put_var] ", put_seconds, " s"
   end subroutine nc_write_target
 
   !> every target field in the order write_target_data emits them (references, no copies)
@@ -290,7 +304,7 @@ contains
     subroutine add(f, stag)
       type(field_t), intent(inout), target :: f
       integer, intent(in) :: stag
-      if (.not. allocated(f%dst)) return
+      if (.not. allocated(f%dst) .and. .not. allocated(f%dst4)) return
       nv = nv + 1
       f%stagger = stag
       fl(nv)%p => f

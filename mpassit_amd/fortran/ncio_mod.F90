@@ -51,6 +51,16 @@ module ncio
       type(*), dimension(*) :: buf
       integer(c_int) :: rc
     end function ncio_get_var
+    !> byte range of a variable / record inside the file; on a file being written the range is made to exist
+    !! (a fresh file reads as zeros there)
+    function ncio_var_extent(f, varid, rec, offset, nbytes) bind(C, name="ncio_var_extent") result(rc)
+      import :: c_ptr, c_int, c_int64_t
+      type(c_ptr), value :: f
+      integer(c_int), value :: varid
+      integer(c_int64_t), value :: rec
+      integer(c_int64_t), intent(out) :: offset, nbytes
+      integer(c_int) :: rc
+    end function ncio_var_extent
     function ncio_create_c(path, fmt, f) bind(C, name="ncio_create") result(rc)
       import :: c_char, c_ptr, c_int
       character(kind=c_char), intent(in) :: path(*)

@@ -95,7 +95,10 @@ def read_grid(path):
 
 def _read_field(r, name):
     v = r.vars[name]
-    return r.get(name, rec=0, dtype=np.float64) if v["record"] else r.get(name, dtype=np.float64)   # widened like nf90_get_var -> r8
+    # NF90_FLOAT variables stay single precision on the host (half the memory and PCIe bytes); the Regrid widens them in
+    # its loads, which is the nf90_get_var -> r8 conversion of input_data.F90:630 done on the GPU.  Other types -> r8.
+    dt = np.float32 if v["type"] == ncio.FLOAT else np.float64
+    return r.get(name, rec=0, dtype=dt) if v["record"] else r.get(name, dtype=dt)
 
 
 _RAW_TYPES = {ncio.FLOAT: ("float32", 4), ncio.DOUBLE: ("float64", 8)}

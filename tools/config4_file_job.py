@@ -84,6 +84,11 @@ def main():
             f.write("".join("%s\t\t%s\n" % p for p in lst))
     open(os.path.join(d, "namelist.input"), "w").write(NAMELIST.format(d=d))
 
+    for nt in [v for v in os.environ.get("C4JOB_NCIO_THREADS", "").split(",") if v]:   # optional sweep of ncio's thread count
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=900, env=dict(os.environ, NCIO_THREADS=nt))
+        print("fortran driver, NCIO_THREADS=%s: %.2f s   %s" % (nt, time.perf_counter() - t0, "  ".join(
+            ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("["))), flush=True)
     t0 = time.perf_counter()
     r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=900)
     t_f = time.perf_counter() - t0
