@@ -1,10 +1,11 @@
-!> Host-side support modules of the Fortran driver: namelist, variable lists, target-grid coordinates and
-!! a raw-binary stand-in for NetCDF (no NetCDF library exists in the build image; I/O is outside the hot
-!! path, SURVEY s8(f)).  All of it is a fresh restatement of what the reference computes on the host:
+!> Host-side support modules of the Fortran driver: namelist, variable lists, target grid and a raw-binary array
+!! container (the first file surface of this build; NetCDF classic files go through ncio_mod / ncfiles_mod).
 !!   program_setup  <- program_setup.F90:87-249 (namelist &config :103-106, derived sizes :163-164,:238-240)
 !!   varlists       <- input_data.F90:1146-1194 (read_varlist), :840-911 (classification)
-!!   target_grid    <- model_grid.F90:644-1201,2188-2219,2450-2507 via llxy_module.F90:166-216 and
-!!                     module_map_utils.F90:1083-1233,1398-1428 (Lambert + lat-lon only)
+!!   target_grid    <- model_grid.F90:644-1201: 'lambert' / 'lat-lon' grids are evaluated on the GPU from the projection
+!!                     scalars (mpg_grid_create_proj replaces get_lat_lon_fields :2188-2219, get_rotang :2450-2507 and
+!!                     get_map_factor :2229-2365); 'file' grids are read from a WRF-style file (:1203-1888) and their
+!!                     corners rebuilt by get_cell_corners (:1902-1972)
 !! Reals are real(8) explicitly (the reference promotes with -r8 / -fdefault-real-8, CMakeLists.txt:80-82).
 
 module program_setup
@@ -21,6 +22,7 @@ module program_setup
   character(len=500) :: target_grid_type = "lambert"
   logical :: interp_diag = .false., interp_hist = .false., wrf_mod_vars = .false., is_regional = .true.
   logical :: interp_as_bundle = .true., esmf_log = .false.
+  logical :: target_from_file = .false.            ! target_grid_type = 'file'
   integer :: i_target = 0, j_target = 0, proj_code = PROJ_LC
   real(dp) :: truelat1 = NAN, truelat2 = NAN, stand_lon = NAN, ref_lat = NAN, ref_lon = NAN, ref_x = NAN, ref_y = NAN
   real(dp) :: pole_lat = 90.0_dp, pole_lon = 0.0_dp
@@ -63,7 +65,11 @@ contains
     if (ierr /= 0) call fatal("READING SETUP NAMELIST.", ierr)
     close (u)
     kind = upper(trim(target_grid_type))
-    if (trim(kind) == 'FILE') call fatal("target_grid_type='file' needs NetCDF (not available in this build)", -1)
+    if (trim(kind) == 'FILE') then               ! everything else comes from the file (define_target_grid_file)
+      if (trim(file_target_grid) == "NULL") call fatal("target_grid_type='file' needs file_target_grid", 3)
+      target_from_file = .true.
+      return
+    end if
     dxkm = dx; dykm = dy
     known_lat = ref_lat; known_lon = ref_lon; known_x = ref_x; known_y = ref_y
     i_target = nx - 1; j_target = ny - 1        ! namelist nx, ny are STAGGERED counts
@@ -86,7 +92,7 @@ contains
         if (known_lat == NAN .or. known_lon == NAN) call fatal("lat-lon with dx/dy needs ref_lat, ref_lon", 3)
       end if
     else
-      call fatal('In namelist, invalid target_grid_type: this build supports "lambert" and "lat-lon".', 3)
+      call fatal('In namelist, invalid target_grid_type: this build supports "lambert", "lat-lon" and "file".', 3)
     end if
     if (known_x == NAN .and. known_y == NAN) then
       known_x = real(i_target + 1, dp)/2.0_dp; known_y = real(j_target + 1, dp)/2.0_dp
@@ -151,6 +157,7 @@ module target_grid
   use, intrinsic :: iso_c_binding
   use program_setup
   use mpg
+  use ncio
   implicit none
   public
   real(dp), allocatable :: lat_m(:, :), lon_m(:, :), lat_u(:, :), lon_u(:, :), lat_v(:, :), lon_v(:, :)
@@ -185,6 +192,98 @@ contains
       call mpg_check(mpg_grid_get_rotang(grid_h, cosa, sina), "IN get_rotang")
     end if
   end subroutine define_target_grid_params
+
+  !> target_grid_type = 'file' (define_target_grid_file, model_grid.F90:1203-1888): dimensions, projection attributes,
+  !! XLONG|XLONG_M, XLAT|XLAT_M, the U / V staggers, MAPFAC_M/U/V and (Lambert) SINALPHA / COSALPHA come from a WRF
+  !! geo_em / wrfinput style file in a NetCDF classic format; the CORNER stagger is rebuilt by get_cell_corners.
+  subroutine define_target_grid_file(grid_h)
+    type(c_ptr), intent(out) :: grid_h
+    type(c_ptr) :: nf
+    integer(c_int64_t) :: ni, nj
+    real(dp), allocatable :: lat_c(:, :), lon_c(:, :)
+    real(dp) :: v
+    call ncio_check(ncio_open(trim(file_target_grid), nf), "opening "//trim(file_target_grid))
+    call ncio_check(ncio_inq_dim(nf, "west_east", ni), "reading west_east")
+    call ncio_check(ncio_inq_dim(nf, "south_north", nj), "reading south_north")
+    i_target = int(ni); j_target = int(nj)
+    call ncio_check(ncio_get_gatt(nf, "DX", dxkm), "reading DX")
+    dykm = dxkm
+    proj_code = PROJ_LC
+    if (ncio_get_gatt(nf, "MAP_PROJ", v) == 0) proj_code = nint(v)
+    if (proj_code /= PROJ_LC .and. proj_code /= PROJ_LATLON) call fatal("file_target_grid: unsupported MAP_PROJ", proj_code)
+    if (ncio_get_gatt(nf, "STAND_LON", v) == 0) stand_lon = v
+    if (ncio_get_gatt(nf, "TRUELAT1", v) == 0) truelat1 = v
+    if (ncio_get_gatt(nf, "TRUELAT2", v) == 0) truelat2 = v
+    if (ncio_get_gatt(nf, "CEN_LAT", v) == 0) ref_lat = v
+    if (ncio_get_gatt(nf, "MOAD_CEN_LAT", v) == 0) ref_lat = v
+    if (ncio_get_gatt(nf, "CEN_LON", v) == 0) ref_lon = v
+    if (ncio_get_gatt(nf, "POLE_LAT", v) == 0) pole_lat = v
+    if (ncio_get_gatt(nf, "POLE_LON", v) == 0) pole_lon = v
+    call get2("XLONG", "XLONG_M", lon_m, i_target, j_target)
+    call get2("XLAT", "XLAT_M", lat_m, i_target, j_target)
+    call get2("XLONG_U", "", lon_u, i_target + 1, j_target)
+    call get2("XLAT_U", "", lat_u, i_target + 1, j_target)
+    call get2("XLONG_V", "", lon_v, i_target, j_target + 1)
+    call get2("XLAT_V", "", lat_v, i_target, j_target + 1)
+    call get2("MAPFAC_M", "", mapfac_m, i_target, j_target)
+    call get2("MAPFAC_U", "", mapfac_u, i_target + 1, j_target)
+    call get2("MAPFAC_V", "", mapfac_v, i_target, j_target + 1)
+    if (proj_code == PROJ_LC) then
+      call get2("SINALPHA", "", sina, i_target, j_target)
+      call get2("COSALPHA", "", cosa, i_target, j_target)
+    end if
+    call ncio_check(ncio_close(nf), "closing "//trim(file_target_grid))
+    call get_cell_corners(lat_m, lon_m, lat_c, lon_c)
+    call mpg_check(mpg_grid_create(int(i_target, c_int), int(j_target, c_int), 0_c_int, lon_m, lat_m, lon_c, lat_c, &
+                                   lon_u, lat_u, lon_v, lat_v, grid_h), "IN GridCreate")
+  contains
+    subroutine get2(name, alt, a, n1, n2)
+      character(len=*), intent(in) :: name, alt
+      real(dp), allocatable, intent(out) :: a(:, :)
+      integer, intent(in) :: n1, n2
+      integer(c_int) :: id
+      if (ncio_inq_varid(nf, name, id) /= 0) then
+        if (len(alt) == 0) call ncio_check(-1_c_int, "reading "//name//" id")
+        call ncio_check(ncio_inq_varid(nf, alt, id), "reading "//name//" / "//alt//" id")
+      end if
+      allocate (a(n1, n2))
+      call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, a), "reading "//name)
+    end subroutine get2
+  end subroutine define_target_grid_file
+
+  !> get_cell_corners (model_grid.F90:1902-1972) as written: every corner is the great-circle destination point at
+  !! distance sqrt(dx**2/2) from a mass point, bearing 135 degrees for the (i, j) block, 225 on the extra column (from
+  !! column i_target), 45 on the extra row (from row j_target), 315 at the far corner; its own pi and earth radius.
+  subroutine get_cell_corners(lat, lon, latc, lonc)
+    real(dp), intent(in) :: lat(:, :), lon(:, :)
+    real(dp), allocatable, intent(out) :: latc(:, :), lonc(:, :)
+    real(dp), parameter :: pi_gc = 3.14159265359_dp, r_gc = 6370000.0_dp
+    real(dp) :: d
+    integer :: i, j, ni, nj
+    ni = size(lat, 1); nj = size(lat, 2)
+    d = sqrt((dxkm**2.0_dp)/2.0_dp)
+    allocate (latc(ni + 1, nj + 1), lonc(ni + 1, nj + 1))
+    do j = 1, nj
+      do i = 1, ni
+        call dest(lat(i, j), lon(i, j), 135.0_dp, latc(i, j), lonc(i, j))
+      end do
+      call dest(lat(ni, j), lon(ni, j), 225.0_dp, latc(ni + 1, j), lonc(ni + 1, j))
+    end do
+    do i = 1, ni
+      call dest(lat(i, nj), lon(i, nj), 45.0_dp, latc(i, nj + 1), lonc(i, nj + 1))
+    end do
+    call dest(lat(ni, nj), lon(ni, nj), 315.0_dp, latc(ni + 1, nj + 1), lonc(ni + 1, nj + 1))
+  contains
+    subroutine dest(la, lo, bearing, la2, lo2)
+      real(dp), intent(in) :: la, lo, bearing
+      real(dp), intent(out) :: la2, lo2
+      real(dp) :: lat1, lon1, brng, lat2, lon2
+      lat1 = la*(pi_gc/180.0_dp); lon1 = lo*(pi_gc/180.0_dp); brng = bearing*(pi_gc/180.0_dp)
+      lat2 = asin(sin(lat1)*cos(d/r_gc) + cos(lat1)*sin(d/r_gc)*cos(brng))
+      lon2 = lon1 + atan2(sin(brng)*sin(d/r_gc)*cos(lat1), cos(d/r_gc) - sin(lat1)*sin(lat2))
+      la2 = lat2*180.0_dp/pi_gc; lo2 = lon2*180.0_dp/pi_gc
+    end subroutine dest
+  end subroutine get_cell_corners
 end module target_grid
 
 !> Raw-binary named-array container ("MPGRAW1"), the NetCDF stand-in of this build.

@@ -70,7 +70,11 @@ contains
   end subroutine lap
 
   subroutine define_target_grid()
-    call define_target_grid_params(target_grid_h)
+    if (target_from_file) then
+      call define_target_grid_file(target_grid_h)
+    else
+      call define_target_grid_params(target_grid_h)
+    end if
   end subroutine define_target_grid
 
   subroutine read_f64(u, name, arr, dims, required)

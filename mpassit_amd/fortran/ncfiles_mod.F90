@@ -190,8 +190,8 @@ contains
     call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "SOUTH-NORTH_GRID_DIMENSION", j_target + 1), "GLOBAL ATT")
     call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "BOTTOM-TOP_GRID_DIMENSION", nz_input + 1), "GLOBAL ATT")
     call ncio_check(ncio_put_att_text(nf_out, NCIO_GLOBAL, "START_DATE", valid_time), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DX", dxkm*1000.0_dp), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DY", dxkm*1000.0_dp), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DX", dxkm), "GLOBAL ATT")
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DY", dxkm), "GLOBAL ATT")
     call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "CEN_LAT", ref_lat), "GLOBAL ATT")
     call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "CEN_LON", ref_lon), "GLOBAL ATT")
     call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "TRUELAT1", truelat1), "GLOBAL ATT")

@@ -51,6 +51,15 @@ module ncio
       type(*), dimension(*) :: buf
       integer(c_int) :: rc
     end function ncio_get_var
+    function ncio_get_att_double_c(f, varid, name, vals, max_n, n) bind(C, name="ncio_get_att_double") result(rc)
+      import :: c_char, c_ptr, c_int, c_double
+      type(c_ptr), value :: f
+      integer(c_int), value :: varid, max_n
+      character(kind=c_char), intent(in) :: name(*)
+      real(c_double), intent(out) :: vals(*)
+      integer(c_int), intent(out) :: n
+      integer(c_int) :: rc
+    end function ncio_get_att_double_c
     !> byte range of a variable / record inside the file; on a file being written the range is made to exist
     !! (a fresh file reads as zeros there)
     function ncio_var_extent(f, varid, rec, offset, nbytes) bind(C, name="ncio_var_extent") result(rc)
@@ -180,6 +189,17 @@ contains
     integer(c_int) :: unl
     rc = ncio_inq_dim_c(f, cstr(name), len, unl)
   end function ncio_inq_dim
+  !> first value of a numeric global attribute (nf90_get_att), converted to double
+  integer(c_int) function ncio_get_gatt(f, name, val) result(rc)
+    type(c_ptr), intent(in) :: f
+    character(len=*), intent(in) :: name
+    real(c_double), intent(out) :: val
+    real(c_double) :: v(1)
+    integer(c_int) :: n
+    v = 0.0_c_double
+    rc = ncio_get_att_double_c(f, NCIO_GLOBAL, cstr(name), v, 1_c_int, n)
+    val = v(1)
+  end function ncio_get_gatt
   integer(c_int) function ncio_inq_varid(f, name, varid) result(rc)
     type(c_ptr), intent(in) :: f
     character(len=*), intent(in) :: name

@@ -14,12 +14,9 @@ from test_fortran_driver import DIAG, NAMELIST, _driver
 pytestmark = pytest.mark.gpu
 
 
-def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
-    from mpassit_amd import interp as I, io_nc, ncio, post, regrid as R, synth
-    exe = _driver()
-    m, g = regional_case
-    d = str(tmp_path)
-    nz, nsoil = 6, 4
+def _write_inputs(d, m, nz=6, nsoil=4):
+    """Synthetic MPAS grid / history / diag files (float32, CDF-5) + the parm lists in directory d."""
+    from mpassit_amd import io_nc, synth
     rng = np.random.default_rng(23)
     hist, diag = {}, {}
     for k, (n, _) in enumerate(HIST_2D):
@@ -46,6 +43,16 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
     for fname, lst in (("diaglist", DIAG), ("histlist_2d", HIST_2D), ("histlist_3d", HIST_3D), ("histlist_soil", SOIL)):
         with open(os.path.join(d, fname), "w") as f:
             f.write("".join("%s\t\t%s\n" % p for p in lst))
+    return ter
+
+
+def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
+    from mpassit_amd import interp as I, io_nc, ncio, post, regrid as R
+    exe = _driver()
+    m, g = regional_case
+    d = str(tmp_path)
+    nz, nsoil = 6, 4
+    ter = _write_inputs(d, m, nz, nsoil)
     open(os.path.join(d, "namelist.input"), "w").write(NAMELIST.format(d=d).replace(".raw", ".nc"))
     r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -64,7 +71,7 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
         assert f.format == 5 and f.unlimited == "Time" and f.numrecs == 1
         assert f.dims["west_east"] == g.nx and f.dims["south_north_stag"] == g.ny + 1 and f.dims["bottom_top"] == nz
         assert f.get("Times", rec=0).tobytes() == b"2024-08-07_12:00:00"
-        assert f.att("MAP_PROJ")[0] == 1 and abs(f.att("TRUELAT1")[0] - 38.5) < 1e-6
+        assert f.att("MAP_PROJ")[0] == 1 and abs(f.att("TRUELAT1")[0] - 38.5) < 1e-6 and abs(f.att("DX")[0] - 30000.0) < 1e-3
         np.testing.assert_allclose(f.get("XLAT", rec=0), g.lat, atol=1e-5)
         np.testing.assert_allclose(f.get("COSALPHA", rec=0), g.cosa, atol=1e-6)
         missing = [k for k in want if k not in f.vars]
@@ -84,3 +91,63 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
         assert f.vars["U"]["dims"] == ("Time", "bottom_top", "south_north", "west_east_stag")
         assert f.vars["V"]["dims"] == ("Time", "bottom_top", "south_north_stag", "west_east")
         assert f.vars["TSLB"]["dims"][1] == "soil_layers_stag" and f.vars["PHB"]["dims"][1] == "bottom_top_stag"
+
+
+def test_driver_with_a_file_defined_target_grid(tmp_path, gpu_lib, regional_case):
+    """target_grid_type = 'file': the Fortran driver reads the grid from a WRF geo_em style file (classic format) and
+    rebuilds the CORNER stagger with get_cell_corners as written; compared with the Python mirror of the same path."""
+    from mpassit_amd import interp as I, io_nc, ncio, post, regrid as R, target_grid as T
+    exe = _driver()
+    m, g = regional_case
+    d = str(tmp_path)
+    nz, nsoil = 6, 4
+    ter = _write_inputs(d, m, nz, nsoil)
+    geo = os.path.join(d, "geo_em.d01.nc")
+    with ncio.Writer(geo, format=2) as w:
+        for name, n in (("Time", None), ("west_east", g.nx), ("south_north", g.ny), ("west_east_stag", g.nx + 1), ("south_north_stag", g.ny + 1)):
+            w.def_dim(name, n)
+        for k, v in (("DX", np.float32(30000.0)), ("DY", np.float32(30000.0)), ("CEN_LAT", np.float32(38.5)), ("CEN_LON", np.float32(-97.5)),
+                     ("TRUELAT1", np.float32(38.5)), ("TRUELAT2", np.float32(38.5)), ("MOAD_CEN_LAT", np.float32(38.5)),
+                     ("STAND_LON", np.float32(-97.5)), ("POLE_LAT", np.float32(90.0)), ("POLE_LON", np.float32(0.0)), ("MAP_PROJ", 1)):
+            w.put_att(k, v)
+        dims = {"M": ("Time", "south_north", "west_east"), "U": ("Time", "south_north", "west_east_stag"),
+                "V": ("Time", "south_north_stag", "west_east")}
+        data = {"XLAT_M": (g.lat, "M"), "XLONG_M": (g.lon, "M"), "XLAT_U": (g.lat_u, "U"), "XLONG_U": (g.lon_u, "U"),
+                "XLAT_V": (g.lat_v, "V"), "XLONG_V": (g.lon_v, "V"), "SINALPHA": (g.sina, "M"), "COSALPHA": (g.cosa, "M"),
+                "MAPFAC_M": (np.full_like(g.lat, 1.01), "M"), "MAPFAC_U": (np.full_like(g.lat_u, 1.02), "U"),
+                "MAPFAC_V": (np.full_like(g.lat_v, 1.03), "V")}
+        for name, (_, st) in data.items():
+            w.def_var(name, ncio.FLOAT, dims[st])
+        for name, (a, _) in data.items():
+            w.put(name, a, rec=0)
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc").replace("target_grid_type = 'lambert'",
+                                                               "target_grid_type = 'file'\n  file_target_grid=\"%s\"" % geo)
+    nml = "\n".join(ln for ln in nml.splitlines() if ln.split("=")[0].strip() not in
+                    ("nx", "ny", "dx", "dy", "ref_lat", "ref_lon", "truelat1", "truelat2", "stand_lon")) + "\n"
+    open(os.path.join(d, "namelist.input"), "w").write(nml)
+    r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    t = T.define_target_grid_file(geo)
+    cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
+    inp, _, _ = io_nc.read_input_data(os.path.join(d, "hist.nc"), cfg, ter, diag_path=os.path.join(d, "diag.nc"))
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(t)
+    want = post.output_fields(I.interp_data(mesh, grid, t, inp, cfg), cfg)
+    mesh.destroy()
+    grid.destroy()
+    with ncio.Reader(os.path.join(d, "out.nc")) as f:
+        assert f.dims["west_east"] == g.nx and f.dims["south_north"] == g.ny and abs(f.att("DX")[0] - 30000.0) < 1e-3
+        assert np.array_equal(f.get("XLAT", rec=0), g.lat.astype(np.float32)) and np.array_equal(f.get("MAPFAC_V", rec=0), np.float32(1.03) + 0 * g.lat_v.astype(np.float32))
+        assert np.array_equal(f.get("SINALPHA", rec=0), g.sina.astype(np.float32))
+        for k, w_ in want.items():
+            got = f.get(k, rec=0)
+            if k == "P_TOP":
+                assert abs(got - w_) <= 1e-6 * abs(w_)
+                continue
+            if k == "Z_C":
+                got = got[:nz]
+            assert got.shape == w_.shape, k
+            if k in ("XLAND", "TSLB", "SMOIS", "SH2O", "MU", "PH", "P"):
+                assert np.array_equal(got, w_), k
+            else:   # the corners come from two libms (flang runtime / numpy): the conservative weights may differ in the last bits
+                assert np.abs(got - w_).max() <= 2e-7 * max(1.0, float(np.abs(w_).max())), k
