@@ -86,9 +86,11 @@ contains
         dlondeg = 360.0_dp/i_target; dlatdeg = 180.0_dp/j_target
         known_x = 1.0_dp; known_y = 1.0_dp
         known_lon = stand_lon + dlondeg/2.0_dp; known_lat = -90.0_dp + dlatdeg/2.0_dp
+        dxkm = EARTH_RADIUS_M*PI*2.0_dp/i_target; dykm = EARTH_RADIUS_M*PI/j_target          ! program_setup.F90:209-210
       else
         if (.not. is_regional) call fatal("For lat-lon projection, if dx/dy are specified a regional grid is assumed.", 3)
         dlatdeg = dy; dlondeg = dx
+        dxkm = dlondeg*EARTH_RADIUS_M*PI*2.0_dp/360.0_dp; dykm = dlatdeg*EARTH_RADIUS_M*PI*2.0_dp/360.0_dp   ! :221-222
         if (known_lat == NAN .or. known_lon == NAN) call fatal("lat-lon with dx/dy needs ref_lat, ref_lon", 3)
       end if
     else

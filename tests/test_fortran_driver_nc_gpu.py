@@ -151,3 +151,53 @@ def test_driver_with_a_file_defined_target_grid(tmp_path, gpu_lib, regional_case
                 assert np.array_equal(got, w_), k
             else:   # the corners come from two libms (flang runtime / numpy): the conservative weights may differ in the last bits
                 assert np.abs(got - w_).max() <= 2e-7 * max(1.0, float(np.abs(w_).max())), k
+
+
+def test_driver_on_a_global_latlon_grid(tmp_path, gpu_lib):
+    """BASELINE configuration 5 in small: global icosahedral mesh -> global lat-lon grid (is_regional=.false.: periodic in
+    i, poles closed), wrf_mod_vars staggered winds, no wind rotation; Fortran driver == Python mirror bit for bit."""
+    import copy
+
+    from mpassit_amd import interp as I, io_nc, ncio, post, regrid as R, workloads
+    exe = _driver()
+    m, g, _, _ = workloads.workload("c5_small")
+    d = str(tmp_path)
+    nz, nsoil = 6, 4
+    ter = _write_inputs(d, m, nz, nsoil)
+    open(os.path.join(d, "namelist.input"), "w").write("""&config
+  grid_file_input_grid="%s/init.nc"
+  hist_file_input_grid="%s/hist.nc"
+  diag_file_input_grid="%s/diag.nc"
+  output_file="%s/out.nc"
+  target_grid_type = 'lat-lon'
+  interp_diag=.true.
+  interp_hist=.true.
+  wrf_mod_vars=.true.
+  is_regional=.false.
+  nx = 361
+  ny = 181
+  stand_lon = 0.0
+/
+""" % (d, d, d, d))
+    r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cfg = I.InterpConfig(wrf_mod_vars=True, proj_is_lambert=False, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
+    inp, _, _ = io_nc.read_input_data(os.path.join(d, "hist.nc"), cfg, ter, diag_path=os.path.join(d, "diag.nc"))
+    gd = copy.copy(g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(gd)
+    want = post.output_fields(I.interp_data(mesh, grid, gd, inp, cfg), cfg)
+    lon_u, _ = grid.coords(R.STAGGERLOC_EDGE1)
+    mesh.destroy()
+    grid.destroy()
+    with ncio.Reader(os.path.join(d, "out.nc")) as f:
+        assert f.dims["west_east"] == 360 and f.dims["south_north"] == 180 and f.att("MAP_PROJ")[0] == 0
+        assert "SINALPHA" not in f.vars and abs(f.att("DX")[0] - 6370000.0 * 2 * np.pi / 360) < 1.0
+        assert np.array_equal(f.get("XLONG_U", rec=0), lon_u.astype(np.float32))
+        for k, w_ in want.items():
+            got = f.get(k, rec=0)
+            if k == "P_TOP":
+                assert got == w_
+                continue
+            if k == "Z_C":
+                got = got[:nz]
+            assert got.shape == w_.shape and np.array_equal(got, w_), k
