@@ -1,0 +1,18 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the CPU-side C code (the NetCDF classic I/O library and the test oracle), driven by
+# their pytest files.  GPU sanitizers are not available on the pool, so this is the sanitizer coverage of the build.
+# The in-tree .so files are replaced by instrumented ones for the run and rebuilt normally afterwards.
+set -euo pipefail
+cd "$(dirname "$0")/.."
+SAN="-O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer"
+PRE="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+restore() {
+  python -c "from mpassit_amd import build; build.build_ncio(force=True)"
+  make -C oracle clean >/dev/null && make -C oracle >/dev/null
+}
+trap restore EXIT
+gcc $SAN -shared -fPIC -pthread -o mpassit_amd/hostio/libmpassit_ncio.so mpassit_amd/hostio/ncclassic.c
+make -C oracle clean >/dev/null
+make -C oracle CFLAGS="$SAN -fPIC -fopenmp -ffp-contract=off" >/dev/null
+LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+  python -m pytest tests/test_ncio.py tests/test_ncio_property.py tests/test_target_grid_file.py tests/test_oracle.py -x -q -m "not gpu"
