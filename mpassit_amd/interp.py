@@ -73,8 +73,11 @@ def rotate_winds_cgrid(target, u, v):
     cosa, sina = target.cosa, target.sina
     if _is_torch(u):
         import torch
-        cosa = torch.as_tensor(np.ascontiguousarray(cosa), device=u.device)
-        sina = torch.as_tensor(np.ascontiguousarray(sina), device=u.device)
+        dev = getattr(target, "_rot_dev", None)            # uploaded once per target grid, not once per call
+        if dev is None or dev[0].device != u.device or dev[2] is not cosa:
+            dev = (torch.as_tensor(np.ascontiguousarray(cosa), device=u.device), torch.as_tensor(np.ascontiguousarray(sina), device=u.device), cosa)
+            target._rot_dev = dev
+        cosa, sina = dev[0], dev[1]
     return R.rotate_winds_cgrid(cosa, sina, u, v)
 
 
@@ -162,3 +165,50 @@ def interp_data(mesh, grid, target, inp, cfg, destagger=None):
     if cfg.interp_hist:
         interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=destagger)
     return out
+
+
+class GraphedInterp:
+    """interp_data for a run of time levels: the launch sequence of one level -- every Regrid, rotation and
+    destaggering for fixed (mesh, grid, field lists, field shapes) -- is captured into ONE hipGraph and replayed on new
+    field values.  The device entry points only enqueue kernels once their handles are warm, so the capture needs nothing
+    special; what it removes is the per-launch host cost of the many small 2-D Regrids (a default diag + hist set is
+    ~60 launches).  `inp` must hold CUDA tensors; they become the static input buffers of the graph:
+        gi = GraphedInterp(mesh, grid, target, inp, cfg)      # Stores + one eager pass + capture
+        out = gi.replay()                                     # same dict of (static) output tensors every time
+        inp.hist["theta"].copy_(next_theta); out = gi.replay()
+    close() releases the route handles the object keeps alive."""
+
+    def __init__(self, mesh, grid, target, inp, cfg):
+        import torch
+        h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars)
+        self._keep = [R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)]
+        if cfg.interp_hist:
+            if h.do_u_interp:
+                self._keep.append(R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1))
+            if h.do_v_interp:
+                self._keep.append(R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2))
+            if h.vert_3d:
+                self._keep.append(R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE))
+            if h.cons_2d:
+                self._keep.append(R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE))
+            if h.nstd_2d:
+                self._keep.append(R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD))
+        self.inp = inp
+        interp_data(mesh, grid, target, inp, cfg)              # eager pass: kernel choices, tile lists, rotation angles
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(self.graph, stream=side):
+                self.out = interp_data(mesh, grid, target, inp, cfg)
+        torch.cuda.current_stream().wait_stream(side)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    def close(self):
+        for rh in self._keep:
+            rh.release()
+        self._keep = []

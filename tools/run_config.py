@@ -96,10 +96,22 @@ def main():
         times.append(time.perf_counter() - t0)
         for h in handles:
             h.release()
+    # the same time level as ONE hipGraph (interp.GraphedInterp): what is left when the per-launch host cost is gone
+    gi = I.GraphedInterp(mesh, grid, g, inp, cfg)
+    gt = []
+    for rep in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gout = gi.replay()
+        torch.cuda.synchronize()
+        gt.append(time.perf_counter() - t0)
+    same = all(torch.equal(out[k], gout[k]) for k in out)
+    gi.close()
     n3d = sum(1 for v in out.values() if v.ndim == 3 and v.shape[0] >= nz)
     rec = {"config": args.config, "workload": desc, "outputs": len(out), "fields_3d": n3d,
            "geometry_ingest_s": t_geom, "mesh_ingest_s": t_mesh, "target_grid_s": t_grid,
            "target_grid": "host numpy + upload" if args.host_grid else "device (mpg_grid_create_proj)", "target_grid_host_numpy_s": t_grid_host, "job_s_cold": times[0], "job_s_warm": min(times[1:]),
+           "job_s_graph_replay": min(gt), "graph_replay_equals_eager": bool(same),
            "fields_3d_per_s_cold": n3d / times[0], "fields_3d_per_s_warm": n3d / min(times[1:])}
     print(json.dumps(rec))
     mesh.destroy()
