@@ -123,7 +123,9 @@ int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc,
  * dst is fully overwritten: [nfields][nlev][ny_dst][nx_dst], unmapped points = 0.0 (zeroregion=TOTAL).
  * src: nfields slabs of nlev*n_src doubles in `src_layout` order.  Host-pointer version copies
  * H2D/D2H internally; the _dev version takes device pointers and a hipStream_t (NULL = default
- * stream) and returns after enqueueing. */
+ * stream) and returns after enqueueing.  The first _dev call on a handle for a given layout decides the kernel and
+ * may build its tile lists (allocation + synchronisation); every later call only enqueues kernels on the stream, so a
+ * caller can capture its per-time-level sequence of _dev calls (Regrid, rotate_winds, post-ops) into a hipGraph. */
 int mpg_regrid(mpg_handle rh, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host);
 int mpg_regrid_dev(mpg_handle rh, const double *src_dev, int src_layout, int nlev, int nfields,
                    double *dst_dev, void *hip_stream);

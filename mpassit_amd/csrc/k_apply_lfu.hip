@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include "geom.h"
+#include <utility>
+
 #include "mpg_internal.h"
 
 #define LFU_THREADS 256
@@ -365,7 +367,30 @@ static int lfu_build(mpg_handle_s *h, int txu, int rpt, hipStream_t s) { return 
 static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
   const int key = txu * 1024 + tyu;
   if (h->ut_rpt == key) return MPG_SUCCESS;
+  if (h->ut2_rpt == key) {  // the other layout's shape: swap the parked lists in, no device work
+    std::swap(h->ut_ptr, h->ut2_ptr);
+    std::swap(h->ut_cells, h->ut2_cells);
+    std::swap(h->lidx, h->lidx2);
+    std::swap(h->ut_rpt, h->ut2_rpt);
+    std::swap(h->ut_max, h->ut2_max);
+    std::swap(h->ut_total, h->ut2_total);
+    return MPG_SUCCESS;
+  }
   int rc;
+  if (h->ut_rpt) {  // park the lists in use (dropping what was parked) and build the new shape beside them
+    h->ut2_ptr.free();
+    h->ut2_cells.free();
+    h->lidx2.free();
+    h->ut2_ptr = h->ut_ptr;
+    h->ut2_cells = h->ut_cells;
+    h->lidx2 = h->lidx;
+    h->ut2_rpt = h->ut_rpt;
+    h->ut2_max = h->ut_max;
+    h->ut2_total = h->ut_total;
+    h->ut_ptr = DevBuf<int32_t>();
+    h->ut_cells = DevBuf<int32_t>();
+    h->lidx = DevBuf<uint16_t>();
+  }
   h->ut_ptr.free();
   h->ut_cells.free();
   h->ut_rpt = 0;

@@ -269,9 +269,7 @@ static void handle_free(mpg_handle_s *h) {
   h->pole_dst.free();
   h->pole_src0.free();
   h->pole_w.free();
-  h->ut_ptr.free();
-  h->ut_cells.free();
-  h->lidx.free();
+  h->free_tile_lists();
   delete h;
 }
 
@@ -578,10 +576,7 @@ int mpg_handle_get_pole(mpg_handle h, int32_t *dst_id_host, int32_t *src_row_sta
 
 // the tile lists of the LDS-staged level-fast kernel hold source ids: re-indexing a handle drops them
 static void lf_invalidate(mpg_handle_s *h) {
-  h->ut_ptr.free();
-  h->ut_cells.free();
-  h->lidx.free();
-  h->ut_rpt = 0;
+  h->free_tile_lists();
   h->lf_choice = 0;
   h->cf_choice = 0;
 }

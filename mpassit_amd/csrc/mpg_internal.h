@@ -194,6 +194,17 @@ struct mpg_handle_s {
   float lf_reuse = 0.f;   // 3 * n_dst / (sum of the tiles' unique cells): references per staged row
   DevBuf<int32_t> ut_ptr, ut_cells;
   DevBuf<uint16_t> lidx;  // [3][n_dst] positions in the tile's list, 0xFFFF = unmapped
+  // a second, parked set of tile lists: a job that alternates layouts on one handle (2-D fields cell-fast, 3-D fields
+  // in file order) needs two tile shapes in turn; the lists of the shape not in use wait here and are swapped back in
+  // instead of being rebuilt (a rebuild allocates and synchronises, which would also break hipGraph capture)
+  int ut2_rpt = 0, ut2_max = 0;
+  int64_t ut2_total = 0;
+  DevBuf<int32_t> ut2_ptr, ut2_cells;
+  DevBuf<uint16_t> lidx2;
+  void free_tile_lists() {
+    ut_ptr.free(); ut_cells.free(); lidx.free(); ut2_ptr.free(); ut2_cells.free(); lidx2.free();
+    ut_rpt = ut2_rpt = 0;
+  }
 };
 
 // ---- launchers implemented in the kernel TUs ---------------------------------------------------

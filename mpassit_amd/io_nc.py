@@ -11,6 +11,7 @@ Differences, all forced by the build image (no libnetcdf): files a
 request), not NetCDF-4; input files in NetCDF-4 have to be converted (`nccopy -k cdf5`) -- ncio says so when it meets
 one.  `write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
 import os
+import threading
 
 import numpy as np
 
@@ -115,20 +116,21 @@ def bswap_(t):
 
 _IO_THREADS = 4
 _IO_CHUNK = 32 << 20
-_io_state = None
+_io_tls = threading.local()
 
 
 def _io():
-    """A few pinned staging buffers + worker threads, created on first use: the GPU moves pinned chunks by DMA at PCIe
-    speed while the threads do the page-cache side (pread / pwrite are kernel copies that one core cannot do at that
+    """A few pinned staging buffers + worker threads, created on first use (one set per calling thread, so that a reader
+    thread can fetch the next file while the main thread writes the current one): the GPU moves pinned chunks by DMA at
+    PCIe speed while the threads do the page-cache side (pread / pwrite are kernel copies that one core cannot do at that
     speed, and they release the GIL)."""
     import torch
-    global _io_state
-    if _io_state is None:
+    st = getattr(_io_tls, "state", None)
+    if st is None:
         from concurrent.futures import ThreadPoolExecutor
         bufs = [torch.empty(_IO_CHUNK, dtype=torch.uint8).pin_memory() for _ in range(2 * _IO_THREADS)]
-        _io_state = (ThreadPoolExecutor(_IO_THREADS), bufs)
-    return _io_state
+        st = _io_tls.state = (ThreadPoolExecutor(_IO_THREADS), bufs)
+    return st
 
 
 def _file_to_dev(path, offset, dev):
@@ -383,4 +385,63 @@ def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=No
     return res
 
 
-__all__ = ["write_mpas_files", "read_grid", "read_input_data", "write_target_data", "run", "F"]
+def run_series(grid_path, jobs, target, cfg, namelist=None, fmt=5, timings=None):
+    """A run of time levels on one mesh and one target grid (one forecast: one history / diag file pair per output time).
+    jobs: list of (hist_path, diag_path or None, out_path).  The reference is started once per file and redoes everything;
+    here the mesh, the target grid and every weight set are built once, one time level of interp_data is captured into a
+    hipGraph (interp.GraphedInterp) and replayed per file, variables travel file <-> GPU as raw bytes (device_io), and a
+    reader thread fetches the next file's variables on its own stream while the current level is regridded and written.
+    Returns the number of files written.  timings: dict that receives setup_s and the wall seconds of every file."""
+    import time
+
+    import torch
+    from . import post
+    if not jobs:
+        return 0
+    t0 = time.perf_counter()
+    mpas, ter, zs = read_grid(grid_path)
+    mesh = R.Mesh.from_mpas(mpas)
+    grid = R.Grid.from_proj(target)
+    stream = torch.cuda.Stream()
+
+    def fetch(job):
+        with torch.cuda.stream(stream):
+            got = read_input_data(job[0], cfg, ter, diag_path=job[1], device="cuda")
+            stream.synchronize()
+        return got
+    from concurrent.futures import ThreadPoolExecutor
+    reader = ThreadPoolExecutor(1)
+    nxt = reader.submit(fetch, jobs[0])
+    inp, _, valid = nxt.result()
+    gi = I.GraphedInterp(mesh, grid, target, inp, cfg)           # Stores + eager pass + capture, on the first file's fields
+    if timings is not None:
+        timings["setup_s"] = time.perf_counter() - t0
+        timings["files_s"] = []
+    try:
+        for k, job in enumerate(jobs):
+            t0 = time.perf_counter()
+            if k > 0:
+                new, _, valid = nxt.result()
+                for store, fresh in ((inp.hist, new.hist), (inp.diag, new.diag)):
+                    for name, buf in store.items():
+                        buf.copy_(fresh[name])                   # into the graph's static input buffers
+                        fresh[name].record_stream(torch.cuda.current_stream())   # allocated on the reader's stream
+                del new
+            if k + 1 < len(jobs):
+                nxt = reader.submit(fetch, jobs[k + 1])
+            out = gi.replay()
+            res = post.output_fields(out, cfg)
+            write_target_data(job[2], target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00",
+                              zs=zs, namelist=namelist, fmt=fmt)
+            if timings is not None:
+                torch.cuda.synchronize()
+                timings["files_s"].append(time.perf_counter() - t0)
+    finally:
+        reader.shutdown(wait=True)
+        gi.close()
+        mesh.destroy()
+        grid.destroy()
+    return len(jobs)
+
+
+__all__ = ["write_mpas_files", "read_grid", "read_input_data", "write_target_data", "run", "run_series", "F"]

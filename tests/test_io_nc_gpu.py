@@ -104,3 +104,40 @@ def test_device_byte_swap_matches_numpy(gpu_lib, dtype):
         assert t.cpu().numpy().tobytes() == a.byteswap().tobytes()
         io_nc.bswap_(t)
         assert np.array_equal(t.cpu().numpy(), a)
+
+
+def test_run_series_equals_one_run_per_file(gpu_lib, tmp_path):
+    """io_nc.run_series (weights once, one captured time level replayed per file, next file prefetched by a reader
+    thread) writes the same bytes as io_nc.run on every file of the series."""
+    from mpassit_amd import build, interp as I, io_nc, synth, target_grid as T, workloads
+    build.build_ncio()
+    m, _, nz, _ = workloads.workload("tiny")
+    nsoil = 4
+    f32 = lambda a: np.asarray(a, np.float32)           # noqa: E731
+    ter = np.random.default_rng(1).uniform(0, 3000, m.nCells)
+    cfg = I.InterpConfig(interp_diag=True, wrf_mod_vars=True, diag_list=[("t2m", "T2"), ("u10", "U10"), ("v10", "V10")],
+                         hist_2d=[("xland", "XLAND"), ("snow", "SNOW"), ("skintemp", "TSK")],
+                         hist_3d=[("zgrid", "PHB"), ("theta", "T"), ("uReconstructZonal", "U"), ("uReconstructMeridional", "V"),
+                                  ("pressure", "P_HYD")], hist_soil=[("tslb", "TSLB")])
+    nml = dict(dx=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+    target = T.define_target_grid_params("lambert", 181, 107, dy=30000.0, arrays=False, **nml)
+    gpath = tmp_path / "grid.nc"
+    jobs = []
+    for k in range(3):
+        rng = np.random.default_rng(100 + k)
+        hist = {"xland": f32(np.floor(rng.uniform(1, 3, m.nCells))), "snow": f32(synth.snow_field(m.latCell, m.lonCell)[0] * (k + 1)),
+                "skintemp": f32(rng.uniform(250, 320, m.nCells)), "zgrid": f32(np.sort(rng.uniform(0, 2.0e4, (m.nCells, nz + 1)), axis=1)),
+                "theta": f32(rng.uniform(280, 500, (m.nCells, nz))), "uReconstructZonal": f32(rng.normal(0, 10, (m.nCells, nz))),
+                "uReconstructMeridional": f32(rng.normal(0, 10, (m.nCells, nz))),
+                "pressure": f32(-np.sort(-rng.uniform(2.0e3, 1.0e5, (m.nCells, nz)), axis=1)), "tslb": f32(rng.uniform(260, 300, (m.nCells, nsoil)))}
+        diag = {"t2m": f32(rng.uniform(250, 310, m.nCells)), "u10": f32(rng.normal(0, 8, m.nCells)), "v10": f32(rng.normal(0, 8, m.nCells))}
+        hp, dp = tmp_path / ("hist%d.nc" % k), tmp_path / ("diag%d.nc" % k)
+        io_nc.write_mpas_files(gpath, hp, m, ter, [0.05, 0.25, 0.7, 1.5], hist, nz, nsoil, diag_path=dp, diag=diag,
+                               xtime="2024-08-07_%02d:00:00" % k)
+        jobs.append((hp, dp, tmp_path / ("series%d.nc" % k)))
+    tm = {}
+    assert io_nc.run_series(gpath, jobs, target, cfg, namelist=nml, timings=tm) == 3 and len(tm["files_s"]) == 3
+    for k, (hp, dp, op) in enumerate(jobs):
+        single = tmp_path / ("single%d.nc" % k)
+        io_nc.run(gpath, hp, single, target, cfg, diag_path=dp, namelist=nml, device_io=True)
+        assert op.read_bytes() == single.read_bytes(), "time level %d" % k

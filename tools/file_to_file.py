@@ -57,7 +57,19 @@ def main():
         outs[mode] = opath
         del res
         torch.cuda.empty_cache()
-    same = open(outs[False], "rb").read() == open(outs[True], "rb").read()
+    # a run of time levels (here: the same history file four times): weights once, captured time level, prefetching reader
+    tm = {}
+    jobs = [(hpath, None, os.path.join(d, "f2f_series_%d.nc" % k)) for k in range(4)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    io_nc.run_series(gpath, jobs, target, cfg, namelist=nml, timings=tm)
+    print("run_series, 4 files:   %.2f s wall  (setup %.2f s, per file %s)" % (time.perf_counter() - t0, tm["setup_s"],
+          " ".join("%.2f" % v for v in tm["files_s"])), flush=True)
+    series_same = all(open(j[2], "rb").read() == open(outs[True], "rb").read() for j in jobs)
+    print("series outputs identical to the single run:", series_same)
+    for j in jobs:
+        os.remove(j[2])
+    same = open(outs[False], "rb").read() == open(outs[True], "rb").read() and series_same
     print("output files identical byte for byte:", same)
     for p in (gpath, hpath, outs[False], outs[True]):
         os.remove(p)
