@@ -72,3 +72,19 @@ def test_product_never_imports_the_oracle():
             "mpassit_amd.fields, mpassit_amd.target_grid, mpassit_amd.workloads; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_ncio_library_exports_every_declared_symbol():
+    """include/mpassit_ncio.h (the nf90_* stand-ins either side of the hot path) vs hostio/libmpassit_ncio.so."""
+    from mpassit_amd import build
+    so = build.build_ncio()
+    txt = open(os.path.join(ROOT, "include", "mpassit_ncio.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    decl = sorted(set(re.findall(r"\b(ncio_[a-z0-9_]+)\s*\(", txt)))
+    assert len(decl) >= 20 and "ncio_var_extent" in decl
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (ncio_[a-z0-9_]+)", out))
+    assert set(decl) <= exported, sorted(set(decl) - exported)
+    lib = ctypes.CDLL(so)
+    for name in decl:
+        assert hasattr(lib, name), name
