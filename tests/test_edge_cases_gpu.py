@@ -1,0 +1,136 @@
+"""Edge cases of the Regrid path: a target that misses the mesh entirely, the smallest grids, ragged level counts against the
+kernels' level chunks (4 / 8 / 16), one-point rows, bad arguments.  All through the C-ABI, checked against the oracle."""
+import numpy as np
+import pytest
+
+from conftest import mesh_xyz
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def test_target_that_misses_the_mesh(gpu_lib, oracle, regional_case):
+    """Mesh over CONUS, target grid over the southern Indian Ocean: bilinear and conservative leave every point unmapped
+    (zero-filled, ESMF_UNMAPPEDACTION_IGNORE + zeroregion TOTAL), nearest still maps every point (it always has a
+    nearest source), and all kernel variants cope with tiles that reference no cell at all."""
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    m, _ = regional_case
+    far = T.define_target_grid_params("lat-lon", 41, 31, dx=0.25, dy=0.25, ref_lat=-40.0, ref_lon=80.0, ref_x=1.0, ref_y=1.0, stand_lon=80.0)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(far)
+    src = synth.analytic_field(m.latCell, m.lonCell, 6) + 5.0
+    for method in (R.REGRIDMETHOD_BILINEAR, R.REGRIDMETHOD_CONSERVE):
+        rh = R.regrid_store(mesh, grid, method)
+        for layout, s in ((R.LAYOUT_CELL_FAST, src), (R.LAYOUT_LEV_FAST, np.ascontiguousarray(src.T))):
+            out = rh.regrid(s, nlev=6, layout=layout)
+            assert out.shape == (1, 6, far.ny, far.nx) and not out.any()
+        assert not rh.regrid(src[0].astype(np.float32), nlev=1).any()
+        rh.release()
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+    cxyz, _ = mesh_xyz(oracle, m)
+    want = oracle.nearest(cxyz, oracle.lonlat_deg_to_xyz(far.lon, far.lat))
+    idx, _ = rh.weights()
+    assert np.array_equal(idx[:, 0], want) and np.array_equal(rh.regrid(src[2], nlev=1).reshape(-1), src[2][want])
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+@pytest.mark.parametrize("nxy", [(2, 2), (2, 5), (65, 2), (3, 300)])
+def test_smallest_and_thinnest_grids(gpu_lib, oracle, global_mesh, nxy):
+    """Namelist nx, ny down to 2 (one mass point, two U points): tiles are mostly padding, rows shorter than a wavefront."""
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    nx, ny = nxy
+    g = T.define_target_grid_params("lat-lon", nx, ny, dx=0.5, dy=0.5, ref_lat=20.0, ref_lon=-100.0, ref_x=1.0, ref_y=1.0, stand_lon=-100.0)
+    m = global_mesh
+    cxyz, _ = mesh_xyz(oracle, m)
+    tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    idx_o, w_o = oracle.bilinear_weights(cxyz, tri, oracle.lonlat_deg_to_xyz(g.lon, g.lat))
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    nlev = 7
+    src = synth.analytic_field(m.latCell, m.lonCell, nlev)
+    want = oracle.apply_fixed(idx_o, w_o, src, nlev)
+    assert (idx_o[:, 0] >= 0).all()
+    for layout, s in ((R.LAYOUT_CELL_FAST, src), (R.LAYOUT_LEV_FAST, np.ascontiguousarray(src.T))):
+        got = rh.regrid(s, nlev=nlev, layout=layout).reshape(nlev, -1)
+        assert got.shape[1] == (nx - 1) * (ny - 1) and _rel(got, want) < 1e-12
+    # the staggered companions exist; a constant comes back as the constant where the point lies inside the hull of the
+    # mass points and as exactly 0 elsewhere -- everywhere when a dimension has a single mass point (no bilinear cell)
+    for stag, shape in ((R.STAGGERLOC_EDGE1, (ny - 1, nx)), (R.STAGGERLOC_EDGE2, (ny, nx - 1))):
+        rs = R.regrid_store_grid(grid, stag)
+        out = rs.regrid(np.full((2, ny - 1, nx - 1), 3.25).reshape(-1), nlev=2)
+        assert out.shape == (1, 2) + shape
+        mapped = out != 0.0
+        assert np.abs(out[mapped] - 3.25).max(initial=0.0) < 1e-13 and np.array_equal(mapped[0, 0], mapped[0, 1])
+        if min(nx - 1, ny - 1) < 2:
+            assert not mapped.any()
+        else:
+            assert mapped.any()
+        rs.release()
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+@pytest.mark.parametrize("nlev", [1, 2, 3, 5, 9, 17, 33])
+def test_ragged_level_counts(gpu_lib, oracle, regional_case, nlev):
+    """Level counts that are not multiples of the kernels' level chunks, both layouts, float64 and float32 sources, and a
+    two-field bundle: the last, partial chunk must neither read nor write past its levels."""
+    import torch
+
+    from mpassit_amd import regrid as R, synth
+    m, g = regional_case
+    cxyz, _ = mesh_xyz(oracle, m)
+    tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    idx_o, w_o = oracle.bilinear_weights(cxyz, tri, oracle.lonlat_deg_to_xyz(g.lon, g.lat))
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    src = synth.analytic_field(m.latCell, m.lonCell, nlev)
+    want = oracle.apply_fixed(idx_o, w_o, src, nlev)
+    P = g.nx * g.ny
+    for layout, s in ((R.LAYOUT_CELL_FAST, src), (R.LAYOUT_LEV_FAST, np.ascontiguousarray(src.T))):
+        # guard band behind the destination: must stay untouched
+        out = torch.full((2 * nlev * P + 4096,), 7.5, dtype=torch.float64, device="cuda")
+        s2 = torch.as_tensor(np.stack([s, -2.0 * s]), device="cuda").reshape(-1)
+        rh.regrid(s2, nlev=nlev, nfields=2, layout=layout, out=out[:2 * nlev * P].view(2, nlev, g.ny, g.nx))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert (got[2 * nlev * P:] == 7.5).all()
+        assert _rel(got[:nlev * P].reshape(nlev, P), want) < 1e-12 and _rel(got[nlev * P:2 * nlev * P].reshape(nlev, P), -2.0 * want) < 1e-12
+        s32 = s.astype(np.float32)
+        want32 = oracle.apply_fixed(idx_o, w_o, (s32 if layout == R.LAYOUT_CELL_FAST else s32.T).astype(np.float64), nlev)
+        got32 = rh.regrid(s32, nlev=nlev, layout=layout).reshape(nlev, P)
+        assert _rel(got32, want32) < 1e-12
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+def test_bad_arguments_are_refused(gpu_lib, regional_case):
+    import ctypes as C
+
+    from mpassit_amd import regrid as R
+    from mpassit_amd._lib import MpgError
+    m, g = regional_case
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    lib = gpu_lib.load()
+    src = np.zeros(m.nCells)
+    dst = np.zeros(g.nx * g.ny)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)          # noqa: E731
+    assert lib.mpg_regrid(rh._h, p(src), C.c_int(0), C.c_int(0), C.c_int(1), p(dst)) == 2 and b"nlev" in lib.mpg_last_error()
+    assert lib.mpg_regrid(rh._h, p(src), C.c_int(0), C.c_int(1), C.c_int(0), p(dst)) == 2
+    assert lib.mpg_regrid(rh._h, p(src), C.c_int(7), C.c_int(1), C.c_int(1), p(dst)) == 2 and b"layout" in lib.mpg_last_error()
+    assert lib.mpg_regrid(rh._h, None, C.c_int(0), C.c_int(1), C.c_int(1), p(dst)) == 2
+    assert lib.mpg_regrid_typed(rh._h, p(src), C.c_int(3), C.c_int(0), C.c_int(1), C.c_int(1), p(dst), C.c_int(0), C.c_double(1.0),
+                                C.c_double(0.0)) == 2
+    with pytest.raises(ValueError):
+        rh.regrid(np.zeros(m.nCells + 1), nlev=1)                           # wrong element count is caught before the call
+    with pytest.raises(MpgError):
+        R.regrid_store(mesh, grid, 17)                                      # unknown regrid method
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
