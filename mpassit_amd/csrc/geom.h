@@ -70,3 +70,11 @@ __device__ __forceinline__ double sph_tri_area(dv3 a, dv3 b, dv3 c) {
   }
   return 2.0 * atan2(num, den);
 }
+
+// Bijective XCD swizzle (cdna_hip_programming.md s5 "XCD swizzle must be bijective"): the hardware deals workgroups b,
+// b+8, b+16, ... to the same XCD, so give each of the 8 XCDs one contiguous range of the linear work space -- tiles that
+// are neighbours in the work space then share an L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
+  unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}

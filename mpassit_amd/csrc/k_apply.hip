@@ -29,13 +29,6 @@
 
 static int g_lev_chunk = 0;  // "lev_chunk" knob: 0 = all levels in one workgroup pass
 
-// bijective XCD swizzle (cdna_hip_programming.md s5 "XCD swizzle must be bijective"): workgroups b and
-// b+8 share an XCD, so give each XCD one contiguous range of the linear work space.
-__device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
-  unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 #define A3_TX 64
 
 // RPT = target rows per thread, WAVES = waves per workgroup (tile = 64 x WAVES*RPT target points), SYNC = keep the

@@ -24,10 +24,6 @@
 #define LFU_THREADS 256
 #define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two
 
-__device__ __forceinline__ unsigned lfu_xcd_remap(unsigned lin, unsigned n) {
-  unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
 
 // ---- per-tile unique cell lists (set-up, runtime tile shape) --------------------------------------------------
 // One workgroup per tile of txu x tyu points: the 3*np cell ids are sorted in LDS (bitonic), duplicates dropped,
@@ -157,7 +153,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__res
   int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
   const int t = threadIdx.x;
@@ -211,7 +207,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
   int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
   const int t = threadIdx.x;
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
   const int nup = ut_max;
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
   const int t = threadIdx.x;
@@ -508,7 +504,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__r
   const int nup = ut_max;
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
   const int t = threadIdx.x;
@@ -594,7 +590,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_t(const int32_t *__r
   int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
   const int t = threadIdx.x;
@@ -669,7 +665,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfr(const int32_t *__res
   TS *rows = (TS *)lds_raw;  // [nU][nlp]
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = lfu_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;

@@ -11,11 +11,6 @@
 #include "geom.h"
 #include "mpg_internal.h"
 
-__device__ __forceinline__ unsigned xcd_remap_t(unsigned lin, unsigned n) {
-  unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                      const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
@@ -23,7 +18,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
   constexpr int RPT = 2, TY = 4 * RPT;
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
-  unsigned lin = xcd_remap_t(blockIdx.x, gridDim.x);
+  unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tile = lin % ntile;
   int fld = lin / ntile;
   int tx = tile % ntx, ty = tile / ntx;
@@ -74,7 +69,7 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
   int32_t *sidx = (int32_t *)(sw + 192);
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
-  unsigned lin = xcd_remap_t(blockIdx.x, gridDim.x);
+  unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tl = lin % ntile;
   int fld = lin / ntile;
   int tx = tl % ntx, ty = tl / ntx;
