@@ -166,6 +166,15 @@ int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const d
 /* In-place byte swap of n elements of elem_size 2, 4 or 8 bytes on the device: NetCDF classic data is big-endian, so a
  * variable can be moved file <-> GPU as raw bytes (ncio_var_extent) and turned around at HBM speed. */
 int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream);
+/* The transport of such a variable: bytes [offset, offset + nbytes) of a file -> device memory and back, untouched,
+ * through pinned staging buffers and a few pread / pwrite threads (the page-cache side of the copy is what limits a
+ * single core).  Replaces the nf90_get_var / nf90_put_var data movement of input_data.F90:630 and
+ * write_data.F90:1008-1475 for NetCDF classic files; offset / nbytes come from ncio_var_extent.  Blocking: hip_stream is
+ * synchronised first (earlier users / the producer of the device buffer), the range is complete on return.  The file
+ * must already have the size (ncio_var_extent extends a file being written).  One read and one write may run
+ * concurrently from two host threads. */
+int mpg_file_to_dev(const char *path, int64_t offset, int64_t nbytes, void *dst_dev, void *hip_stream);
+int mpg_dev_to_file(const char *path, int64_t offset, int64_t nbytes, const void *src_dev, void *hip_stream);
 int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream);
 int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream);
 int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream);

@@ -11,7 +11,6 @@ Differences, all forced by the build image (no libnetcdf): files a
 request), not NetCDF-4; input files in NetCDF-4 have to be converted (`nccopy -k cdf5`) -- ncio says so when it meets
 one.  `write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
 import os
-import threading
 
 import numpy as np
 
@@ -114,76 +113,21 @@ def bswap_(t):
     return t
 
 
-_IO_THREADS = 4
-_IO_CHUNK = 32 << 20
-_io_tls = threading.local()
-
-
-def _io():
-    """A few pinned staging buffers + worker threads, created on first use (one set per calling thread, so that a reader
-    thread can fetch the next file while the main thread writes the current one): the GPU moves pinned chunks by DMA at
-    PCIe speed while the threads do the page-cache side (pread / pwrite are kernel copies that one core cannot do at that
-    speed, and they release the GIL)."""
-    import torch
-    st = getattr(_io_tls, "state", None)
-    if st is None:
-        from concurrent.futures import ThreadPoolExecutor
-        bufs = [torch.empty(_IO_CHUNK, dtype=torch.uint8).pin_memory() for _ in range(2 * _IO_THREADS)]
-        st = _io_tls.state = (ThreadPoolExecutor(_IO_THREADS), bufs)
-    return st
-
-
 def _file_to_dev(path, offset, dev):
-    """bytes [offset, offset + dev.numel()) of the file -> the 1-D uint8 CUDA tensor `dev`."""
+    """bytes [offset, offset + dev.numel()) of the file -> the 1-D uint8 CUDA tensor `dev` (mpg_file_to_dev: pinned staging
+    buffers and pread threads inside the library; blocking)."""
+    import ctypes as C
     import torch
-    pool, bufs = _io()
-    n, nb = dev.numel(), len(bufs)
-    fd = os.open(path, os.O_RDONLY)
-    try:
-        chunks = [(lo, min(n, lo + _IO_CHUNK)) for lo in range(0, n, _IO_CHUNK)]
-        free = [None] * nb                                          # event after which buffer k may be overwritten
-        reads = {}
-
-        def start(c):
-            k = c % nb
-            if free[k] is not None:
-                free[k].synchronize()
-            lo, hi = chunks[c]
-            reads[c] = pool.submit(os.preadv, fd, [memoryview(bufs[k].numpy())[:hi - lo]], offset + lo)
-        for c in range(min(nb, len(chunks))):
-            start(c)
-        for c, (lo, hi) in enumerate(chunks):
-            if reads.pop(c).result() != hi - lo:
-                raise IOError("%s: short read" % path)
-            k = c % nb
-            dev[lo:hi].copy_(bufs[k][:hi - lo], non_blocking=True)
-            free[k] = torch.cuda.Event()
-            free[k].record()
-            if c + nb < len(chunks):
-                start(c + nb)
-        torch.cuda.current_stream().synchronize()
-    finally:
-        os.close(fd)
+    L.check(L.load().mpg_file_to_dev(str(path).encode(), C.c_int64(offset), C.c_int64(dev.numel()), C.c_void_p(dev.data_ptr()),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
 def _dev_to_file(path, offset, dev):
-    """the 1-D uint8 CUDA tensor `dev` -> bytes [offset, ...) of the file (which already has that size)."""
-    pool, bufs = _io()
-    n, nb = dev.numel(), len(bufs)
-    fd = os.open(path, os.O_WRONLY)
-    try:
-        busy = [None] * nb
-        for c, lo in enumerate(range(0, n, _IO_CHUNK)):
-            hi, k = min(n, lo + _IO_CHUNK), c % nb
-            if busy[k] is not None and busy[k].result() < 0:
-                raise IOError("%s: write failed" % path)
-            bufs[k][:hi - lo].copy_(dev[lo:hi])                      # blocking DMA into pinned memory
-            busy[k] = pool.submit(os.pwrite, fd, memoryview(bufs[k].numpy())[:hi - lo], offset + lo)
-        for f in busy:
-            if f is not None:
-                f.result()
-    finally:
-        os.close(fd)
+    """the 1-D uint8 CUDA tensor `dev` -> bytes [offset, ...) of the file, which already has that size (mpg_dev_to_file)."""
+    import ctypes as C
+    import torch
+    L.check(L.load().mpg_dev_to_file(str(path).encode(), C.c_int64(offset), C.c_int64(dev.numel()), C.c_void_p(dev.data_ptr()),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
 
 def _read_field_dev(r, name, device):
@@ -269,7 +213,6 @@ def _put_dev(w, name, a):
     if a.numel() and not bool(a.view(torch.int32).any()):
         return                                            # all-zero bit patterns (MU, PH, P of wrf_mod_vars): nothing to store
     be = bswap_(a.clone()).view(torch.uint8).reshape(-1)
-    torch.cuda.current_stream().synchronize()
     _dev_to_file(w.path, off, be)                         # Z_C: nz of the declared nzp1 levels, the rest stays zero
 
 
