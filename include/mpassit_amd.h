@@ -163,6 +163,15 @@ int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const d
  *   mpg_post_layer_mean_dev  Z_C(k) = 0.5*(PHB(k+1) + PHB(k)), src [nlevp1][n_pts] -> dst [nlevp1-1][n_pts] (:1406-1415)
  *   mpg_post_ptop_dev        P_TOP from P_HYD [nlev][n_pts]: min(maxval(P_HYD), 0.8*P_HYD(top) over columns whose top
  *                            value is >= 10) (:1362-1371); float64 result returned to the host, blocks on the stream */
+/* ---- device buffers for hosts without a HIP binding of their own ---------------------------------------------------
+ * ESMF owned the field storage (ESMF_FieldCreate, farrayPtr: input_data.F90:638, interp.F90:702).  A host that keeps its
+ * fields in HBM between the input and the output file (fortran/mpassit_driver.F90 on NetCDF files) allocates them
+ * here and passes the pointers to the _dev entry points.  upload / download are plain blocking copies. */
+int mpg_dev_alloc(int64_t nbytes, void **out_dev);
+int mpg_dev_free(void *dev);
+int mpg_dev_upload(void *dst_dev, const void *src_host, int64_t nbytes);
+int mpg_dev_download(void *dst_host, const void *src_dev, int64_t nbytes);
+
 /* In-place byte swap of n elements of elem_size 2, 4 or 8 bytes on the device: NetCDF classic data is big-endian, so a
  * variable can be moved file <-> GPU as raw bytes (ncio_var_extent) and turned around at HBM speed. */
 int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream);

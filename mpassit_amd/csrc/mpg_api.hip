@@ -637,6 +637,37 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
   return mpg_k_pack(src_dev, n_src, nlev, ids_dev, n_ids, dst_dev, (hipStream_t)hip_stream);
 }
 
+// ---- device buffers for hosts without a HIP binding of their own (the Fortran driver keeps its fields in HBM between
+// the input file and the output file; ESMF owned that storage behind ESMF_FieldCreate / farrayPtr) ---------------------
+int mpg_dev_alloc(int64_t nbytes, void **out_dev) {
+  MPG_CHECK_INIT();
+  MPG_ARG(out_dev && nbytes >= 0, "mpg_dev_alloc: bad argument");
+  *out_dev = nullptr;
+  if (nbytes == 0) return MPG_SUCCESS;
+  MPG_HIP(hipMalloc(out_dev, (size_t)nbytes));
+  return MPG_SUCCESS;
+}
+
+int mpg_dev_free(void *dev) {
+  MPG_CHECK_INIT();
+  if (dev) MPG_HIP(hipFree(dev));
+  return MPG_SUCCESS;
+}
+
+int mpg_dev_upload(void *dst_dev, const void *src_host, int64_t nbytes) {
+  MPG_CHECK_INIT();
+  MPG_ARG(nbytes >= 0 && (nbytes == 0 || (dst_dev && src_host)), "mpg_dev_upload: bad argument");
+  if (nbytes) MPG_HIP(hipMemcpy(dst_dev, src_host, (size_t)nbytes, hipMemcpyHostToDevice));
+  return MPG_SUCCESS;
+}
+
+int mpg_dev_download(void *dst_host, const void *src_dev, int64_t nbytes) {
+  MPG_CHECK_INIT();
+  MPG_ARG(nbytes >= 0 && (nbytes == 0 || (dst_host && src_dev)), "mpg_dev_download: bad argument");
+  if (nbytes) MPG_HIP(hipMemcpy(dst_host, src_dev, (size_t)nbytes, hipMemcpyDeviceToHost));
+  return MPG_SUCCESS;
+}
+
 // ---- output epilogues (kernels in k_post.hip) ------------------------------------------------------------
 int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream) {
   MPG_CHECK_INIT();

@@ -16,6 +16,10 @@ module model_data
                                                 ! host memory and PCIe bytes; the Regrid kernel widens in its loads)
     real(dp), allocatable :: dst(:)             ! (nx, ny, nlev) i-fastest
     real(c_float), allocatable :: dst4(:)       ! the same as the NF90_FLOAT the output file holds (f32_out), instead of dst
+    ! device-resident flow (dev_flow): the field lives in HBM from the input file to the output file
+    type(c_ptr) :: src_dev = c_null_ptr, dst_dev = c_null_ptr
+    logical :: src_is_f32 = .false., dst_is_f32 = .false.
+    integer(c_int64_t) :: n_dst_elems = 0
   end type field_t
   type bundle_t
     integer :: n = 0
@@ -31,6 +35,10 @@ module model_data
   !> the output is a NetCDF file (every variable NF90_FLOAT, write_data.F90:587-980): fields nothing else needs in
   !! float64 come back from the Regrid as float32 with the writer's affine post-op fused (T - 300, write_data.F90:1343)
   logical :: f32_out = .false.
+  !> NetCDF classic files in and out: variables travel file <-> GPU as raw bytes (mpg_file_to_dev / mpg_dev_to_file,
+  !! byte order turned on the device) and every field stays in device buffers (mpg_dev_alloc) in between; the host
+  !! arrays of field_t are not used at all
+  logical :: dev_flow = .false.
 
 contains
 
@@ -55,6 +63,8 @@ contains
     if (allocated(a%src4)) call move_alloc(a%src4, b%src4)
     if (allocated(a%dst)) call move_alloc(a%dst, b%dst)
     if (allocated(a%dst4)) call move_alloc(a%dst4, b%dst4)
+    b%src_dev = a%src_dev; b%dst_dev = a%dst_dev; a%src_dev = c_null_ptr; a%dst_dev = c_null_ptr
+    b%src_is_f32 = a%src_is_f32; b%dst_is_f32 = a%dst_is_f32; b%n_dst_elems = a%n_dst_elems
   end subroutine move_field
 end module model_data
 
@@ -67,6 +77,7 @@ module interp
   implicit none
   private
   public :: interp_data
+  type(c_ptr) :: cosa_dev = c_null_ptr, sina_dev = c_null_ptr
 
 contains
 
@@ -99,6 +110,20 @@ contains
     if (allocated(f%dst4)) deallocate (f%dst4)
     layout = MPG_LAYOUT_LEV_FAST
     if (f%nlev == 1) layout = MPG_LAYOUT_CELL_FAST
+    if (dev_flow) then
+      if (c_associated(f%dst_dev)) call mpg_check(mpg_dev_free(f%dst_dev), "IN dev_free")
+      f%dst_is_f32 = .not. keeps_r8(f)
+      f%n_dst_elems = n_dst*f%nlev
+      call mpg_check(mpg_dev_alloc(f%n_dst_elems*merge(4, 8, f%dst_is_f32), f%dst_dev), "IN dev_alloc "//trim(f%name))
+      offset = 0.0_c_double
+      if (f%dst_is_f32 .and. wrf_mod_vars .and. trim(f%tname) == 'T') offset = -300.0_c_double
+      call mpg_check(mpg_regrid_typed_dev(rh, f%src_dev, merge(1_c_int, 0_c_int, f%src_is_f32), layout, int(f%nlev, c_int), 1_c_int, &
+                                          f%dst_dev, merge(1_c_int, 0_c_int, f%dst_is_f32), 1.0_c_double, offset, c_null_ptr), &
+                     "IN FieldRegrid "//trim(f%name))
+      call mpg_check(mpg_dev_free(f%src_dev), "IN dev_free")      ! the source is not needed again
+      f%src_dev = c_null_ptr
+      return
+    end if
     if (allocated(f%src4)) then
       sp = c_loc(f%src4); src_f32 = 1
     else
@@ -159,6 +184,11 @@ contains
       call destagger(rh_stag, vmass, v_field)
       call mpg_check(mpg_handle_release(rh_stag), "IN FieldRegridRelease")
     end if
+    if (dev_flow) then                  ! UMASS / VMASS are not output variables of the NetCDF file
+      if (c_associated(umass%dst_dev)) call mpg_check(mpg_dev_free(umass%dst_dev), "IN dev_free")
+      if (c_associated(vmass%dst_dev)) call mpg_check(mpg_dev_free(vmass%dst_dev), "IN dev_free")
+      umass%dst_dev = c_null_ptr; vmass%dst_dev = c_null_ptr
+    end if
     if (hist_3d_nzp1%n > 0) call regrid_bundle(rh_patch, hist_3d_nzp1)
     if (hist_3d_vert%n > 0) then        ! node-located sources (vorticity), interp.F90:350-366
       print *, "- CREATE HIST BUNDLE VERT BILINEAR REGRID ROUTEHANDLE"
@@ -201,6 +231,11 @@ contains
     type(field_t), intent(inout) :: dst
     call regrid_field(rh, src)
     dst%nlev = src%nlev
+    if (dev_flow) then
+      dst%dst_dev = src%dst_dev; src%dst_dev = c_null_ptr
+      dst%dst_is_f32 = src%dst_is_f32; dst%n_dst_elems = src%n_dst_elems
+      return
+    end if
     call move_alloc(src%dst, dst%dst)
   end subroutine regrid_to
 
@@ -214,6 +249,15 @@ contains
     call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
     if (allocated(stag%dst)) deallocate (stag%dst)
     if (allocated(stag%dst4)) deallocate (stag%dst4)
+    if (dev_flow) then
+      if (c_associated(stag%dst_dev)) call mpg_check(mpg_dev_free(stag%dst_dev), "IN dev_free")
+      stag%dst_is_f32 = .true.
+      stag%n_dst_elems = n_dst*mass%nlev
+      call mpg_check(mpg_dev_alloc(stag%n_dst_elems*4, stag%dst_dev), "IN dev_alloc")
+      call mpg_check(mpg_regrid_typed_dev(rh, mass%dst_dev, 0_c_int, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, stag%dst_dev, &
+                                          1_c_int, 1.0_c_double, 0.0_c_double, c_null_ptr), "IN FieldRegrid")
+      return
+    end if
     if (f32_out) then
       allocate (stag%dst4(n_dst*mass%nlev))
       call mpg_check(mpg_regrid_typed(rh, c_loc(mass%dst), 0_c_int, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, &
@@ -227,6 +271,19 @@ contains
   !> rotate_winds_cgrid (interp.F90:689-749) on the device
   subroutine rotate_winds_cgrid(u, v)
     type(field_t), intent(inout) :: u, v
+    integer(c_int64_t) :: npts
+    if (dev_flow) then
+      npts = int(i_target, c_int64_t)*int(j_target, c_int64_t)
+      if (.not. c_associated(cosa_dev)) then                    ! the rotation angles go up once
+        call mpg_check(mpg_dev_alloc(npts*8, cosa_dev), "IN dev_alloc")
+        call mpg_check(mpg_dev_alloc(npts*8, sina_dev), "IN dev_alloc")
+        call mpg_check(mpg_dev_upload(cosa_dev, cosa, npts*8), "IN dev_upload")
+        call mpg_check(mpg_dev_upload(sina_dev, sina, npts*8), "IN dev_upload")
+      end if
+      call mpg_check(mpg_rotate_winds_dev(npts, int(u%nlev, c_int), cosa_dev, sina_dev, u%dst_dev, v%dst_dev, c_null_ptr), &
+                     "IN rotate_winds_cgrid")
+      return
+    end if
     call mpg_check(mpg_rotate_winds(int(i_target, c_int64_t)*int(j_target, c_int64_t), int(u%nlev, c_int), cosa, sina, u%dst, v%dst), &
                    "IN rotate_winds_cgrid")
   end subroutine rotate_winds_cgrid

@@ -23,6 +23,7 @@ program mpassit
   logical :: nc_in = .false.
   type(c_ptr) :: nf_in = c_null_ptr
   integer :: nargs
+  character(len=16) :: envbuf
   integer(int64) :: clk0, clk_prev, clk_now, clk_rate
 
   nargs = command_argument_count()
@@ -35,6 +36,11 @@ program mpassit
   clk_prev = clk0
   print *, "- READ SETUP NAMELIST"
   call read_setup_namelist(trim(nml_file))
+  f32_out = is_nc_name(output_file)
+  call get_environment_variable("MPASSIT_HOST_ARRAYS", envbuf)
+  dev_flow = f32_out .and. len_trim(envbuf) == 0 .and. nc_is_netcdf(grid_file_input_grid) .and. &
+             (.not. interp_hist .or. nc_is_netcdf(hist_file_input_grid)) .and. (.not. interp_diag .or. nc_is_netcdf(diag_file_input_grid))
+  if (dev_flow) print *, "- NETCDF IN AND OUT: FIELDS STAY ON THE DEVICE BETWEEN THE FILES"
   call mpg_check(mpg_init(0_c_int), "INITIALIZING GPU RUNTIME")
   call lap("SETUP + GPU RUNTIME")
   print *, "- DEFINE TARGET GRID"
@@ -43,7 +49,6 @@ program mpassit
   print *, "- DEFINE INPUT GRID"
   call define_input_grid()
   call lap("DEFINE INPUT GRID")
-  f32_out = is_nc_name(output_file)
   print *, "- READ INPUT DATA"
   call read_input_data()
   call lap("READ INPUT DATA")
@@ -232,6 +237,7 @@ contains
     nc_in = nc_is_netcdf(file)
     u = -1
     if (nc_in) then
+      nc_in_path = file
       call ncio_check(ncio_open(file, nf_in), "opening "//trim(file))
       if (ncio_inq_varid(nf_in, "xtime", id) == 0) then
         tb = 32_c_int8_t

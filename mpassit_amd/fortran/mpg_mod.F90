@@ -120,6 +120,91 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid_typed
 
+    !> the same on device pointers (mpg_dev_alloc), enqueued on `stream` (c_null_ptr = default stream)
+    function mpg_regrid_typed_dev(rh, src, src_f32, src_layout, nlev, nfields, dst, dst_f32, scale, offset, stream) &
+      bind(C, name="mpg_regrid_typed_dev") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: rh, src, dst, stream
+      integer(c_int), value :: src_f32, src_layout, nlev, nfields, dst_f32
+      real(c_double), value :: scale, offset
+      integer(c_int) :: rc
+    end function mpg_regrid_typed_dev
+
+    function mpg_rotate_winds_dev(npts, nlev, cosa, sina, u, v, stream) bind(C, name="mpg_rotate_winds_dev") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      integer(c_int64_t), value :: npts
+      integer(c_int), value :: nlev
+      type(c_ptr), value :: cosa, sina, u, v, stream
+      integer(c_int) :: rc
+    end function mpg_rotate_winds_dev
+
+    !> device buffers for fields that stay in HBM between the input and the output file
+    function mpg_dev_alloc(nbytes, dev) bind(C, name="mpg_dev_alloc") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      integer(c_int64_t), value :: nbytes
+      type(c_ptr), intent(out) :: dev
+      integer(c_int) :: rc
+    end function mpg_dev_alloc
+    function mpg_dev_free(dev) bind(C, name="mpg_dev_free") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: dev
+      integer(c_int) :: rc
+    end function mpg_dev_free
+    function mpg_dev_upload(dst_dev, src_host, nbytes) bind(C, name="mpg_dev_upload") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: dst_dev
+      type(*), dimension(*), intent(in) :: src_host
+      integer(c_int64_t), value :: nbytes
+      integer(c_int) :: rc
+    end function mpg_dev_upload
+
+    !> bytes [offset, offset + nbytes) of a file <-> device memory, untouched (NetCDF classic variables: ncio_var_extent)
+    function mpg_file_to_dev_c(path, offset, nbytes, dst_dev, stream) bind(C, name="mpg_file_to_dev") result(rc)
+      import :: c_int, c_int64_t, c_ptr, c_char
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int64_t), value :: offset, nbytes
+      type(c_ptr), value :: dst_dev, stream
+      integer(c_int) :: rc
+    end function mpg_file_to_dev_c
+    function mpg_dev_to_file_c(path, offset, nbytes, src_dev, stream) bind(C, name="mpg_dev_to_file") result(rc)
+      import :: c_int, c_int64_t, c_ptr, c_char
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int64_t), value :: offset, nbytes
+      type(c_ptr), value :: src_dev, stream
+      integer(c_int) :: rc
+    end function mpg_dev_to_file_c
+    function mpg_bswap_dev(buf, n, elem_size, stream) bind(C, name="mpg_bswap_dev") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: buf, stream
+      integer(c_int64_t), value :: n
+      integer(c_int), value :: elem_size
+      integer(c_int) :: rc
+    end function mpg_bswap_dev
+
+    !> writer epilogues on device-resident float64 fields (write_data.F90:1339-1475), float32 results
+    function mpg_post_cast_dev(src, n, scale, offset, dst, stream) bind(C, name="mpg_post_cast_dev") result(rc)
+      import :: c_int, c_int64_t, c_double, c_ptr
+      type(c_ptr), value :: src, dst, stream
+      integer(c_int64_t), value :: n
+      real(c_double), value :: scale, offset
+      integer(c_int) :: rc
+    end function mpg_post_cast_dev
+    function mpg_post_layer_mean_dev(src, nlevp1, npts, dst, stream) bind(C, name="mpg_post_layer_mean_dev") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: src, dst, stream
+      integer(c_int), value :: nlevp1
+      integer(c_int64_t), value :: npts
+      integer(c_int) :: rc
+    end function mpg_post_layer_mean_dev
+    function mpg_post_ptop_dev(p_hyd, nlev, npts, ptop, stream) bind(C, name="mpg_post_ptop_dev") result(rc)
+      import :: c_int, c_int64_t, c_double, c_ptr
+      type(c_ptr), value :: p_hyd, stream
+      integer(c_int), value :: nlev
+      integer(c_int64_t), value :: npts
+      real(c_double), intent(out) :: ptop
+      integer(c_int) :: rc
+    end function mpg_post_ptop_dev
+
     function mpg_handle_release(rh) bind(C, name="mpg_handle_release") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: rh
@@ -199,6 +284,20 @@ contains
 
   !> Same contract as the reference's error_handler (utils.F90:16-33): print and abort with code 999 on any
   !! non-zero rc -- every ESMF rc in interp.F90 is checked this way (e.g. :130-131).
+  integer(c_int) function mpg_file_to_dev(path, offset, nbytes, dst_dev) result(rc)
+    character(len=*), intent(in) :: path
+    integer(c_int64_t), intent(in) :: offset, nbytes
+    type(c_ptr), intent(in) :: dst_dev
+    rc = mpg_file_to_dev_c(trim(path)//c_null_char, offset, nbytes, dst_dev, c_null_ptr)
+  end function mpg_file_to_dev
+
+  integer(c_int) function mpg_dev_to_file(path, offset, nbytes, src_dev) result(rc)
+    character(len=*), intent(in) :: path
+    integer(c_int64_t), intent(in) :: offset, nbytes
+    type(c_ptr), intent(in) :: src_dev
+    rc = mpg_dev_to_file_c(trim(path)//c_null_char, offset, nbytes, src_dev, c_null_ptr)
+  end function mpg_dev_to_file
+
   subroutine mpg_check(rc, where)
     integer(c_int), intent(in) :: rc
     character(len=*), intent(in) :: where

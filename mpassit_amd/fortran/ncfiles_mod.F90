@@ -9,17 +9,20 @@ module ncfiles
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: int64
   use ncio
+  use mpg
   use program_setup
   use target_grid
   use model_data
   implicit none
   private
   public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target
+  character(len=500), public :: nc_in_path = ""      ! path of the file nc_load_field reads from (device flow: raw ranges)
 
   type fref
     type(field_t), pointer :: p => null()
   end type fref
   type(c_ptr) :: nf_out = c_null_ptr
+  character(len=500) :: out_path = ""
   real(dp) :: put_seconds = 0.0_dp             ! wall time inside ncio_put_var (the rest of WRITE DATA is host post-ops)
   integer(c_int) :: d_time, d_we, d_wes, d_sn, d_sns, d_bt, d_bts, d_soil, d_str
 
@@ -70,6 +73,12 @@ contains
     call get_f64(nf, "ter", hgt%src, nc)
     hgt%name = "ter"; hgt%tname = "HGT"; hgt%nlev = 1
     if (ncio_inq_varid(nf, "zs", id) == 0 .and. ncio_inq_dim(nf, "nSoilLevels", ns) == 0) call get_f64(nf, "zs", zs_input, ns)
+    if (dev_flow) then
+      call mpg_check(mpg_dev_alloc(nc*8, hgt%src_dev), "IN dev_alloc ter")
+      call mpg_check(mpg_dev_upload(hgt%src_dev, hgt%src, nc*8), "IN dev_upload ter")
+      hgt%src_is_f32 = .false.
+      deallocate (hgt%src)
+    end if
     call ncio_check(ncio_close(nf), "closing grid file")
   end subroutine nc_read_grid
 
@@ -92,6 +101,10 @@ contains
       f%nlev = int(shp(d0 + 1))                  ! file order [nCells][nlev] == Fortran (nlev, nCells)
       n = shp(d0)*shp(d0 + 1)
     end if
+    if (dev_flow) then
+      call load_dev(nf, id, xtype, n, f)
+      return
+    end if
     if (xtype == NCIO_FLOAT) then                 ! stays single precision: the Regrid widens it on the GPU
       allocate (f%src4(n))
       call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_FLOAT, f%src4), "reading field - "//trim(name))
@@ -100,6 +113,30 @@ contains
       call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, f%src), "reading field - "//trim(name))
     end if
   end subroutine nc_load_field
+
+  !> device flow: the variable's bytes go file -> GPU as stored and are turned to host byte order there; types other
+  !! than NF90_FLOAT / NF90_DOUBLE are converted by ncio on the host and uploaded as float64
+  subroutine load_dev(nf, id, xtype, n, f)
+    type(c_ptr), intent(in) :: nf
+    integer(c_int), intent(in) :: id, xtype
+    integer(c_int64_t), intent(in) :: n
+    type(field_t), intent(inout) :: f
+    integer(c_int64_t) :: off, nb
+    real(dp), allocatable :: tmp(:)
+    if (xtype == NCIO_FLOAT .or. xtype == NCIO_DOUBLE) then
+      call ncio_check(ncio_var_extent(nf, id, 0_c_int64_t, off, nb), "locating "//trim(f%name))
+      f%src_is_f32 = xtype == NCIO_FLOAT
+      call mpg_check(mpg_dev_alloc(nb, f%src_dev), "IN dev_alloc "//trim(f%name))
+      call mpg_check(mpg_file_to_dev(trim(nc_in_path), off, nb, f%src_dev), "reading field - "//trim(f%name))
+      call mpg_check(mpg_bswap_dev(f%src_dev, n, merge(4_c_int, 8_c_int, f%src_is_f32), c_null_ptr), "IN bswap")
+    else
+      allocate (tmp(n))
+      call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, tmp), "reading field - "//trim(f%name))
+      f%src_is_f32 = .false.
+      call mpg_check(mpg_dev_alloc(n*8, f%src_dev), "IN dev_alloc "//trim(f%name))
+      call mpg_check(mpg_dev_upload(f%src_dev, tmp, n*8), "IN dev_upload "//trim(f%name))
+    end if
+  end subroutine load_dev
 
   ! ---- output ---------------------------------------------------------------------------------------------------
   subroutine def_field(name, nlev, stag, id)
@@ -146,6 +183,59 @@ contains
     call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
   end subroutine put_zero
 
+  !> device flow: n float32 values in HBM -> the variable's byte range (byte order turned on the GPU first unless the
+  !! buffer already holds big-endian values from an earlier put)
+  subroutine put_dev(id, ptr, n, swap)
+    integer(c_int), intent(in) :: id
+    type(c_ptr), intent(in) :: ptr
+    integer(c_int64_t), intent(in) :: n
+    logical, intent(in) :: swap
+    integer(c_int64_t) :: off, nb
+    integer(int64) :: c0, c1, cr
+    call system_clock(c0, cr)
+    if (swap) call mpg_check(mpg_bswap_dev(ptr, n, 4_c_int, c_null_ptr), "IN bswap")
+    call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
+    if (n*4 > nb) call fatal("put_dev: field larger than its variable", int(id))
+    call mpg_check(mpg_dev_to_file(trim(out_path), off, n*4, ptr), "WRITING RECORD")
+    call system_clock(c1)
+    put_seconds = put_seconds + real(c1 - c0, dp)/real(cr, dp)
+  end subroutine put_dev
+
+  !> one target field of the device flow with the writer's post-ops as device epilogues (write_data.F90:1339-1475)
+  subroutine write_field_dev(p, id, id_extra, id_ptop, npts)
+    type(field_t), intent(inout) :: p
+    integer(c_int), intent(in) :: id, id_extra(8), id_ptop
+    integer, intent(in) :: npts
+    type(c_ptr) :: tmp
+    real(dp) :: ptop
+    integer(c_int64_t) :: n
+    n = p%n_dst_elems
+    if (p%dst_is_f32) then
+      call put_dev(id, p%dst_dev, n, .true.)
+    else
+      call mpg_check(mpg_dev_alloc(n*4, tmp), "IN dev_alloc")
+      if (trim(p%tname) == 'PHB') then
+        call mpg_check(mpg_post_layer_mean_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), tmp, c_null_ptr), "IN Z_C")   ! :1406-1415
+        call put_dev(id_extra(3), tmp, int(npts, c_int64_t)*(p%nlev - 1), .true.)
+        call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 9.81_c_double, 0.0_c_double, tmp, c_null_ptr), "IN PHB*9.81")              ! :1418
+        call put_dev(id, tmp, n, .true.)
+        if (wrf_mod_vars) call put_zero(id_extra(4))
+      else
+        if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') then                                                                    ! :1362-1379
+          call mpg_check(mpg_post_ptop_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), ptop, c_null_ptr), "IN P_TOP")
+          call ncio_check(ncio_put_var(nf_out, id_ptop, 0_c_int64_t, NCIO_DOUBLE, [ptop]), "WRITING P_TOP")
+        end if
+        call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 1.0_c_double, 0.0_c_double, tmp, c_null_ptr), "IN cast")
+        call put_dev(id, tmp, n, .true.)
+        if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') call put_dev(id_extra(2), tmp, n, .false.)                              ! PB = P_HYD
+      end if
+      call mpg_check(mpg_dev_free(tmp), "IN dev_free")
+    end if
+    if (wrf_mod_vars .and. trim(p%tname) == 'MUB') call put_zero(id_extra(1))
+    call mpg_check(mpg_dev_free(p%dst_dev), "IN dev_free")
+    p%dst_dev = c_null_ptr
+  end subroutine write_field_dev
+
   subroutine put_r4(id, a)
     integer(c_int), intent(in) :: id
     real(c_float), intent(in) :: a(*)
@@ -176,6 +266,7 @@ contains
     nzp1_input = nz_input + 1
     if (hist_soil%n > 0) nsoil_input = hist_soil%f(1)%nlev
     nsoil_input = max(nsoil_input, 1)
+    out_path = file
     call ncio_check(ncio_create(file, 5, nf_out), "CREATING FILE "//trim(file))
     call ncio_check(ncio_def_dim(nf_out, "Time", 0, d_time), "DEFINING Time")                    ! write_data.F90:177-194
     call ncio_check(ncio_def_dim(nf_out, "west_east", i_target, d_we), "DEFINING west_east")
@@ -244,6 +335,10 @@ contains
     call ncio_check(ncio_put_var(nf_out, id_times, 0_c_int64_t, NCIO_CHAR, tbytes), "WRITING Times")
     npts = i_target*j_target
     do i = 1, nv
+      if (dev_flow) then
+        call write_field_dev(fl(i)%p, ids(i), id_extra, id_ptop, npts)
+        cycle
+      end if
       if (allocated(fl(i)%p%dst4)) then                                                          ! came back as NF90_FLOAT, post-op fused
         call put_r4(ids(i), fl(i)%p%dst4)
       else if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'T') then
@@ -304,7 +399,7 @@ contains
     subroutine add(f, stag)
       type(field_t), intent(inout), target :: f
       integer, intent(in) :: stag
-      if (.not. allocated(f%dst) .and. .not. allocated(f%dst4)) return
+      if (.not. allocated(f%dst) .and. .not. allocated(f%dst4) .and. .not. c_associated(f%dst_dev)) return
       nv = nv + 1
       f%stagger = stag
       fl(nv)%p => f
