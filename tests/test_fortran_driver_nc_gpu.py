@@ -56,6 +56,12 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
     open(os.path.join(d, "namelist.input"), "w").write(NAMELIST.format(d=d).replace(".raw", ".nc"))
     r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "FIELDS STAY ON THE DEVICE" in r.stdout                  # NetCDF in and out: the device-resident flow
+    # the same job on host arrays (the flow of the raw container): the same file, byte for byte
+    open(os.path.join(d, "namelist.host"), "w").write(NAMELIST.format(d=d).replace(".raw", ".nc").replace("out.nc", "out_host.nc"))
+    r = subprocess.run([exe, "namelist.host"], cwd=d, capture_output=True, text=True, timeout=300, env=dict(os.environ, MPASSIT_HOST_ARRAYS="1"))
+    assert r.returncode == 0 and "FIELDS STAY ON THE DEVICE" not in r.stdout, r.stdout + r.stderr
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_host.nc"), "rb").read()
 
     cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
     inp, _, valid = io_nc.read_input_data(os.path.join(d, "hist.nc"), cfg, ter, diag_path=os.path.join(d, "diag.nc"))
