@@ -5,6 +5,10 @@
 !! File I/O: NetCDF classic files (CDF-1/2/5, through ncio: the image has no libnetcdf, so NetCDF-4 is not read) are
 !! recognised by their magic; anything else is taken as the MPGRAW1 raw container.  An output_file ending in ".nc" is
 !! written as CDF-5 with the reference's dimension / variable names and post-ops (ncfiles_mod.F90).
+!! Two data flows: with NetCDF at both ends every listed variable goes file -> GPU as raw bytes, stays in device buffers
+!! through Regrid / rotation / destaggering / post-ops and goes GPU -> file the same way (dev_flow; no host array, no
+!! host conversion); otherwise (raw container, or MPASSIT_HOST_ARRAYS set) fields live in host arrays like the
+!! reference's and cross PCIe inside mpg_regrid / mpg_regrid_typed.  Both write the same bytes.
 program mpassit
   use, intrinsic :: iso_c_binding
   use, intrinsic :: iso_fortran_env, only: int32, int64
