@@ -141,3 +141,31 @@ def test_run_series_equals_one_run_per_file(gpu_lib, tmp_path):
         single = tmp_path / ("single%d.nc" % k)
         io_nc.run(gpath, hp, single, target, cfg, diag_path=dp, namelist=nml, device_io=True)
         assert op.read_bytes() == single.read_bytes(), "time level %d" % k
+
+
+def test_file_range_to_device_and_back(gpu_lib, tmp_path):
+    """mpg_file_to_dev / mpg_dev_to_file: byte ranges at odd offsets and sizes (below one staging chunk, several chunks with
+    a ragged tail, empty), both directions, plus the failure modes."""
+    import ctypes as C
+
+    import torch
+    lib = gpu_lib.load()
+    rng = np.random.default_rng(8)
+    data = rng.integers(0, 256, (3 << 25) + 12345, dtype=np.uint8)          # ~100 MB + a ragged tail
+    src = tmp_path / "blob.bin"
+    src.write_bytes(data.tobytes())
+    dst = tmp_path / "copy.bin"
+    dst.write_bytes(b"\0" * data.size)
+    for off, n in ((0, data.size), (7, 1), (13, 0), (4097, (1 << 25) + 1), (data.size - 1000, 1000), (3, 5 << 20)):
+        t = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        gpu_lib.check(lib.mpg_file_to_dev(str(src).encode(), C.c_int64(off), C.c_int64(n), C.c_void_p(t.data_ptr()), None))
+        got = t.cpu().numpy()
+        assert np.array_equal(got[:n], data[off:off + n]) and not got[n:].any()
+        gpu_lib.check(lib.mpg_dev_to_file(str(dst).encode(), C.c_int64(off), C.c_int64(n), C.c_void_p(t.data_ptr()), None))
+    assert dst.read_bytes() == data.tobytes()                                # the first range covered everything
+    t = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    assert lib.mpg_file_to_dev(str(tmp_path / "missing.bin").encode(), C.c_int64(0), C.c_int64(16), C.c_void_p(t.data_ptr()), None) == 2
+    assert b"cannot open" in lib.mpg_last_error()
+    assert lib.mpg_file_to_dev(str(src).encode(), C.c_int64(data.size - 8), C.c_int64(16), C.c_void_p(t.data_ptr()), None) == 2   # past the end
+    assert b"short read" in lib.mpg_last_error()
+    assert lib.mpg_dev_to_file(str(dst).encode(), C.c_int64(-1), C.c_int64(16), C.c_void_p(t.data_ptr()), None) == 2
