@@ -41,6 +41,20 @@ struct Lane {
     ready = true;
     return MPG_SUCCESS;
   }
+  void release() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (int t = 0; t < NTHREAD; ++t) {
+      if (stream[t]) (void)hipStreamDestroy(stream[t]);
+      stream[t] = nullptr;
+      for (int b = 0; b < 2; ++b) {
+        if (buf[t][b]) (void)hipHostFree(buf[t][b]);
+        if (done[t][b]) (void)hipEventDestroy(done[t][b]);
+        buf[t][b] = nullptr;
+        done[t][b] = nullptr;
+      }
+    }
+    ready = false;
+  }
 };
 Lane g_read, g_write;
 
@@ -121,6 +135,12 @@ int run(bool to_dev, const char *path, int64_t offset, int64_t nbytes, void *dev
   return MPG_SUCCESS;
 }
 }  // namespace
+
+// mpg_finalize: the staging buffers and streams belong to the device that was current when they were made
+void mpg_fileio_release() {
+  g_read.release();
+  g_write.release();
+}
 
 extern "C" int mpg_file_to_dev(const char *path, int64_t offset, int64_t nbytes, void *dst_dev, void *hip_stream) {
   MPG_CHECK_INIT();

@@ -207,6 +207,8 @@ struct mpg_handle_s {
   }
 };
 
+void mpg_fileio_release();  // mpg_fileio.hip: staging buffers / streams of mpg_file_to_dev, dropped by mpg_finalize
+
 // ---- launchers implemented in the kernel TUs ---------------------------------------------------
 int mpg_k_mesh_coords(int64_t n, const double *lon_rad, const double *lat_rad, PointSet &out, hipStream_t s);
 int mpg_k_grid_coords(int64_t n, const double *lon_deg, const double *lat_deg, PointSet &out, hipStream_t s);
