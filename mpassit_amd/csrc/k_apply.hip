@@ -320,6 +320,7 @@ int mpg_k_tune(const char *key, int value) {
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "lfu_min_reuse_x10")) { mpg_lfu_set_min_reuse_x10(value); return MPG_SUCCESS; }
   if (!strcmp(key, "a3_staged")) {
     if (value < -2 || value >= mpg_cfu_num_variants()) return MPG_ERR_INVALID_ARG;
     g_a3_staged = value;

@@ -438,6 +438,8 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
 // reuse = 3 * n_dst / sum(unique cells per tile): ~2.5 on C4, 5-6 on C2 / C5.
 static int g_lfu_auto_variant = 11;
 #define LFU_AUTO_MIN_REUSE 3.5f
+static float g_lfu_min_reuse = LFU_AUTO_MIN_REUSE;  // "lfu_min_reuse_x10" knob (level-fast choice only; decided at a handle's first call)
+void mpg_lfu_set_min_reuse_x10(int v) { g_lfu_min_reuse = 0.1f * (float)v; }
 void mpg_lfu_set_auto_variant(int v) { g_lfu_auto_variant = v; }
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
   const LfuVariant &v = g_lfu_variants[g_lfu_auto_variant];
@@ -445,7 +447,7 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
     int rc = lfu_build(h, v.txu, v.rpt, s);
     if (rc) return rc;
     h->lf_reuse = h->ut_total > 0 ? 3.0f * (float)h->n_dst / (float)h->ut_total : 0.f;
-    h->lf_choice = h->lf_reuse >= LFU_AUTO_MIN_REUSE ? 1 : -1;
+    h->lf_choice = h->lf_reuse >= g_lfu_min_reuse ? 1 : -1;
     if (h->lf_choice < 0 && h->cf_choice <= 0) {  // not needed: give the memory back
       h->ut_ptr.free();
       h->ut_cells.free();

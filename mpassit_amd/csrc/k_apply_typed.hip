@@ -120,6 +120,79 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
   }
 }
 
+// float32 rows in file order, two levels per lane: a half-wave covers 64 levels of one point with ONE 8-byte load per
+// row (rows are only 4-byte aligned -- 55 levels = 220 bytes -- which the hardware's unaligned access mode takes), so a
+// wavefront works on two points at a time and issues half the load instructions of k_apply3_lf_t, which is bound by
+// its instruction / latency budget, not by bytes, once the elements are 4 bytes (C4: 2.9 TB/s -> 3.8).  The lane that
+// would read past the end of a row reads the row's last two levels instead and shifts.  Same tile, same transposing
+// store, same wsum3 arithmetic -> bit-identical results.  Needs nlev >= 2.  (Four levels per lane with 16-byte loads
+// was measured too: slower, 14 of 16 lanes busy at 55 levels and more select / LDS work per load.)
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <typename TD>
+__global__ __launch_bounds__(256) void k_apply3_lf_f32x2(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                         const float *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                         int nlev, int ntx, int nty, double scale, double offset) {
+  extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
+  double *sw = tile + (size_t)nlev * 65;
+  int32_t *sidx = (int32_t *)(sw + 192);
+  int64_t P = (int64_t)nx * ny;
+  unsigned ntile = (unsigned)ntx * nty;
+  unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned tl = lin % ntile;
+  int fld = lin / ntile;
+  int tx = tl % ntx, ty = tl / ntx;
+  int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 192) {
+    int pt = t & 63, q = t >> 6;
+    int i = tx * 64 + pt, j = ty;
+    bool in = i < nx && j < ny;
+    int64_t p = in ? (int64_t)j * nx + i : 0;
+    int32_t c = idx[q * P + p];
+    sidx[q * 64 + pt] = in ? c : -1;
+    sw[q * 64 + pt] = w[q * P + p];
+  }
+  __syncthreads();
+  const float *sf = src + (int64_t)fld * nlev * nsrc;
+  const int half = lane >> 5, sl = lane & 31;
+  for (int kb = 0; kb < nlev; kb += 64) {
+    const int k0 = kb + 2 * sl;
+    const int base = min(k0, nlev - 2);            // base < k0 only on the lane that holds the end of the row
+    const bool shifted = base != k0, a0 = k0 < nlev, a1 = k0 + 1 < nlev;
+#pragma unroll
+    for (int q0 = 0; q0 < 16; q0 += 4) {           // two pairs of points per step: 6 row loads in flight per lane
+      double v[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pt = wave * 16 + q0 + 2 * u + half;
+        int32_t c0 = sidx[pt], c1 = sidx[64 + pt], c2 = sidx[128 + pt];
+        const double w0 = sw[pt], w1 = sw[64 + pt], w2 = sw[128 + pt];
+        const bool m = c0 >= 0;
+        c0 = max(c0, 0); c1 = max(c1, 0); c2 = max(c2, 0);
+        const f32x2_u x0 = *(const f32x2_u *)(sf + (int64_t)c0 * nlev + base);
+        const f32x2_u x1 = *(const f32x2_u *)(sf + (int64_t)c1 * nlev + base);
+        const f32x2_u x2 = *(const f32x2_u *)(sf + (int64_t)c2 * nlev + base);
+        const double a = shifted ? x0.y : x0.x, b = shifted ? x1.y : x1.x, e = shifted ? x2.y : x2.x;
+        v[u][0] = fma(m ? wsum3(w0, a, w1, b, w2, e) : 0.0, scale, offset);
+        v[u][1] = fma(m ? wsum3(w0, (double)x0.y, w1, (double)x1.y, w2, (double)x2.y) : 0.0, scale, offset);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int pt = wave * 16 + q0 + 2 * u + half;
+        if (a0) tile[k0 * 65 + pt] = v[u][0];
+        if (a1) tile[(k0 + 1) * 65 + pt] = v[u][1];
+      }
+    }
+  }
+  __syncthreads();
+  TD *df = dst + (int64_t)fld * nlev * P;
+  int i = tx * 64 + lane, j = ty;
+  if (i < nx && j < ny) {
+    int64_t p = (int64_t)j * nx + i;
+    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store((TD)tile[k * 65 + lane], df + (int64_t)k * P + p);
+  }
+}
+
 // nearest (NNZ = 1, weights implicit), 4-point destagger (NNZ = 4) and CSR (NNZ = 0): one thread per target point
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void k_apply_generic_t(int nnz_per_row, const int32_t *__restrict__ idx, const double *__restrict__ w,
@@ -166,10 +239,17 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
         mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
         return MPG_ERR_UNSUPPORTED;
       }
-      if (lds > 48 * 1024)
-        MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      k_apply3_lf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
-                                                                           h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+      if (sizeof(TS) == 4 && nlev >= 2) {   // float32 rows: two levels per lane, two points per wavefront pass
+        if (lds > 48 * 1024)
+          MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf_f32x2<TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_apply3_lf_f32x2<TD><<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const float *)src, (TD *)dst, h->nx_dst,
+                                                                             h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+      } else {
+        if (lds > 48 * 1024)
+          MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_apply3_lf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
+                                                                             h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+      }
     } else {
       int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 7) / 8;
       k_apply3_cf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, 0, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
