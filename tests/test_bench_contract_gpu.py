@@ -1,0 +1,31 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (metric / value / unit / n_gpus / steps / warmup /
+ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus the roofline and
+cpu_baseline objects; checked here on the tiny workload so that a change to bench.py cannot silently break the contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_the_contract_line(gpu_lib):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--fields", "2", "--steps", "3", "--warmup", "1",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["metric"].startswith("interpolated 3-D fields/sec") and rec["unit"] == "fields/s" and rec["value"] > 0
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["ms_per_step"] > 0
+    assert rec["higher_is_better"] is True and rec["scaling"] in ("weak", "strong") and rec["vs_baseline"] is None
+    assert rec["dtype"] == "f64" and rec["data"] == "synthetic" and "tiny" in rec["config"]["workload"] and "model" not in rec["config"]
+    assert abs(rec["value"] - 2 * 3 / (rec["ms_per_step"] * 3e-3)) < 1e-6 * rec["value"]          # fields * steps / time
+    ro = rec["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and ro["achieved"] > 0
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and (ro["traffic"] is None or ro["traffic"] > 0)
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "fields/s" and cb["value"] > 0 and cb["cores"] >= 1 and isinstance(cb["sample"], str)
