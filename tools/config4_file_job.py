@@ -133,9 +133,10 @@ def main():
     if missing:
         print("not in the fortran output:", missing)
     print("fortran vs python output: %d variables compared, %d missing, worst |diff| / max(1, |field|max) = %.2e" % (len(names), len(missing), worst))
-    for f in os.listdir(d):
-        os.remove(os.path.join(d, f))
-    os.rmdir(d)
+    if not os.environ.get("C4JOB_KEEP"):             # C4JOB_KEEP=1: leave inputs, lists and namelist for a profiler run of the driver
+        for f in os.listdir(d):
+            os.remove(os.path.join(d, f))
+        os.rmdir(d)
     return 0 if same and not missing and worst < 1e-6 else 1
 
 
