@@ -271,11 +271,19 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
             w.def_var(name, ncio.FLOAT, ("Time",) + dims, MemoryOrder="XYZ" if a.ndim == 3 else "XY ", coordinates="XLONG XLAT XTIME",
                       stagger="X" if a.shape[-1] == nx + 1 else ("Y" if a.shape[-2] == ny + 1 else ""), FieldType=104)
         # ---- data (:1003-1475) ----
+        from_file = bool(target.extra.get("from_file"))        # target_grid_type = 'file': the grid variables are the file's own
+        host = {"M": (target.lon, target.lat, "mapfac_m"), "U": (target.lon_u, target.lat_u, "mapfac_u"), "V": (target.lon_v, target.lat_v, "mapfac_v")}
         for name, st, dims, _, _ in _GRID_VARS:
-            lon, lat = grid.coords(stag[st][0])
-            w.put(name, grid.mapfac(stag[st][0]) if name.startswith("MAPFAC") else (lon if "LONG" in name else lat), rec=0)
+            if from_file:
+                lon, lat, mk = host[st]
+                mf = target.extra.get(mk)
+                mf = np.ones_like(lon) if mf is None else mf
+            else:
+                lon, lat = grid.coords(stag[st][0])
+                mf = grid.mapfac(stag[st][0]) if name.startswith("MAPFAC") else None
+            w.put(name, mf if name.startswith("MAPFAC") else (lon if "LONG" in name else lat), rec=0)
         if lc:
-            cosa, sina = grid.rotang()
+            cosa, sina = (target.cosa, target.sina) if from_file else grid.rotang()
             w.put("SINALPHA", sina, rec=0)
             w.put("COSALPHA", cosa, rec=0)
         w.put("ZS", np.zeros(max(nsoil, 1), np.float32) if zs is None else np.asarray(zs, np.float32), rec=0)
@@ -314,7 +322,7 @@ def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=No
     inp, _, valid = read_input_data(hist_path, cfg, ter, diag_path=diag_path, device="cuda" if device_io else None)
     t = lap("read_input_data", t)
     mesh = R.Mesh.from_mpas(mpas)
-    grid = R.Grid.from_proj(target)
+    grid = R.Grid.from_target(target) if target.extra.get("from_file") else R.Grid.from_proj(target)
     t = lap("mesh_grid_create", t)
     out = I.interp_data(mesh, grid, target, inp, cfg)
     t = lap("interp_data", t)
@@ -344,7 +352,7 @@ def run_series(grid_path, jobs, target, cfg, namelist=None, fmt=5, timings=None)
     t0 = time.perf_counter()
     mpas, ter, zs = read_grid(grid_path)
     mesh = R.Mesh.from_mpas(mpas)
-    grid = R.Grid.from_proj(target)
+    grid = R.Grid.from_target(target) if target.extra.get("from_file") else R.Grid.from_proj(target)
     stream = torch.cuda.Stream()
 
     def fetch(job):

@@ -303,6 +303,6 @@ def define_target_grid_file(path):
                 pass
         if code == PROJ_LC:
             g.sina, g.cosa = var("SINALPHA"), var("COSALPHA")
-        g.extra.update(ref_lat=att("MOAD_CEN_LAT", att("CEN_LAT")), ref_lon=att("CEN_LON"), pole_lat=att("POLE_LAT", 90.0),
+        g.extra.update(from_file=True, ref_lat=att("MOAD_CEN_LAT", att("CEN_LAT")), ref_lon=att("CEN_LON"), pole_lat=att("POLE_LAT", 90.0),
                        pole_lon=att("POLE_LON", 0.0))
     return g

@@ -157,6 +157,12 @@ def test_driver_with_a_file_defined_target_grid(tmp_path, gpu_lib, regional_case
                 assert np.array_equal(got, w_), k
             else:   # the corners come from two libms (flang runtime / numpy): the conservative weights may differ in the last bits
                 assert np.abs(got - w_).max() <= 2e-7 * max(1.0, float(np.abs(w_).max())), k
+    # the Python file job takes the same file-defined grid (grid variables = the file's own)
+    io_nc.run(os.path.join(d, "init.nc"), os.path.join(d, "hist.nc"), os.path.join(d, "out_py.nc"), t, cfg, diag_path=os.path.join(d, "diag.nc"),
+              namelist=dict(dx=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5), device_io=True)
+    with ncio.Reader(os.path.join(d, "out.nc")) as f, ncio.Reader(os.path.join(d, "out_py.nc")) as fp:
+        for k in ("XLAT", "XLONG_U", "MAPFAC_M", "MAPFAC_V", "SINALPHA", "COSALPHA", "T", "U", "V", "XLAND", "TSLB", "P_TOP"):
+            assert np.array_equal(f.get(k, rec=0), fp.get(k, rec=0)), k
 
 
 def test_driver_on_a_global_latlon_grid(tmp_path, gpu_lib):
