@@ -40,9 +40,29 @@ NAMELIST = """&config
 """
 
 
+NAMELIST_C5 = """&config
+  grid_file_input_grid="{d}/init.nc"
+  hist_file_input_grid="{d}/hist.nc"
+  diag_file_input_grid="{d}/diag.nc"
+  output_file="{d}/out_fortran.nc"
+  target_grid_type = 'lat-lon'
+  interp_diag=.true.
+  interp_hist=.true.
+  wrf_mod_vars=.true.
+  is_regional=.false.
+  nx = 3601
+  ny = 1801
+  stand_lon = 0.0
+/
+"""
+
+
 def main():
     import torch
     from test_fields import HIST_2D, HIST_3D, SOIL
+    c5 = os.environ.get("C4JOB_CONFIG") == "5"      # configuration 5: 2.6 M-cell global mesh -> 3600x1800 global lat-lon grid
+    if c5:
+        HIST_3D = [p for p in HIST_3D if p[0] in ("zgrid", "theta", "uReconstructZonal", "uReconstructMeridional", "pressure", "qv")]
 
     from mpassit_amd import _lib, build, interp as I, io_nc, ncio, synth, workloads
     build.build()
@@ -50,9 +70,12 @@ def main():
     _lib.init(0)
     d = sys.argv[1] if len(sys.argv) > 1 else "/dev/shm/c4job"
     os.makedirs(d, exist_ok=True)
-    m, g, nz, _ = workloads.workload("c4_3m_regional", arrays=False)
+    if c5:
+        m, g, nz, _ = workloads.workload("c5_global_latlon")
+    else:
+        m, g, nz, _ = workloads.workload("c4_3m_regional", arrays=False)
     nsoil = 4
-    diag_list = [("u10", "U10"), ("v10", "V10"), ("refl10cm", "REFL_10CM")] + [("d2d_%02d" % k, "D2D_%02d" % k) for k in range(16)]
+    diag_list = [("u10", "U10"), ("v10", "V10"), ("refl10cm", "REFL_10CM")] + [("d2d_%02d" % k, "D2D_%02d" % k) for k in range(2 if c5 else 16)]
     rng = np.random.default_rng(4)
     f32 = lambda a: np.asarray(a, np.float32)           # noqa: E731
     t0 = time.perf_counter()
@@ -82,7 +105,7 @@ def main():
     for fname, lst in (("diaglist", diag_list), ("histlist_2d", HIST_2D), ("histlist_3d", HIST_3D), ("histlist_soil", SOIL)):
         with open(os.path.join(d, fname), "w") as f:
             f.write("".join("%s\t\t%s\n" % p for p in lst))
-    open(os.path.join(d, "namelist.input"), "w").write(NAMELIST.format(d=d))
+    open(os.path.join(d, "namelist.input"), "w").write((NAMELIST_C5 if c5 else NAMELIST).format(d=d))
 
     for nt in [v for v in os.environ.get("C4JOB_NCIO_THREADS", "").split(",") if v]:   # optional sweep of ncio's thread count
         t0 = time.perf_counter()
@@ -104,8 +127,10 @@ def main():
     print("fortran, device flow:  %.2f s wall (process start to exit; %.2f GB out)" % (t_f, gb_out), flush=True)
     print("    " + "  ".join(ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("[")), flush=True)
 
-    cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=diag_list, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
+    cfg = I.InterpConfig(wrf_mod_vars=True, proj_is_lambert=not c5, diag_list=diag_list, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
     nml = dict(dx=3000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+    if c5:
+        nml = dict(dx=6370000.0 * 2 * np.pi / 3600, stand_lon=0.0)
     for mode, out in ((False, "out_host.nc"), (True, "out_dev.nc"), (True, "out_dev.nc")):
         tm = {}
         torch.cuda.synchronize()
