@@ -60,16 +60,35 @@ def synth_fields_device(torch, lat, lon, nlev, nfields, out_rows, seed=20240807)
         out_rows[r].copy_(co[r, 0] + co[r, 1] * x + co[r, 2] * y + co[r, 3] * z + wig)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a torch.distributed.run environment: start the N ranks as a
+    fresh child job (one process per GPU, rendezvous on 127.0.0.1) and relay its output and exit code.  This parent has
+    not touched the GPU (nothing but argparse has run) and never replaces itself with another program; rank 0 of the
+    child job prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL P2P over xGMI on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start bench.py with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     ndev = torch.cuda.device_count()
@@ -136,23 +155,27 @@ def main():
         bufs = [local, local2]
         owns = [own, sr.own_view(local2)] if sr.sched.mode == "range" else [own, own]
         halo_stream = torch.cuda.Stream(device=dev)
-        pipe = {"n": 0, "halo_done": [None, None], "comp_done": [None, None]}
+        pipe = {"n": 0, "halo_done": [torch.cuda.Event(), torch.cuda.Event()], "comp_done": [None, None], "ev": []}
 
-        def exchange_into(b):
+        def exchange_into(b, record=False):
             with torch.cuda.stream(halo_stream):
                 if pipe["comp_done"][b] is not None:
                     halo_stream.wait_event(pipe["comp_done"][b])   # the Regrid that last read this buffer
+                if record:
+                    x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    x0.record(halo_stream)
                 sr.sched.exchange(owns[b], bufs[b], pack_fn=sr._pack)
-                e = torch.cuda.Event()
-                e.record(halo_stream)
-                pipe["halo_done"][b] = e
+                if record:
+                    x1.record(halo_stream)
+                    pipe["ev"].append((x0, x1))
+                pipe["halo_done"][b].record(halo_stream)
         halo_stream.wait_stream(torch.cuda.current_stream())
         exchange_into(0)
 
     def one_step(record):
         if world > 1:
             b = pipe["n"] % 2
-            exchange_into(1 - b)                                   # next batch's halo, overlapped
+            exchange_into(1 - b, record)                           # next batch's halo, overlapped
             torch.cuda.current_stream().wait_event(pipe["halo_done"][b])
             src_t = bufs[b]
         else:
@@ -168,9 +191,9 @@ def main():
             e1.record()
             ev.append((e0, e1))
         if world > 1:
-            e = torch.cuda.Event()
-            e.record()
-            pipe["comp_done"][b] = e
+            if pipe["comp_done"][b] is None:
+                pipe["comp_done"][b] = torch.cuda.Event()
+            pipe["comp_done"][b].record()
             pipe["n"] += 1
 
     if args.calib:  # 1 GiB read / 1 GiB write, 8 B per lane fully coalesced: calibrates FETCH_SIZE / WRITE_SIZE
@@ -203,6 +226,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    halo = None
+    if world > 1:   # the exchange as the halo stream saw it (it overlaps the Regrid of the previous batch), and what it moved
+        plan = sr.sched.plan(F * nlev, local)
+        per_rank = all_gather_object({"exchange_ms": float(np.mean([a.elapsed_time(b) for a, b in pipe["ev"]])) if pipe["ev"] else None,
+                                      "kernel_ms": kern_ms, "sent": int(plan.bytes_sent), "received": int(plan.bytes_received),
+                                      "n_local": int(sr.sched.n_local), "needed": int(sr.n_needed), "rows": int(sr.j1 - sr.j0)})
+        halo = {"mode": sr.sched.mode, "transport": "%s all_to_all_single (grouped send/recv, zero-size peers skipped)" % backend,
+                "ranks_in_group": dist.get_world_size(),
+                "exchange_ms_max": max(r["exchange_ms"] or 0.0 for r in per_rank),
+                "kernel_ms_max": max(r["kernel_ms"] for r in per_rank),
+                "halo_bytes_per_step": sum(r["received"] for r in per_rank),
+                "halo_bytes_per_step_max_rank": max(r["received"] for r in per_rank),
+                "per_rank": per_rank}
 
     # correctness guard inside the bench: constant field -> constant on mapped points (sum of weights = 1)
     chk = torch.full((nlev, sr.sched.n_local), 2.5, dtype=torch.float64, device=dev)
@@ -277,6 +313,7 @@ def main():
                          "device_copy_GBs": copy_gbs},
             "cpu_baseline": cpu,
             "end_to_end_pcie": e2e,
+            "halo": halo,
             "store_ms": sr.store_ms,
             "device": {"arch": arch, "cus": n_cu, "hbm_gib": round(hbm / 2 ** 30, 1), "name": torch.cuda.get_device_name(dev),
                        "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))},

@@ -55,6 +55,7 @@ class HaloSchedule:
     send_ids: list = field(default_factory=list)   # per peer: owned-slab offsets to send (np.int32) or (a, b) range
     recv_pos: list = field(default_factory=list)   # per peer: (a, b) destination range in the local index space
     own_pos: tuple = (0, 0)        # range mode: where the own block sits in the local index space
+    _plans: dict = field(default_factory=dict, repr=False)   # (rows, dtype, device) -> preallocated exchange buffers
 
     @staticmethod
     def build(needed_ids, n_cells, rank, world, all_gather_object, ownership="aligned", range_slack=1.25):
@@ -132,49 +133,81 @@ class HaloSchedule:
         recv = [b - a for a, b in self.recv_pos]
         return send, recv
 
-    def exchange(self, own_rows, local_rows, pack_fn=None):
-        """own_rows: tensor [R][n_own] of this rank's block (R = nfields*nlev rows);
-        local_rows: tensor [R][n_local], filled in place.  In range mode `own_rows` may be a view of
-        `local_rows` (own data already in place).  pack_fn(own_rows, ids) -> [R][len(ids)] gathers columns
-        (HIP pack kernel on the GPU, index_select in the CPU tests)."""
+    def plan(self, R, like):
+        """Everything `exchange` needs for batches of R rows, allocated ONCE per (R, dtype, device): the packed send and
+        receive buffers, their per-peer views, the split lists of the all-to-all-v and (gloo rehearsal on device tensors
+        only) pinned host staging.  The per-step path then consists of copy launches and one collective -- no allocation,
+        no list building, no torch.cat."""
         import torch
-        import torch.distributed as dist
-        R = own_rows.shape[0]
+        key = (int(R), like.dtype, like.device)
+        p = self._plans.get(key)
+        if p is not None:
+            return p
         send_n, recv_n = self.counts()
-        parts = []
+        p = _HaloPlan()
+        p.sendbuf = torch.empty(R * sum(send_n), dtype=like.dtype, device=like.device)
+        p.recvbuf = torch.empty(R * sum(recv_n), dtype=like.dtype, device=like.device)
+        p.in_splits, p.out_splits = [R * n for n in recv_n], [R * n for n in send_n]
+        p.send_views, p.recv_views = [], []
+        off = 0
         for q in range(self.world):
-            if send_n[q] == 0:
-                continue
-            if self.mode == "range":
-                a, b = self.send_ids[q]
-                parts.append(own_rows[:, a:b].reshape(-1))
-            else:
-                ids = self.send_ids[q]
-                if pack_fn is not None:
-                    parts.append(pack_fn(own_rows, ids).reshape(-1))
+            n = send_n[q]
+            if n:
+                view = p.sendbuf[off:off + R * n].view(R, n)
+                if self.mode == "range":
+                    p.send_views.append((view, self.send_ids[q], None))
                 else:
-                    parts.append(own_rows[:, torch.as_tensor(ids, dtype=torch.long, device=own_rows.device)].reshape(-1))
-        sendbuf = torch.cat(parts) if parts else own_rows.new_empty(0)
-        recvbuf = own_rows.new_empty(R * sum(recv_n))
-        if self.world > 1:
-            if sendbuf.is_cuda and dist.get_backend() == "gloo":
-                # rehearsal transport (gloo moves host memory); the production transport is RCCL on device memory
-                rb = torch.empty(recvbuf.shape, dtype=recvbuf.dtype)
-                dist.all_to_all_single(rb, sendbuf.cpu(), [R * n for n in recv_n], [R * n for n in send_n])
-                recvbuf.copy_(rb)
-            else:
-                dist.all_to_all_single(recvbuf, sendbuf, [R * n for n in recv_n], [R * n for n in send_n])
-        else:
-            recvbuf.copy_(sendbuf)
+                    ids = self.send_ids[q]
+                    p.send_views.append((view, ids, torch.as_tensor(ids, dtype=torch.long, device=like.device)))
+                off += R * n
         off = 0
         for q in range(self.world):
             n = recv_n[q]
-            if n == 0:
-                continue
-            a, b = self.recv_pos[q]
-            local_rows[:, a:b].copy_(recvbuf[off:off + R * n].view(R, n))
-            off += R * n
+            if n:
+                p.recv_views.append((p.recvbuf[off:off + R * n].view(R, n), self.recv_pos[q]))
+                off += R * n
+        p.host_send = p.host_recv = None
+        p.bytes_sent = p.sendbuf.numel() * p.sendbuf.element_size()
+        p.bytes_received = p.recvbuf.numel() * p.recvbuf.element_size()
+        self._plans[key] = p
+        return p
+
+    def exchange(self, own_rows, local_rows, pack_fn=None):
+        """own_rows: tensor [R][n_own] of this rank's block (R = nfields*nlev rows);
+        local_rows: tensor [R][n_local], filled in place.  In range mode `own_rows` may be a view of
+        `local_rows` (own data already in place).  pack_fn(own_rows, ids, out) gathers columns into `out` [R][len(ids)]
+        (HIP pack kernel on the GPU; index_select in the CPU tests when pack_fn is None)."""
+        import torch
+        import torch.distributed as dist
+        p = self.plan(own_rows.shape[0], own_rows)
+        for view, ids, ids_t in p.send_views:
+            if ids_t is None:
+                view.copy_(own_rows[:, ids[0]:ids[1]])
+            elif pack_fn is not None:
+                pack_fn(own_rows, ids, view)
+            else:
+                torch.index_select(own_rows, 1, ids_t, out=view)
+        if self.world > 1:
+            if p.sendbuf.is_cuda and dist.get_backend() == "gloo":
+                # rehearsal transport (gloo moves host memory); the production transport is RCCL on device memory
+                if p.host_send is None:
+                    p.host_send = torch.empty(p.sendbuf.shape, dtype=p.sendbuf.dtype).pin_memory()
+                    p.host_recv = torch.empty(p.recvbuf.shape, dtype=p.recvbuf.dtype).pin_memory()
+                p.host_send.copy_(p.sendbuf)
+                dist.all_to_all_single(p.host_recv, p.host_send, p.in_splits, p.out_splits)
+                p.recvbuf.copy_(p.host_recv)
+            else:
+                dist.all_to_all_single(p.recvbuf, p.sendbuf, p.in_splits, p.out_splits)
+        else:
+            p.recvbuf.copy_(p.sendbuf)
+        for view, (a, b) in p.recv_views:
+            local_rows[:, a:b].copy_(view)
         return local_rows
+
+
+class _HaloPlan:
+    __slots__ = ("sendbuf", "recvbuf", "in_splits", "out_splits", "send_views", "recv_views", "host_send", "host_recv",
+                 "bytes_sent", "bytes_received")
 
 
 class ShardedRegrid:
@@ -197,8 +230,8 @@ class ShardedRegrid:
             self.rh.localize()
         self._ids_dev = {}
 
-    def _pack(self, own_rows, ids):
-        """HIP gather of owned columns (mpg_pack_dev)."""
+    def _pack(self, own_rows, ids, out=None):
+        """HIP gather of owned columns (mpg_pack_dev) into `out` [R][len(ids)] (contiguous)."""
         import ctypes as C
 
         import torch
@@ -208,7 +241,8 @@ class ShardedRegrid:
         if key not in self._ids_dev:
             self._ids_dev[key] = torch.as_tensor(ids, device=own_rows.device)
         ids_d = self._ids_dev[key]
-        out = torch.empty((own_rows.shape[0], ids.size), dtype=own_rows.dtype, device=own_rows.device)
+        if out is None:
+            out = torch.empty((own_rows.shape[0], ids.size), dtype=own_rows.dtype, device=own_rows.device)
         L.check(L.load().mpg_pack_dev(C.c_void_p(own_rows.data_ptr()), C.c_int64(own_rows.shape[1]), C.c_int(own_rows.shape[0]),
                                       C.c_void_p(ids_d.data_ptr()), C.c_int64(ids.size), C.c_void_p(out.data_ptr()),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))

@@ -28,10 +28,18 @@ def workload(name, arrays=True):
         g = conus_lambert_grid()
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
         return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1801x1061 Lambert (1800x1060 mass points)"
-    if name == "c2_655k_regional":
+    if name == "c2_655k_global":
+        # BASELINE configs 2 and 3: the GLOBAL quasi-uniform 655 362-cell mesh (10*4^8 + 2 cells = MPAS x1.655362, SURVEY
+        # s8(d)) under the README Lambert domain, which touches only 2-3 % of its cells; Morton-numbered.
+        g = conus_lambert_grid()
+        m = synth.icosahedral_mesh(8)
+        return m, g, 55, "655 362-cell global icosahedral mesh (x1.655362) x 55 levels -> 1801x1061 Lambert (1800x1060 mass points)"
+    if name == "x_655k_lattice":
+        # extra workload (not a BASELINE config): 655 362 cells of a row-numbered regional lattice laid over the Lambert
+        # domain -- every cell referenced, 2.9 target points per cell
         g = conus_lambert_grid()
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 655_362)
-        return m, g, 55, "655 362-cell regional hex mesh x 55 levels -> 1801x1061 Lambert"
+        return m, g, 55, "655 362-cell regional hex lattice x 55 levels -> 1801x1061 Lambert"
     if name == "c1_65k_global":
         g = tg.define_target_grid_params("lat-lon", 201, 201, dx=0.1, dy=0.1, ref_lat=30.0, ref_lon=-110.0, ref_x=1.0, ref_y=1.0,
                                          stand_lon=-110.0)

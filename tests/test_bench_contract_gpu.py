@@ -29,3 +29,26 @@ def test_bench_prints_the_contract_line(gpu_lib):
     assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12 and (ro["traffic"] is None or ro["traffic"] > 0)
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "fields/s" and cb["value"] > 0 and cb["cores"] >= 1 and isinstance(cb["sample"], str)
+
+
+def test_bench_gpus2_launches_itself(gpu_lib):
+    """`python bench.py --gpus 2` with no torch.distributed.run around it starts its own two ranks (a child job, the
+    parent never touches the GPU) and rank 0 prints the line; on the one-GPU box the ranks share the card and the halo
+    travels over gloo (MPASSIT_DIST_BACKEND=gloo), on the 8-GPU node the same flow runs over RCCL.  The headline
+    workload itself (C4, strong scaling: the same global problem split by target rows)."""
+    env = dict(os.environ, MPASSIT_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "strong" and rec["value"] > 0
+    assert "c4_3m_regional" in rec["config"]["workload"] and rec["config"]["parallelism"].startswith("rows2+halo")
+    h = rec["halo"]
+    assert h["ranks_in_group"] == 2 and h["mode"] == "range" and len(h["per_rank"]) == 2
+    assert sum(p["rows"] for p in h["per_rank"]) == 1060
+    # aligned ownership: only the strips straddling the row-block boundary travel -- a few lattice rows of 13 x 55 values
+    assert 0 < h["halo_bytes_per_step"] < 200e6 and h["exchange_ms_max"] > 0

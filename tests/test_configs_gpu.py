@@ -1,0 +1,270 @@
+"""BASELINE.json configurations 1-3 at their full sizes, against the oracle (the oracle's searches are hashed and its
+apply loops threaded, so the 655 362-cell mesh -> 1800x1060 points takes it seconds):
+
+  C1  65 536-cell quasi-uniform global mesh, 10 levels, 5 histlist_3d fields -> 200x200 lat-lon; all three methods.
+  C2  655 362-cell GLOBAL mesh (10*4^8+2 cells = MPAS x1.655362), 55 levels, the reference's full parm/histlist_2d +
+      histlist_3d through interp_data (bilinear + nearest) -> 1801x1061 Lambert of the README namelist.
+  C3  the same mesh + conservative snow/snowh + parm/histlist_soil with the method fall-through of interp.F90:436-447.
+
+The Lambert domain covers 2-3 % of the global mesh: most source cells are never referenced.
+Configurations 4 and 5: tests/test_fullsize_gpu.py and tests/test_config5_gpu.py.
+"""
+import numpy as np
+import pytest
+
+from _parity_helpers import assert_csr_equal, assert_fixed_weights_equal, assert_nearest_equal, conserve_tol, rel_err
+from conftest import mesh_xyz
+from test_fields import HIST_2D, HIST_3D, SOIL
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6   # north_star tolerance (bilinear / conservative values); indices, nearest copies and rotation: bit-exact
+
+
+class OracleSide:
+    """Everything the oracle needs for one (mesh, grid): unit vectors, dual triangles, the three weight sets."""
+
+    def __init__(self, o, m, g):
+        self.o, self.m, self.g = o, m, g
+        self.cxyz, self.vxyz = mesh_xyz(o, m)
+        self.tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, self.cxyz)
+        self.pxyz = o.lonlat_deg_to_xyz(g.lon, g.lat)
+        self.shape = (g.ny, g.nx)
+        self.ctol = conserve_tol(o, g)
+        self._bil = self._near = self._cons = None
+
+    @property
+    def bil(self):
+        if self._bil is None:
+            self._bil = self.o.bilinear_weights(self.cxyz, self.tri, self.pxyz)
+        return self._bil
+
+    @property
+    def near(self):
+        if self._near is None:
+            self._near = self.o.nearest(self.cxyz, self.pxyz)
+        return self._near
+
+    @property
+    def cons(self):
+        if self._cons is None:
+            g = self.g
+            self._cons = self.o.conserve(self.m.verticesOnCell, self.vxyz, g.nx, g.ny, self.o.lonlat_deg_to_xyz(g.lon_c, g.lat_c))
+        return self._cons
+
+    def apply_bil(self, x, L):
+        return self.o.apply_fixed(self.bil[0], self.bil[1], np.atleast_2d(x), L).reshape((L,) + self.shape)
+
+
+def check_stores(R, mesh, grid, osd, methods):
+    """RegridStore of every method against the oracle's weight sets, every differing entry examined."""
+    m = osd.m
+    out = {}
+    if "bilinear" in methods:
+        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+        idx_g, w_g = rh.weights()
+        out["bil_ties"] = assert_fixed_weights_equal(osd.bil[0], osd.bil[1], idx_g, w_g, tol=1e-11)
+        out["mapped"] = idx_g[:, 0] >= 0
+        assert np.abs(w_g[out["mapped"]].sum(1) - 1).max() < 1e-13
+        out["unique_sources"] = rh.unique_sources().size
+        rh.release()
+    if "nearest" in methods:
+        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+        idx_g = rh.weights()[0][:, 0]
+        out["near_ties"] = assert_nearest_equal(osd.near, idx_g, osd.pxyz, osd.cxyz, max_ties=2)
+        out["near_idx"] = idx_g
+        rh.release()
+    if "conserve" in methods:
+        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+        rp_g, col_g, val_g = rh.csr()
+        rp_o, col_o, val_o = osd.cons
+        n_common, only_o, only_g = assert_csr_equal(rp_o, col_o, val_o, rp_g, col_g, val_g, m.nCells, tol=osd.ctol)
+        assert n_common > 0.999 * max(col_o.size, col_g.size)
+        P = rp_g.size - 1
+        rowsum = np.bincount(np.repeat(np.arange(P), np.diff(rp_g)), weights=val_g, minlength=P)
+        assert val_g.min() > 0 and rowsum.max() < 1 + 8 * osd.ctol
+        out["rowsum"] = rowsum
+        rh.release()
+    return out
+
+
+def make_inputs(torch, synth, m, lists2d, lists3d, soil, nz, nsoil, seed0=100):
+    """Seeded device-resident fields for the reference's lists (names classify them, input_data.F90:840-911)."""
+    from mpassit_amd import interp as I
+    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil)
+    host = {}
+    rng = np.random.default_rng(seed0)
+
+    def dev(a):
+        return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+    host["hgt"] = synth.analytic_field(m.latCell, m.lonCell, 1, seed=seed0 + 1)[0] * 1000.0
+    inp.hgt = dev(host["hgt"])
+    for k, (n, _) in enumerate(lists2d):
+        if n in ("xland", "ivgtyp", "isltyp", "landmask"):
+            a = synth.category_field(m.nCells, 1, seed=seed0 + 2 + k, ncat=17)[0]
+        elif n in ("snow", "snowh"):
+            a = synth.snow_field(m.latCell, m.lonCell)[0] * (1.0 + k)
+        else:
+            a = synth.analytic_field(m.latCell, m.lonCell, 1, seed=seed0 + 20 + k)[0] + 280.0
+        host[n] = a
+        inp.hist[n] = dev(a)
+    for k, (n, _) in enumerate(lists3d):
+        a = synth.analytic_field(m.latCell, m.lonCell, nz + 1 if n in ("zgrid", "w") else nz, seed=seed0 + 40 + k)
+        host[n] = a
+        inp.hist[n] = dev(a)
+    for k, (n, _) in enumerate(soil):
+        a = rng.uniform(0.0, 1.0, (nsoil, m.nCells))
+        host[n] = a
+        inp.hist[n] = dev(a)
+    return inp, host
+
+
+def check_hist_outputs(o, osd, g, out, host, lists2d, lists3d, soil, nz, nsoil, wrf_mod_vars, lambert):
+    """interp_hist_data's outputs (interp.F90:183-465) field by field against the same sequence from oracle primitives."""
+    shp = osd.shape
+
+    def got(t):
+        return out.pop(t).cpu().numpy()
+    assert rel_err(got("HGT"), osd.apply_bil(host["hgt"], 1)[0]) < 1e-12
+    names2d = [n for n, _ in lists2d]
+    soil_by = "nearest" if any(n in ("xland", "ivgtyp", "isltyp", "landmask") for n in names2d) else (
+        "conserve" if any(n in ("snow", "snowh") for n in names2d) else "bilinear")
+    for n, t in lists2d:
+        if n in ("snow", "snowh"):
+            want = o.apply_csr(*osd.cons, host[n][None, :], 1).reshape(shp)
+            assert rel_err(got(t), want) < osd.ctol < RTOL, n
+        elif n in ("xland", "ivgtyp", "isltyp", "landmask"):
+            assert np.array_equal(got(t), o.apply_nearest(osd.near, host[n][None, :], 1).reshape(shp)), n   # bit exact
+        else:
+            assert rel_err(got(t), osd.apply_bil(host[n], 1)[0]) < 1e-12, n
+    um = vm = None
+    for n, t in lists3d:
+        if wrf_mod_vars and n in ("uReconstructZonal", "uReconstructMeridional"):
+            continue
+        L = nz + 1 if n in ("zgrid", "w") else nz
+        a = got(t)
+        assert a.shape == (L,) + shp
+        assert rel_err(a, osd.apply_bil(host[n], L)) < 1e-12 < RTOL, n
+    if wrf_mod_vars:
+        um, vm = osd.apply_bil(host["uReconstructZonal"], nz), osd.apply_bil(host["uReconstructMeridional"], nz)
+        if lambert:
+            um, vm = o.rotate_winds(g.cosa, g.sina, um, vm)
+            um, vm = um.reshape((nz,) + shp), vm.reshape((nz,) + shp)
+        assert rel_err(got("UMASS"), um) < 1e-12 and rel_err(got("VMASS"), vm) < 1e-12
+        cen = o.lonlat_deg_to_xyz(g.lon, g.lat)
+        for name, src, st, lon, lat in (("U", um, 1, g.lon_u, g.lat_u), ("V", vm, 2, g.lon_v, g.lat_v)):
+            gi, gw = o.grid_bilinear(g.nx, g.ny, cen, st, o.lonlat_deg_to_xyz(lon, lat))
+            want = o.apply_fixed(gi, gw, src.reshape(nz, -1), nz).reshape((nz,) + lon.shape)
+            a = got(name)
+            assert a.shape == want.shape                               # U on EDGE1 (nx+1), V on EDGE2 (ny+1)
+            interior = np.zeros(lon.shape, bool)
+            interior[1:-1, 1:-1] = True                                # outer ring: implementation-defined (App. A4)
+            assert np.abs(a[:, interior] - want[:, interior]).max() < 1e-9, name
+    for n, t in soil:   # soil follows the last method set (interp.F90:436-441; App. C3)
+        a = got(t)
+        if soil_by == "nearest":
+            assert np.array_equal(a, o.apply_nearest(osd.near, host[n], nsoil).reshape((nsoil,) + shp)), n
+        elif soil_by == "conserve":
+            assert rel_err(a, o.apply_csr(*osd.cons, host[n], nsoil).reshape((nsoil,) + shp)) < osd.ctol, n
+        else:
+            assert rel_err(a, osd.apply_bil(host[n], nsoil)) < 1e-12, n
+    assert not out, "unexpected outputs %s" % list(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config1_65k_global_to_latlon(gpu_lib, oracle):
+    """configs[0]: 65 536 cells, 10 levels, 5 histlist_3d fields -> 200x200 0.1-degree lat-lon grid."""
+    import torch
+    from mpassit_amd import interp as I, regrid as R, synth, workloads
+    m, g, nlev, _ = workloads.workload("c1_65k_global")
+    assert m.nCells == 65536 and (g.nx, g.ny, nlev) == (200, 200, 10)
+    osd = OracleSide(oracle, m, g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    assert np.array_equal(mesh.triangles(), osd.tri)
+    st = check_stores(R, mesh, grid, osd, ("bilinear", "nearest", "conserve"))
+    assert st["mapped"].all()                               # a closed sphere has no hull
+    assert np.abs(st["rowsum"] - 1).max() < 8 * osd.ctol           # every destination cell fully covered
+    lists3d = [p for p in HIST_3D if p[0] in ("theta", "qv", "qc", "pressure", "rho")]
+    assert len(lists3d) == 5
+    inp, host = make_inputs(torch, synth, m, [], lists3d, [], nlev, 1)
+    cfg = I.InterpConfig(interp_diag=False, wrf_mod_vars=False, proj_is_lambert=False, hist_3d=lists3d)
+    out = I.interp_data(mesh, grid, g, inp, cfg)
+    torch.cuda.synchronize()
+    check_hist_outputs(oracle, osd, g, out, host, [], lists3d, [], nlev, 1, False, False)
+    # the same five fields in MPAS file order, float32 as the history file stores them: fused transpose + widening
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    for n, _ in lists3d:
+        f32 = host[n].astype(np.float32)
+        want = oracle.apply_fixed(osd.bil[0], osd.bil[1], f32.astype(np.float64), nlev)
+        a = rh.regrid_typed(torch.as_tensor(np.ascontiguousarray(f32.T), device="cuda").view(-1), nlev=nlev, layout=R.LAYOUT_LEV_FAST,
+                            out_dtype=torch.float32)
+        assert np.array_equal(a.cpu().numpy().reshape(nlev, -1), want.astype(np.float32)) or \
+            rel_err(a.cpu().numpy().reshape(nlev, -1).astype(np.float64), want) < 2.0 ** -23
+    # nearest and conservative on 3-D data as well (the kernels that serve soil / snow)
+    cat = synth.category_field(m.nCells, nlev=nlev)
+    rh_n = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+    assert np.array_equal(rh_n.regrid(cat, nlev=nlev).reshape(nlev, -1), oracle.apply_nearest(osd.near, cat, nlev))
+    rh_c = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    assert rel_err(rh_c.regrid(host["theta"], nlev=nlev).reshape(nlev, -1), oracle.apply_csr(*osd.cons, host["theta"], nlev)) < osd.ctol
+    for h in (rh, rh_n, rh_c):
+        h.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+@pytest.fixture(scope="module")
+def c23(gpu_lib, oracle):
+    from mpassit_amd import regrid as R, workloads
+    m, g, nlev, _ = workloads.workload("c2_655k_global")
+    assert m.nCells == 655362 and (g.nx, g.ny, nlev) == (1800, 1060, 55)
+    osd = OracleSide(oracle, m, g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    yield dict(m=m, g=g, nlev=nlev, osd=osd, mesh=mesh, grid=grid)
+    mesh.destroy()
+    grid.destroy()
+
+
+def test_config2_655k_global_bilinear_nearest(c23, oracle):
+    """configs[1]: full parm/histlist_2d + histlist_3d at 55 levels -> 1801x1061 Lambert; bilinear + nearest.
+    (snow/snowh of histlist_2d are conservative by classification; they are checked in the C3 test, so this test runs
+    the 2-D list without them and the C3 test runs the full 2-D list + soil.)"""
+    import torch
+    from mpassit_amd import interp as I, regrid as R, synth
+    m, g, nz, osd, mesh, grid = (c23[k] for k in ("m", "g", "nlev", "osd", "mesh", "grid"))
+    assert np.array_equal(mesh.triangles(), osd.tri)
+    st = check_stores(R, mesh, grid, osd, ("bilinear", "nearest"))
+    assert st["mapped"].all()
+    assert 0.015 * m.nCells < st["unique_sources"] < 0.04 * m.nCells      # 2-3 % of the global mesh is touched
+    lists2d = [p for p in HIST_2D if p[0] not in ("snow", "snowh")]
+    inp, host = make_inputs(torch, synth, m, lists2d, HIST_3D, [], nz, 4)
+    cfg = I.InterpConfig(interp_diag=False, wrf_mod_vars=True, hist_2d=lists2d, hist_3d=HIST_3D)
+    out = I.interp_data(mesh, grid, g, inp, cfg)
+    torch.cuda.synchronize()
+    del inp
+    check_hist_outputs(oracle, osd, g, out, host, lists2d, HIST_3D, [], nz, 4, True, True)
+
+
+def test_config3_655k_conservative_snow_and_soil(c23, oracle):
+    """configs[2]: + conservative snow/snowh (interp.F90:368-416) + parm/histlist_soil through the method fall-through
+    (interp.F90:436-447): with the default lists the soil bundle inherits NEAREST_STOD (xland is listed); without any
+    nearest field it inherits CONSERVE."""
+    import torch
+    from mpassit_amd import interp as I, regrid as R, synth
+    m, g, nz, osd, mesh, grid = (c23[k] for k in ("m", "g", "nlev", "osd", "mesh", "grid"))
+    st = check_stores(R, mesh, grid, osd, ("conserve",))
+    assert np.abs(st["rowsum"] - 1).max() < 8 * osd.ctol                          # the Lambert domain lies inside the global mesh
+    nz3 = 3                                                               # 3-D lists are C2's business; keep the bundle small here
+    lists3d = [p for p in HIST_3D if p[0] in ("zgrid", "theta")]
+    for lists2d in (HIST_2D, [p for p in HIST_2D if p[0] != "xland"]):
+        inp, host = make_inputs(torch, synth, m, lists2d, lists3d, SOIL, nz3, 4)
+        cfg = I.InterpConfig(interp_diag=False, wrf_mod_vars=False, hist_2d=lists2d, hist_3d=lists3d, hist_soil=SOIL)
+        out = I.interp_data(mesh, grid, g, inp, cfg)
+        torch.cuda.synchronize()
+        check_hist_outputs(oracle, osd, g, out, host, lists2d, lists3d, SOIL, nz3, 4, False, True)
+    # conservation on the covered region: sum_j A_j dst_j = sum_i (sum_j A_j w_ij) src_i, with the oracle's matrix
+    rp_o, col_o, val_o = osd.cons
+    snow = synth.snow_field(m.latCell, m.lonCell)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    got = rh.regrid(snow, nlev=1).reshape(-1)
+    want = oracle.apply_csr(rp_o, col_o, val_o, snow, 1)[0]
+    assert rel_err(got, want) < osd.ctol
+    rh.release()

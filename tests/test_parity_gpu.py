@@ -5,6 +5,7 @@ two implementations agree to ~1e-12 and the tests assert that tighter bound wher
 import numpy as np
 import pytest
 
+from _parity_helpers import assert_csr_equal, assert_fixed_weights_equal, assert_nearest_equal
 from conftest import mesh_xyz
 
 pytestmark = pytest.mark.gpu
@@ -63,9 +64,10 @@ def test_bilinear_store_and_regrid(case, request, oracle):
     assert np.array_equal(mapped_o, mapped_g)
     if case == "regi":
         assert (~mapped_g).sum() > 0, "regional case must exercise unmapped points"
-    same = (idx_o == idx_g).all(axis=1)
-    assert same.mean() > 0.999  # shared-edge ties may pick the neighbouring triangle
-    assert np.abs(w_o[same] - w_g[same]).max() < 1e-11
+    # identical rows within 1e-11; any other point is examined and must be a shared-edge tie (both triangles give
+    # the same sparse weight vector)
+    n_ties = assert_fixed_weights_equal(idx_o, w_o, idx_g, w_g, tol=1e-11)
+    assert n_ties <= 0.001 * idx_o.shape[0]
     assert np.abs(w_g[mapped_g].sum(1) - 1).max() < 1e-13
     nlev = 5
     src = synth.analytic_field(m.latCell, m.lonCell, nlev)
@@ -98,12 +100,7 @@ def test_nearest_bit_exact(case, request, oracle):
     idx_g, _ = rh.weights()
     idx_g = idx_g[:, 0]
     assert (idx_g >= 0).all()  # every destination point is mapped, also outside the mesh footprint
-    diff = np.nonzero(idx_g != idx_o)[0]
-    for p in diff:  # only ties within rounding of the two sin/cos implementations may differ
-        d_o = np.sum((pxyz[p] - c["cxyz"][idx_o[p]]) ** 2)
-        d_g = np.sum((pxyz[p] - c["cxyz"][idx_g[p]]) ** 2)
-        assert abs(d_o - d_g) <= 8 * np.finfo(np.float64).eps * d_o
-    assert diff.size <= 1
+    assert_nearest_equal(idx_o, idx_g, pxyz, c["cxyz"], max_ties=1)  # only ties within rounding may differ
     cat = synth.category_field(m.nCells, nlev=4)
     got = rh.regrid(cat, nlev=4).reshape(4, -1)
     want = oracle.apply_nearest(idx_g, cat, 4)
@@ -130,10 +127,10 @@ def test_conservative(case, request, oracle):
         assert np.abs(rowsum - 1).max() < 1e-10  # fully covered destination cells
     else:
         assert (rowsum < 0.5).sum() > 0  # uncovered / partially covered rim cells exist
-    # identical sparsity pattern except slivers at the drop threshold
-    if np.array_equal(rp_g, rp_o):
-        assert np.array_equal(col_g, col_o)
-        assert np.abs(val_g - val_o).max() < 1e-11
+    # the two matrices as sets of (row, col) entries, unconditionally: common entries within 1e-11, entries on one
+    # side only must be slivers at the drop threshold (1e-14 of the destination cell)
+    n_common, only_o, only_g = assert_csr_equal(rp_o, col_o, val_o, rp_g, col_g, val_g, m.nCells)
+    assert n_common > 0.999 * max(col_o.size, col_g.size)
     snow = synth.snow_field(m.latCell, m.lonCell)
     want = oracle.apply_csr(rp_o, col_o, val_o, snow, 1)
     got = rh.regrid(snow, nlev=1).reshape(1, -1)
@@ -164,8 +161,17 @@ def test_grid_to_grid_destagger(glob, oracle):
         else:
             ring[0, :] = ring[-1, :] = True
         assert not mg.reshape(lon.shape)[ring].any()
-        agree = mo == mg
-        assert agree.mean() > 0.995  # first/last row sits within rounding of the hull edge: implementation-defined
+        # Every point on which the mapped masks differ is examined: it must sit on the rim of the stagger array
+        # (first/last row for U, first/last column for V), where the stagger point lies within rounding of the hull
+        # edge of the centres (App. A4: implementation-defined); nowhere else may the two disagree.
+        dis = (mo != mg).reshape(lon.shape)
+        rim = np.zeros(lon.shape, bool)
+        if stagger_o == 1:
+            rim[0, :] = rim[-1, :] = True
+        else:
+            rim[:, 0] = rim[:, -1] = True
+        assert not (dis & ~rim).any(), "mapped masks differ away from the hull edge at %s" % np.argwhere(dis & ~rim)[:5]
+        assert dis.sum() <= rim.sum()
         want = oracle.apply_fixed(idx_o, w_o, umass.reshape(3, -1), 3)
         got = rh.regrid(umass.reshape(3, -1), nlev=3).reshape(3, -1)
         both = mo & mg
@@ -275,9 +281,8 @@ def test_node_located_bilinear(case, request, oracle):
     rh = R.regrid_store(c["mesh"], c["grid"], R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)
     assert rh.n_src == m.nVertices
     idx_g, w_g = rh.weights()
-    assert np.array_equal(idx_o[:, 0] >= 0, idx_g[:, 0] >= 0)
-    same = (idx_o == idx_g).all(1)
-    assert same.mean() > 0.999 and np.abs(w_o[same] - w_g[same]).max() < 1e-11
+    n_ties = assert_fixed_weights_equal(idx_o, w_o, idx_g, w_g, tol=1e-11)
+    assert n_ties <= 0.001 * idx_o.shape[0]
     vort = np.random.default_rng(9).standard_normal((4, m.nVertices))
     got = rh.regrid(vort, nlev=4).reshape(4, -1)
     assert rel_err(got, oracle.apply_fixed(idx_o, w_o, vort, 4)) < 1e-12

@@ -39,7 +39,7 @@ def main():
     import torch
     from mpassit_amd import _lib, interp as I, regrid as R, workloads
     _lib.init(0)
-    wl = "c4_3m_regional" if args.config == 4 else "c2_655k_regional"
+    wl = "c4_3m_regional" if args.config == 4 else "c2_655k_global"
     m, g, nz, desc = workloads.workload(wl)
     from mpassit_amd import target_grid as T
     t0 = time.perf_counter()
