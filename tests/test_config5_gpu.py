@@ -1,7 +1,8 @@
 """BASELINE config 5 at full size: 2 621 442-cell global icosahedral mesh -> 3600 x 1800 global lat-lon grid
-(is_regional=.false.), wrf_mod_vars staggered winds.  The oracle would need many minutes here, so parity goes
-through properties only a GLOBAL remap offers: every target point is mapped (poles and date line included), the
-conservative remap preserves the global integral, the pole rows of V are zonal means, U wraps around the seam."""
+(is_regional=.false.), wrf_mod_vars staggered winds.  Properties only a GLOBAL remap offers -- every target point is
+mapped (poles and date line included), the conservative remap preserves the global integral, the pole rows of V are
+zonal means, U wraps around the seam -- and the oracle itself at full size (test_c5_full_size_oracle_parity: the three
+weight sets entry by entry over all 6.48 M points)."""
 import numpy as np
 import pytest
 
@@ -122,3 +123,60 @@ def test_c5_staggered_winds(c5):
     one = rv.regrid(torch.full((g.nx * g.ny,), 3.5, dtype=torch.float64, device="cuda"), nlev=1)
     assert float((one - 3.5).abs().max()) < 1e-13
     rv.release()
+
+
+def test_c5_full_size_oracle_parity(c5, oracle):
+    """configs[4] against the ORACLE at full size (2.6 M cells -> 6.48 M points, poles and date line included): the three
+    weight sets entry by entry, every differing entry examined, and a 5-level field through the default Regrid."""
+    from _parity_helpers import assert_csr_equal, assert_fixed_weights_equal, assert_nearest_equal, conserve_tol, rel_err
+    from conftest import mesh_xyz
+    from mpassit_amd import regrid as R, synth
+    torch, m, g = c5["torch"], c5["m"], c5["g"]
+    o = oracle
+    cxyz, vxyz = mesh_xyz(o, m)
+    tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    assert np.array_equal(c5["mesh"].triangles(), tri)
+    pxyz = o.lonlat_deg_to_xyz(g.lon, g.lat)
+    idx_o, w_o = o.bilinear_weights(cxyz, tri, pxyz)
+    rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_BILINEAR)
+    idx_g, w_g = rh.weights()
+    n_ties = assert_fixed_weights_equal(idx_o, w_o, idx_g, w_g, tol=1e-10)
+    assert n_ties <= 1e-4 * idx_o.shape[0]
+    L = 5
+    src = synth.analytic_field(m.latCell, m.lonCell, L)
+    got = rh.regrid(torch.as_tensor(src, device="cuda").view(-1), nlev=L).cpu().numpy().reshape(L, -1)
+    assert rel_err(got, o.apply_fixed(idx_o, w_o, src, L)) < 1e-11 < 1e-6
+    rh.release()
+    del idx_o, w_o, idx_g, w_g, got
+    rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_NEAREST_STOD)
+    # rows at +-89.95 degrees: 3600 points within 5 km of the pole see several cells at nearly equal distance
+    assert_nearest_equal(o.nearest(cxyz, pxyz), rh.weights()[0][:, 0], pxyz, cxyz, max_ties=16)
+    rh.release()
+    rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_CONSERVE)
+    rp_o, col_o, val_o = o.conserve(m.verticesOnCell, vxyz, g.nx, g.ny, o.lonlat_deg_to_xyz(g.lon_c, g.lat_c))
+    rp_g, col_g, val_g = rh.csr()
+    # polar slivers: a 0.1-degree cell at 89.95 degrees is 11 km x 10 m -> area 4e-12 of the unit sphere; weights there are
+    # ratios of areas that carry ~1e-16 absolute rounding, so the bound of conserve_tol reaches 1e-3 for those rows and
+    # is no test.  Compare WEIGHTED by destination area instead (what conservation and the regridded values see): the
+    # absolute area of every overlap A_j w_ij agrees to 1e-13 of the unit sphere, all latitudes alike.
+    lat_e = np.deg2rad(g.lat_c[:, 0])
+    A_dst = np.repeat(np.deg2rad(360.0 / g.nx) * (np.sin(lat_e[1:]) - np.sin(lat_e[:-1])), g.nx)
+    rows_o = np.repeat(np.arange(A_dst.size), np.diff(rp_o))
+    rows_g = np.repeat(np.arange(A_dst.size), np.diff(rp_g))
+    n_common, only_o, only_g = assert_csr_equal(rp_o, col_o, val_o * A_dst[rows_o], rp_g, col_g, val_g * A_dst[rows_g], m.nCells,
+                                                tol=1e-13, sliver=1e-13)
+    assert n_common > 0.99 * max(col_o.size, col_g.size)
+    # away from the polar caps (|lat| < 85) the plain weights obey the area-scaled bound as everywhere else
+    mid_rows = np.abs(np.repeat(g.lat[:, 0], g.nx)) < 85.0
+    keep_o, keep_g = mid_rows[rows_o], mid_rows[rows_g]
+    tol = max(1e-11, 16 * np.finfo(np.float64).eps / A_dst[mid_rows].min())
+
+    def sub(rp, col, val, keep, rows):
+        cnt = np.bincount(rows[keep], minlength=A_dst.size)
+        return np.concatenate([[0], np.cumsum(cnt)]), col[keep], val[keep]
+    assert_csr_equal(*sub(rp_o, col_o, val_o, keep_o, rows_o), *sub(rp_g, col_g, val_g, keep_g, rows_g), m.nCells, tol=tol)
+    snow = synth.snow_field(m.latCell, m.lonCell, lat0=np.deg2rad(80.0))
+    got = rh.regrid(snow, nlev=1).reshape(-1)
+    want = o.apply_csr(rp_o, col_o, val_o, snow, 1)[0]
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max() < 1e-6
+    rh.release()

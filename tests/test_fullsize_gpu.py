@@ -1,7 +1,8 @@
-"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle would need minutes
-there): partition of unity, exact reproduction of constants, linearity, closed-form answer for Cartesian-linear
-fields, nearest-neighbour optimality on a sample and value-set preservation, conservative row sums /
-non-negativity, equality of the two source layouts, determinism of repeated Stores."""
+"""BASELINE configs[3] (3.0 M cells x 55 levels -> 1800x1060) at full size: size-independent properties (partition of
+unity, exact reproduction of constants, linearity, closed-form answer for Cartesian-linear fields, nearest-neighbour
+optimality on a sample and value-set preservation, conservative row sums / non-negativity, equality of the two source
+layouts, determinism of repeated Stores) AND the oracle itself at full size (test_c4_full_size_oracle_parity: all three
+weight sets entry by entry, one whole 55-level field)."""
 import numpy as np
 import pytest
 
@@ -102,4 +103,42 @@ def test_c4_conservative_properties(c4):
     out = rh.regrid(const, nlev=1).cpu().numpy().ravel()
     assert np.abs(out - 4.5).max() < 1e-8
     print("store_ms conserve C4:", rh.store_ms, "nnz/row", len(col) / P)
+    rh.release()
+
+
+def test_c4_full_size_oracle_parity(c4, oracle):
+    """configs[3] against the ORACLE at full size (its hashed searches and threaded loops finish 3.0 M cells x 1.9 M
+    points in ~20 s): the three weight sets entry by entry -- every differing entry examined -- and one whole 55-level
+    field through the default Regrid kernel."""
+    from _parity_helpers import assert_csr_equal, assert_fixed_weights_equal, assert_nearest_equal, conserve_tol, rel_err
+    from conftest import mesh_xyz
+    from mpassit_amd import regrid as R, synth
+    torch, m, g, L = c4["torch"], c4["m"], c4["g"], c4["nlev"]
+    o = oracle
+    cxyz, vxyz = mesh_xyz(o, m)
+    tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    assert np.array_equal(c4["mesh"].triangles(), tri)
+    pxyz = o.lonlat_deg_to_xyz(g.lon, g.lat)
+    idx_o, w_o = o.bilinear_weights(cxyz, tri, pxyz)
+    rh = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_BILINEAR)
+    idx_g, w_g = rh.weights()
+    n_ties = assert_fixed_weights_equal(idx_o, w_o, idx_g, w_g, tol=1e-10)   # 3-km triangles: weights are ratios of 1e-7 areas
+    assert n_ties <= 1e-4 * idx_o.shape[0]
+    src = synth.analytic_field(m.latCell, m.lonCell, L)
+    got = rh.regrid(torch.as_tensor(src, device="cuda").view(-1), nlev=L).cpu().numpy().reshape(L, -1)
+    assert rel_err(got, o.apply_fixed(idx_o, w_o, src, L)) < 1e-11 < 1e-6
+    got_lf = rh.regrid(torch.as_tensor(np.ascontiguousarray(src.T), device="cuda").view(-1), nlev=L, layout=R.LAYOUT_LEV_FAST)
+    assert np.array_equal(got_lf.cpu().numpy().reshape(L, -1), got)
+    rh.release()
+    rh = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_NEAREST_STOD)
+    assert_nearest_equal(o.nearest(cxyz, pxyz), rh.weights()[0][:, 0], pxyz, cxyz, max_ties=4)
+    rh.release()
+    rh = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_CONSERVE)
+    rp_o, col_o, val_o = o.conserve(m.verticesOnCell, vxyz, g.nx, g.ny, o.lonlat_deg_to_xyz(g.lon_c, g.lat_c))
+    rp_g, col_g, val_g = rh.csr()
+    tol = conserve_tol(o, g)
+    n_common, only_o, only_g = assert_csr_equal(rp_o, col_o, val_o, rp_g, col_g, val_g, m.nCells, tol=tol)
+    assert n_common > 0.999 * max(col_o.size, col_g.size)
+    snow = synth.snow_field(m.latCell, m.lonCell)
+    assert rel_err(rh.regrid(snow, nlev=1).reshape(1, -1), o.apply_csr(rp_o, col_o, val_o, snow, 1)) < tol < 1e-6
     rh.release()
