@@ -429,6 +429,8 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
   return MPG_SUCCESS;
 }
 
+int mpg_lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) { return lfu_build_shape(h, txu, tyu, s); }
+
 // Which level-fast kernel serves this handle?  Measured on MI355X (profiles/r01_sweep_lfu.txt), 4 fields x 55 levels:
 //   target points per source cell   row-gather k_apply3_lf   LDS-staged
 //   1.4  (C4, 3 M cells)            4.76 TB/s                3.3 TB/s

@@ -286,6 +286,11 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
     int rc = mpg_k_apply3_lfr(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
     if (rc != MPG_ERR_UNSUPPORTED) return rc;
   }
+  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() >= 300) {
+    int rc = mpg_k_apply3_lfs(h, mpg_lf_variant() - 300, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, (size_t)160 * 1024, s);
+    if (rc == MPG_SUCCESS && h->n_pole) rc = mpg_k_pole_fix(h, src, src_f32, layout, nlev, nfields, dst, dst_f32, scale, offset, s);
+    if (rc != MPG_ERR_UNSUPPORTED) return rc;
+  }
   if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() == -1) {
     int rc = mpg_k_apply3_lfu_typed(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);  // staged, when it pays
     if (rc != MPG_ERR_UNSUPPORTED) return rc;

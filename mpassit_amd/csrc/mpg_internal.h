@@ -236,6 +236,10 @@ int mpg_k_apply3_lfr(mpg_handle_s *h, const void *src, int src_f32, int nlev, in
                      hipStream_t s);
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
                            double offset, hipStream_t s);
+int mpg_lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s);  // tile lists for txu x tyu-point tiles (cached per handle)
+int mpg_lfs_num_variants();
+int mpg_k_apply3_lfs(mpg_handle_s *h, int shape, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
+                     double offset, size_t lds_cap, hipStream_t s);
 int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits);
 int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
                            double offset, hipStream_t s);

@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LFU = list(range(100, 120)) + [200]   # 100-105 two-phase, 106-111 pipelined, 112-119 compact tiles, 200 rows-resident
+LFU = list(range(100, 120)) + [200, 300, 301, 302]   # 100-105 two-phase, 106-111 pipelined, 112-119 compact tiles, 200 / 300-302 rows-resident
 A3_STAGED_DEFAULT = -1           # library default of the "a3_staged" knob (per-handle choice)
 
 
@@ -91,7 +91,7 @@ def test_typed_staged_paths_agree(gpu_lib):
             src = s64.to(sdt)
             src_lf = src.permute(0, 2, 1).contiguous()
             outs = []
-            for staged, lfv in ((1, -1), (-2, 4), (1, 200)):
+            for staged, lfv in ((1, -1), (-2, 4), (1, 200), (1, 300), (1, 301), (1, 302)):
                 gpu_lib.tune("a3_staged", staged)
                 gpu_lib.tune("lf_variant", lfv)
                 outs.append(rh.regrid_typed(src.reshape(-1), nlev=nlev, nfields=nf, out_dtype=ddt, scale=9.81, offset=-300.0))

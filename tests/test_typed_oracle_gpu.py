@@ -17,6 +17,7 @@ KERNELS = [                    # (a3_staged, lf_variant): which kernel family se
     (-2, 4),                   # lane-gather (cell-fast) / row-gather (level-fast; float32 rows -> k_apply3_lf_f32x2)
     (1, 100),                  # LDS-staged cell-fast / LDS-staged level-fast, forced
     (13, 106),                 # the tile shapes bench.py's default run ends up with on C4 / the pipelined staged variant
+    (-1, 300), (-1, 301), (-1, 302),   # rows-resident level-fast kernel k_apply3_lfs, tiles 64x1 / 64x2 / 64x4
 ]
 
 
