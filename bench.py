@@ -275,7 +275,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not io32:
-        cpu = cpu_baseline(sr, src_for_kernel if layout == R.LAYOUT_CELL_FAST else local, nlev, args.cpu_seconds)
+        cpu = cpu_baseline(sr, src_for_kernel if layout == R.LAYOUT_CELL_FAST else local, nlev, args.cpu_seconds, m, g)
 
     # "report two timings" -- kernel-only above, and end to end through the PCIe link (one 3-D field from
     # pageable host memory to pageable host memory: upload, Regrid, download; never `value`)
@@ -295,6 +295,13 @@ def main():
         e2e["what"] = ("one 3-D field, host -> device -> host through mpg_regrid_typed (chunked upload / kernel / download), f64 or f32 on "
                        "both sides of the link, float64 arithmetic; pageable host buffers")
 
+    # The headline mesh numbers its cells row by row -- the best case for a cell-fast gather.  Beside it: the SAME 3.0 M cells
+    # renumbered along a Morton curve (workload c4_3m_morton), what a production mesh reordered by a space-filling curve
+    # or a graph partitioner looks like.  Extra object, never `value`.
+    numbering = None
+    if rank == 0 and world == 1 and args.workload == "c4_3m_regional" and not io32 and not args.no_cpu_baseline:
+        numbering = realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, sr.rh)
+
     if rank == 0:
         fields_per_s = F * args.steps / dt
         rec = {
@@ -313,6 +320,7 @@ def main():
                          "device_copy_GBs": copy_gbs},
             "cpu_baseline": cpu,
             "end_to_end_pcie": e2e,
+            "cell_numbering": numbering,
             "halo": halo,
             "store_ms": sr.store_ms,
             "device": {"arch": arch, "cus": n_cu, "hbm_gib": round(hbm / 2 ** 30, 1), "name": torch.cuda.get_device_name(dev),
@@ -325,6 +333,40 @@ def main():
         dist.destroy_process_group()
 
 
+def realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, rh_rows):
+    """The same step on workload c4_3m_morton (Morton-numbered cells): fields/s, roofline fraction, the kernel the library
+    picked and its tile-list locality statistics next to those of the row-numbered headline mesh."""
+    m, g, nlev, desc = workloads.workload("c4_3m_morton")
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    U = rh.unique_sources().size
+    src = torch.empty((F * nlev, m.nCells), dtype=torch.float64, device=dev)
+    synth_fields_device(torch, m.latCell, m.lonCell, nlev, F, src)
+    if layout == R.LAYOUT_LEV_FAST:
+        src = src.view(F, nlev, -1).permute(0, 2, 1).contiguous()
+    steps = max(3, min(args.steps, 10))
+    for _ in range(2):
+        rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    alg = F * nlev * 8.0 * (U + rh.n_dst) + rh.n_dst * 36.0
+    res = {"workload": "c4_3m_morton: %s" % desc, "fields_per_s": F / ms * 1e3, "kernel_ms": ms, "steps": steps,
+           "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg, "kernel": kernel_label(rh, layout, R),
+           "tile_stats": dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh.tile_stats() or ())),
+           "tile_stats_row_numbered": dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh_rows.tile_stats() or ())),
+           "what": "the same 3.0 M cells and target grid, cells renumbered along a Morton curve (locality-preserving, not row-banded); "
+                   "line_fill = used fraction of the 128-byte source lines a tile touches"}
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+    return res
+
+
 def kernel_label(rh, layout, R):
     """Name of the Regrid kernel the library picked for this handle (mpg_handle_kernel_choice)."""
     cf, lf, mu = rh.kernel_choice()
@@ -333,7 +375,7 @@ def kernel_label(rh, layout, R):
     return "k_apply3_lfu_p (staged, <= %d cells per tile)" % mu if lf > 0 else "k_apply3_lf (row-gather)"
 
 
-def cpu_baseline(sr, local_rows, nlev, seconds):
+def cpu_baseline(sr, local_rows, nlev, seconds, m, g):
     """Oracle ('port') apply loop on the host cores, one whole 3-D field of the same workload, same weights.
     Test infrastructure used only as the reported CPU comparator; never on the product path."""
     cores = len(os.sched_getaffinity(0))
@@ -357,9 +399,18 @@ def cpu_baseline(sr, local_rows, nlev, seconds):
         el = time.perf_counter() - t0
         if el > seconds or reps >= 200:
             break
-    return {"value": reps / el, "unit": "fields/s", "cores": cores, "kind": "port",
+    # the other half of a cold job: the oracle's RegridStore (bilinear: coordinates -> unit vectors, dual triangles, hashed
+    # point-in-triangle search + weights) on the same host cores, once -- beside the GPU's `store_ms`
+    t0 = time.perf_counter()
+    lon_d, lat_d = o.mesh_coords_deg(m.lonCell, m.latCell)
+    cxyz = o.lonlat_deg_to_xyz(lon_d, lat_d)
+    tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    o.bilinear_weights(cxyz, tri, o.lonlat_deg_to_xyz(g.lon, g.lat))
+    store_s = time.perf_counter() - t0
+    return {"value": reps / el, "unit": "fields/s", "cores": cores, "kind": "port", "store_ms": store_s * 1e3,
             "sample": "%d full 3-D fields (%d levels, all %d target points) through the oracle's OpenMP apply loop, "
-                      "weights taken from the GPU handle; CPU restatement, not ESMF (ESMF unavailable)" % (reps, nlev, idx.shape[0])}
+                      "weights taken from the GPU handle; store_ms = the oracle's bilinear RegridStore of the same mesh and grid, once; "
+                      "CPU restatement, not ESMF (ESMF unavailable)" % (reps, nlev, idx.shape[0])}
 
 
 if __name__ == "__main__":

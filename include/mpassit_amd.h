@@ -209,6 +209,14 @@ int mpg_handle_get_csr(mpg_handle rh, int64_t *rowptr_host, int32_t *col_host, d
  * cell_fast_kernel / lev_fast_kernel: 0 = not decided yet (layout not used so far), -1 = lane- / row-gather kernel,
  * > 0 = LDS-staged variant index + 1;  max_unique = largest number of distinct source cells one tile references. */
 int mpg_handle_kernel_choice(mpg_handle rh, int *cell_fast_kernel, int *lev_fast_kernel, int *max_unique);
+/* Locality of the source cells as the staged Regrid kernels see them, from the tile lists in use (error before the first
+ * staged Regrid of the handle): the tile shape in target points; reuse = 3 * n_dst / (sum over the tiles of their
+ * distinct source cells) -- how often a staged value is used; line_fill = the fraction of every 128-byte line of a
+ * cell-fast float64 field touched by a tile that the tile actually uses (1 = its cells are dense runs of consecutive
+ * ids, as on a row-numbered regional mesh; towards 1/16 = scattered ids: the mesh's cell numbering has no locality and
+ * the level-fast (file-order) layout, which gathers whole rows, is the better route).  Diagnostics only; the reference
+ * has no counterpart (ESMF hides its route handle). */
+int mpg_handle_tile_stats(mpg_handle rh, int *tile_nx, int *tile_ny, double *reuse, double *line_fill);
 /* Pole terms of a Grid -> Grid handle on a periodic (monopole) grid.  Destination points inside a pole cap
  * (triangle pole / A / B of the first or last CENTER row) carry, besides the A and B entries reported by
  * mpg_handle_get_weights, a weight on the pole node; the pole's value is the mean of the `row_len` sources

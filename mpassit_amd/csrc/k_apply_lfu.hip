@@ -16,6 +16,8 @@
 #include <limits.h>
 #include <string.h>
 
+#include <rocprim/rocprim.hpp>
+
 #include "geom.h"
 #include <utility>
 
@@ -31,7 +33,8 @@
 template <bool FILL>
 __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__restrict__ idx, int nx, int ny, int txu, int tyu, int ntx,
                                                            int32_t *__restrict__ ut_count, const int32_t *__restrict__ ut_ptr,
-                                                           int32_t *__restrict__ ut_cells, uint16_t *__restrict__ lidx) {
+                                                           int32_t *__restrict__ ut_cells, uint16_t *__restrict__ lidx,
+                                                           unsigned long long *__restrict__ line_count) {
   constexpr int SB = LFU_SORT, PER = SB / LFU_THREADS;
   __shared__ int32_t keys[SB];
   __shared__ int32_t part[LFU_THREADS + 1];
@@ -90,6 +93,13 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
     ut_cells[ut_ptr[tile] + base + q] = mine[q];
   }
   __syncthreads();
+  // locality statistic: distinct groups of 16 consecutive ids (= 128-byte lines of a cell-fast float64 field) in the list
+  if (line_count) {
+    int nl = 0;
+    for (int e = t; e < total; e += LFU_THREADS) nl += e == 0 || (keys[e] >> 4) != (keys[e - 1] >> 4);
+    for (int o = 32; o > 0; o >>= 1) nl += __shfl_down(nl, o);
+    if ((t & 63) == 0 && nl) atomicAdd(line_count, (unsigned long long)nl);
+  }
   for (int pt = t; pt < np; pt += LFU_THREADS) {
     int i = tx * txu + pt % txu, j = ty * tyu + pt / txu;
     if (i >= nx || j >= ny) continue;
@@ -370,6 +380,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     std::swap(h->ut_rpt, h->ut2_rpt);
     std::swap(h->ut_max, h->ut2_max);
     std::swap(h->ut_total, h->ut2_total);
+    std::swap(h->ut_lines, h->ut2_lines);
     return MPG_SUCCESS;
   }
   int rc;
@@ -383,6 +394,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     h->ut2_rpt = h->ut_rpt;
     h->ut2_max = h->ut_max;
     h->ut2_total = h->ut_total;
+    h->ut2_lines = h->ut_lines;
     h->ut_ptr = DevBuf<int32_t>();
     h->ut_cells = DevBuf<int32_t>();
     h->lidx = DevBuf<uint16_t>();
@@ -400,32 +412,39 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
   if ((rc = count.alloc(ntile + 1)) || (rc = h->ut_ptr.alloc(ntile + 1))) return rc;
   if (!h->lidx.p && (rc = h->lidx.alloc(3 * (size_t)h->n_dst))) return rc;
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (ntile + 1), s));
-  k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, count.p, nullptr, nullptr, nullptr);
+  k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, count.p, nullptr, nullptr, nullptr,
+                                                            nullptr);
   MPG_HIP(hipGetLastError());
-  std::vector<int32_t> hc((size_t)ntile + 1), hp((size_t)ntile + 1);
-  MPG_HIP(hipMemcpyAsync(hc.data(), count.p, sizeof(int32_t) * (ntile + 1), hipMemcpyDeviceToHost, s));
+  // list offsets and the longest list on the device (rocPRIM scan / reduce); only three scalars come back to the host
+  TmpBuf<char> tmp;
+  TmpBuf<unsigned long long> scal;   // [0] distinct 128-byte lines, [1] (as int32) longest list
+  size_t b_scan = 0, b_max = 0;
+  MPG_HIP(rocprim::exclusive_scan(nullptr, b_scan, count.p, h->ut_ptr.p, (int32_t)0, (size_t)ntile + 1, rocprim::plus<int32_t>(), s));
+  if ((rc = scal.alloc(2))) return rc;
+  MPG_HIP(rocprim::reduce(nullptr, b_max, count.p, (int32_t *)(scal.p + 1), (int32_t)0, (size_t)ntile, rocprim::maximum<int32_t>(), s));
+  if ((rc = tmp.alloc((b_scan > b_max ? b_scan : b_max) + 16))) return rc;
+  MPG_HIP(hipMemsetAsync(scal.p, 0, 2 * sizeof(unsigned long long), s));
+  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, b_scan, count.p, h->ut_ptr.p, (int32_t)0, (size_t)ntile + 1, rocprim::plus<int32_t>(), s));
+  MPG_HIP(rocprim::reduce((void *)tmp.p, b_max, count.p, (int32_t *)(scal.p + 1), (int32_t)0, (size_t)ntile, rocprim::maximum<int32_t>(), s));
+  int32_t tot32 = 0;
+  MPG_HIP(hipMemcpyAsync(&tot32, h->ut_ptr.p + ntile, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
-  int64_t tot = 0;
-  int mx = 0;
-  for (int64_t q = 0; q < ntile; ++q) {
-    hp[q] = (int32_t)tot;
-    tot += hc[q];
-    mx = hc[q] > mx ? hc[q] : mx;
-  }
-  hp[ntile] = (int32_t)tot;
-  if (tot >= 0x7fffffff) {
+  if (tot32 < 0) {   // the int32 scan wrapped
     mpg_set_error("tile cell lists exceed 2^31 entries");
     return MPG_ERR_OVERFLOW;
   }
-  MPG_HIP(hipMemcpyAsync(h->ut_ptr.p, hp.data(), sizeof(int32_t) * (ntile + 1), hipMemcpyHostToDevice, s));
+  const int64_t tot = tot32;
   if ((rc = h->ut_cells.alloc((size_t)tot + 1))) return rc;
   k_lfu_build<true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p,
-                                                           h->lidx.p);
+                                                           h->lidx.p, scal.p);
   MPG_HIP(hipGetLastError());
+  unsigned long long hs[2] = {0, 0};
+  MPG_HIP(hipMemcpyAsync(hs, scal.p, sizeof(hs), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   h->ut_rpt = key;
-  h->ut_max = mx;
+  h->ut_max = (int)(int32_t)(hs[1] & 0xffffffffu);
   h->ut_total = tot;
+  h->ut_lines = (int64_t)hs[0];
   return MPG_SUCCESS;
 }
 

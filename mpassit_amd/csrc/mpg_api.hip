@@ -558,6 +558,19 @@ int mpg_handle_kernel_choice(mpg_handle h, int *cell_fast_kernel, int *lev_fast_
   return MPG_SUCCESS;
 }
 
+int mpg_handle_tile_stats(mpg_handle h, int *tile_nx, int *tile_ny, double *reuse, double *line_fill) {
+  MPG_ARG(h, "mpg_handle_tile_stats: NULL handle");
+  if (h->ut_rpt == 0 || h->ut_total <= 0) {
+    mpg_set_error("mpg_handle_tile_stats: the handle has no tile lists (no staged Regrid has run on it yet)");
+    return MPG_ERR_INVALID_ARG;
+  }
+  if (tile_nx) *tile_nx = h->ut_rpt / 1024;
+  if (tile_ny) *tile_ny = h->ut_rpt % 1024;
+  if (reuse) *reuse = 3.0 * (double)h->n_dst / (double)h->ut_total;
+  if (line_fill) *line_fill = h->ut_lines > 0 ? (double)h->ut_total / (16.0 * (double)h->ut_lines) : 0.0;
+  return MPG_SUCCESS;
+}
+
 int mpg_handle_pole_count(mpg_handle h, int64_t *n_points, int *row_len) {
   MPG_ARG(h, "mpg_handle_pole_count: NULL handle");
   if (n_points) *n_points = h->n_pole;

@@ -188,6 +188,7 @@ struct mpg_handle_s {
   // per-tile unique source cells of the LDS-staged level-fast Regrid (k_apply_lfu.hip), built on first use
   int ut_rpt = 0, ut_max = 0;
   int64_t ut_total = 0;
+  int64_t ut_lines = 0, ut2_lines = 0;   // sum over the tiles of the distinct groups of 16 consecutive cell ids in their lists
   int lf_choice = 0;      // level-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 row-gather
   int cf_choice = 0;      // cell-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 lane-gather
   int cf_for = -99;       // "a3_staged" knob value the choice was made for

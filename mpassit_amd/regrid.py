@@ -276,6 +276,14 @@ class RouteHandle:
         check(L.load().mpg_handle_kernel_choice(self._h, C.byref(cf), C.byref(lf), C.byref(mu)))
         return cf.value, lf.value, mu.value
 
+    def tile_stats(self):
+        """(tile_nx, tile_ny, reuse, line_fill) of the tile lists in use (mpg_handle_tile_stats); None before the first
+        staged Regrid of the handle."""
+        tx, ty, reuse, fill = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        if L.load().mpg_handle_tile_stats(self._h, C.byref(tx), C.byref(ty), C.byref(reuse), C.byref(fill)) != L.MPG_SUCCESS:
+            return None
+        return tx.value, ty.value, reuse.value, fill.value
+
     def pole(self):
         """Pole terms of a Grid -> Grid handle on a periodic grid: (dst_id, src_row_start, w_pole, row_len);
         empty arrays for every other handle (mpg_handle_get_pole)."""

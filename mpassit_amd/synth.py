@@ -264,6 +264,28 @@ def regional_mesh_for_lambert(proj, nx, ny, n_cells, margin=0.05, seed=SEED):
     return regional_hex_mesh(proj, x0, y0, q_cells, r_cells, spacing, seed=seed)
 
 
+def renumber_cells(m, perm):
+    """Renumber the cells of a mesh: new cell i is old cell perm[i] (vertices keep their numbers; verticesOnCell refers to
+    vertices only, so the connectivity needs no translation)."""
+    perm = np.asarray(perm)
+    return MpasMesh(m.latCell[perm], m.lonCell[perm], m.latVertex, m.lonVertex, m.verticesOnCell[perm])
+
+
+def morton_cells(m, bits=12):
+    """Cells renumbered along a 2-D Morton (Z-order) curve over the mesh's own lat / lon extent: the locality-preserving
+    but NOT row-banded numbering that graph partitioners and space-filling-curve reorderings give real MPAS meshes.
+    Consecutive ids are spatial neighbours only inside blocks of 4, 16, 64 ... cells; a row of target points crosses
+    many such blocks."""
+    lon = np.where(m.lonCell > np.pi, m.lonCell - 2.0 * np.pi, m.lonCell)
+    qx = ((lon - lon.min()) / max(np.ptp(lon), 1e-300) * ((1 << bits) - 1)).astype(np.int64)
+    qy = ((m.latCell - m.latCell.min()) / max(np.ptp(m.latCell), 1e-300) * ((1 << bits) - 1)).astype(np.int64)
+    code = np.zeros(m.nCells, np.int64)
+    for b in range(bits):
+        code |= ((qx >> b) & 1) << (2 * b)
+        code |= ((qy >> b) & 1) << (2 * b + 1)
+    return renumber_cells(m, np.argsort(code, kind="stable"))
+
+
 def shuffle_cells(m, seed=SEED, block=1):
     """Renumber the cells of a mesh: random permutation of blocks of `block` consecutive cells (block=1: fully random).
     Real MPAS meshes are not necessarily numbered along rows; this is the worst case for gather locality."""

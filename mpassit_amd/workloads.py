@@ -53,6 +53,13 @@ def workload(name, arrays=True):
         m = synth.icosahedral_mesh(level)
         return m, g, 55, "%d-cell global icosahedral mesh x 55 levels -> %dx%d global lat-lon (%dx%d mass points)" % (
             m.nCells, nx, ny, nx - 1, ny - 1)
+    if name == "c4_3m_morton":
+        # configuration 4 with a REALISTIC cell numbering: the same 3.0 M cells, renumbered along a Morton curve
+        # (locality-preserving, not row-banded -- what a production mesh reordered by a space-filling curve or a graph
+        # partitioner looks like); c4_3m_regional numbers the lattice row by row, the best case for a cell-fast gather
+        g = conus_lambert_grid()
+        m = synth.morton_cells(synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000))
+        return m, g, 55, "3.0 M-cell regional hex mesh, Morton-numbered cells, x 55 levels -> 1801x1061 Lambert (1800x1060 mass points)"
     if name.startswith("c4_3m_shuffled"):  # same mesh, cells renumbered at random (optionally in blocks: c4_3m_shuffled_b64)
         g = conus_lambert_grid()
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)

@@ -142,3 +142,45 @@ def test_c4_full_size_oracle_parity(c4, oracle):
     snow = synth.snow_field(m.latCell, m.lonCell)
     assert rel_err(rh.regrid(snow, nlev=1).reshape(1, -1), o.apply_csr(rp_o, col_o, val_o, snow, 1)) < tol < 1e-6
     rh.release()
+
+
+def test_c4_morton_numbering_same_answer(c4):
+    """configs[3] with a realistic cell numbering (workload c4_3m_morton: the same 3.0 M cells renumbered along a Morton
+    curve instead of row by row): the geometry is unchanged, so every method must give the same answer on the permuted
+    fields -- nearest bit for bit, bilinear to rounding (the dual triangles list their corners in another order) -- and
+    the library's tile statistics must report the poorer line locality of the numbering."""
+    from mpassit_amd import regrid as R, synth
+    torch, m, g, L = c4["torch"], c4["m"], c4["g"], c4["nlev"]
+    lon = np.where(m.lonCell > np.pi, m.lonCell - 2.0 * np.pi, m.lonCell)
+    mm = synth.morton_cells(m)
+    # recover the permutation (new cell i = old cell perm[i]) from the coordinates
+    key_old = np.lexsort((m.lonCell, m.latCell))
+    key_new = np.lexsort((mm.lonCell, mm.latCell))
+    perm = np.empty(m.nCells, np.int64)
+    perm[key_new] = key_old
+    assert np.array_equal(m.latCell[perm], mm.latCell) and np.array_equal(m.lonCell[perm], mm.lonCell)
+    assert np.abs(np.diff(perm)).mean() > 100            # not row-banded any more
+    mesh_m = R.Mesh.from_mpas(mm)
+    src = synth.analytic_field(m.latCell, m.lonCell, L)
+    src_m = np.ascontiguousarray(src[:, perm])
+    stats = {}
+    for name, meshh, s in (("rows", c4["mesh"], src), ("morton", mesh_m, src_m)):
+        rh = R.regrid_store(meshh, c4["grid"], R.REGRIDMETHOD_BILINEAR)
+        out = rh.regrid(torch.as_tensor(s, device="cuda").view(-1), nlev=L)
+        ts = rh.tile_stats()                             # of the cell-fast kernel's tile lists
+        out_lf = rh.regrid(torch.as_tensor(np.ascontiguousarray(s.T), device="cuda").view(-1), nlev=L, layout=R.LAYOUT_LEV_FAST)
+        assert torch.equal(out, out_lf)
+        stats[name] = (out.cpu().numpy(), ts, rh.kernel_choice())
+        rh.release()
+    a, b = stats["rows"][0], stats["morton"][0]
+    assert np.abs(a - b).max() < 1e-12 * np.abs(a).max()
+    (tx, ty, reuse_r, fill_r), (_, _, reuse_m, fill_m) = stats["rows"][1], stats["morton"][1]
+    assert abs(reuse_r - reuse_m) < 0.05 * reuse_r       # the same cells per tile, only their ids differ
+    assert fill_r > 0.7 and fill_m < 0.9 * fill_r        # Morton blocks: a tile's cells are shorter runs of consecutive ids
+    print("tile lists %dx%d: reuse %.2f; line fill row-numbered %.2f, Morton-numbered %.2f" % (tx, ty, reuse_r, fill_r, fill_m))
+    rn_r = R.regrid_store(c4["mesh"], c4["grid"], R.REGRIDMETHOD_NEAREST_STOD)
+    rn_m = R.regrid_store(mesh_m, c4["grid"], R.REGRIDMETHOD_NEAREST_STOD)
+    assert np.array_equal(perm[rn_m.weights()[0][:, 0]], rn_r.weights()[0][:, 0])
+    rn_r.release()
+    rn_m.release()
+    mesh_m.destroy()
