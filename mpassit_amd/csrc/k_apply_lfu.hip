@@ -347,6 +347,8 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16>},  {64, 4, 2, k_apply3_cfu_p<64, 4, 2, 8>},   {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 20>},
     // 13: 64 x 8 tiles with room for 1024 unique cells per tile (C4 needs 756 of the 768 that variant 1 holds)
     {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 16>},
+    // (compact tiles of 32 x 32, 16 x 64 and 32 x 16 points with the same 1024-cell capacity were measured in round 2 on C4,
+    //  Morton-numbered C4, C2 and C5: 0-15 % slower than 64 x 8 / 64 x 16 everywhere, profiles/r02_sweep_cfu_compact.txt)
 };
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--io", default="f32", choices=["f32", "f64"])
     ap.add_argument("--variants", default="4,-1,200,300,301,302,303")
     ap.add_argument("--layout", default="lev_fast", choices=["lev_fast", "cell_fast"])
+    ap.add_argument("--plain", action="store_true", help="float64 through mpg_regrid_dev (the headline entry point; honours a3_staged / lf_variant 100..)")
     ap.add_argument("--nlev", type=int, default=0, help="override the workload's level count (alignment experiments)")
     ap.add_argument("--knob", default="", help="knob to sweep instead of lf_variant (e.g. a3_staged with --layout cell_fast)")
     args = ap.parse_args()
@@ -43,12 +44,18 @@ def main():
     alg = F * nlev * esz * (U + g.nx * g.ny) + g.nx * g.ny * 36.0
     knob = args.knob or "lf_variant"
     variants = [int(v) for v in args.variants.split(",")]
+
+    def run():
+        if args.plain:
+            rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+        else:
+            rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out, scale=9.81, offset=-300.0)
     times = {v: [] for v in variants}
     ref = None
     for rnd in range(args.rounds + 1):
         for v in variants:
             _lib.tune(knob, v)
-            rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out, scale=9.81, offset=-300.0)   # untimed (tile lists)
+            run()   # untimed (tile lists)
             torch.cuda.synchronize()
             if rnd == 0:
                 if ref is None:
@@ -58,7 +65,7 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out, scale=9.81, offset=-300.0)
+                run()
             e1.record()
             torch.cuda.synchronize()
             if rnd > 0:
