@@ -26,6 +26,7 @@ module program_setup
   integer :: i_target = 0, j_target = 0, proj_code = PROJ_LC
   real(dp) :: truelat1 = NAN, truelat2 = NAN, stand_lon = NAN, ref_lat = NAN, ref_lon = NAN, ref_x = NAN, ref_y = NAN
   real(dp) :: pole_lat = 90.0_dp, pole_lon = 0.0_dp
+  character(len=500) :: map_proj_char = ""          ! program_setup.F90:172-187, model_grid.F90:1288-1295
   real(dp) :: dxkm, dykm, dlondeg, dlatdeg, known_lat, known_lon, known_x, known_y
 
 contains
@@ -75,12 +76,14 @@ contains
     i_target = nx - 1; j_target = ny - 1        ! namelist nx, ny are STAGGERED counts
     if (trim(kind) == 'LAMBERT') then
       proj_code = PROJ_LC
+      map_proj_char = 'Lambert Conformal'
       if (truelat2 == NAN) then
         if (truelat1 == NAN) call fatal("No TRUELAT1 specified for Lambert conformal projection.", 3)
         truelat2 = truelat1
       end if
     else if (trim(kind) == 'LAT-LON') then
       proj_code = PROJ_LATLON
+      map_proj_char = 'Lat/Lon'
       if (dx == NAN .and. dy == NAN) then
         if (is_regional) call fatal("For lat-lon projection, if dx/dy are not specified a global grid is assumed.", 3)
         dlondeg = 360.0_dp/i_target; dlatdeg = 180.0_dp/j_target
@@ -221,6 +224,9 @@ contains
     if (ncio_get_gatt(nf, "CEN_LON", v) == 0) ref_lon = v
     if (ncio_get_gatt(nf, "POLE_LAT", v) == 0) pole_lat = v
     if (ncio_get_gatt(nf, "POLE_LON", v) == 0) pole_lon = v
+    if (ncio_get_gatt_text(nf, "MAP_PROJ_CHAR", map_proj_char) /= 0) then                     ! model_grid.F90:1288-1295
+      map_proj_char = merge("Lambert Conformal", "Lat/Lon          ", proj_code == PROJ_LC)
+    end if
     call get2("XLONG", "XLONG_M", lon_m, i_target, j_target)
     call get2("XLAT", "XLAT_M", lat_m, i_target, j_target)
     call get2("XLONG_U", "", lon_u, i_target + 1, j_target)

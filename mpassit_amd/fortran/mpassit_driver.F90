@@ -187,7 +187,7 @@ contains
     nzp1_vars = [character(len=50) :: 'zgrid', 'w']
     if (interp_diag) then
       call read_varlist('diaglist', n, names, targets)
-      call open_in(diag_file_input_grid, u)
+      call open_in(diag_file_input_grid, u, .true.)
       do i = 1, n
         call load_field(u, names(i), targets(i), f)
         call append(diag_bundle, f)
@@ -197,7 +197,7 @@ contains
       call close_in(u)
     end if
     if (interp_hist) then
-      call open_in(hist_file_input_grid, u)
+      call open_in(hist_file_input_grid, u, .false.)
       call read_varlist('histlist_2d', n, names, targets)
       do i = 1, n
         call load_field(u, names(i), targets(i), f)
@@ -233,9 +233,10 @@ contains
     end if
   end subroutine read_input_data
 
-  subroutine open_in(file, u)
+  subroutine open_in(file, u, is_diag)
     character(len=*), intent(in) :: file
     integer, intent(out) :: u
+    logical, intent(in) :: is_diag
     integer(c_int) :: id, rc
     integer(c_int8_t) :: tb(64)
     nc_in = nc_is_netcdf(file)
@@ -243,6 +244,7 @@ contains
     if (nc_in) then
       nc_in_path = file
       call ncio_check(ncio_open(file, nf_in), "opening "//trim(file))
+      call nc_read_meta(nf_in, is_diag)
       if (ncio_inq_varid(nf_in, "xtime", id) == 0) then
         tb = 32_c_int8_t
         rc = ncio_get_var(nf_in, id, 0_c_int64_t, NCIO_CHAR, tb)

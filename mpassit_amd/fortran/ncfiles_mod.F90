@@ -15,7 +15,11 @@ module ncfiles
   use model_data
   implicit none
   private
-  public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target
+  public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target, nc_read_meta
+  ! what the output header takes from the input files (model_grid.F90:34-46,182; read by input_data.F90:219-245,347-389)
+  character(len=50), public :: start_time = ""
+  real(dp), public :: config_dt = 0.0_dp
+  integer, public :: lsm_scheme = 0, mp_scheme = 0, conv_scheme = 0, diag_out_interval = 0
   character(len=500), public :: nc_in_path = ""      ! path of the file nc_load_field reads from (device flow: raw ranges)
 
   type fref
@@ -27,6 +31,80 @@ module ncfiles
   integer(c_int) :: d_time, d_we, d_wes, d_sn, d_sns, d_bt, d_bts, d_soil, d_str
 
 contains
+
+  !> global attributes of an open MPAS file that the writer copies into its header.  is_diag: the diag file
+  !! (input_data.F90:219-245: start time, config_dt, output_interval); otherwise the history file (:347-389: physics
+  !! schemes by name -> WRF option numbers, start time, config_dt).  Missing attributes -> 0, like the reference.
+  subroutine nc_read_meta(nf, is_diag)
+    type(c_ptr), intent(in) :: nf
+    logical, intent(in) :: is_diag
+    character(len=64) :: txt
+    real(dp) :: v
+    if (ncio_get_gatt_text(nf, "config_start_time", txt) == 0) start_time = txt
+    config_dt = 0.0_dp
+    if (ncio_get_gatt(nf, "config_dt", v) == 0) config_dt = v
+    if (is_diag) then
+      diag_out_interval = 0
+      if (ncio_get_gatt(nf, "output_interval", v) == 0) diag_out_interval = int(v)
+      return
+    end if
+    if (ncio_get_gatt_text(nf, "config_lsm_scheme", txt) /= 0) then
+      lsm_scheme = 0
+    else if (trim(txt) == 'noah') then
+      lsm_scheme = 2
+    else if (trim(txt) == 'ruc') then
+      lsm_scheme = 3
+    end if
+    if (ncio_get_gatt_text(nf, "config_microp_scheme", txt) /= 0) then
+      mp_scheme = 0
+    else if (trim(txt) == 'mp_thompson') then
+      mp_scheme = 8
+    else if (trim(txt) == 'mp_nssl2m') then
+      mp_scheme = 18
+    end if
+    if (ncio_get_gatt_text(nf, "config_convection_scheme", txt) /= 0) then
+      conv_scheme = 0
+    else if (trim(txt) == 'cu_ntiedke') then
+      conv_scheme = 16
+    else if (trim(txt) == 'cu_kain_fritsch') then
+      conv_scheme = 1
+    else if (trim(txt) == 'cu_grell_freitas') then
+      conv_scheme = 3
+    end if
+  end subroutine nc_read_meta
+
+  !> days since 1970-01-01 of a proleptic Gregorian date (the datetime arithmetic of write_data.F90:1225)
+  integer(int64) function days_from_civil(y0, m, d) result(days)
+    integer, intent(in) :: y0, m, d
+    integer(int64) :: y, era, yoe, doy, doe
+    y = y0
+    if (m <= 2) y = y - 1
+    era = merge(y, y - 399, y >= 0)/400
+    yoe = y - era*400
+    doy = (153*(m + merge(-3, 9, m > 2)) + 2)/5 + d - 1
+    doe = yoe*365 + yoe/4 - yoe/100 + doy
+    days = era*146097 + doe - 719468
+  end function days_from_civil
+
+  !> seconds of "YYYY-MM-DD_hh:mm:ss" since 1970; ok = .false. when the string does not parse
+  integer(int64) function stamp_seconds(s, ok) result(sec)
+    character(len=*), intent(in) :: s
+    logical, intent(out) :: ok
+    integer :: y, mo, d, h, mi, se, ios(6)
+    sec = 0
+    ok = .false.
+    if (len_trim(s) < 19) return
+    read (s(1:4), *, iostat=ios(1)) y
+    read (s(6:7), *, iostat=ios(2)) mo
+    read (s(9:10), *, iostat=ios(3)) d
+    read (s(12:13), *, iostat=ios(4)) h
+    read (s(15:16), *, iostat=ios(5)) mi
+    read (s(18:19), *, iostat=ios(6)) se
+    if (any(ios /= 0)) return
+    if (mo < 1 .or. mo > 12 .or. d < 1 .or. d > 31) return
+    sec = days_from_civil(y, mo, d)*86400_int64 + h*3600 + mi*60 + se
+    ok = .true.
+  end function stamp_seconds
 
   logical function nc_is_netcdf(file)
     character(len=*), intent(in) :: file
@@ -246,10 +324,29 @@ contains
     put_seconds = put_seconds + real(c1 - c0, dp)/real(cr, dp)
   end subroutine put_r4
 
+  subroutine gatt_t(name, text)
+    character(len=*), intent(in) :: name, text
+    call ncio_check(ncio_put_att_text(nf_out, NCIO_GLOBAL, name, text), "DEFINING "//name//" GLOBAL ATTRIBUTE")
+  end subroutine gatt_t
+  subroutine gatt_i(name, val)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: val
+    call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, name, val), "DEFINING "//name//" GLOBAL ATTRIBUTE")
+  end subroutine gatt_i
+  subroutine gatt_r(name, val)
+    character(len=*), intent(in) :: name
+    real(dp), intent(in) :: val
+    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, name, val), "DEFINING "//name//" GLOBAL ATTRIBUTE")
+  end subroutine gatt_r
+
   subroutine nc_write_target(file, valid_time)
     character(len=*), intent(in) :: file, valid_time
     integer, parameter :: MAXV = 512
-    integer(c_int) :: ids(MAXV), id_extra(8), id_grid(8), id_mf(3), id_zs, id_times, id_ptop
+    integer(c_int) :: ids(MAXV), id_extra(8), id_grid(8), id_mf(3), id_zs, id_times, id_ptop, id_itime, id_xtime
+    character(len=19) :: st
+    integer(int64) :: xt_sec
+    integer(c_int32_t) :: itime(1)
+    logical :: s_ok, v_ok
     real(dp), allocatable :: zs(:)
     integer :: nv, i, k, npts
     type(fref), allocatable :: fl(:)
@@ -280,15 +377,42 @@ contains
     call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "WEST-EAST_GRID_DIMENSION", i_target + 1), "GLOBAL ATT")   ! :196-308
     call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "SOUTH-NORTH_GRID_DIMENSION", j_target + 1), "GLOBAL ATT")
     call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "BOTTOM-TOP_GRID_DIMENSION", nz_input + 1), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_text(nf_out, NCIO_GLOBAL, "START_DATE", valid_time), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DX", dxkm), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "DY", dxkm), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "CEN_LAT", ref_lat), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "CEN_LON", ref_lon), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "TRUELAT1", truelat1), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "TRUELAT2", truelat2), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_real(nf_out, NCIO_GLOBAL, "STAND_LON", stand_lon), "GLOBAL ATT")
-    call ncio_check(ncio_put_att_int(nf_out, NCIO_GLOBAL, "MAP_PROJ", proj_code), "GLOBAL ATT")
+    st = start_time(1:19)
+    if (len_trim(start_time) == 0) st = valid_time
+    call gatt_t("SIMULATION_START_DATE", st)
+    call gatt_t("START_DATE", st)
+    call gatt_r("DX", dxkm)
+    call gatt_r("DY", dxkm)
+    call gatt_r("DT", config_dt)
+    call gatt_i("SF_SURFACE_PHYSICS", lsm_scheme)
+    call gatt_i("MP_PHYSICS", mp_scheme)
+    call gatt_i("CU_PHYSICS", conv_scheme)
+    call gatt_r("CEN_LAT", ref_lat)
+    call gatt_r("CEN_LON", ref_lon)
+    call gatt_r("TRUELAT1", truelat1)
+    call gatt_r("TRUELAT2", truelat2)
+    call gatt_r("MOAD_CEN_LAT", ref_lat)
+    call gatt_r("STAND_LON", stand_lon)
+    call gatt_r("POLE_LAT", pole_lat)
+    call gatt_r("POLE_LON", pole_lon)
+    call gatt_r("POL_ELAT", pole_lat)                                                            ! sic (:253)
+    call gatt_i("MAP_PROJ", proj_code)
+    call gatt_t("MAP_PROJ_CHAR", trim(map_proj_char))
+    if (interp_diag) call gatt_i("PREC_ACC_DT", diag_out_interval)                               ! :262-265
+    call gatt_i("I_PARENT_START", 1)
+    call gatt_i("J_PARENT_START", 1)
+    call gatt_i("WEST-EAST_PATCH_START_UNSTAG", 1)
+    call gatt_i("WEST-EAST_PATCH_START_STAG", 1)
+    call gatt_i("SOUTH-NORTH_PATCH_START_UNSTAG", 1)
+    call gatt_i("SOUTH-NORTH_PATCH_START_STAG", 1)
+    call gatt_i("BOTTOM-TOP_PATCH_START_UNSTAG", 1)
+    call gatt_i("BOTTOM-TOP_PATCH_START_STAG", 1)
+    call gatt_i("WEST-EAST_PATCH_END_UNSTAG", i_target)
+    call gatt_i("WEST-EAST_PATCH_END_STAG", i_target + 1)
+    call gatt_i("SOUTH-NORTH_PATCH_END_UNSTAG", j_target)
+    call gatt_i("SOUTH-NORTH_PATCH_END_STAG", j_target + 1)
+    call gatt_i("BOTTOM-TOP_PATCH_END_UNSTAG", nz_input)
+    call gatt_i("BOTTOM-TOP_PATCH_END_STAG", nz_input + 1)
     ! grid variables (:312-476): XLONG, XLAT on the three staggers, SINALPHA / COSALPHA for Lambert
     call def_field("XLONG", 1, 0, id_grid(1)); call def_field("XLAT", 1, 0, id_grid(2))
     call def_field("XLONG_U", 1, 1, id_grid(3)); call def_field("XLAT_U", 1, 1, id_grid(4))
@@ -298,7 +422,24 @@ contains
     end if
     call def_field("MAPFAC_M", 1, 0, id_mf(1)); call def_field("MAPFAC_U", 1, 1, id_mf(2)); call def_field("MAPFAC_V", 1, 2, id_mf(3))
     call ncio_check(ncio_def_var(nf_out, "ZS", NCIO_FLOAT, [d_time, d_soil], id_zs), "DEFINING ZS")
-    call ncio_check(ncio_def_var(nf_out, "Times", NCIO_CHAR, [d_time, d_str], id_times), "DEFINING Times")
+    call ncio_check(ncio_def_var(nf_out, "Times", NCIO_CHAR, [d_time, d_str], id_times), "DEFINING Times")          ! :522-534
+    call ncio_check(ncio_put_att_text(nf_out, id_times, "description", "Times"), "DEFINING Times NAME")
+    call ncio_check(ncio_put_att_text(nf_out, id_times, "units", "m"), "DEFINING Times UNITS")
+    call ncio_check(ncio_put_att_text(nf_out, id_times, "coordinates", "Time"), "DEFINING Times COORD")
+    call ncio_check(ncio_put_att_text(nf_out, id_times, "stagger", ""), "DEFINING STAGGER")
+    call ncio_check(ncio_put_att_int(nf_out, id_times, "FieldType", 104), "DEFINING FieldType")
+    call ncio_check(ncio_def_var(nf_out, "ITIMESTEP", NCIO_INT, [d_time], id_itime), "DEFINING ITIMESTEP")              ! :537-548
+    call ncio_check(ncio_put_att_text(nf_out, id_itime, "description", ""), "DEFINING ITIMESTEP NAME")
+    call ncio_check(ncio_put_att_text(nf_out, id_itime, "units", ""), "DEFINING ITIMESTEP UNITS")
+    call ncio_check(ncio_put_att_text(nf_out, id_itime, "stagger", ""), "DEFINING STAGGER")
+    call ncio_check(ncio_put_att_int(nf_out, id_itime, "FieldType", 106), "DEFINING FieldType")
+    call ncio_check(ncio_put_att_text(nf_out, id_itime, "MemoryOrder", "O "), "DEFINING MemoryOrder")
+    call ncio_check(ncio_def_var(nf_out, "XTIME", NCIO_FLOAT, [d_time], id_xtime), "DEFINING XTIME")                   ! :550-561
+    call ncio_check(ncio_put_att_text(nf_out, id_xtime, "description", "minutes since "//st), "DEFINING XTIME NAME")
+    call ncio_check(ncio_put_att_text(nf_out, id_xtime, "units", "minutes since "//st), "DEFINING XTIME UNITS")
+    call ncio_check(ncio_put_att_text(nf_out, id_xtime, "stagger", ""), "DEFINING STAGGER")
+    call ncio_check(ncio_put_att_int(nf_out, id_xtime, "FieldType", 104), "DEFINING FieldType")
+    call ncio_check(ncio_put_att_text(nf_out, id_xtime, "MemoryOrder", "O "), "DEFINING MemoryOrder")
     ! target fields in the writer's order (:1150-1475)
     call collect(fl, nv)
     if (nv > MAXV) call fatal("too many output variables", nv)
@@ -333,6 +474,16 @@ contains
     tstr = valid_time
     tbytes = transfer(tstr, tbytes)
     call ncio_check(ncio_put_var(nf_out, id_times, 0_c_int64_t, NCIO_CHAR, tbytes), "WRITING Times")
+    ! XTIME = datetime(start) - datetime(valid) in minutes, in THIS order as the reference has it (:1225-1227: a valid time
+    ! after the start gives a negative value); ITIMESTEP = int(seconds / config_dt), 0 without a time step (:1233-1240)
+    xt_sec = 0
+    s_ok = .false.; v_ok = .false.
+    xt_sec = stamp_seconds(st, s_ok) - stamp_seconds(tstr, v_ok)
+    if (.not. (s_ok .and. v_ok)) xt_sec = 0
+    call ncio_check(ncio_put_var(nf_out, id_xtime, 0_c_int64_t, NCIO_DOUBLE, [real(xt_sec, dp)/60.0_dp]), "WRITING XTIME RECORD")
+    itime(1) = 0
+    if (config_dt > 0.0_dp) itime(1) = int(real(xt_sec, dp)/config_dt, c_int32_t)
+    call ncio_check(ncio_put_var(nf_out, id_itime, 0_c_int64_t, NCIO_INT, itime), "WRITING ITIMESTEP RECORD")
     npts = i_target*j_target
     do i = 1, nv
       if (dev_flow) then

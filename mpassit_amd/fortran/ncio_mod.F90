@@ -109,6 +109,22 @@ module ncio
       integer(c_int32_t), intent(in) :: vals(*)
       integer(c_int) :: rc
     end function ncio_put_att_int_c
+    function ncio_put_att_double_c(f, varid, name, vals, n) bind(C, name="ncio_put_att_double") result(rc)
+      import :: c_char, c_ptr, c_int, c_double
+      type(c_ptr), value :: f
+      integer(c_int), value :: varid, n
+      character(kind=c_char), intent(in) :: name(*)
+      real(c_double), intent(in) :: vals(*)
+      integer(c_int) :: rc
+    end function ncio_put_att_double_c
+    function ncio_get_att_text_c(f, varid, name, buf, buf_len) bind(C, name="ncio_get_att_text") result(rc)
+      import :: c_char, c_ptr, c_int
+      type(c_ptr), value :: f
+      integer(c_int), value :: varid, buf_len
+      character(kind=c_char), intent(in) :: name(*)
+      character(kind=c_char), intent(out) :: buf(*)
+      integer(c_int) :: rc
+    end function ncio_get_att_text_c
     function ncio_put_att_float_c(f, varid, name, vals, n) bind(C, name="ncio_put_att_float") result(rc)
       import :: c_char, c_ptr, c_int, c_float
       type(c_ptr), value :: f
@@ -239,6 +255,23 @@ contains
     integer(c_int), intent(in) :: varid
     character(len=*), intent(in) :: name
     real(c_double), intent(in) :: val
-    rc = ncio_put_att_float_c(f, varid, cstr(name), [real(val, c_float)], 1_c_int)
+    ! the reference is built with -r8 (CMakeLists.txt:80-82): its `real` attributes are NF90_DOUBLE
+    rc = ncio_put_att_double_c(f, varid, cstr(name), [val], 1_c_int)
   end function ncio_put_att_real
+  !> text global attribute (nf90_get_att into a character variable); blank-padded, rc /= 0 when absent or not text
+  integer(c_int) function ncio_get_gatt_text(f, name, text) result(rc)
+    type(c_ptr), intent(in) :: f
+    character(len=*), intent(in) :: name
+    character(len=*), intent(out) :: text
+    character(kind=c_char) :: buf(512)
+    integer :: i
+    text = ""
+    buf = c_null_char
+    rc = ncio_get_att_text_c(f, NCIO_GLOBAL, cstr(name), buf, 512_c_int)
+    if (rc /= 0) return
+    do i = 1, min(len(text), 511)
+      if (buf(i) == c_null_char) exit
+      text(i:i) = buf(i)
+    end do
+  end function ncio_get_gatt_text
 end module ncio

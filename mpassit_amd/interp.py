@@ -30,6 +30,7 @@ class InputData:
     nzp1: int = 0
     nsoil: int = 0
     layout: int = R.LAYOUT_CELL_FAST
+    meta: dict = field(default_factory=dict)      # global attributes of the input files the writer needs (io_nc.read_file_meta)
 
 
 @dataclass

@@ -26,7 +26,7 @@ DATESTRLEN = 19
 
 # ---- synthetic inputs in MPAS layout -----------------------------------------------------------------------------
 def write_mpas_files(grid_path, hist_path, mesh, ter, zs, hist, nz, nsoil, diag_path=None, diag=None, xtime="2024-08-07_00:00:00",
-                     fmt=5):
+                     fmt=5, start_time=None):
     """mesh: synth.MpasMesh; hist / diag: name -> [nCells] | [nCells][L] arrays (file order), written as float32 with a
     leading Time record like MPAS history files.  Grid variables go to grid_path (static file), fields to hist_path."""
     nc, nv, me = mesh.nCells, mesh.nVertices, mesh.maxEdges
@@ -60,8 +60,12 @@ def write_mpas_files(grid_path, hist_path, mesh, ter, zs, hist, nz, nsoil, diag_
             w.def_dim("nVertLevelsP1", nz + 1)
             w.def_dim("nSoilLevels", nsoil)
             w.def_dim("StrLen", 64)
-            w.put_att("config_start_time", xtime)
+            w.put_att("config_start_time", start_time or xtime)
             w.put_att("config_dt", 20.0)
+            w.put_att("config_lsm_scheme", "noah")
+            w.put_att("config_microp_scheme", "mp_thompson")
+            w.put_att("config_convection_scheme", "cu_grell_freitas")
+            w.put_att("output_interval", np.int32(3600))
             w.def_var("xtime", ncio.CHAR, ("Time", "StrLen"))
             levdim = {nz: "nVertLevels", nz + 1: "nVertLevelsP1", nsoil: "nSoilLevels"}
             for name, a in flds.items():
@@ -144,6 +148,61 @@ def _read_field_dev(r, name, device):
     return bswap_(t.view(getattr(torch, _RAW_TYPES[v["type"]][0]))).reshape(shape)
 
 
+_LSM = {"noah": 2, "ruc": 3}                                                  # input_data.F90:347-355
+_MP = {"mp_thompson": 8, "mp_nssl2m": 18}                                       # :362-369
+_CU = {"cu_ntiedke": 16, "cu_kain_fritsch": 1, "cu_grell_freitas": 3}          # :374-383
+
+
+def read_file_meta(r, meta, diag=False):
+    """The global attributes of an MPAS history / diag file that end up in the output header (input_data.F90:219-245 for
+    the diag file, :347-389 for the history file, which is read second and wins).  Missing attributes -> the reference's
+    defaults (0 / 0.0); an unknown scheme name leaves the previous value, as the reference's if-chain does."""
+    def text(name):
+        try:
+            v = r.att(name)
+        except ncio.NcioError:
+            return None
+        return v.strip().strip("\x00") if isinstance(v, str) else None
+
+    def num(name):
+        try:
+            return float(np.atleast_1d(r.att(name))[0])
+        except (ncio.NcioError, TypeError, ValueError):
+            return None
+    st = text("config_start_time")
+    if st is not None:
+        meta["start_time"] = st
+    dt = num("config_dt")
+    meta["config_dt"] = 0.0 if dt is None else dt
+    if diag:
+        oi = num("output_interval")
+        meta["diag_out_interval"] = 0 if oi is None else int(oi)
+        return meta
+    for key, att, table in (("lsm_scheme", "config_lsm_scheme", _LSM), ("mp_scheme", "config_microp_scheme", _MP),
+                            ("conv_scheme", "config_convection_scheme", _CU)):
+        v = text(att)
+        if v is None:
+            meta[key] = 0
+        elif v in table:
+            meta[key] = table[v]
+        else:
+            meta.setdefault(key, 0)
+    return meta
+
+
+def xtime_minutes(start_time, valid_time):
+    """XTIME as write_target_data computes it (write_data.F90:1211-1227): datetime(start) - datetime(valid), in minutes --
+    the reference subtracts in THIS order, so a valid time after the start gives a negative XTIME; kept as written."""
+    import datetime as dtm
+
+    def parse(s):
+        return dtm.datetime(int(s[0:4]), int(s[5:7]), int(s[8:10]), int(s[11:13]), int(s[14:16]), int(s[17:19]))
+    try:
+        return (parse(start_time) - parse(valid_time)).total_seconds() / 60.0
+    except ValueError:
+        return 0.0
+
+
 def read_input_data(hist_path, cfg, ter, diag_path=None, device=None):
     """-> (interp.InputData with layout = LEV_FAST, attrs dict name -> (units, long_name), valid time string).
     Every variable of the lists is read whole, first Time record (input_data.F90:316-812).
@@ -165,9 +224,13 @@ def read_input_data(hist_path, cfg, ter, diag_path=None, device=None):
                 attrs[n] = (r.att("units", var=n), r.att("long_name", var=n))
             except ncio.NcioError:
                 attrs[n] = ("-", n)
+    if cfg.interp_diag and diag_path is not None:
+        with ncio.Reader(diag_path) as r:
+            read_file_meta(r, inp.meta, diag=True)
     if cfg.interp_hist:
         r_path = hist_path
         with ncio.Reader(hist_path) as r:
+            read_file_meta(r, inp.meta)
             inp.nz = r.dims.get("nVertLevels", 0)
             inp.nzp1 = r.dims.get("nVertLevelsP1", inp.nz + 1)
             inp.nsoil = r.dims.get("nSoilLevels", 0)
@@ -217,27 +280,38 @@ def _put_dev(w, name, a):
 
 
 def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time="0000-00-00_00:00:00", start_time=None,
-                      zs=None, namelist=None, fmt=5):
+                      zs=None, namelist=None, fmt=5, meta=None):
     """res: post.output_fields() result (float32 arrays, [L][ny][nx] C order = Fortran (i, j, L)).  grid: a
     regrid.Grid built with Grid.from_proj (coordinates / map factors / rotation come from the device).
-    namelist: dict with dx, ref_lat, ref_lon, truelat1, truelat2, stand_lon for the global attributes."""
+    namelist: dict with dx, ref_lat, ref_lon, truelat1, truelat2, stand_lon for the global attributes.
+    meta: what read_file_meta took from the input files (start_time, config_dt, physics schemes, diag output interval).
+    Header = write_data.F90:177-560 attribute for attribute and in its order; the reference is built with -r8
+    (CMakeLists.txt:80-82), so its `real` attributes are NF90_DOUBLE and so are they here."""
+    meta = dict(meta or {})
     nl = dict(dx=0.0, ref_lat=0.0, ref_lon=0.0, truelat1=0.0, truelat2=0.0, stand_lon=0.0, pole_lat=90.0, pole_lon=0.0)
     nl.update(namelist or {})
     nx, ny = target.nx, target.ny
-    start_time = start_time or valid_time
+    start_time = start_time or meta.get("start_time") or valid_time
     with ncio.Writer(path, format=fmt) as w:
         for name, n in (("Time", None), ("west_east", nx), ("west_east_stag", nx + 1), ("south_north", ny), ("south_north_stag", ny + 1),
                         ("bottom_top", nz), ("bottom_top_stag", nzp1), ("soil_layers_stag", max(nsoil, 1)), ("StrLen", DATESTRLEN)):
             w.def_dim(name, n)                                                        # write_data.F90:177-194
+        f8 = np.float64
         ga = [("WEST-EAST_GRID_DIMENSION", nx + 1), ("SOUTH-NORTH_GRID_DIMENSION", ny + 1), ("BOTTOM-TOP_GRID_DIMENSION", nz + 1),
-              ("SIMULATION_START_DATE", start_time), ("START_DATE", start_time), ("DX", np.float32(nl["dx"])), ("DY", np.float32(nl["dx"])),
-              ("CEN_LAT", np.float32(nl["ref_lat"])), ("CEN_LON", np.float32(nl["ref_lon"])), ("TRUELAT1", np.float32(nl["truelat1"])),
-              ("TRUELAT2", np.float32(nl["truelat2"])), ("MOAD_CEN_LAT", np.float32(nl["ref_lat"])), ("STAND_LON", np.float32(nl["stand_lon"])),
-              ("POLE_LAT", np.float32(nl["pole_lat"])), ("POLE_LON", np.float32(nl["pole_lon"])), ("MAP_PROJ", int(target.proj.code)),
-              ("MAP_PROJ_CHAR", "Lambert Conformal" if target.proj.code == 1 else "Cylindrical Equidistant"),
-              ("I_PARENT_START", 1), ("J_PARENT_START", 1), ("WEST-EAST_PATCH_END_UNSTAG", nx), ("WEST-EAST_PATCH_END_STAG", nx + 1),
-              ("SOUTH-NORTH_PATCH_END_UNSTAG", ny), ("SOUTH-NORTH_PATCH_END_STAG", ny + 1), ("BOTTOM-TOP_PATCH_END_UNSTAG", nz),
-              ("BOTTOM-TOP_PATCH_END_STAG", nz + 1)]
+              ("SIMULATION_START_DATE", start_time), ("START_DATE", start_time), ("DX", f8(nl["dx"])), ("DY", f8(nl["dx"])),
+              ("DT", f8(meta.get("config_dt", 0.0))), ("SF_SURFACE_PHYSICS", int(meta.get("lsm_scheme", 0))),
+              ("MP_PHYSICS", int(meta.get("mp_scheme", 0))), ("CU_PHYSICS", int(meta.get("conv_scheme", 0))),
+              ("CEN_LAT", f8(nl["ref_lat"])), ("CEN_LON", f8(nl["ref_lon"])), ("TRUELAT1", f8(nl["truelat1"])),
+              ("TRUELAT2", f8(nl["truelat2"])), ("MOAD_CEN_LAT", f8(nl["ref_lat"])), ("STAND_LON", f8(nl["stand_lon"])),
+              ("POLE_LAT", f8(nl["pole_lat"])), ("POLE_LON", f8(nl["pole_lon"])), ("POL_ELAT", f8(nl["pole_lat"])),   # sic, :253
+              ("MAP_PROJ", int(target.proj.code)),
+              ("MAP_PROJ_CHAR", target.extra.get("map_proj_char") or ("Lambert Conformal" if target.proj.code == 1 else "Lat/Lon"))]
+        if cfg.interp_diag:
+            ga.append(("PREC_ACC_DT", int(meta.get("diag_out_interval", 0))))                                          # :262-265
+        ga += [("I_PARENT_START", 1), ("J_PARENT_START", 1)]
+        ga += [("%s_PATCH_START_%s" % (d, st), 1) for d in ("WEST-EAST", "SOUTH-NORTH", "BOTTOM-TOP") for st in ("UNSTAG", "STAG")]
+        ga += [("WEST-EAST_PATCH_END_UNSTAG", nx), ("WEST-EAST_PATCH_END_STAG", nx + 1), ("SOUTH-NORTH_PATCH_END_UNSTAG", ny),
+               ("SOUTH-NORTH_PATCH_END_STAG", ny + 1), ("BOTTOM-TOP_PATCH_END_UNSTAG", nz), ("BOTTOM-TOP_PATCH_END_STAG", nz + 1)]
         for k, v in ga:                                                               # :196-308
             w.put_att(k, v)
         stag = {"M": (R.STAGGERLOC_CENTER, ""), "U": (R.STAGGERLOC_EDGE1, "X"), "V": (R.STAGGERLOC_EDGE2, "Y")}
@@ -250,7 +324,10 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
                 w.def_var(name, ncio.FLOAT, ("Time", "south_north", "west_east"), description="Local %s of map rotation" %
                           ("sine" if name[0] == "S" else "cosine"), units="", MemoryOrder="XY ", stagger="", FieldType=104)
         w.def_var("ZS", ncio.FLOAT, ("Time", "soil_layers_stag"), description="DEPTHS OF CENTERS OF SOIL LAYERS", units="m", MemoryOrder="X")
-        w.def_var("Times", ncio.CHAR, ("Time", "StrLen"))
+        w.def_var("Times", ncio.CHAR, ("Time", "StrLen"), description="Times", units="m", coordinates="Time", stagger="", FieldType=104)
+        w.def_var("ITIMESTEP", ncio.INT, ("Time",), description="", units="", stagger="", FieldType=106, MemoryOrder="O ")     # :537-548
+        w.def_var("XTIME", ncio.FLOAT, ("Time",), description="minutes since " + start_time, units="minutes since " + start_time,
+                  stagger="", FieldType=104, MemoryOrder="O ")                                                              # :550-561
         dimsets = {(ny, nx): ("south_north", "west_east"), (nz, ny, nx): ("bottom_top", "south_north", "west_east"),
                    (nz, ny, nx + 1): ("bottom_top", "south_north", "west_east_stag"),
                    (nz, ny + 1, nx): ("bottom_top", "south_north_stag", "west_east"),
@@ -288,6 +365,10 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
             w.put("COSALPHA", cosa, rec=0)
         w.put("ZS", np.zeros(max(nsoil, 1), np.float32) if zs is None else np.asarray(zs, np.float32), rec=0)
         w.put("Times", valid_time.encode()[:DATESTRLEN].ljust(DATESTRLEN), rec=0)
+        xt = xtime_minutes(start_time, valid_time)                                                                          # :1211-1240
+        dt_cfg = float(meta.get("config_dt", 0.0))
+        w.put("XTIME", np.array([xt], np.float32), rec=0)
+        w.put("ITIMESTEP", np.array([int(xt * 60.0 / dt_cfg) if dt_cfg > 0.0 else 0], np.int32), rec=0)
         for name, a in arrays.items():
             if _is_dev(a):
                 _put_dev(w, name, a)
@@ -329,7 +410,7 @@ def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=No
     res = post.output_fields(out, cfg)
     t = lap("post_ops", t)
     write_target_data(out_path, target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00", zs=zs,
-                      namelist=namelist, fmt=fmt)
+                      namelist=namelist, fmt=fmt, meta=inp.meta)
     t = lap("write_target_data", t)
     mesh.destroy()
     grid.destroy()
@@ -377,13 +458,14 @@ def run_series(grid_path, jobs, target, cfg, namelist=None, fmt=5, timings=None)
                     for name, buf in store.items():
                         buf.copy_(fresh[name])                   # into the graph's static input buffers
                         fresh[name].record_stream(torch.cuda.current_stream())   # allocated on the reader's stream
+                inp.meta = new.meta                              # every file carries its own start time / time step / schemes
                 del new
             if k + 1 < len(jobs):
                 nxt = reader.submit(fetch, jobs[k + 1])
             out = gi.replay()
             res = post.output_fields(out, cfg)
             write_target_data(job[2], target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00",
-                              zs=zs, namelist=namelist, fmt=fmt)
+                              zs=zs, namelist=namelist, fmt=fmt, meta=inp.meta)
             if timings is not None:
                 torch.cuda.synchronize()
                 timings["files_s"].append(time.perf_counter() - t0)
@@ -395,4 +477,4 @@ def run_series(grid_path, jobs, target, cfg, namelist=None, fmt=5, timings=None)
     return len(jobs)
 
 
-__all__ = ["write_mpas_files", "read_grid", "read_input_data", "write_target_data", "run", "run_series", "F"]
+__all__ = ["write_mpas_files", "read_grid", "read_input_data", "read_file_meta", "xtime_minutes", "write_target_data", "run", "run_series", "F"]

@@ -305,4 +305,9 @@ def define_target_grid_file(path):
             g.sina, g.cosa = var("SINALPHA"), var("COSALPHA")
         g.extra.update(from_file=True, ref_lat=att("MOAD_CEN_LAT", att("CEN_LAT")), ref_lon=att("CEN_LON"), pole_lat=att("POLE_LAT", 90.0),
                        pole_lon=att("POLE_LON", 0.0))
+        try:                                                              # model_grid.F90:1288-1295
+            mpc = r.att("MAP_PROJ_CHAR")
+            g.extra["map_proj_char"] = mpc.strip() if isinstance(mpc, str) else None
+        except ncio.NcioError:
+            g.extra["map_proj_char"] = None
     return g

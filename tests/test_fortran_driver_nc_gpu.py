@@ -39,7 +39,7 @@ def _write_inputs(d, m, nz=6, nsoil=4):
     diag = {k: np.asarray(v, np.float32) for k, v in diag.items()}
     ter = synth.analytic_field(m.latCell, m.lonCell, 1, seed=1)[0] * 1000
     io_nc.write_mpas_files(os.path.join(d, "init.nc"), os.path.join(d, "hist.nc"), m, ter, [0.05, 0.25, 0.7, 1.5], hist, nz, nsoil,
-                           diag_path=os.path.join(d, "diag.nc"), diag=diag, xtime="2024-08-07_12:00:00", fmt=5)
+                           diag_path=os.path.join(d, "diag.nc"), diag=diag, xtime="2024-08-07_12:00:00", fmt=5, start_time="2024-08-07_00:00:00")
     for fname, lst in (("diaglist", DIAG), ("histlist_2d", HIST_2D), ("histlist_3d", HIST_3D), ("histlist_soil", SOIL)):
         with open(os.path.join(d, fname), "w") as f:
             f.write("".join("%s\t\t%s\n" % p for p in lst))
@@ -97,6 +97,21 @@ def test_driver_netcdf_in_netcdf_out(tmp_path, gpu_lib, regional_case):
         assert f.vars["U"]["dims"] == ("Time", "bottom_top", "south_north", "west_east_stag")
         assert f.vars["V"]["dims"] == ("Time", "bottom_top", "south_north_stag", "west_east")
         assert f.vars["TSLB"]["dims"][1] == "soil_layers_stag" and f.vars["PHB"]["dims"][1] == "bottom_top_stag"
+        # XTIME / ITIMESTEP as the reference computes them (write_data.F90:1211-1240): datetime(start) - datetime(valid)
+        assert float(f.get("XTIME", rec=0)) == np.float32(-720.0) and int(f.get("ITIMESTEP", rec=0)) == -2160
+    # ---- header parity: both writers against the list transcribed from write_data.F90:177-560, and against each other
+    from _header_check import check_output_header
+    start = "2024-08-07_00:00:00"
+    h_f = check_output_header(os.path.join(d, "out.nc"), True, 1, start, config_dt=20.0, physics=(2, 8, 3), prec_acc_dt=3600)
+    io_nc.write_target_data(os.path.join(d, "out_py.nc"), gd, R.Grid.from_proj(gd), want, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid,
+                            zs=[0.05, 0.25, 0.7, 1.5], meta=inp.meta,
+                            namelist=dict(dx=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5))
+    h_p = check_output_header(os.path.join(d, "out_py.nc"), True, 1, start, config_dt=20.0, physics=(2, 8, 3), prec_acc_dt=3600)
+    assert h_f["dims"] == h_p["dims"] and h_f["gatts"] == h_p["gatts"]
+    vf, vp = {v["name"]: v for v in h_f["vars"]}, {v["name"]: v for v in h_p["vars"]}
+    assert set(vf) == set(vp), set(vf) ^ set(vp)
+    for name in vf:
+        assert vf[name]["dims"] == vp[name]["dims"] and vf[name]["type"] == vp[name]["type"], name
 
 
 def test_driver_with_a_file_defined_target_grid(tmp_path, gpu_lib, regional_case):
