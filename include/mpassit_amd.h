@@ -49,6 +49,8 @@ enum {
 };
 
 /* ---- runtime: ESMF_Initialize / ESMF_Finalize (mpassit.F90:84,140) ------------------------------ */
+/* mpg_init may be repeated with the SAME device index (no-op); a different index while initialised is refused with
+ * MPG_ERR_INVALID_ARG (streams and pinned staging belong to the first device): mpg_finalize first. */
 int mpg_init(int device);
 int mpg_finalize(void);
 const char *mpg_last_error(void);
@@ -232,6 +234,8 @@ int mpg_mesh_get_triangles(mpg_mesh mesh, int32_t *tri_host);
  * references.  Call with ids_host == NULL to get the count.  mpg_handle_localize rewrites the handle's
  * indices to positions in that list so that Regrid reads a compact [nlev][n_unique] halo buffer. */
 int mpg_handle_unique_sources(mpg_handle rh, int64_t *n_unique, int32_t *ids_host);
+/* Both re-index the handle IN PLACE and detach it from the Store cache; a handle that is shared (mpg_regrid_store returned
+ * the same pointer twice: refcount 2) is refused with MPG_ERR_INVALID_ARG -- release the other reference first. */
 int mpg_handle_localize(mpg_handle rh);
 /* Halo in "range" form (spatially banded cell numbering): subtract `base` from every source index and
  * declare the local source extent n_local, so that Regrid reads a [nlev][n_local] buffer holding the

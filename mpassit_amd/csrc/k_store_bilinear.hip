@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
                                                     const double *__restrict__ cx, const double *__restrict__ cy,
                                                     const double *__restrict__ cz, PyramidView pyr, int npx, int npy,
                                                     const double *__restrict__ px, const double *__restrict__ py,
-                                                    const double *__restrict__ pz, int32_t *__restrict__ owner) {
+                                                    const double *__restrict__ pz, int32_t *__restrict__ owner,
+                                                    int32_t *__restrict__ overflow) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= nTri) return;
   int32_t ia = tri[t];
@@ -65,7 +66,12 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
 #pragma unroll
         for (int di = 0; di < 2; ++di) {
           int ci = 2 * bi + di, cj = 2 * bj + dj;
-          if (ci < cnx && cj < cny && sp < RASTER_STACK) stack[sp++] = ((lev - 1) << 26) | (cj * cnx + ci);
+          if (ci < cnx && cj < cny) {
+            // depth-first with four children per node needs 3 * levels + 1 slots (49 at MPG_PYR_MAXLEV = 16): a full stack
+            // cannot happen, and if it ever did it is reported (MPG_ERR_OVERFLOW), never a silently unmapped point
+            if (sp < RASTER_STACK) stack[sp++] = ((lev - 1) << 26) | (cj * cnx + ci);
+            else atomicOr(overflow, 1);
+          }
         }
     }
   }
@@ -182,14 +188,24 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   if ((rc = owner.alloc((size_t)P))) return rc;
   int fb = (int)((P + 255) / 256);
   if (fb > 8192) fb = 8192;
+  TmpBuf<int32_t> ovf;
+  if ((rc = ovf.alloc(1))) return rc;
+  MPG_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
   k_fill_i32<<<fb, 256, 0, s>>>(P, 0x7fffffff, owner.p);
   k_tri_raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sp->x.p, sp->y.p, sp->z.p,
                                                            mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p,
-                                                           pts.z.p, owner.p);
+                                                           pts.z.p, owner.p, ovf.p);
   k_tri_finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sp->x.p, sp->y.p, sp->z.p, pts.x.p, pts.y.p,
                                                             pts.z.p, h->idx.p, h->w.p);
   MPG_HIP(hipGetLastError());
+  int32_t h_ovf = 0;
+  MPG_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   owner.free();
+  if (h_ovf) {
+    mpg_set_error("RegridStore(bilinear): traversal stack of the triangle rasteriser overflowed (pyramid deeper than %d levels)",
+                  (RASTER_STACK - 1) / 3);
+    return MPG_ERR_OVERFLOW;
+  }
   return MPG_SUCCESS;
 }

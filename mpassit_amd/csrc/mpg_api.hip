@@ -36,6 +36,12 @@ int mpg_init(int device) {
     return MPG_ERR_NOT_INITIALIZED;
   }
   MPG_ARG(device >= 0 && device < n, "mpg_init: device index out of range");
+  if (g_init && device != g_device) {
+    // the set-up stream, the file-io lanes and their pinned buffers belong to the first device; objects created there would
+    // be paired with a stream of another device.  One device per process (one process per GPU); finalize first to switch.
+    mpg_set_error("mpg_init: already initialised on device %d; call mpg_finalize before initialising device %d", g_device, device);
+    return MPG_ERR_INVALID_ARG;
+  }
   MPG_HIP(hipSetDevice(device));
   if (!g_init) MPG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   g_device = device;
@@ -85,7 +91,12 @@ int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const doubl
     mpg_mesh_destroy(m);
     return rc;
   }
-  MPG_HIP(hipMemcpyAsync(m->voc.p, verticesOnCell, sizeof(int32_t) * (size_t)nCells * maxEdges, hipMemcpyHostToDevice, s));
+  hipError_t he = hipMemcpyAsync(m->voc.p, verticesOnCell, sizeof(int32_t) * (size_t)nCells * maxEdges, hipMemcpyHostToDevice, s);
+  if (he != hipSuccess) {
+    mpg_set_error("mpg_mesh_create: uploading verticesOnCell failed: %s", hipGetErrorString(he));
+    mpg_mesh_destroy(m);
+    return MPG_ERR_HIP;
+  }
   if ((rc = mpg_k_dual_triangles(m, s))) {
     mpg_mesh_destroy(m);
     return rc;
@@ -613,6 +624,8 @@ int mpg_handle_localize(mpg_handle h) {
   MPG_CHECK_INIT();
   MPG_ARG(h, "mpg_handle_localize: NULL handle");
   MPG_ARG(!h->localized, "mpg_handle_localize: handle already localized");
+  MPG_ARG(h->refcount <= 1, "mpg_handle_localize: the handle is shared (a second mpg_regrid_store returned it from the cache); "
+                            "re-indexing it in place would corrupt the other holder's indices -- release the other reference first");
   MPG_ARG(h->n_pole == 0, "mpg_handle_localize: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
   // a localized handle no longer matches its cache key: detach it
   if (h->cached) {
@@ -628,6 +641,8 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
   MPG_CHECK_INIT();
   MPG_ARG(h, "mpg_handle_rebase: NULL handle");
   MPG_ARG(!h->localized, "mpg_handle_rebase: handle already localized");
+  MPG_ARG(h->refcount <= 1, "mpg_handle_rebase: the handle is shared (a second mpg_regrid_store returned it from the cache); "
+                            "re-indexing it in place would corrupt the other holder's indices -- release the other reference first");
   MPG_ARG(h->n_pole == 0, "mpg_handle_rebase: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
   MPG_ARG(base >= 0 && n_local >= 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
   if (h->cached) {

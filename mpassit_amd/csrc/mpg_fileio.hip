@@ -29,8 +29,7 @@ struct Lane {
   void *buf[NTHREAD][2] = {};
   hipStream_t stream[NTHREAD] = {};
   hipEvent_t done[NTHREAD][2] = {};
-  int init() {
-    if (ready) return MPG_SUCCESS;
+  int init_all() {
     for (int t = 0; t < NTHREAD; ++t) {
       MPG_HIP(hipStreamCreateWithFlags(&stream[t], hipStreamNonBlocking));
       for (int b = 0; b < 2; ++b) {
@@ -38,11 +37,23 @@ struct Lane {
         MPG_HIP(hipEventCreateWithFlags(&done[t][b], hipEventDisableTiming));
       }
     }
+    return MPG_SUCCESS;
+  }
+  int init() {   // caller holds mu
+    if (ready) return MPG_SUCCESS;
+    int rc = init_all();
+    if (rc) {
+      free_all();   // a partial set (e.g. pinned memory exhausted half way) is given back, the next call starts clean
+      return rc;
+    }
     ready = true;
     return MPG_SUCCESS;
   }
   void release() {
     std::lock_guard<std::mutex> lock(mu);
+    free_all();
+  }
+  void free_all() {
     for (int t = 0; t < NTHREAD; ++t) {
       if (stream[t]) (void)hipStreamDestroy(stream[t]);
       stream[t] = nullptr;

@@ -73,7 +73,7 @@ static void swap_buf(void *p, int64_t n, int size) {
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* header reading                                                                                               */
-typedef struct { FILE *fp; int fmt; int bad; } rd_t;
+typedef struct { FILE *fp; int fmt; int bad; int64_t fsize; } rd_t;   /* fsize bounds every count the header claims */
 static uint32_t rd_u32(rd_t *r) {
   uint32_t v = 0;
   if (fread(&v, 4, 1, r->fp) != 1) r->bad = 1;
@@ -103,6 +103,7 @@ static int rd_atts(rd_t *r, int *natts, att_t **atts) {
   if (tag == 0 && n == 0) return 0;
   if (tag != TAG_ATT || n < 0 || n > 100000) { r->bad = 1; return -1; }
   *atts = (att_t *)calloc((size_t)n, sizeof(att_t));
+  if (!*atts) { r->bad = 1; return -1; }
   *natts = (int)n;
   for (int64_t a = 0; a < n && !r->bad; ++a) {
     att_t *t = &(*atts)[a];
@@ -110,10 +111,13 @@ static int rd_atts(rd_t *r, int *natts, att_t **atts) {
     t->type = (int)rd_u32(r);
     t->n = rd_nonneg(r);
     int sz = tsize(t->type);
-    if (r->bad || !sz || t->n < 0) { r->bad = 1; break; }
+    /* a damaged or hostile header must end in NCIO_EFORMAT, not in an overflowing product, a huge allocation or a NULL
+     * dereference: an attribute cannot hold more values than the file has bytes */
+    if (r->bad || !sz || t->n < 0 || t->n > r->fsize / sz) { r->bad = 1; t->n = 0; break; }
     int64_t bytes = pad4(t->n * sz);
     t->data = calloc((size_t)bytes + 1, 1);
-    if (bytes && fread(t->data, 1, (size_t)bytes, r->fp) != (size_t)bytes) r->bad = 1;
+    if (!t->data) { r->bad = 1; t->n = 0; break; }
+    if (bytes && fread(t->data, 1, (size_t)bytes, r->fp) != (size_t)bytes) { r->bad = 1; t->n = 0; break; }
     swap_buf(t->data, t->n, sz);
   }
   return r->bad ? -1 : 0;
@@ -169,15 +173,17 @@ int ncio_open(const char *path, ncio_file **out) {
   f->fp = fp;
   f->format = m[3];
   f->recdim = -1;
-  rd_t r = {fp, f->format, 0};
+  rd_t r = {fp, f->format, 0, 0};
+  if (fseeko(fp, 0, SEEK_END) == 0) r.fsize = (int64_t)ftello(fp);
+  if (r.fsize <= 0 || fseeko(fp, 4, SEEK_SET) != 0) { free_file(f); return fail(NCIO_EIO, "ncio_open: cannot size %s", path); }
   f->numrecs = rd_nonneg(&r);
   if (f->format != 5 && f->numrecs == 0xFFFFFFFFll) f->numrecs = 0; /* STREAMING marker */
   uint32_t tag = rd_u32(&r);
   int64_t n = rd_nonneg(&r);
   if (!r.bad && !(tag == 0 && n == 0)) {
-    if (tag != TAG_DIM || n < 0 || n > 100000) r.bad = 1;
+    if (tag != TAG_DIM || n < 0 || n > 100000 || n > r.fsize / 8) r.bad = 1;
+    else if (!(f->dims = (dim_t *)calloc((size_t)n, sizeof(dim_t)))) r.bad = 1;
     else {
-      f->dims = (dim_t *)calloc((size_t)n, sizeof(dim_t));
       f->ndims = (int)n;
       for (int d = 0; d < f->ndims && !r.bad; ++d) {
         f->dims[d].name = rd_name(&r);
@@ -191,9 +197,9 @@ int ncio_open(const char *path, ncio_file **out) {
     tag = rd_u32(&r);
     n = rd_nonneg(&r);
     if (!(tag == 0 && n == 0)) {
-      if (tag != TAG_VAR || n < 0 || n > 1000000) r.bad = 1;
+      if (tag != TAG_VAR || n < 0 || n > 1000000 || n > r.fsize / 16) r.bad = 1;
+      else if (!(f->vars = (var_t *)calloc((size_t)n, sizeof(var_t)))) r.bad = 1;
       else {
-        f->vars = (var_t *)calloc((size_t)n, sizeof(var_t));
         f->nvars = (int)n;
         for (int v = 0; v < f->nvars && !r.bad; ++v) {
           var_t *x = &f->vars[v];
@@ -218,6 +224,24 @@ int ncio_open(const char *path, ncio_file **out) {
   }
   if (r.bad) { free_file(f); return fail(NCIO_EFORMAT, "ncio_open: %s has a damaged or truncated header", path); }
   if (f->recdim >= 0) f->dims[f->recdim].len = 0;
+  /* every variable must lie inside the file: a corrupted dimension length or offset is caught here, not as an absurd
+   * allocation or a short read later (the record count is checked against the record size the same way) */
+  for (int v = 0; v < f->nvars; ++v) {
+    var_t *x = &f->vars[v];
+    int64_t n = 1;
+    int isrec = 0, ok = x->begin >= 0 && x->begin <= r.fsize && x->name != NULL;
+    for (int d = 0; d < x->ndims && ok; ++d) {
+      if (x->dimids[d] == f->recdim) { isrec = 1; if (d != 0) ok = 0; continue; }
+      int64_t len = f->dims[x->dimids[d]].len;
+      if (len < 0 || (len > 0 && n > r.fsize / len)) ok = 0;
+      else n *= len;
+    }
+    if (ok && n > (r.fsize - x->begin) / tsize(x->type) && !(isrec && f->numrecs == 0)) ok = 0;
+    if (ok && isrec && f->numrecs > 0 && n > 0 && f->numrecs > r.fsize / (n * tsize(x->type)) + 1) ok = 0;
+    if (!ok) { free_file(f); return fail(NCIO_EFORMAT, "ncio_open: %s: variable %d does not fit the file (damaged header)", path, v); }
+  }
+  for (int d = 0; d < f->ndims; ++d)
+    if (!f->dims[d].name) { free_file(f); return fail(NCIO_EFORMAT, "ncio_open: %s has a damaged header", path); }
   finish_layout_info(f);
   *out = f;
   return 0;

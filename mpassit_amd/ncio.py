@@ -55,9 +55,9 @@ class Reader:
             name = C.create_string_buffer(256)
             n, unl = C.c_int64(), C.c_int()
             _check(lib().ncio_inq_dim_by_id(self._h, d, name, 256, C.byref(n), C.byref(unl)))
-            self.dims[name.value.decode()] = n.value
+            self.dims[name.value.decode("utf-8", "replace")] = n.value
             if unl.value:
-                self.unlimited = name.value.decode()
+                self.unlimited = name.value.decode("utf-8", "replace")
         self.vars = {}
         dim_names = list(self.dims)
         for v in range(lib().ncio_nvars(self._h)):
@@ -65,7 +65,7 @@ class Reader:
             t, nd, rec = C.c_int(), C.c_int(), C.c_int()
             shape, ids = (C.c_int64 * 8)(), (C.c_int * 8)()
             _check(lib().ncio_inq_var(self._h, v, name, 256, C.byref(t), C.byref(nd), shape, ids, C.byref(rec)))
-            self.vars[name.value.decode()] = dict(id=v, type=t.value, shape=tuple(shape[:nd.value]),
+            self.vars[name.value.decode("utf-8", "replace")] = dict(id=v, type=t.value, shape=tuple(shape[:nd.value]),
                                                   dims=tuple(dim_names[i] for i in ids[:nd.value]), record=bool(rec.value))
 
     def get(self, name, rec=None, dtype=None):

@@ -134,3 +134,34 @@ def test_bad_arguments_are_refused(gpu_lib, regional_case):
     rh.release()
     mesh.destroy()
     grid.destroy()
+
+
+def test_shared_handle_is_not_reindexed_in_place(gpu_lib, regional_case):
+    """mpg_handle_localize / mpg_handle_rebase re-index a handle in place; a handle the Store cache has handed out twice
+    (same 5-tuple -> same pointer, refcount 2) must be refused, or the other holder's next Regrid would read wrong cells."""
+    from mpassit_amd import regrid as R
+    from mpassit_amd._lib import MpgError
+    m, g = regional_case
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    a = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    b = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    assert a._h.value == b._h.value
+    with pytest.raises(MpgError, match="shared"):
+        a.localize()
+    with pytest.raises(MpgError, match="shared"):
+        b.rebase(0, m.nCells)
+    b.release()
+    ids = a.localize()                                   # sole owner now: allowed
+    assert a.n_src == ids.size
+    a.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+def test_reinit_on_another_device_is_refused(gpu_lib):
+    """mpg_init twice with the same device is a no-op; a different index while initialised is refused (streams and pinned
+    staging belong to the first device)."""
+    import ctypes as C
+    lib = gpu_lib.load()
+    assert lib.mpg_init(C.c_int(0)) == 0
+    assert lib.mpg_init(C.c_int(1)) != 0                 # out of range on a one-GPU box, "already initialised" on a node

@@ -67,3 +67,44 @@ def test_random_files_round_trip(ncio, tmp_path, fmt, dims, specs, nrec, seed):
             want = arr if rec else arr[0]
             assert np.array_equal(got.reshape(want.shape), want), name
         f.close()
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 5])
+def test_damaged_headers_fail_cleanly(ncio, tmp_path, fmt):
+    """A truncated or corrupted header must end in NcioError (NCIO_EFORMAT / NCIO_EIO), never in a crash, a huge
+    allocation or a NULL dereference: every truncation point of the header, and every 4-byte word of it overwritten with
+    0x7fffffff / 0xffffffff (attribute counts, name lengths, dimension and variable counts, types).  Runs under
+    AddressSanitizer in tools/sanitize_cpu.sh."""
+    good = tmp_path / "good.nc"
+    with ncio.Writer(str(good), format=fmt) as w:
+        w.def_dim("Time", None)
+        w.def_dim("x", 5)
+        w.put_att("title", "damaged header test")
+        w.put_att("numbers", np.arange(4, dtype=np.float64))
+        w.def_var("a", ncio.FLOAT, ("Time", "x"), units="m", long_name="a variable", valid=np.array([1, 2], np.int32))
+        w.def_var("b", ncio.DOUBLE, ("x",))
+        w.put("a", np.arange(5, dtype=np.float32), rec=0)
+        w.put("b", np.arange(5, dtype=np.float64))
+    blob = good.read_bytes()
+    with ncio.Reader(str(good)) as r:
+        hdr = min(r.extent("a", 0)[0], r.extent("b")[0])          # the header ends where the first variable's data begin
+    bad = tmp_path / "bad.nc"
+    opened = 0
+    for cut in range(0, hdr):
+        bad.write_bytes(blob[:cut])
+        with pytest.raises(ncio.NcioError):
+            ncio.Reader(str(bad))
+    for off in range(4, hdr - 3, 4):
+        for word in (b"\x7f\xff\xff\xff", b"\xff\xff\xff\xff"):
+            bad.write_bytes(blob[:off] + word + blob[off + 4:])
+            try:
+                with ncio.Reader(str(bad)) as r:                   # some words are payload (attribute values, offsets): still a valid file
+                    opened += 1
+                    for name in r.vars:
+                        try:
+                            r.get(name)
+                        except ncio.NcioError:
+                            pass
+            except ncio.NcioError:
+                pass
+    assert opened > 0

@@ -110,10 +110,18 @@ def main():
     for nt in [v for v in os.environ.get("C4JOB_NCIO_THREADS", "").split(",") if v]:   # optional sweep of ncio's thread count
         t0 = time.perf_counter()
         r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=900, env=dict(os.environ, NCIO_THREADS=nt))
+        if r.returncode != 0:
+            print("fortran driver (NCIO_THREADS=%s) failed with rc %d" % (nt, r.returncode))
+            print(r.stdout[-3000:], r.stderr[-3000:])
+            return 1
         print("fortran driver, NCIO_THREADS=%s: %.2f s   %s" % (nt, time.perf_counter() - t0, "  ".join(
             ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("["))), flush=True)
     t0 = time.perf_counter()       # the driver with host arrays (what it does for raw-container inputs / outputs)
     r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=900, env=dict(os.environ, MPASSIT_HOST_ARRAYS="1"))
+    if r.returncode != 0:          # the driver's own message, not a FileNotFoundError from the rename below
+        print("fortran driver (host arrays) failed with rc %d" % r.returncode)
+        print(r.stdout[-3000:], r.stderr[-3000:])
+        return 1
     print("fortran, host arrays:  %.2f s wall   %s" % (time.perf_counter() - t0, "  ".join(
         ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("["))), flush=True)
     os.replace(os.path.join(d, "out_fortran.nc"), os.path.join(d, "out_fortran_host.nc"))

@@ -3,11 +3,11 @@
 # destaggering, post-op and byte-swap kernel of one file-to-file run) -> gpurun_out/prof_job/.  Run through gpurun from the
 # repo root; the inputs are produced by tools/config4_file_job.py (C4JOB_KEEP=1 leaves them in /dev/shm/c4job).
 set -e
+trap 'rm -rf /dev/shm/c4job' EXIT   # gigabytes of inputs live in memory-backed /dev/shm: never leave them behind, whatever fails
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_job
 mkdir -p $OUT
 C4JOB_KEEP=1 python3 $REPO/tools/config4_file_job.py > $OUT/job.log 2>&1
 cd /dev/shm/c4job && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $REPO/mpassit_amd/fortran/mpassit namelist.input > $OUT/driver.log 2>&1
-rm -rf /dev/shm/c4job
 head -40 $OUT/stats/stats_kernel_stats.csv | cut -c1-160
