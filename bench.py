@@ -292,8 +292,9 @@ def main():
                 sr.rh.regrid_typed_host(hs, nlev=nlev, out=ho)
                 ts.append(time.perf_counter() - t0)
             e2e[name + "_fields_per_s"] = 1.0 / min(ts)
-        e2e["what"] = ("one 3-D field, host -> device -> host through mpg_regrid_typed (chunked upload / kernel / download), f64 or f32 on "
-                       "both sides of the link, float64 arithmetic; pageable host buffers")
+        e2e["what"] = ("one 3-D field, host -> device -> host through mpg_regrid_typed (chunked: upload and download as asynchronous copies "
+                       "on two streams from two threads = both PCIe directions at once; device slots kept between calls), f64 or f32 on both "
+                       "sides of the link, float64 arithmetic; pageable host buffers, reused across the repetitions")
 
     # The headline mesh numbers its cells row by row -- the best case for a cell-fast gather.  Beside it: the SAME 3.0 M cells
     # renumbered along a Morton curve (workload c4_3m_morton), what a production mesh reordered by a space-filling curve

@@ -52,6 +52,7 @@ int mpg_init(int device) {
 int mpg_finalize(void) {
   if (!g_init) return MPG_SUCCESS;
   mpg_fileio_release();
+  mpg_hostpipe_release();
   (void)hipStreamSynchronize(g_stream);
   (void)hipStreamDestroy(g_stream);
   g_stream = nullptr;

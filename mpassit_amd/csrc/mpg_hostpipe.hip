@@ -9,9 +9,16 @@
 //   * full duplex: the field is cut into chunks of levels (cell-fast) or fields; the calling thread uploads chunk c+1
 //     and launches its kernel while a helper thread downloads chunk c-1, three device slots in flight, so upload and
 //     download overlap instead of alternating.
-// Caller buffers are ordinary pageable memory (Fortran allocatables, numpy arrays); hipMemcpy stages them itself.
-// (Page-locking them for the call with hipHostRegister was measured: +5 % at best, not worth touching caller memory.)
+// Caller buffers are ordinary pageable memory (Fortran allocatables, numpy arrays).  What the link gives such a caller on
+// MI355X (tools/pcie_probe.hip, profiles/r02_pcie_probe.txt): 57 GB/s in one direction, and 90-93 GB/s in BOTH at once only
+// when the two directions are asynchronous copies on two separate non-blocking streams issued from two threads (blocking
+// hipMemcpy calls share the null stream and serialise: 57 GB/s in total, however many threads); page-locking the caller's
+// buffers first costs as much as the transfer itself (hipHostRegister: ~50 ms per GB), so they are left alone -- the
+// runtime pins a pageable range on first use and remembers it, repeated calls on the same buffers run at the pinned rate.
+// hipMalloc is expensive too (55-145 ms for the 2.2 GB of one float64 field), so the device slots, streams and the
+// download thread's stream are created once per process and reused by every call (released by mpg_finalize).
 #include <atomic>
+#include <mutex>
 #include <thread>
 
 #include "mpg_internal.h"
@@ -22,9 +29,56 @@ struct Chunk {
   int nlev, nfields;
 };
 constexpr int NSLOT = 3;
+
+// per-process transfer resources, grown on demand, reused by every mpg_regrid / mpg_regrid_typed call
+struct Pipe {
+  std::mutex mu;                       // one host-path Regrid at a time
+  hipStream_t s_up = nullptr, s_k = nullptr, s_down = nullptr;
+  char *dsrc[NSLOT] = {}, *ddst[NSLOT] = {};
+  size_t cap_s = 0, cap_d = 0;
+  int ensure(size_t need_s, size_t need_d) {
+    if (!s_up) MPG_HIP(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking));
+    if (!s_k) MPG_HIP(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+    if (!s_down) MPG_HIP(hipStreamCreateWithFlags(&s_down, hipStreamNonBlocking));
+    if (need_s > cap_s) {
+      for (int q = 0; q < NSLOT; ++q) {
+        if (dsrc[q]) (void)hipFree(dsrc[q]);
+        dsrc[q] = nullptr;
+      }
+      cap_s = 0;
+      for (int q = 0; q < NSLOT; ++q) MPG_HIP(hipMalloc((void **)&dsrc[q], need_s));
+      cap_s = need_s;
+    }
+    if (need_d > cap_d) {
+      for (int q = 0; q < NSLOT; ++q) {
+        if (ddst[q]) (void)hipFree(ddst[q]);
+        ddst[q] = nullptr;
+      }
+      cap_d = 0;
+      for (int q = 0; q < NSLOT; ++q) MPG_HIP(hipMalloc((void **)&ddst[q], need_d));
+      cap_d = need_d;
+    }
+    return MPG_SUCCESS;
+  }
+  void release() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (int q = 0; q < NSLOT; ++q) {
+      if (dsrc[q]) (void)hipFree(dsrc[q]);
+      if (ddst[q]) (void)hipFree(ddst[q]);
+      dsrc[q] = ddst[q] = nullptr;
+    }
+    cap_s = cap_d = 0;
+    if (s_up) (void)hipStreamDestroy(s_up);
+    if (s_k) (void)hipStreamDestroy(s_k);
+    if (s_down) (void)hipStreamDestroy(s_down);
+    s_up = s_k = s_down = nullptr;
+  }
+};
+Pipe g_pipe;
 }  // namespace
 
 int mpg_device_index();  // mpg_api.hip
+void mpg_hostpipe_release() { g_pipe.release(); }
 
 extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32, int src_layout, int nlev, int nfields, void *dst_host,
                                 int dst_f32, double scale, double offset) {
@@ -53,30 +107,25 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
     max_s = c.src_n > max_s ? c.src_n : max_s;
     max_d = c.dst_n > max_d ? c.dst_n : max_d;
   }
-  const int nslot = (int)plan.size() < NSLOT ? (int)plan.size() : NSLOT;
-  TmpBuf<char> dsrc[NSLOT], ddst[NSLOT];
-  int rc;
-  for (int q = 0; q < nslot; ++q)
-    if ((rc = dsrc[q].alloc(max_s * es + 16)) || (rc = ddst[q].alloc(max_d * ed + 16))) return rc;
-  struct Res {  // streams and events of one call, released on every exit path
-    hipStream_t s_up = nullptr, s_k = nullptr;
+  const int nslot = NSLOT;
+  std::lock_guard<std::mutex> pipe_lock(g_pipe.mu);
+  int rc = g_pipe.ensure(max_s * es + 16, max_d * ed + 16);
+  if (rc) return rc;
+  char *const *dsrc = g_pipe.dsrc, *const *ddst = g_pipe.ddst;
+  struct Res {  // events of one call, released on every exit path
     std::vector<hipEvent_t> up, done;
     ~Res() {
       for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
       for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
-      if (s_up) (void)hipStreamDestroy(s_up);
-      if (s_k) (void)hipStreamDestroy(s_k);
     }
   } res;
-  MPG_HIP(hipStreamCreateWithFlags(&res.s_up, hipStreamNonBlocking));
-  MPG_HIP(hipStreamCreateWithFlags(&res.s_k, hipStreamNonBlocking));
   res.up.assign(plan.size(), nullptr);
   res.done.assign(plan.size(), nullptr);
   for (size_t c = 0; c < plan.size(); ++c) {
     MPG_HIP(hipEventCreateWithFlags(&res.up[c], hipEventDisableTiming));
     MPG_HIP(hipEventCreateWithFlags(&res.done[c], hipEventDisableTiming));
   }
-  hipStream_t s_up = res.s_up, s_k = res.s_k;
+  hipStream_t s_up = g_pipe.s_up, s_k = g_pipe.s_k, s_down = g_pipe.s_down;
   std::vector<hipEvent_t> &up = res.up, &done = res.done;
   std::atomic<int> produced{0}, consumed{0}, err{0};
   const int dev = mpg_device_index();
@@ -87,8 +136,10 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
         if (err.load()) return;
         std::this_thread::yield();
       }
-      if (hipEventSynchronize(done[c]) != hipSuccess ||
-          hipMemcpy((char *)dst_host + plan[c].dst_off * ed, ddst[c % nslot].p, plan[c].dst_n * ed, hipMemcpyDeviceToHost) != hipSuccess) {
+      // asynchronous copy on the download stream of its own + wait: runs beside the uploads of s_up (two DMA directions at once)
+      if (hipStreamWaitEvent(s_down, done[c], 0) != hipSuccess ||
+          hipMemcpyAsync((char *)dst_host + plan[c].dst_off * ed, ddst[c % nslot], plan[c].dst_n * ed, hipMemcpyDeviceToHost, s_down) != hipSuccess ||
+          hipStreamSynchronize(s_down) != hipSuccess) {
         err = MPG_ERR_HIP;
         return;
       }
@@ -100,10 +151,10 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
     const int q = (int)(c % nslot);
     while ((int)c >= nslot && consumed.load(std::memory_order_acquire) <= (int)c - nslot && !err.load()) std::this_thread::yield();
     if (plan[c].src_n &&
-        hipMemcpyAsync(dsrc[q].p, (const char *)src_host + plan[c].src_off * es, plan[c].src_n * es, hipMemcpyHostToDevice, s_up) != hipSuccess)
+        hipMemcpyAsync(dsrc[q], (const char *)src_host + plan[c].src_off * es, plan[c].src_n * es, hipMemcpyHostToDevice, s_up) != hipSuccess)
       rc = MPG_ERR_HIP;
     if (!rc && (hipEventRecord(up[c], s_up) != hipSuccess || hipStreamWaitEvent(s_k, up[c], 0) != hipSuccess)) rc = MPG_ERR_HIP;
-    if (!rc) rc = mpg_k_apply_typed(h, dsrc[q].p, src_f32, src_layout, plan[c].nlev, plan[c].nfields, ddst[q].p, dst_f32, scale, offset, s_k);
+    if (!rc) rc = mpg_k_apply_typed(h, dsrc[q], src_f32, src_layout, plan[c].nlev, plan[c].nfields, ddst[q], dst_f32, scale, offset, s_k);
     if (!rc && hipEventRecord(done[c], s_k) != hipSuccess) rc = MPG_ERR_HIP;
     if (!rc) produced.store((int)c + 1, std::memory_order_release);
   }
@@ -112,6 +163,7 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
   if (!rc && err.load()) rc = err.load();
   (void)hipStreamSynchronize(s_k);
   (void)hipStreamSynchronize(s_up);
+  (void)hipStreamSynchronize(s_down);
   if (rc == MPG_ERR_HIP) mpg_set_error("mpg_regrid_typed: a HIP call of the transfer pipeline failed: %s", hipGetErrorString(hipGetLastError()));
   return rc;
 }
