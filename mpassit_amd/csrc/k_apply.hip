@@ -321,6 +321,11 @@ int mpg_k_tune(const char *key, int value) {
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "nn_variant")) {   // nearest-neighbour Store: 1 = wave-cooperative search, 0 = one thread per point
+    if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
+    mpg_set_nearest_variant(value);
+    return MPG_SUCCESS;
+  }
   if (!strcmp(key, "lfu_min_reuse_x10")) { mpg_lfu_set_min_reuse_x10(value); return MPG_SUCCESS; }
   if (!strcmp(key, "a3_staged")) {
     if (value < -2 || value >= mpg_cfu_num_variants()) return MPG_ERR_INVALID_ARG;

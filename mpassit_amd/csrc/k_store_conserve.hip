@@ -7,12 +7,13 @@
 // (i,j) (model_grid.F90:784-794,959-984).  Uncovered destination cells stay 0.
 //
 // MI355X-native formulation: source polygons are rasterised onto the destination cells through an
-// AABB pyramid over the CORNER points (same machinery as the bilinear rasteriser).  ONE clipping pass: every
-// source cell writes its overlaps to a private 16-slot list and bumps the destination cells' counters; a
-// rocPRIM scan turns the counters into CSR row offsets, a scatter pass moves the lists into place (source
-// cells with more than 16 overlaps -- polar cells under lat-lon slivers -- are clipped again, writing in
-// place), and every (short) row is sorted by source id so the stored matrix and the summation order are
-// deterministic.  Destination cell areas are computed once per Store, not per overlap.
+// AABB pyramid over the CORNER points (same machinery as the bilinear rasteriser), in two steps: (1) one thread per
+// source cell walks the pyramid and LISTS the destination cells that survive the box / bounding-sphere tests;
+// (2) one thread per (source cell, destination cell) PAIR clips it, both polygon buffers in LDS, and bumps the
+// destination cell's counter.  A rocPRIM scan turns the counters into CSR row offsets, a scatter pass moves the pairs
+// into place (source cells with more candidates than their list holds -- polar cells under lat-lon slivers -- are
+// clipped by one workgroup each, writing in place), and every (short) row is sorted by source id so the stored matrix
+// and the summation order are deterministic.  Destination cell areas are computed once per Store, not per overlap.
 // Clipping = Sutherland-Hodgman against the 4 great-circle half-spaces.
 #include <cstring>
 
@@ -63,12 +64,12 @@ __device__ double clip_area(int ns, const dv3 *src, const dv3 *quad) {
   return s > 0.0 ? s : 0.0;
 }
 
-// One clipping pass.  MODE 0 ("pairs"): every overlap (dst cell, area ratio) of source cell c goes to the cell's private
-// slot list tmp_dst/tmp_val[c*CONS_CAP ..] (cnt_src[c] counts ALL overlaps, also those beyond the capacity) and count[p]
-// is bumped; a rocPRIM scan turns count into CSR row offsets and k_conserve_scatter moves the lists into place.
-// MODE 1 ("overflow fill"): only the source cells whose overlaps did not fit (cnt_src[c] > CONS_CAP: e.g. a polar cell
-// under thousands of lat-lon slivers) are clipped a second time and write straight to rowptr[p] + cursor[p]++.
-#define CONS_CAP 16
+// The pyramid walk of one source cell.  MODE 3 ("candidates", one thread per source cell): every destination cell that
+// passes the box / bounding-sphere tests goes into the cell's slot list tmp_dst[c*CAND_CAP ..]; the pairs are clipped by
+// k_conserve_clip_pairs below.  A cell with more than CAND_CAP candidates (a polar cell under thousands of lat-lon
+// slivers) is handed to the cooperative passes instead: MODE 2 counts its overlaps per destination cell, MODE 1 ("overflow
+// fill") clips it again after the scan and writes straight to rowptr[p] + cursor[p]++ -- one WORKGROUP per such cell.
+#define CAND_CAP 24   // candidate destination cells per source cell kept by the candidate pass
 template <int MODE>
 __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
                                                          const double *__restrict__ vx, const double *__restrict__ vy,
@@ -79,11 +80,12 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          const int32_t *__restrict__ rowptr,
                                                          int32_t *__restrict__ col, double *__restrict__ val,
                                                          int32_t *__restrict__ cnt_src, int32_t *__restrict__ tmp_dst,
-                                                         double *__restrict__ tmp_val, int32_t *__restrict__ ovf,
-                                                         int32_t *__restrict__ n_ovf) {
-  // MODE 0: one thread per source cell.  MODE 1: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]); its threads
+                                                         int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
+                                                         uint8_t *__restrict__ flip) {
+  // MODE 3: one thread per source cell.  MODE 1 / 2: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]); its threads
   // share the cell's subtrees of the pyramid, so a polar cell under thousands of slivers is clipped by 128 lanes at once.
-  int64_t c = MODE != 0 ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  constexpr bool COOP = MODE == 1 || MODE == 2;
+  int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
   int found = 0;
   dv3 poly[CONS_MAXV];
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   __shared__ int q_nodes[2][CONS_QUEUE];
   __shared__ int q_n[2], q_over;
   int seed_lev = pyr.nlev - 1, nseed = 1, cur = 0;
-  if (MODE != 0) {
+  if (COOP) {
     if (threadIdx.x == 0) { q_nodes[0][0] = 0; q_n[0] = 1; q_over = 0; }
     __syncthreads();
     while (seed_lev > 1) {
@@ -147,8 +149,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
     }
     nseed = q_n[cur];
   }
-  for (int sk = MODE != 0 ? (int)threadIdx.x : 0; sk < nseed; sk += MODE != 0 ? (int)blockDim.x : 1) {
-  const int seed = MODE != 0 ? q_nodes[cur][sk] : 0;
+  for (int sk = COOP ? (int)threadIdx.x : 0; sk < nseed; sk += COOP ? (int)blockDim.x : 1) {
+  const int seed = COOP ? q_nodes[cur][sk] : 0;
   int sp = 0;
   stack[sp++] = (seed_lev << 26) | seed;
   while (sp > 0) {
@@ -191,18 +193,19 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
           double aq = qarea[p];   // signed area of the destination quad, computed once per grid (k_cell_areas)
           if (aq < 0.0) { dv3 t = q[1]; q[1] = q[3]; q[3] = t; aq = -aq; }
           if (!(aq > 0.0)) continue;
+          if (MODE == 3) {   // candidate pass: the pair (c, p) is clipped later by k_conserve_clip_pairs, one thread per PAIR
+            if (found == CAND_CAP) {
+              cnt_src[c] = CAND_CAP + 1;
+              ovf[atomicAdd(n_ovf, 1)] = (int32_t)c;
+              return;
+            }
+            tmp_dst[c * CAND_CAP + found] = (int32_t)p;
+            ++found;
+            continue;
+          }
           double ar = clip_area(n, poly, q);
           if (ar > 1e-14 * aq) {
-            if (MODE == 0) {
-              if (found == CONS_CAP) {  // does not fit: hand the whole cell to the cooperative passes and stop here
-                cnt_src[c] = CONS_CAP + 1;
-                ovf[atomicAdd(n_ovf, 1)] = (int32_t)c;
-                return;
-              }
-              tmp_dst[c * CONS_CAP + found] = (int32_t)p;
-              tmp_val[c * CONS_CAP + found] = ar / aq;
-              ++found;
-            } else if (MODE == 2) {
+            if (MODE == 2) {
               atomicAdd(&count[p], 1);
             } else {
               int slot = atomicAdd(&count[p], 1);
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
     }
   }
   }
-  if (MODE == 0) cnt_src[c] = found;
+  if (MODE == 3) cnt_src[c] = found;
+  if (MODE == 3 && flip) flip[c] = area < 0.0;
 }
 
 // signed area of every destination cell (corner order i,j -> i+1,j -> i+1,j+1 -> i,j+1), once per grid
@@ -254,33 +258,6 @@ __global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double
   qsph[3 * P + p] = r2 * (1.0 + 1e-9) + 1e-18;
 }
 
-// row lengths from the private lists (source cells that fitted)
-__global__ __launch_bounds__(256) void k_conserve_count_lists(int64_t nCells, const int32_t *__restrict__ cnt_src,
-                                                              const int32_t *__restrict__ tmp_dst, int32_t *__restrict__ count) {
-  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= nCells) return;
-  int n = cnt_src[c];
-  if (n > CONS_CAP) return;
-  for (int e = 0; e < n; ++e) atomicAdd(&count[tmp_dst[c * CONS_CAP + e]], 1);
-}
-
-// the private lists of the source cells that fitted -> CSR slots (cursor = the zeroed count array)
-__global__ __launch_bounds__(256) void k_conserve_scatter(int64_t nCells, const int32_t *__restrict__ cnt_src,
-                                                          const int32_t *__restrict__ tmp_dst, const double *__restrict__ tmp_val,
-                                                          const int32_t *__restrict__ rowptr, int32_t *__restrict__ cursor,
-                                                          int32_t *__restrict__ col, double *__restrict__ val) {
-  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= nCells) return;
-  int n = cnt_src[c];
-  if (n > CONS_CAP) return;  // handled by the overflow fill pass
-  for (int e = 0; e < n; ++e) {
-    int32_t p = tmp_dst[c * CONS_CAP + e];
-    int slot = atomicAdd(&cursor[p], 1);
-    col[rowptr[p] + slot] = (int32_t)c;
-    val[rowptr[p] + slot] = tmp_val[c * CONS_CAP + e];
-  }
-}
-
 __global__ __launch_bounds__(256) void k_csr_sort_rows(int64_t P, const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
                                                        double *__restrict__ val) {
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -298,6 +275,133 @@ __global__ __launch_bounds__(256) void k_csr_sort_rows(int64_t P, const int32_t 
     col[j + 1] = kc;
     val[j + 1] = kv;
   }
+}
+
+// ---- pair-parallel clipping ---------------------------------------------------------------------------------------------
+// Measured on C4 (tools/store_timing.py, round 2): of the 31 ms of the one-thread-per-source-cell pass, 24 ms were the
+// Sutherland-Hodgman clip -- its two polygon buffers are private arrays indexed at run time, i.e. scratch memory, ~200
+// vector-memory operations per clipped pair -- and 7 ms everything else.  So the pass is split: the traversal only LISTS
+// the candidate pairs (source cell, destination cell) that survive the box / bounding-sphere tests (k_conserve_raster<3>),
+// and one thread per PAIR clips it (balanced: no lane waits for a neighbour with more candidates) with both polygon
+// buffers in LDS, laid out [buffer][vertex][component][lane] so that any per-lane vertex index is conflict-free.
+// Same arithmetic in the same order as clip_area / clip_halfspace above -> bit-identical weights.
+__global__ __launch_bounds__(256) void k_conserve_clamp_counts(int64_t nCells, const int32_t *__restrict__ cnt_src, int32_t *__restrict__ npair) {
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c > nCells) return;
+  int n = c < nCells ? cnt_src[c] : 0;
+  npair[c] = n > CAND_CAP ? 0 : n;       // cells handed to the cooperative passes list no pairs
+}
+__global__ __launch_bounds__(256) void k_conserve_fill_pairs(int64_t nCells, const int32_t *__restrict__ npair, const int32_t *__restrict__ poff,
+                                                             const int32_t *__restrict__ tmp_dst, int32_t *__restrict__ pair_c,
+                                                             int32_t *__restrict__ pair_p) {
+  int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nCells) return;
+  const int n = npair[c], o = poff[c];
+  for (int e = 0; e < n; ++e) {
+    pair_c[o + e] = (int32_t)c;
+    pair_p[o + e] = tmp_dst[c * CAND_CAP + e];
+  }
+}
+
+#define CLIP_NT 64
+struct LdsPoly {   // vertex i of polygon buffer `buf` of this lane
+  double *base;    // lds + lane
+  int cb;
+  __device__ __forceinline__ dv3 get(int buf, int i) const {
+    const double *p = base + (size_t)((buf * cb + i) * 3) * CLIP_NT;
+    return dv3{p[0], p[CLIP_NT], p[2 * CLIP_NT]};
+  }
+  __device__ __forceinline__ void set(int buf, int i, dv3 v) const {
+    double *p = base + (size_t)((buf * cb + i) * 3) * CLIP_NT;
+    p[0] = v.x;
+    p[CLIP_NT] = v.y;
+    p[2 * CLIP_NT] = v.z;
+  }
+};
+// clip_halfspace with the buffers in LDS: the same operations in the same order (cap = CONS_BUF of the private version)
+__device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, int in, dv3 nrm, int out, int cap) {
+  int m = 0;
+  double eps = 1e-15 * sqrt(dot3(nrm, nrm));
+  for (int i = 0; i < n; ++i) {
+    dv3 X1 = L.get(in, i), X2 = L.get(in, (i + 1 == n) ? 0 : i + 1);
+    double d1 = dot3(nrm, X1), d2 = dot3(nrm, X2);
+    bool in1 = d1 >= -eps, in2 = d2 >= -eps;
+    if (in1 && m < cap) L.set(out, m++, X1);
+    if (in1 != in2 && m < cap) {
+      dv3 X = X1 * d2 - X2 * d1;
+      double sgn = (d2 - d1) > 0.0 ? 1.0 : -1.0;
+      double nn = sqrt(dot3(X, X));
+      if (nn > 0.0) L.set(out, m++, X * (sgn / nn));
+    }
+  }
+  return m;
+}
+__global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs, const int32_t *__restrict__ pair_c, const int32_t *__restrict__ pair_p,
+                                                                 int maxEdges, const int32_t *__restrict__ voc, const double *__restrict__ vx,
+                                                                 const double *__restrict__ vy, const double *__restrict__ vz,
+                                                                 const uint8_t *__restrict__ flip, int nx, const double *__restrict__ qx,
+                                                                 const double *__restrict__ qy, const double *__restrict__ qz,
+                                                                 const double *__restrict__ qarea, int cb, double *__restrict__ pair_val,
+                                                                 int32_t *__restrict__ count) {
+  extern __shared__ double clip_lds[];   // [2][cb][3][CLIP_NT]
+  const int64_t t = blockIdx.x * (int64_t)CLIP_NT + threadIdx.x;
+  if (t >= npairs) return;
+  const LdsPoly L{clip_lds + threadIdx.x, cb};
+  const int64_t c = pair_c[t], p = pair_p[t];
+  // the source polygon, counter-clockwise seen from outside (orientation decided once per cell by the candidate pass)
+  int n = 0;
+  for (int j = 0; j < maxEdges && n < CONS_MAXV; ++j) {
+    int32_t v = voc[c * maxEdges + j];
+    if (v > 0) L.set(0, n++, dv3{vx[v - 1], vy[v - 1], vz[v - 1]});
+  }
+  if (flip[c])
+    for (int i = 0; i < n / 2; ++i) {
+      dv3 a = L.get(0, i), b = L.get(0, n - 1 - i);
+      L.set(0, i, b);
+      L.set(0, n - 1 - i, a);
+    }
+  const int i = (int)(p % nx), j = (int)(p / nx), nxc = nx + 1;
+  const int64_t k00 = (int64_t)j * nxc + i;
+  dv3 q[4] = {dv3{qx[k00], qy[k00], qz[k00]}, dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
+              dv3{qx[k00 + nxc + 1], qy[k00 + nxc + 1], qz[k00 + nxc + 1]}, dv3{qx[k00 + nxc], qy[k00 + nxc], qz[k00 + nxc]}};
+  double aq = qarea[p];
+  if (aq < 0.0) { dv3 tq = q[1]; q[1] = q[3]; q[3] = tq; aq = -aq; }
+  double ar = 0.0;
+  if (aq > 0.0) {
+    int cur = 0;
+    for (int e = 0; e < 4 && n >= 3; ++e) {
+      const dv3 qa = e == 0 ? q[0] : e == 1 ? q[1] : e == 2 ? q[2] : q[3];
+      const dv3 qb = e == 0 ? q[1] : e == 1 ? q[2] : e == 2 ? q[3] : q[0];
+      dv3 side = qb - qa;
+      if (dot3(side, side) < 1e-24) continue;     // collapsed side (pole): bounds nothing
+      n = clip_halfspace_lds(n, L, cur, cross3(qa, qb), cur ^ 1, cb);
+      cur ^= 1;
+    }
+    if (n >= 3) {
+      double sa = 0.0;
+      const dv3 v0 = L.get(cur, 0);
+      for (int k = 1; k + 1 < n; ++k) sa += sph_tri_area(v0, L.get(cur, k), L.get(cur, k + 1));
+      ar = sa > 0.0 ? sa : 0.0;
+    }
+  }
+  double ratio = 0.0;
+  if (ar > 1e-14 * aq) {
+    ratio = ar / aq;
+    atomicAdd(&count[p], 1);
+  }
+  pair_val[t] = ratio;
+}
+__global__ __launch_bounds__(256) void k_conserve_scatter_pairs(int64_t npairs, const int32_t *__restrict__ pair_c, const int32_t *__restrict__ pair_p,
+                                                                const double *__restrict__ pair_val, const int32_t *__restrict__ rowptr,
+                                                                int32_t *__restrict__ cursor, int32_t *__restrict__ col, double *__restrict__ val) {
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= npairs) return;
+  const double r = pair_val[t];
+  if (!(r > 0.0)) return;
+  const int32_t p = pair_p[t];
+  const int slot = atomicAdd(&cursor[p], 1);
+  col[rowptr[p] + slot] = pair_c[t];
+  val[rowptr[p] + slot] = r;
 }
 
 int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStream_t s) {
@@ -320,35 +424,60 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   h->n_dst = P;
   h->nx_dst = nx;
   h->ny_dst = ny;
-  TmpBuf<int32_t> count, cnt_src, tmp_dst, ovf, n_ovf;
-  TmpBuf<double> tmp_val, qarea, qsph;
+  TmpBuf<int32_t> count, cnt_src, tmp_dst, ovf, n_ovf, npair, poff, pair_c, pair_p;
+  TmpBuf<double> qarea, qsph, pair_val;
+  TmpBuf<uint8_t> flip;
+  const int64_t nC = m->nCells;
   if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P)) || (rc = qsph.alloc(4 * (size_t)P)) ||
-      (rc = cnt_src.alloc((size_t)m->nCells)) || (rc = tmp_dst.alloc((size_t)m->nCells * CONS_CAP)) ||
-      (rc = tmp_val.alloc((size_t)m->nCells * CONS_CAP)) || (rc = ovf.alloc((size_t)m->nCells)) || (rc = n_ovf.alloc(1)))
+      (rc = cnt_src.alloc((size_t)nC)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP)) || (rc = ovf.alloc((size_t)nC)) || (rc = n_ovf.alloc(1)) ||
+      (rc = npair.alloc((size_t)nC + 1)) || (rc = poff.alloc((size_t)nC + 1)) || (rc = flip.alloc((size_t)nC)))
     return rc;
   MPG_HIP(hipMemsetAsync(n_ovf.p, 0, sizeof(int32_t), s));
-  MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)m->nCells, s));  // degenerate cells leave early
+  MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)nC, s));  // degenerate cells leave early
+  MPG_HIP(hipMemsetAsync(flip.p, 0, (size_t)nC, s));
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
-  unsigned nb = (unsigned)((m->nCells + 127) / 128);
+  unsigned nb = (unsigned)((nC + 127) / 128);
   PyramidView pv = mpg_pyr_view(g->cellpyr);
   k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
-  k_conserve_raster<0><<<nb, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
-                                        cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, nullptr, nullptr, nullptr, cnt_src.p, tmp_dst.p, tmp_val.p, ovf.p,
-                                        n_ovf.p);
+  // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
+  k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
+                                        qarea.p, qsph.p, nullptr, nullptr, nullptr, nullptr, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
   MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  k_conserve_count_lists<<<(unsigned)((m->nCells + 255) / 256), 256, 0, s>>>(m->nCells, cnt_src.p, tmp_dst.p, count.p);
-  MPG_HIP(hipStreamSynchronize(s));
-  if (novf > 0)  // MODE 2: cooperative count of the overflowed cells
-    k_conserve_raster<2><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, nullptr, nullptr, nullptr, cnt_src.p,
-                                                       nullptr, nullptr, ovf.p, nullptr);
-  MPG_HIP(hipGetLastError());
-  size_t tmp_bytes = 0;
-  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
+  // (2) pair list: offsets by scan, then (cell, destination) per pair
+  k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
+  size_t tmp_bytes = 0, b2 = 0;
+  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
+  MPG_HIP(rocprim::exclusive_scan(nullptr, b2, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
   TmpBuf<char> tmp;
-  if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
+  if ((rc = tmp.alloc((tmp_bytes > b2 ? tmp_bytes : b2) + 16))) return rc;
+  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
+  int32_t npairs = 0;
+  MPG_HIP(hipMemcpyAsync(&npairs, poff.p + nC, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  if (npairs < 0) {
+    mpg_set_error("conservative RegridStore: more than 2^31 candidate pairs");
+    return MPG_ERR_OVERFLOW;
+  }
+  if ((rc = pair_c.alloc((size_t)npairs + 1)) || (rc = pair_p.alloc((size_t)npairs + 1)) || (rc = pair_val.alloc((size_t)npairs + 1))) return rc;
+  k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
+  // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
+  // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12
+  const int cb = m->maxEdges + 6 < CONS_BUF ? m->maxEdges + 6 : CONS_BUF;
+  const size_t clip_lds_bytes = sizeof(double) * 2 * cb * 3 * CLIP_NT;
+  if (clip_lds_bytes > 48 * 1024)
+    MPG_HIP(hipFuncSetAttribute((const void *)k_conserve_clip_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clip_lds_bytes));
+  if (npairs > 0)
+    k_conserve_clip_pairs<<<(unsigned)(((int64_t)npairs + CLIP_NT - 1) / CLIP_NT), CLIP_NT, clip_lds_bytes, s>>>(
+        npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
+        pair_val.p, count.p);
+  if (novf > 0)  // MODE 2: cooperative count of the cells with more candidates than the lists hold (polar cells under slivers)
+    k_conserve_raster<2><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
+                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, nullptr, nullptr, nullptr, cnt_src.p,
+                                                       nullptr, ovf.p, nullptr, nullptr);
+  MPG_HIP(hipGetLastError());
+  tmp_bytes = b2;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
   int32_t nnz = 0;
   MPG_HIP(hipMemcpyAsync(&nnz, h->rowptr.p + P, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -360,13 +489,14 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   h->nnz = nnz;
   if ((rc = h->col.alloc((size_t)nnz + 1)) || (rc = h->val.alloc((size_t)nnz + 1))) return rc;
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
-  k_conserve_scatter<<<(unsigned)((m->nCells + 255) / 256), 256, 0, s>>>(m->nCells, cnt_src.p, tmp_dst.p, tmp_val.p, h->rowptr.p, count.p, h->col.p,
-                                                                        h->val.p);
-  // the few source cells with more than CONS_CAP overlaps are clipped again, one workgroup each, writing in place
+  if (npairs > 0)
+    k_conserve_scatter_pairs<<<(unsigned)(((int64_t)npairs + 255) / 256), 256, 0, s>>>(npairs, pair_c.p, pair_p.p, pair_val.p, h->rowptr.p, count.p,
+                                                                                      h->col.p, h->val.p);
+  // the few source cells with more than CAND_CAP candidates are clipped again, one workgroup each, writing in place
   if (novf > 0)
     k_conserve_raster<1><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
                                                        cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, h->rowptr.p, h->col.p, h->val.p,
-                                                       cnt_src.p, nullptr, nullptr, ovf.p, nullptr);
+                                                       cnt_src.p, nullptr, ovf.p, nullptr, nullptr);
   k_csr_sort_rows<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, h->rowptr.p, h->col.p, h->val.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));

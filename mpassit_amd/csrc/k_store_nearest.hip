@@ -128,6 +128,10 @@ int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s) {
   return MPG_SUCCESS;
 }
 
+static int g_nn_variant = 1;   // "nn_variant": 1 = wave-cooperative search (default), 0 = one thread per point
+int mpg_nearest_variant() { return g_nn_variant; }
+void mpg_set_nearest_variant(int v) { g_nn_variant = v; }
+
 #define NN_STACK 96
 __global__ __launch_bounds__(256) void k_nearest_query(int64_t P, const double *__restrict__ px, const double *__restrict__ py,
                                                        const double *__restrict__ pz, SiteBvhView b, int32_t *__restrict__ out) {
@@ -179,6 +183,79 @@ __global__ __launch_bounds__(256) void k_nearest_query(int64_t P, const double *
   out[p] = best_id;
 }
 
+// Wave-cooperative form of the same exact search.  A wavefront owns a patch of 8 x 8 neighbouring target points and walks
+// the BVH ONCE for all of them: one shared stack (LDS), every node box and every leaf site fetched with wave-uniform
+// (scalar) loads, each lane keeping its own (best, best_id) with the very comparisons of k_nearest_query.  A node is
+// opened when ANY lane's bound admits it (wavefront ballot); a lane whose bound does not admit it evaluates it anyway,
+// which cannot change its answer (every site in the box is at least as far as the box).  So the result is identical
+// to the one-thread-per-point search, but the per-lane private stacks, the divergent descents and the 64-fold
+// re-fetching of the same boxes are gone: neighbouring points share almost their whole search path.
+// Children are pushed so that the one nearest to the patch (smallest bound of the patch's first point) is popped first.
+#define NNW_STACK 128
+#define NNW_WAVES 4
+__global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int npy, const double *__restrict__ px,
+                                                                   const double *__restrict__ py, const double *__restrict__ pz,
+                                                                   SiteBvhView b, int32_t *__restrict__ out, int32_t *__restrict__ overflow) {
+  __shared__ int stk[NNW_WAVES][NNW_STACK];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nbx = (npx + 7) >> 3;
+  const int64_t patch = (int64_t)blockIdx.x * NNW_WAVES + wave;
+  const int64_t npatch = (int64_t)nbx * ((npy + 7) >> 3);
+  if (patch >= npatch) return;
+  const int i = (int)(patch % nbx) * 8 + (lane & 7), j = (int)(patch / nbx) * 8 + (lane >> 3);
+  const bool act = i < npx && j < npy;
+  const int64_t p = act ? (int64_t)j * npx + i : 0;
+  const double X = px[p], Y = py[p], Z = pz[p];
+  double best = act ? INFINITY : -1.0;      // an inactive lane admits nothing
+  int32_t best_id = 0x7fffffff;
+  int *st = stk[wave];
+  int sp = 0;
+  st[sp++] = (b.nlev - 1) << 27;
+  while (sp > 0) {
+    const int e = __builtin_amdgcn_readfirstlane(st[--sp]);
+    const int lev = e >> 27;
+    const int64_t node = e & ((1 << 27) - 1);
+    const double dbox = boxdist2_nofma(X, Y, Z, b.box + 6 * (b.off[lev] + node));
+    if (__ballot(!(dbox > best)) == 0) continue;     // equal bounds are explored: a tie with a lower id may hide inside
+    if (lev == 0) {
+      const int64_t e1 = min(b.n, (node + 1) * MPG_BVH_LEAF);
+      for (int64_t q = node * MPG_BVH_LEAF; q < e1; ++q) {
+        const double d = dist2_nofma(X, Y, Z, b.sx[q], b.sy[q], b.sz[q]);
+        const int32_t id = b.sid[q];
+        if (d < best || (d == best && id < best_id)) {
+          best = d;
+          best_id = id;
+        }
+      }
+    } else {
+      const int64_t c0 = node * MPG_BVH_FAN, c1 = min(b.nnodes[lev - 1], c0 + MPG_BVH_FAN);
+      double key[MPG_BVH_FAN];   // ordering key: the bound seen by the patch's first lane (uniform)
+      int ci[MPG_BVH_FAN];
+      int nc = 0;
+      for (int64_t c = c0; c < c1; ++c) {
+        const double d = boxdist2_nofma(X, Y, Z, b.box + 6 * (b.off[lev - 1] + c));
+        if (__ballot(!(d > best)) == 0) continue;
+        const double k0 = __builtin_bit_cast(double, ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(__builtin_bit_cast(unsigned long long, d) >> 32)) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(unsigned long long, d)));
+        int k = nc++;
+        while (k > 0 && key[k - 1] < k0) {
+          key[k] = key[k - 1];
+          ci[k] = ci[k - 1];
+          --k;
+        }
+        key[k] = k0;
+        ci[k] = (int)(c - c0);
+      }
+      if (sp + nc > NNW_STACK) {   // cannot happen (7 pushes per level, <= 12 levels); reported, never silently dropped
+        if (lane == 0) atomicOr(overflow, 1);
+        nc = NNW_STACK - sp;
+      }
+      for (int k = 0; k < nc; ++k) st[sp++] = ((lev - 1) << 27) | (int)(c0 + ci[k]);
+    }
+  }
+  if (act) out[p] = best_id;
+}
+
 int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s) {
   int rc;
   if ((rc = mpg_k_build_bvh(m, s))) return rc;
@@ -210,8 +287,25 @@ int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s 
   for (int i = 0; i < MPG_BVH_MAXLEV; ++i) v.nnodes[i] = b.nnodes[i];
   for (int i = 0; i <= MPG_BVH_MAXLEV; ++i) v.off[i] = b.off[i];
   v.box = b.box.p;
-  k_nearest_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p);
+  if (mpg_nearest_variant() == 0) {   // "nn_variant" knob 0: the one-thread-per-point search (kept as the cross-check of the tests)
+    k_nearest_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p);
+    MPG_HIP(hipGetLastError());
+    MPG_HIP(hipStreamSynchronize(s));
+    return MPG_SUCCESS;
+  }
+  TmpBuf<int32_t> ovf;
+  if ((rc = ovf.alloc(1))) return rc;
+  MPG_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
+  const int64_t npatch = (int64_t)((npx + 7) / 8) * ((npy + 7) / 8);
+  k_nearest_query_w<<<(unsigned)((npatch + NNW_WAVES - 1) / NNW_WAVES), 64 * NNW_WAVES, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p,
+                                                                                                ovf.p);
   MPG_HIP(hipGetLastError());
+  int32_t h_ovf = 0;
+  MPG_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
+  if (h_ovf) {
+    mpg_set_error("RegridStore(nearest): traversal stack of the wave-cooperative search overflowed");
+    return MPG_ERR_OVERFLOW;
+  }
   return MPG_SUCCESS;
 }

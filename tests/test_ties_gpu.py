@@ -77,3 +77,30 @@ def test_argument_limits(gpu_lib):
     assert lib.mpg_grid_create(C.c_int(50000), C.c_int(50000), C.c_int(0), one, one, None, None, None, None, None, None, C.byref(h)) == 2
     assert lib.mpg_regrid_store(None, C.c_int(0), None, C.c_int(0), C.c_int(0), C.byref(h)) == 2
     assert lib.mpg_handle_release(None) == 0                              # releasing nothing is fine (like ESMF on a null handle)
+
+
+@pytest.mark.parametrize("case", ["global", "regional", "latlon_global"])
+def test_wave_cooperative_search_equals_per_thread_search(gpu_lib, global_mesh, conus_grid_30km, regional_case, case):
+    """nn_variant 1 (default: one wavefront walks the BVH for a patch of 8 x 8 points, shared stack, ballot-pruned) against
+    nn_variant 0 (one thread per point, private stack): the same comparisons in every lane -> the same indices, ties
+    included, on ragged patches (grid sizes not multiples of 8), outside the mesh footprint and across the date line."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    if case == "global":
+        m, g = global_mesh, conus_grid_30km
+    elif case == "regional":
+        m, g = regional_case
+    else:
+        m, g = synth.icosahedral_mesh(5), tg.define_target_grid_params("lat-lon", 73, 37, stand_lon=-180.0, is_regional=False)
+    got = {}
+    try:
+        for v in (0, 1):
+            gpu_lib.tune("nn_variant", v)
+            mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)     # fresh objects: no cached handle
+            rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+            got[v] = rh.weights()[0][:, 0].copy()
+            rh.release()
+            mesh.destroy()
+            grid.destroy()
+    finally:
+        gpu_lib.tune("nn_variant", 1)
+    assert got[0].min() >= 0 and np.array_equal(got[0], got[1])
