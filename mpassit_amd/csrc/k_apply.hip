@@ -321,6 +321,7 @@ int mpg_k_tune(const char *key, int value) {
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "cfu_fields_per_wg")) { mpg_cfu_set_fields_per_wg(value); return MPG_SUCCESS; }
   if (!strcmp(key, "nn_variant")) {   // nearest-neighbour Store: 1 = wave-cooperative search, 0 = one thread per point
     if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
     mpg_set_nearest_variant(value);

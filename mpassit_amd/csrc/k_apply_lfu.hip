@@ -284,13 +284,20 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
   const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
-  const int f = lin / ntile;
+  // A workgroup serves `fpw` consecutive fields of its tile (packed into the upper half of `nfields` by the launcher): the
+  // bundle is stored [field][level][cell] / [field][level][point], so fields f0 .. f0+fpw-1 are simply fpw * nlev consecutive
+  // "levels" -- the chunk pipeline runs across the field boundaries, and the tile's list, ranks and weights are fetched
+  // once per fpw fields instead of once per field.
+  const int fpw = max(1, nfields >> 16), nf = nfields & 0xffff;
+  const int f = (int)(lin / ntile) * fpw;
+  const int nlev_all = nlev;
+  nlev = min(fpw, nf - f) * nlev_all;
   const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   LfuPoints<TXU, RPT> pts;
   pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, 1);
-  const double *sf = src + (int64_t)f * nlev * nsrc;
-  double *df = dst + (int64_t)f * nlev * P;
+  const double *sf = src + (int64_t)f * nlev_all * nsrc;
+  double *df = dst + (int64_t)f * nlev_all * P;
   int32_t cell[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
@@ -350,6 +357,8 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     // (compact tiles of 32 x 32, 16 x 64 and 32 x 16 points with the same 1024-cell capacity were measured in round 2 on C4,
     //  Morton-numbered C4, C2 and C5: 0-15 % slower than 64 x 8 / 64 x 16 everywhere, profiles/r02_sweep_cfu_compact.txt)
 };
+static int g_cfu_fpw = 1;   // "cfu_fields_per_wg": fields of a bundle served by one workgroup of the staged cell-fast kernel
+void mpg_cfu_set_fields_per_wg(int v) { g_cfu_fpw = v < 1 ? 1 : v; }
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
 static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16};
@@ -818,8 +827,14 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
     return MPG_ERR_UNSUPPORTED;
   }
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  v.fn<<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst,
-                                                              h->n_src, nlev, ntx, nty, nfields, (int)um);
+  if (nfields > 0xffff) {
+    mpg_set_error("Regrid: more than 65535 fields in one bundle");
+    return MPG_ERR_UNSUPPORTED;
+  }
+  const int fpw = g_cfu_fpw < nfields ? g_cfu_fpw : nfields;
+  const int ngroups = (nfields + fpw - 1) / fpw;
+  v.fn<<<(unsigned)ntx * nty * ngroups, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst,
+                                                              h->n_src, nlev, ntx, nty, nfields | (fpw << 16), (int)um);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

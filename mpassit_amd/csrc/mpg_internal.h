@@ -232,6 +232,7 @@ int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
 int mpg_lfu_num_variants();
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_cfu_num_variants();
+void mpg_cfu_set_fields_per_wg(int v);
 int mpg_a3_staged();  // current "a3_staged" knob
 int mpg_lf_variant(); // current "lf_variant" knob
 int mpg_k_apply3_lfr(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale, double offset,
