@@ -189,6 +189,11 @@ int mpg_dev_to_file(const char *path, int64_t offset, int64_t nbytes, const void
 int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream);
 int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream);
 int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream);
+/* The two reductions P_TOP is made of, for a host that holds only a block of the grid rows (one driver image per GPU):
+ * vmax = maxval(P_HYD) of the block, candmin = min of 0.8*P_HYD(top) over its columns with P_HYD(top) >= 10 (has_cand = 0
+ * when there is none).  P_TOP = min(max of the vmax, min of the candmin) over the blocks -- exact, independent of the split. */
+int mpg_post_ptop_parts_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *vmax_host, double *candmin_host, int *has_cand_host,
+                            void *hip_stream);
 
 /* ---- bring-your-own weights: the factorList / factorIndexList form of ESMF_FieldRegridStore (and of an
  * ESMF_RegridWeightGen file: S, col, row).  Builds a route handle that applies externally computed weights with the

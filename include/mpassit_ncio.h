@@ -71,6 +71,10 @@ int ncio_var_extent(ncio_file *f, int varid, int64_t rec, int64_t *offset, int64
 
 int ncio_close(ncio_file *f);                   /* writer: fills numrecs, flushes */
 
+/* two POSIX helpers for hosts that coordinate several driver images through marker files (sleep; atomic rename) */
+int ncio_msleep(int milliseconds);
+int ncio_rename(const char *from, const char *to);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,27 @@ int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, 
   return MPG_SUCCESS;
 }
 
+// the two reductions P_TOP is made of, for a host that holds only a block of the grid rows (one image per GPU): the
+// blocks' maxima and candidate minima combine exactly (max of maxima, min of minima), the result does not depend on the split
+int mpg_k_post_ptop_parts(const double *src, int nlev, int64_t P, double *vmax_host, double *candmin_host, int *has_cand_host, hipStream_t s) {
+  TmpBuf<unsigned long long> keys;
+  int rc;
+  if ((rc = keys.alloc(2))) return rc;
+  unsigned long long init[2] = {0ull, ~0ull}, out[2];
+  MPG_HIP(hipMemcpyAsync(keys.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  int64_t n = (int64_t)nlev * P;
+  unsigned nb = (unsigned)((n + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  k_post_ptop<<<nb, 256, 0, s>>>(src, nlev, P, keys.p);
+  MPG_HIP(hipGetLastError());
+  MPG_HIP(hipMemcpyAsync(out, keys.p, sizeof(out), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  *vmax_host = ord_val_host(out[0]);
+  *has_cand_host = out[1] != ~0ull;
+  *candmin_host = *has_cand_host ? ord_val_host(out[1]) : 0.0;
+  return MPG_SUCCESS;
+}
+
 int mpg_k_post_ptop(const double *src, int nlev, int64_t P, double *ptop_host, hipStream_t s) {
   TmpBuf<unsigned long long> keys;
   int rc;

@@ -724,4 +724,11 @@ int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *
   return mpg_k_post_ptop(p_hyd_dev, nlev, n_pts, ptop_host, (hipStream_t)hip_stream);
 }
 
+int mpg_post_ptop_parts_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *vmax_host, double *candmin_host, int *has_cand_host,
+                            void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(p_hyd_dev && vmax_host && candmin_host && has_cand_host && nlev >= 1 && n_pts >= 1, "mpg_post_ptop_parts_dev: bad argument");
+  return mpg_k_post_ptop_parts(p_hyd_dev, nlev, n_pts, vmax_host, candmin_host, has_cand_host, (hipStream_t)hip_stream);
+}
+
 }  // extern "C"

@@ -254,6 +254,7 @@ int mpg_k_bswap(void *buf, int64_t n, int elem_size, hipStream_t s);
 int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, hipStream_t s);
 int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, hipStream_t s);
 int mpg_k_post_ptop(const double *src, int nlev, int64_t P, double *ptop_host, hipStream_t s);
+int mpg_k_post_ptop_parts(const double *src, int nlev, int64_t P, double *vmax_host, double *candmin_host, int *has_cand_host, hipStream_t s);
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);

@@ -28,8 +28,56 @@ module program_setup
   real(dp) :: pole_lat = 90.0_dp, pole_lon = 0.0_dp
   character(len=500) :: map_proj_char = ""          ! program_setup.F90:172-187, model_grid.F90:1288-1295
   real(dp) :: dxkm, dykm, dlondeg, dlatdeg, known_lat, known_lon, known_x, known_y
+  ! One driver image per GPU (the reference's PETs, mpassit.F90:84-96): image `myrank` of `nranks` owns the target mass rows
+  ! j_lo..j_hi (the split of regDecomp=(/1,npets/), model_grid.F90:693, by para_range :2428-2441) and regrids rows
+  ! je_lo..je_hi -- its own plus one halo row each side, which the CENTER -> EDGE destaggering of its first / last row needs.
+  ! Every image reads the input files whole, like every rank of the reference (input_data.F90:645); no data moves between
+  ! the images.  Set by the launcher through MPASSIT_NRANKS / MPASSIT_RANK / MPASSIT_RUN_ID (tools/mpassit_ranks.py).
+  integer :: nranks = 1, myrank = 0, j_lo = 1, j_hi = 0, je_lo = 1, je_hi = 0, ny_ext = 0
+  character(len=64) :: run_id = "0"
 
 contains
+
+  !> model_grid.F90:2428-2441: inclusive 1-based block [ista, iend] of rank irank
+  subroutine para_range(n1, n2, nprocs, irank, ista, iend)
+    integer, intent(in) :: n1, n2, nprocs, irank
+    integer, intent(out) :: ista, iend
+    integer :: iwork1, iwork2
+    iwork1 = (n2 - n1 + 1)/nprocs
+    iwork2 = mod(n2 - n1 + 1, nprocs)
+    ista = irank*iwork1 + n1 + min(irank, iwork2)
+    iend = ista + iwork1 - 1
+    if (iwork2 > irank) iend = iend + 1
+  end subroutine para_range
+
+  subroutine setup_ranks()
+    character(len=64) :: buf
+    integer :: ios
+    call get_environment_variable("MPASSIT_NRANKS", buf)
+    if (len_trim(buf) > 0) then
+      read (buf, *, iostat=ios) nranks
+      if (ios /= 0 .or. nranks < 1) call fatal("MPASSIT_NRANKS must be a positive integer", ios)
+    end if
+    call get_environment_variable("MPASSIT_RANK", buf)
+    if (len_trim(buf) > 0) then
+      read (buf, *, iostat=ios) myrank
+      if (ios /= 0 .or. myrank < 0 .or. myrank >= nranks) call fatal("MPASSIT_RANK must lie in 0 .. MPASSIT_NRANKS-1", ios)
+    end if
+    call get_environment_variable("MPASSIT_RUN_ID", buf)
+    if (len_trim(buf) > 0) run_id = buf
+  end subroutine setup_ranks
+
+  !> row blocks once the target grid's size is known
+  subroutine setup_row_block()
+    if (nranks > j_target) call fatal("more driver images than target rows", nranks)
+    call para_range(1, j_target, nranks, myrank, j_lo, j_hi)
+    je_lo = max(j_lo - 1, 1)
+    je_hi = min(j_hi + 1, j_target)
+    if (nranks == 1) then
+      je_lo = 1; je_hi = j_target
+    end if
+    ny_ext = je_hi - je_lo + 1
+  end subroutine setup_row_block
 
   subroutine fatal(msg, code)
     character(len=*), intent(in) :: msg
@@ -172,6 +220,7 @@ contains
     type(c_ptr), intent(out) :: grid_h
     type(mpg_proj) :: p
     integer(c_int) :: flags
+    real(dp), allocatable :: lat_c(:, :), lon_c(:, :)
     p%code = int(proj_code, c_int)                           ! the arguments of map_set (model_grid.F90:676-678)
     p%known_lat = known_lat; p%known_lon = known_lon; p%known_x = known_x; p%known_y = known_y
     p%dx_m = 0.0_dp; p%stand_lon = 0.0_dp; p%truelat1 = 0.0_dp; p%truelat2 = 0.0_dp; p%dlat_deg = 0.0_dp; p%dlon_deg = 0.0_dp
@@ -196,7 +245,31 @@ contains
       allocate (cosa(i_target, j_target), sina(i_target, j_target))
       call mpg_check(mpg_grid_get_rotang(grid_h, cosa, sina), "IN get_rotang")
     end if
+    call setup_row_block()
+    if (nranks > 1) then
+      allocate (lat_c(i_target + 1, j_target + 1), lon_c(i_target + 1, j_target + 1))
+      call mpg_check(mpg_grid_get_coords(grid_h, MPG_STAGGERLOC_CORNER, lon_c, lat_c), "IN GridGetCoord")
+      call mpg_check(mpg_grid_destroy(grid_h), "IN GridDestroy")
+      call create_row_block_grid(lat_c, lon_c, grid_h)
+    end if
   end subroutine define_target_grid_params
+
+  !> the grid object of this image's row block je_lo..je_hi, from the rows of the full coordinate arrays (the same numbers
+  !! the single-image run regrids to, so the results are the same bits); a global grid keeps only the pole caps it touches
+  subroutine create_row_block_grid(lat_c, lon_c, grid_h)
+    real(dp), intent(in) :: lat_c(:, :), lon_c(:, :)
+    type(c_ptr), intent(out) :: grid_h
+    integer(c_int) :: flags
+    flags = 0
+    if (.not. is_regional) then
+      flags = MPG_GRID_PERIODIC_I
+      if (je_lo > 1) flags = ior(flags, MPG_GRID_NO_SOUTH_POLE)
+      if (je_hi < j_target) flags = ior(flags, MPG_GRID_NO_NORTH_POLE)
+    end if
+    call mpg_check(mpg_grid_create(int(i_target, c_int), int(ny_ext, c_int), flags, lon_m(:, je_lo:je_hi), lat_m(:, je_lo:je_hi), &
+                                   lon_c(:, je_lo:je_hi + 1), lat_c(:, je_lo:je_hi + 1), lon_u(:, je_lo:je_hi), lat_u(:, je_lo:je_hi), &
+                                   lon_v(:, je_lo:je_hi + 1), lat_v(:, je_lo:je_hi + 1), grid_h), "IN GridCreate (row block)")
+  end subroutine create_row_block_grid
 
   !> target_grid_type = 'file' (define_target_grid_file, model_grid.F90:1203-1888): dimensions, projection attributes,
   !! XLONG|XLONG_M, XLAT|XLAT_M, the U / V staggers, MAPFAC_M/U/V and (Lambert) SINALPHA / COSALPHA come from a WRF
@@ -242,8 +315,13 @@ contains
     end if
     call ncio_check(ncio_close(nf), "closing "//trim(file_target_grid))
     call get_cell_corners(lat_m, lon_m, lat_c, lon_c)
-    call mpg_check(mpg_grid_create(int(i_target, c_int), int(j_target, c_int), 0_c_int, lon_m, lat_m, lon_c, lat_c, &
-                                   lon_u, lat_u, lon_v, lat_v, grid_h), "IN GridCreate")
+    call setup_row_block()
+    if (nranks > 1) then
+      call create_row_block_grid(lat_c, lon_c, grid_h)
+    else
+      call mpg_check(mpg_grid_create(int(i_target, c_int), int(j_target, c_int), 0_c_int, lon_m, lat_m, lon_c, lat_c, &
+                                     lon_u, lat_u, lon_v, lat_v, grid_h), "IN GridCreate")
+    end if
   contains
     subroutine get2(name, alt, a, n1, n2)
       character(len=*), intent(in) :: name, alt

@@ -72,7 +72,7 @@ module interp
   use, intrinsic :: iso_c_binding
   use mpg
   use model_data
-  use program_setup, only: dp, interp_diag, interp_hist, proj_code, PROJ_LC, i_target, j_target, wrf_mod_vars
+  use program_setup, only: dp, interp_diag, interp_hist, proj_code, PROJ_LC, i_target, j_target, wrf_mod_vars, je_lo, je_hi, ny_ext
   use target_grid, only: cosa, sina
   implicit none
   private
@@ -273,12 +273,12 @@ contains
     type(field_t), intent(inout) :: u, v
     integer(c_int64_t) :: npts
     if (dev_flow) then
-      npts = int(i_target, c_int64_t)*int(j_target, c_int64_t)
+      npts = int(i_target, c_int64_t)*int(ny_ext, c_int64_t)  ! this image's row block (all rows with one image)
       if (.not. c_associated(cosa_dev)) then                    ! the rotation angles go up once
         call mpg_check(mpg_dev_alloc(npts*8, cosa_dev), "IN dev_alloc")
         call mpg_check(mpg_dev_alloc(npts*8, sina_dev), "IN dev_alloc")
-        call mpg_check(mpg_dev_upload(cosa_dev, cosa, npts*8), "IN dev_upload")
-        call mpg_check(mpg_dev_upload(sina_dev, sina, npts*8), "IN dev_upload")
+        call mpg_check(mpg_dev_upload(cosa_dev, cosa(:, je_lo:je_hi), npts*8), "IN dev_upload")
+        call mpg_check(mpg_dev_upload(sina_dev, sina(:, je_lo:je_hi), npts*8), "IN dev_upload")
       end if
       call mpg_check(mpg_rotate_winds_dev(npts, int(u%nlev, c_int), cosa_dev, sina_dev, u%dst_dev, v%dst_dev, c_null_ptr), &
                      "IN rotate_winds_cgrid")

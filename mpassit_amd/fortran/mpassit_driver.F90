@@ -26,7 +26,7 @@ program mpassit
   character(len=19) :: valid_time = "0000-00-00_00:00:00"
   logical :: nc_in = .false.
   type(c_ptr) :: nf_in = c_null_ptr
-  integer :: nargs
+  integer :: nargs, gpu
   character(len=16) :: envbuf
   integer(int64) :: clk0, clk_prev, clk_now, clk_rate
 
@@ -40,12 +40,18 @@ program mpassit
   clk_prev = clk0
   print *, "- READ SETUP NAMELIST"
   call read_setup_namelist(trim(nml_file))
+  call setup_ranks()
+  if (nranks > 1) print '(a,i0,a,i0)', " - DRIVER IMAGE ", myrank, " OF ", nranks
   f32_out = is_nc_name(output_file)
   call get_environment_variable("MPASSIT_HOST_ARRAYS", envbuf)
   dev_flow = f32_out .and. len_trim(envbuf) == 0 .and. nc_is_netcdf(grid_file_input_grid) .and. &
              (.not. interp_hist .or. nc_is_netcdf(hist_file_input_grid)) .and. (.not. interp_diag .or. nc_is_netcdf(diag_file_input_grid))
   if (dev_flow) print *, "- NETCDF IN AND OUT: FIELDS STAY ON THE DEVICE BETWEEN THE FILES"
-  call mpg_check(mpg_init(0_c_int), "INITIALIZING GPU RUNTIME")
+  ! one image per GPU: MPASSIT_DEVICE (set by the launcher: rank modulo the GPUs of the node), else device 0
+  call get_environment_variable("MPASSIT_DEVICE", envbuf)
+  gpu = 0
+  if (len_trim(envbuf) > 0) read (envbuf, *) gpu
+  call mpg_check(mpg_init(int(gpu, c_int)), "INITIALIZING GPU RUNTIME")
   call lap("SETUP + GPU RUNTIME")
   print *, "- DEFINE TARGET GRID"
   call define_target_grid()

@@ -204,6 +204,15 @@ module mpg
       real(c_double), intent(out) :: ptop
       integer(c_int) :: rc
     end function mpg_post_ptop_dev
+    function mpg_post_ptop_parts_dev(p_hyd, nlev, npts, vmax, candmin, has_cand, stream) bind(C, name="mpg_post_ptop_parts_dev") result(rc)
+      import :: c_int, c_int64_t, c_double, c_ptr
+      type(c_ptr), value :: p_hyd, stream
+      integer(c_int), value :: nlev
+      integer(c_int64_t), value :: npts
+      real(c_double), intent(out) :: vmax, candmin
+      integer(c_int), intent(out) :: has_cand
+      integer(c_int) :: rc
+    end function mpg_post_ptop_parts_dev
 
     function mpg_handle_release(rh) bind(C, name="mpg_handle_release") result(rc)
       import :: c_int, c_ptr

@@ -29,6 +29,9 @@ module ncfiles
   character(len=500) :: out_path = ""
   real(dp) :: put_seconds = 0.0_dp             ! wall time inside ncio_put_var (the rest of WRITE DATA is host post-ops)
   integer(c_int) :: d_time, d_we, d_wes, d_sn, d_sns, d_bt, d_bts, d_soil, d_str
+  real(dp) :: ptop_vmax = 0.0_dp, ptop_cmin = 0.0_dp       ! this image's reductions for P_TOP (several images)
+  integer(c_int) :: ptop_has = 0
+  logical :: have_ptop_parts = .false.
 
 contains
 
@@ -222,6 +225,10 @@ contains
     integer, intent(in) :: nlev, stag            ! stag: 0 mass, 1 U (west_east_stag), 2 V (south_north_stag)
     integer(c_int), intent(out) :: id
     integer(c_int) :: dx, dy, dz
+    if (myrank > 0) then                          ! the header is image 0's; the others only need the variable's id
+      call ncio_check(ncio_inq_varid(nf_out, name, id), "LOCATING "//trim(name))
+      return
+    end if
     dx = merge(d_wes, d_we, stag == 1)
     dy = merge(d_sns, d_sn, stag == 2)
     if (nlev == 1) then
@@ -258,54 +265,85 @@ contains
   subroutine put_zero(id)
     integer(c_int), intent(in) :: id
     integer(c_int64_t) :: off, nb
+    if (myrank > 0) return
     call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
   end subroutine put_zero
 
-  !> device flow: n float32 values in HBM -> the variable's byte range (byte order turned on the GPU first unless the
-  !! buffer already holds big-endian values from an earlier put)
-  subroutine put_dev(id, ptr, n, swap)
+  !> device flow: a float32 field [nlev][rows][nxv] in HBM -> the variable's byte range (byte order turned on the GPU first
+  !! unless the buffer already holds big-endian values from an earlier put).  With one image the buffer IS the variable; with
+  !! several it holds this image's row block je_lo..je_hi (+1 row on the V stagger) and the owned rows j_lo..j_hi of every
+  !! level go to their place in the variable (the last image also owns the top V row).
+  subroutine put_dev(id, ptr, nlev, stag, swap)
     integer(c_int), intent(in) :: id
     type(c_ptr), intent(in) :: ptr
-    integer(c_int64_t), intent(in) :: n
+    integer, intent(in) :: nlev, stag
     logical, intent(in) :: swap
-    integer(c_int64_t) :: off, nb
+    integer(c_int64_t) :: off, nb, n, nxv, ny_buf, ny_glob, jb0, jg0, nrows, k
     integer(int64) :: c0, c1, cr
     call system_clock(c0, cr)
+    nxv = i_target + merge(1, 0, stag == 1)
+    ny_buf = ny_ext + merge(1, 0, stag == 2)
+    n = int(nlev, c_int64_t)*ny_buf*nxv
     if (swap) call mpg_check(mpg_bswap_dev(ptr, n, 4_c_int, c_null_ptr), "IN bswap")
     call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
-    if (n*4 > nb) call fatal("put_dev: field larger than its variable", int(id))
-    call mpg_check(mpg_dev_to_file(trim(out_path), off, n*4, ptr), "WRITING RECORD")
+    if (nranks == 1) then
+      if (n*4 > nb) call fatal("put_dev: field larger than its variable", int(id))
+      call mpg_check(mpg_dev_to_file(trim(out_path), off, n*4, ptr), "WRITING RECORD")
+    else
+      ny_glob = j_target + merge(1, 0, stag == 2)
+      jb0 = j_lo - je_lo
+      jg0 = j_lo - 1
+      nrows = j_hi - j_lo + 1
+      if (stag == 2 .and. myrank == nranks - 1) nrows = nrows + 1
+      if (((nlev - 1)*ny_glob + jg0 + nrows)*nxv*4 > nb) call fatal("put_dev: rows beyond the variable", int(id))
+      do k = 0, nlev - 1
+        call mpg_check(mpg_dev_to_file(trim(out_path), off + ((k*ny_glob + jg0)*nxv)*4, nrows*nxv*4, &
+                                       ptr_add(ptr, ((k*ny_buf + jb0)*nxv)*4)), "WRITING RECORD")
+      end do
+    end if
     call system_clock(c1)
     put_seconds = put_seconds + real(c1 - c0, dp)/real(cr, dp)
   end subroutine put_dev
+
+  type(c_ptr) function ptr_add(p, nbytes)
+    type(c_ptr), intent(in) :: p
+    integer(c_int64_t), intent(in) :: nbytes
+    ptr_add = transfer(transfer(p, 0_c_intptr_t) + int(nbytes, c_intptr_t), p)
+  end function ptr_add
 
   !> one target field of the device flow with the writer's post-ops as device epilogues (write_data.F90:1339-1475)
   subroutine write_field_dev(p, id, id_extra, id_ptop, npts)
     type(field_t), intent(inout) :: p
     integer(c_int), intent(in) :: id, id_extra(8), id_ptop
-    integer, intent(in) :: npts
+    integer, intent(in) :: npts                   ! points of this image's row block on the mass stagger
     type(c_ptr) :: tmp
     real(dp) :: ptop
     integer(c_int64_t) :: n
     n = p%n_dst_elems
     if (p%dst_is_f32) then
-      call put_dev(id, p%dst_dev, n, .true.)
+      call put_dev(id, p%dst_dev, p%nlev, p%stagger, .true.)
     else
       call mpg_check(mpg_dev_alloc(n*4, tmp), "IN dev_alloc")
       if (trim(p%tname) == 'PHB') then
         call mpg_check(mpg_post_layer_mean_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), tmp, c_null_ptr), "IN Z_C")   ! :1406-1415
-        call put_dev(id_extra(3), tmp, int(npts, c_int64_t)*(p%nlev - 1), .true.)
+        call put_dev(id_extra(3), tmp, p%nlev - 1, 0, .true.)
         call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 9.81_c_double, 0.0_c_double, tmp, c_null_ptr), "IN PHB*9.81")              ! :1418
-        call put_dev(id, tmp, n, .true.)
+        call put_dev(id, tmp, p%nlev, p%stagger, .true.)
         if (wrf_mod_vars) call put_zero(id_extra(4))
       else
         if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') then                                                                    ! :1362-1379
-          call mpg_check(mpg_post_ptop_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), ptop, c_null_ptr), "IN P_TOP")
-          call ncio_check(ncio_put_var(nf_out, id_ptop, 0_c_int64_t, NCIO_DOUBLE, [ptop]), "WRITING P_TOP")
+          if (nranks == 1) then
+            call mpg_check(mpg_post_ptop_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), ptop, c_null_ptr), "IN P_TOP")
+            call ncio_check(ncio_put_var(nf_out, id_ptop, 0_c_int64_t, NCIO_DOUBLE, [ptop]), "WRITING P_TOP")
+          else   ! the block's two reductions; image 0 combines them once every image has reported (finish_ranks)
+            call mpg_check(mpg_post_ptop_parts_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), ptop_vmax, ptop_cmin, ptop_has, &
+                                                   c_null_ptr), "IN P_TOP")
+            have_ptop_parts = .true.
+          end if
         end if
         call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 1.0_c_double, 0.0_c_double, tmp, c_null_ptr), "IN cast")
-        call put_dev(id, tmp, n, .true.)
-        if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') call put_dev(id_extra(2), tmp, n, .false.)                              ! PB = P_HYD
+        call put_dev(id, tmp, p%nlev, p%stagger, .true.)
+        if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') call put_dev(id_extra(2), tmp, p%nlev, p%stagger, .false.)              ! PB = P_HYD
       end if
       call mpg_check(mpg_dev_free(tmp), "IN dev_free")
     end if
@@ -313,6 +351,108 @@ contains
     call mpg_check(mpg_dev_free(p%dst_dev), "IN dev_free")
     p%dst_dev = c_null_ptr
   end subroutine write_field_dev
+
+  ! ---- several driver images, one output file -----------------------------------------------------------------------
+  ! Image 0 creates the file, writes the header, the grid and time variables and its own rows, closes it and raises
+  ! <output>.<run id>.ready; the other images (which have regridded their blocks meanwhile) then write their rows straight
+  ! into the variables' byte ranges and report <output>.<run id>.done.<rank> with their two P_TOP reductions; image 0 waits
+  ! for all of them, stores P_TOP and removes the marker files.  No data moves between the images.
+  function marker_name(kind, rank) result(name)
+    character(len=*), intent(in) :: kind
+    integer, intent(in) :: rank
+    character(len=600) :: name
+    if (rank >= 0) then
+      write (name, '(a,".",a,".",a,".",i0)') trim(out_path), trim(run_id), kind, rank
+    else
+      write (name, '(a,".",a,".",a)') trim(out_path), trim(run_id), kind
+    end if
+  end function marker_name
+
+  subroutine wait_for(file)
+    character(len=*), intent(in) :: file
+    logical :: there
+    integer(int64) :: c0, c1, cr
+    call system_clock(c0, cr)
+    do
+      inquire (file=trim(file), exist=there)
+      if (there) exit
+      call system_clock(c1)
+      if (real(c1 - c0, dp)/real(cr, dp) > 1800.0_dp) call fatal("timed out waiting for "//trim(file), -1)
+      if (ncio_msleep(2_c_int) /= 0) exit
+    end do
+  end subroutine wait_for
+
+  subroutine write_marker(file, vals)
+    character(len=*), intent(in) :: file
+    real(dp), intent(in) :: vals(:)
+    integer :: u
+    ! written under a temporary name and renamed: a reader never sees a half-written marker
+    open (newunit=u, file=trim(file)//".tmp", form='formatted', status='replace', action='write')
+    write (u, '(4es26.17e3)') vals
+    close (u)
+    call rename_file(trim(file)//".tmp", trim(file))
+  end subroutine write_marker
+
+  subroutine rename_file(a, b)
+    character(len=*), intent(in) :: a, b
+    if (ncio_rename(a, b) /= 0) call fatal("renaming "//a, -1)
+  end subroutine rename_file
+
+  subroutine remove_file(file)
+    character(len=*), intent(in) :: file
+    integer :: u, ios
+    open (newunit=u, file=trim(file), status='old', iostat=ios)
+    if (ios == 0) close (u, status='delete')
+  end subroutine remove_file
+
+  !> after this image's rows are in the file
+  subroutine finish_ranks(id_ptop_var, have_ptop)
+    integer(c_int), intent(in) :: id_ptop_var
+    logical, intent(in) :: have_ptop
+    real(dp) :: vals(3), vmax, cmin
+    logical :: any_c
+    integer :: r, u
+    integer(c_int64_t) :: off, nb
+    integer(c_int8_t) :: b4(4)
+    real(c_float) :: ptop4
+    type(c_ptr) :: nf_r
+    if (myrank > 0) then
+      call write_marker(marker_name("done", myrank), [ptop_vmax, ptop_cmin, real(ptop_has, dp)])
+      return
+    end if
+    vmax = ptop_vmax; cmin = ptop_cmin; any_c = ptop_has /= 0
+    do r = 1, nranks - 1
+      call wait_for(marker_name("done", r))
+      open (newunit=u, file=trim(marker_name("done", r)), form='formatted', status='old', action='read')
+      read (u, *) vals
+      close (u)
+      vmax = max(vmax, vals(1))
+      if (vals(3) /= 0.0_dp) then
+        if (any_c) then
+          cmin = min(cmin, vals(2))
+        else
+          cmin = vals(2)
+        end if
+        any_c = .true.
+      end if
+    end do
+    if (have_ptop .and. have_ptop_parts) then      ! write_data.F90:1362-1371 on the combined reductions
+      ptop4 = real(vmax, c_float)
+      if (any_c) ptop4 = real(min(vmax, cmin), c_float)
+      call ncio_check(ncio_open(trim(out_path), nf_r), "reopening "//trim(out_path))
+      call ncio_check(ncio_var_extent(nf_r, id_ptop_var, 0_c_int64_t, off, nb), "locating P_TOP")
+      call ncio_check(ncio_close(nf_r), "closing "//trim(out_path))
+      b4 = transfer(ptop4, b4)
+      b4 = b4(4:1:-1)                              ! NetCDF classic stores big-endian
+      open (newunit=u, file=trim(out_path), access='stream', form='unformatted', status='old', action='readwrite')
+      write (u, pos=off + 1) b4
+      close (u)
+    end if
+    do r = 1, nranks - 1
+      call remove_file(marker_name("done", r))
+    end do
+    call remove_file(marker_name("ready", -1))
+  end subroutine finish_ranks
 
   subroutine put_r4(id, a)
     integer(c_int), intent(in) :: id
@@ -364,6 +504,13 @@ contains
     if (hist_soil%n > 0) nsoil_input = hist_soil%f(1)%nlev
     nsoil_input = max(nsoil_input, 1)
     out_path = file
+    if (nranks > 1 .and. .not. dev_flow) call fatal("several driver images need NetCDF in and out (the device-resident flow)", nranks)
+    if (myrank > 0) then
+      ! image 0 has created the file, written header, grid and time variables and its own rows, and closed it
+      call wait_for(marker_name("ready", -1))
+      call ncio_check(ncio_open(trim(file), nf_out), "opening "//trim(file))
+    else
+      call remove_file(marker_name("ready", -1))
     call ncio_check(ncio_create(file, 5, nf_out), "CREATING FILE "//trim(file))
     call ncio_check(ncio_def_dim(nf_out, "Time", 0, d_time), "DEFINING Time")                    ! write_data.F90:177-194
     call ncio_check(ncio_def_dim(nf_out, "west_east", i_target, d_we), "DEFINING west_east")
@@ -413,6 +560,7 @@ contains
     call gatt_i("SOUTH-NORTH_PATCH_END_STAG", j_target + 1)
     call gatt_i("BOTTOM-TOP_PATCH_END_UNSTAG", nz_input)
     call gatt_i("BOTTOM-TOP_PATCH_END_STAG", nz_input + 1)
+    end if
     ! grid variables (:312-476): XLONG, XLAT on the three staggers, SINALPHA / COSALPHA for Lambert
     call def_field("XLONG", 1, 0, id_grid(1)); call def_field("XLAT", 1, 0, id_grid(2))
     call def_field("XLONG_U", 1, 1, id_grid(3)); call def_field("XLAT_U", 1, 1, id_grid(4))
@@ -421,6 +569,7 @@ contains
       call def_field("SINALPHA", 1, 0, id_grid(7)); call def_field("COSALPHA", 1, 0, id_grid(8))
     end if
     call def_field("MAPFAC_M", 1, 0, id_mf(1)); call def_field("MAPFAC_U", 1, 1, id_mf(2)); call def_field("MAPFAC_V", 1, 2, id_mf(3))
+    if (myrank == 0) then
     call ncio_check(ncio_def_var(nf_out, "ZS", NCIO_FLOAT, [d_time, d_soil], id_zs), "DEFINING ZS")
     call ncio_check(ncio_def_var(nf_out, "Times", NCIO_CHAR, [d_time, d_str], id_times), "DEFINING Times")          ! :522-534
     call ncio_check(ncio_put_att_text(nf_out, id_times, "description", "Times"), "DEFINING Times NAME")
@@ -440,6 +589,7 @@ contains
     call ncio_check(ncio_put_att_text(nf_out, id_xtime, "stagger", ""), "DEFINING STAGGER")
     call ncio_check(ncio_put_att_int(nf_out, id_xtime, "FieldType", 104), "DEFINING FieldType")
     call ncio_check(ncio_put_att_text(nf_out, id_xtime, "MemoryOrder", "O "), "DEFINING MemoryOrder")
+    end if
     ! target fields in the writer's order (:1150-1475)
     call collect(fl, nv)
     if (nv > MAXV) call fatal("too many output variables", nv)
@@ -449,7 +599,11 @@ contains
       call def_field(trim(fl(i)%p%tname), fl(i)%p%nlev, fl(i)%p%stagger, ids(i))
       if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'MUB') call def_field("MU", fl(i)%p%nlev, 0, id_extra(1))
       if (wrf_mod_vars .and. trim(fl(i)%p%tname) == 'P_HYD') then
-        call ncio_check(ncio_def_var(nf_out, "P_TOP", NCIO_FLOAT, [d_time], id_ptop), "DEFINING P_TOP")
+        if (myrank == 0) then
+          call ncio_check(ncio_def_var(nf_out, "P_TOP", NCIO_FLOAT, [d_time], id_ptop), "DEFINING P_TOP")
+        else
+          call ncio_check(ncio_inq_varid(nf_out, "P_TOP", id_ptop), "LOCATING P_TOP")
+        end if
         call def_field("PB", fl(i)%p%nlev, 0, id_extra(2))
         have_ptop = .true.
       end if
@@ -459,6 +613,7 @@ contains
       end if
     end do
     if (wrf_mod_vars .and. hist_3d_nz%n > 0) call def_field("P", nz_input, 0, id_extra(5))
+    if (myrank == 0) then
     call ncio_check(ncio_enddef(nf_out), "ENDDEF")
     ! ---- data ----
     call put_r8(id_grid(1), lon_m); call put_r8(id_grid(2), lat_m)
@@ -484,7 +639,9 @@ contains
     itime(1) = 0
     if (config_dt > 0.0_dp) itime(1) = int(real(xt_sec, dp)/config_dt, c_int32_t)
     call ncio_check(ncio_put_var(nf_out, id_itime, 0_c_int64_t, NCIO_INT, itime), "WRITING ITIMESTEP RECORD")
-    npts = i_target*j_target
+    if (have_ptop .and. nranks > 1) call ncio_check(ncio_put_var(nf_out, id_ptop, 0_c_int64_t, NCIO_DOUBLE, [0.0_dp]), "WRITING P_TOP")
+    end if
+    npts = i_target*ny_ext                              ! this image's row block (the whole grid with one image)
     do i = 1, nv
       if (dev_flow) then
         call write_field_dev(fl(i)%p, ids(i), id_extra, id_ptop, npts)
@@ -522,6 +679,10 @@ contains
     end do
     if (id_extra(5) >= 0) call put_zero(id_extra(5))
     call ncio_check(ncio_close(nf_out), "CLOSING FILE")
+    if (nranks > 1) then
+      if (myrank == 0) call write_marker(marker_name("ready", -1), [real(nranks, dp)])
+      call finish_ranks(id_ptop, have_ptop)
+    end if
     print '(a,f9.3,a)', "   [WRITE DATA: of which inside ncio_put_var] ", put_seconds, " s"
   end subroutine nc_write_target
 

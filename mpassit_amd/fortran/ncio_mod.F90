@@ -109,6 +109,16 @@ module ncio
       integer(c_int32_t), intent(in) :: vals(*)
       integer(c_int) :: rc
     end function ncio_put_att_int_c
+    function ncio_msleep(ms) bind(C, name="ncio_msleep") result(rc)
+      import :: c_int
+      integer(c_int), value :: ms
+      integer(c_int) :: rc
+    end function ncio_msleep
+    function ncio_rename_c(from, to) bind(C, name="ncio_rename") result(rc)
+      import :: c_char, c_int
+      character(kind=c_char), intent(in) :: from(*), to(*)
+      integer(c_int) :: rc
+    end function ncio_rename_c
     function ncio_put_att_double_c(f, varid, name, vals, n) bind(C, name="ncio_put_att_double") result(rc)
       import :: c_char, c_ptr, c_int, c_double
       type(c_ptr), value :: f
@@ -258,6 +268,10 @@ contains
     ! the reference is built with -r8 (CMakeLists.txt:80-82): its `real` attributes are NF90_DOUBLE
     rc = ncio_put_att_double_c(f, varid, cstr(name), [val], 1_c_int)
   end function ncio_put_att_real
+  integer(c_int) function ncio_rename(from, to) result(rc)
+    character(len=*), intent(in) :: from, to
+    rc = ncio_rename_c(cstr(from), cstr(to))
+  end function ncio_rename
   !> text global attribute (nf90_get_att into a character variable); blank-padded, rc /= 0 when absent or not text
   integer(c_int) function ncio_get_gatt_text(f, name, text) result(rc)
     type(c_ptr), intent(in) :: f

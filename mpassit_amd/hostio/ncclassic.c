@@ -717,3 +717,13 @@ int ncio_close(ncio_file *f) {
   free_file(f);
   return rc;
 }
+
+/* ---- two POSIX helpers of the multi-image Fortran driver (ncfiles_mod.F90: marker files between driver images) ---- */
+int ncio_msleep(int ms) {
+  if (ms > 0) usleep((useconds_t)ms * 1000u);
+  return 0;
+}
+int ncio_rename(const char *from, const char *to) {
+  if (!from || !to) return fail(NCIO_EINVAL, "ncio_rename: NULL argument");
+  return rename(from, to) == 0 ? 0 : fail(NCIO_EIO, "ncio_rename: cannot rename %s to %s", from, to);
+}

@@ -228,3 +228,70 @@ def test_driver_on_a_global_latlon_grid(tmp_path, gpu_lib):
             if k == "Z_C":
                 got = got[:nz]
             assert got.shape == w_.shape and np.array_equal(got, w_), k
+
+
+def _run_images(d, namelist_name, ranks):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mpassit_ranks
+    res = mpassit_ranks.launch(namelist_name, ranks, gpus=1, exe=_driver(), cwd=d, timeout=600)
+    for r, (code, so, se) in enumerate(res):
+        assert code == 0, "image %d: %s\n%s" % (r, so[-2000:], se[-2000:])
+    return res
+
+
+def test_three_driver_images_write_the_same_file(tmp_path, gpu_lib, regional_case):
+    """The Fortran driver as several images, one per GPU (here: three sharing the one card) -- the reference's
+    `mpirun -np N` (mpassit.F90:84-96): every image reads the files whole (input_data.F90:645), regrids its block of
+    target rows (regDecomp=(/1,npets/), model_grid.F90:693; one halo row each side for the CENTER -> EDGE destaggering)
+    and writes its rows into the one CDF-5 file; P_TOP is combined from the images' reductions.  The file must be the one
+    a single image writes, byte for byte."""
+    m, g = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc")
+    open(os.path.join(d, "namelist.one"), "w").write(nml)
+    open(os.path.join(d, "namelist.three"), "w").write(nml.replace("out.nc", "out3.nc"))
+    r = subprocess.run([_driver(), "namelist.one"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = _run_images(d, "namelist.three", 3)
+    assert "DRIVER IMAGE 2 OF 3" in res[2][1]
+    one, three = open(os.path.join(d, "out.nc"), "rb").read(), open(os.path.join(d, "out3.nc"), "rb").read()
+    assert len(one) == len(three)
+    if one != three:                                   # say which variable differs before failing
+        from mpassit_amd import ncio
+        with ncio.Reader(os.path.join(d, "out.nc")) as a, ncio.Reader(os.path.join(d, "out3.nc")) as b:
+            bad = [k for k in a.vars if not np.array_equal(a.get(k, rec=0) if a.vars[k]["record"] else a.get(k),
+                                                            b.get(k, rec=0) if b.vars[k]["record"] else b.get(k))]
+        assert not bad, bad
+    assert one == three
+    assert not [f for f in os.listdir(d) if ".ready" in f or ".done." in f]      # the marker files are gone
+
+
+def test_two_driver_images_on_a_global_grid(tmp_path, gpu_lib):
+    """Row blocks of a periodic grid with pole caps (is_regional=.false.): each image keeps the cap it touches."""
+    from mpassit_amd import workloads
+    m, g, _, _ = workloads.workload("c5_small")
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    nml = """&config
+  grid_file_input_grid="%s/init.nc"
+  hist_file_input_grid="%s/hist.nc"
+  diag_file_input_grid="%s/diag.nc"
+  output_file="%s/out.nc"
+  target_grid_type = 'lat-lon'
+  interp_diag=.true.
+  interp_hist=.true.
+  wrf_mod_vars=.true.
+  is_regional=.false.
+  nx = 361
+  ny = 181
+  stand_lon = 0.0
+/
+""" % (d, d, d, d)
+    open(os.path.join(d, "namelist.one"), "w").write(nml)
+    open(os.path.join(d, "namelist.two"), "w").write(nml.replace("out.nc", "out2.nc"))
+    r = subprocess.run([_driver(), "namelist.one"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    _run_images(d, "namelist.two", 2)
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out2.nc"), "rb").read()
