@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmpassit_amd.so")
+SO_PATH = os.environ.get("MPASSIT_AMD_LIB") or os.path.join(_HERE, "libmpassit_amd.so")   # override: A/B builds of experiments
 
 # every symbol include/mpassit_amd.h declares (tests check they are all exported)
 SYMBOLS = [

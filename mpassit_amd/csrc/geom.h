@@ -78,3 +78,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
   unsigned q = n / 8, r = n % 8, xcd = lin % 8, k = lin / 8;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
+
+// Order of the tiles of ONE field inside the linear work space: row-major tiles would put the tile below (tx, ty) a whole
+// tile row (ntx workgroups) later, by when the source cells the two share along their common edge have left the 4 MiB L2
+// (C4: 29 tiles x 160 KB in between).  Bands of `band` tile rows walked column by column make vertical neighbours
+// consecutive and horizontal neighbours `band` apart; only the band's outer edges are fetched twice.  Bijective on
+// [0, ntx * nty); band <= 1 is the row-major order.
+__device__ __forceinline__ unsigned band_order(unsigned tl, unsigned ntx, unsigned nty, unsigned band) {
+  if (band <= 1) return tl;
+  const unsigned per = band * ntx, b = tl / per, r = tl - b * per;
+  const unsigned y0 = b * band, bh = min(band, nty - y0);
+  const unsigned tx = r / bh, ty = y0 + (r - tx * bh);
+  return ty * ntx + tx;
+}

@@ -61,18 +61,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   int bh = min(tgroup, nty - band * tgroup);   // rows in this (possibly last, shorter) band
   int tx = rem / bh, ty = band * tgroup + rem % bh;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int i = tx * A3_TX + (wave % CG) * WX + (lane % WX);
+  int ib = tx * A3_TX + (wave % CG) * WX + (lane % WX);
   int j0 = ty * TY + (wave / CG) * (WH * RPT) + lane / WX;   // thread rows: j0, j0 + WH, ...
   int k0 = chunk * lev_chunk, k1 = min(nlev, k0 + lev_chunk);
 
   int32_t c[RPT][3];
   double ww[RPT][3];
   bool act[RPT], mapped[RPT];
+  int64_t po[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     int j = j0 + r * WH;
-    act[r] = (i < nx) && (j < ny);
+    int i = ib - mpg_tile_shift(j, nx);       // row-shifted tile: aligned store segments (mpg_internal.h)
+    act[r] = (i >= 0) && (i < nx) && (j < ny);
     int64_t p = act[r] ? (int64_t)j * nx + i : 0;
+    po[r] = p;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       c[r][q] = idx[q * P + p];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   }
   for (int f = f0; f < f1; ++f) {
     const double *s = src + ((int64_t)f * nlev + k0) * nsrc;
-    double *d = dst + ((int64_t)f * nlev + k0) * P + (int64_t)j0 * nx + i;
+    double *d = dst + ((int64_t)f * nlev + k0) * P;
     for (int k = k0; k < k1; ++k) {
       if (SYNC) __syncthreads();
       double v[RPT];
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
       }
 #pragma unroll
       for (int r = 0; r < RPT; ++r)
-        if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + (int64_t)r * WH * nx);
+        if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + po[r]);
       s += nsrc;
       d += P;
     }
@@ -149,16 +152,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_lf(const int32_t *__restr
   int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 192) {
     int pt = t & 63, q = t >> 6;
-    int i = tx * TXL + (pt % TXL), j = ty * TYL + (pt / TXL);
-    bool in = i < nx && j < ny;
+    int j = ty * TYL + (pt / TXL), i = tx * TXL + (pt % TXL) - mpg_tile_shift(j, nx);
+    bool in = i >= 0 && i < nx && j < ny;
     int64_t p = in ? (int64_t)j * nx + i : 0;
     int32_t c = idx[q * P + p];
     sidx[q * 64 + pt] = in ? c : -1;
     sw[q * 64 + pt] = w[q * P + p];
   }
   __syncthreads();
-  int oi = tx * TXL + (lane % TXL), oj = ty * TYL + (lane / TXL);
-  bool oact = oi < nx && oj < ny;
+  int oj = ty * TYL + (lane / TXL), oi = tx * TXL + (lane % TXL) - mpg_tile_shift(oj, nx);
+  bool oact = oi >= 0 && oi < nx && oj < ny;
   int64_t op = oact ? (int64_t)oj * nx + oi : 0;
  for (int fld = f0; fld < f1; ++fld) {   // the tile's indices/weights stay staged in LDS for all its fields
   const double *sf = src + (int64_t)fld * nlev * nsrc;
@@ -313,7 +316,7 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "lf_fields_per_wg")) { g_lf_fpw = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_variant")) {  // 0.. : k_apply3_lf variants; 100.. : LDS-staged unique-cell variants (k_apply_lfu.hip)
     if (value == -1 || value == 200 || (value >= 100 && value < 100 + mpg_lfu_num_variants()) ||
-        (value >= 300 && value < 300 + mpg_lfs_num_variants()) ) {  // 200: rows-resident (32 x 4); 300..: rows-resident, deep prefetch (k_apply_lfs.hip)
+        (value >= 300 && value < 300 + mpg_lfs_num_variants()) || (value >= 400 && value < 420)) {  // 200: rows-resident (32 x 4); 300..: rows-resident, deep prefetch (k_apply_lfs.hip)
       g_lf_variant = value;
       return MPG_SUCCESS;
     }
@@ -321,6 +324,7 @@ int mpg_k_tune(const char *key, int value) {
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "tile_band")) { mpg_set_tile_band(value); return MPG_SUCCESS; }
   if (!strcmp(key, "cfu_fields_per_wg")) { mpg_cfu_set_fields_per_wg(value); return MPG_SUCCESS; }
   if (!strcmp(key, "nn_variant")) {   // nearest-neighbour Store: 1 = wave-cooperative search, 0 = one thread per point
     if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
@@ -368,6 +372,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
       if (rc != MPG_ERR_UNSUPPORTED) return rc;
       lfv = LF_DEFAULT_ROW_GATHER;  // rows of a tile do not fit the LDS
     }
+    if (lev_fast && lfv >= 400) lfv = LF_DEFAULT_ROW_GATHER;  // 400..: experiments of the typed float32 kernel only
     if (lev_fast && lfv >= 300) {
       int rc = mpg_k_apply3_lfs(h, lfv - 300, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, (size_t)160 * 1024, s);
       if (rc != MPG_ERR_UNSUPPORTED) {
@@ -382,7 +387,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
     } else if (lev_fast) {
       const LfVariant &lv = g_lf_variants[lfv];
       int tyl = 64 / lv.txl;
-      int ntx = (h->nx_dst + lv.txl - 1) / lv.txl, nty = (h->ny_dst + tyl - 1) / tyl;
+      int ntx = mpg_tile_ntx(h->nx_dst, lv.txl), nty = (h->ny_dst + tyl - 1) / tyl;
       size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
       if (lds > 160 * 1024) {
         mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
@@ -409,7 +414,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
       if (staged >= 0) return mpg_k_apply3_cfu(h, staged, src, nlev, nfields, dst, s);
       const A3Variant &av = g_a3_variants[g_a3_variant];
       int tyv = a3_tile_rows(av);
-      int ntx = (h->nx_dst + A3_TX - 1) / A3_TX, nty = (h->ny_dst + tyv - 1) / tyv;
+      int ntx = mpg_tile_ntx(h->nx_dst, A3_TX), nty = (h->ny_dst + tyv - 1) / tyv;
       int lc = g_lev_chunk > 0 ? g_lev_chunk : nlev;
       int nchunk = (nlev + lc - 1) / lc;
       int fpw = g_fpw > 0 ? (g_fpw < nfields ? g_fpw : nfields) : nfields;

@@ -34,7 +34,7 @@ typedef float lfs_f32x4 __attribute__((ext_vector_type(4), aligned(4)));
 template <typename TS, typename TD, int TY, int NH, int NB, int MODE>
 __global__ __launch_bounds__(LFS_THREADS) void k_apply3_lfs(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                             const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
                                                             int nlev, int rs, int ntx, int nty, int ut_max, double scale, double offset) {
   constexpr int NP = 64 * TY;                       // target points per tile
   constexpr int UN = 4;                             // levels per trip of the combine loop
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(LFS_THREADS) void k_apply3_lfs(const int32_t *__res
   const int tx = tile % ntx, ty = tile / ntx;
   const int pt = t % NP;
   const int lg = __builtin_amdgcn_readfirstlane(t / NP);      // level group: uniform over the wave
-  const int i = tx * 64 + (pt & 63), j = ty * TY + (pt >> 6);
-  const bool act = i < nx && j < ny;
+  const int j = ty * TY + (pt >> 6), i = tx * 64 + (pt & 63) - mpg_tile_shift(j, nx, talign);
+  const bool act = i >= 0 && i < nx && j < ny;
   const unsigned off = act ? (unsigned)(j * nx + i) : 0u;
   int l0 = lidx[off], l1 = lidx[P + off], l2 = lidx[2 * P + off];
   double w0 = w[off], w1 = w[P + off], w2 = w[2 * P + off];
@@ -180,7 +180,7 @@ template <typename TS, typename TD, int TY, int NH, int MODE = 0>
 static int launch_lfs(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, size_t lds_cap,
                       hipStream_t s) {
   constexpr int NB = 16;
-  const int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + TY - 1) / TY;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + TY - 1) / TY;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   const int rs = nlev | 1;  // row stride in elements, odd: a column read walks all banks (float64: all bank pairs)
   const size_t lds = sizeof(TS) * (um + 1) * rs + sizeof(int32_t) * um + 16;
@@ -188,7 +188,7 @@ static int launch_lfs(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   auto fn = k_apply3_lfs<TS, TD, TY, NH, NB, MODE>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fn<<<(unsigned)ntx * nty * nfields, LFS_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
-                                                           h->ny_dst, h->n_src, nlev, rs, ntx, nty, (int)um, scale, offset);
+                                                           h->ny_dst, h->ut_align, h->n_src, nlev, rs, ntx, nty, (int)um, scale, offset);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

@@ -31,7 +31,7 @@
 // One workgroup per tile of txu x tyu points: the 3*np cell ids are sorted in LDS (bitonic), duplicates dropped,
 // and each point's three ids are replaced by their rank in the tile's list.  FILL = false only counts.
 template <bool FILL>
-__global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__restrict__ idx, int nx, int ny, int txu, int tyu, int ntx,
+__global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__restrict__ idx, int nx, int ny, int talign, int txu, int tyu, int ntx,
                                                            int32_t *__restrict__ ut_count, const int32_t *__restrict__ ut_ptr,
                                                            int32_t *__restrict__ ut_cells, uint16_t *__restrict__ lidx,
                                                            unsigned long long *__restrict__ line_count) {
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
     int32_t key = INT_MAX;
     if (e < nk) {
       int q = e / np, pt = e % np;
-      int i = tx * txu + pt % txu, j = ty * tyu + pt / txu;
-      if (i < nx && j < ny) {
+      int j = ty * tyu + pt / txu, i = tx * txu + pt % txu - mpg_tile_shift(j, nx, talign);
+      if (i >= 0 && i < nx && j < ny) {
         int32_t c = idx[q * P + (int64_t)j * nx + i];
         if (c >= 0) key = c;
       }
@@ -101,8 +101,8 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
     if ((t & 63) == 0 && nl) atomicAdd(line_count, (unsigned long long)nl);
   }
   for (int pt = t; pt < np; pt += LFU_THREADS) {
-    int i = tx * txu + pt % txu, j = ty * tyu + pt / txu;
-    if (i >= nx || j >= ny) continue;
+    int j = ty * tyu + pt / txu, i = tx * txu + pt % txu - mpg_tile_shift(j, nx, talign);
+    if (i < 0 || i >= nx || j >= ny) continue;
     int64_t p = (int64_t)j * nx + i;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -131,14 +131,14 @@ struct LfuPoints {
   double ww[RPT][3];
   bool act[RPT], mapped[RPT];
   int64_t off[RPT];  // j*nx + i
-  __device__ __forceinline__ void load(const uint16_t *__restrict__ lidx, const double *__restrict__ w, int nx, int ny, int tx, int ty, int LS) {
+  __device__ __forceinline__ void load(const uint16_t *__restrict__ lidx, const double *__restrict__ w, int nx, int ny, int talign, int tx, int ty, int LS) {
     constexpr int TY = LFU_THREADS * RPT / TXU;
     const int64_t P = (int64_t)nx * ny;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       int pt = (int)threadIdx.x + LFU_THREADS * r;
-      int i = tx * TXU + pt % TXU, j = ty * TY + pt / TXU;
-      act[r] = i < nx && j < ny;
+      int j = ty * TY + pt / TXU, i = tx * TXU + pt % TXU - mpg_tile_shift(j, nx, talign);
+      act[r] = i >= 0 && i < nx && j < ny;
       off[r] = act[r] ? (int64_t)j * nx + i : 0;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -156,7 +156,7 @@ struct LfuPoints {
 template <int TXU, int RPT, int LC>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                             const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                            const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                            const double *__restrict__ src, double *__restrict__ dst, int nx, int ny, int talign,
                                                             int64_t nsrc, int nlev, int ntx, int nty, int nfields, int ut_max) {
   constexpr int LS = LC + 1, RPP = LFU_THREADS / LC;  // RPP = rows loaded per pass
   extern __shared__ double lds[];                     // rows [ut_max][LS] | cell ids [ut_max]
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__res
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   for (int r = t; r < nU; r += LFU_THREADS) cells[r] = ut_cells[u0 + r];
   LfuPoints<TXU, RPT> pts;
-  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, LS);
+  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, LS);
   const double *sf = src + (int64_t)f * nlev * nsrc;
   double *df = dst + (int64_t)f * nlev * P;
   const int lrow = t / LC, llev = t % LC;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__res
 template <int TXU, int RPT, int LC, int NPF>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                              const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                              const double *__restrict__ src, double *__restrict__ dst, int nx, int ny, int talign,
                                                               int64_t nsrc, int nlev, int ntx, int nty, int nfields, int ut_max) {
   constexpr int LS = LC + 1, RPP = LFU_THREADS / LC;
   extern __shared__ double lds[];
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   for (int r = t; r < nU; r += LFU_THREADS) cells[r] = ut_cells[u0 + r];
   LfuPoints<TXU, RPT> pts;
-  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, LS);
+  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, LS);
   const double *sf = src + (int64_t)f * nlev * nsrc;
   double *df = dst + (int64_t)f * nlev * P;
   const int lrow = t / LC, llev = t % LC;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
 template <int TXU, int RPT, int LC, int NPF>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                              const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                              const double *__restrict__ src, double *__restrict__ dst, int nx, int ny, int talign,
                                                               int64_t nsrc, int nlev, int ntx, int nty, int nfields, int ut_max) {
   constexpr int UPT = NPF / LC;                 // unique cells per thread held in registers
   extern __shared__ double lds[];               // [LC][nup]
@@ -283,19 +283,19 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned tile = lin % ntile;
+  const unsigned tile = band_order(lin % ntile, ntx, nty, (unsigned)nfields >> 24);
   // A workgroup serves `fpw` consecutive fields of its tile (packed into the upper half of `nfields` by the launcher): the
   // bundle is stored [field][level][cell] / [field][level][point], so fields f0 .. f0+fpw-1 are simply fpw * nlev consecutive
   // "levels" -- the chunk pipeline runs across the field boundaries, and the tile's list, ranks and weights are fetched
   // once per fpw fields instead of once per field.
-  const int fpw = max(1, nfields >> 16), nf = nfields & 0xffff;
+  const int fpw = max(1, (nfields >> 16) & 0xff), nf = nfields & 0xffff;   // bits 24..31: tile band (band_order)
   const int f = (int)(lin / ntile) * fpw;
   const int nlev_all = nlev;
   nlev = min(fpw, nf - f) * nlev_all;
   const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   LfuPoints<TXU, RPT> pts;
-  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, 1);
+  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, 1);
   const double *sf = src + (int64_t)f * nlev_all * nsrc;
   double *df = dst + (int64_t)f * nlev_all * P;
   int32_t cell[UPT];
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
   }
 }
 
-typedef void (*lfu_fn)(const int32_t *, const int32_t *, const uint16_t *, const double *, const double *, double *, int, int, int64_t,
+typedef void (*lfu_fn)(const int32_t *, const int32_t *, const uint16_t *, const double *, const double *, double *, int, int, int, int64_t,
                        int, int, int, int, int);
 struct LfuVariant { int txu, rpt, lc; lfu_fn fn; };
 static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 100 + index
@@ -357,8 +357,11 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     // (compact tiles of 32 x 32, 16 x 64 and 32 x 16 points with the same 1024-cell capacity were measured in round 2 on C4,
     //  Morton-numbered C4, C2 and C5: 0-15 % slower than 64 x 8 / 64 x 16 everywhere, profiles/r02_sweep_cfu_compact.txt)
 };
+static int g_tile_band = 0;  // "tile_band": tile rows per band of the tile order (geom.h band_order); 0 = row-major
+void mpg_set_tile_band(int v) { g_tile_band = v < 0 ? 0 : (v > 255 ? 255 : v); }
+int mpg_tile_band() { return g_tile_band; }
 static int g_cfu_fpw = 1;   // "cfu_fields_per_wg": fields of a bundle served by one workgroup of the staged cell-fast kernel
-void mpg_cfu_set_fields_per_wg(int v) { g_cfu_fpw = v < 1 ? 1 : v; }
+void mpg_cfu_set_fields_per_wg(int v) { g_cfu_fpw = v < 1 ? 1 : (v > 255 ? 255 : v); }
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
 static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16};
@@ -390,6 +393,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     std::swap(h->lidx, h->lidx2);
     std::swap(h->ut_rpt, h->ut2_rpt);
     std::swap(h->ut_max, h->ut2_max);
+    std::swap(h->ut_align, h->ut2_align);
     std::swap(h->ut_total, h->ut2_total);
     std::swap(h->ut_lines, h->ut2_lines);
     return MPG_SUCCESS;
@@ -404,6 +408,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     h->lidx2 = h->lidx;
     h->ut2_rpt = h->ut_rpt;
     h->ut2_max = h->ut_max;
+    h->ut2_align = h->ut_align;
     h->ut2_total = h->ut_total;
     h->ut2_lines = h->ut_lines;
     h->ut_ptr = DevBuf<int32_t>();
@@ -417,36 +422,56 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     mpg_set_error("staged Regrid: tile of %d x %d points exceeds the sort buffer", txu, tyu);
     return MPG_ERR_UNSUPPORTED;
   }
-  const int ntx = (h->nx_dst + txu - 1) / txu, nty = (h->ny_dst + tyu - 1) / tyu;
-  const int64_t ntile = (int64_t)ntx * nty;
+  // Row-shifted tiles (aligned store segments, mpg_internal.h) first; when their longest list does not fit the staged
+  // kernels' 1024 cells per tile (grids whose rows start at many different offsets in a line: the shifted rows of a tile
+  // then spread over up to 31 more columns) the lists are built for unshifted tiles instead.
+  h->ut_align = (h->nx_dst % MPG_TILE_ALIGN) ? MPG_TILE_ALIGN : 1;
+  const int nty = (h->ny_dst + tyu - 1) / tyu;
+  int ntx = 0;
+  int64_t ntile = 0;
   TmpBuf<int32_t> count;
-  if ((rc = count.alloc(ntile + 1)) || (rc = h->ut_ptr.alloc(ntile + 1))) return rc;
-  if (!h->lidx.p && (rc = h->lidx.alloc(3 * (size_t)h->n_dst))) return rc;
-  MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (ntile + 1), s));
-  k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, count.p, nullptr, nullptr, nullptr,
-                                                            nullptr);
-  MPG_HIP(hipGetLastError());
-  // list offsets and the longest list on the device (rocPRIM scan / reduce); only three scalars come back to the host
   TmpBuf<char> tmp;
   TmpBuf<unsigned long long> scal;   // [0] distinct 128-byte lines, [1] (as int32) longest list
-  size_t b_scan = 0, b_max = 0;
-  MPG_HIP(rocprim::exclusive_scan(nullptr, b_scan, count.p, h->ut_ptr.p, (int32_t)0, (size_t)ntile + 1, rocprim::plus<int32_t>(), s));
-  if ((rc = scal.alloc(2))) return rc;
-  MPG_HIP(rocprim::reduce(nullptr, b_max, count.p, (int32_t *)(scal.p + 1), (int32_t)0, (size_t)ntile, rocprim::maximum<int32_t>(), s));
-  if ((rc = tmp.alloc((b_scan > b_max ? b_scan : b_max) + 16))) return rc;
-  MPG_HIP(hipMemsetAsync(scal.p, 0, 2 * sizeof(unsigned long long), s));
-  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, b_scan, count.p, h->ut_ptr.p, (int32_t)0, (size_t)ntile + 1, rocprim::plus<int32_t>(), s));
-  MPG_HIP(rocprim::reduce((void *)tmp.p, b_max, count.p, (int32_t *)(scal.p + 1), (int32_t)0, (size_t)ntile, rocprim::maximum<int32_t>(), s));
   int32_t tot32 = 0;
-  MPG_HIP(hipMemcpyAsync(&tot32, h->ut_ptr.p + ntile, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MPG_HIP(hipStreamSynchronize(s));
+  for (;;) {
+    ntx = mpg_tile_ntx(h->nx_dst, txu, h->ut_align);
+    ntile = (int64_t)ntx * nty;
+    count.free();
+    h->ut_ptr.free();
+    tmp.free();
+    scal.free();
+    if ((rc = count.alloc(ntile + 1)) || (rc = h->ut_ptr.alloc(ntile + 1))) return rc;
+    if (!h->lidx.p && (rc = h->lidx.alloc(3 * (size_t)h->n_dst))) return rc;
+    MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (ntile + 1), s));
+    k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, count.p, nullptr, nullptr,
+                                                              nullptr, nullptr);
+    MPG_HIP(hipGetLastError());
+    // list offsets and the longest list on the device (rocPRIM scan / reduce); only three scalars come back to the host
+    size_t b_scan = 0, b_max = 0;
+    MPG_HIP(rocprim::exclusive_scan(nullptr, b_scan, count.p, h->ut_ptr.p, (int32_t)0, (size_t)ntile + 1, rocprim::plus<int32_t>(), s));
+    if ((rc = scal.alloc(2))) return rc;
+    MPG_HIP(rocprim::reduce(nullptr, b_max, count.p, (int32_t *)(scal.p + 1), (int32_t)0, (size_t)ntile, rocprim::maximum<int32_t>(), s));
+    if ((rc = tmp.alloc((b_scan > b_max ? b_scan : b_max) + 16))) return rc;
+    MPG_HIP(hipMemsetAsync(scal.p, 0, 2 * sizeof(unsigned long long), s));
+    MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, b_scan, count.p, h->ut_ptr.p, (int32_t)0, (size_t)ntile + 1, rocprim::plus<int32_t>(), s));
+    MPG_HIP(rocprim::reduce((void *)tmp.p, b_max, count.p, (int32_t *)(scal.p + 1), (int32_t)0, (size_t)ntile, rocprim::maximum<int32_t>(), s));
+    int32_t max32 = 0;
+    MPG_HIP(hipMemcpyAsync(&tot32, h->ut_ptr.p + ntile, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipMemcpyAsync(&max32, (int32_t *)(scal.p + 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    if (h->ut_align > 1 && max32 > 1024) {
+      h->ut_align = 1;
+      continue;
+    }
+    break;
+  }
   if (tot32 < 0) {   // the int32 scan wrapped
     mpg_set_error("tile cell lists exceed 2^31 entries");
     return MPG_ERR_OVERFLOW;
   }
   const int64_t tot = tot32;
   if ((rc = h->ut_cells.alloc((size_t)tot + 1))) return rc;
-  k_lfu_build<true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, txu, tyu, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p,
+  k_lfu_build<true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p,
                                                            h->lidx.p, scal.p);
   MPG_HIP(hipGetLastError());
   unsigned long long hs[2] = {0, 0};
@@ -530,7 +555,7 @@ int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
 template <typename TS, typename TD>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                              const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                              const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
                                                               int nlev, int ntx, int nty, int nfields, int ut_max, double scale,
                                                               double offset) {
   constexpr int TXU = 64, RPT = 2, LC = 4, NPF = 16, UPT = NPF / LC;
@@ -544,7 +569,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__r
   const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   LfuPoints<TXU, RPT> pts;
-  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, 1);
+  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, 1);
   const TS *sf = src + (int64_t)f * nlev * nsrc;
   TD *df = dst + (int64_t)f * nlev * P;
   int32_t cell[UPT];
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__r
 
 template <typename TS, typename TD>
 static int launch_cfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
-  const int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 7) / 8;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + 7) / 8;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   size_t lds = sizeof(double) * um * 4 + 16;
   if (lds > 160 * 1024) {
@@ -603,7 +628,7 @@ static int launch_cfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields,
   if (lds > 48 * 1024)
     MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_cfu_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_apply3_cfu_t<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
-                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
+                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty,
                                                                                 nfields, (int)um, scale, offset);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
@@ -616,7 +641,7 @@ static int launch_cfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields,
 template <typename TS, typename TD>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                              const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                              const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
                                                               int nlev, int ntx, int nty, int nfields, int ut_max, double scale,
                                                               double offset) {
   constexpr int TXU = 64, RPT = 1, LC = 16, NPF = 16, LS = LC + 1, RPP = LFU_THREADS / LC;
@@ -631,7 +656,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_t(const int32_t *__r
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
   for (int r = t; r < nU; r += LFU_THREADS) cells[r] = ut_cells[u0 + r];
   LfuPoints<TXU, RPT> pts;
-  pts.load(lidx, w, nx, ny, tile % ntx, tile / ntx, LS);
+  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, LS);
   const TS *sf = src + (int64_t)f * nlev * nsrc;
   TD *df = dst + (int64_t)f * nlev * P;
   const int lrow = t / LC, llev = t % LC;
@@ -670,14 +695,14 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_t(const int32_t *__r
 
 template <typename TS, typename TD>
 static int launch_lfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
-  const int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 3) / 4;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + 3) / 4;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   size_t lds = sizeof(double) * um * 17 + sizeof(int32_t) * um + 16;
   if (lds > 160 * 1024) return MPG_ERR_UNSUPPORTED;
   if (lds > 48 * 1024)
     MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lfu_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_apply3_lfu_t<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
-                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
+                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty,
                                                                                 nfields, (int)um, scale, offset);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
@@ -692,7 +717,7 @@ static int launch_lfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields,
 template <typename TS, typename TD>
 __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfr(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                             const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
+                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
                                                             int nlev, int nlp, int ntx, int nty, int nfields, double scale, double offset) {
   constexpr int TXU = 32, TYU = 4, NP = TXU * TYU;
   extern __shared__ double lds_raw[];
@@ -725,8 +750,8 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfr(const int32_t *__res
   }
   // this thread's point
   const int pt = t % NP, par = t / NP;
-  const int i = (tile % ntx) * TXU + pt % TXU, j = (tile / ntx) * TYU + pt / TXU;
-  const bool act = i < nx && j < ny;
+  const int j = (tile / ntx) * TYU + pt / TXU, i = (tile % ntx) * TXU + pt % TXU - mpg_tile_shift(j, nx, talign);
+  const bool act = i >= 0 && i < nx && j < ny;
   const int64_t p = act ? (int64_t)j * nx + i : 0;
   int l0 = lidx[p], l1 = lidx[P + p], l2 = lidx[2 * P + p];
   const double w0 = w[p], w1 = w[P + p], w2 = w[2 * P + p];
@@ -745,14 +770,14 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfr(const int32_t *__res
 
 template <typename TS, typename TD>
 static int launch_lfr(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
-  const int ntx = (h->nx_dst + 31) / 32, nty = (h->ny_dst + 3) / 4;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 32, h->ut_align), nty = (h->ny_dst + 3) / 4;
   const int nlp = nlev | 1;  // odd row stride: conflict-free column reads
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   size_t lds = sizeof(TS) * um * nlp + 16;
   if (lds > 80 * 1024) return MPG_ERR_UNSUPPORTED;  // fewer than two workgroups per CU: not worth it
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lfr<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   k_apply3_lfr<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
-                                                                              (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, nlp, ntx, nty, nfields,
+                                                                              (TD *)dst, h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, nlp, ntx, nty, nfields,
                                                                               scale, offset);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
@@ -819,7 +844,7 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
   int rc = lfu_build(h, v.txu, v.rpt, s);
   if (rc) return rc;
   const int tyu = LFU_THREADS * v.rpt / v.txu;
-  const int ntx = (h->nx_dst + v.txu - 1) / v.txu, nty = (h->ny_dst + tyu - 1) / tyu;
+  const int ntx = mpg_tile_ntx(h->nx_dst, v.txu, h->ut_align), nty = (h->ny_dst + tyu - 1) / tyu;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   size_t lds = sizeof(double) * um * v.lc + 16;
   if (lds > 160 * 1024) {
@@ -833,8 +858,8 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
   }
   const int fpw = g_cfu_fpw < nfields ? g_cfu_fpw : nfields;
   const int ngroups = (nfields + fpw - 1) / fpw;
-  v.fn<<<(unsigned)ntx * nty * ngroups, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst,
-                                                              h->n_src, nlev, ntx, nty, nfields | (fpw << 16), (int)um);
+  v.fn<<<(unsigned)ntx * nty * ngroups, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->ut_align,
+                                                              h->n_src, nlev, ntx, nty, nfields | ((fpw & 0xff) << 16) | (g_tile_band << 24), (int)um);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -844,7 +869,7 @@ int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
   int rc = lfu_build(h, v.txu, v.rpt, s);
   if (rc) return rc;
   const int tyu = LFU_THREADS * v.rpt / v.txu;
-  const int ntx = (h->nx_dst + v.txu - 1) / v.txu, nty = (h->ny_dst + tyu - 1) / tyu;
+  const int ntx = mpg_tile_ntx(h->nx_dst, v.txu, h->ut_align), nty = (h->ny_dst + tyu - 1) / tyu;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;  // unmapped points read row 0
   size_t lds = sizeof(double) * um * (v.lc + 1) + sizeof(int32_t) * um + 16;
   if (lds > 160 * 1024) {
@@ -852,7 +877,7 @@ int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
     return MPG_ERR_UNSUPPORTED;
   }
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  v.fn<<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst,
+  v.fn<<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->ut_align,
                                                               h->n_src, nlev, ntx, nty, nfields, (int)um);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;

@@ -8,6 +8,8 @@
 // so the float32 results are bit-identical to what the reference's writer would put in the file, while the
 // HBM traffic per 3-D field drops from 8+8 to 4+4 bytes per source/destination element.
 // Same structure as k_apply3_cf<2,4,true> / k_apply3_lf<64> in k_apply.hip.
+#include <algorithm>
+
 #include "geom.h"
 #include "mpg_internal.h"
 
@@ -23,16 +25,18 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
   int fld = lin / ntile;
   int tx = tile % ntx, ty = tile / ntx;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int i = tx * 64 + lane;
   int j0 = ty * TY + wave * RPT;
   int32_t c[RPT][3];
   double ww[RPT][3];
   bool act[RPT], mapped[RPT];
+  int64_t po[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
     int j = j0 + r;
-    act[r] = (i < nx) && (j < ny);
+    int i = tx * 64 + lane - mpg_tile_shift(j, nx);   // row-shifted tile: aligned store segments (mpg_internal.h)
+    act[r] = (i >= 0) && (i < nx) && (j < ny);
     int64_t p = act[r] ? (int64_t)j * nx + i : 0;
+    po[r] = p;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       c[r][q] = idx[q * P + p];
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
     for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
   }
   const TS *s = src + (int64_t)fld * nlev * nsrc;
-  TD *d = dst + (int64_t)fld * nlev * P + (int64_t)j0 * nx + i;
+  TD *d = dst + (int64_t)fld * nlev * P;
   for (int k = 0; k < nlev; ++k) {
     __syncthreads();
     double v[RPT];
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
     }
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
-      if (act[r]) __builtin_nontemporal_store((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), d + (int64_t)r * nx);
+      if (act[r]) __builtin_nontemporal_store((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), d + po[r]);
     s += nsrc;
     d += P;
   }
@@ -64,9 +68,9 @@ template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                      const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
                                                      int nlev, int ntx, int nty, double scale, double offset) {
-  extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
-  double *sw = tile + (size_t)nlev * 65;
-  int32_t *sidx = (int32_t *)(sw + 192);
+  extern __shared__ double sw[];    // sw[3][64] | sidx[3][64] | tile[nlev][65] in the DESTINATION type (narrowing at the tile
+  int32_t *sidx = (int32_t *)(sw + 192);            // write or at the store gives the same bits; float32 halves the LDS -> 8 WGs / CU)
+  TD *tile = (TD *)(sidx + 192);
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
   int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 192) {
     int pt = t & 63, q = t >> 6;
-    int i = tx * 64 + pt, j = ty;
-    bool in = i < nx && j < ny;
+    int j = ty, i = tx * 64 + pt - mpg_tile_shift(j, nx);
+    bool in = i >= 0 && i < nx && j < ny;
     int64_t p = in ? (int64_t)j * nx + i : 0;
     int32_t c = idx[q * P + p];
     sidx[q * 64 + pt] = in ? c : -1;
@@ -107,16 +111,16 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
       }
       if (kact) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) tile[k * 65 + wave * 16 + q0 + u] = v[u];
+        for (int u = 0; u < 4; ++u) tile[k * 65 + wave * 16 + q0 + u] = (TD)v[u];
       }
     }
   }
   __syncthreads();
   TD *df = dst + (int64_t)fld * nlev * P;
-  int i = tx * 64 + lane, j = ty;
-  if (i < nx && j < ny) {
+  int j = ty, i = tx * 64 + lane - mpg_tile_shift(j, nx);
+  if (i >= 0 && i < nx && j < ny) {
     int64_t p = (int64_t)j * nx + i;
-    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store((TD)tile[k * 65 + lane], df + (int64_t)k * P + p);
+    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + p);
   }
 }
 
@@ -129,17 +133,17 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
 // was measured too: slower, 14 of 16 lanes busy at 55 levels and more select / LDS work per load.)
 typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 
-template <typename TD>
-__global__ __launch_bounds__(256) void k_apply3_lf_f32x2(const int32_t *__restrict__ idx, const double *__restrict__ w,
+template <typename TD, int WPE, int UNR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_apply3_lf_f32x2(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                          const float *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
-                                                         int nlev, int ntx, int nty, double scale, double offset) {
-  extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
-  double *sw = tile + (size_t)nlev * 65;
-  int32_t *sidx = (int32_t *)(sw + 192);
+                                                         int nlev, int ntx, int nty, double scale, double offset, unsigned band) {
+  extern __shared__ double sw[];    // sw[3][64] | sidx[3][64] | tile[nlev][65] in the DESTINATION type (narrowing at the tile
+  int32_t *sidx = (int32_t *)(sw + 192);            // write or at the store gives the same bits; float32 halves the LDS -> 8 WGs / CU)
+  TD *tile = (TD *)(sidx + 192);
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  unsigned tl = lin % ntile;
+  unsigned tl = band_order(lin % ntile, ntx, nty, band);
   int fld = lin / ntile;
   int tx = tl % ntx, ty = tl / ntx;
   int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void k_apply3_lf_f32x2(const int32_t *__restri
     const int k0 = kb + 2 * sl;
     const int base = min(k0, nlev - 2);            // base < k0 only on the lane that holds the end of the row
     const bool shifted = base != k0, a0 = k0 < nlev, a1 = k0 + 1 < nlev;
-#pragma unroll
+#pragma unroll UNR
     for (int q0 = 0; q0 < 16; q0 += 4) {           // two pairs of points per step: 6 row loads in flight per lane
       double v[2][2];
 #pragma unroll
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(256) void k_apply3_lf_f32x2(const int32_t *__restri
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int pt = wave * 16 + q0 + 2 * u + half;
-        if (a0) tile[k0 * 65 + pt] = v[u][0];
-        if (a1) tile[(k0 + 1) * 65 + pt] = v[u][1];
+        if (a0) tile[k0 * 65 + pt] = (TD)v[u][0];
+        if (a1) tile[(k0 + 1) * 65 + pt] = (TD)v[u][1];
       }
     }
   }
@@ -189,7 +193,75 @@ __global__ __launch_bounds__(256) void k_apply3_lf_f32x2(const int32_t *__restri
   int i = tx * 64 + lane, j = ty;
   if (i < nx && j < ny) {
     int64_t p = (int64_t)j * nx + i;
-    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store((TD)tile[k * 65 + lane], df + (int64_t)k * P + p);
+    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + p);
+  }
+}
+
+// The same row gather with LINEAR tiles and several fields per workgroup.  A tile is 64 consecutive target points of the
+// flattened [ny][nx] plane starting at a multiple of 64, so every store of a level is one naturally aligned 256-byte
+// (float32) / 512-byte (float64) segment whatever nx is (64 x 1 tiles of a 1800-wide grid start 32 bytes off a line in three
+// rows of four: 10 % more bytes written, PMC, and two partial lines per store); the three cell offsets (premultiplied by
+// nlev, 32 bit, added to a scalar field base: no 64-bit address arithmetic per load) and weights of the tile are fetched
+// ONCE and serve `fpw` fields of the bundle (per field they are 36 of the 542 bytes a point moves at 55 float32 levels).
+template <typename TD, int UNR, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_apply3_lf_f32m(
+    const int32_t *__restrict__ idx, const double *__restrict__ w, const float *__restrict__ src, TD *__restrict__ dst, int64_t P, int64_t nsrc,
+    int nlev, unsigned ntile, int nfields, int fpw, double scale, double offset) {
+  extern __shared__ double sw[];                    // sw[3][64] | soff[3][64] | tile[nlev][65] in the destination type
+  uint32_t *soff = (uint32_t *)(sw + 192);
+  TD *tile = (TD *)(soff + 192);
+  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tl = lin % ntile;
+  const int f0 = (int)(lin / ntile) * fpw, f1 = min(nfields, f0 + fpw);
+  const int64_t p0 = (int64_t)tl * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t < 192) {
+    const int pt = t & 63, q = t >> 6;
+    const bool in = p0 + pt < P;
+    const int64_t p = in ? p0 + pt : 0;
+    const int32_t c = idx[q * P + p];
+    soff[q * 64 + pt] = (in && c >= 0) ? (uint32_t)c * (uint32_t)nlev : 0xFFFFFFFFu;
+    sw[q * 64 + pt] = w[q * P + p];
+  }
+  __syncthreads();
+  const int half = lane >> 5, sl = lane & 31;
+  const bool store_lane = p0 + lane < P;
+  for (int f = f0; f < f1; ++f) {
+    const float *sf = src + (int64_t)f * nlev * nsrc;
+    for (int kb = 0; kb < nlev; kb += 64) {
+      const int k0 = kb + 2 * sl;
+      const int base = min(k0, nlev - 2);            // base < k0 only on the lane that holds the end of the row
+      const bool shifted = base != k0, a0 = k0 < nlev, a1 = k0 + 1 < nlev;
+#pragma unroll UNR
+      for (int q0 = 0; q0 < 16; q0 += 4) {
+        double v[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pt = wave * 16 + q0 + 2 * u + half;
+          uint32_t o0 = soff[pt], o1 = soff[64 + pt], o2 = soff[128 + pt];
+          const double w0 = sw[pt], w1 = sw[64 + pt], w2 = sw[128 + pt];
+          const bool m = o0 != 0xFFFFFFFFu;
+          o0 = m ? o0 : 0u; o1 = m ? o1 : 0u; o2 = m ? o2 : 0u;
+          const f32x2_u x0 = *(const f32x2_u *)(sf + (o0 + (uint32_t)base));
+          const f32x2_u x1 = *(const f32x2_u *)(sf + (o1 + (uint32_t)base));
+          const f32x2_u x2 = *(const f32x2_u *)(sf + (o2 + (uint32_t)base));
+          const double a = shifted ? x0.y : x0.x, b = shifted ? x1.y : x1.x, e = shifted ? x2.y : x2.x;
+          v[u][0] = fma(m ? wsum3(w0, a, w1, b, w2, e) : 0.0, scale, offset);
+          v[u][1] = fma(m ? wsum3(w0, (double)x0.y, w1, (double)x1.y, w2, (double)x2.y) : 0.0, scale, offset);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pt = wave * 16 + q0 + 2 * u + half;
+          if (a0) tile[k0 * 65 + pt] = (TD)v[u][0];
+          if (a1) tile[(k0 + 1) * 65 + pt] = (TD)v[u][1];
+        }
+      }
+    }
+    __syncthreads();
+    TD *df = dst + (int64_t)f * nlev * P + p0;
+    if (store_lane)
+      for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + lane);
+    __syncthreads();                                 // the tile is rewritten by the next field
   }
 }
 
@@ -234,24 +306,52 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
   if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3) {
     if (lev_fast) {
       int ntx = (h->nx_dst + 63) / 64, nty = h->ny_dst;
-      size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
+      size_t lds = sizeof(TD) * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192;
       if (lds > 160 * 1024) {
         mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
         return MPG_ERR_UNSUPPORTED;
       }
       if (sizeof(TS) == 4 && nlev >= 2) {   // float32 rows: two levels per lane, two points per wavefront pass
-        if (lds > 48 * 1024)
-          MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf_f32x2<TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_apply3_lf_f32x2<TD><<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const float *)src, (TD *)dst, h->nx_dst,
-                                                                             h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+        auto go = [&](auto fn) -> int {
+          if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          fn<<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const float *)src, (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev,
+                                                            ntx, nty, scale, offset, (unsigned)mpg_tile_band());
+          return MPG_SUCCESS;
+        };
+        // default: linear 64-point tiles, 32-bit row offsets (k_apply3_lf_f32m); lf_variant 4 / 401-403 keep the 64 x 1 tiles of
+        // a grid row for comparison, 410-418 are the measured alternatives (fields per workgroup, unroll, occupancy)
+        const int lfv = mpg_lf_variant();
+        if (!(lfv == 4 || (lfv >= 401 && lfv <= 403)) && (uint64_t)h->n_src * (uint64_t)nlev < 0xFFFFFFFFull) {
+          static const int fpws[] = {1, 2, 4, 1 << 20, 13, 7, 1, 1, 1, 1};
+          const int v = (lfv >= 410 && lfv < 420) ? lfv - 410 : 6;
+          const int fpw = std::min(nfields, fpws[v]);
+          const unsigned ntile = (unsigned)((P + 63) / 64), ngroups = (unsigned)((nfields + fpw - 1) / fpw);
+          auto fn = k_apply3_lf_f32m<TD, 1, 8>;
+          if (v == 6) fn = k_apply3_lf_f32m<TD, 2, 8>;
+          if (v == 7) fn = k_apply3_lf_f32m<TD, 4, 4>;
+          if (v == 8) fn = k_apply3_lf_f32m<TD, 2, 6>;
+          if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          fn<<<ntile * ngroups, 256, lds, s>>>(h->idx.p, h->w.p, (const float *)src, (TD *)dst, P, h->n_src, nlev, ntile, nfields, fpw, scale, offset);
+          MPG_HIP(hipGetLastError());
+          return MPG_SUCCESS;
+        }
+        int rc0;
+        switch (mpg_lf_variant()) {   // 401-403: occupancy experiments (registers capped for 5 / 6 / 8 waves per SIMD)
+          case 401: rc0 = go(k_apply3_lf_f32x2<TD, 8, 1>); break;
+          case 402: rc0 = go(k_apply3_lf_f32x2<TD, 5, 2>); break;
+          case 403: rc0 = go(k_apply3_lf_f32x2<TD, 8, 2>); break;
+          default: rc0 = go(k_apply3_lf_f32x2<TD, 4, 4>); break;
+        }
+        if (rc0) return rc0;
       } else {
         if (lds > 48 * 1024)
           MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_apply3_lf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
-                                                                             h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
+        const int ntxs = mpg_tile_ntx(h->nx_dst, 64);
+        k_apply3_lf_t<TS, TD><<<(unsigned)ntxs * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
+                                                                              h->ny_dst, h->n_src, nlev, ntxs, nty, scale, offset);
       }
     } else {
-      int ntx = (h->nx_dst + 63) / 64, nty = (h->ny_dst + 7) / 8;
+      int ntx = mpg_tile_ntx(h->nx_dst, 64), nty = (h->ny_dst + 7) / 8;
       k_apply3_cf_t<TS, TD><<<(unsigned)ntx * nty * nfields, 256, 0, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
                                                                          h->ny_dst, h->n_src, nlev, ntx, nty, scale, offset);
     }
@@ -276,17 +376,16 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout,
     MPG_HIP(hipMemsetAsync(dst, 0, (dst_f32 ? 4 : 8) * (size_t)h->n_dst * nlev * nfields, s));
     return MPG_SUCCESS;
   }
-  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_CELL_FAST && mpg_a3_staged() != -2 && !(h->cf_choice < 0 && h->cf_for == 1)) {
+  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_CELL_FAST && mpg_a3_staged() != -2 && !h->cft_unfit) {
     int rc = mpg_k_apply3_cfu_typed(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);  // LDS-staged (k_apply_lfu.hip)
     if (rc != MPG_ERR_UNSUPPORTED) return rc;
-    h->cf_choice = -1;  // tile lists too long for the staged kernel: lane-gather from now on
-    h->cf_for = 1;
+    h->cft_unfit = true;  // tile lists too long for the staged typed kernel: lane-gather from now on (decided once per handle)
   }
   if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() == 200) {
     int rc = mpg_k_apply3_lfr(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
     if (rc != MPG_ERR_UNSUPPORTED) return rc;
   }
-  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() >= 300) {
+  if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3 && layout == MPG_LAYOUT_LEV_FAST && mpg_lf_variant() >= 300 && mpg_lf_variant() < 400) {
     int rc = mpg_k_apply3_lfs(h, mpg_lf_variant() - 300, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, (size_t)160 * 1024, s);
     if (rc == MPG_SUCCESS && h->n_pole) rc = mpg_k_pole_fix(h, src, src_f32, layout, nlev, nfields, dst, dst_f32, scale, offset, s);
     if (rc != MPG_ERR_UNSUPPORTED) return rc;

@@ -605,6 +605,7 @@ static void lf_invalidate(mpg_handle_s *h) {
   h->free_tile_lists();
   h->lf_choice = 0;
   h->cf_choice = 0;
+  h->cft_unfit = false;
 }
 
 // ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------

@@ -9,6 +9,18 @@
 
 #include "../../include/mpassit_amd.h"
 
+// Tiles of the Regrid kernels are txu x tyu target points whose x origin is shifted per grid row so that every segment of a
+// row a workgroup stores starts at a multiple of MPG_TILE_ALIGN elements of the flattened [ny][nx] plane (128 bytes for
+// float32, 256 for float64): with nx = 1800 the unshifted 64-point segments start 32 / 64 / 96 bytes into a line in three
+// rows of four, and aligned segments were measured 4 % (float64 cell-fast), 5 % (float64 level-fast) and 17 % (float32
+// cell-fast) faster on configuration 4 (profiles/r02_alignment.txt).  Tile column tx of row j holds
+// i = tx * txu - mpg_tile_shift(j, nx) + 0 .. txu-1; points with i < 0 or i >= nx do not exist.
+#ifndef MPG_TILE_ALIGN
+#define MPG_TILE_ALIGN 32
+#endif
+static inline __host__ __device__ int mpg_tile_shift(int j, int nx, int align = MPG_TILE_ALIGN) { return align > 1 ? (int)(((long long)j * nx) % align) : 0; }
+static inline int mpg_tile_ntx(int nx, int txu, int align = MPG_TILE_ALIGN) { return (nx + (align > 1 && nx % align ? align - 1 : 0) + txu - 1) / txu; }
+
 #define MPG_WAVE 64
 
 void mpg_set_error(const char *fmt, ...);
@@ -187,18 +199,20 @@ struct mpg_handle_s {
   DevBuf<double> pole_w;
   // per-tile unique source cells of the LDS-staged level-fast Regrid (k_apply_lfu.hip), built on first use
   int ut_rpt = 0, ut_max = 0;
+  int ut_align = MPG_TILE_ALIGN;   // row shift of the tiles these lists were built for (1: none -- the shifted tiles' lists did not fit)
   int64_t ut_total = 0;
   int64_t ut_lines = 0, ut2_lines = 0;   // sum over the tiles of the distinct groups of 16 consecutive cell ids in their lists
   int lf_choice = 0;      // level-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 row-gather
   int cf_choice = 0;      // cell-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 lane-gather
   int cf_for = -99;       // "a3_staged" knob value the choice was made for
+  bool cft_unfit = false; // the typed staged cell-fast kernel (fixed 64 x 8 tiles, 1024 cells) does not fit this handle
   float lf_reuse = 0.f;   // 3 * n_dst / (sum of the tiles' unique cells): references per staged row
   DevBuf<int32_t> ut_ptr, ut_cells;
   DevBuf<uint16_t> lidx;  // [3][n_dst] positions in the tile's list, 0xFFFF = unmapped
   // a second, parked set of tile lists: a job that alternates layouts on one handle (2-D fields cell-fast, 3-D fields
   // in file order) needs two tile shapes in turn; the lists of the shape not in use wait here and are swapped back in
   // instead of being rebuilt (a rebuild allocates and synchronises, which would also break hipGraph capture)
-  int ut2_rpt = 0, ut2_max = 0;
+  int ut2_rpt = 0, ut2_max = 0, ut2_align = MPG_TILE_ALIGN;
   int64_t ut2_total = 0;
   DevBuf<int32_t> ut2_ptr, ut2_cells;
   DevBuf<uint16_t> lidx2;
@@ -233,6 +247,8 @@ int mpg_lfu_num_variants();
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_cfu_num_variants();
 void mpg_cfu_set_fields_per_wg(int v);
+void mpg_set_tile_band(int v);
+int mpg_tile_band();
 int mpg_a3_staged();  // current "a3_staged" knob
 int mpg_lf_variant(); // current "lf_variant" knob
 int mpg_k_apply3_lfr(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale, double offset,

@@ -28,6 +28,12 @@ def workload(name, arrays=True):
         g = conus_lambert_grid()
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
         return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1801x1061 Lambert (1800x1060 mass points)"
+    if name == "x_c4_nx1793":
+        # extra (alignment experiment): configuration 4's mesh under a grid 1792 mass points wide -- every row of the output
+        # planes starts on a 128-byte line for float32 and float64 alike
+        g = conus_lambert_grid(nx=1793)
+        m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
+        return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1793x1061 Lambert (1792x1060 mass points)"
     if name == "c2_655k_global":
         # BASELINE configs 2 and 3: the GLOBAL quasi-uniform 655 362-cell mesh (10*4^8 + 2 cells = MPAS x1.655362, SURVEY
         # s8(d)) under the README Lambert domain, which touches only 2-3 % of its cells; Morton-numbered.

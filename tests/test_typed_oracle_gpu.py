@@ -18,6 +18,7 @@ KERNELS = [                    # (a3_staged, lf_variant): which kernel family se
     (1, 100),                  # LDS-staged cell-fast / LDS-staged level-fast, forced
     (13, 106),                 # the tile shapes bench.py's default run ends up with on C4 / the pipelined staged variant
     (-1, 300), (-1, 301), (-1, 302),   # rows-resident level-fast kernel k_apply3_lfs, tiles 64x1 / 64x2 / 64x4
+    (-2, 401), (-2, 410), (-2, 413), (-2, 417),   # float32 row gather: 64x1 tiles at 8 waves / SIMD; linear tiles, 1 / all fields per WG, unroll 4
 ]
 
 

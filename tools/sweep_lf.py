@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--plain", action="store_true", help="float64 through mpg_regrid_dev (the headline entry point; honours a3_staged / lf_variant 100..)")
     ap.add_argument("--nlev", type=int, default=0, help="override the workload's level count (alignment experiments)")
     ap.add_argument("--knob", default="", help="knob to sweep instead of lf_variant (e.g. a3_staged with --layout cell_fast)")
+    ap.add_argument("--set", default="", help="knobs held fixed during the sweep: key=value[,key=value]")
     args = ap.parse_args()
     import torch
     from mpassit_amd import _lib, regrid as R, workloads
@@ -50,6 +51,8 @@ def main():
             rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
         else:
             rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out, scale=9.81, offset=-300.0)
+    for kv in filter(None, args.set.split(",")):
+        _lib.tune(kv.split("=")[0], int(kv.split("=")[1]))
     times = {v: [] for v in variants}
     ref = None
     for rnd in range(args.rounds + 1):
@@ -70,7 +73,7 @@ def main():
             torch.cuda.synchronize()
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1) / 3)
-    _lib.tune(knob, -1)
+    _lib.tune(knob, 0 if knob == "tile_band" else -1)
     res = []
     for v, ts in times.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
