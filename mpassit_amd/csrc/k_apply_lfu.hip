@@ -30,12 +30,12 @@
 // ---- per-tile unique cell lists (set-up, runtime tile shape) --------------------------------------------------
 // One workgroup per tile of txu x tyu points: the 3*np cell ids are sorted in LDS (bitonic), duplicates dropped,
 // and each point's three ids are replaced by their rank in the tile's list.  FILL = false only counts.
-template <bool FILL>
+template <bool FILL, int SB = LFU_SORT>
 __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__restrict__ idx, int nx, int ny, int talign, int txu, int tyu, int ntx,
                                                            int32_t *__restrict__ ut_count, const int32_t *__restrict__ ut_ptr,
                                                            int32_t *__restrict__ ut_cells, uint16_t *__restrict__ lidx,
                                                            unsigned long long *__restrict__ line_count) {
-  constexpr int SB = LFU_SORT, PER = SB / LFU_THREADS;
+  constexpr int PER = SB / LFU_THREADS;
   __shared__ int32_t keys[SB];
   __shared__ int32_t part[LFU_THREADS + 1];
   const int np = txu * tyu, nk = 3 * np;
@@ -125,18 +125,18 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
 // ---- Regrid ---------------------------------------------------------------------------------------------
 // Thread t serves points pt = t + 256*r (r < RPT) of the tile in row-major order: a wave covers 64 consecutive
 // points = 64/TXU rows of TXU points (512-, 256- or 128-byte store segments).
-template <int TXU, int RPT>
+template <int TXU, int RPT, int NT = LFU_THREADS>
 struct LfuPoints {
   int l[RPT][3];
   double ww[RPT][3];
   bool act[RPT], mapped[RPT];
   int64_t off[RPT];  // j*nx + i
   __device__ __forceinline__ void load(const uint16_t *__restrict__ lidx, const double *__restrict__ w, int nx, int ny, int talign, int tx, int ty, int LS) {
-    constexpr int TY = LFU_THREADS * RPT / TXU;
+    constexpr int TY = NT * RPT / TXU;
     const int64_t P = (int64_t)nx * ny;
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      int pt = (int)threadIdx.x + LFU_THREADS * r;
+      int pt = (int)threadIdx.x + NT * r;
       int j = ty * TY + pt / TXU, i = tx * TXU + pt % TXU - mpg_tile_shift(j, nx, talign);
       act[r] = i >= 0 && i < nx && j < ny;
       off[r] = act[r] ? (int64_t)j * nx + i : 0;
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu_p(const int32_t *__r
 // the tile's unique cells once (lanes along the sorted cell list: neighbouring ids, coalesced) into LDS [LC][NUP] and
 // the points combine from there.  Same tile lists, same wsum3 arithmetic; chunk c+1 is prefetched into registers
 // (NPF = LC * ceil(NUP/256) values) while chunk c is combined and stored.
-template <int TXU, int RPT, int LC, int NPF>
-__global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
+template <int TXU, int RPT, int LC, int NPF, int NT = LFU_THREADS>
+__global__ __launch_bounds__(NT) void k_apply3_cfu_p(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                               const double *__restrict__ src, double *__restrict__ dst, int nx, int ny, int talign,
                                                               int64_t nsrc, int nlev, int ntx, int nty, int nfields, int ut_max) {
@@ -294,14 +294,14 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
   nlev = min(fpw, nf - f) * nlev_all;
   const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
-  LfuPoints<TXU, RPT> pts;
+  LfuPoints<TXU, RPT, NT> pts;
   pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, 1);
   const double *sf = src + (int64_t)f * nlev_all * nsrc;
   double *df = dst + (int64_t)f * nlev_all * P;
   int32_t cell[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
-    int q = t + LFU_THREADS * u;
+    int q = t + NT * u;
     cell[u] = q < nU ? ut_cells[u0 + q] : -1;
   }
   double pf[NPF];
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
     for (int lv = 0; lv < LC; ++lv)
 #pragma unroll
       for (int u = 0; u < UPT; ++u)
-        if (cell[u] >= 0) lds[lv * nup + t + LFU_THREADS * u] = pf[lv * UPT + u];
-    for (int q = t + LFU_THREADS * UPT; q < nU; q += LFU_THREADS) {  // surplus cells of an unusually large tile
+        if (cell[u] >= 0) lds[lv * nup + t + NT * u] = pf[lv * UPT + u];
+    for (int q = t + NT * UPT; q < nU; q += NT) {  // surplus cells of an unusually large tile
       int32_t c = ut_cells[u0 + q];
       for (int lv = 0; lv < LC; ++lv) lds[lv * nup + q] = (k0 + lv < nlev) ? sf[(int64_t)(k0 + lv) * nsrc + c] : 0.0;
     }
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_p(const int32_t *__r
 
 typedef void (*lfu_fn)(const int32_t *, const int32_t *, const uint16_t *, const double *, const double *, double *, int, int, int, int64_t,
                        int, int, int, int, int);
-struct LfuVariant { int txu, rpt, lc; lfu_fn fn; };
+struct LfuVariant { int txu, rpt, lc; lfu_fn fn; int nt = LFU_THREADS; };   // tile = txu x (nt * rpt / txu) points
 static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 100 + index
     {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 8>},   {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 12>},  {64, 2, 8, k_apply3_cfu_p<64, 2, 8, 16>},
     {64, 1, 4, k_apply3_cfu_p<64, 1, 4, 4>},   {64, 1, 8, k_apply3_cfu_p<64, 1, 8, 8>},   {64, 1, 8, k_apply3_cfu_p<64, 1, 8, 16>},
@@ -354,6 +354,9 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16>},  {64, 4, 2, k_apply3_cfu_p<64, 4, 2, 8>},   {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 20>},
     // 13: 64 x 8 tiles with room for 1024 unique cells per tile (C4 needs 756 of the 768 that variant 1 holds)
     {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 16>},
+    // 14-15: 64 x 32-point tiles served by 512 threads (4 points each): half the tile-edge re-reads of 64 x 16 where a tile
+    // has few cells per point (a global lat-lon grid finer than its mesh, C5); room for 1536 / 2048 cells per tile
+    {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 12, 512>, 512}, {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16, 512>, 512},
     // (compact tiles of 32 x 32, 16 x 64 and 32 x 16 points with the same 1024-cell capacity were measured in round 2 on C4,
     //  Morton-numbered C4, C2 and C5: 0-15 % slower than 64 x 8 / 64 x 16 everywhere, profiles/r02_sweep_cfu_compact.txt)
 };
@@ -364,8 +367,13 @@ static int g_cfu_fpw = 1;   // "cfu_fields_per_wg": fields of a bundle served by
 void mpg_cfu_set_fields_per_wg(int v) { g_cfu_fpw = v < 1 ? 1 : (v > 255 ? 255 : v); }
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
-static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16};
-static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * LFU_THREADS; }
+static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16, 12, 16};
+static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * g_cfu_variants[variant].nt; }
+static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap = 1024);
+static int cfu_build(mpg_handle_s *h, int variant, hipStream_t s) {
+  const LfuVariant &v = g_cfu_variants[variant];
+  return lfu_build_shape(h, v.txu, v.nt * v.rpt / v.txu, s, cfu_capacity(variant) > 1024 ? cfu_capacity(variant) : 1024);
+}
 static const LfuVariant g_lfu_variants[] = {
     // 0-5: two-phase, 64-wide tiles
     {64, 1, 8, k_apply3_lfu<64, 1, 8>},   {64, 1, 16, k_apply3_lfu<64, 1, 16>}, {64, 2, 8, k_apply3_lfu<64, 2, 8>},
@@ -380,11 +388,11 @@ static const LfuVariant g_lfu_variants[] = {
 };
 int mpg_lfu_num_variants() { return (int)(sizeof(g_lfu_variants) / sizeof(g_lfu_variants[0])); }
 
-static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s);
 static int lfu_build(mpg_handle_s *h, int txu, int rpt, hipStream_t s) { return lfu_build_shape(h, txu, LFU_THREADS * rpt / txu, s); }
 
+
 // tile lists for tiles of txu x tyu target points (cached in the handle, keyed by the shape)
-static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
+static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap) {
   const int key = txu * 1024 + tyu;
   if (h->ut_rpt == key) return MPG_SUCCESS;
   if (h->ut2_rpt == key) {  // the other layout's shape: swap the parked lists in, no device work
@@ -418,7 +426,8 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
   h->ut_ptr.free();
   h->ut_cells.free();
   h->ut_rpt = 0;
-  if (3 * txu * tyu > LFU_SORT) {
+  const bool big = 3 * txu * tyu > LFU_SORT;   // tiles of more than 1365 points sort in an 8192-entry buffer
+  if (3 * txu * tyu > 2 * LFU_SORT) {
     mpg_set_error("staged Regrid: tile of %d x %d points exceeds the sort buffer", txu, tyu);
     return MPG_ERR_UNSUPPORTED;
   }
@@ -443,8 +452,12 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     if ((rc = count.alloc(ntile + 1)) || (rc = h->ut_ptr.alloc(ntile + 1))) return rc;
     if (!h->lidx.p && (rc = h->lidx.alloc(3 * (size_t)h->n_dst))) return rc;
     MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (ntile + 1), s));
-    k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, count.p, nullptr, nullptr,
-                                                              nullptr, nullptr);
+    if (big)
+      k_lfu_build<false, 2 * LFU_SORT><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, count.p,
+                                                                              nullptr, nullptr, nullptr, nullptr);
+    else
+      k_lfu_build<false><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, count.p, nullptr, nullptr,
+                                                                nullptr, nullptr);
     MPG_HIP(hipGetLastError());
     // list offsets and the longest list on the device (rocPRIM scan / reduce); only three scalars come back to the host
     size_t b_scan = 0, b_max = 0;
@@ -459,7 +472,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
     MPG_HIP(hipMemcpyAsync(&tot32, h->ut_ptr.p + ntile, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MPG_HIP(hipMemcpyAsync(&max32, (int32_t *)(scal.p + 1), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MPG_HIP(hipStreamSynchronize(s));
-    if (h->ut_align > 1 && max32 > 1024) {
+    if (h->ut_align > 1 && max32 > cap) {
       h->ut_align = 1;
       continue;
     }
@@ -471,8 +484,12 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s) {
   }
   const int64_t tot = tot32;
   if ((rc = h->ut_cells.alloc((size_t)tot + 1))) return rc;
-  k_lfu_build<true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, nullptr, h->ut_ptr.p, h->ut_cells.p,
-                                                           h->lidx.p, scal.p);
+  if (big)
+    k_lfu_build<true, 2 * LFU_SORT><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, nullptr,
+                                                                           h->ut_ptr.p, h->ut_cells.p, h->lidx.p, scal.p);
+  else
+    k_lfu_build<true><<<(unsigned)ntile, LFU_THREADS, 0, s>>>(h->idx.p, h->nx_dst, h->ny_dst, h->ut_align, txu, tyu, ntx, nullptr, h->ut_ptr.p,
+                                                             h->ut_cells.p, h->lidx.p, scal.p);
   MPG_HIP(hipGetLastError());
   unsigned long long hs[2] = {0, 0};
   MPG_HIP(hipMemcpyAsync(hs, scal.p, sizeof(hs), hipMemcpyDeviceToHost, s));
@@ -529,13 +546,13 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
   if (h->cf_choice == 0 || h->cf_for != -1) {
     h->cf_for = -1;
-    int rc = lfu_build(h, g_cfu_variants[CFU_WIDE].txu, g_cfu_variants[CFU_WIDE].rpt, s);
+    int rc = cfu_build(h, CFU_WIDE, s);
     if (rc) return rc;
     float reuse = h->ut_total > 0 ? 3.0f * (float)h->n_dst / (float)h->ut_total : 0.f;
     if (reuse >= LFU_AUTO_MIN_REUSE && h->ut_max <= cfu_capacity(CFU_WIDE)) {
       h->cf_choice = CFU_WIDE + 1;
     } else {
-      if ((rc = lfu_build(h, g_cfu_variants[CFU_BASE].txu, g_cfu_variants[CFU_BASE].rpt, s))) return rc;
+      if ((rc = cfu_build(h, CFU_BASE, s))) return rc;
       h->cf_choice = h->ut_max <= cfu_capacity(CFU_BASE) ? CFU_BASE + 1 : -1;
     }
     if (h->cf_choice < 0 && h->lf_choice <= 0) {
@@ -824,8 +841,7 @@ int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nl
 int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits) {
   if (h->cf_choice == 0 || h->cf_for != variant) {
     h->cf_for = variant;
-    const LfuVariant &v = g_cfu_variants[variant];
-    int rc = lfu_build(h, v.txu, v.rpt, s);
+    int rc = cfu_build(h, variant, s);
     if (rc) return rc;
     h->cf_choice = h->ut_max <= cfu_capacity(variant) ? variant + 1 : -1;
     if (h->cf_choice < 0 && h->lf_choice <= 0) {
@@ -841,9 +857,9 @@ int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits) {
 
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
   const LfuVariant &v = g_cfu_variants[variant];
-  int rc = lfu_build(h, v.txu, v.rpt, s);
+  int rc = cfu_build(h, variant, s);
   if (rc) return rc;
-  const int tyu = LFU_THREADS * v.rpt / v.txu;
+  const int tyu = v.nt * v.rpt / v.txu;
   const int ntx = mpg_tile_ntx(h->nx_dst, v.txu, h->ut_align), nty = (h->ny_dst + tyu - 1) / tyu;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   size_t lds = sizeof(double) * um * v.lc + 16;
@@ -858,7 +874,7 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
   }
   const int fpw = g_cfu_fpw < nfields ? g_cfu_fpw : nfields;
   const int ngroups = (nfields + fpw - 1) / fpw;
-  v.fn<<<(unsigned)ntx * nty * ngroups, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->ut_align,
+  v.fn<<<(unsigned)ntx * nty * ngroups, v.nt, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->ut_align,
                                                               h->n_src, nlev, ntx, nty, nfields | ((fpw & 0xff) << 16) | (g_tile_band << 24), (int)um);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;

@@ -229,31 +229,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   for (int f = f0; f < f1; ++f) {
     const float *sf = src + (int64_t)f * nlev * nsrc;
     for (int kb = 0; kb < nlev; kb += 64) {
+      // Branch-free body (a divergent `mapped ?` / `level < nlev ?` made the compiler wait for each point's three loads before
+      // it issued the next point's): lanes past the end of a row are clamped onto its last two levels and re-write the
+      // values of level nlev-1 where the lane that owns that level writes the same bits; unmapped points read row 0 and
+      // their result is masked to +0.0 before the epilogue.
       const int k0 = kb + 2 * sl;
-      const int base = min(k0, nlev - 2);            // base < k0 only on the lane that holds the end of the row
-      const bool shifted = base != k0, a0 = k0 < nlev, a1 = k0 + 1 < nlev;
+      const int base = min(k0, nlev - 2);
+      const bool shifted = base != k0;
+      const int kw0 = min(k0, nlev - 1) * 65, kw1 = min(k0 + 1, nlev - 1) * 65;
 #pragma unroll UNR
       for (int q0 = 0; q0 < 16; q0 += 4) {
-        double v[2][2];
+        f32x2_u x[2][3];
+        double ww[2][3];
+        unsigned long long keep[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int pt = wave * 16 + q0 + 2 * u + half;
           uint32_t o0 = soff[pt], o1 = soff[64 + pt], o2 = soff[128 + pt];
-          const double w0 = sw[pt], w1 = sw[64 + pt], w2 = sw[128 + pt];
+          ww[u][0] = sw[pt]; ww[u][1] = sw[64 + pt]; ww[u][2] = sw[128 + pt];
           const bool m = o0 != 0xFFFFFFFFu;
+          keep[u] = m ? ~0ull : 0ull;
           o0 = m ? o0 : 0u; o1 = m ? o1 : 0u; o2 = m ? o2 : 0u;
-          const f32x2_u x0 = *(const f32x2_u *)(sf + (o0 + (uint32_t)base));
-          const f32x2_u x1 = *(const f32x2_u *)(sf + (o1 + (uint32_t)base));
-          const f32x2_u x2 = *(const f32x2_u *)(sf + (o2 + (uint32_t)base));
-          const double a = shifted ? x0.y : x0.x, b = shifted ? x1.y : x1.x, e = shifted ? x2.y : x2.x;
-          v[u][0] = fma(m ? wsum3(w0, a, w1, b, w2, e) : 0.0, scale, offset);
-          v[u][1] = fma(m ? wsum3(w0, (double)x0.y, w1, (double)x1.y, w2, (double)x2.y) : 0.0, scale, offset);
+          x[u][0] = *(const f32x2_u *)(sf + (o0 + (uint32_t)base));
+          x[u][1] = *(const f32x2_u *)(sf + (o1 + (uint32_t)base));
+          x[u][2] = *(const f32x2_u *)(sf + (o2 + (uint32_t)base));
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int pt = wave * 16 + q0 + 2 * u + half;
-          if (a0) tile[k0 * 65 + pt] = (TD)v[u][0];
-          if (a1) tile[(k0 + 1) * 65 + pt] = (TD)v[u][1];
+          const double a = shifted ? x[u][0].y : x[u][0].x, b = shifted ? x[u][1].y : x[u][1].x, e = shifted ? x[u][2].y : x[u][2].x;
+          const double r0 = wsum3(ww[u][0], a, ww[u][1], b, ww[u][2], e);
+          const double r1 = wsum3(ww[u][0], (double)x[u][0].y, ww[u][1], (double)x[u][1].y, ww[u][2], (double)x[u][2].y);
+          const double v0 = fma(__longlong_as_double((long long)((unsigned long long)__double_as_longlong(r0) & keep[u])), scale, offset);
+          const double v1 = fma(__longlong_as_double((long long)((unsigned long long)__double_as_longlong(r1) & keep[u])), scale, offset);
+          tile[kw0 + pt] = (TD)v0;
+          tile[kw1 + pt] = (TD)v1;
         }
       }
     }
