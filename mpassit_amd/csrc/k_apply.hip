@@ -316,7 +316,7 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "lf_fields_per_wg")) { g_lf_fpw = value < 1 ? 1 : value; return MPG_SUCCESS; }
   if (!strcmp(key, "lf_variant")) {  // 0.. : k_apply3_lf variants; 100.. : LDS-staged unique-cell variants (k_apply_lfu.hip)
     if (value == -1 || value == 200 || (value >= 100 && value < 100 + mpg_lfu_num_variants()) ||
-        (value >= 300 && value < 300 + mpg_lfs_num_variants()) || (value >= 400 && value < 420)) {  // 200: rows-resident (32 x 4); 300..: rows-resident, deep prefetch (k_apply_lfs.hip)
+        (value >= 300 && value < 300 + mpg_lfs_num_variants()) || (value >= 400 && value < 420) || value == 500) {  // 200: rows-resident (32 x 4); 300..: rows-resident, deep prefetch (k_apply_lfs.hip)
       g_lf_variant = value;
       return MPG_SUCCESS;
     }
@@ -365,14 +365,21 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
     if (lev_fast && lfv < 0) {  // auto: per handle, by the reuse statistic of its tile lists (k_apply_lfu.hip)
       int pick, rc = mpg_lfu_auto(h, s, &pick);
       if (rc) return rc;
-      lfv = pick >= 0 ? 100 + pick : LF_DEFAULT_ROW_GATHER;
+      lfv = pick >= 0 ? 100 + pick : 500;
     }
     if (lev_fast && lfv == 200) {
       int rc = mpg_k_apply3_lfr(h, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, s);
       if (rc != MPG_ERR_UNSUPPORTED) return rc;
       lfv = LF_DEFAULT_ROW_GATHER;  // rows of a tile do not fit the LDS
     }
-    if (lev_fast && lfv >= 400) lfv = LF_DEFAULT_ROW_GATHER;  // 400..: experiments of the typed float32 kernel only
+    if (lev_fast && lfv >= 400) {  // 500 (and the 400.. experiment numbers of the typed entry): row gather on linear aligned tiles
+      int rc = mpg_k_apply3_lf_rows(h, src, nlev, nfields, dst, s);   // k_apply_typed.hip: k_apply3_lf_f32m<double, double>
+      if (rc != MPG_ERR_UNSUPPORTED) {
+        if (rc == MPG_SUCCESS && h->n_pole) return mpg_k_pole_fix(h, src, 0, layout, nlev, nfields, dst, 0, 1.0, 0.0, s);
+        return rc;
+      }
+      lfv = LF_DEFAULT_ROW_GATHER;
+    }
     if (lev_fast && lfv >= 300) {
       int rc = mpg_k_apply3_lfs(h, lfv - 300, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, (size_t)160 * 1024, s);
       if (rc != MPG_ERR_UNSUPPORTED) {

@@ -203,10 +203,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 // rows of four: 10 % more bytes written, PMC, and two partial lines per store); the three cell offsets (premultiplied by
 // nlev, 32 bit, added to a scalar field base: no 64-bit address arithmetic per load) and weights of the tile are fetched
 // ONCE and serve `fpw` fields of the bundle (per field they are 36 of the 542 bytes a point moves at 55 float32 levels).
-template <typename TD, int UNR, int WPE>
+// TS = float64 rows work the same way with one 16-byte load per lane (rows are 8-byte aligned); EPI = false leaves the
+// affine epilogue out (mpg_regrid_dev: the float64 result as it stands, sign of zero included).
+typedef double f64x2_u __attribute__((ext_vector_type(2), aligned(8)));
+template <typename TS> struct Row2;
+template <> struct Row2<float> { typedef f32x2_u type; };
+template <> struct Row2<double> { typedef f64x2_u type; };
+
+template <typename TS, typename TD, int UNR, int WPE, bool EPI = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void k_apply3_lf_f32m(
-    const int32_t *__restrict__ idx, const double *__restrict__ w, const float *__restrict__ src, TD *__restrict__ dst, int64_t P, int64_t nsrc,
+    const int32_t *__restrict__ idx, const double *__restrict__ w, const TS *__restrict__ src, TD *__restrict__ dst, int64_t P, int64_t nsrc,
     int nlev, unsigned ntile, int nfields, int fpw, double scale, double offset) {
+  typedef typename Row2<TS>::type row2;
   extern __shared__ double sw[];                    // sw[3][64] | soff[3][64] | tile[nlev][65] in the destination type
   uint32_t *soff = (uint32_t *)(sw + 192);
   TD *tile = (TD *)(soff + 192);
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
   const int half = lane >> 5, sl = lane & 31;
   const bool store_lane = p0 + lane < P;
   for (int f = f0; f < f1; ++f) {
-    const float *sf = src + (int64_t)f * nlev * nsrc;
+    const TS *sf = src + (int64_t)f * nlev * nsrc;
     for (int kb = 0; kb < nlev; kb += 64) {
       // Branch-free body (a divergent `mapped ?` / `level < nlev ?` made the compiler wait for each point's three loads before
       // it issued the next point's): lanes past the end of a row are clamped onto its last two levels and re-write the
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
       const int kw0 = min(k0, nlev - 1) * 65, kw1 = min(k0 + 1, nlev - 1) * 65;
 #pragma unroll UNR
       for (int q0 = 0; q0 < 16; q0 += 4) {
-        f32x2_u x[2][3];
+        row2 x[2][3];
         double ww[2][3];
         unsigned long long keep[2];
 #pragma unroll
@@ -250,9 +258,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           const bool m = o0 != 0xFFFFFFFFu;
           keep[u] = m ? ~0ull : 0ull;
           o0 = m ? o0 : 0u; o1 = m ? o1 : 0u; o2 = m ? o2 : 0u;
-          x[u][0] = *(const f32x2_u *)(sf + (o0 + (uint32_t)base));
-          x[u][1] = *(const f32x2_u *)(sf + (o1 + (uint32_t)base));
-          x[u][2] = *(const f32x2_u *)(sf + (o2 + (uint32_t)base));
+          x[u][0] = *(const row2 *)(sf + (o0 + (uint32_t)base));
+          x[u][1] = *(const row2 *)(sf + (o1 + (uint32_t)base));
+          x[u][2] = *(const row2 *)(sf + (o2 + (uint32_t)base));
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -260,8 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
           const double a = shifted ? x[u][0].y : x[u][0].x, b = shifted ? x[u][1].y : x[u][1].x, e = shifted ? x[u][2].y : x[u][2].x;
           const double r0 = wsum3(ww[u][0], a, ww[u][1], b, ww[u][2], e);
           const double r1 = wsum3(ww[u][0], (double)x[u][0].y, ww[u][1], (double)x[u][1].y, ww[u][2], (double)x[u][2].y);
-          const double v0 = fma(__longlong_as_double((long long)((unsigned long long)__double_as_longlong(r0) & keep[u])), scale, offset);
-          const double v1 = fma(__longlong_as_double((long long)((unsigned long long)__double_as_longlong(r1) & keep[u])), scale, offset);
+          double v0 = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(r0) & keep[u]));
+          double v1 = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(r1) & keep[u]));
+          if constexpr (EPI) {
+            v0 = fma(v0, scale, offset);
+            v1 = fma(v1, scale, offset);
+          }
           tile[kw0 + pt] = (TD)v0;
           tile[kw1 + pt] = (TD)v1;
         }
@@ -321,6 +333,24 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
         mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
         return MPG_ERR_UNSUPPORTED;
       }
+      // default: linear 64-point tiles, 32-bit row offsets, two levels per lane (k_apply3_lf_f32m, float32 and float64 rows);
+      // lf_variant 4 / 401-403 keep the 64 x 1 tiles of a grid row for comparison, 410-418 are the measured alternatives
+      // (fields per workgroup, unroll, occupancy)
+      const int lfv = mpg_lf_variant();
+      if (nlev >= 2 && !(lfv == 4 || (lfv >= 401 && lfv <= 403)) && (uint64_t)h->n_src * (uint64_t)nlev < 0xFFFFFFFFull) {
+        static const int fpws[] = {1, 2, 4, 1 << 20, 13, 7, 1, 1, 1, 1};
+        const int v = (lfv >= 410 && lfv < 420) ? lfv - 410 : (sizeof(TS) == 4 ? 6 : 0);   // measured: unroll 2 for float32 rows, 1 for float64
+        const int fpw = std::min(nfields, fpws[v]);
+        const unsigned ntile = (unsigned)((P + 63) / 64), ngroups = (unsigned)((nfields + fpw - 1) / fpw);
+        auto fn = k_apply3_lf_f32m<TS, TD, 1, 8>;
+        if (v == 6) fn = k_apply3_lf_f32m<TS, TD, 2, 8>;
+        if (v == 7) fn = k_apply3_lf_f32m<TS, TD, 4, 4>;
+        if (v == 8) fn = k_apply3_lf_f32m<TS, TD, 2, 6>;
+        if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fn<<<ntile * ngroups, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, nfields, fpw, scale, offset);
+        MPG_HIP(hipGetLastError());
+        return MPG_SUCCESS;
+      }
       if (sizeof(TS) == 4 && nlev >= 2) {   // float32 rows: two levels per lane, two points per wavefront pass
         auto go = [&](auto fn) -> int {
           if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -328,23 +358,6 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
                                                             ntx, nty, scale, offset, (unsigned)mpg_tile_band());
           return MPG_SUCCESS;
         };
-        // default: linear 64-point tiles, 32-bit row offsets (k_apply3_lf_f32m); lf_variant 4 / 401-403 keep the 64 x 1 tiles of
-        // a grid row for comparison, 410-418 are the measured alternatives (fields per workgroup, unroll, occupancy)
-        const int lfv = mpg_lf_variant();
-        if (!(lfv == 4 || (lfv >= 401 && lfv <= 403)) && (uint64_t)h->n_src * (uint64_t)nlev < 0xFFFFFFFFull) {
-          static const int fpws[] = {1, 2, 4, 1 << 20, 13, 7, 1, 1, 1, 1};
-          const int v = (lfv >= 410 && lfv < 420) ? lfv - 410 : 6;
-          const int fpw = std::min(nfields, fpws[v]);
-          const unsigned ntile = (unsigned)((P + 63) / 64), ngroups = (unsigned)((nfields + fpw - 1) / fpw);
-          auto fn = k_apply3_lf_f32m<TD, 1, 8>;
-          if (v == 6) fn = k_apply3_lf_f32m<TD, 2, 8>;
-          if (v == 7) fn = k_apply3_lf_f32m<TD, 4, 4>;
-          if (v == 8) fn = k_apply3_lf_f32m<TD, 2, 6>;
-          if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          fn<<<ntile * ngroups, 256, lds, s>>>(h->idx.p, h->w.p, (const float *)src, (TD *)dst, P, h->n_src, nlev, ntile, nfields, fpw, scale, offset);
-          MPG_HIP(hipGetLastError());
-          return MPG_SUCCESS;
-        }
         int rc0;
         switch (mpg_lf_variant()) {   // 401-403: occupancy experiments (registers capped for 5 / 6 / 8 waves per SIMD)
           case 401: rc0 = go(k_apply3_lf_f32x2<TD, 8, 1>); break;
@@ -371,6 +384,20 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
                                                                       h->rowptr.p, h->col.p, h->val.p, (const TS *)src, (TD *)dst, P,
                                                                       h->n_src, nlev, lev_fast, nblk, scale, offset);
   }
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+// float64 rows in, float64 out, no epilogue: the level-fast row gather of mpg_regrid_dev (k_apply.hip).
+// -> MPG_ERR_UNSUPPORTED when the 32-bit row offsets or the LDS tile do not fit (the caller keeps its older kernel).
+int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
+  const int64_t P = h->n_dst;
+  const size_t lds = sizeof(double) * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192;
+  if (nlev < 2 || (uint64_t)h->n_src * (uint64_t)nlev >= 0xFFFFFFFFull || lds > 160 * 1024) return MPG_ERR_UNSUPPORTED;
+  const unsigned ntile = (unsigned)((P + 63) / 64);
+  auto fn = k_apply3_lf_f32m<double, double, 1, 8, false>;
+  if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, nfields, 1, 1.0, 0.0);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

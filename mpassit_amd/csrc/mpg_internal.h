@@ -248,6 +248,7 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, 
 int mpg_cfu_num_variants();
 void mpg_cfu_set_fields_per_wg(int v);
 void mpg_set_tile_band(int v);
+int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_tile_band();
 int mpg_a3_staged();  // current "a3_staged" knob
 int mpg_lf_variant(); // current "lf_variant" knob

@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LFU = list(range(100, 120)) + [200, 300, 301, 302]   # 100-105 two-phase, 106-111 pipelined, 112-119 compact tiles, 200 / 300-302 rows-resident
+LFU = list(range(100, 120)) + [200, 300, 301, 302, 4, 500]   # 100-105 two-phase, 106-111 pipelined, 112-119 compact tiles, 200 / 300-302 rows-resident, 4 / 500 row gather on row tiles / on linear aligned tiles
 A3_STAGED_DEFAULT = -1           # library default of the "a3_staged" knob (per-handle choice)
 
 
