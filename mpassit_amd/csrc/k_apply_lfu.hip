@@ -357,6 +357,8 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     // 14-15: 64 x 32-point tiles served by 512 threads (4 points each): half the tile-edge re-reads of 64 x 16 where a tile
     // has few cells per point (a global lat-lon grid finer than its mesh, C5); room for 1536 / 2048 cells per tile
     {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 12, 512>, 512}, {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16, 512>, 512},
+    // 16-17: 64 x 16-point tiles on 512 threads (2 points each, the registers of the 64 x 8 kernel)
+    {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 16, 512>, 512}, {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 12, 512>, 512},
     // (compact tiles of 32 x 32, 16 x 64 and 32 x 16 points with the same 1024-cell capacity were measured in round 2 on C4,
     //  Morton-numbered C4, C2 and C5: 0-15 % slower than 64 x 8 / 64 x 16 everywhere, profiles/r02_sweep_cfu_compact.txt)
 };
@@ -367,7 +369,7 @@ static int g_cfu_fpw = 1;   // "cfu_fields_per_wg": fields of a bundle served by
 void mpg_cfu_set_fields_per_wg(int v) { g_cfu_fpw = v < 1 ? 1 : (v > 255 ? 255 : v); }
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
-static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16, 12, 16};
+static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16, 12, 16, 16, 12};
 static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * g_cfu_variants[variant].nt; }
 static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap = 1024);
 static int cfu_build(mpg_handle_s *h, int variant, hipStream_t s) {
@@ -543,14 +545,21 @@ int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant) {
 // cf_choice holds variant + 1, or -1 for the lane-gather kernel.
 #define CFU_WIDE 10
 #define CFU_BASE 13
+#define CFU_TALL 16
+// Round 2: when cells are not shared enough for the 256-thread 64 x 16 kernel, the same 64 x 16 tiles on 512 threads
+// (variant 16: two points per thread like the 64 x 8 kernel, 2048 cells per tile) serve the handle: equal to 64 x 8 on the
+// row-numbered C4 (4.91 ms both), 5 % faster on the Morton-numbered one (4.72 vs 4.96 ms), and the lists built for the
+// reuse statistic are the ones used (one list build per handle instead of two).
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
   if (h->cf_choice == 0 || h->cf_for != -1) {
     h->cf_for = -1;
-    int rc = cfu_build(h, CFU_WIDE, s);
+    int rc = cfu_build(h, CFU_TALL, s);   // 64 x 16 lists, shifted rows as long as 2048 cells per tile hold them
     if (rc) return rc;
     float reuse = h->ut_total > 0 ? 3.0f * (float)h->n_dst / (float)h->ut_total : 0.f;
     if (reuse >= LFU_AUTO_MIN_REUSE && h->ut_max <= cfu_capacity(CFU_WIDE)) {
       h->cf_choice = CFU_WIDE + 1;
+    } else if (h->ut_max <= cfu_capacity(CFU_TALL)) {
+      h->cf_choice = CFU_TALL + 1;
     } else {
       if ((rc = cfu_build(h, CFU_BASE, s))) return rc;
       h->cf_choice = h->ut_max <= cfu_capacity(CFU_BASE) ? CFU_BASE + 1 : -1;
@@ -569,13 +578,13 @@ int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant) {
 // Typed form of the staged cell-fast kernel (mpg_regrid_typed_dev): float32 or float64 source as the MPAS file stores
 // it, float64 arithmetic (wsum3), dst = (TD)(value * scale + offset) -- the writer's T - 300 / PHB * 9.81 / NF90_FLOAT
 // conversion fused in.  Fixed shape <64 x 8 points, 4 levels per chunk, 16 prefetch registers> = the f64 base variant.
-template <typename TS, typename TD>
-__global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
+template <typename TS, typename TD, int RPT = 2, int NT = LFU_THREADS>
+__global__ __launch_bounds__(NT) void k_apply3_cfu_t(const int32_t *__restrict__ ut_ptr, const int32_t *__restrict__ ut_cells,
                                                               const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                               const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
                                                               int nlev, int ntx, int nty, int nfields, int ut_max, double scale,
                                                               double offset) {
-  constexpr int TXU = 64, RPT = 2, LC = 4, NPF = 16, UPT = NPF / LC;
+  constexpr int TXU = 64, LC = 4, NPF = 16, UPT = NPF / LC;
   extern __shared__ double lds[];  // [LC][nup]
   const int nup = ut_max;
   const int64_t P = (int64_t)nx * ny;
@@ -585,14 +594,14 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__r
   const int f = lin / ntile;
   const int t = threadIdx.x;
   const int u0 = ut_ptr[tile], nU = ut_ptr[tile + 1] - u0;
-  LfuPoints<TXU, RPT> pts;
+  LfuPoints<TXU, RPT, NT> pts;
   pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, 1);
   const TS *sf = src + (int64_t)f * nlev * nsrc;
   TD *df = dst + (int64_t)f * nlev * P;
   int32_t cell[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
-    int q = t + LFU_THREADS * u;
+    int q = t + NT * u;
     cell[u] = q < nU ? ut_cells[u0 + q] : -1;
   }
   TS pf[NPF];
@@ -605,8 +614,8 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__r
     for (int lv = 0; lv < LC; ++lv)
 #pragma unroll
       for (int u = 0; u < UPT; ++u)
-        if (cell[u] >= 0) lds[lv * nup + t + LFU_THREADS * u] = (double)pf[lv * UPT + u];
-    for (int q = t + LFU_THREADS * UPT; q < nU; q += LFU_THREADS) {
+        if (cell[u] >= 0) lds[lv * nup + t + NT * u] = (double)pf[lv * UPT + u];
+    for (int q = t + NT * UPT; q < nU; q += NT) {
       int32_t c = ut_cells[u0 + q];
       for (int lv = 0; lv < LC; ++lv) lds[lv * nup + q] = (k0 + lv < nlev) ? (double)sf[(int64_t)(k0 + lv) * nsrc + c] : 0.0;
     }
@@ -633,20 +642,20 @@ __global__ __launch_bounds__(LFU_THREADS) void k_apply3_cfu_t(const int32_t *__r
   }
 }
 
-template <typename TS, typename TD>
+template <typename TS, typename TD, int RPT, int NT>
 static int launch_cfu_t(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
-  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + 7) / 8;
+  constexpr int TYU = NT * RPT / 64;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + TYU - 1) / TYU;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;
   size_t lds = sizeof(double) * um * 4 + 16;
   if (lds > 160 * 1024) {
     mpg_set_error("Regrid(CELL_FAST, staged): %d unique cells per tile exceed the LDS", h->ut_max);
     return MPG_ERR_UNSUPPORTED;
   }
-  if (lds > 48 * 1024)
-    MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_cfu_t<TS, TD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  k_apply3_cfu_t<TS, TD><<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src,
-                                                                                (TD *)dst, h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty,
-                                                                                nfields, (int)um, scale, offset);
+  auto fn = k_apply3_cfu_t<TS, TD, RPT, NT>;
+  if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_ptr.p, h->ut_cells.p, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst, h->ny_dst,
+                                                   h->ut_align, h->n_src, nlev, ntx, nty, nfields, (int)um, scale, offset);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -824,15 +833,32 @@ int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nl
   return launch_lfu_t<double, double>(h, src, nlev, nfields, dst, scale, offset, s);
 }
 
+template <int RPT, int NT>
+static int launch_cfu_t_types(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
+                              double offset, hipStream_t s) {
+  if (src_f32 && dst_f32) return launch_cfu_t<float, float, RPT, NT>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (src_f32) return launch_cfu_t<float, double, RPT, NT>(h, src, nlev, nfields, dst, scale, offset, s);
+  if (dst_f32) return launch_cfu_t<double, float, RPT, NT>(h, src, nlev, nfields, dst, scale, offset, s);
+  return launch_cfu_t<double, double, RPT, NT>(h, src, nlev, nfields, dst, scale, offset, s);
+}
+
+// The typed entry follows the handle's per-handle choice of tile shape (mpg_cfu_auto: 64 x 16 points on 256 or 512
+// threads, else 64 x 8), so that float64 and typed Regrids of one handle share ONE set of tile lists.
 int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
                            double offset, hipStream_t s) {
-  int rc = lfu_build(h, 64, 2, s);
-  if (rc) return rc;
-  if (h->ut_max > 1024) return MPG_ERR_UNSUPPORTED;  // caller falls back to the lane-gather typed kernel
-  if (src_f32 && dst_f32) return launch_cfu_t<float, float>(h, src, nlev, nfields, dst, scale, offset, s);
-  if (src_f32) return launch_cfu_t<float, double>(h, src, nlev, nfields, dst, scale, offset, s);
-  if (dst_f32) return launch_cfu_t<double, float>(h, src, nlev, nfields, dst, scale, offset, s);
-  return launch_cfu_t<double, double>(h, src, nlev, nfields, dst, scale, offset, s);
+  int variant = -1, rc;
+  if (mpg_a3_staged() == -1) {
+    if ((rc = mpg_cfu_auto(h, s, &variant))) return rc;
+    if (variant < 0) return MPG_ERR_UNSUPPORTED;   // caller falls back to the lane-gather typed kernel
+  }
+  if (variant == CFU_TALL || variant == CFU_WIDE) {
+    if ((rc = cfu_build(h, variant, s))) return rc;
+    if (variant == CFU_TALL) return launch_cfu_t_types<2, 512>(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
+    return launch_cfu_t_types<4, LFU_THREADS>(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
+  }
+  if ((rc = lfu_build(h, 64, 2, s))) return rc;
+  if (h->ut_max > 1024) return MPG_ERR_UNSUPPORTED;
+  return launch_cfu_t_types<2, LFU_THREADS>(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
 }
 
 // Does the explicit staged variant suit this handle?  Tiles whose points share almost no cells (a fine mesh under a coarse
