@@ -16,6 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 NAMELIST = """&config
   grid_file_input_grid="{d}/init.nc"
@@ -134,6 +135,27 @@ def main():
     gb_out = os.path.getsize(os.path.join(d, "out_fortran.nc")) / 1e9
     print("fortran, device flow:  %.2f s wall (process start to exit; %.2f GB out)" % (t_f, gb_out), flush=True)
     print("    " + "  ".join(ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("[")), flush=True)
+
+    nr = int(os.environ.get("C4JOB_RANKS", "0"))      # C4JOB_RANKS=N: the same job as N driver images (row blocks of the target grid)
+    if nr > 1:
+        import mpassit_ranks
+        nml_txt = open(os.path.join(d, "namelist.input")).read().replace("out_fortran.nc", "out_fortran_r%d.nc" % nr)
+        open(os.path.join(d, "namelist.ranks"), "w").write(nml_txt)
+        t0 = time.perf_counter()
+        res = mpassit_ranks.launch("namelist.ranks", nr, gpus=int(os.environ.get("C4JOB_GPUS", "1")), exe=exe, cwd=d, timeout=900)
+        t_r = time.perf_counter() - t0
+        bad = [(i, r[0]) for i, r in enumerate(res) if r[0] != 0]
+        if bad:
+            print("multi-image run failed:", bad, res[bad[0][0]][1][-2000:], res[bad[0][0]][2][-2000:])
+            return 1
+        same_r = open(os.path.join(d, "out_fortran.nc"), "rb").read() == open(os.path.join(d, "out_fortran_r%d.nc" % nr), "rb").read()
+        print("fortran, %d images on %s GPU(s): %.2f s wall; output identical to the single image's byte for byte: %s" % (
+            nr, os.environ.get("C4JOB_GPUS", "1"), t_r, same_r), flush=True)
+        for i, r in enumerate(res):
+            print("    image %d: %s" % (i, "  ".join(ln.strip() for ln in r[1].splitlines() if ln.lstrip().startswith("["))), flush=True)
+        os.remove(os.path.join(d, "out_fortran_r%d.nc" % nr))
+        if not same_r:
+            return 1
 
     cfg = I.InterpConfig(wrf_mod_vars=True, proj_is_lambert=not c5, diag_list=diag_list, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
     nml = dict(dx=3000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
