@@ -94,14 +94,17 @@ int mpg_grid_destroy(mpg_grid grid); /* ESMF_GridDestroy model_grid.F90:2156 */
  * j_target); stagger shapes as in mpg_grid_create.  The grid keeps lon/lat (degrees), cos/sin(alpha) and the map
  * factors on the device; the getters copy them to the host (XLAT/XLONG/MAPFAC/SINALPHA/COSALPHA of the output file,
  * write_data.F90:1003-1140).
- * Map factors: PROJ_LC as get_map_factor; PROJ_LATLON has no branch there (the reference writes unset memory) and
+ * PROJ_PS (polar stereographic: truelat1, stand_lon, dx_m; set_ps / ijll_ps, module_map_utils.F90:682-822) and PROJ_MERC
+ * (Mercator: truelat1, dx_m; set_merc / ijll_merc, :1293-1362) take the arguments push_source_projection passes for them
+ * (llxy_module.F90:71-79,123-132).
+ * Map factors: PROJ_LC / PROJ_PS / PROJ_MERC as get_map_factor; PROJ_LATLON has no branch there (the reference writes unset memory) and
  * returns 1.0 here.  cos/sin(alpha) exist for PROJ_LC only (model_grid.F90:1113), as in the reference. */
-enum { MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1 }; /* misc_definitions_module.F90:38-39 */
+enum { MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1, MPG_PROJ_PS = 2, MPG_PROJ_MERC = 3 }; /* misc_definitions_module.F90:38-42 */
 typedef struct mpg_proj {
   int code;
   double known_lat, known_lon, known_x, known_y; /* lat1, lon1, knowni, knownj */
-  double dx_m;                                   /* PROJ_LC: grid spacing in metres */
-  double stand_lon, truelat1, truelat2;          /* PROJ_LC */
+  double dx_m;                                   /* PROJ_LC, PROJ_PS, PROJ_MERC: grid spacing in metres */
+  double stand_lon, truelat1, truelat2;          /* PROJ_LC; PROJ_PS: stand_lon, truelat1; PROJ_MERC: truelat1 */
   double dlat_deg, dlon_deg;                     /* PROJ_LATLON: latinc, loninc */
 } mpg_proj;
 int mpg_grid_create_proj(const mpg_proj *proj, int nx, int ny, int periodic_i, mpg_grid *out);

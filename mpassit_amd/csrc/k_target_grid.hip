@@ -5,7 +5,8 @@
 // numpy mirror of those loops costs ~20x the whole interpolation job.  Here one kernel per stagger evaluates
 //   get_lat_lon_fields (model_grid.F90:2188-2219): xytoll(real(i-0.5)+0.5, real(j-0.5)+0.5, stagger)
 //   xytoll             (llxy_module.F90:166-216):   U: x-0.5, V: y-0.5, CORNER: both
-//   ij_to_latlon       (module_map_utils.F90:629-679; Lambert :1160-1233, lat-lon :1398-1428)
+//   ij_to_latlon       (module_map_utils.F90:629-679; Lambert :1160-1233, lat-lon :1398-1428, polar stereographic
+//                       :763-822, Mercator :1344-1362)
 // and writes lon/lat (degrees), the unit vector every Store kernel works with, and the map factor
 // (get_map_factor, model_grid.F90:2229-2365); a second kernel does get_rotang (:2450-2507) on the CENTER points.
 // Pure ALU + transcendental work, a few MB written once: nowhere near any roofline, it only has to be off the host.
@@ -47,6 +48,36 @@ __device__ __forceinline__ void ij_to_latlon(const ProjDev &p, double i, double 
     if (lon < -180.0) lon += 360.0;
     *lat_out = lat;
     *lon_out = lon;
+  } else if (p.code == MPG_PROJ_PS) {                     // ijll_ps, module_map_utils.F90:763-822
+    double reflon = p.stdlon + 90.0;
+    double scale_top = 1.0 + p.hemi * sin(p.truelat1 * TG_RAD_PER_DEG);
+    double xx = i - p.polei;
+    double yy = (j - p.polej) * p.hemi;
+    double r2 = xx * xx + yy * yy;
+    double lat, lon;
+    if (r2 == 0.0) {
+      lat = p.hemi * 90.0;
+      lon = reflon;
+    } else {
+      double gi = p.rebydx * scale_top;
+      double gi2 = gi * gi;
+      lat = TG_DEG_PER_RAD * p.hemi * asin((gi2 - r2) / (gi2 + r2));
+      double c = xx / sqrt(r2);
+      c = fmin(fmax(c, -1.0), 1.0);
+      double arccos = acos(c);
+      lon = yy > 0.0 ? reflon + TG_DEG_PER_RAD * arccos : reflon - TG_DEG_PER_RAD * arccos;
+    }
+    if (lon > 180.0) lon -= 360.0;
+    if (lon < -180.0) lon += 360.0;
+    *lat_out = lat;
+    *lon_out = lon;
+  } else if (p.code == MPG_PROJ_MERC) {                   // ijll_merc, module_map_utils.F90:1344-1362
+    double lat = 2.0 * atan(exp(p.dlon * (p.rsw + j - p.knownj))) * TG_DEG_PER_RAD - 90.0;
+    double lon = (i - p.knowni) * p.dlon * TG_DEG_PER_RAD + p.lon1;
+    if (lon > 180.0) lon -= 360.0;
+    if (lon < -180.0) lon += 360.0;
+    *lat_out = lat;
+    *lon_out = lon;
   } else {
     double span = (double)(p.nxmax - p.nxmin + 1);
     double iw = i;
@@ -59,6 +90,12 @@ __device__ __forceinline__ void ij_to_latlon(const ProjDev &p, double i, double 
 
 __device__ __forceinline__ double map_factor(const ProjDev &p, double lat) {
 #pragma clang fp contract(off)
+  if (p.code == MPG_PROJ_PS)       // model_grid.F90:2279-2286
+    return (1.0 + sin(TG_RAD_PER_DEG * fabs(p.truelat1))) / (1.0 + sin(TG_RAD_PER_DEG * copysign(1.0, p.truelat1) * lat));
+  if (p.code == MPG_PROJ_MERC) {   // :2289-2298
+    double colat0 = TG_RAD_PER_DEG * (90.0 - p.truelat1);
+    return sin(colat0) / sin(TG_RAD_PER_DEG * (90.0 - lat));
+  }
   if (p.code != MPG_PROJ_LC) return 1.0;  // PROJ_LATLON: no branch in get_map_factor
   double colat = TG_RAD_PER_DEG * (90.0 - lat);
   if (p.truelat1 != p.truelat2) {
@@ -160,6 +197,35 @@ static int derive(const mpg_proj *in, ProjDev *p) {
     double arg = p->cone * (deltalon1 * TG_RAD_PER_DEG);
     p->polei = p->hemi * p->knowni - p->hemi * rsw * sin(arg);
     p->polej = p->hemi * p->knownj + rsw * cos(arg);
+  } else if (in->code == MPG_PROJ_PS) {    // map_set + set_ps (module_map_utils.F90:682-715)
+    if (!(in->dx_m > 0.0) || fabs(in->truelat1) > 90.0) {
+      mpg_set_error("mpg_grid_create_proj: polar stereographic needs dx_m > 0 and |truelat1| <= 90");
+      return MPG_ERR_INVALID_ARG;
+    }
+    p->stdlon = wrap180(in->stand_lon);
+    p->truelat1 = in->truelat1;
+    p->hemi = in->truelat1 < 0.0 ? -1.0 : 1.0;
+    p->rebydx = TG_EARTH_RADIUS_M / in->dx_m;
+    double reflon = p->stdlon + 90.0;
+    double scale_top = 1.0 + p->hemi * sin(p->truelat1 * TG_RAD_PER_DEG);
+    double ala1 = p->lat1 * TG_RAD_PER_DEG;
+    double rsw = p->rebydx * cos(ala1) * scale_top / (1.0 + p->hemi * sin(ala1));
+    double alo1 = (p->lon1 - reflon) * TG_RAD_PER_DEG;
+    p->rsw = rsw;
+    p->polei = p->knowni - rsw * cos(alo1);
+    p->polej = p->knownj - p->hemi * rsw * sin(alo1);
+  } else if (in->code == MPG_PROJ_MERC) {  // map_set + set_merc (:1293-1317)
+    if (!(in->dx_m > 0.0) || fabs(in->truelat1) >= 90.0) {
+      mpg_set_error("mpg_grid_create_proj: Mercator needs dx_m > 0 and |truelat1| < 90");
+      return MPG_ERR_INVALID_ARG;
+    }
+    p->truelat1 = in->truelat1;
+    p->hemi = in->truelat1 < 0.0 ? -1.0 : 1.0;
+    p->rebydx = TG_EARTH_RADIUS_M / in->dx_m;
+    double clain = cos(TG_RAD_PER_DEG * p->truelat1);
+    p->dlon = in->dx_m / (TG_EARTH_RADIUS_M * clain);
+    p->rsw = 0.0;
+    if (p->lat1 != 0.0) p->rsw = log(tan(0.5 * ((p->lat1 + 90.0) * TG_RAD_PER_DEG))) / p->dlon;
   } else if (in->code == MPG_PROJ_LATLON) {
     if (in->dlat_deg == 0.0 || !(in->dlon_deg > 0.0)) {
       mpg_set_error("mpg_grid_create_proj: lat-lon needs dlat_deg != 0 and dlon_deg > 0");
@@ -170,7 +236,7 @@ static int derive(const mpg_proj *in, ProjDev *p) {
     p->nxmin = 1;
     p->nxmax = (int)nearbyint(360.0 / in->dlon_deg);
   } else {
-    mpg_set_error("mpg_grid_create_proj: projection code %d not supported (PROJ_LC, PROJ_LATLON)", in->code);
+    mpg_set_error("mpg_grid_create_proj: projection code %d not supported (PROJ_LATLON, PROJ_LC, PROJ_PS, PROJ_MERC)", in->code);
     return MPG_ERR_UNSUPPORTED;
   }
   return MPG_SUCCESS;

@@ -170,6 +170,7 @@ struct mpg_grid_s {
 struct ProjDev {
   int code;
   double hemi, truelat1, truelat2, stdlon, cone, polei, polej, rebydx, lat1, lon1, knowni, knownj, latinc, loninc;
+  double rsw, dlon;   // PROJ_PS / PROJ_MERC (set_ps, set_merc)
   int nxmin, nxmax;
 };
 

@@ -13,7 +13,7 @@ module program_setup
   public
   integer, parameter :: dp = kind(1.0d0)
   real(dp), parameter :: NAN = 1.0e20_dp           ! misc_definitions_module.F90:12 ("unset" sentinel)
-  integer, parameter :: PROJ_LATLON = 0, PROJ_LC = 1  ! misc_definitions_module.F90:38-39
+  integer, parameter :: PROJ_LATLON = 0, PROJ_LC = 1, PROJ_PS = 2, PROJ_MERC = 3  ! misc_definitions_module.F90:38-42
   real(dp), parameter :: PI = 3.141592653589793_dp, RAD_PER_DEG = PI/180.0_dp, DEG_PER_RAD = 180.0_dp/PI
   real(dp), parameter :: EARTH_RADIUS_M = 6370000.0_dp
 
@@ -129,6 +129,12 @@ contains
         if (truelat1 == NAN) call fatal("No TRUELAT1 specified for Lambert conformal projection.", 3)
         truelat2 = truelat1
       end if
+    else if (trim(kind) == 'MERCATOR') then        ! program_setup.F90:174-177
+      proj_code = PROJ_MERC
+      map_proj_char = 'Mercator'
+    else if (trim(kind) == 'POLAR') then           ! :179-182
+      proj_code = PROJ_PS
+      map_proj_char = 'Polar Stereographic'
     else if (trim(kind) == 'LAT-LON') then
       proj_code = PROJ_LATLON
       map_proj_char = 'Lat/Lon'
@@ -145,7 +151,8 @@ contains
         if (known_lat == NAN .or. known_lon == NAN) call fatal("lat-lon with dx/dy needs ref_lat, ref_lon", 3)
       end if
     else
-      call fatal('In namelist, invalid target_grid_type: this build supports "lambert", "lat-lon" and "file".', 3)
+      call fatal('In namelist, invalid target_grid_type specified. Valid projections are "lambert", "mercator", "polar", '// &
+                 '"lat-lon" and "file".', 3)
     end if
     if (known_x == NAN .and. known_y == NAN) then
       known_x = real(i_target + 1, dp)/2.0_dp; known_y = real(j_target + 1, dp)/2.0_dp
@@ -226,6 +233,10 @@ contains
     p%dx_m = 0.0_dp; p%stand_lon = 0.0_dp; p%truelat1 = 0.0_dp; p%truelat2 = 0.0_dp; p%dlat_deg = 0.0_dp; p%dlon_deg = 0.0_dp
     if (proj_code == PROJ_LC) then
       p%dx_m = dxkm; p%stand_lon = stand_lon; p%truelat1 = truelat1; p%truelat2 = truelat2
+    else if (proj_code == PROJ_PS) then                      ! llxy_module.F90:123-132
+      p%dx_m = dxkm; p%stand_lon = stand_lon; p%truelat1 = truelat1
+    else if (proj_code == PROJ_MERC) then                    ! llxy_module.F90:71-79
+      p%dx_m = dxkm; p%truelat1 = truelat1
     else
       p%dlat_deg = dlatdeg; p%dlon_deg = dlondeg
     end if
@@ -288,7 +299,7 @@ contains
     dykm = dxkm
     proj_code = PROJ_LC
     if (ncio_get_gatt(nf, "MAP_PROJ", v) == 0) proj_code = nint(v)
-    if (proj_code /= PROJ_LC .and. proj_code /= PROJ_LATLON) call fatal("file_target_grid: unsupported MAP_PROJ", proj_code)
+    if (proj_code < PROJ_LATLON .or. proj_code > PROJ_MERC) call fatal("file_target_grid: unsupported MAP_PROJ", proj_code)
     if (ncio_get_gatt(nf, "STAND_LON", v) == 0) stand_lon = v
     if (ncio_get_gatt(nf, "TRUELAT1", v) == 0) truelat1 = v
     if (ncio_get_gatt(nf, "TRUELAT2", v) == 0) truelat2 = v
@@ -298,7 +309,12 @@ contains
     if (ncio_get_gatt(nf, "POLE_LAT", v) == 0) pole_lat = v
     if (ncio_get_gatt(nf, "POLE_LON", v) == 0) pole_lon = v
     if (ncio_get_gatt_text(nf, "MAP_PROJ_CHAR", map_proj_char) /= 0) then                     ! model_grid.F90:1288-1295
-      map_proj_char = merge("Lambert Conformal", "Lat/Lon          ", proj_code == PROJ_LC)
+      select case (proj_code)
+      case (PROJ_LC); map_proj_char = "Lambert Conformal"
+      case (PROJ_PS); map_proj_char = "Polar Stereographic"
+      case (PROJ_MERC); map_proj_char = "Mercator"
+      case default; map_proj_char = "Lat/Lon"
+      end select
     end if
     call get2("XLONG", "XLONG_M", lon_m, i_target, j_target)
     call get2("XLAT", "XLAT_M", lat_m, i_target, j_target)

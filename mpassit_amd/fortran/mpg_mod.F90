@@ -22,7 +22,7 @@ module mpg
                                MPG_STAGGERLOC_CORNER = 3
   integer(c_int), parameter :: MPG_LAYOUT_CELL_FAST = 0, MPG_LAYOUT_LEV_FAST = 1
   integer(c_int), parameter :: MPG_GRID_PERIODIC_I = 1, MPG_GRID_NO_SOUTH_POLE = 2, MPG_GRID_NO_NORTH_POLE = 4
-  integer(c_int), parameter :: MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1
+  integer(c_int), parameter :: MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1, MPG_PROJ_PS = 2, MPG_PROJ_MERC = 3
   !> struct mpg_proj (include/mpassit_amd.h): the arguments of push_source_projection (model_grid.F90:676-678)
   type, bind(C) :: mpg_proj
     integer(c_int) :: code

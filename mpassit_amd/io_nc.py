@@ -305,7 +305,8 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
               ("TRUELAT2", f8(nl["truelat2"])), ("MOAD_CEN_LAT", f8(nl["ref_lat"])), ("STAND_LON", f8(nl["stand_lon"])),
               ("POLE_LAT", f8(nl["pole_lat"])), ("POLE_LON", f8(nl["pole_lon"])), ("POL_ELAT", f8(nl["pole_lat"])),   # sic, :253
               ("MAP_PROJ", int(target.proj.code)),
-              ("MAP_PROJ_CHAR", target.extra.get("map_proj_char") or ("Lambert Conformal" if target.proj.code == 1 else "Lat/Lon"))]
+              ("MAP_PROJ_CHAR", target.extra.get("map_proj_char") or
+               {1: "Lambert Conformal", 2: "Polar Stereographic", 3: "Mercator"}.get(int(target.proj.code), "Lat/Lon"))]   # program_setup.F90:169-187
         if cfg.interp_diag:
             ga.append(("PREC_ACC_DT", int(meta.get("diag_out_interval", 0))))                                          # :262-265
         ga += [("I_PARENT_START", 1), ("J_PARENT_START", 1)]

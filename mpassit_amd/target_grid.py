@@ -21,7 +21,7 @@ DEG_PER_RAD = 180.0 / PI
 EARTH_RADIUS_M = 6370000.0  # constants_module.F90:25
 NAN = 1.0e20  # misc_definitions_module.F90:12 (namelist "unset" sentinel)
 
-PROJ_LATLON, PROJ_LC = 0, 1  # misc_definitions_module.F90:38-39
+PROJ_LATLON, PROJ_LC, PROJ_PS, PROJ_MERC = 0, 1, 2, 3  # misc_definitions_module.F90:38-42
 M, U, V, CORNER = 1, 2, 3, 6  # misc_definitions_module.F90:29
 
 
@@ -38,7 +38,7 @@ def _wrap180(x):
 
 @dataclass
 class Proj:
-    """`proj_info` subset (module_map_utils.F90:140-192) for PROJ_LC and PROJ_LATLON."""
+    """`proj_info` subset (module_map_utils.F90:140-192) for PROJ_LC, PROJ_LATLON, PROJ_PS and PROJ_MERC."""
     code: int
     lat1: float = 0.0
     lon1: float = 0.0
@@ -58,6 +58,7 @@ class Proj:
     loninc: float = 0.0
     nxmin: int = 1
     nxmax: int = 0
+    dlon: float = 0.0
 
     @staticmethod
     def lc_cone(truelat1, truelat2):
@@ -92,6 +93,35 @@ class Proj:
         return p
 
     @classmethod
+    def polar(cls, truelat1, stdlon, lat1, lon1, knowni, knownj, dx):
+        """map_set(PROJ_PS) + set_ps (module_map_utils.F90:682-715), arguments as push_source_projection passes them
+        (llxy_module.F90:123-132)."""
+        p = cls(PROJ_PS, lat1=lat1, lon1=_wrap180(lon1), knowni=knowni, knownj=knownj, dx=dx, stdlon=_wrap180(stdlon), truelat1=truelat1)
+        p.hemi = -1.0 if truelat1 < 0.0 else 1.0
+        p.rebydx = EARTH_RADIUS_M / dx
+        reflon = p.stdlon + 90.0
+        scale_top = 1.0 + p.hemi * np.sin(p.truelat1 * RAD_PER_DEG)
+        ala1 = p.lat1 * RAD_PER_DEG
+        p.rsw = float(p.rebydx * np.cos(ala1) * scale_top / (1.0 + p.hemi * np.sin(ala1)))
+        alo1 = (p.lon1 - reflon) * RAD_PER_DEG
+        p.polei = float(p.knowni - p.rsw * np.cos(alo1))
+        p.polej = float(p.knownj - p.hemi * p.rsw * np.sin(alo1))
+        return p
+
+    @classmethod
+    def mercator(cls, truelat1, lat1, lon1, knowni, knownj, dx):
+        """map_set(PROJ_MERC) + set_merc (module_map_utils.F90:1293-1317; llxy_module.F90:71-79)."""
+        p = cls(PROJ_MERC, lat1=lat1, lon1=_wrap180(lon1), knowni=knowni, knownj=knownj, dx=dx, truelat1=truelat1)
+        p.hemi = -1.0 if truelat1 < 0.0 else 1.0
+        p.rebydx = EARTH_RADIUS_M / dx
+        clain = np.cos(RAD_PER_DEG * truelat1)
+        p.dlon = float(dx / (EARTH_RADIUS_M * clain))
+        p.rsw = 0.0
+        if lat1 != 0.0:
+            p.rsw = float(np.log(np.tan(0.5 * ((lat1 + 90.0) * RAD_PER_DEG))) / p.dlon)
+        return p
+
+    @classmethod
     def latlon(cls, lat1, lon1, knowni, knownj, latinc, loninc):
         return cls(PROJ_LATLON, lat1=lat1, lon1=_wrap180(lon1), knowni=knowni, knownj=knownj,
                    latinc=latinc, loninc=loninc, nxmin=1, nxmax=int(round(360.0 / loninc)))
@@ -121,6 +151,29 @@ class Proj:
             lon = np.where(lon > 180.0, lon - 360.0, lon)
             lon = np.where(lon < -180.0, lon + 360.0, lon)
             return lat, lon
+        if self.code == PROJ_PS:                      # ijll_ps (module_map_utils.F90:763-822)
+            reflon = self.stdlon + 90.0
+            scale_top = 1.0 + self.hemi * np.sin(self.truelat1 * RAD_PER_DEG)
+            xx = i - self.polei
+            yy = (j - self.polej) * self.hemi
+            r2 = xx * xx + yy * yy
+            gi2 = (self.rebydx * scale_top) ** 2.0
+            with np.errstate(divide="ignore", invalid="ignore"):
+                lat = DEG_PER_RAD * self.hemi * np.arcsin((gi2 - r2) / (gi2 + r2))
+                arccos = np.arccos(np.clip(xx / np.sqrt(r2), -1.0, 1.0))
+            lon = np.where(yy > 0, reflon + DEG_PER_RAD * arccos, reflon - DEG_PER_RAD * arccos)
+            pole = r2 == 0.0
+            lat = np.where(pole, self.hemi * 90.0, lat)
+            lon = np.where(pole, reflon, lon)
+            lon = np.where(lon > 180.0, lon - 360.0, lon)
+            lon = np.where(lon < -180.0, lon + 360.0, lon)
+            return lat, lon
+        if self.code == PROJ_MERC:                    # ijll_merc (:1344-1362)
+            lat = 2.0 * np.arctan(np.exp(self.dlon * (self.rsw + j - self.knownj))) * DEG_PER_RAD - 90.0
+            lon = (i - self.knowni) * self.dlon * DEG_PER_RAD + self.lon1
+            lon = np.where(lon > 180.0, lon - 360.0, lon)
+            lon = np.where(lon < -180.0, lon + 360.0, lon)
+            return lat, lon
         span = float(self.nxmax - self.nxmin + 1)
         i_work = np.where(i < self.nxmin - 0.5, i + span, i)
         i_work = np.where(i >= self.nxmax + 0.5, i - span, i_work)
@@ -129,10 +182,25 @@ class Proj:
         return lat, lon
 
     def latlon_to_ij(self, lat, lon):
-        """llij_lc (module_map_utils.F90:1236-1290); Lambert only (used by the synthetic meshes)."""
-        assert self.code == PROJ_LC
+        """llij_lc (module_map_utils.F90:1236-1290), llij_ps (:718-760), llij_merc (:1320-1341); used by the synthetic
+        meshes and the round-trip tests."""
         lat = np.asarray(lat, np.float64)
         lon = np.asarray(lon, np.float64)
+        if self.code == PROJ_PS:
+            reflon = self.stdlon + 90.0
+            scale_top = 1.0 + self.hemi * np.sin(self.truelat1 * RAD_PER_DEG)
+            ala = lat * RAD_PER_DEG
+            rm = self.rebydx * np.cos(ala) * scale_top / (1.0 + self.hemi * np.sin(ala))
+            alo = (lon - reflon) * RAD_PER_DEG
+            return self.polei + rm * np.cos(alo), self.polej + self.hemi * rm * np.sin(alo)
+        if self.code == PROJ_MERC:
+            deltalon = lon - self.lon1
+            deltalon = np.where(deltalon < -180.0, deltalon + 360.0, deltalon)
+            deltalon = np.where(deltalon > 180.0, deltalon - 360.0, deltalon)
+            i = self.knowni + (deltalon / (self.dlon * DEG_PER_RAD))
+            j = self.knownj + np.log(np.tan(0.5 * ((lat + 90.0) * RAD_PER_DEG))) / self.dlon - self.rsw
+            return i, j
+        assert self.code == PROJ_LC
         deltalon = lon - self.stdlon
         deltalon = np.where(deltalon > 180.0, deltalon - 360.0, deltalon)
         deltalon = np.where(deltalon < -180.0, deltalon + 360.0, deltalon)
@@ -159,6 +227,25 @@ class Proj:
         """get_lat_lon_fields: arrays [nj][ni] (i fastest) for 1-based points (i, j)."""
         jj, ii = np.meshgrid(np.arange(1, nj + 1, dtype=np.float64), np.arange(1, ni + 1, dtype=np.float64), indexing="ij")
         return self.xytoll((ii - 0.5) + 0.5, (jj - 0.5) + 0.5, stagger)
+
+
+def get_map_factor(proj, xlat):
+    """MAPFAC at the points with latitude xlat (get_map_factor, model_grid.F90:2229-2365): Lambert (one or two true
+    latitudes), polar stereographic, Mercator; lat-lon has no branch there (1.0 here, like the device kernel)."""
+    xlat = np.asarray(xlat, np.float64)
+    if proj.code == PROJ_LC:
+        colat = RAD_PER_DEG * (90.0 - xlat)
+        if proj.truelat1 != proj.truelat2:
+            colat1, colat2 = RAD_PER_DEG * (90.0 - proj.truelat1), RAD_PER_DEG * (90.0 - proj.truelat2)
+            n = (np.log(np.sin(colat1)) - np.log(np.sin(colat2))) / (np.log(np.tan(colat1 / 2.0)) - np.log(np.tan(colat2 / 2.0)))
+            return np.sin(colat2) / np.sin(colat) * (np.tan(colat / 2.0) / np.tan(colat2 / 2.0)) ** n
+        colat0 = RAD_PER_DEG * (90.0 - proj.truelat1)
+        return np.sin(colat0) / np.sin(colat) * (np.tan(colat / 2.0) / np.tan(colat0 / 2.0)) ** np.cos(colat0)
+    if proj.code == PROJ_PS:
+        return (1.0 + np.sin(RAD_PER_DEG * abs(proj.truelat1))) / (1.0 + np.sin(RAD_PER_DEG * np.copysign(1.0, proj.truelat1) * xlat))
+    if proj.code == PROJ_MERC:
+        return np.sin(RAD_PER_DEG * (90.0 - proj.truelat1)) / np.sin(RAD_PER_DEG * (90.0 - xlat))
+    return np.ones_like(xlat)
 
 
 def get_rotang(xlat, xlon):
@@ -220,14 +307,22 @@ def define_target_grid_params(target_grid_type, nx, ny, dx=NAN, dy=NAN, ref_lat=
             dlatdeg, dlondeg = dy, dx
             if known_lat == NAN or known_lon == NAN:
                 raise ValueError("For lat-lon projection with dx/dy, ref_lat/ref_lon must be specified")
+    elif kind in ("MERCATOR", "POLAR"):
+        if truelat1 == NAN:
+            raise ValueError("No TRUELAT1 specified for the %s projection." % kind.lower())
     else:
-        raise ValueError('invalid target_grid_type; this build supports "lambert" and "lat-lon"')
+        raise ValueError('In namelist, invalid target_grid_type specified. Valid projections are "lambert", "mercator", "polar", and '
+                         '"lat-lon".')
     if known_x == NAN and known_y == NAN:
         known_x, known_y = (i_target + 1) / 2.0, (j_target + 1) / 2.0
     elif known_x == NAN or known_y == NAN:
         raise ValueError("In namelist, neither or both of ref_x, ref_y must be specified.")
     if kind == "LAMBERT":
         proj = Proj.lambert(truelat1, truelat2, stand_lon, known_lat, known_lon, known_x, known_y, dx)
+    elif kind == "POLAR":
+        proj = Proj.polar(truelat1, stand_lon, known_lat, known_lon, known_x, known_y, dx)
+    elif kind == "MERCATOR":
+        proj = Proj.mercator(truelat1, known_lat, known_lon, known_x, known_y, dx)
     else:
         proj = Proj.latlon(known_lat, known_lon, known_x, known_y, dlatdeg, dlondeg)
     g = TargetGrid(i_target, j_target, proj, is_regional)

@@ -640,9 +640,10 @@ void orc_rotate_winds(int64_t npts, int nlev, const double *cosa, const double *
  * All reals are float64 (CMakeLists.txt:80-82).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
-  int code;            /* 1 = LC, 0 = LATLON (misc_definitions_module.F90 PROJ_LC=1, PROJ_LATLON=0) */
+  int code;            /* 0 = LATLON, 1 = LC, 2 = PS, 3 = MERC (misc_definitions_module.F90:38-42) */
   double lat1, lon1, knowni, knownj, dx, stdlon, truelat1, truelat2, hemi, cone, polei, polej, rsw, rebydx;
   double latinc, loninc; int nxmin, nxmax;
+  double dlon;         /* PROJ_MERC (set_merc) */
 } orc_proj;
 
 static double wrap180(double x) {
@@ -690,6 +691,81 @@ void orc_map_set_latlon(orc_proj *p, double lat1, double lon1, double knowni, do
   p->latinc = latinc; p->loninc = loninc; p->nxmin = 1; p->nxmax = (int)lround(360.0 / loninc);
 }
 
+/* map_set(PROJ_PS,...) as called from llxy_module.F90:123-132 + set_ps (module_map_utils.F90:682-715) */
+void orc_map_set_ps(orc_proj *p, double truelat1, double stdlon, double lat1, double lon1, double knowni, double knownj, double dx) {
+  memset(p, 0, sizeof(*p));
+  p->code = 2;
+  p->lat1 = lat1; p->lon1 = wrap180(lon1); p->knowni = knowni; p->knownj = knownj; p->dx = dx;
+  p->stdlon = wrap180(stdlon); p->truelat1 = truelat1;
+  p->hemi = truelat1 < 0. ? -1.0 : 1.0;
+  p->rebydx = ORC_EARTH_RADIUS_M / dx;
+  double reflon = p->stdlon + 90.;
+  double scale_top = 1. + p->hemi * sin(p->truelat1 * ORC_RAD_PER_DEG);
+  double ala1 = p->lat1 * ORC_RAD_PER_DEG;
+  p->rsw = p->rebydx * cos(ala1) * scale_top / (1. + p->hemi * sin(ala1));
+  double alo1 = (p->lon1 - reflon) * ORC_RAD_PER_DEG;
+  p->polei = p->knowni - p->rsw * cos(alo1);
+  p->polej = p->knownj - p->hemi * p->rsw * sin(alo1);
+}
+
+/* map_set(PROJ_MERC,...) as called from llxy_module.F90:71-79 + set_merc (module_map_utils.F90:1293-1317) */
+void orc_map_set_merc(orc_proj *p, double truelat1, double lat1, double lon1, double knowni, double knownj, double dx) {
+  memset(p, 0, sizeof(*p));
+  p->code = 3;
+  p->lat1 = lat1; p->lon1 = wrap180(lon1); p->knowni = knowni; p->knownj = knownj; p->dx = dx; p->truelat1 = truelat1;
+  p->hemi = truelat1 < 0. ? -1.0 : 1.0;
+  p->rebydx = ORC_EARTH_RADIUS_M / dx;
+  double clain = cos(ORC_RAD_PER_DEG * p->truelat1);
+  p->dlon = dx / (ORC_EARTH_RADIUS_M * clain);
+  p->rsw = 0.;
+  if (p->lat1 != 0.) p->rsw = log(tan(0.5 * ((p->lat1 + 90.) * ORC_RAD_PER_DEG))) / p->dlon;
+}
+
+/* module_map_utils.F90:763-822 */
+static void ijll_ps(const orc_proj *p, double i, double j, double *lat, double *lon) {
+  double reflon = p->stdlon + 90.;
+  double scale_top = 1. + p->hemi * sin(p->truelat1 * ORC_RAD_PER_DEG);
+  double xx = i - p->polei, yy = (j - p->polej) * p->hemi;
+  double r2 = xx * xx + yy * yy;
+  if (r2 == 0.) { *lat = p->hemi * 90.; *lon = reflon; }
+  else {
+    double gi2 = pow(p->rebydx * scale_top, 2.);
+    *lat = ORC_DEG_PER_RAD * p->hemi * asin((gi2 - r2) / (gi2 + r2));
+    double c = xx / sqrt(r2);
+    if (c < -1.) c = -1.;
+    if (c > 1.) c = 1.;
+    double arccos = acos(c);
+    *lon = yy > 0 ? reflon + ORC_DEG_PER_RAD * arccos : reflon - ORC_DEG_PER_RAD * arccos;
+  }
+  if (*lon > 180.) *lon -= 360.;
+  if (*lon < -180.) *lon += 360.;
+}
+/* module_map_utils.F90:718-760 */
+static void llij_ps(const orc_proj *p, double lat, double lon, double *i, double *j) {
+  double reflon = p->stdlon + 90.;
+  double scale_top = 1. + p->hemi * sin(p->truelat1 * ORC_RAD_PER_DEG);
+  double ala = lat * ORC_RAD_PER_DEG;
+  double rm = p->rebydx * cos(ala) * scale_top / (1. + p->hemi * sin(ala));
+  double alo = (lon - reflon) * ORC_RAD_PER_DEG;
+  *i = p->polei + rm * cos(alo);
+  *j = p->polej + p->hemi * rm * sin(alo);
+}
+/* module_map_utils.F90:1344-1362 */
+static void ijll_merc(const orc_proj *p, double i, double j, double *lat, double *lon) {
+  *lat = 2.0 * atan(exp(p->dlon * (p->rsw + j - p->knownj))) * ORC_DEG_PER_RAD - 90.;
+  *lon = (i - p->knowni) * p->dlon * ORC_DEG_PER_RAD + p->lon1;
+  if (*lon > 180.) *lon -= 360.;
+  if (*lon < -180.) *lon += 360.;
+}
+/* module_map_utils.F90:1320-1341 */
+static void llij_merc(const orc_proj *p, double lat, double lon, double *i, double *j) {
+  double deltalon = lon - p->lon1;
+  if (deltalon < -180.) deltalon += 360.;
+  if (deltalon > 180.) deltalon -= 360.;
+  *i = p->knowni + (deltalon / (p->dlon * ORC_DEG_PER_RAD));
+  *j = p->knownj + log(tan(0.5 * ((lat + 90.) * ORC_RAD_PER_DEG))) / p->dlon - p->rsw;
+}
+
 /* module_map_utils.F90:1160-1233 */
 static void ijll_lc(const orc_proj *p, double i, double j, double *lat, double *lon) {
   double chi1 = (90. - p->hemi * p->truelat1) * ORC_RAD_PER_DEG;
@@ -734,7 +810,32 @@ static void ijll_latlon(const orc_proj *p, double i, double j, double *lat, doub
 }
 
 void orc_ij_to_latlon(const orc_proj *p, double i, double j, double *lat, double *lon) {
-  if (p->code == 1) ijll_lc(p, i, j, lat, lon); else ijll_latlon(p, i, j, lat, lon);
+  if (p->code == 1) ijll_lc(p, i, j, lat, lon);
+  else if (p->code == 2) ijll_ps(p, i, j, lat, lon);
+  else if (p->code == 3) ijll_merc(p, i, j, lat, lon);
+  else ijll_latlon(p, i, j, lat, lon);
+}
+/* latlon_to_ij (module_map_utils.F90:570-626) for the projected grids */
+void orc_latlon_to_ij(const orc_proj *p, double lat, double lon, double *i, double *j) {
+  if (p->code == 2) llij_ps(p, lat, lon, i, j);
+  else if (p->code == 3) llij_merc(p, lat, lon, i, j);
+  else llij_lc(p, lat, lon, i, j);
+}
+/* get_map_factor (model_grid.F90:2229-2365) at one latitude: LC (one / two true latitudes), PS, MERC */
+double orc_map_factor(const orc_proj *p, double xlat) {
+  if (p->code == 1) {
+    double colat = ORC_RAD_PER_DEG * (90.0 - xlat);
+    if (p->truelat1 != p->truelat2) {
+      double colat1 = ORC_RAD_PER_DEG * (90.0 - p->truelat1), colat2 = ORC_RAD_PER_DEG * (90.0 - p->truelat2);
+      double n = (log(sin(colat1)) - log(sin(colat2))) / (log(tan(colat1 / 2.0)) - log(tan(colat2 / 2.0)));
+      return sin(colat2) / sin(colat) * pow(tan(colat / 2.0) / tan(colat2 / 2.0), n);
+    }
+    double colat0 = ORC_RAD_PER_DEG * (90.0 - p->truelat1);
+    return sin(colat0) / sin(colat) * pow(tan(colat / 2.0) / tan(colat0 / 2.0), cos(colat0));
+  }
+  if (p->code == 2) return (1.0 + sin(ORC_RAD_PER_DEG * fabs(p->truelat1))) / (1.0 + sin(ORC_RAD_PER_DEG * copysign(1., p->truelat1) * xlat));
+  if (p->code == 3) return sin(ORC_RAD_PER_DEG * (90.0 - p->truelat1)) / sin(ORC_RAD_PER_DEG * (90.0 - xlat));
+  return 1.0;
 }
 void orc_latlon_to_ij_lc(const orc_proj *p, double lat, double lon, double *i, double *j) { llij_lc(p, lat, lon, i, j); }
 

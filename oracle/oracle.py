@@ -211,6 +211,23 @@ class Proj:
         lib().orc_map_set_latlon(p.buf, *(C.c_double(x) for x in (lat1, lon1, knowni, knownj, latinc, loninc)))
         return p
 
+    @classmethod
+    def polar(cls, truelat1, stdlon, lat1, lon1, knowni, knownj, dx):
+        p = cls()
+        lib().orc_map_set_ps(p.buf, *(C.c_double(x) for x in (truelat1, stdlon, lat1, lon1, knowni, knownj, dx)))
+        return p
+
+    @classmethod
+    def mercator(cls, truelat1, lat1, lon1, knowni, knownj, dx):
+        p = cls()
+        lib().orc_map_set_merc(p.buf, *(C.c_double(x) for x in (truelat1, lat1, lon1, knowni, knownj, dx)))
+        return p
+
+    def map_factor(self, lat):
+        """get_map_factor at latitudes `lat` (array) for this projection."""
+        lib().orc_map_factor.restype = C.c_double
+        return np.array([lib().orc_map_factor(self.buf, C.c_double(float(v))) for v in np.asarray(lat, np.float64).ravel()]).reshape(np.shape(lat))
+
     def fields(self):
         names = ["code_pad", "lat1", "lon1", "knowni", "knownj", "dx", "stdlon", "truelat1", "truelat2", "hemi", "cone",
                  "polei", "polej", "rsw", "rebydx", "latinc", "loninc"]
@@ -224,7 +241,7 @@ class Proj:
 
     def latlon_to_ij(self, lat, lon):
         i, j = C.c_double(), C.c_double()
-        lib().orc_latlon_to_ij_lc(self.buf, C.c_double(lat), C.c_double(lon), C.byref(i), C.byref(j))
+        lib().orc_latlon_to_ij(self.buf, C.c_double(lat), C.c_double(lon), C.byref(i), C.byref(j))
         return i.value, j.value
 
     def lat_lon_fields(self, ni, nj, stagger):

@@ -230,6 +230,73 @@ def test_driver_on_a_global_latlon_grid(tmp_path, gpu_lib):
             assert got.shape == w_.shape and np.array_equal(got, w_), k
 
 
+@pytest.mark.parametrize("kind", ["polar", "mercator"])
+def test_driver_on_polar_stereographic_and_mercator_grids(tmp_path, gpu_lib, kind):
+    """target_grid_type = 'polar' / 'mercator' (program_setup.F90:174-182; set_ps / set_merc, module_map_utils.F90): the
+    global mesh under a regional grid containing the pole / crossing the date line; grid variables, map factors, header
+    attributes and every field: Fortran driver == Python mirror bit for bit.  No wind rotation (proj_code /= PROJ_LC,
+    interp.F90:138,291) and no SINALPHA / COSALPHA (write_data.F90:447)."""
+    import copy
+
+    from mpassit_amd import interp as I, io_nc, ncio, post, regrid as R, target_grid as tg, workloads
+    exe = _driver()
+    m, _, _, _ = workloads.workload("c5_small")
+    par = (dict(nx=121, ny=101, dx=60000.0, ref_lat=86.0, ref_lon=10.0, truelat1=70.0, stand_lon=-30.0) if kind == "polar" else
+           dict(nx=141, ny=81, dx=80000.0, ref_lat=5.0, ref_lon=175.0, truelat1=20.0, stand_lon=175.0))
+    g = tg.define_target_grid_params(kind, par["nx"], par["ny"], dx=par["dx"], dy=par["dx"], ref_lat=par["ref_lat"], ref_lon=par["ref_lon"],
+                                     truelat1=par["truelat1"], stand_lon=par["stand_lon"])
+    d = str(tmp_path)
+    nz, nsoil = 6, 4
+    ter = _write_inputs(d, m, nz, nsoil)
+    open(os.path.join(d, "namelist.input"), "w").write("""&config
+  grid_file_input_grid="%s/init.nc"
+  hist_file_input_grid="%s/hist.nc"
+  diag_file_input_grid="%s/diag.nc"
+  output_file="%s/out.nc"
+  target_grid_type = '%s'
+  interp_diag=.true.
+  interp_hist=.true.
+  wrf_mod_vars=.true.
+  nx = %d
+  ny = %d
+  dx = %.1f
+  dy = %.1f
+  ref_lat = %.1f
+  ref_lon = %.1f
+  truelat1 = %.1f
+  stand_lon = %.1f
+/
+""" % (d, d, d, d, kind, par["nx"], par["ny"], par["dx"], par["dx"], par["ref_lat"], par["ref_lon"], par["truelat1"], par["stand_lon"]))
+    r = subprocess.run([exe, "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cfg = I.InterpConfig(wrf_mod_vars=True, proj_is_lambert=False, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
+    inp, _, _ = io_nc.read_input_data(os.path.join(d, "hist.nc"), cfg, ter, diag_path=os.path.join(d, "diag.nc"))
+    gd = copy.copy(g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(gd)
+    want = post.output_fields(I.interp_data(mesh, grid, gd, inp, cfg), cfg)
+    lon_u, lat_u = grid.coords(R.STAGGERLOC_EDGE1)
+    mf_v = grid.mapfac(R.STAGGERLOC_EDGE2)
+    mesh.destroy()
+    grid.destroy()
+    assert np.abs(lat_u - g.lat_u).max() < 1e-11                       # device grid == numpy mirror of set_ps / set_merc
+    with ncio.Reader(os.path.join(d, "out.nc")) as f:
+        assert f.att("MAP_PROJ")[0] == (2 if kind == "polar" else 3)
+        assert f.att("MAP_PROJ_CHAR").strip() == ("Polar Stereographic" if kind == "polar" else "Mercator")
+        assert "SINALPHA" not in f.vars and "COSALPHA" not in f.vars
+        assert np.array_equal(f.get("XLONG_U", rec=0), lon_u.astype(np.float32))
+        assert np.array_equal(f.get("XLAT_U", rec=0), lat_u.astype(np.float32))
+        assert np.array_equal(f.get("MAPFAC_V", rec=0), mf_v.astype(np.float32))
+        assert float(np.abs(f.get("T2", rec=0)).max()) > 0
+        for k, w_ in want.items():
+            got = f.get(k, rec=0)
+            if k == "P_TOP":
+                assert got == w_
+                continue
+            if k == "Z_C":
+                got = got[:nz]
+            assert got.shape == w_.shape and np.array_equal(got, w_), k
+
+
 def _run_images(d, namelist_name, ranks):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

@@ -75,3 +75,105 @@ def test_latlon_grid_is_plain_arithmetic(oracle, glob):
     assert np.abs(g.lat_c[:-1, :-1] - (g.lat - dlat / 2)).max() < 1e-12 and np.abs(g.lon_c[:-1, :-1] - (g.lon - dlon / 2)).max() < 1e-12
     if glob:
         assert g.lat_c[0, 0] == -90.0 and g.lat_c[-1, 0] == 90.0 and abs(((g.lon_c[0, -1] - g.lon_c[0, 0]) + 180.0) % 360.0 - 180.0) < 1e-12   # the duplicate column, one period later
+
+
+def _haversine_m(lat1, lon1, lat2, lon2, R=6370000.0):
+    p1, p2 = np.radians(lat1), np.radians(lat2)
+    a = np.sin((p2 - p1) / 2) ** 2 + np.cos(p1) * np.cos(p2) * np.sin(np.radians(lon2 - lon1) / 2) ** 2
+    return 2 * R * np.arcsin(np.sqrt(a))
+
+
+POLARS = [dict(truelat1=70.0, stdlon=-45.0, lat1=78.0, lon1=-40.0, knowni=200.5, knownj=175.5, dx=15000.0),
+          dict(truelat1=-71.0, stdlon=90.0, lat1=-75.0, lon1=100.0, knowni=60.0, knownj=80.0, dx=25000.0),
+          dict(truelat1=90.0, stdlon=0.0, lat1=60.0, lon1=10.0, knowni=1.0, knownj=1.0, dx=50000.0)]
+
+
+@pytest.mark.parametrize("k", range(len(POLARS)))
+def test_polar_stereographic_against_snyder_and_round_trips(oracle, k):
+    """set_ps / ijll_ps / llij_ps (module_map_utils.F90:682-822) as the numpy mirror and the oracle restate them, against
+    an independent derivation: on a sphere the polar stereographic radius of latitude phi, true at phi_1, is
+    rho = R (1 + sin|phi_1|) tan(pi/4 - |phi|/2) (Snyder 1987, eq. 21-33 with k_0 from the standard parallel), the azimuth
+    is the longitude itself; plus the known point, round trips, and the map factor as the ratio grid length : ground length."""
+    from mpassit_amd import target_grid as T
+    c = POLARS[k]
+    pm = T.Proj.polar(**c)
+    po = oracle.Proj.polar(c["truelat1"], c["stdlon"], c["lat1"], c["lon1"], c["knowni"], c["knownj"], c["dx"])
+    rng = np.random.default_rng(70 + k)
+    ii, jj = rng.uniform(-50, 450, 1500), rng.uniform(-50, 400, 1500)
+    lat, lon = pm.ij_to_latlon(ii, jj)
+    for q in range(0, 1500, 50):                                   # mirror == oracle, point by point
+        la, lo = po.xytoll(ii[q], jj[q])
+        assert abs(la - lat[q]) < 1e-12 and min(abs(lo - lon[q]), 360 - abs(lo - lon[q])) < 1e-12
+    la, lo = pm.ij_to_latlon(c["knowni"], c["knownj"])           # the known point
+    assert abs(la - c["lat1"]) < 1e-10 and abs(lo - c["lon1"]) < 1e-10
+    i2, j2 = pm.latlon_to_ij(lat, lon)                             # round trip
+    assert np.abs(i2 - ii).max() < 1e-7 and np.abs(j2 - jj).max() < 1e-7
+    io, jo = po.latlon_to_ij(float(lat[3]), float(lon[3]))
+    assert abs(io - ii[3]) < 1e-7 and abs(jo - jj[3]) < 1e-7
+    hemi = -1.0 if c["truelat1"] < 0 else 1.0                      # Snyder: distance from the pole in grid lengths
+    rho = 6370000.0 * (1 + np.sin(np.radians(abs(c["truelat1"])))) * np.tan(np.pi / 4 - np.radians(hemi * lat) / 2) / c["dx"]
+    assert np.abs(np.hypot(ii - pm.polei, jj - pm.polej) - rho).max() < 1e-7
+    pole_lat, _ = pm.ij_to_latlon(pm.polei, pm.polej)
+    assert abs(pole_lat - hemi * 90.0) < 1e-9
+    # conformal: one grid length east / north of a point is dx / mapfac on the ground (finite step of 1e-3 grid lengths)
+    h = 1e-3
+    mf = T.get_map_factor(pm, lat)
+    np.testing.assert_allclose(po.map_factor(lat[:40]), mf[:40], rtol=1e-13)
+    for di, dj in ((h, 0.0), (0.0, h)):
+        la2, lo2 = pm.ij_to_latlon(ii + di, jj + dj)
+        ground = _haversine_m(lat, lon, la2, lo2) / h
+        far = np.hypot(ii - pm.polei, jj - pm.polej) > 2.0         # away from the pole itself
+        np.testing.assert_allclose(ground[far], (c["dx"] / mf)[far], rtol=2e-5)
+
+
+MERCS = [dict(truelat1=15.0, lat1=8.0, lon1=150.0, knowni=250.5, knownj=150.5, dx=12000.0),
+         dict(truelat1=-30.0, lat1=-20.0, lon1=-70.0, knowni=1.0, knownj=1.0, dx=20000.0),
+         dict(truelat1=0.0, lat1=0.0, lon1=0.0, knowni=10.0, knownj=20.0, dx=50000.0)]
+
+
+@pytest.mark.parametrize("k", range(len(MERCS)))
+def test_mercator_against_closed_form_and_round_trips(oracle, k):
+    """set_merc / ijll_merc / llij_merc (module_map_utils.F90:1293-1362): x = R cos(phi_1) (lambda - lambda_1),
+    y = R cos(phi_1) (psi(phi) - psi(phi_1)) with the isometric latitude psi = ln tan(pi/4 + phi/2) (Snyder eq. 7-1, 7-2 scaled
+    by the standard parallel); known point, round trips, oracle == mirror, map factor = grid length : ground length."""
+    from mpassit_amd import target_grid as T
+    c = MERCS[k]
+    pm = T.Proj.mercator(**c)
+    po = oracle.Proj.mercator(c["truelat1"], c["lat1"], c["lon1"], c["knowni"], c["knownj"], c["dx"])
+    rng = np.random.default_rng(80 + k)
+    ii, jj = rng.uniform(-100, 600, 1500), rng.uniform(-100, 400, 1500)
+    lat, lon = pm.ij_to_latlon(ii, jj)
+    assert np.abs(lat).max() < 90.0
+    for q in range(0, 1500, 50):
+        la, lo = po.xytoll(ii[q], jj[q])
+        assert abs(la - lat[q]) < 1e-12 and min(abs(lo - lon[q]), 360 - abs(lo - lon[q])) < 1e-12
+    la, lo = pm.ij_to_latlon(c["knowni"], c["knownj"])
+    assert abs(la - c["lat1"]) < 1e-10 and abs(lo - c["lon1"]) < 1e-10
+    i2, j2 = pm.latlon_to_ij(lat, lon)
+    inside = np.abs((ii - c["knowni"]) * pm.dlon) < np.pi           # the longitude wraps once around the globe
+    assert np.abs(i2 - ii)[inside].max() < 1e-7 and np.abs(j2 - jj).max() < 1e-7
+    Rc = 6370000.0 * np.cos(np.radians(c["truelat1"])) / c["dx"]
+    psi = lambda phi: np.log(np.tan(np.pi / 4 + np.radians(phi) / 2))
+    assert np.abs((jj - c["knownj"]) - Rc * (psi(lat) - psi(c["lat1"]))).max() < 1e-7
+    dl = (lon - c["lon1"] + 540.0) % 360.0 - 180.0
+    assert np.abs(((ii - c["knowni"]) - Rc * np.radians(dl))[inside]).max() < 1e-7
+    h = 1e-3
+    mf = T.get_map_factor(pm, lat)
+    np.testing.assert_allclose(po.map_factor(lat[:40]), mf[:40], rtol=1e-13)
+    for di, dj in ((h, 0.0), (0.0, h)):
+        la2, lo2 = pm.ij_to_latlon(ii + di, jj + dj)
+        np.testing.assert_allclose(_haversine_m(lat, lon, la2, lo2) / h, c["dx"] / mf, rtol=2e-5)
+
+
+def test_namelist_accepts_the_four_projections_and_rejects_others():
+    """program_setup.F90:166-191."""
+    from mpassit_amd import target_grid as T
+    g = T.define_target_grid_params("polar", 101, 91, dx=20000.0, dy=20000.0, ref_lat=80.0, ref_lon=0.0, truelat1=70.0, stand_lon=0.0)
+    assert g.proj.code == T.PROJ_PS and g.lat.shape == (90, 100) and g.cosa is None
+    g = T.define_target_grid_params("Mercator", 101, 91, dx=20000.0, dy=20000.0, ref_lat=10.0, ref_lon=0.0, truelat1=10.0, stand_lon=0.0)
+    assert g.proj.code == T.PROJ_MERC and g.lat_c.shape == (91, 101)
+    assert abs(g.lat[44, 49] + g.lat[45, 50] - 20.0) < 0.5           # the known point is the domain centre by default
+    with pytest.raises(ValueError):
+        T.define_target_grid_params("albers", 101, 91, dx=20000.0, dy=20000.0, ref_lat=10.0, ref_lon=0.0, truelat1=10.0, stand_lon=0.0)
+    with pytest.raises(ValueError):
+        T.define_target_grid_params("polar", 101, 91, dx=20000.0, dy=20000.0, ref_lat=80.0, ref_lon=0.0, stand_lon=0.0)

@@ -18,7 +18,8 @@ def _lon_close(a, b, tol):
     return np.minimum(d, np.abs(d - 360.0)).max() < tol
 
 
-@pytest.mark.parametrize("case", ["readme_lambert", "two_truelats_south", "regional_latlon", "global_latlon"])
+@pytest.mark.parametrize("case", ["readme_lambert", "two_truelats_south", "regional_latlon", "global_latlon", "polar_north", "polar_south",
+                                  "mercator"])
 def test_device_grid_matches_host_mirror(oracle, gpu_lib, case):
     from mpassit_amd import regrid as R, target_grid as T
     kw = {"readme_lambert": dict(target_grid_type="lambert", nx=1801, ny=1061, dx=3000.0, dy=3000.0, ref_lat=38.5, ref_lon=-97.5,
@@ -27,7 +28,13 @@ def test_device_grid_matches_host_mirror(oracle, gpu_lib, case):
                                      truelat1=-30.0, truelat2=-60.0, stand_lon=135.0, ref_x=100.0, ref_y=80.0),
           "regional_latlon": dict(target_grid_type="lat-lon", nx=201, ny=201, dx=0.1, dy=0.1, ref_lat=30.0, ref_lon=-110.0, ref_x=1.0,
                                   ref_y=1.0, stand_lon=-110.0),
-          "global_latlon": dict(target_grid_type="lat-lon", nx=361, ny=181, stand_lon=0.0, is_regional=False)}[case]
+          "global_latlon": dict(target_grid_type="lat-lon", nx=361, ny=181, stand_lon=0.0, is_regional=False),
+          "polar_north": dict(target_grid_type="polar", nx=401, ny=351, dx=15000.0, dy=15000.0, ref_lat=78.0, ref_lon=-40.0, truelat1=70.0,
+                              stand_lon=-45.0),                      # the pole lies inside this domain
+          "polar_south": dict(target_grid_type="polar", nx=201, ny=221, dx=25000.0, dy=25000.0, ref_lat=-75.0, ref_lon=100.0, truelat1=-71.0,
+                              stand_lon=90.0, ref_x=60.0, ref_y=80.0),
+          "mercator": dict(target_grid_type="mercator", nx=501, ny=301, dx=12000.0, dy=12000.0, ref_lat=8.0, ref_lon=150.0, truelat1=15.0,
+                           stand_lon=150.0)}[case]       # crosses the date line
     host = T.define_target_grid_params(**kw)
     lean = T.define_target_grid_params(arrays=False, **kw)
     assert lean.lat is None and lean.nx == host.nx
@@ -38,8 +45,15 @@ def test_device_grid_matches_host_mirror(oracle, gpu_lib, case):
         assert lon_d.shape == lon_h.shape
         assert np.abs(lat_d - lat_h).max() < DEG_TOL and _lon_close(lon_d, lon_h, DEG_TOL)
     for st, lat_h in ((R.STAGGERLOC_CENTER, host.lat), (R.STAGGERLOC_EDGE1, host.lat_u), (R.STAGGERLOC_EDGE2, host.lat_v)):
-        want = oracle.map_factor(lat_h, host.proj.code, kw.get("truelat1", 0.0), kw.get("truelat2", 0.0))
-        np.testing.assert_allclose(g.mapfac(st), want, rtol=1e-13)
+        if host.proj.code in (T.PROJ_PS, T.PROJ_MERC):
+            op = (oracle.Proj.polar(kw["truelat1"], kw["stand_lon"], host.proj.lat1, host.proj.lon1, host.proj.knowni, host.proj.knownj, kw["dx"])
+                  if host.proj.code == T.PROJ_PS else
+                  oracle.Proj.mercator(kw["truelat1"], host.proj.lat1, host.proj.lon1, host.proj.knowni, host.proj.knownj, kw["dx"]))
+            want = op.map_factor(lat_h)
+            np.testing.assert_allclose(T.get_map_factor(host.proj, lat_h), want, rtol=1e-13)
+        else:
+            want = oracle.map_factor(lat_h, host.proj.code, kw.get("truelat1", 0.0), kw.get("truelat2", 0.0))
+        np.testing.assert_allclose(g.mapfac(st), want, rtol=1e-12)
     if host.proj.code == T.PROJ_LC:
         cosa, sina = g.rotang()
         cosa_o, sina_o = oracle.get_rotang(host.lat, host.lon)
