@@ -436,7 +436,8 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
   // Row-shifted tiles (aligned store segments, mpg_internal.h) first; when their longest list does not fit the staged
   // kernels' 1024 cells per tile (grids whose rows start at many different offsets in a line: the shifted rows of a tile
   // then spread over up to 31 more columns) the lists are built for unshifted tiles instead.
-  h->ut_align = (h->nx_dst % MPG_TILE_ALIGN) ? MPG_TILE_ALIGN : 1;
+  h->ut_align = mpg_tile_align(h->nx_dst);
+  if (h->nx_dst % h->ut_align == 0) h->ut_align = 1;   // every row starts aligned already: nothing to shift
   const int nty = (h->ny_dst + tyu - 1) / tyu;
   int ntx = 0;
   int64_t ntile = 0;

@@ -10,16 +10,35 @@
 #include "../../include/mpassit_amd.h"
 
 // Tiles of the Regrid kernels are txu x tyu target points whose x origin is shifted per grid row so that every segment of a
-// row a workgroup stores starts at a multiple of MPG_TILE_ALIGN elements of the flattened [ny][nx] plane (128 bytes for
+// row a workgroup stores starts at a multiple of A elements of the flattened [ny][nx] plane (A = 32: 128 bytes for
 // float32, 256 for float64): with nx = 1800 the unshifted 64-point segments start 32 / 64 / 96 bytes into a line in three
 // rows of four, and aligned segments were measured 4 % (float64 cell-fast), 5 % (float64 level-fast) and 17 % (float32
 // cell-fast) faster on configuration 4 (profiles/r02_alignment.txt).  Tile column tx of row j holds
 // i = tx * txu - mpg_tile_shift(j, nx) + 0 .. txu-1; points with i < 0 or i >= nx do not exist.
+// The shift widens a 2-D tile: two neighbouring grid rows share their source cells, and their segments now start
+// d = (nx mod A, folded to +-A/2) points apart, so the tile references about |d| / 64 more cells (C5, nx = 3600, A = 32:
+// d = 16, the staged level-fast kernel lost 15 %).  mpg_tile_align picks the largest A in {32, 16, 8} whose d stays
+// within 8 points: nx = 1800 -> 32 (d = 8), 3600 -> 16 (d = 0: no shift at all), 1801 -> 16 (d = 7), 150 -> 16 (d = 6).
 #ifndef MPG_TILE_ALIGN
-#define MPG_TILE_ALIGN 32
+#define MPG_TILE_ALIGN 32   // the largest alignment tried (elements); -DMPG_TILE_ALIGN=1 builds without the shift (A/B runs)
 #endif
-static inline __host__ __device__ int mpg_tile_shift(int j, int nx, int align = MPG_TILE_ALIGN) { return align > 1 ? (int)(((long long)j * nx) % align) : 0; }
-static inline int mpg_tile_ntx(int nx, int txu, int align = MPG_TILE_ALIGN) { return (nx + (align > 1 && nx % align ? align - 1 : 0) + txu - 1) / txu; }
+static inline __host__ __device__ int mpg_tile_align(int nx) {
+  for (int a = MPG_TILE_ALIGN; a >= 8; a >>= 1) {
+    int d = nx % a;
+    d = d < a - d ? d : a - d;
+    if (d <= 8) return a;
+  }
+  return MPG_TILE_ALIGN >= 8 ? 8 : 1;
+}
+// align < 0: the grid's own choice (mpg_tile_align); 1: no shift
+static inline __host__ __device__ int mpg_tile_shift(int j, int nx, int align = -1) {
+  if (align < 0) align = mpg_tile_align(nx);
+  return align > 1 ? (int)(((long long)j * nx) % align) : 0;
+}
+static inline int mpg_tile_ntx(int nx, int txu, int align = -1) {
+  if (align < 0) align = mpg_tile_align(nx);
+  return (nx + (align > 1 && nx % align ? align - 1 : 0) + txu - 1) / txu;
+}
 
 #define MPG_WAVE 64
 
