@@ -75,7 +75,7 @@ def test_smallest_and_thinnest_grids(gpu_lib, oracle, global_mesh, nxy):
     grid.destroy()
 
 
-@pytest.mark.parametrize("nlev", [1, 2, 3, 5, 9, 17, 33])
+@pytest.mark.parametrize("nlev", [1, 2, 3, 5, 9, 17, 33, 64, 65, 129])
 def test_ragged_level_counts(gpu_lib, oracle, regional_case, nlev):
     """Level counts that are not multiples of the kernels' level chunks, both layouts, float64 and float32 sources, and a
     two-field bundle: the last, partial chunk must neither read nor write past its levels."""
@@ -104,6 +104,17 @@ def test_ragged_level_counts(gpu_lib, oracle, regional_case, nlev):
         want32 = oracle.apply_fixed(idx_o, w_o, (s32 if layout == R.LAYOUT_CELL_FAST else s32.T).astype(np.float64), nlev)
         got32 = rh.regrid(s32, nlev=nlev, layout=layout).reshape(nlev, P)
         assert _rel(got32, want32) < 1e-12
+        # float32 in, float32 out (the file-to-file path: linear 64-point tiles, two levels per lane; 64 / 65 / 129 levels
+        # take more than one pass over the lanes), guard band behind the float32 destination
+        o32 = torch.full((nlev * P + 4096,), 7.5, dtype=torch.float32, device="cuda")
+        rh.regrid_typed(torch.as_tensor(s32, device="cuda").reshape(-1), nlev=nlev, layout=layout, out_dtype=torch.float32, offset=-1.5,
+                        out=o32[:nlev * P].view(1, nlev, g.ny, g.nx))
+        torch.cuda.synchronize()
+        g32 = o32.cpu().numpy()
+        assert (g32[nlev * P:] == 7.5).all()
+        ref = (want32 - 1.5).astype(np.float32)
+        ne = g32[:nlev * P].reshape(nlev, P) != ref
+        assert ne.mean() < 1e-4 and (np.abs(g32[:nlev * P].reshape(nlev, P)[ne].astype(np.float64) - ref[ne]) <= np.spacing(np.abs(ref[ne]))).all()
     rh.release()
     mesh.destroy()
     grid.destroy()
