@@ -268,3 +268,35 @@ def test_config3_655k_conservative_snow_and_soil(c23, oracle):
     want = oracle.apply_csr(rp_o, col_o, val_o, snow, 1)[0]
     assert rel_err(got, want) < osd.ctol
     rh.release()
+
+
+@pytest.mark.parametrize("kind", ["polar", "mercator"])
+def test_stores_on_polar_stereographic_and_mercator_grids(gpu_lib, oracle, kind):
+    """The two other projections of the namelist (program_setup.F90:174-182) through all three RegridStores against the
+    oracle: a polar stereographic grid with the NORTH POLE inside a destination cell (the conservative clip has to handle a
+    cell whose corners surround the pole; longitudes of neighbouring points jump by up to 180 degrees) and a Mercator grid
+    across the date line."""
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    m = synth.icosahedral_mesh(6)                              # 40 962 cells, ~120 km
+    if kind == "polar":
+        g = T.define_target_grid_params("polar", 141, 121, dx=50000.0, dy=50000.0, ref_lat=89.0, ref_lon=25.0, truelat1=75.0, stand_lon=-100.0)
+        assert g.lat.max() > 89.5                               # the pole lies inside the mass grid
+    else:
+        g = T.define_target_grid_params("mercator", 161, 91, dx=70000.0, dy=70000.0, ref_lat=-8.0, ref_lon=179.0, truelat1=-15.0, stand_lon=179.0)
+        assert (g.lon > 170).any() and (g.lon < -170).any()     # both sides of the date line
+    osd = OracleSide(oracle, m, g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    res = check_stores(R, mesh, grid, osd, ("bilinear", "nearest", "conserve"))
+    assert res["mapped"].all()                                   # a global mesh maps every point of a regional grid
+    # a field through the bilinear handle, and the conservative one: a constant stays the constant (rows sum to 1)
+    L = 3
+    src = synth.analytic_field(m.latCell, m.lonCell, L)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    assert rel_err(rh.regrid(src, nlev=L).reshape((L,) + osd.shape), osd.apply_bil(src, L)) < 1e-12
+    rh.release()
+    rc = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    one = rc.regrid(np.full(m.nCells, 2.5), nlev=1)
+    assert np.abs(one - 2.5).max() < 1e-11
+    rc.release()
+    mesh.destroy()
+    grid.destroy()
