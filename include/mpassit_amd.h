@@ -253,9 +253,19 @@ int mpg_handle_rebase(mpg_handle rh, int64_t base, int64_t n_local);
 int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *ids_dev, int64_t n_ids,
                  double *dst_dev, void *hip_stream);
 
-/* kernel-selection knobs for benchmarking (defaults are the tuned production values):
- *   "lev_chunk"  levels per workgroup pass of the 3-point apply kernel (0 = all levels)
- *   "a3_variant" index into the compiled (rows-per-thread, level-unroll, non-temporal) variants */
+/* kernel-selection knobs for benchmarking and the A/B tests (defaults are the tuned production values; DESIGN.md s4.1 has
+ * the measurements behind every default).  They select among kernels that produce identical bits:
+ *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0..17 a staged variant
+ *                 (13: 64x8-point tiles, 10: 64x16 on 256 threads, 16: 64x16 on 512 threads, 14/15: 64x32 on 512 threads)
+ *   "lf_variant"  level-fast 3-point Regrid: -1 per-handle choice (default), 0..9 row-gather variants on 64x1 row tiles,
+ *                 100..119 level-chunked staged variants, 200 / 300..302 rows-resident, 401..403 / 410..418 the float32
+ *                 row-gather experiments of the typed entry, 500 the row gather on linear aligned tiles
+ *   "a3_variant", "lev_chunk", "fields_per_wg", "tile_group"   shape of the lane-gather kernel
+ *   "cfu_fields_per_wg", "lf_fields_per_wg"   fields of a bundle served by one workgroup (default 1)
+ *   "tile_band"   tile rows per band of the staged cell-fast kernel's tile order (0 = row-major, default)
+ *   "nn_variant"  nearest-neighbour search: 1 wave-cooperative (default), 0 one thread per point
+ *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice
+ * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */
 int mpg_tune(const char *key, int value);
 
 /* timing of the last Store phases in ms (search build, search, finalize); any pointer may be NULL */
