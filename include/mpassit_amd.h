@@ -255,7 +255,7 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
 
 /* kernel-selection knobs for benchmarking and the A/B tests (defaults are the tuned production values; DESIGN.md s4.1 has
  * the measurements behind every default).  They select among kernels that produce identical bits:
- *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0..17 a staged variant
+ *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0..18 a staged variant
  *                 (13: 64x8-point tiles, 10: 64x16 on 256 threads, 16: 64x16 on 512 threads, 14/15: 64x32 on 512 threads)
  *   "lf_variant"  level-fast 3-point Regrid: -1 per-handle choice (default), 0..9 row-gather variants on 64x1 row tiles,
  *                 100..119 level-chunked staged variants, 200 / 300..302 rows-resident, 401..403 / 410..418 the float32

@@ -359,6 +359,8 @@ static const LfuVariant g_cfu_variants[] = {  // cell-fast staged: a3_variant 10
     {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 12, 512>, 512}, {64, 4, 4, k_apply3_cfu_p<64, 4, 4, 16, 512>, 512},
     // 16-17: 64 x 16-point tiles on 512 threads (2 points each, the registers of the 64 x 8 kernel)
     {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 16, 512>, 512}, {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 12, 512>, 512},
+    // 18: 64 x 32-point tiles on 1024 threads (2 points each)
+    {64, 2, 4, k_apply3_cfu_p<64, 2, 4, 8, 1024>, 1024},
     // (compact tiles of 32 x 32, 16 x 64 and 32 x 16 points with the same 1024-cell capacity were measured in round 2 on C4,
     //  Morton-numbered C4, C2 and C5: 0-15 % slower than 64 x 8 / 64 x 16 everywhere, profiles/r02_sweep_cfu_compact.txt)
 };
@@ -369,7 +371,7 @@ static int g_cfu_fpw = 1;   // "cfu_fields_per_wg": fields of a bundle served by
 void mpg_cfu_set_fields_per_wg(int v) { g_cfu_fpw = v < 1 ? 1 : (v > 255 ? 255 : v); }
 int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_variants[0])); }
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
-static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16, 12, 16, 16, 12};
+static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16, 12, 16, 16, 12, 8};
 static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * g_cfu_variants[variant].nt; }
 static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap = 1024);
 static int cfu_build(mpg_handle_s *h, int variant, hipStream_t s) {

@@ -28,9 +28,9 @@ def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
         rh.rebase(0, m.nCells)                               # re-indexing drops the tile lists; they are rebuilt on demand
         got = rh.regrid(src_lf.reshape(-1), nlev=nlev, nfields=nfields, layout=R.LAYOUT_LEV_FAST)
         assert np.array_equal(got, want)
-        # cell-fast staged variants (a3_staged 0..17; 14-15: 64 x 32 tiles, 16-17: 64 x 16 tiles, 512 threads) and the per-handle choice (-1) against
+        # cell-fast staged variants (a3_staged 0..18; 14-15: 64 x 32 tiles, 16-17: 64 x 16 tiles on 512 threads, 18: 64 x 32 on 1024) and the per-handle choice (-1) against
         # the lane-gather kernel (-2)
-        for v in list(range(18)) + [-1]:
+        for v in list(range(19)) + [-1]:
             gpu_lib.tune("a3_staged", v)
             got = rh.regrid(src.reshape(-1), nlev=nlev, nfields=nfields)
             assert np.array_equal(got, want), "a3_staged %d differs" % v
