@@ -34,6 +34,13 @@ def workload(name, arrays=True):
         g = conus_lambert_grid(nx=1793)
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
         return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1793x1061 Lambert (1792x1060 mass points)"
+    if name.startswith("x_c4_rows"):
+        # extra (strong-scaling rehearsal on one GPU): one rank's share of configuration 4 at N ranks = a block of
+        # 1060 / N grid rows of the same 1800-wide grid over the same mesh, e.g. x_c4_rows133 for N = 8
+        rows = int(name[len("x_c4_rows"):])
+        g = conus_lambert_grid(ny=rows + 1)
+        m = synth.regional_mesh_for_lambert(conus_lambert_grid().proj, 1801, 1061, 3_000_000)
+        return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> a %d-row block of the 1800-wide Lambert grid" % rows
     if name == "c2_655k_global":
         # BASELINE configs 2 and 3: the GLOBAL quasi-uniform 655 362-cell mesh (10*4^8 + 2 cells = MPAS x1.655362, SURVEY
         # s8(d)) under the README Lambert domain, which touches only 2-3 % of its cells; Morton-numbered.
