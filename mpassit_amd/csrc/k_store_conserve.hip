@@ -11,9 +11,10 @@
 // source cell walks the pyramid and LISTS the destination cells that survive the box / bounding-sphere tests;
 // (2) one thread per (source cell, destination cell) PAIR clips it, both polygon buffers in LDS, and bumps the
 // destination cell's counter.  A rocPRIM scan turns the counters into CSR row offsets, a scatter pass moves the pairs
-// into place (source cells with more candidates than their list holds -- polar cells under lat-lon slivers -- are
-// clipped by one workgroup each, writing in place), and every (short) row is sorted by source id so the stored matrix
-// and the summation order are deterministic.  Destination cell areas are computed once per Store, not per overlap.
+// into place, and every (short) row is sorted by source id so the stored matrix and the summation order are
+// deterministic.  Source cells with more candidates than the fixed-size list of step (1) holds -- polar cells under
+// lat-lon slivers, or every cell of a coarse mesh under a fine grid -- are walked again by one WORKGROUP each, which
+// counts and then lists their candidates at exact size; the pairs join the same pair-parallel clip.  Destination cell areas are computed once per Store, not per overlap.
 // Clipping = Sutherland-Hodgman against the 4 great-circle half-spaces.
 #include <cstring>
 
@@ -27,48 +28,13 @@
 #define CONS_STACK 64
 #define CONS_QUEUE 2048  // breadth-first node queue of the cooperative passes
 
-__device__ int clip_halfspace(int n, const dv3 *in, dv3 nrm, dv3 *out) {
-  int m = 0;
-  double eps = 1e-15 * sqrt(dot3(nrm, nrm));
-  for (int i = 0; i < n; ++i) {
-    dv3 X1 = in[i], X2 = in[(i + 1 == n) ? 0 : i + 1];
-    double d1 = dot3(nrm, X1), d2 = dot3(nrm, X2);
-    bool in1 = d1 >= -eps, in2 = d2 >= -eps;
-    if (in1 && m < CONS_BUF) out[m++] = X1;
-    if (in1 != in2 && m < CONS_BUF) {
-      dv3 X = X1 * d2 - X2 * d1;
-      double sgn = (d2 - d1) > 0.0 ? 1.0 : -1.0;
-      double nn = sqrt(dot3(X, X));
-      if (nn > 0.0) out[m++] = X * (sgn / nn);
-    }
-  }
-  return m;
-}
-__device__ double clip_area(int ns, const dv3 *src, const dv3 *quad) {
-  dv3 a[CONS_BUF], b[CONS_BUF];
-  int n = ns;
-  for (int i = 0; i < ns; ++i) a[i] = src[i];
-  dv3 *cur = a, *nxt = b;
-  for (int e = 0; e < 4 && n >= 3; ++e) {
-    // a collapsed side (the two CORNER points of a lat-lon cell at a pole, equal up to the rounding of cos(90))
-    // bounds nothing, and the direction of its great circle is noise: skip it
-    dv3 side = quad[(e + 1) & 3] - quad[e];
-    if (dot3(side, side) < 1e-24) continue;
-    dv3 nrm = cross3(quad[e], quad[(e + 1) & 3]);
-    n = clip_halfspace(n, cur, nrm, nxt);
-    dv3 *t = cur; cur = nxt; nxt = t;
-  }
-  if (n < 3) return 0.0;
-  double s = 0.0;
-  for (int i = 1; i + 1 < n; ++i) s += sph_tri_area(cur[0], cur[i], cur[i + 1]);
-  return s > 0.0 ? s : 0.0;
-}
-
 // The pyramid walk of one source cell.  MODE 3 ("candidates", one thread per source cell): every destination cell that
-// passes the box / bounding-sphere tests goes into the cell's slot list tmp_dst[c*CAND_CAP ..]; the pairs are clipped by
-// k_conserve_clip_pairs below.  A cell with more than CAND_CAP candidates (a polar cell under thousands of lat-lon
-// slivers) is handed to the cooperative passes instead: MODE 2 counts its overlaps per destination cell, MODE 1 ("overflow
-// fill") clips it again after the scan and writes straight to rowptr[p] + cursor[p]++ -- one WORKGROUP per such cell.
+// passes the box / bounding-sphere tests goes into the cell's slot list tmp_dst[c*CAND_CAP ..]; a cell with more than
+// CAND_CAP candidates is put on the overflow list instead.  MODE 5 / 6 (one WORKGROUP per overflowed cell, its threads
+// share the cell's subtrees of the pyramid): 5 counts the cell's candidates (-> cnt_src[c]), 6 writes them as pairs at
+// pair_[cp][poff[c] ..] after the scan.  Every pair is clipped by k_conserve_clip_pairs below.
+// (Round 2 first clipped the overflowed cells inside this walk, polygon buffers in scratch memory: 28 ms for configuration
+// 2, where all 22 204 referenced 30-km cells overflow under the 3-km grid.)
 #define CAND_CAP 24   // candidate destination cells per source cell kept by the candidate pass
 template <int MODE>
 __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
@@ -76,15 +42,12 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          const double *__restrict__ vz, PyramidView pyr, int nx, int ny,
                                                          const double *__restrict__ qx, const double *__restrict__ qy,
                                                          const double *__restrict__ qz, const double *__restrict__ qarea,
-                                                         const double *__restrict__ qsph, int32_t *__restrict__ count,
-                                                         const int32_t *__restrict__ rowptr,
-                                                         int32_t *__restrict__ col, double *__restrict__ val,
-                                                         int32_t *__restrict__ cnt_src, int32_t *__restrict__ tmp_dst,
-                                                         int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
-                                                         uint8_t *__restrict__ flip) {
-  // MODE 3: one thread per source cell.  MODE 1 / 2: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]); its threads
-  // share the cell's subtrees of the pyramid, so a polar cell under thousands of slivers is clipped by 128 lanes at once.
-  constexpr bool COOP = MODE == 1 || MODE == 2;
+                                                         const double *__restrict__ qsph, int32_t *__restrict__ cnt_src,
+                                                         int32_t *__restrict__ tmp_dst, int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
+                                                         uint8_t *__restrict__ flip, const int32_t *__restrict__ poff,
+                                                         int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p) {
+  // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
+  constexpr bool COOP = MODE == 5 || MODE == 6;
   int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
   int found = 0;
@@ -98,6 +61,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   double area = 0.0;
   for (int i = 1; i + 1 < n; ++i) area += sph_tri_area(poly[0], poly[i], poly[i + 1]);
   if (area == 0.0) return;
+  if (MODE == 3 && flip) flip[c] = area < 0.0;   // the clip kernel orients the polygon the same way (also for cells that overflow below)
   if (area < 0.0)  // make CCW seen from outside
     for (int i = 0; i < n / 2; ++i) {
       dv3 t = poly[i]; poly[i] = poly[n - 1 - i]; poly[n - 1 - i] = t;
@@ -119,10 +83,10 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   // Seeds of the depth-first walk.  MODE 0: the root.  Cooperative modes: the workgroup first expands the pyramid
   // breadth-first in LDS (one node per thread and level) down to 8 x 8-cell nodes, then every thread walks its share.
   __shared__ int q_nodes[2][CONS_QUEUE];
-  __shared__ int q_n[2], q_over;
+  __shared__ int q_n[2], q_over, s_found;
   int seed_lev = pyr.nlev - 1, nseed = 1, cur = 0;
   if (COOP) {
-    if (threadIdx.x == 0) { q_nodes[0][0] = 0; q_n[0] = 1; q_over = 0; }
+    if (threadIdx.x == 0) { q_nodes[0][0] = 0; q_n[0] = 1; q_over = 0; s_found = 0; }
     __syncthreads();
     while (seed_lev > 1) {
       const int nq = q_n[cur];
@@ -201,17 +165,12 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
             }
             tmp_dst[c * CAND_CAP + found] = (int32_t)p;
             ++found;
-            continue;
-          }
-          double ar = clip_area(n, poly, q);
-          if (ar > 1e-14 * aq) {
-            if (MODE == 2) {
-              atomicAdd(&count[p], 1);
-            } else {
-              int slot = atomicAdd(&count[p], 1);
-              col[rowptr[p] + slot] = (int32_t)c;
-              val[rowptr[p] + slot] = ar / aq;
-            }
+          } else if (MODE == 5) {
+            atomicAdd(&s_found, 1);
+          } else {
+            const int slot = atomicAdd(&s_found, 1);
+            pair_c[poff[c] + slot] = (int32_t)c;
+            pair_p[poff[c] + slot] = (int32_t)p;
           }
         }
     } else {
@@ -227,7 +186,10 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   }
   }
   if (MODE == 3) cnt_src[c] = found;
-  if (MODE == 3 && flip) flip[c] = area < 0.0;
+  if (MODE == 5) {
+    __syncthreads();
+    if (threadIdx.x == 0) cnt_src[c] = s_found;
+  }
 }
 
 // signed area of every destination cell (corner order i,j -> i+1,j -> i+1,j+1 -> i,j+1), once per grid
@@ -289,7 +251,7 @@ __global__ __launch_bounds__(256) void k_conserve_clamp_counts(int64_t nCells, c
   int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c > nCells) return;
   int n = c < nCells ? cnt_src[c] : 0;
-  npair[c] = n > CAND_CAP ? 0 : n;       // cells handed to the cooperative passes list no pairs
+  npair[c] = n;                          // overflowed cells: their exact count from the cooperative count pass
 }
 __global__ __launch_bounds__(256) void k_conserve_fill_pairs(int64_t nCells, const int32_t *__restrict__ npair, const int32_t *__restrict__ poff,
                                                              const int32_t *__restrict__ tmp_dst, int32_t *__restrict__ pair_c,
@@ -297,6 +259,7 @@ __global__ __launch_bounds__(256) void k_conserve_fill_pairs(int64_t nCells, con
   int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
   const int n = npair[c], o = poff[c];
+  if (n > CAND_CAP) return;              // overflowed cell: its pairs are written by k_conserve_raster<6>
   for (int e = 0; e < n; ++e) {
     pair_c[o + e] = (int32_t)c;
     pair_p[o + e] = tmp_dst[c * CAND_CAP + e];
@@ -441,10 +404,15 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
-                                        qarea.p, qsph.p, nullptr, nullptr, nullptr, nullptr, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p);
+                                        qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
   MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
+    k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
+                                                       cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
+                                                       nullptr, nullptr);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
   size_t tmp_bytes = 0, b2 = 0;
@@ -462,6 +430,11 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   }
   if ((rc = pair_c.alloc((size_t)npairs + 1)) || (rc = pair_p.alloc((size_t)npairs + 1)) || (rc = pair_val.alloc((size_t)npairs + 1))) return rc;
   k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
+  if (novf > 0)
+    k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
+                                                       cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
+                                                       pair_c.p, pair_p.p);
+  MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12
   const int cb = m->maxEdges + 6 < CONS_BUF ? m->maxEdges + 6 : CONS_BUF;
@@ -472,10 +445,6 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     k_conserve_clip_pairs<<<(unsigned)(((int64_t)npairs + CLIP_NT - 1) / CLIP_NT), CLIP_NT, clip_lds_bytes, s>>>(
         npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
         pair_val.p, count.p);
-  if (novf > 0)  // MODE 2: cooperative count of the cells with more candidates than the lists hold (polar cells under slivers)
-    k_conserve_raster<2><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, nullptr, nullptr, nullptr, cnt_src.p,
-                                                       nullptr, ovf.p, nullptr, nullptr);
   MPG_HIP(hipGetLastError());
   tmp_bytes = b2;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
@@ -492,11 +461,6 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (npairs > 0)
     k_conserve_scatter_pairs<<<(unsigned)(((int64_t)npairs + 255) / 256), 256, 0, s>>>(npairs, pair_c.p, pair_p.p, pair_val.p, h->rowptr.p, count.p,
                                                                                       h->col.p, h->val.p);
-  // the few source cells with more than CAND_CAP candidates are clipped again, one workgroup each, writing in place
-  if (novf > 0)
-    k_conserve_raster<1><<<(unsigned)novf, 128, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny,
-                                                       cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p, count.p, h->rowptr.p, h->col.p, h->val.p,
-                                                       cnt_src.p, nullptr, ovf.p, nullptr, nullptr);
   k_csr_sort_rows<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, h->rowptr.p, h->col.p, h->val.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
