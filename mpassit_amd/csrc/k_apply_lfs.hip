@@ -15,7 +15,8 @@
 //     point at an all-zero LDS row instead of being selected away.
 // Measured (round 2, profiles/r02_lfs_*.txt, float32 in / out, 13 fields): C5 6.82 ms and the 655 k-cell configurations
 // 1.62 / 2.20 ms -- 2-6 % faster than the level-chunked staged kernel; C4 3.4-3.6 ms against 3.1-3.3 ms of the
-// row-gather kernel k_apply3_lf_f32x2, which therefore stays the default there.  MODE 1-7 are the ablations that show
+// row-gather kernel k_apply3_lf_f32x2 (later replaced as the default by k_apply3_lf_f32m, k_apply_typed.hip: 2.6 ms on the
+// same workload with linear aligned tiles, 32-bit row offsets and 8 workgroups per CU).  MODE 1-7 are the ablations that show
 // why: every phase alone is fast (stores alone 6.3 TB/s, row gather alone 7 TB/s), but a workgroup
 // lives 7.5 us -- 2.7 us of dependent prologue loads, 2.9 us until its rows have landed, 1.1 us combine, 0.5 us store
 // acknowledgement -- and LDS lets only ~5 of them share a CU; with 4-byte elements that latency chain, not bytes or

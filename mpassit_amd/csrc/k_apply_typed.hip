@@ -7,7 +7,8 @@
 //     dst = (TD)( regrid(src) * scale + offset )
 // so the float32 results are bit-identical to what the reference's writer would put in the file, while the
 // HBM traffic per 3-D field drops from 8+8 to 4+4 bytes per source/destination element.
-// Same structure as k_apply3_cf<2,4,true> / k_apply3_lf<64> in k_apply.hip.
+// k_apply3_cf_t / k_apply3_lf_t / k_apply3_lf_f32x2 have the structure of k_apply3_cf<2,4,true> / k_apply3_lf<64> in k_apply.hip;
+// k_apply3_lf_f32m (further down) is the level-fast row gather both entry points use by default, for float32 and float64 rows.
 #include <algorithm>
 
 #include "geom.h"
