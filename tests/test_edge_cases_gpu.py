@@ -176,3 +176,30 @@ def test_reinit_on_another_device_is_refused(gpu_lib):
     lib = gpu_lib.load()
     assert lib.mpg_init(C.c_int(0)) == 0
     assert lib.mpg_init(C.c_int(1)) != 0                 # out of range on a one-GPU box, "already initialised" on a node
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_conservative_store_of_a_very_coarse_mesh(gpu_lib, oracle, level):
+    """12 / 42 source cells under a 300 x 250 grid: every source cell has tens of thousands of candidate destination cells, far
+    beyond the fixed-size candidate lists -- all of them take the cooperative count / list passes (and outgrow the 2048-node
+    breadth-first queue of those passes), every destination cell lies inside one to three source cells."""
+    from _parity_helpers import assert_csr_equal, conserve_tol
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    m = synth.icosahedral_mesh(level)
+    g = T.define_target_grid_params("lat-lon", 301, 251, dx=0.2, dy=0.2, ref_lat=-25.0, ref_lon=100.0, ref_x=1.0, ref_y=1.0, stand_lon=100.0)
+    cxyz, vxyz = mesh_xyz(oracle, m)
+    rp_o, col_o, val_o = oracle.conserve(m.verticesOnCell, vxyz, g.nx, g.ny, oracle.lonlat_deg_to_xyz(g.lon_c, g.lat_c))
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    rp_g, col_g, val_g = rh.csr()
+    n_common, only_o, only_g = assert_csr_equal(rp_o, col_o, val_o, rp_g, col_g, val_g, m.nCells, tol=conserve_tol(oracle, g))
+    assert n_common >= g.nx * g.ny and n_common > 0.999 * max(col_o.size, col_g.size)
+    P = g.nx * g.ny
+    rowsum = np.bincount(np.repeat(np.arange(P), np.diff(rp_g)), weights=val_g, minlength=P)
+    assert np.abs(rowsum - 1).max() < 1e-9                       # the mesh covers the sphere: every destination cell fully covered
+    out = rh.regrid(np.arange(m.nCells, dtype=np.float64) + 1.0, nlev=1).reshape(-1)
+    want = np.bincount(np.repeat(np.arange(P), np.diff(rp_o)), weights=val_o * (col_o + 1.0), minlength=P)
+    assert _rel(out, want) < 1e-9
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
