@@ -337,7 +337,8 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
       const dv3 qb = e == 0 ? q[1] : e == 1 ? q[2] : e == 2 ? q[3] : q[0];
       dv3 side = qb - qa;
       if (dot3(side, side) < 1e-24) continue;     // collapsed side (pole): bounds nothing
-      n = clip_halfspace_lds(n, L, cur, cross3(qa, qb), cur ^ 1, cb);
+      // a x (b - a) = a x b in difference form: the direct product's rounding would shift the plane by 1e-16 / |b - a| radians
+      n = clip_halfspace_lds(n, L, cur, cross3(qa, side), cur ^ 1, cb);
       cur ^= 1;
     }
     if (n >= 3) {

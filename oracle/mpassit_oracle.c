@@ -372,7 +372,10 @@ static double clip_area(int ns, const v3 *src, const v3 *quad) {
     /* collapsed side (both CORNER points of a lat-lon cell at a pole): bounds nothing, direction is noise */
     v3 side = v3sub(quad[(e + 1) & 3], quad[e]);
     if (v3dot(side, side) < 1e-24) continue;
-    v3 nrm = v3cross(quad[e], quad[(e + 1) & 3]);
+    /* normal of the great circle through the side, in difference form: a x (b - a) = a x b, but the rounding error of the
+     * direct product (1e-16 absolute on a vector of length |b - a|) would shift the plane by 1e-16 / |b - a| radians --
+     * 4e-10 of a 3-km cell (tests/test_weight_goldens.py) */
+    v3 nrm = v3cross(quad[e], side);
     n = clip_halfspace(n, cur, nrm, nxt);
     v3 *t = cur; cur = nxt; nxt = t;
   }
