@@ -12,6 +12,9 @@ DIFFERENT route at 50 digits (mpmath):
   from Sutherland-Hodgman clipping carried out at 50 digits, and areas from GIRARD's theorem (sum of the interior angles
   minus (n - 2) pi) instead of the code's triangle fan with the Van Oosterom-Strackee formula.
 
+* grid -> grid bilinear on the quad of four CENTER points (A4, the U / V destaggering): the bilinear map
+  X(s, t) = lam P solved by mpmath.findroot at 40 digits (the code under test runs its own Newton iteration in float64).
+
 Cases span the scales of the BASELINE configurations (3-km to 500-km cells) because the difference forms exist for the small
 ones.  Output: inputs as float64 (exactly what the tests feed the oracle) and expected weights as float64 roundings of the
 50-digit results.
@@ -174,12 +177,40 @@ def main():
                     aq = girard_area(quad)
                     rows.append(float(ai / aq) if ai > 0 else 0.0)
             cons.append(dict(scale_km=scale_km, ratio=ratio, src=src, corners=corners, w=rows, src_area=float(girard_area(S))))
-    out = dict(note="generated by tests/golden/make_weight_goldens.py (mpmath, 50 digits); see its docstring", bilinear=bil, conserve=cons)
+    # ---- grid -> grid bilinear on a quad of four CENTER points (A4): X(s, t) = A + s (B - A) + t (D - A) + s t (A - B + C - D) = lam P
+    quads = []
+    for scale_km in (3.0, 12.0, 60.0, 300.0):
+        for _ in range(10):
+            lon0, lat0 = rng.uniform(-180, 180), rng.uniform(-80, 80)
+            d = scale_km / 111.0
+            coslat = max(0.15, float(mp.cos(mp.mpf(lat0) * mp.pi / 180)))
+            rot = rng.uniform(-0.5, 0.5)
+            cr, sr = float(mp.cos(rot)), float(mp.sin(rot))
+            cen = []
+            for (x, y) in ((0, 0), (1, 0), (0, 1), (1, 1)):      # flat index j * 2 + i of a 2 x 2 CENTER grid
+                xx, yy = (x + rng.uniform(-0.05, 0.05)) * d, (y + rng.uniform(-0.05, 0.05)) * d
+                cen.append(as_f64(unit(from_lonlat(lon0 + (cr * xx - sr * yy) / coslat, lat0 + (sr * xx + cr * yy)))))
+            A, B, D, Cq = (lift(v) for v in cen)
+            pts, ws = [], []
+            for _k in range(6):                                    # EDGE1 stagger of a 2 x 2 grid has 3 x 2 points
+                s0, t0 = rng.uniform(0.05, 0.95), rng.uniform(0.05, 0.95)
+                X = [A[i] + s0 * (B[i] - A[i]) + t0 * (D[i] - A[i]) + s0 * t0 * (A[i] - B[i] + Cq[i] - D[i]) for i in range(3)]
+                P = as_f64(unit(X))
+                Pm = lift(P)
+                f = lambda s_, t_, l_: [A[i] + s_ * (B[i] - A[i]) + t_ * (D[i] - A[i]) + s_ * t_ * (A[i] - B[i] + Cq[i] - D[i]) - l_ * Pm[i]
+                                        for i in range(3)]
+                sol = mp.findroot(f, (mp.mpf(s0), mp.mpf(t0), mp.mpf(1)), tol=mp.mpf(10) ** -40, maxsteps=50)
+                s1, t1 = sol[0], sol[1]
+                pts.append(P)
+                ws.append(as_f64([(1 - s1) * (1 - t1), s1 * (1 - t1), (1 - s1) * t1, s1 * t1]))   # weights of flat centres 0..3
+            quads.append(dict(scale_km=scale_km, centres=cen, pts=pts, w=ws))
+    out = dict(note="generated by tests/golden/make_weight_goldens.py (mpmath, 50 digits); see its docstring", bilinear=bil, conserve=cons,
+               quad=quads)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights_hp.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
         f.write("\n")
-    print("wrote %s: %d triangles, %d polygon / 4x4-grid cases" % (path, len(bil), len(cons)))
+    print("wrote %s: %d triangles, %d polygon / 4x4-grid cases, %d quads x 6 points" % (path, len(bil), len(cons), len(quads)))
 
 
 if __name__ == "__main__":

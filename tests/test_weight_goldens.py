@@ -51,3 +51,17 @@ def test_conservative_overlap_weights(oracle):
     for (scale_km, ratio), e in worst.items():
         h = scale_km * ratio / 6370.0
         assert e < 64 * 2.2e-16 / h, (scale_km, ratio, e, worst)
+
+
+def test_quad_bilinear_weights(oracle):
+    """Grid -> grid bilinear (CENTER -> EDGE, the destaggering of U and V): four weights per point on a 2 x 2 CENTER grid."""
+    worst = {}
+    for c in GOLD["quad"]:
+        idx, w = oracle.grid_bilinear(2, 2, np.array(c["centres"]), 1, np.array(c["pts"]))
+        for p in (1, 4):      # the U points between the two CENTER columns: the ones whose candidate quads include the only quad
+            assert sorted(idx[p].tolist()) == [0, 1, 2, 3], (c["scale_km"], idx[p])
+            got = np.empty(4)
+            got[idx[p]] = w[p]
+            err = np.abs(got - np.array(c["w"][p])).max()
+            worst[c["scale_km"]] = max(worst.get(c["scale_km"], 0.0), err)
+    assert max(worst.values()) < 1e-12, worst
