@@ -9,6 +9,8 @@ import argparse
 import os
 import subprocess
 import sys
+import tempfile
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -18,19 +20,36 @@ def launch(namelist, ranks, gpus=1, exe=None, cwd=None, env=None, timeout=1800):
     exe = exe or os.path.join(ROOT, "mpassit_amd", "fortran", "mpassit")
     base = dict(os.environ if env is None else env)
     base.update(MPASSIT_NRANKS=str(ranks), MPASSIT_RUN_ID=str(os.getpid()))
-    procs = []
+    procs, logs = [], []
     for r in range(ranks):
         e = dict(base, MPASSIT_RANK=str(r), MPASSIT_DEVICE=str(r % max(1, gpus)))
-        procs.append(subprocess.Popen([exe, namelist], cwd=cwd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    out = []
-    for p in procs:
-        try:
-            so, se = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
+        fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")      # files, not pipes: nothing to fill up while we poll
+        logs.append((fo, fe))
+        procs.append(subprocess.Popen([exe, namelist], cwd=cwd, env=e, stdout=fo, stderr=fe, text=True))
+    # wait for all images; the first one that fails takes the others down (they would wait for its marker files otherwise)
+    t0 = time.monotonic()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+        if failed or time.monotonic() - t0 > timeout:
             for q in procs:
-                q.kill()
-            raise
-        out.append((p.returncode, so, se))
+                if q.poll() is None:
+                    q.kill()
+            for q in procs:
+                q.wait()
+            if not failed:
+                raise subprocess.TimeoutExpired([exe, namelist], timeout)
+            break
+        time.sleep(0.05)
+    out = []
+    for p, (fo, fe) in zip(procs, logs):
+        p.wait()
+        fo.seek(0)
+        fe.seek(0)
+        out.append((p.returncode, fo.read(), fe.read()))
+        fo.close()
+        fe.close()
     return out
 
 
