@@ -362,3 +362,19 @@ def test_two_driver_images_on_a_global_grid(tmp_path, gpu_lib):
     assert r.returncode == 0, r.stdout + r.stderr
     _run_images(d, "namelist.two", 2)
     assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out2.nc"), "rb").read()
+
+
+def test_a_failing_image_takes_the_others_down(tmp_path, gpu_lib):
+    """Multi-image run whose input file does not exist: every image stops (the one that fails first is not waited for by the
+    others until their marker time-out), the launcher returns the codes within seconds and nothing is left behind."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mpassit_ranks
+    d = str(tmp_path)
+    open(os.path.join(d, "namelist.bad"), "w").write(NAMELIST.format(d=d).replace(".raw", ".nc"))   # no input files were written
+    t0 = time.monotonic()
+    res = mpassit_ranks.launch("namelist.bad", 3, gpus=1, exe=_driver(), cwd=d, timeout=120)
+    assert time.monotonic() - t0 < 60
+    assert all(code != 0 for code, _, _ in res)
+    assert not [f for f in os.listdir(d) if ".ready" in f or ".done." in f or f.endswith("out.nc")]
