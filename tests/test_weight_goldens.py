@@ -65,3 +65,82 @@ def test_quad_bilinear_weights(oracle):
             err = np.abs(got - np.array(c["w"][p])).max()
             worst[c["scale_km"]] = max(worst.get(c["scale_km"], 0.0), err)
     assert max(worst.values()) < 1e-12, worst
+
+
+# ---- the same known answers through the C-ABI (GPU) ------------------------------------------------------------------------
+# The kernels take latitude / longitude (radians for the mesh, degrees for the grid), not unit vectors: the goldens' float64
+# unit vectors go through asin / atan2 here and through the device's sin / cos there, two or three roundings of 1e-16 rad each,
+# i.e. up to ~1e-12 of a 3-km cell -- the tolerance below is 5e-12.
+def _latlon_rad(xyz):
+    xyz = np.asarray(xyz, np.float64)
+    return np.arcsin(np.clip(xyz[:, 2], -1, 1)), np.arctan2(xyz[:, 1], xyz[:, 0])
+
+
+@pytest.mark.gpu
+def test_bilinear_goldens_through_the_c_abi(gpu_lib):
+    from mpassit_amd import regrid as R
+    cases = GOLD["bilinear"]
+    n = len(cases)
+    cells = np.array([v for c in cases for v in c["tri"]])                 # cells 3v .. 3v+2 share vertex v
+    latc, lonc = _latlon_rad(cells)
+    cen = np.array([np.mean(c["tri"], axis=0) for c in cases])
+    latv, lonv = _latlon_rad(cen / np.linalg.norm(cen, axis=1)[:, None])
+    voc = np.zeros((3 * n, 3), np.int32)
+    voc[:, 0] = np.repeat(np.arange(1, n + 1), 3)
+    mesh = R.Mesh(latc, np.where(lonc < 0, lonc + 2 * np.pi, lonc), latv, np.where(lonv < 0, lonv + 2 * np.pi, lonv), voc)
+    latp, lonp = _latlon_rad(np.array([c["p"] for c in cases]))
+    lat, lon = np.degrees(latp)[None, :], np.degrees(lonp)[None, :]          # a 1 x n "grid" of the target points
+    pad = lambda a, ny, nx: np.resize(a, (ny, nx))                           # the staggered companions are not used by this Store
+    grid = R.Grid(lon, lat, pad(lon, 2, n + 1), pad(lat, 2, n + 1), pad(lon, 1, n + 1), pad(lat, 1, n + 1), pad(lon, 2, n), pad(lat, 2, n))
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    idx, w = rh.weights()
+    checked, worst = 0, 0.0
+    for v, c in enumerate(cases):
+        if sorted(idx[v].tolist()) != [3 * v, 3 * v + 1, 3 * v + 2]:
+            continue                 # the point also lies in another, lower-numbered random triangle: that one wins, by design
+        got = np.empty(3)
+        got[idx[v] - 3 * v] = w[v]
+        worst = max(worst, np.abs(got - np.array(c["w"])).max())
+        checked += 1
+    print("bilinear through the C-ABI: %d triangles checked, worst |dw| %.2e" % (checked, worst))
+    assert checked >= n - 4 and worst < 5e-12, (checked, worst)
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+@pytest.mark.gpu
+def test_conservative_goldens_through_the_c_abi(gpu_lib):
+    from mpassit_amd import regrid as R
+    worst = {}
+    for c in GOLD["conserve"]:
+        src = np.array(c["src"])
+        nv = src.shape[0]
+        latv, lonv = _latlon_rad(src)
+        cen = src.mean(axis=0)
+        latc, lonc = _latlon_rad((cen / np.linalg.norm(cen))[None, :])
+        voc = np.zeros((1, 8), np.int32)
+        voc[0, :nv] = np.arange(1, nv + 1)
+        wrap = lambda a: np.where(a < 0, a + 2 * np.pi, a)
+        mesh = R.Mesh(latc, wrap(lonc), latv, wrap(lonv), voc)
+        latq, lonq = _latlon_rad(np.array(c["corners"]))
+        lat_c, lon_c = np.degrees(latq).reshape(5, 5), np.degrees(lonq).reshape(5, 5)
+        mid = lambda a: 0.25 * (a[:-1, :-1] + a[1:, :-1] + a[:-1, 1:] + a[1:, 1:])     # centres / edges: not used by this Store
+        grid = R.Grid(mid(lon_c), mid(lat_c), lon_c, lat_c, lon_c[:-1, :], lat_c[:-1, :], lon_c[:, :-1], lat_c[:, :-1])
+        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+        rp, col, val = rh.csr()
+        got = np.zeros(16)
+        for p in range(16):
+            if rp[p + 1] > rp[p]:
+                got[p] = val[rp[p]]
+        want = np.array(c["w"])
+        big = want > 1e-9
+        key = (c["scale_km"], c["ratio"])
+        worst[key] = max(worst.get(key, 0.0), np.abs(got - want)[big].max())
+        rh.release()
+        mesh.destroy()
+        grid.destroy()
+    print("conservative through the C-ABI, worst |dw| per (cell km, dst / src size):", {k: float("%.2e" % v) for k, v in worst.items()})
+    for (scale_km, ratio), e in worst.items():
+        h = scale_km * ratio / 6370.0
+        assert e < 256 * 2.2e-16 / h, (scale_km, ratio, e, worst)      # 1.2e-10 at 3 km (input roundings included); measured below 1e-11
