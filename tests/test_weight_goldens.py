@@ -144,3 +144,28 @@ def test_conservative_goldens_through_the_c_abi(gpu_lib):
     for (scale_km, ratio), e in worst.items():
         h = scale_km * ratio / 6370.0
         assert e < 256 * 2.2e-16 / h, (scale_km, ratio, e, worst)      # 1.2e-10 at 3 km (input roundings included); measured below 1e-11
+
+
+@pytest.mark.gpu
+def test_quad_goldens_through_the_c_abi(gpu_lib):
+    """CENTER -> EDGE1 destaggering weights of a 2 x 2 CENTER grid whose middle U points are the goldens' points."""
+    from mpassit_amd import regrid as R
+    worst = 0.0
+    for c in GOLD["quad"]:
+        latc, lonc = _latlon_rad(np.array(c["centres"]))
+        lat, lon = np.degrees(latc).reshape(2, 2), np.degrees(lonc).reshape(2, 2)
+        latu, lonu = _latlon_rad(np.array(c["pts"]))
+        lat_u, lon_u = np.degrees(latu).reshape(2, 3), np.degrees(lonu).reshape(2, 3)
+        pad = lambda a, ny, nx: np.resize(a, (ny, nx))
+        grid = R.Grid(lon, lat, pad(lon, 3, 3), pad(lat, 3, 3), lon_u, lat_u, pad(lon, 3, 2), pad(lat, 3, 2))
+        rs = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1)
+        idx, w = rs.weights()
+        for p in (1, 4):
+            assert sorted(idx[p].tolist()) == [0, 1, 2, 3], (c["scale_km"], idx[p])
+            got = np.empty(4)
+            got[idx[p]] = w[p]
+            worst = max(worst, np.abs(got - np.array(c["w"][p])).max())
+        rs.release()
+        grid.destroy()
+    print("quad bilinear through the C-ABI: worst |dw| %.2e" % worst)
+    assert worst < 5e-12
