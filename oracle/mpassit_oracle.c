@@ -19,6 +19,10 @@
  * What IS pinned: the target-grid projection (orc_lc_*, orc_xytoll) reproduces the
  * compiled-reference golden values recorded in SURVEY.md Appendix E
  * (tests/golden/projection_lc.json), and every routine has analytic known-answer tests.
+ * Pinned to the MATHEMATICS (not to ESMF, not to the reference's binary) by independent high-precision goldens with
+ * committed generators: the four projections at 4 680 points (tests/golden/make_projection_goldens.py, mpmath 40 digits)
+ * and the bilinear / conservative / quad-bilinear weight formulas at 50 digits along a different route
+ * (tests/golden/make_weight_goldens.py).
  *
  * Search structures here (3-D box hash) deliberately differ from the GPU ones
  * (target pyramid rasteriser / Morton BVH) so that agreement is a real cross-check.
