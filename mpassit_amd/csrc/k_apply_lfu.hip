@@ -373,10 +373,10 @@ int mpg_cfu_num_variants() { return (int)(sizeof(g_cfu_variants) / sizeof(g_cfu_
 // unique cells per tile a variant keeps in registers (NPF / LC * 256); beyond it a slow synchronous path takes over
 static const int g_cfu_npf[] = {8, 12, 16, 4, 8, 16, 8, 8, 4, 32, 16, 8, 20, 16, 12, 16, 16, 12, 8};
 static int cfu_capacity(int variant) { return g_cfu_npf[variant] / g_cfu_variants[variant].lc * g_cfu_variants[variant].nt; }
-static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap = 1024);
+static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap = 1024, int dmax = 8);
 static int cfu_build(mpg_handle_s *h, int variant, hipStream_t s) {
   const LfuVariant &v = g_cfu_variants[variant];
-  return lfu_build_shape(h, v.txu, v.nt * v.rpt / v.txu, s, cfu_capacity(variant) > 1024 ? cfu_capacity(variant) : 1024);
+  return lfu_build_shape(h, v.txu, v.nt * v.rpt / v.txu, s, cfu_capacity(variant) > 1024 ? cfu_capacity(variant) : 1024, 16);
 }
 static const LfuVariant g_lfu_variants[] = {
     // 0-5: two-phase, 64-wide tiles
@@ -396,8 +396,8 @@ static int lfu_build(mpg_handle_s *h, int txu, int rpt, hipStream_t s) { return 
 
 
 // tile lists for tiles of txu x tyu target points (cached in the handle, keyed by the shape)
-static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap) {
-  const int key = txu * 1024 + tyu;
+static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap, int dmax) {
+  const int key = (txu * 1024 + tyu) | (dmax > 8 ? 1 << 24 : 0);   // the same shape under the two alignment rules: two sets of lists
   if (h->ut_rpt == key) return MPG_SUCCESS;
   if (h->ut2_rpt == key) {  // the other layout's shape: swap the parked lists in, no device work
     std::swap(h->ut_ptr, h->ut2_ptr);
@@ -438,7 +438,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
   // Row-shifted tiles (aligned store segments, mpg_internal.h) first; when their longest list does not fit the staged
   // kernels' 1024 cells per tile (grids whose rows start at many different offsets in a line: the shifted rows of a tile
   // then spread over up to 31 more columns) the lists are built for unshifted tiles instead.
-  h->ut_align = mpg_tile_align(h->nx_dst);
+  h->ut_align = mpg_tile_align(h->nx_dst, dmax);
   if (h->nx_dst % h->ut_align == 0) h->ut_align = 1;   // every row starts aligned already: nothing to shift
   const int nty = (h->ny_dst + tyu - 1) / tyu;
   int ntx = 0;
@@ -859,7 +859,7 @@ int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nl
     if (variant == CFU_TALL) return launch_cfu_t_types<2, 512>(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
     return launch_cfu_t_types<4, LFU_THREADS>(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
   }
-  if ((rc = lfu_build(h, 64, 2, s))) return rc;
+  if ((rc = cfu_build(h, CFU_BASE, s))) return rc;
   if (h->ut_max > 1024) return MPG_ERR_UNSUPPORTED;
   return launch_cfu_t_types<2, LFU_THREADS>(h, src, src_f32, nlev, nfields, dst, dst_f32, scale, offset, s);
 }

@@ -576,8 +576,8 @@ int mpg_handle_tile_stats(mpg_handle h, int *tile_nx, int *tile_ny, double *reus
     mpg_set_error("mpg_handle_tile_stats: the handle has no tile lists (no staged Regrid has run on it yet)");
     return MPG_ERR_INVALID_ARG;
   }
-  if (tile_nx) *tile_nx = h->ut_rpt / 1024;
-  if (tile_ny) *tile_ny = h->ut_rpt % 1024;
+  if (tile_nx) *tile_nx = (h->ut_rpt & 0xFFFFFF) / 1024;   // bit 24: alignment rule of the lists (k_apply_lfu.hip)
+  if (tile_ny) *tile_ny = (h->ut_rpt & 0xFFFFFF) % 1024;
   if (reuse) *reuse = 3.0 * (double)h->n_dst / (double)h->ut_total;
   if (line_fill) *line_fill = h->ut_lines > 0 ? (double)h->ut_total / (16.0 * (double)h->ut_lines) : 0.0;
   return MPG_SUCCESS;

@@ -19,14 +19,16 @@
 // d = (nx mod A, folded to +-A/2) points apart, so the tile references about |d| / 64 more cells (C5, nx = 3600, A = 32:
 // d = 16, the staged level-fast kernel lost 15 %).  mpg_tile_align picks the largest A in {32, 16, 8} whose d stays
 // within 8 points: nx = 1800 -> 32 (d = 8), 3600 -> 16 (d = 0: no shift at all), 1801 -> 16 (d = 7), 150 -> 16 (d = 6).
+// The tile lists of the CELL-fast staged kernels allow d <= 16 (C5 again: float32 cell-fast is 8 % faster on 128-byte
+// aligned segments, float64 equal, while the level-fast staged kernels lose 5-14 % to the wider footprint).
 #ifndef MPG_TILE_ALIGN
 #define MPG_TILE_ALIGN 32   // the largest alignment tried (elements); -DMPG_TILE_ALIGN=1 builds without the shift (A/B runs)
 #endif
-static inline __host__ __device__ int mpg_tile_align(int nx) {
+static inline __host__ __device__ int mpg_tile_align(int nx, int dmax = 8) {
   for (int a = MPG_TILE_ALIGN; a >= 8; a >>= 1) {
     int d = nx % a;
     d = d < a - d ? d : a - d;
-    if (d <= 8) return a;
+    if (d <= dmax) return a;
   }
   return MPG_TILE_ALIGN >= 8 ? 8 : 1;
 }
