@@ -155,7 +155,8 @@ def main():
                 lat, lon, m = FUN[s["kind"]](s, mp.mpf(i) - ox, mp.mpf(j) - oy)
                 pts.append([st, i, j, float(lat), None if lon is None else float(lon), None if m is None else float(m)])
         out["setups"].append(dict(params={k: v for k, v in s.items()}, points=pts))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "projection_wide.json")
+    import sys
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "projection_wide.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
         f.write("\n")

@@ -206,7 +206,8 @@ def main():
             quads.append(dict(scale_km=scale_km, centres=cen, pts=pts, w=ws))
     out = dict(note="generated by tests/golden/make_weight_goldens.py (mpmath, 50 digits); see its docstring", bilinear=bil, conserve=cons,
                quad=quads)
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights_hp.json")
+    import sys
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights_hp.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
         f.write("\n")

@@ -169,3 +169,15 @@ def test_quad_goldens_through_the_c_abi(gpu_lib):
         grid.destroy()
     print("quad bilinear through the C-ABI: worst |dw| %.2e" % worst)
     assert worst < 5e-12
+
+
+@pytest.mark.parametrize("script,fixture", [("make_projection_goldens.py", "projection_wide.json"), ("make_weight_goldens.py", "weights_hp.json")])
+def test_golden_generators_reproduce_the_committed_fixtures(tmp_path, script, fixture):
+    """The fixtures are what their committed generators write, byte for byte (mpmath, fixed seeds)."""
+    import subprocess
+    import sys
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    out = str(tmp_path / fixture)
+    r = subprocess.run([sys.executable, os.path.join(gold, script), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == open(os.path.join(gold, fixture), "rb").read()
