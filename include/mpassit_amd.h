@@ -139,16 +139,21 @@ int mpg_regrid_dev(mpg_handle rh, const double *src_dev, int src_layout, int nle
  * and the destination float32 (every output variable is NF90_FLOAT, write_data.F90:779).  The arithmetic stays
  * float64 and  dst = (dst type)( regrid(src) * scale + offset )  reproduces the writer's post-ops (T - 300,
  * write_data.F90:1343; PHB * 9.81, :1418), so float32 results are bit-identical to the reference's file contents.
- * src_f32 / dst_f32: 0 = float64, 1 = float32.  Device pointers, stream as in mpg_regrid_dev. */
-int mpg_regrid_typed_dev(mpg_handle rh, const void *src_dev, int src_f32, int src_layout, int nlev, int nfields,
-                         void *dst_dev, int dst_f32, double scale, double offset, void *hip_stream);
+ * src_type / dst_type: MPG_TYPE_F64 or MPG_TYPE_F32, optionally | MPG_TYPE_BE: the values are big-endian in memory, as a
+ * NetCDF classic (CDF-1/2/5) variable stores them -- the bytes of nf90_get_var's source (input_data.F90:630) and of
+ * nf90_put_var's destination (write_data.F90:1339-1475) travel file <-> HBM untouched (mpg_file_to_dev / mpg_dev_to_file)
+ * and the Regrid reads / writes them as they are: no byte-swap pass over the data exists.
+ * Device pointers, stream as in mpg_regrid_dev. */
+enum { MPG_TYPE_F64 = 0, MPG_TYPE_F32 = 1, MPG_TYPE_BE = 2 };
+int mpg_regrid_typed_dev(mpg_handle rh, const void *src_dev, int src_type, int src_layout, int nlev, int nfields,
+                         void *dst_dev, int dst_type, double scale, double offset, void *hip_stream);
 /* The same on HOST buffers (pageable memory: Fortran allocatables, numpy arrays), for hosts that keep the reference's
  * file -> host array -> regrid -> host array -> file shape and are therefore bound by the PCIe link: float32 sources
  * and results cross the link as they are stored in the files (half the bytes of the float64 route), and the field is cut
  * into chunks whose upload, kernel and download overlap (full duplex, a helper thread downloads while the caller
  * uploads).  Blocks until dst_host is complete. */
-int mpg_regrid_typed(mpg_handle rh, const void *src_host, int src_f32, int src_layout, int nlev, int nfields,
-                     void *dst_host, int dst_f32, double scale, double offset);
+int mpg_regrid_typed(mpg_handle rh, const void *src_host, int src_type, int src_layout, int nlev, int nfields,
+                     void *dst_host, int dst_type, double scale, double offset);
 /* ESMF_FieldBundleRegridRelease (interp.F90:450,455,461) */
 int mpg_handle_release(mpg_handle rh);
 
@@ -162,7 +167,8 @@ int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const d
 /* ---- output epilogues: what write_data.F90 computes on rank 0 between ESMF_FieldGather and nf90_put_var, done on
  * the device-resident regridded fields so that only final float32 arrays leave the GPU.
  * Every output variable is NF90_FLOAT (write_data.F90:312-980) while the fields are float64: the cast below is the
- * conversion nf90_put_var applies (round to nearest).  Device pointers; hip_stream as in mpg_regrid_dev.
+ * conversion nf90_put_var applies (round to nearest).  Device pointers; hip_stream as in mpg_regrid_dev.  dst_be != 0
+ * stores the float32 results big-endian (the variable's bytes in a NetCDF classic file), as MPG_TYPE_BE does for Regrid.
  *   mpg_post_cast_dev        dst = (float)(src*scale + offset): plain fields (scale 1, offset 0), T - 300 (:1339-1347,
  *                            the `continue` in that loop is a no-op statement, so every point is shifted), PHB*9.81 (:1418)
  *   mpg_post_layer_mean_dev  Z_C(k) = 0.5*(PHB(k+1) + PHB(k)), src [nlevp1][n_pts] -> dst [nlevp1-1][n_pts] (:1406-1415)
@@ -177,8 +183,8 @@ int mpg_dev_free(void *dev);
 int mpg_dev_upload(void *dst_dev, const void *src_host, int64_t nbytes);
 int mpg_dev_download(void *dst_host, const void *src_dev, int64_t nbytes);
 
-/* In-place byte swap of n elements of elem_size 2, 4 or 8 bytes on the device: NetCDF classic data is big-endian, so a
- * variable can be moved file <-> GPU as raw bytes (ncio_var_extent) and turned around at HBM speed. */
+/* In-place byte swap of n elements of elem_size 2, 4 or 8 bytes on the device, for big-endian file data that does NOT
+ * pass through mpg_regrid_typed_dev / mpg_post_*_dev (those take and produce it directly, MPG_TYPE_BE). */
 int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream);
 /* The transport of such a variable: bytes [offset, offset + nbytes) of a file -> device memory and back, untouched,
  * through pinned staging buffers and a few pread / pwrite threads (the page-cache side of the copy is what limits a
@@ -189,8 +195,8 @@ int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream);
  * concurrently from two host threads. */
 int mpg_file_to_dev(const char *path, int64_t offset, int64_t nbytes, void *dst_dev, void *hip_stream);
 int mpg_dev_to_file(const char *path, int64_t offset, int64_t nbytes, const void *src_dev, void *hip_stream);
-int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream);
-int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream);
+int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, int dst_be, void *hip_stream);
+int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, int dst_be, void *hip_stream);
 int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream);
 /* The two reductions P_TOP is made of, for a host that holds only a block of the grid rows (one driver image per GPU):
  * vmax = maxval(P_HYD) of the block, candmin = min of 0.8*P_HYD(top) over its columns with P_HYD(top) >= 10 (has_cand = 0
@@ -216,8 +222,9 @@ int mpg_handle_get_weights(mpg_handle rh, int32_t *idx_host, double *w_host);
 /* CSR handles: rowptr [n_dst+1], col/val [nnz] (host) */
 int mpg_handle_get_csr(mpg_handle rh, int64_t *rowptr_host, int32_t *col_host, double *val_host);
 /* Which Regrid kernel serves a 3-point (bilinear) handle, decided when its tile lists are built on the first Regrid:
- * cell_fast_kernel / lev_fast_kernel: 0 = not decided yet (layout not used so far), -1 = lane- / row-gather kernel,
- * > 0 = LDS-staged variant index + 1;  max_unique = largest number of distinct source cells one tile references. */
+ * cell_fast_kernel / lev_fast_kernel: 0 = not decided yet (no bundle of >= 8 levels in that layout so far), -1 = lane- /
+ * row-gather kernel, > 0 = LDS-staged ("a3_staged" value + 1 / 1);  max_unique = largest number of distinct source cells one
+ * tile of the lists in use references (0 without lists). */
 int mpg_handle_kernel_choice(mpg_handle rh, int *cell_fast_kernel, int *lev_fast_kernel, int *max_unique);
 /* Locality of the source cells as the staged Regrid kernels see them, from the tile lists in use (error before the first
  * staged Regrid of the handle): the tile shape in target points; reuse = 3 * n_dst / (sum over the tiles of their
@@ -255,16 +262,13 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
 
 /* kernel-selection knobs for benchmarking and the A/B tests (defaults are the tuned production values; DESIGN.md s4.1 has
  * the measurements behind every default).  They select among kernels that produce identical bits:
- *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0..18 a staged variant
- *                 (13: 64x8-point tiles, 10: 64x16 on 256 threads, 16: 64x16 on 512 threads, 14/15: 64x32 on 512 threads)
- *   "lf_variant"  level-fast 3-point Regrid: -1 per-handle choice (default), 0..9 row-gather variants on 64x1 row tiles,
- *                 100..119 level-chunked staged variants, 200 / 300..302 rows-resident, 401..403 / 410..418 the float32
- *                 row-gather experiments of the typed entry, 500 the row gather on linear aligned tiles
- *   "a3_variant", "lev_chunk", "fields_per_wg", "tile_group"   shape of the lane-gather kernel
- *   "cfu_fields_per_wg", "lf_fields_per_wg"   fields of a bundle served by one workgroup (default 1)
- *   "tile_band"   tile rows per band of the staged cell-fast kernel's tile order (0 = row-major, default)
+ *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0 / 1 / 2 the LDS-staged
+ *                 kernel on 64x8-point tiles / 64x16 on 256 threads / 64x16 on 512 threads
+ *   "lf_variant"  level-fast (file-order) 3-point Regrid: -1 per-handle choice (default), 0 row gather on linear aligned
+ *                 tiles, 1 LDS-staged in 16-level chunks, 2 row gather on grid-row tiles (the capacity fallback),
+ *                 3 LDS-staged with whole rows resident
  *   "nn_variant"  nearest-neighbour search: 1 wave-cooperative (default), 0 one thread per point
- *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice
+ *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice (default 35)
  * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */
 int mpg_tune(const char *key, int value);
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "_build")
 SO = os.path.join(HERE, "libmpassit_amd.so")
 SOURCES = ["mpg_api.hip", "mpg_hostpipe.hip", "mpg_fileio.hip", "k_setup.hip", "k_target_grid.hip", "k_store_bilinear.hip", "k_store_nearest.hip", "k_store_conserve.hip",
-           "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_lfs.hip", "k_apply_typed.hip", "k_pole.hip", "k_post.hip", "k_halo.hip"]
+           "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_pole.hip", "k_post.hip", "k_halo.hip"]
 HEADERS = ["mpg_internal.h", "geom.h", os.path.join("..", "..", "include", "mpassit_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",

@@ -79,15 +79,33 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// Order of the tiles of ONE field inside the linear work space: row-major tiles would put the tile below (tx, ty) a whole
-// tile row (ntx workgroups) later, by when the source cells the two share along their common edge have left the 4 MiB L2
-// (C4: 29 tiles x 160 KB in between).  Bands of `band` tile rows walked column by column make vertical neighbours
-// consecutive and horizontal neighbours `band` apart; only the band's outer edges are fetched twice.  Bijective on
-// [0, ntx * nty); band <= 1 is the row-major order.
-__device__ __forceinline__ unsigned band_order(unsigned tl, unsigned ntx, unsigned nty, unsigned band) {
-  if (band <= 1) return tl;
-  const unsigned per = band * ntx, b = tl / per, r = tl - b * per;
-  const unsigned y0 = b * band, bh = min(band, nty - y0);
-  const unsigned tx = r / bh, ty = y0 + (r - tx * bh);
-  return ty * ntx + tx;
+// ---- element access of the fused ingest / egress kernels ------------------------------------------------------------
+// A NetCDF classic variable is big-endian (the files MPASSIT reads, input_data.F90:630, and writes, write_data.F90:779,
+// when they are CDF-1/2/5): the typed Regrid and the post-op kernels take and produce such values as they are stored, so
+// that no separate byte-swap pass touches the data (round 2: k_bswap was the largest item of a cold configuration-4 job,
+// one extra read + write of every ingested and emitted byte).  The swap is one v_perm_b32 per 32-bit word with a
+// wave-uniform selector: identity or byte reversal, so one kernel serves any mix of byte orders on its two sides.
+struct Swz {
+  uint32_t s32;            // 32-bit element: selector over {0, word}
+  uint32_t lo64, hi64;     // 64-bit element: selectors over {hi, lo} for the new low / high word
+};
+__device__ __forceinline__ Swz make_swz(int big_endian) {
+  Swz z;
+  z.s32 = big_endian ? 0x00010203u : 0x03020100u;
+  z.lo64 = big_endian ? 0x04050607u : 0x03020100u;
+  z.hi64 = big_endian ? 0x00010203u : 0x07060504u;
+  return z;
+}
+template <bool SWZ>
+__device__ __forceinline__ float swz(float v, const Swz &z) {
+  if constexpr (!SWZ) return v;
+  return __uint_as_float(__builtin_amdgcn_perm(0u, __float_as_uint(v), z.s32));
+}
+template <bool SWZ>
+__device__ __forceinline__ double swz(double v, const Swz &z) {
+  if constexpr (!SWZ) return v;
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+  const uint32_t nlo = __builtin_amdgcn_perm(hi, lo, z.lo64), nhi = __builtin_amdgcn_perm(hi, lo, z.hi64);
+  return __longlong_as_double((long long)(((unsigned long long)nhi << 32) | nlo));
 }

@@ -7,11 +7,13 @@
 //
 //   K2  k_apply3_cf    3-point gather, source cell-fastest [nlev][ncell] (reference memory order,
 //                       input_data.F90:653-655), destination [nlev][ny][nx]: the lane-gather form; the default
-//                       for cell-fast sources is the LDS-staged k_apply3_cfu_p of k_apply_lfu.hip (chosen per
-//                       handle in mpg_k_apply below), this one serves handles whose tiles share no cells
+//                       for cell-fast bundles is the LDS-staged k_apply3_cfu of k_apply_lfu.hip (chosen per
+//                       handle in mpg_k_apply below), this one serves short bundles (2-D fields) and handles
+//                       whose tiles share no cells
 //   K2' k_apply3_lf    same from level-fastest [ncell][nlev] (MPAS file order, input_data.F90:630,645):
-//                       the reference's host transpose is fused away through an LDS tile transpose; the
-//                       row-gather form, used when target points share few cells (else k_apply3_lfu_p)
+//                       the reference's host transpose is fused away through an LDS tile transpose; the older
+//                       row-gather form on grid-row tiles (default: k_apply3_lf_rows, k_apply_typed.hip, when
+//                       target points share few cells, else k_apply3_lfu / k_apply3_lfw)
 //   K3  k_apply1       nearest-neighbour copy
 //   K4  k_apply_csr    conservative (variable row length)
 //   K6  k_applyN<4>    4-point destagger (CENTER -> EDGE1/EDGE2)
@@ -27,43 +29,27 @@
 #include "geom.h"
 #include "mpg_internal.h"
 
-static int g_lev_chunk = 0;  // "lev_chunk" knob: 0 = all levels in one workgroup pass
-
 #define A3_TX 64
 
-// RPT = target rows per thread, WAVES = waves per workgroup (tile = 64 x WAVES*RPT target points), SYNC = keep the
-// workgroup's waves in level lock-step with a barrier so that lines shared between neighbouring rows are
-// still in L1/L2 when the next wave asks for them.  Each workgroup serves `fpw` fields of its tile back to back,
-// so indices and weights are read once per tile instead of once per field.  Destination stores are non-temporal.
-// WX = target points a wave spans in i (64: one row of 64; 16: a 16 x 4 patch, i.e. four 128-byte store segments per
-// instruction).  Compact patches keep the gather footprint of ONE load instruction inside few cache lines when the
-// source cells are numbered along a space-filling curve (production MPAS meshes, synth.icosahedral_mesh) instead of
-// row by row; the tile stays 64 wide.
-template <int RPT, int WAVES, bool SYNC, int WX = 64>
-__global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
-                                                          const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
-                                                          int64_t nsrc, int nlev, int lev_chunk, int ntx, int nty, int nchunk,
-                                                          int nfields, int fpw, int tgroup) {
-  constexpr int WH = 64 / WX;           // rows a wave spans per instruction
-  constexpr int CG = A3_TX / WX;        // waves side by side in a tile
-  static_assert(WAVES % CG == 0, "waves must fill whole tile rows");
-  constexpr int TY = (WAVES / CG) * WH * RPT;
+// The lane-gather form: a 256-thread workgroup = 64 (i) x 8 (j) target points, two rows per thread; the waves are kept
+// in level lock-step by one barrier per level so that lines shared between neighbouring rows are still in L1/L2 when the
+// next wave asks for them.  Indices and weights are read once per tile and kept in registers for all levels; destination
+// stores are non-temporal.  (Shapes measured in round 1 and dropped from the library in round 3 -- more rows per thread,
+// 8 / 16 waves, level chunks, several fields per workgroup, banded tile order, 16 x 4 / 32 x 2 wave patches: all equal or
+// slower, profiles/r01_sweep_apply*.txt.)
+__global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                   const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                   int64_t nsrc, int nlev, int ntx, int nty) {
+  constexpr int RPT = 2, TY = 4 * RPT;
   int64_t P = (int64_t)nx * ny;
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tile = lin % ntile;
-  unsigned rest = lin / ntile;  // = field group * nchunk + chunk
-  int chunk = rest % nchunk;
-  int f0 = (rest / nchunk) * fpw, f1 = min(nfields, f0 + fpw);
-  // tiles are walked in bands of `tgroup` tile rows, column by column inside a band: workgroups dispatched back to
-  // back are vertical neighbours (they share footprint rows), horizontal neighbours follow `tgroup` slots later
-  int band = tile / (ntx * tgroup), rem = tile % (ntx * tgroup);
-  int bh = min(tgroup, nty - band * tgroup);   // rows in this (possibly last, shorter) band
-  int tx = rem / bh, ty = band * tgroup + rem % bh;
+  int f = lin / ntile;
+  int tx = tile % ntx, ty = tile / ntx;
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int ib = tx * A3_TX + (wave % CG) * WX + (lane % WX);
-  int j0 = ty * TY + (wave / CG) * (WH * RPT) + lane / WX;   // thread rows: j0, j0 + WH, ...
-  int k0 = chunk * lev_chunk, k1 = min(nlev, k0 + lev_chunk);
+  int ib = tx * A3_TX + lane;
+  int j0 = ty * TY + wave * RPT;
 
   int32_t c[RPT][3];
   double ww[RPT][3];
@@ -71,7 +57,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
   int64_t po[RPT];
 #pragma unroll
   for (int r = 0; r < RPT; ++r) {
-    int j = j0 + r * WH;
+    int j = j0 + r;
     int i = ib - mpg_tile_shift(j, nx);       // row-shifted tile: aligned store segments (mpg_internal.h)
     act[r] = (i >= 0) && (i < nx) && (j < ny);
     int64_t p = act[r] ? (int64_t)j * nx + i : 0;
@@ -85,61 +71,37 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_cf(const int32_t *__restr
 #pragma unroll
     for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
   }
-  for (int f = f0; f < f1; ++f) {
-    const double *s = src + ((int64_t)f * nlev + k0) * nsrc;
-    double *d = dst + ((int64_t)f * nlev + k0) * P;
-    for (int k = k0; k < k1; ++k) {
-      if (SYNC) __syncthreads();
-      double v[RPT];
+  const double *s = src + (int64_t)f * nlev * nsrc;
+  double *d = dst + (int64_t)f * nlev * P;
+  for (int k = 0; k < nlev; ++k) {
+    __syncthreads();
+    double v[RPT];
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
-        v[r] = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
-      }
-#pragma unroll
-      for (int r = 0; r < RPT; ++r)
-        if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + po[r]);
-      s += nsrc;
-      d += P;
+    for (int r = 0; r < RPT; ++r) {
+      double a = s[c[r][0]], b = s[c[r][1]], e = s[c[r][2]];
+      v[r] = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
     }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + po[r]);
+    s += nsrc;
+    d += P;
   }
 }
+static int g_a3_staged = -1;  // "a3_staged" knob: -2 lane-gather only, -1 per-handle choice (default), 0..2 that LDS-staged variant
 
-typedef void (*apply3_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int, int, int, int);
-struct A3Variant { int rpt, waves, sync, wx; apply3_fn fn; };
-static const A3Variant g_a3_variants[] = {
-    {2, 4, 0, 64, k_apply3_cf<2, 4, false>},  {2, 4, 1, 64, k_apply3_cf<2, 4, true>},   {2, 8, 0, 64, k_apply3_cf<2, 8, false>},
-    {2, 8, 1, 64, k_apply3_cf<2, 8, true>},   {2, 16, 0, 64, k_apply3_cf<2, 16, false>}, {2, 16, 1, 64, k_apply3_cf<2, 16, true>},
-    {1, 8, 1, 64, k_apply3_cf<1, 8, true>},   {1, 16, 1, 64, k_apply3_cf<1, 16, true>},  {4, 4, 0, 64, k_apply3_cf<4, 4, false>},
-    {4, 8, 1, 64, k_apply3_cf<4, 8, true>},   {1, 4, 0, 64, k_apply3_cf<1, 4, false>},   {1, 16, 0, 64, k_apply3_cf<1, 16, false>},
-    {4, 4, 1, 64, k_apply3_cf<4, 4, true>},
-    // 13..: compact wave patches (16 x 4 and 32 x 2 points per instruction)
-    {2, 4, 1, 16, k_apply3_cf<2, 4, true, 16>},  {2, 4, 0, 16, k_apply3_cf<2, 4, false, 16>}, {2, 8, 1, 16, k_apply3_cf<2, 8, true, 16>},
-    {1, 8, 1, 16, k_apply3_cf<1, 8, true, 16>},  {4, 4, 1, 16, k_apply3_cf<4, 4, true, 16>},  {2, 4, 1, 32, k_apply3_cf<2, 4, true, 32>},
-    {2, 8, 1, 32, k_apply3_cf<2, 8, true, 32>},  {1, 8, 1, 32, k_apply3_cf<1, 8, true, 32>},
-};
-static inline int a3_tile_rows(const A3Variant &v) { return (v.waves / (64 / v.wx)) * (64 / v.wx) * v.rpt; }
-static int g_a3_variant = 1;  // "a3_variant" knob (tuned on MI355X: profiles/r01_sweep_apply*.txt)
-static int g_a3_staged = -1;  // "a3_staged" knob: -2 lane-gather only, -1 per-handle choice (default), >= 0 that LDS-staged variant
-static int g_fpw = 1;         // "fields_per_wg" knob (0 = all fields in one workgroup pass)
-static int g_tgroup = 1;      // "tile_group" knob: tile rows per band (1 = plain row-major tile order)
-
-// Level-fastest source ([ncell][nlev], MPAS file order): the reference transposes on the host
-// (input_data.F90:653-655); here the transpose is fused through LDS.  One workgroup = a TXL x (64/TXL) tile of 64
-// target points x all levels (2-D so that the points of a tile share source rows).
+// Level-fastest source ([ncell][nlev], MPAS file order) on tiles of 64 points of ONE grid row: the older row gather, kept as
+// the route for handles the default (k_apply3_lf_rows, k_apply_typed.hip: linear tiles, 32-bit row offsets) cannot take --
+// n_src * nlev >= 2^32 or a single level -- and as its cross-check ("lf_variant" 2).
 // phase 0: the tile's 64 x 3 indices/weights are staged in LDS (coalesced);
-// phase 1: wave w serves points 16w..16w+15, lanes = levels: the cell id is wave-uniform (readfirstlane -> scalar
-//          row base), so each gather is one coalesced nlev*8-byte row read; 4 points (12 loads) in flight;
-// phase 2: lanes = points: TXL*8-byte contiguous non-temporal stores per level.
+// phase 1: wave w serves points 8w..8w+7, lanes = levels: the cell id is wave-uniform (readfirstlane -> scalar row base),
+//          so each gather is one coalesced nlev*8-byte row read; 4 points (12 loads) in flight;
+// phase 2: lanes = points: 512-byte contiguous non-temporal stores per level.
 // LDS tile [nlev][65] doubles (row pad 1: conflict-free ds_write_b64 column writes).
-// WAVES = waves per workgroup (64/WAVES points per wave), BATCH = points whose 3 row loads are issued before the
-// wave waits (memory-level parallelism per wave = 3*BATCH loads of nlev*8 bytes).
-template <int TXL, int WAVES, int BATCH>
-__global__ __launch_bounds__(64 * WAVES) void k_apply3_lf(const int32_t *__restrict__ idx, const double *__restrict__ w,
-                                                          const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
-                                                          int64_t nsrc, int nlev, int ntx, int nty, int nfields, int fpw) {
-  constexpr int TYL = 64 / TXL, PPW = 64 / WAVES;
-  static_assert(PPW % BATCH == 0, "batch must divide the points per wave");
+__global__ __launch_bounds__(512) void k_apply3_lf(const int32_t *__restrict__ idx, const double *__restrict__ w,
+                                                   const double *__restrict__ src, double *__restrict__ dst, int nx, int ny,
+                                                   int64_t nsrc, int nlev, int ntx, int nty) {
+  constexpr int WAVES = 8, PPW = 64 / WAVES, BATCH = 4;
   extern __shared__ double tile[];  // [nlev][65] | sw[3][64] | sidx[3][64]
   double *sw = tile + (size_t)nlev * 65;
   int32_t *sidx = (int32_t *)(sw + 192);
@@ -147,12 +109,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_lf(const int32_t *__restr
   unsigned ntile = (unsigned)ntx * nty;
   unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tl = lin % ntile;
-  int f0 = (lin / ntile) * fpw, f1 = min(nfields, f0 + fpw);
+  int fld = lin / ntile;
   int tx = tl % ntx, ty = tl / ntx;
   int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 192) {
     int pt = t & 63, q = t >> 6;
-    int j = ty * TYL + (pt / TXL), i = tx * TXL + (pt % TXL) - mpg_tile_shift(j, nx);
+    int j = ty, i = tx * 64 + pt - mpg_tile_shift(j, nx);
     bool in = i >= 0 && i < nx && j < ny;
     int64_t p = in ? (int64_t)j * nx + i : 0;
     int32_t c = idx[q * P + p];
@@ -160,10 +122,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_lf(const int32_t *__restr
     sw[q * 64 + pt] = w[q * P + p];
   }
   __syncthreads();
-  int oj = ty * TYL + (lane / TXL), oi = tx * TXL + (lane % TXL) - mpg_tile_shift(oj, nx);
+  int oj = ty, oi = tx * 64 + lane - mpg_tile_shift(oj, nx);
   bool oact = oi >= 0 && oi < nx && oj < ny;
   int64_t op = oact ? (int64_t)oj * nx + oi : 0;
- for (int fld = f0; fld < f1; ++fld) {   // the tile's indices/weights stay staged in LDS for all its fields
   const double *sf = src + (int64_t)fld * nlev * nsrc;
   for (int kb = 0; kb < nlev; kb += 64) {
     int k = kb + lane;
@@ -195,19 +156,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_apply3_lf(const int32_t *__restr
   double *df = dst + (int64_t)fld * nlev * P;
   if (oact)
     for (int k = wave; k < nlev; k += WAVES) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + op);
-  __syncthreads();   // the tile is rewritten by the next field
- }
 }
-typedef void (*apply3lf_fn)(const int32_t *, const double *, const double *, double *, int, int, int64_t, int, int, int, int, int);
-struct LfVariant { int txl, waves; apply3lf_fn fn; };
-static const LfVariant g_lf_variants[] = {
-    {64, 4, k_apply3_lf<64, 4, 4>},  {64, 4, k_apply3_lf<64, 4, 8>},  {64, 4, k_apply3_lf<64, 4, 16>}, {64, 8, k_apply3_lf<64, 8, 8>},
-    {64, 8, k_apply3_lf<64, 8, 4>},  {64, 16, k_apply3_lf<64, 16, 4>}, {64, 16, k_apply3_lf<64, 16, 2>}, {32, 8, k_apply3_lf<32, 8, 8>},
-    {64, 2, k_apply3_lf<64, 2, 16>}, {64, 2, k_apply3_lf<64, 2, 8>},
-};
-#define LF_DEFAULT_ROW_GATHER 4  // 8 waves x 8 points, 4 points in flight: tuned on MI355X
-static int g_lf_variant = -1;    // "lf_variant" knob: -1 = per-handle choice between row-gather #4 and the LDS-staged kernel
-static int g_lf_fpw = 1;      // "lf_fields_per_wg" knob (looping fields inside a workgroup measured slower)
+// "lf_variant" knob: -1 per-handle choice (default) between 0 and 1; 0 row gather on linear aligned tiles
+// (k_apply3_lf_rows), 1 level-chunked LDS-staged kernel (k_apply_lfu.hip), 2 row gather on grid-row tiles (k_apply3_lf /
+// k_apply3_lf_t: the capacity fallback), 3 rows-resident staged kernel (k_apply_lfu.hip: k_apply3_lfw)
+static int g_lf_variant = -1;
 
 // nearest neighbour: bit-exact copy
 __global__ __launch_bounds__(256) void k_apply1(const int32_t *__restrict__ idx, const double *__restrict__ src,
@@ -309,37 +262,24 @@ int mpg_a3_staged() { return g_a3_staged; }
 int mpg_lf_variant() { return g_lf_variant; }
 
 int mpg_k_tune(const char *key, int value) {
-
-  if (!strcmp(key, "lev_chunk")) { g_lev_chunk = value; return MPG_SUCCESS; }
-  if (!strcmp(key, "fields_per_wg")) { g_fpw = value; return MPG_SUCCESS; }
-  if (!strcmp(key, "tile_group")) { g_tgroup = value < 1 ? 1 : value; return MPG_SUCCESS; }
-  if (!strcmp(key, "lf_fields_per_wg")) { g_lf_fpw = value < 1 ? 1 : value; return MPG_SUCCESS; }
-  if (!strcmp(key, "lf_variant")) {  // 0.. : k_apply3_lf variants; 100.. : LDS-staged unique-cell variants (k_apply_lfu.hip)
-    if (value == -1 || value == 200 || (value >= 100 && value < 100 + mpg_lfu_num_variants()) ||
-        (value >= 300 && value < 300 + mpg_lfs_num_variants()) || (value >= 400 && value < 420) || value == 500) {  // 200: rows-resident (32 x 4); 300..: rows-resident, deep prefetch (k_apply_lfs.hip)
-      g_lf_variant = value;
-      return MPG_SUCCESS;
-    }
-    if (value < 0 || value >= (int)(sizeof(g_lf_variants) / sizeof(g_lf_variants[0]))) return MPG_ERR_INVALID_ARG;
+  if (!strcmp(key, "lf_variant")) {
+    if (value < -1 || value > 3) return MPG_ERR_INVALID_ARG;
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
-  if (!strcmp(key, "tile_band")) { mpg_set_tile_band(value); return MPG_SUCCESS; }
-  if (!strcmp(key, "cfu_fields_per_wg")) { mpg_cfu_set_fields_per_wg(value); return MPG_SUCCESS; }
-  if (!strcmp(key, "nn_variant")) {   // nearest-neighbour Store: 1 = wave-cooperative search, 0 = one thread per point
-    if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
-    mpg_set_nearest_variant(value);
-    return MPG_SUCCESS;
-  }
-  if (!strcmp(key, "lfu_min_reuse_x10")) { mpg_lfu_set_min_reuse_x10(value); return MPG_SUCCESS; }
   if (!strcmp(key, "a3_staged")) {
     if (value < -2 || value >= mpg_cfu_num_variants()) return MPG_ERR_INVALID_ARG;
     g_a3_staged = value;
     return MPG_SUCCESS;
   }
-  if (!strcmp(key, "a3_variant")) {
-    if (value < 0 || value >= (int)(sizeof(g_a3_variants) / sizeof(g_a3_variants[0]))) return MPG_ERR_INVALID_ARG;
-    g_a3_variant = value;
+  if (!strcmp(key, "nn_variant")) {   // nearest-neighbour Store: 1 = wave-cooperative search, 0 = one thread per point
+    if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
+    mpg_set_nearest_variant(value);
+    return MPG_SUCCESS;
+  }
+  if (!strcmp(key, "lfu_min_reuse_x10")) {
+    if (value < 0 || value > 1000) return MPG_ERR_INVALID_ARG;
+    mpg_lfu_set_min_reuse_x10(value);
     return MPG_SUCCESS;
   }
   return MPG_ERR_INVALID_ARG;
@@ -360,76 +300,58 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
     k_apply1<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
   } else if (h->nnz_per_row == 4) {
     k_applyN<4><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
-  } else if (h->nnz_per_row == 3) {
+  } else if (h->nnz_per_row == 3 && lev_fast && nlev > 1) {
     int lfv = g_lf_variant;
-    if (lev_fast && lfv < 0) {  // auto: per handle, by the reuse statistic of its tile lists (k_apply_lfu.hip)
-      int pick, rc = mpg_lfu_auto(h, s, &pick);
-      if (rc) return rc;
-      lfv = pick >= 0 ? 100 + pick : 500;
+    if (lfv < 0) {  // per handle, by the (sampled) reuse statistic of its tiles (k_apply_lfu.hip); short bundles: row gather
+      lfv = MPG_LF_ROWS;
+      if (nlev * nfields >= MPG_STAGE_MIN_LEVELS) {
+        int rc = mpg_lfu_auto(h, s, &lfv);
+        if (rc) return rc;
+      }
     }
-    if (lev_fast && lfv == 200) {
-      int rc = mpg_k_apply3_lfr(h, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, s);
+    if (lfv == MPG_LF_RESIDENT) {
+      int rc = mpg_k_apply3_lfw(h, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, s, false);
       if (rc != MPG_ERR_UNSUPPORTED) return rc;
-      lfv = LF_DEFAULT_ROW_GATHER;  // rows of a tile do not fit the LDS
+      lfv = MPG_LF_STAGED;   // not even one level of the tile's rows fits the LDS
     }
-    if (lev_fast && lfv >= 400) {  // 500 (and the 400.. experiment numbers of the typed entry): row gather on linear aligned tiles
-      int rc = mpg_k_apply3_lf_rows(h, src, nlev, nfields, dst, s);   // k_apply_typed.hip: k_apply3_lf_f32m<double, double>
-      if (rc != MPG_ERR_UNSUPPORTED) {
-        if (rc == MPG_SUCCESS && h->n_pole) return mpg_k_pole_fix(h, src, 0, layout, nlev, nfields, dst, 0, 1.0, 0.0, s);
-        return rc;
-      }
-      lfv = LF_DEFAULT_ROW_GATHER;
+    if (lfv == MPG_LF_STAGED) {
+      int rc = mpg_k_apply3_lfu(h, src, nlev, nfields, dst, s);
+      if (rc != MPG_ERR_UNSUPPORTED) return rc;
+      lfv = MPG_LF_ROWS;     // the tile lists outgrow the LDS: row gather
     }
-    if (lev_fast && lfv >= 300) {
-      int rc = mpg_k_apply3_lfs(h, lfv - 300, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, (size_t)160 * 1024, s);
-      if (rc != MPG_ERR_UNSUPPORTED) {
-        if (rc == MPG_SUCCESS && h->n_pole) return mpg_k_pole_fix(h, src, 0, layout, nlev, nfields, dst, 0, 1.0, 0.0, s);
-        return rc;
-      }
-      lfv = LF_DEFAULT_ROW_GATHER;
+    if (lfv == MPG_LF_ROWS) {
+      int rc = mpg_k_apply3_lf_rows(h, src, nlev, nfields, dst, s);   // k_apply_typed.hip
+      if (rc != MPG_ERR_UNSUPPORTED) return rc;
     }
-    if (lev_fast && lfv >= 100) {
-      int rc = mpg_k_apply3_lfu(h, lfv - 100, src, nlev, nfields, dst, s);
-      if (rc) return rc;
-    } else if (lev_fast) {
-      const LfVariant &lv = g_lf_variants[lfv];
-      int tyl = 64 / lv.txl;
-      int ntx = mpg_tile_ntx(h->nx_dst, lv.txl), nty = (h->ny_dst + tyl - 1) / tyl;
-      size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
-      if (lds > 160 * 1024) {
-        mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
-        return MPG_ERR_UNSUPPORTED;
-      }
-      if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)lv.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      int fpw = g_lf_fpw < nfields ? g_lf_fpw : nfields;
-      int ngroups = (nfields + fpw - 1) / fpw;
-      lv.fn<<<(unsigned)ntx * nty * ngroups, 64 * lv.waves, lds, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty,
-                                                                     nfields, fpw);
-    } else {
-      // cell-fast.  g_a3_staged: -2 = lane-gather kernel only, -1 = per-handle choice by the reuse statistic of the tile
-      // lists, >= 0 = that LDS-staged variant (k_apply_lfu.hip)
-      int staged = g_a3_staged;
-      if (staged == -1) {
+    int ntx = mpg_tile_ntx(h->nx_dst, 64), nty = h->ny_dst;
+    size_t lds = sizeof(double) * (65 * (size_t)nlev + 192) + sizeof(int32_t) * 192;
+    if (lds > 160 * 1024) {
+      mpg_set_error("Regrid(LEV_FAST): %d levels exceed the LDS tile", nlev);
+      return MPG_ERR_UNSUPPORTED;
+    }
+    if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)k_apply3_lf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_apply3_lf<<<(unsigned)ntx * nty * nfields, 512, lds, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty);
+  } else if (h->nnz_per_row == 3) {
+    // cell-fast (a single level is the same memory in both layouts).  g_a3_staged: -2 = lane-gather kernel only, -1 =
+    // per-handle choice by the reuse statistic of the tile lists, >= 0 = that LDS-staged variant (k_apply_lfu.hip)
+    int staged = g_a3_staged;
+    if (staged == -1) {
+      staged = -2;
+      if (nlev * nfields >= MPG_STAGE_MIN_LEVELS || h->cf_choice > 0) {   // short bundles: no list build for them
         int rc = mpg_cfu_auto(h, s, &staged);
         if (rc) return rc;
       }
-      else if (staged >= 0) {
-        int fits, rc = mpg_cfu_fits(h, staged, s, &fits);
-        if (rc) return rc;
-        if (!fits) staged = -2;  // hardly any cell shared inside a tile: the lane-gather kernel serves this handle
-      }
-      if (staged >= 0) return mpg_k_apply3_cfu(h, staged, src, nlev, nfields, dst, s);
-      const A3Variant &av = g_a3_variants[g_a3_variant];
-      int tyv = a3_tile_rows(av);
-      int ntx = mpg_tile_ntx(h->nx_dst, A3_TX), nty = (h->ny_dst + tyv - 1) / tyv;
-      int lc = g_lev_chunk > 0 ? g_lev_chunk : nlev;
-      int nchunk = (nlev + lc - 1) / lc;
-      int fpw = g_fpw > 0 ? (g_fpw < nfields ? g_fpw : nfields) : nfields;
-      int ngroups = (nfields + fpw - 1) / fpw;
-      unsigned nwg = (unsigned)ntx * nty * nchunk * ngroups;
-      av.fn<<<nwg, 64 * av.waves, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, lc, ntx, nty, nchunk,
-                                          nfields, fpw, g_tgroup < nty ? g_tgroup : nty);
+    } else if (staged >= 0) {
+      int fits, rc = mpg_cfu_fits(h, staged, s, &fits);
+      if (rc) return rc;
+      if (!fits) staged = -2;  // hardly any cell shared inside a tile: the lane-gather kernel serves this handle
     }
+    if (staged >= 0) {
+      int rc = mpg_k_apply3_cfu(h, staged, src, 0, nlev, nfields, dst, 0, false, 1.0, 0.0, s);
+      if (rc != MPG_ERR_UNSUPPORTED) return rc;
+    }
+    int ntx = mpg_tile_ntx(h->nx_dst, A3_TX), nty = (h->ny_dst + 7) / 8;
+    k_apply3_cf<<<(unsigned)ntx * nty * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntx, nty);
   } else {
     mpg_set_error("Regrid: unsupported handle");
     return MPG_ERR_UNSUPPORTED;

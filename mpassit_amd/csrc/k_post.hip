@@ -10,34 +10,38 @@
 // All are HBM streams (8 B read + 4 B written per value): 16-byte loads, one pass.
 #include <string.h>
 
+#include "geom.h"
 #include "mpg_internal.h"
 
+// dst_be: the float32 results are stored big-endian, as a NetCDF classic variable holds them (one v_perm_b32 per value)
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_post_cast(const double *__restrict__ src, int64_t n, double scale, double offset,
-                                                   float *__restrict__ dst) {
+                                                   float *__restrict__ dst, int dbe) {
+  const Swz zd = make_swz(dbe);
   int64_t i = 2 * (blockIdx.x * (int64_t)blockDim.x + threadIdx.x);
   if (!VEC) {
-    if (i < n) dst[i] = (float)fma(src[i], scale, offset);
-    if (i + 1 < n) dst[i + 1] = (float)fma(src[i + 1], scale, offset);
+    if (i < n) dst[i] = swz<true>((float)fma(src[i], scale, offset), zd);
+    if (i + 1 < n) dst[i + 1] = swz<true>((float)fma(src[i + 1], scale, offset), zd);
   } else if (i + 1 < n) {
     double2 v = *reinterpret_cast<const double2 *>(src + i);
-    float2 o = {(float)fma(v.x, scale, offset), (float)fma(v.y, scale, offset)};
+    float2 o = {swz<true>((float)fma(v.x, scale, offset), zd), swz<true>((float)fma(v.y, scale, offset), zd)};
     *reinterpret_cast<float2 *>(dst + i) = o;
   } else if (i < n) {
-    dst[i] = (float)fma(src[i], scale, offset);
+    dst[i] = swz<true>((float)fma(src[i], scale, offset), zd);
   }
 }
 
 // thread per target point, levels walked bottom-up with the previous level kept in a register: every source
 // value is read once
 __global__ __launch_bounds__(256) void k_post_layer_mean(const double *__restrict__ src, int nlevp1, int64_t P,
-                                                         float *__restrict__ dst) {
+                                                         float *__restrict__ dst, int dbe) {
+  const Swz zd = make_swz(dbe);
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (p >= P) return;
   double prev = src[p];
   for (int k = 1; k < nlevp1; ++k) {
     double cur = src[(int64_t)k * P + p];
-    dst[(int64_t)(k - 1) * P + p] = (float)(0.5 * (cur + prev));
+    dst[(int64_t)(k - 1) * P + p] = swz<true>((float)(0.5 * (cur + prev)), zd);
     prev = cur;
   }
 }
@@ -114,19 +118,19 @@ int mpg_k_bswap(void *buf, int64_t n, int elem_size, hipStream_t s) {
   return MPG_SUCCESS;
 }
 
-int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, hipStream_t s) {
+int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, int dst_be, hipStream_t s) {
   if (n == 0) return MPG_SUCCESS;
   int64_t nthr = (n + 1) / 2;
   bool vec = ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0;  // sub-arrays of a caller's tensor may be odd-aligned
-  if (vec) k_post_cast<true><<<(unsigned)((nthr + 255) / 256), 256, 0, s>>>(src, n, scale, offset, dst);
-  else k_post_cast<false><<<(unsigned)((nthr + 255) / 256), 256, 0, s>>>(src, n, scale, offset, dst);
+  if (vec) k_post_cast<true><<<(unsigned)((nthr + 255) / 256), 256, 0, s>>>(src, n, scale, offset, dst, dst_be);
+  else k_post_cast<false><<<(unsigned)((nthr + 255) / 256), 256, 0, s>>>(src, n, scale, offset, dst, dst_be);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
 
-int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, hipStream_t s) {
+int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, int dst_be, hipStream_t s) {
   if (P == 0 || nlevp1 < 2) return MPG_SUCCESS;
-  k_post_layer_mean<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(src, nlevp1, P, dst);
+  k_post_layer_mean<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(src, nlevp1, P, dst, dst_be);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

@@ -382,14 +382,14 @@ int mpg_regrid_dev(mpg_handle h, const double *src_dev, int src_layout, int nlev
   return mpg_k_apply(h, src_dev, src_layout, nlev, nfields, dst_dev, (hipStream_t)hip_stream);
 }
 
-int mpg_regrid_typed_dev(mpg_handle h, const void *src_dev, int src_f32, int src_layout, int nlev, int nfields, void *dst_dev,
-                         int dst_f32, double scale, double offset, void *hip_stream) {
+int mpg_regrid_typed_dev(mpg_handle h, const void *src_dev, int src_type, int src_layout, int nlev, int nfields, void *dst_dev,
+                         int dst_type, double scale, double offset, void *hip_stream) {
   MPG_CHECK_INIT();
   MPG_ARG(h && dst_dev && (src_dev || h->n_src == 0), "mpg_regrid_typed: NULL argument");
   MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid_typed: nlev and nfields must be >= 1");
   MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid_typed: bad src_layout");
-  MPG_ARG((src_f32 == 0 || src_f32 == 1) && (dst_f32 == 0 || dst_f32 == 1), "mpg_regrid_typed: src_f32/dst_f32 must be 0 or 1");
-  return mpg_k_apply_typed(h, src_dev, src_f32, src_layout, nlev, nfields, dst_dev, dst_f32, scale, offset, (hipStream_t)hip_stream);
+  MPG_ARG(src_type >= 0 && src_type <= 3 && dst_type >= 0 && dst_type <= 3, "mpg_regrid_typed: src_type / dst_type must be MPG_TYPE_F64 or MPG_TYPE_F32, optionally | MPG_TYPE_BE");
+  return mpg_k_apply_typed(h, src_dev, src_type, src_layout, nlev, nfields, dst_dev, dst_type, scale, offset, (hipStream_t)hip_stream);
 }
 
 int mpg_regrid(mpg_handle h, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host) {
@@ -605,7 +605,6 @@ static void lf_invalidate(mpg_handle_s *h) {
   h->free_tile_lists();
   h->lf_choice = 0;
   h->cf_choice = 0;
-  h->cft_unfit = false;
 }
 
 // ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------
@@ -706,17 +705,17 @@ int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream) {
   return mpg_k_bswap(buf_dev, n, elem_size, (hipStream_t)hip_stream);
 }
 
-int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, void *hip_stream) {
+int mpg_post_cast_dev(const double *src_dev, int64_t n, double scale, double offset, float *dst_dev, int dst_be, void *hip_stream) {
   MPG_CHECK_INIT();
   MPG_ARG(n >= 0 && (n == 0 || (src_dev && dst_dev)), "mpg_post_cast_dev: NULL argument");
-  return mpg_k_post_cast(src_dev, n, scale, offset, dst_dev, (hipStream_t)hip_stream);
+  return mpg_k_post_cast(src_dev, n, scale, offset, dst_dev, dst_be != 0, (hipStream_t)hip_stream);
 }
 
-int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, void *hip_stream) {
+int mpg_post_layer_mean_dev(const double *src_dev, int nlevp1, int64_t n_pts, float *dst_dev, int dst_be, void *hip_stream) {
   MPG_CHECK_INIT();
   MPG_ARG(nlevp1 >= 2 && n_pts >= 0, "mpg_post_layer_mean_dev: needs at least two levels");
   MPG_ARG(n_pts == 0 || (src_dev && dst_dev), "mpg_post_layer_mean_dev: NULL argument");
-  return mpg_k_post_layer_mean(src_dev, nlevp1, n_pts, dst_dev, (hipStream_t)hip_stream);
+  return mpg_k_post_layer_mean(src_dev, nlevp1, n_pts, dst_dev, dst_be != 0, (hipStream_t)hip_stream);
 }
 
 int mpg_post_ptop_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, double *ptop_host, void *hip_stream) {

@@ -86,8 +86,8 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
   MPG_ARG(h && dst_host && (src_host || h->n_src == 0), "mpg_regrid_typed: NULL argument");
   MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid_typed: nlev and nfields must be >= 1");
   MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid_typed: bad src_layout");
-  MPG_ARG((src_f32 == 0 || src_f32 == 1) && (dst_f32 == 0 || dst_f32 == 1), "mpg_regrid_typed: src_f32/dst_f32 must be 0 or 1");
-  const size_t es = src_f32 ? 4 : 8, ed = dst_f32 ? 4 : 8;
+  MPG_ARG(src_f32 >= 0 && src_f32 <= 3 && dst_f32 >= 0 && dst_f32 <= 3, "mpg_regrid_typed: src_type / dst_type must be MPG_TYPE_F64 or MPG_TYPE_F32, optionally | MPG_TYPE_BE");
+  const size_t es = (src_f32 & MPG_TYPE_F32) ? 4 : 8, ed = (dst_f32 & MPG_TYPE_F32) ? 4 : 8;
   const size_t ns = (size_t)h->n_src, P = (size_t)h->n_dst;
   // chunk plan: ~96 MB of source per chunk
   std::vector<Chunk> plan;

@@ -224,22 +224,22 @@ struct mpg_handle_s {
   int ut_align = MPG_TILE_ALIGN;   // row shift of the tiles these lists were built for (1: none -- the shifted tiles' lists did not fit)
   int64_t ut_total = 0;
   int64_t ut_lines = 0, ut2_lines = 0;   // sum over the tiles of the distinct groups of 16 consecutive cell ids in their lists
-  int lf_choice = 0;      // level-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 row-gather
+  int lf_choice = 0;      // level-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 row-gather (from a sampled statistic)
   int cf_choice = 0;      // cell-fast kernel picked for this handle: 0 undecided, 1 LDS-staged, -1 lane-gather
   int cf_for = -99;       // "a3_staged" knob value the choice was made for
-  bool cft_unfit = false; // the typed staged cell-fast kernel (fixed 64 x 8 tiles, 1024 cells) does not fit this handle
   float lf_reuse = 0.f;   // 3 * n_dst / (sum of the tiles' unique cells): references per staged row
-  DevBuf<int32_t> ut_ptr, ut_cells;
+  DevBuf<int32_t> ut_cnt, ut_cells;   // list of tile t: ut_cells[t * ut_stride .. + ut_cnt[t])
+  int ut_stride = 0, ut2_stride = 0;
   DevBuf<uint16_t> lidx;  // [3][n_dst] positions in the tile's list, 0xFFFF = unmapped
   // a second, parked set of tile lists: a job that alternates layouts on one handle (2-D fields cell-fast, 3-D fields
   // in file order) needs two tile shapes in turn; the lists of the shape not in use wait here and are swapped back in
   // instead of being rebuilt (a rebuild allocates and synchronises, which would also break hipGraph capture)
   int ut2_rpt = 0, ut2_max = 0, ut2_align = MPG_TILE_ALIGN;
   int64_t ut2_total = 0;
-  DevBuf<int32_t> ut2_ptr, ut2_cells;
+  DevBuf<int32_t> ut2_cnt, ut2_cells;
   DevBuf<uint16_t> lidx2;
   void free_tile_lists() {
-    ut_ptr.free(); ut_cells.free(); lidx.free(); ut2_ptr.free(); ut2_cells.free(); lidx2.free();
+    ut_cnt.free(); ut_cells.free(); lidx.free(); ut2_cnt.free(); ut2_cells.free(); lidx2.free();
     ut_rpt = ut2_rpt = 0;
   }
 };
@@ -262,36 +262,38 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
 int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, hipStream_t s);
 int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s);
 int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s);
-int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
+// src_type / dst_type below: MPG_TYPE_F64 / MPG_TYPE_F32, optionally | MPG_TYPE_BE (include/mpassit_amd.h)
+int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,
                       double scale, double offset, hipStream_t s);
-int mpg_k_apply3_lfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
-int mpg_lfu_num_variants();
-int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
+// "lf_variant" numbering of the level-fast 3-point Regrid
+enum { MPG_LF_ROWS = 0, MPG_LF_STAGED = 1, MPG_LF_ROWTILES = 2, MPG_LF_RESIDENT = 3 };
+#ifndef MPG_LF_STAGED_DEFAULT
+#define MPG_LF_STAGED_DEFAULT MPG_LF_STAGED   // what the per-handle choice takes when staging pays
+#endif
+// a bundle of fewer levels than this (nlev * nfields) is served by the gather kernels in the per-handle modes: building
+// tile lists costs more than every 2-D field of a job together (profiles/r02j: 4.9 ms of list builds in a cold
+// configuration-4 job), and one level gives a staged kernel nothing to amortise its prologue over
+#define MPG_STAGE_MIN_LEVELS 8
 int mpg_cfu_num_variants();
-void mpg_cfu_set_fields_per_wg(int v);
-void mpg_set_tile_band(int v);
+int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, bool epi,
+                     double scale, double offset, hipStream_t s);
+int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
+int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
+                           double offset, hipStream_t s);
+int mpg_k_apply3_lfw(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale, double offset,
+                     hipStream_t s, bool epi = true);
 int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
-int mpg_tile_band();
 int mpg_a3_staged();  // current "a3_staged" knob
 int mpg_lf_variant(); // current "lf_variant" knob
-int mpg_k_apply3_lfr(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale, double offset,
-                     hipStream_t s);
-int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
-                           double offset, hipStream_t s);
 int mpg_lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s);  // tile lists for txu x tyu-point tiles (cached per handle)
-int mpg_lfs_num_variants();
-int mpg_k_apply3_lfs(mpg_handle_s *h, int shape, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
-                     double offset, size_t lds_cap, hipStream_t s);
 int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits);
-int mpg_k_apply3_cfu_typed(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, double scale,
-                           double offset, hipStream_t s);
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant);  // -> variant index or -1 (use k_apply3_cf)
-int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lfu_variant);  // -> variant index or -1 (use the row-gather kernel)
-int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_f32, int layout, int nlev, int nfields, void *dst, int dst_f32,
+int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lf_variant);   // -> MPG_LF_ROWS or the staged default
+int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,
                    double scale, double offset, hipStream_t s);
 int mpg_k_bswap(void *buf, int64_t n, int elem_size, hipStream_t s);
-int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, hipStream_t s);
-int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, hipStream_t s);
+int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, int dst_be, hipStream_t s);
+int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, int dst_be, hipStream_t s);
 int mpg_k_post_ptop(const double *src, int nlev, int64_t P, double *ptop_host, hipStream_t s);
 int mpg_k_post_ptop_parts(const double *src, int nlev, int64_t P, double *vmax_host, double *candmin_host, int *has_cand_host, hipStream_t s);
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);

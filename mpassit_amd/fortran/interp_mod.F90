@@ -19,6 +19,8 @@ module model_data
     ! device-resident flow (dev_flow): the field lives in HBM from the input file to the output file
     type(c_ptr) :: src_dev = c_null_ptr, dst_dev = c_null_ptr
     logical :: src_is_f32 = .false., dst_is_f32 = .false.
+    !> the device buffer holds the file's big-endian bytes as they are (NetCDF classic): the Regrid reads / writes them so
+    logical :: src_is_be = .false., dst_is_be = .false.
     integer(c_int64_t) :: n_dst_elems = 0
   end type field_t
   type bundle_t
@@ -65,6 +67,7 @@ contains
     if (allocated(a%dst4)) call move_alloc(a%dst4, b%dst4)
     b%src_dev = a%src_dev; b%dst_dev = a%dst_dev; a%src_dev = c_null_ptr; a%dst_dev = c_null_ptr
     b%src_is_f32 = a%src_is_f32; b%dst_is_f32 = a%dst_is_f32; b%n_dst_elems = a%n_dst_elems
+    b%src_is_be = a%src_is_be; b%dst_is_be = a%dst_is_be
   end subroutine move_field
 end module model_data
 
@@ -113,12 +116,13 @@ contains
     if (dev_flow) then
       if (c_associated(f%dst_dev)) call mpg_check(mpg_dev_free(f%dst_dev), "IN dev_free")
       f%dst_is_f32 = .not. keeps_r8(f)
+      f%dst_is_be = f%dst_is_f32                 ! NF90_FLOAT results go straight to the file: produced as the file stores them
       f%n_dst_elems = n_dst*f%nlev
       call mpg_check(mpg_dev_alloc(f%n_dst_elems*merge(4, 8, f%dst_is_f32), f%dst_dev), "IN dev_alloc "//trim(f%name))
       offset = 0.0_c_double
       if (f%dst_is_f32 .and. wrf_mod_vars .and. trim(f%tname) == 'T') offset = -300.0_c_double
-      call mpg_check(mpg_regrid_typed_dev(rh, f%src_dev, merge(1_c_int, 0_c_int, f%src_is_f32), layout, int(f%nlev, c_int), 1_c_int, &
-                                          f%dst_dev, merge(1_c_int, 0_c_int, f%dst_is_f32), 1.0_c_double, offset, c_null_ptr), &
+      call mpg_check(mpg_regrid_typed_dev(rh, f%src_dev, elem_type(f%src_is_f32, f%src_is_be), layout, int(f%nlev, c_int), 1_c_int, &
+                                          f%dst_dev, elem_type(f%dst_is_f32, f%dst_is_be), 1.0_c_double, offset, c_null_ptr), &
                      "IN FieldRegrid "//trim(f%name))
       call mpg_check(mpg_dev_free(f%src_dev), "IN dev_free")      ! the source is not needed again
       f%src_dev = c_null_ptr
@@ -141,6 +145,11 @@ contains
                                       1.0_c_double, offset), "IN FieldRegrid "//trim(f%name))
     end if
   end subroutine regrid_field
+
+  integer(c_int) function elem_type(is_f32, is_be)
+    logical, intent(in) :: is_f32, is_be
+    elem_type = merge(MPG_TYPE_F32, MPG_TYPE_F64, is_f32) + merge(MPG_TYPE_BE, 0_c_int, is_be)
+  end function elem_type
 
   subroutine interp_diag_data()
     type(c_ptr) :: rh_patch
@@ -233,7 +242,7 @@ contains
     dst%nlev = src%nlev
     if (dev_flow) then
       dst%dst_dev = src%dst_dev; src%dst_dev = c_null_ptr
-      dst%dst_is_f32 = src%dst_is_f32; dst%n_dst_elems = src%n_dst_elems
+      dst%dst_is_f32 = src%dst_is_f32; dst%dst_is_be = src%dst_is_be; dst%n_dst_elems = src%n_dst_elems
       return
     end if
     call move_alloc(src%dst, dst%dst)
@@ -251,11 +260,12 @@ contains
     if (allocated(stag%dst4)) deallocate (stag%dst4)
     if (dev_flow) then
       if (c_associated(stag%dst_dev)) call mpg_check(mpg_dev_free(stag%dst_dev), "IN dev_free")
-      stag%dst_is_f32 = .true.
+      stag%dst_is_f32 = .true.; stag%dst_is_be = .true.
       stag%n_dst_elems = n_dst*mass%nlev
       call mpg_check(mpg_dev_alloc(stag%n_dst_elems*4, stag%dst_dev), "IN dev_alloc")
-      call mpg_check(mpg_regrid_typed_dev(rh, mass%dst_dev, 0_c_int, MPG_LAYOUT_CELL_FAST, int(mass%nlev, c_int), 1_c_int, stag%dst_dev, &
-                                          1_c_int, 1.0_c_double, 0.0_c_double, c_null_ptr), "IN FieldRegrid")
+      call mpg_check(mpg_regrid_typed_dev(rh, mass%dst_dev, elem_type(mass%dst_is_f32, mass%dst_is_be), MPG_LAYOUT_CELL_FAST, &
+                                          int(mass%nlev, c_int), 1_c_int, stag%dst_dev, MPG_TYPE_F32 + MPG_TYPE_BE, 1.0_c_double, 0.0_c_double, &
+                                          c_null_ptr), "IN FieldRegrid")
       return
     end if
     if (f32_out) then

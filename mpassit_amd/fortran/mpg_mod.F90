@@ -21,6 +21,9 @@ module mpg
   integer(c_int), parameter :: MPG_STAGGERLOC_CENTER = 0, MPG_STAGGERLOC_EDGE1 = 1, MPG_STAGGERLOC_EDGE2 = 2, &
                                MPG_STAGGERLOC_CORNER = 3
   integer(c_int), parameter :: MPG_LAYOUT_CELL_FAST = 0, MPG_LAYOUT_LEV_FAST = 1
+  !> element type codes of mpg_regrid_typed[_dev]: float64 / float32, + MPG_TYPE_BE when the values are big-endian in
+  !! memory (the bytes of a NetCDF classic variable, moved file <-> HBM untouched)
+  integer(c_int), parameter :: MPG_TYPE_F64 = 0, MPG_TYPE_F32 = 1, MPG_TYPE_BE = 2
   integer(c_int), parameter :: MPG_GRID_PERIODIC_I = 1, MPG_GRID_NO_SOUTH_POLE = 2, MPG_GRID_NO_NORTH_POLE = 4
   integer(c_int), parameter :: MPG_PROJ_LATLON = 0, MPG_PROJ_LC = 1, MPG_PROJ_PS = 2, MPG_PROJ_MERC = 3
   !> struct mpg_proj (include/mpassit_amd.h): the arguments of push_source_projection (model_grid.F90:676-678)
@@ -109,8 +112,8 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid
 
-    !> Regrid on host buffers of the files' own types: src_f32 / dst_f32 = 1 for real(c_float) arrays (MPAS history
-    !! variables are NF90_FLOAT), 0 for real(c_double); float64 arithmetic, dst = regrid(src)*scale + offset.
+    !> Regrid on host buffers of the files' own types: src_type / dst_type = MPG_TYPE_F32 for real(c_float) arrays (MPAS
+    !! history variables are NF90_FLOAT), MPG_TYPE_F64 for real(c_double); float64 arithmetic, dst = regrid(src)*scale + offset.
     function mpg_regrid_typed(rh, src, src_f32, src_layout, nlev, nfields, dst, dst_f32, scale, offset) &
       bind(C, name="mpg_regrid_typed") result(rc)
       import :: c_int, c_double, c_ptr
@@ -120,7 +123,8 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid_typed
 
-    !> the same on device pointers (mpg_dev_alloc), enqueued on `stream` (c_null_ptr = default stream)
+    !> the same on device pointers (mpg_dev_alloc), enqueued on `stream` (c_null_ptr = default stream); src_f32 / dst_f32
+    !! are MPG_TYPE_* codes: + MPG_TYPE_BE for the raw bytes of a NetCDF classic variable
     function mpg_regrid_typed_dev(rh, src, src_f32, src_layout, nlev, nfields, dst, dst_f32, scale, offset, stream) &
       bind(C, name="mpg_regrid_typed_dev") result(rc)
       import :: c_int, c_double, c_ptr
@@ -181,18 +185,20 @@ module mpg
       integer(c_int) :: rc
     end function mpg_bswap_dev
 
-    !> writer epilogues on device-resident float64 fields (write_data.F90:1339-1475), float32 results
-    function mpg_post_cast_dev(src, n, scale, offset, dst, stream) bind(C, name="mpg_post_cast_dev") result(rc)
+    !> writer epilogues on device-resident float64 fields (write_data.F90:1339-1475), float32 results, stored big-endian
+    !! (as the output file holds them) when dst_be /= 0
+    function mpg_post_cast_dev(src, n, scale, offset, dst, dst_be, stream) bind(C, name="mpg_post_cast_dev") result(rc)
       import :: c_int, c_int64_t, c_double, c_ptr
       type(c_ptr), value :: src, dst, stream
       integer(c_int64_t), value :: n
       real(c_double), value :: scale, offset
+      integer(c_int), value :: dst_be
       integer(c_int) :: rc
     end function mpg_post_cast_dev
-    function mpg_post_layer_mean_dev(src, nlevp1, npts, dst, stream) bind(C, name="mpg_post_layer_mean_dev") result(rc)
+    function mpg_post_layer_mean_dev(src, nlevp1, npts, dst, dst_be, stream) bind(C, name="mpg_post_layer_mean_dev") result(rc)
       import :: c_int, c_int64_t, c_ptr
       type(c_ptr), value :: src, dst, stream
-      integer(c_int), value :: nlevp1
+      integer(c_int), value :: nlevp1, dst_be
       integer(c_int64_t), value :: npts
       integer(c_int) :: rc
     end function mpg_post_layer_mean_dev

@@ -195,8 +195,8 @@ contains
     end if
   end subroutine nc_load_field
 
-  !> device flow: the variable's bytes go file -> GPU as stored and are turned to host byte order there; types other
-  !! than NF90_FLOAT / NF90_DOUBLE are converted by ncio on the host and uploaded as float64
+  !> device flow: the variable's bytes go file -> GPU as stored (big-endian) and the Regrid reads them so (MPG_TYPE_BE);
+  !! types other than NF90_FLOAT / NF90_DOUBLE are converted by ncio on the host and uploaded as float64
   subroutine load_dev(nf, id, xtype, n, f)
     type(c_ptr), intent(in) :: nf
     integer(c_int), intent(in) :: id, xtype
@@ -209,7 +209,7 @@ contains
       f%src_is_f32 = xtype == NCIO_FLOAT
       call mpg_check(mpg_dev_alloc(nb, f%src_dev), "IN dev_alloc "//trim(f%name))
       call mpg_check(mpg_file_to_dev(trim(nc_in_path), off, nb, f%src_dev), "reading field - "//trim(f%name))
-      call mpg_check(mpg_bswap_dev(f%src_dev, n, merge(4_c_int, 8_c_int, f%src_is_f32), c_null_ptr), "IN bswap")
+      f%src_is_be = .true.
     else
       allocate (tmp(n))
       call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, tmp), "reading field - "//trim(f%name))
@@ -269,22 +269,20 @@ contains
     call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
   end subroutine put_zero
 
-  !> device flow: a float32 field [nlev][rows][nxv] in HBM -> the variable's byte range (byte order turned on the GPU first
-  !! unless the buffer already holds big-endian values from an earlier put).  With one image the buffer IS the variable; with
+  !> device flow: a float32 field [nlev][rows][nxv] in HBM, big-endian as the Regrid / post-op kernels left it -> the
+  !! variable's byte range.  With one image the buffer IS the variable; with
   !! several it holds this image's row block je_lo..je_hi (+1 row on the V stagger) and the owned rows j_lo..j_hi of every
   !! level go to their place in the variable (the last image also owns the top V row).
-  subroutine put_dev(id, ptr, nlev, stag, swap)
+  subroutine put_dev(id, ptr, nlev, stag)
     integer(c_int), intent(in) :: id
     type(c_ptr), intent(in) :: ptr
     integer, intent(in) :: nlev, stag
-    logical, intent(in) :: swap
     integer(c_int64_t) :: off, nb, n, nxv, ny_buf, ny_glob, jb0, jg0, nrows, k
     integer(int64) :: c0, c1, cr
     call system_clock(c0, cr)
     nxv = i_target + merge(1, 0, stag == 1)
     ny_buf = ny_ext + merge(1, 0, stag == 2)
     n = int(nlev, c_int64_t)*ny_buf*nxv
-    if (swap) call mpg_check(mpg_bswap_dev(ptr, n, 4_c_int, c_null_ptr), "IN bswap")
     call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
     if (nranks == 1) then
       if (n*4 > nb) call fatal("put_dev: field larger than its variable", int(id))
@@ -321,14 +319,15 @@ contains
     integer(c_int64_t) :: n
     n = p%n_dst_elems
     if (p%dst_is_f32) then
-      call put_dev(id, p%dst_dev, p%nlev, p%stagger, .true.)
+      if (.not. p%dst_is_be) call fatal("write_field_dev: float32 field in host byte order - "//trim(p%tname), -1)
+      call put_dev(id, p%dst_dev, p%nlev, p%stagger)
     else
       call mpg_check(mpg_dev_alloc(n*4, tmp), "IN dev_alloc")
       if (trim(p%tname) == 'PHB') then
-        call mpg_check(mpg_post_layer_mean_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), tmp, c_null_ptr), "IN Z_C")   ! :1406-1415
-        call put_dev(id_extra(3), tmp, p%nlev - 1, 0, .true.)
-        call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 9.81_c_double, 0.0_c_double, tmp, c_null_ptr), "IN PHB*9.81")              ! :1418
-        call put_dev(id, tmp, p%nlev, p%stagger, .true.)
+        call mpg_check(mpg_post_layer_mean_dev(p%dst_dev, int(p%nlev, c_int), int(npts, c_int64_t), tmp, 1_c_int, c_null_ptr), "IN Z_C")   ! :1406-1415
+        call put_dev(id_extra(3), tmp, p%nlev - 1, 0)
+        call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 9.81_c_double, 0.0_c_double, tmp, 1_c_int, c_null_ptr), "IN PHB*9.81")     ! :1418
+        call put_dev(id, tmp, p%nlev, p%stagger)
         if (wrf_mod_vars) call put_zero(id_extra(4))
       else
         if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') then                                                                    ! :1362-1379
@@ -341,9 +340,9 @@ contains
             have_ptop_parts = .true.
           end if
         end if
-        call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 1.0_c_double, 0.0_c_double, tmp, c_null_ptr), "IN cast")
-        call put_dev(id, tmp, p%nlev, p%stagger, .true.)
-        if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') call put_dev(id_extra(2), tmp, p%nlev, p%stagger, .false.)              ! PB = P_HYD
+        call mpg_check(mpg_post_cast_dev(p%dst_dev, n, 1.0_c_double, 0.0_c_double, tmp, 1_c_int, c_null_ptr), "IN cast")
+        call put_dev(id, tmp, p%nlev, p%stagger)
+        if (wrf_mod_vars .and. trim(p%tname) == 'P_HYD') call put_dev(id_extra(2), tmp, p%nlev, p%stagger)                       ! PB = P_HYD
       end if
       call mpg_check(mpg_dev_free(tmp), "IN dev_free")
     end if

@@ -50,6 +50,15 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _is_be(a):
+    """io_nc's device flow marks tensors that hold a NetCDF classic variable's bytes as stored (big-endian)."""
+    return bool(getattr(a, "mpg_be", False))
+
+
+def _be_kw(a):
+    return {"src_be": True} if _is_be(a) else {}
+
+
 def _stack(arrs):
     if _is_torch(arrs[0]):
         import torch
@@ -64,7 +73,7 @@ def _bundle_regrid(rh, arrs, nlev, layout):
     if _is_torch(arrs[0]):
         # device-resident fields live in separate tensors: regrid them one by one through the shared handle
         # (identical to the bundle call) instead of stacking gigabytes into a temporary
-        return [rh.regrid(a.contiguous().reshape(-1), nlev=nlev, layout=layout)[0] for a in arrs]
+        return [rh.regrid(a.contiguous().reshape(-1), nlev=nlev, layout=layout, src_be=_is_be(a))[0] for a in arrs]
     out = rh.regrid(_stack(arrs).reshape(-1), nlev=nlev, nfields=len(arrs), layout=layout)
     return [out[i] for i in range(len(arrs))]
 
@@ -115,13 +124,15 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
     rh_patch = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)    # interp.F90:207 / :226 / :241 / ...
     for (n, t), o in zip(h.patch_2d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.patch_2d], 1, R.LAYOUT_CELL_FAST)):
         out[t] = o[0]
-    out["HGT"] = rh_patch.regrid(inp.hgt, nlev=1)[0, 0]              # interp.F90:226-238
+    out["HGT"] = rh_patch.regrid(inp.hgt, nlev=1, **_be_kw(inp.hgt))[0, 0]   # interp.F90:226-238
     for (n, t), o in zip(h.nz_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nz_3d], inp.nz, inp.layout)):
         out[t] = o                                                    # interp.F90:240-254
     if h.do_u_interp:
-        out["UMASS"] = rh_patch.regrid(inp.hist["uReconstructZonal"], nlev=inp.nz, layout=inp.layout)[0]      # :256-272
+        out["UMASS"] = rh_patch.regrid(inp.hist["uReconstructZonal"], nlev=inp.nz, layout=inp.layout,
+                                       **_be_kw(inp.hist["uReconstructZonal"]))[0]                          # :256-272
     if h.do_v_interp:
-        out["VMASS"] = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout)[0]  # :274-289
+        out["VMASS"] = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout,
+                                       **_be_kw(inp.hist["uReconstructMeridional"]))[0]                     # :274-289
     if h.do_u_interp and h.do_v_interp and cfg.proj_is_lambert:
         rotate_winds_cgrid(target, out["UMASS"], out["VMASS"])        # :291-293
     destagger = destagger or _destagger_local

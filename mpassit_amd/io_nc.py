@@ -136,7 +136,8 @@ def _dev_to_file(path, offset, dev):
 
 def _read_field_dev(r, name, device):
     """The variable's bytes go file mapping -> GPU as stored (no host conversion pass, NF90_FLOAT stays 4 bytes on the
-    bus) and are turned to host byte order there; Regrid widens float32 in its loads."""
+    bus) and STAY as stored: the tensor is marked mpg_be and Regrid reads big-endian float32 / float64 in its loads
+    (MPG_TYPE_BE) -- no byte-swap pass over the data."""
     import torch
     v = r.vars[name]
     if v["type"] not in _RAW_TYPES:
@@ -145,7 +146,9 @@ def _read_field_dev(r, name, device):
     t = torch.empty(nb, dtype=torch.uint8, device=device)
     _file_to_dev(r.path, off, t)
     shape = [int(n) for n in v["shape"]][1 if v["record"] else 0:]
-    return bswap_(t.view(getattr(torch, _RAW_TYPES[v["type"]][0]))).reshape(shape)
+    t = t.view(getattr(torch, _RAW_TYPES[v["type"]][0])).reshape(shape)
+    t.mpg_be = True
+    return t
 
 
 _LSM = {"noah": 2, "ruc": 3}                                                  # input_data.F90:347-355
@@ -268,14 +271,15 @@ def _is_dev(x):
 
 
 def _put_dev(w, name, a):
-    """float32 CUDA tensor -> the variable's bytes in the file mapping: swapped to big-endian on the GPU (on a copy,
-    the caller keeps its tensor), one device -> mapping copy, no host conversion pass."""
+    """float32 CUDA tensor -> the variable's bytes in the file mapping.  Tensors the post-ops produced big-endian
+    (mpg_be) go out as they are; others are swapped on the GPU on a copy (the caller keeps its tensor)."""
     import torch
+    is_be = bool(getattr(a, "mpg_be", False))
     a = a.contiguous()
     off, _ = w.extent(name, rec=0)                        # makes the record exist: a file being created reads as zeros
     if a.numel() and not bool(a.view(torch.int32).any()):
         return                                            # all-zero bit patterns (MU, PH, P of wrf_mod_vars): nothing to store
-    be = bswap_(a.clone()).view(torch.uint8).reshape(-1)
+    be = (a if is_be else bswap_(a.clone())).view(torch.uint8).reshape(-1)
     _dev_to_file(w.path, off, be)                         # Z_C: nz of the declared nzp1 levels, the rest stays zero
 
 
@@ -385,7 +389,8 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
 
 def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=None, fmt=5, device_io=False, timings=None):
     """mpassit.F90's main sequence on files: read grid + data, regrid on the GPU, post-ops, write.  Returns the
-    dictionary that went to the file (float32, post.output_fields order).
+    dictionary that went to the file (float32, post.output_fields order; with device_io the CUDA tensors hold the values
+    big-endian, as the file does).
     device_io: variables travel file <-> GPU as raw big-endian bytes and every field stays device resident in between
     (same file, bit for bit, as the host-array path).  timings: dict that receives the wall seconds of each stage."""
     import time
@@ -408,7 +413,7 @@ def run(grid_path, hist_path, out_path, target, cfg, diag_path=None, namelist=No
     t = lap("mesh_grid_create", t)
     out = I.interp_data(mesh, grid, target, inp, cfg)
     t = lap("interp_data", t)
-    res = post.output_fields(out, cfg)
+    res = post.output_fields(out, cfg, be=device_io)     # device flow: float32 results as the file stores them
     t = lap("post_ops", t)
     write_target_data(out_path, target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00", zs=zs,
                       namelist=namelist, fmt=fmt, meta=inp.meta)
@@ -464,7 +469,7 @@ def run_series(grid_path, jobs, target, cfg, namelist=None, fmt=5, timings=None)
             if k + 1 < len(jobs):
                 nxt = reader.submit(fetch, jobs[k + 1])
             out = gi.replay()
-            res = post.output_fields(out, cfg)
+            res = post.output_fields(out, cfg, be=True)
             write_target_data(job[2], target, grid, res, cfg, inp.nz, inp.nzp1, inp.nsoil, valid_time=valid or "0000-00-00_00:00:00",
                               zs=zs, namelist=namelist, fmt=fmt, meta=inp.meta)
             if timings is not None:

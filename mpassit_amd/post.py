@@ -36,23 +36,33 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def cast_f32(x, scale=1.0, offset=0.0):
-    """(float)(x*scale + offset) -- nf90_put_var's float64 -> NF90_FLOAT conversion with the writer's affine post-op."""
+def cast_f32(x, scale=1.0, offset=0.0, be=False):
+    """(float)(x*scale + offset) -- nf90_put_var's float64 -> NF90_FLOAT conversion with the writer's affine post-op.
+    be: store the float32 values big-endian, as the NetCDF classic output file holds them (CUDA tensors only; the
+    result carries the attribute mpg_be = True)."""
     import torch
     d, was_t = _dev(x)
+    if be and not was_t:
+        raise ValueError("big-endian results are for the device flow: pass a CUDA tensor")
     out = torch.empty(d.shape, dtype=torch.float32, device=d.device)
     check(L.load().mpg_post_cast_dev(C.c_void_p(d.data_ptr()), C.c_int64(d.numel()), C.c_double(scale), C.c_double(offset),
-                                     C.c_void_p(out.data_ptr()), _stream()))
+                                     C.c_void_p(out.data_ptr()), C.c_int(int(be)), _stream()))
+    if be:
+        out.mpg_be = True
     return out if was_t else out.cpu().numpy()
 
 
-def layer_mean_f32(x):
-    """Z_C: [nlevp1][...] -> [nlevp1-1][...], 0.5*(x[k+1] + x[k]) (write_data.F90:1406-1415)."""
+def layer_mean_f32(x, be=False):
+    """Z_C: [nlevp1][...] -> [nlevp1-1][...], 0.5*(x[k+1] + x[k]) (write_data.F90:1406-1415).  be: as in cast_f32."""
     import torch
     d, was_t = _dev(x)
+    if be and not was_t:
+        raise ValueError("big-endian results are for the device flow: pass a CUDA tensor")
     out = torch.empty((d.shape[0] - 1,) + tuple(d.shape[1:]), dtype=torch.float32, device=d.device)
     check(L.load().mpg_post_layer_mean_dev(C.c_void_p(d.data_ptr()), C.c_int(d.shape[0]), C.c_int64(d[0].numel()),
-                                           C.c_void_p(out.data_ptr()), _stream()))
+                                           C.c_void_p(out.data_ptr()), C.c_int(int(be)), _stream()))
+    if be:
+        out.mpg_be = True
     return out if was_t else out.cpu().numpy()
 
 
@@ -64,6 +74,10 @@ def p_top(p_hyd):
     return np.float32(v.value)
 
 
+def _is_cuda(x):
+    return type(x).__module__.startswith("torch") and x.is_cuda
+
+
 def _zeros_like_f32(x):
     import torch
     if type(x).__module__.startswith("torch"):
@@ -71,9 +85,16 @@ def _zeros_like_f32(x):
     return np.zeros(x.shape, np.float32)
 
 
-def output_fields(out, cfg):
+def output_fields(out, cfg, be=False):
     """interp_data's result (target name -> float64 array) -> ordered dict of what write_target_data puts in the file
-    for those fields (float32).  Grid variables (XLAT, MAPFAC_*, ...) and time records are not part of the hot path."""
+    for those fields (float32).  Grid variables (XLAT, MAPFAC_*, ...) and time records are not part of the hot path.
+    be: CUDA results big-endian (io_nc's device flow writes them to the file as they are)."""
+    def cast_f32(x, scale=1.0, offset=0.0):
+        return globals()["cast_f32"](x, scale, offset, be=be and _is_cuda(x))
+
+    def layer_mean_f32(x):
+        return globals()["layer_mean_f32"](x, be=be and _is_cuda(x))
+
     h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars)
     res = {}
     if "HGT" in out:

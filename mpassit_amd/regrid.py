@@ -172,17 +172,18 @@ class RouteHandle:
         self.__init__(self._h)
 
     # -- ESMF_FieldRegrid / ESMF_FieldBundleRegrid ---------------------------------------------------
-    def regrid(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out=None):
+    def regrid(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out=None, src_be=False):
         """src: nfields slabs of nlev*n_src float64 (numpy on host or torch on the GPU).
-        Returns dst [nfields][nlev][ny_dst][nx_dst] (squeezing nfields == 1 and nlev == 1 is left to the caller)."""
+        Returns dst [nfields][nlev][ny_dst][nx_dst] (squeezing nfields == 1 and nlev == 1 is left to the caller).
+        src_be: the CUDA tensor holds the big-endian bytes of a NetCDF classic variable (io_nc device flow)."""
         shape = (nfields, nlev, self.ny_dst, self.nx_dst)
         need = nfields * nlev * self.n_src
         if _is_torch(src):
             import torch
-            if src.is_cuda and src.dtype == torch.float32 and src.is_contiguous():
-                # a field still in the file's NF90_FLOAT type: widened inside the kernel's loads (same result as
-                # widening first, nf90_get_var -> r8 in input_data.F90), float64 out
-                return self.regrid_typed(src, nlev=nlev, nfields=nfields, layout=layout, out_dtype=torch.float64, out=out)
+            if src.is_cuda and (src.dtype == torch.float32 or src_be) and src.is_contiguous():
+                # a field still in the file's NF90_FLOAT type (and byte order): widened inside the kernel's loads (same
+                # result as widening first, nf90_get_var -> r8 in input_data.F90), float64 out
+                return self.regrid_typed(src, nlev=nlev, nfields=nfields, layout=layout, out_dtype=torch.float64, out=out, src_be=src_be)
             if not src.is_cuda or src.dtype != torch.float64 or not src.is_contiguous():
                 raise ValueError("device regrid needs a contiguous float32/float64 CUDA tensor")
             if src.numel() != need:
@@ -202,9 +203,11 @@ class RouteHandle:
         check(L.load().mpg_regrid(self._h, _ptr(src), C.c_int(layout), C.c_int(nlev), C.c_int(nfields), _ptr(out)))
         return out
 
-    def regrid_typed(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offset=0.0, out=None):
+    def regrid_typed(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offset=0.0, out=None,
+                     src_be=False, dst_be=False):
         """Fused ingest/egress Regrid on device tensors: float32 or float64 source (as in the MPAS file), float32 or
-        float64 destination (as in the output file), float64 arithmetic, dst = cast(regrid(src)*scale + offset)."""
+        float64 destination (as in the output file), float64 arithmetic, dst = cast(regrid(src)*scale + offset).
+        src_be / dst_be: that side holds big-endian values (the bytes of a NetCDF classic variable; MPG_TYPE_BE)."""
         import torch
         if not (src.is_cuda and src.is_contiguous() and src.dtype in (torch.float32, torch.float64)):
             raise ValueError("regrid_typed needs a contiguous float32/float64 CUDA tensor")
@@ -213,9 +216,10 @@ class RouteHandle:
         out_dtype = out_dtype or src.dtype
         if out is None:
             out = torch.empty((nfields, nlev, self.ny_dst, self.nx_dst), dtype=out_dtype, device=src.device)
-        check(L.load().mpg_regrid_typed_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(int(src.dtype == torch.float32)), C.c_int(layout),
-                                            C.c_int(nlev), C.c_int(nfields), C.c_void_p(out.data_ptr()),
-                                            C.c_int(int(out.dtype == torch.float32)), C.c_double(scale), C.c_double(offset), _stream_ptr()))
+        check(L.load().mpg_regrid_typed_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(int(src.dtype == torch.float32) | (2 if src_be else 0)),
+                                            C.c_int(layout), C.c_int(nlev), C.c_int(nfields), C.c_void_p(out.data_ptr()),
+                                            C.c_int(int(out.dtype == torch.float32) | (2 if dst_be else 0)), C.c_double(scale), C.c_double(offset),
+                                            _stream_ptr()))
         return out
 
     def regrid_typed_host(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offset=0.0, out=None):

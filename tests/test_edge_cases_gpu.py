@@ -136,7 +136,7 @@ def test_bad_arguments_are_refused(gpu_lib, regional_case):
     assert lib.mpg_regrid(rh._h, p(src), C.c_int(0), C.c_int(1), C.c_int(0), p(dst)) == 2
     assert lib.mpg_regrid(rh._h, p(src), C.c_int(7), C.c_int(1), C.c_int(1), p(dst)) == 2 and b"layout" in lib.mpg_last_error()
     assert lib.mpg_regrid(rh._h, None, C.c_int(0), C.c_int(1), C.c_int(1), p(dst)) == 2
-    assert lib.mpg_regrid_typed(rh._h, p(src), C.c_int(3), C.c_int(0), C.c_int(1), C.c_int(1), p(dst), C.c_int(0), C.c_double(1.0),
+    assert lib.mpg_regrid_typed(rh._h, p(src), C.c_int(4), C.c_int(0), C.c_int(1), C.c_int(1), p(dst), C.c_int(0), C.c_double(1.0),
                                 C.c_double(0.0)) == 2
     with pytest.raises(ValueError):
         rh.regrid(np.zeros(m.nCells + 1), nlev=1)                           # wrong element count is caught before the call

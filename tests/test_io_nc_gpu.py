@@ -76,8 +76,9 @@ def test_file_to_file_run_matches_the_in_memory_pipeline(gpu_lib, tmp_path):
         assert r.format == 5
         assert np.array_equal(r.get("T", rec=0), res5["T"]) and np.array_equal(r.get("TSLB", rec=0), res5["TSLB"])
 
-    # device-side ingest / egress: variables cross as raw big-endian bytes, swapped on the GPU, fields device resident
-    # in between -> the very same file, byte for byte
+    # device-side ingest / egress: variables cross as raw big-endian bytes and stay so on the GPU (the Regrid and the
+    # post-ops read / write big-endian values, no swap pass), fields device resident in between -> the very same file,
+    # byte for byte
     import torch
     resd = io_nc.run(gpath, hpath, tmp_path / "out5d.nc", target, cfg, diag_path=dpath, namelist=nml, fmt=5, device_io=True)
     assert list(resd) == list(res5)
@@ -85,7 +86,9 @@ def test_file_to_file_run_matches_the_in_memory_pipeline(gpu_lib, tmp_path):
     assert (tmp_path / "out5d.nc").read_bytes() == (tmp_path / "out5.nc").read_bytes()
     inp_d, _, _ = io_nc.read_input_data(hpath, cfg, ter, diag_path=dpath, device="cuda")
     assert inp_d.hist["theta"].dtype == torch.float32 and tuple(inp_d.hist["theta"].shape) == (m.nCells, nz)
-    assert np.array_equal(inp_d.hist["theta"].cpu().numpy(), hist["theta"]) and np.array_equal(inp_d.diag["u10"].cpu().numpy(), diag["u10"])
+    assert inp_d.hist["theta"].mpg_be and inp_d.diag["u10"].mpg_be            # the file's bytes as they are stored
+    assert np.array_equal(inp_d.hist["theta"].cpu().numpy().view(">f4"), hist["theta"])
+    assert np.array_equal(inp_d.diag["u10"].cpu().numpy().view(">f4"), diag["u10"])
     mesh.destroy()
     grid.destroy()
 

@@ -1,4 +1,4 @@
-"""LDS-staged level-fast Regrid (k_apply_lfu.hip): every variant must reproduce the cell-fast kernel bit for bit
+"""LDS-staged Regrid kernels (k_apply_lfu.hip): every variant must reproduce the cell-fast kernel bit for bit
 (same wsum3 arithmetic, only the data path differs) on meshes with unmapped rims, global meshes with Morton or
 bisection numbering, randomly renumbered cells, ragged tile edges and several fields."""
 import numpy as np
@@ -6,7 +6,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-LFU = list(range(100, 120)) + [200, 300, 301, 302, 4, 500]   # 100-105 two-phase, 106-111 pipelined, 112-119 compact tiles, 200 / 300-302 rows-resident, 4 / 500 row gather on row tiles / on linear aligned tiles
+LFU = [0, 1, 2, 3]               # "lf_variant": row gather on linear tiles, staged in level chunks, row gather on grid-row tiles, staged with rows resident
+A3 = [-2, 0, 1, 2]               # "a3_staged": lane gather, staged on 64x8 / 64x16 (256 threads) / 64x16 (512 threads) tiles
 A3_STAGED_DEFAULT = -1           # library default of the "a3_staged" knob (per-handle choice)
 
 
@@ -28,9 +29,8 @@ def _check(R, gpu_lib, m, g, nlev, nfields=2, seed=0):
         rh.rebase(0, m.nCells)                               # re-indexing drops the tile lists; they are rebuilt on demand
         got = rh.regrid(src_lf.reshape(-1), nlev=nlev, nfields=nfields, layout=R.LAYOUT_LEV_FAST)
         assert np.array_equal(got, want)
-        # cell-fast staged variants (a3_staged 0..18; 14-15: 64 x 32 tiles, 16-17: 64 x 16 tiles on 512 threads, 18: 64 x 32 on 1024) and the per-handle choice (-1) against
-        # the lane-gather kernel (-2)
-        for v in list(range(19)) + [-1]:
+        # cell-fast staged variants and the per-handle choice (-1) against the lane-gather kernel (-2)
+        for v in A3 + [-1]:
             gpu_lib.tune("a3_staged", v)
             got = rh.regrid(src.reshape(-1), nlev=nlev, nfields=nfields)
             assert np.array_equal(got, want), "a3_staged %d differs" % v
@@ -92,7 +92,7 @@ def test_typed_staged_paths_agree(gpu_lib):
             src = s64.to(sdt)
             src_lf = src.permute(0, 2, 1).contiguous()
             outs = []
-            for staged, lfv in ((1, -1), (-2, 4), (1, 200), (1, 300), (1, 301), (1, 302)):
+            for staged, lfv in ((1, -1), (-2, 2), (0, 0), (2, 1), (-1, 3)):
                 gpu_lib.tune("a3_staged", staged)
                 gpu_lib.tune("lf_variant", lfv)
                 outs.append(rh.regrid_typed(src.reshape(-1), nlev=nlev, nfields=nf, out_dtype=ddt, scale=9.81, offset=-300.0))

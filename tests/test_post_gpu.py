@@ -21,6 +21,11 @@ def test_cast_layer_mean_ptop_bit_exact(oracle, gpu_lib):
         odd = xt.reshape(-1)[1:]                                      # 8-byte aligned only: scalar path
         assert np.array_equal(post.cast_f32(odd).cpu().numpy(), oracle.post_cast(x.reshape(-1)[1:]))
         assert post.cast_f32(xt).dtype == torch.float32 and post.cast_f32(xt).is_cuda
+        # big-endian results (the bytes nf90_put_var stores in a classic file): the oracle's values, byte-reversed
+        for got, want in ((post.cast_f32(xt, scale=9.81, offset=-300.0, be=True), oracle.post_cast(x, scale=9.81, offset=-300.0)),
+                          (post.cast_f32(odd, be=True), oracle.post_cast(x.reshape(-1)[1:])),
+                          (post.layer_mean_f32(xt, be=True), oracle.post_layer_mean(x))):
+            assert got.mpg_be and got.cpu().numpy().tobytes() == want.astype(">f4").tobytes()
     p = np.abs(rng.normal(5.0e4, 2.0e4, (55, 30, 40)))
     p[-1] = rng.uniform(0.0, 6000.0, (30, 40))
     p[-1, :3] = 0.0                                                   # unmapped columns (regrid leaves 0.0) are skipped

@@ -1,6 +1,6 @@
 """Direct oracle parity of the fused ingest/egress Regrid (mpg_regrid_typed_dev) and of the staged kernels: every
 combination of source layout (cell-fast / MPAS file order), element types (float32 / float64 on either side) and kernel
-family (library default, forced lane-/row-gather incl. k_apply3_lf_f32x2, forced LDS-staged) against the ORACLE's
+family (library default, forced lane-/row-gather, forced LDS-staged) against the ORACLE's
 chain -- widen at read (input_data.F90:630-655), float64 weights from the oracle's own search, float64 apply,
 post-op, narrow at write (write_data.F90:779,1343,1418) -- not against another GPU kernel."""
 import numpy as np
@@ -11,15 +11,23 @@ from conftest import mesh_xyz
 
 pytestmark = pytest.mark.gpu
 
-NLEV = 55                      # the level count of the BASELINE configs (odd: the f32x2 kernel's last lane shifts)
+NLEV = 55                      # the level count of the BASELINE configs (odd: the row kernels' last lane shifts)
 KERNELS = [                    # (a3_staged, lf_variant): which kernel family serves the 3-point handle
     (-1, -1),                  # library default (per-handle choice)
-    (-2, 4),                   # lane-gather (cell-fast) / row-gather (level-fast; float32 rows -> k_apply3_lf_f32x2)
-    (1, 100),                  # LDS-staged cell-fast / LDS-staged level-fast, forced
-    (13, 106),                 # the tile shapes bench.py's default run ends up with on C4 / the pipelined staged variant
-    (-1, 300), (-1, 301), (-1, 302),   # rows-resident level-fast kernel k_apply3_lfs, tiles 64x1 / 64x2 / 64x4
-    (-2, 401), (-2, 410), (-2, 413), (-2, 417),   # float32 row gather: 64x1 tiles at 8 waves / SIMD; linear tiles, 1 / all fields per WG, unroll 4
+    (-2, 2),                   # lane gather (cell-fast) / row gather on grid-row tiles (level-fast)
+    (0, 0),                    # LDS-staged 64x8 tiles / row gather on linear aligned tiles
+    (1, 1),                    # LDS-staged 64x16 tiles on 256 threads / LDS-staged in 16-level chunks
+    (2, 3),                    # LDS-staged 64x16 tiles on 512 threads / LDS-staged with rows resident
 ]
+
+
+def _same_as_oracle_f32(got32, ref32, what):
+    """equal to the oracle's narrowing except where the two float64 values (<= 1e-12 apart) straddle a float32 rounding
+    boundary -> at most one float32 ulp, on a vanishing fraction of the points"""
+    ne = got32 != ref32
+    assert ne.mean() < 1e-5, (what, ne.mean())
+    if ne.any():
+        assert (np.abs(got32[ne].astype(np.float64) - ref32[ne]) <= np.spacing(np.abs(ref32[ne])).astype(np.float64)).all(), what
 
 
 def _cases():
@@ -69,10 +77,20 @@ def test_typed_and_staged_kernels_against_oracle(gpu_lib, oracle, case):
                     ref32 = (ref * scale + offset).astype(np.float32)
                     got32 = rh.regrid_typed(src_t, nlev=NLEV, nfields=nf, layout=layout, out_dtype=torch.float32, scale=scale,
                                             offset=offset).cpu().numpy().reshape(ref.shape)
-                    ne = got32 != ref32
-                    assert ne.mean() < 1e-5, (name, staged, lfv, sname, layout, ne.mean())
-                    if ne.any():
-                        assert (np.abs(got32[ne].astype(np.float64) - ref32[ne]) <= np.spacing(np.abs(ref32[ne])).astype(np.float64)).all()
+                    _same_as_oracle_f32(got32, ref32, (name, staged, lfv, sname, layout))
+                    # the same with both sides BIG-ENDIAN, as the Fortran driver's file flow runs it: the source holds the bytes
+                    # of a NetCDF classic variable (input_data.F90:630 reads them through nf90_get_var), the result the bytes
+                    # nf90_put_var would store (write_data.F90:1339-1475) -- against the oracle's chain, and bit for bit against
+                    # the host-order call
+                    src_be_t = torch.as_tensor(src.byteswap().view(src.dtype), device="cuda").view(-1)
+                    be32 = rh.regrid_typed(src_be_t, nlev=NLEV, nfields=nf, layout=layout, out_dtype=torch.float32, scale=scale, offset=offset,
+                                           src_be=True, dst_be=True).cpu().numpy().reshape(ref.shape)
+                    be32 = be32.view(">f4").astype(np.float32)
+                    _same_as_oracle_f32(be32, ref32, (name, staged, lfv, sname, layout, "be"))
+                    assert np.array_equal(be32.view(np.uint32), got32.view(np.uint32)), (name, staged, lfv, sname, layout, "be != le")
+                    # mixed: big-endian source, float64 host-order result (what the driver keeps for rotation / P_TOP / Z_C)
+                    be64 = rh.regrid_typed(src_be_t, nlev=NLEV, nfields=nf, layout=layout, out_dtype=torch.float64, src_be=True).cpu().numpy()
+                    assert np.array_equal(be64.reshape(ref.shape), got), (name, staged, lfv, sname, layout, "be -> f64")
                     checked += 1
             # the plain float64 entry point (mpg_regrid_dev) in both layouts under the same kernel choice
             for layout in (R.LAYOUT_CELL_FAST, R.LAYOUT_LEV_FAST):

@@ -2,7 +2,7 @@
 """Interleaved A/B sweep of the LEVEL-fast (MPAS file order) Regrid kernels in one process, typed entry point
 (mpg_regrid_typed_dev): float32 or float64 elements on either side, every variant checked bit for bit against the
 first one before it is timed.
-Usage (GPU box): python tools/sweep_lf.py --workload c4_3m_regional --io f32 --variants 4,-1,300,301,302,303"""
+Usage (GPU box): python tools/sweep_lf.py --workload c4_3m_regional --io f32 --variants -1,0,1,2,3 [--be]"""
 import argparse
 import json
 import os
@@ -19,9 +19,10 @@ def main():
     ap.add_argument("--fields", type=int, default=4)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--io", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--variants", default="4,-1,200,300,301,302,303")
+    ap.add_argument("--variants", default="-1,0,1,2,3")
+    ap.add_argument("--be", action="store_true", help="both sides big-endian (MPG_TYPE_BE): the Fortran driver's file flow")
     ap.add_argument("--layout", default="lev_fast", choices=["lev_fast", "cell_fast"])
-    ap.add_argument("--plain", action="store_true", help="float64 through mpg_regrid_dev (the headline entry point; honours a3_staged / lf_variant 100..)")
+    ap.add_argument("--plain", action="store_true", help="float64 through mpg_regrid_dev (the headline entry point)")
     ap.add_argument("--nlev", type=int, default=0, help="override the workload's level count (alignment experiments)")
     ap.add_argument("--knob", default="", help="knob to sweep instead of lf_variant (e.g. a3_staged with --layout cell_fast)")
     ap.add_argument("--set", default="", help="knobs held fixed during the sweep: key=value[,key=value]")
@@ -50,7 +51,7 @@ def main():
         if args.plain:
             rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
         else:
-            rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out, scale=9.81, offset=-300.0)
+            rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out, scale=9.81, offset=-300.0, src_be=args.be, dst_be=args.be)
     for kv in filter(None, args.set.split(",")):
         _lib.tune(kv.split("=")[0], int(kv.split("=")[1]))
     times = {v: [] for v in variants}
@@ -73,7 +74,7 @@ def main():
             torch.cuda.synchronize()
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1) / 3)
-    _lib.tune(knob, 0 if knob == "tile_band" else -1)
+    _lib.tune(knob, 1 if knob == "nn_variant" else -1)
     res = []
     for v, ts in times.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
