@@ -37,11 +37,12 @@ def parse():
     ap.add_argument("--fields", type=int, default=13, help="3-D fields per Regrid bundle (histlist_3d has 13 nz fields)")
     ap.add_argument("--layout", default="cell_fast", choices=["cell_fast", "lev_fast"])
     ap.add_argument("--io", default="f64", choices=["f64", "f32"], help="field element type in HBM; f64 = reference-faithful headline")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline and the extra legs (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip production_path / store / job / cell_numbering / end_to_end_pcie")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--calib", action="store_true", help="also launch a known-byte-count streaming kernel (PMC calibration)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
-                    help="kernel knob for experiments (mpg_tune), e.g. a3_variant=12; the default run sets none")
+                    help="kernel knob for experiments (mpg_tune), e.g. a3_staged=0; the default run sets none")
     return ap.parse_args()
 
 
@@ -268,10 +269,9 @@ def main():
     esz = 4.0 if io32 else 8.0  # element size of the field values in HBM (float64 = reference-faithful headline)
     alg_bytes = F * nlev * esz * (U + P_local) + P_local * 36.0  # U*L*e + P*L*e per field + P*36 once per launch
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s_f%d_%s%s.json" % (args.workload, F, args.layout, "_io32" if io32 else ""))
-    if world == 1 and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    traffic, traffic_source = (None, None)
+    if world == 1:
+        traffic, traffic_source = recorded_traffic(args.workload, F, args.layout, io32)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not io32:
@@ -280,7 +280,8 @@ def main():
     # "report two timings" -- kernel-only above, and end to end through the PCIe link (one 3-D field from
     # pageable host memory to pageable host memory: upload, Regrid, download; never `value`)
     e2e = None
-    if rank == 0 and world == 1 and layout == R.LAYOUT_CELL_FAST and not io32 and not args.no_cpu_baseline:
+    extras = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.no_extras
+    if extras and layout == R.LAYOUT_CELL_FAST and not io32:
         e2e = {}
         for name, dt_np in (("f64", np.float64), ("f32", np.float32)):
             hs = np.random.default_rng(1).standard_normal((nlev, sr.sched.n_local)).astype(dt_np)
@@ -300,8 +301,17 @@ def main():
     # renumbered along a Morton curve (workload c4_3m_morton), what a production mesh reordered by a space-filling curve
     # or a graph partitioner looks like.  Extra object, never `value`.
     numbering = None
-    if rank == 0 and world == 1 and args.workload == "c4_3m_regional" and not io32 and not args.no_cpu_baseline:
+    if extras and args.workload == "c4_3m_regional" and not io32:
         numbering = realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, sr.rh)
+    # what the shipped Fortran driver runs: float32 as the MPAS / WRF files hold it, MPAS file order, either byte order
+    production = store = job = None
+    if extras and not io32 and layout == R.LAYOUT_CELL_FAST:
+        production = production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint=sr.n_needed)
+        del out
+        store = store_leg(R, sr, m, g)
+        del local, src_for_kernel, own
+        torch.cuda.empty_cache()
+        job = job_leg(torch, R, workloads, args, dev)
 
     if rank == 0:
         fields_per_s = F * args.steps / dt
@@ -316,11 +326,14 @@ def main():
                        "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
                        "unmapped_points_rank0": n_unmapped},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": kernel_label(sr.rh, layout, R),
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
                          "device_copy_GBs": copy_gbs},
             "cpu_baseline": cpu,
             "end_to_end_pcie": e2e,
+            "production_path": production,
+            "store": store,
+            "job": job,
             "cell_numbering": numbering,
             "halo": halo,
             "store_ms": sr.store_ms,
@@ -372,8 +385,142 @@ def kernel_label(rh, layout, R):
     """Name of the Regrid kernel the library picked for this handle (mpg_handle_kernel_choice)."""
     cf, lf, mu = rh.kernel_choice()
     if layout == R.LAYOUT_CELL_FAST:
-        return "k_apply3_cfu_p (staged variant %d, <= %d cells per tile)" % (cf - 1, mu) if cf > 0 else "k_apply3_cf (lane-gather)"
-    return "k_apply3_lfu_p (staged, <= %d cells per tile)" % mu if lf > 0 else "k_apply3_lf (row-gather)"
+        return "k_apply3_cfu (staged, a3_staged %d, <= %d cells per tile)" % (cf - 1, mu) if cf > 0 else "k_apply3_cf (lane gather)"
+    return "k_apply3_lfu / k_apply3_lfw (staged, <= %d cells per tile)" % mu if lf > 0 else "k_apply3_lf_rows (row gather, linear tiles)"
+
+
+def recorded_traffic(workload, F, layout, io32):
+    """HBM bytes per launch from the PMC passes of the same command (tools/profile_bench.sh -> tools/summarize_profile.py ->
+    profiles/traffic_*.json).  NOT measured in this run: the file is regenerated whenever the default kernel changes, and
+    `traffic_source` names the summary it came from."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_f%d_%s%s.json" % (workload, F, layout, "_io32" if io32 else ""))
+    if not os.path.exists(tpath):
+        return None, None
+    d = json.load(open(tpath))
+    return d.get("hbm_bytes_per_launch"), "recorded, not live: %s" % d.get("source", os.path.relpath(tpath, ROOT))
+
+
+def _time_launches(torch, fn, steps):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint):
+    """`--io f32 --layout lev_fast` on the same workload: float32 sources in MPAS file order [field][cell][level]
+    (input_data.F90:630,645), float32 results (NF90_FLOAT, write_data.F90:779), float64 arithmetic -- the Regrid the Fortran
+    driver issues -- in host byte order and with both sides big-endian (what the driver's NetCDF-classic file flow passes)."""
+    rh = sr.rh
+    P = rh.n_dst
+    src = local.view(F, nlev, -1).permute(0, 2, 1).float().contiguous()
+    out = torch.empty((F, nlev, rh.ny_dst, rh.nx_dst), dtype=torch.float32, device=dev)
+    steps = max(3, min(args.steps, 10))
+    alg = F * nlev * 4.0 * (U_hint + P) + P * 36.0
+    res = {"flags": "--io f32 --layout lev_fast", "fields_per_step": F, "steps": steps, "alg_bytes_per_launch": alg}
+    ms = _time_launches(torch, lambda: rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=R.LAYOUT_LEV_FAST, out=out), steps)
+    res.update(kernel_ms=ms, fields_per_s=F / ms * 1e3, roofline_frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, kernel=kernel_label(rh, R.LAYOUT_LEV_FAST, R))
+    ms_be = _time_launches(torch, lambda: rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=R.LAYOUT_LEV_FAST, out=out, src_be=True,
+                                                          dst_be=True), steps)
+    res.update(kernel_ms_big_endian=ms_be, fields_per_s_big_endian=F / ms_be * 1e3, roofline_frac_big_endian=alg / (ms_be * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    res["traffic"], res["traffic_source"] = recorded_traffic(args.workload, F, "lev_fast", True)
+    return res
+
+
+def store_leg(R, sr, m, g):
+    """RegridStore of the three methods on the headline mesh and grid (weights are data: built once per run, cached), as
+    points/s with the algorithmic bytes of SURVEY s8(d): P*16 (target coordinates) + T*(3*4 + 48) (elements: ids + box) +
+    the weights written."""
+    P = int(g.nx * g.ny)
+    res = {}
+    mesh, grid = sr.mesh, sr.grid
+    nT, nC, nE = int(m.nVertices), int(m.nCells), int(m.verticesOnCell.shape[1])
+    for name, code in (("bilinear", R.REGRIDMETHOD_BILINEAR), ("nearest", R.REGRIDMETHOD_NEAREST_STOD), ("conserve", R.REGRIDMETHOD_CONSERVE)):
+        if name == "bilinear":
+            rh, ms = sr.rh, sr.store_ms
+        else:
+            rh = R.regrid_store(mesh, grid, code)
+            ms = rh.store_ms
+        if name == "bilinear":
+            alg = P * 16.0 + nT * (12.0 + 48.0) + P * 36.0
+        elif name == "nearest":
+            alg = P * 16.0 + nC * (24.0 + 4.0) + P * 4.0
+        else:
+            alg = (P + g.nx + g.ny + 1) * 16.0 + nC * (nE * 4.0 + 48.0) + nT * 16.0 + rh.nnz * 12.0 + (P + 1) * 4.0
+        res[name] = {"ms": ms, "points_per_s": P / (ms * 1e-3), "alg_bytes": alg, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "nnz": int(rh.nnz)}
+        if name != "bilinear":
+            rh.release()
+    res["what"] = ("mpg_handle_store_ms of a cold Store (search structure + search + weights), %d target points; not memory-bound: what binds "
+                   "each kernel is in profiles/r03_store_pmc.md" % P)
+    return res
+
+
+def job_leg(torch, R, workloads, args, dev):
+    """The whole hot path of one run, through the C-ABI: interp_data (interp.F90:92-465) over the reference's default
+    diag + hist lists with wrf_mod_vars=.true. -- every RegridStore, every Regrid, the wind rotation and the destaggering --
+    on device-resident float32 fields in MPAS file order, target grid generated on the device.  cold = fresh mesh / grid
+    objects (every Store and every tile-list build inside the timed region); warm = the weights of the same objects kept
+    (a second time level)."""
+    from mpassit_amd import interp as I
+    if args.workload != "c4_3m_regional":
+        return None
+    m, g, nz, desc = workloads.workload(args.workload, arrays=False)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20240807)
+
+    def f2():
+        return torch.rand(m.nCells, dtype=torch.float32, device=dev, generator=gen)
+
+    def f3(L):
+        return torch.rand((m.nCells, L), dtype=torch.float32, device=dev, generator=gen)
+    nsoil = 4
+    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil, hgt=torch.rand(m.nCells, dtype=torch.float64, device=dev, generator=gen), layout=R.LAYOUT_LEV_FAST)
+    for n, _ in workloads.JOB_HIST_2D:
+        inp.hist[n] = torch.floor(f2() * 3) if n == "xland" else f2()
+    for n, _ in workloads.JOB_HIST_3D:
+        inp.hist[n] = f3(nz + 1 if n in ("zgrid", "w") else nz)
+    for n, _ in workloads.JOB_SOIL:
+        inp.hist[n] = f3(nsoil)
+    for n, _ in workloads.JOB_DIAG:
+        inp.diag[n] = f3(nz) if n == "refl10cm" else f2()
+    cfg = I.InterpConfig(interp_diag=True, wrf_mod_vars=True, diag_list=workloads.JOB_DIAG, hist_2d=workloads.JOB_HIST_2D,
+                         hist_3d=workloads.JOB_HIST_3D, hist_soil=workloads.JOB_SOIL)
+    cold, warm, geom = [], [], []
+    n3d = nout = 0
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mesh = R.Mesh.from_mpas(m)
+        grid = R.Grid.from_proj(g)
+        torch.cuda.synchronize()
+        geom.append((time.perf_counter() - t0) * 1e3)
+        for k in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            out = I.interp_data(mesh, grid, g, inp, cfg)
+            e1.record()
+            torch.cuda.synchronize()
+            (cold if k == 0 else warm).append(((time.perf_counter() - t0) * 1e3, e0.elapsed_time(e1)))
+            n3d, nout = sum(1 for v in out.values() if v.ndim == 3 and v.shape[0] >= nz), len(out)
+            del out
+        mesh.destroy()
+        grid.destroy()
+    return {"workload": "%s: %s" % (args.workload, desc), "outputs": nout, "fields_3d": n3d,
+            "cold_ms": min(c[0] for c in cold), "warm_ms": min(w[0] for w in warm), "geometry_ingest_ms": min(geom),
+            "cold_ms_all": [round(c[0], 2) for c in cold], "warm_ms_all": [round(w[0], 2) for w in warm],
+            "fields_3d_per_s_cold": n3d / (min(c[0] for c in cold) * 1e-3), "fields_3d_per_s_warm": n3d / (min(w[0] for w in warm) * 1e-3),
+            "what": "interp_data over the reference's default lists (wrf_mod_vars=.true.: rotation, U/V destaggering), float32 file-order "
+                    "sources resident in HBM, float64 results; host wall ms between two device synchronisations; cold = every "
+                    "RegridStore (bilinear element + nearest + conservative + 2 grid-to-grid) inside; geometry_ingest = "
+                    "mpg_mesh_create (upload + dual triangles) + mpg_grid_create_proj, not part of cold_ms"}
 
 
 def cpu_baseline(sr, local_rows, nlev, seconds, m, g):

@@ -117,7 +117,10 @@ int mpg_grid_rotang_dev(mpg_grid grid, const double **cosa_dev, const double **s
 /* ---- ESMF_Field[Bundle]RegridStore (interp.F90:123,207,226,241,259,277,334,353,372,394,421,437) ---
  * srcTermProcessing=1, unmappedaction=IGNORE are implied.  Mesh -> Grid.  Handles are cached: the same
  * (mesh, src_loc, grid, dst_stagger, method) returns the same handle (reference recomputes it up to
- * 13x per run); each Store must be paired with one mpg_handle_release. */
+ * 13x per run); each Store must be paired with one mpg_handle_release.  A handle whose last reference
+ * was released keeps its weights in the cache (up to 8 such handles; dropped when their mesh or grid is destroyed or
+ * at mpg_finalize), so the Store / Regrid / Release / Store-again sequence of interp_diag_data followed by
+ * interp_hist_data (interp.F90:123-148, :207) builds the element -> CENTER bilinear weights once. */
 int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod,
                      mpg_handle *out);
 /* Grid -> Grid on the same grid, CENTER -> EDGE1/EDGE2 bilinear (interp.F90:298,316). */
@@ -265,8 +268,7 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
  *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0 / 1 / 2 the LDS-staged
  *                 kernel on 64x8-point tiles / 64x16 on 256 threads / 64x16 on 512 threads
  *   "lf_variant"  level-fast (file-order) 3-point Regrid: -1 per-handle choice (default), 0 row gather on linear aligned
- *                 tiles, 1 LDS-staged in 16-level chunks, 2 row gather on grid-row tiles (the capacity fallback),
- *                 3 LDS-staged with whole rows resident
+ *                 tiles, 1 LDS-staged in 16-level chunks, 2 row gather on grid-row tiles (the capacity fallback)
  *   "nn_variant"  nearest-neighbour search: 1 wave-cooperative (default), 0 one thread per point
  *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice (default 35)
  * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */

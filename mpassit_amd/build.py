@@ -57,6 +57,34 @@ def build(force=False, verbose=False):
     return SO
 
 
+def build_alt(name, defines, sources=("k_apply_typed.hip", "k_apply_lfu.hip", "k_apply.hip")):
+    """A/B build of an experiment: the listed sources recompiled with extra -D flags, the rest of the objects taken from the
+    product build, linked into mpassit_amd/_alt/lib<name>.so (git-ignored; travels to the GPU box).  Selected at run time
+    with MPASSIT_AMD_LIB=<path> (_lib.py).  Never the shipped library."""
+    build()
+    alt = os.path.join(HERE, "_alt")
+    od = os.path.join(alt, "obj_" + name)
+    os.makedirs(od, exist_ok=True)
+    objs, jobs = [], []
+    for s in SOURCES:
+        if s in sources:
+            o = os.path.join(od, s.replace(".hip", ".o"))
+            jobs.append([HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, s), "-o", o])
+        else:
+            o = os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        objs.append(o)
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    so = os.path.join(alt, "lib%s.so" % name)
+    run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    return so
+
+
 NCIO_SRC = os.path.join(HERE, "hostio", "ncclassic.c")
 NCIO_SO = os.path.join(HERE, "hostio", "libmpassit_ncio.so")
 

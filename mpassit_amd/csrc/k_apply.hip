@@ -13,7 +13,7 @@
 //   K2' k_apply3_lf    same from level-fastest [ncell][nlev] (MPAS file order, input_data.F90:630,645):
 //                       the reference's host transpose is fused away through an LDS tile transpose; the older
 //                       row-gather form on grid-row tiles (default: k_apply3_lf_rows, k_apply_typed.hip, when
-//                       target points share few cells, else k_apply3_lfu / k_apply3_lfw)
+//                       target points share few cells, else k_apply3_lfu)
 //   K3  k_apply1       nearest-neighbour copy
 //   K4  k_apply_csr    conservative (variable row length)
 //   K6  k_applyN<4>    4-point destagger (CENTER -> EDGE1/EDGE2)
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void k_apply3_lf(const int32_t *__restrict__ i
 }
 // "lf_variant" knob: -1 per-handle choice (default) between 0 and 1; 0 row gather on linear aligned tiles
 // (k_apply3_lf_rows), 1 level-chunked LDS-staged kernel (k_apply_lfu.hip), 2 row gather on grid-row tiles (k_apply3_lf /
-// k_apply3_lf_t: the capacity fallback), 3 rows-resident staged kernel (k_apply_lfu.hip: k_apply3_lfw)
+// k_apply3_lf_t: the capacity fallback)
 static int g_lf_variant = -1;
 
 // nearest neighbour: bit-exact copy
@@ -263,7 +263,7 @@ int mpg_lf_variant() { return g_lf_variant; }
 
 int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "lf_variant")) {
-    if (value < -1 || value > 3) return MPG_ERR_INVALID_ARG;
+    if (value < -1 || value > 2) return MPG_ERR_INVALID_ARG;
     g_lf_variant = value;
     return MPG_SUCCESS;
   }
@@ -308,11 +308,6 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
         int rc = mpg_lfu_auto(h, s, &lfv);
         if (rc) return rc;
       }
-    }
-    if (lfv == MPG_LF_RESIDENT) {
-      int rc = mpg_k_apply3_lfw(h, src, 0, nlev, nfields, dst, 0, 1.0, 0.0, s, false);
-      if (rc != MPG_ERR_UNSUPPORTED) return rc;
-      lfv = MPG_LF_STAGED;   // not even one level of the tile's rows fits the LDS
     }
     if (lfv == MPG_LF_STAGED) {
       int rc = mpg_k_apply3_lfu(h, src, nlev, nfields, dst, s);

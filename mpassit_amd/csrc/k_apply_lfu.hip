@@ -9,9 +9,6 @@
 //                     into registers while chunk c is combined; three tile shapes (g_cfu_variants)
 //   k_apply3_lfu      level-fastest source [ncell][nlev] (MPAS file order, :630,645), 64 x 4-point tiles, 16 levels per
 //                     chunk, lanes along the levels, the same register prefetch
-//   k_apply3_lfw      level-fastest source, whole rows (or halves of them) of the tile's unique cells resident in LDS in
-//                     the SOURCE element type, 64 x 8-point tiles: every 128-byte line of a row is fetched once
-//                     instead of once per 16-level chunk (float32 rows of 55 levels are 220 bytes at 4-byte alignment)
 //
 // Why staging: with 2.5-2.9 target points per source cell (BASELINE configs 2, 3, 5) the gather kernels fetch every
 // value ~3x through L2 -> CU and end up latency / issue bound at 2.6-3.3 TB/s; staged, the same workloads run at the HBM
@@ -23,8 +20,10 @@
 // double> without the epilogue.
 // Shapes measured in rounds 1-2 and dropped from the library in round 3 (two-phase form without prefetch, 32- and
 // 16-wide tiles, 64 x 32 tiles on 512 / 1024 threads, 2 / 8 / 16 levels per chunk, several fields per workgroup, banded
-// tile order, rows-resident 32 x 4 and 64 x 1 / 2 / 4 tiles with deep prefetch): profiles/r01_sweep_cfu.txt,
-// r01_sweep_lfu.txt, r02_sweep_cfu_compact.txt, r02_sweep_cfu_fpw.txt, r02_tile_order_and_height.txt, r02_lfs_*.txt.
+// tile order, rows-resident 32 x 4 and 64 x 1 / 2 / 4 tiles with deep prefetch; round 3: rows-resident 64 x 8 tiles with a
+// per-tile level chunk, two levels per lane in k_apply3_lfu, 128-byte level chunks with the slab in the source type -- all
+// slower on configuration 5): profiles/r01_sweep_cfu.txt, r01_sweep_lfu.txt, r02_sweep_cfu_compact.txt,
+// r02_sweep_cfu_fpw.txt, r02_tile_order_and_height.txt, r02_lfs_*.txt, r03_lf_experiments.txt.
 #include <limits.h>
 #include <string.h>
 
@@ -576,127 +575,4 @@ int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, 
   int rc = lfu_build_shape(h, 64, 4, s);
   if (rc) return rc;
   return launch_lfu<double, double, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s);
-}
-
-// ---- level-fast, rows resident ---------------------------------------------------------------------------------
-// Tile = 64 x 8 target points on 256 threads (two points each).  The rows of the tile's unique cells are loaded ONCE per
-// level chunk of `lcw` levels -- lcw = nlev when the tile's rows fit the LDS budget, else the levels are cut into 2, 3, ...
-// equal chunks -- as contiguous pieces, two levels per lane (one 8- / 16-byte load; rows are element-aligned only), `lpr`
-// lanes per row, all of a tile's loads in flight before the first wait.  LDS holds them in the SOURCE element type
-// ([row][lcw | 1]: odd stride in elements, conflict-free column reads), host byte order; every thread then combines its
-// two points level by level (three LDS reads, widen, wsum3, epilogue, narrow) and stores 256- / 512-byte aligned row
-// segments.  No register prefetch: two or three workgroups per CU overlap one's loads with another's combine.
-template <typename TS> struct Pair;
-template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
-template <> struct Pair<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
-
-template <typename TS, typename TD, bool EPI, bool SWZ>
-__global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfw(const int32_t *__restrict__ ut_cnt, const int32_t *__restrict__ ut_cells, int stride,
-                                                            const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
-                                                            int nlev, int ntx, int nty, int lcw, int lpr_shift, double scale, double offset, int sbe,
-                                                            int dbe) {
-  typedef typename Pair<TS>::type pair_t;
-  constexpr int RPT = 2;
-  extern __shared__ double lds_raw[];
-  TS *rows = (TS *)lds_raw;                       // [nU][ls]
-  const int ls = lcw | 1;
-  const Swz zs = make_swz(sbe), zd = make_swz(dbe);
-  const int64_t P = (int64_t)nx * ny;
-  const unsigned ntile = (unsigned)ntx * nty;
-  const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned tile = lin % ntile;
-  const int f = lin / ntile;
-  const int t = threadIdx.x;
-  const int nU = ut_cnt[tile];
-  const int32_t *list = ut_cells + (int64_t)tile * stride;
-  LfuPoints<RPT, LFU_THREADS> pts;
-  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, ls);
-  const TS *sf = src + (int64_t)f * nlev * nsrc;
-  TD *df = dst + (int64_t)f * nlev * P;
-  const int lpr = 1 << lpr_shift, rpp = LFU_THREADS >> lpr_shift;   // lanes per row, rows per pass of the workgroup
-  const int lrow = t >> lpr_shift, sl = t & (lpr - 1);
-  for (int k0 = 0; k0 < nlev; k0 += lcw) {
-    const int kn = min(lcw, nlev - k0);            // levels of this chunk (>= 1)
-    // lane sl holds levels k0 + 2 sl, + 1 of its row; the lane that would cross the end of the chunk loads the chunk's last
-    // two levels instead and keeps the second (kn == 1: a single element)
-    const int kk = 2 * sl;
-    const int base = kn >= 2 ? min(kk, kn - 2) : 0;
-    const bool shifted = base != kk, a0 = kk < kn, a1 = kk + 1 < kn;
-    for (int rb = lrow; rb < nU; rb += 4 * rpp) {
-      pair_t x[4];
-      TS x1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = rb + u * rpp;
-        if (row < nU && a0) {
-          const TS *rp = sf + (int64_t)list[row] * nlev + k0;
-          if (kn >= 2) x[u] = *(const pair_t *)(rp + base);
-          else x1[u] = rp[0];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = rb + u * rpp;
-        if (row < nU && a0) {
-          TS *lp = rows + row * ls;
-          if (kn >= 2) {
-            lp[kk] = swz<SWZ>(shifted ? x[u].y : x[u].x, zs);
-            if (a1) lp[kk + 1] = swz<SWZ>(x[u].y, zs);
-          } else {
-            lp[0] = swz<SWZ>(x1[u], zs);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    for (int q = 0; q < kn; ++q) {
-#pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const double a = (double)rows[pts.l[r][0] + q], b = (double)rows[pts.l[r][1] + q], e = (double)rows[pts.l[r][2] + q];
-        double val = pts.mapped[r] ? wsum3(pts.ww[r][0], a, pts.ww[r][1], b, pts.ww[r][2], e) : 0.0;
-        if constexpr (EPI) val = fma(val, scale, offset);
-        if (pts.act[r]) __builtin_nontemporal_store(swz<SWZ>((TD)val, zd), df + (int64_t)(k0 + q) * P + pts.off[r]);
-      }
-    }
-    __syncthreads();
-  }
-}
-
-#define LFW_LDS_BUDGET (52 * 1024)   // three workgroups per CU
-
-template <typename TS, typename TD, bool EPI>
-static int launch_lfw(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
-                      hipStream_t s) {
-  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + 7) / 8;
-  const size_t um = h->ut_max > 0 ? h->ut_max : 1;
-  int nchunk = 1, lcw = nlev;
-  while (nchunk < nlev && sizeof(TS) * um * (size_t)(lcw | 1) > LFW_LDS_BUDGET) {
-    ++nchunk;
-    lcw = (nlev + nchunk - 1) / nchunk;
-  }
-  const size_t lds = sizeof(TS) * um * (size_t)(lcw | 1) + 16;
-  if (lds > 160 * 1024 || lcw > 64) return MPG_ERR_UNSUPPORTED;
-  int lpr_shift = 0;
-  while ((2 << lpr_shift) < lcw) ++lpr_shift;    // lanes per row: the power of two >= lcw / 2
-  auto fn = (sbe || dbe) ? k_apply3_lfw<TS, TD, EPI, true> : k_apply3_lfw<TS, TD, EPI, false>;
-  if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fn<<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_cnt.p, h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
-                                                            h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, lcw, lpr_shift, scale, offset,
-                                                            sbe, dbe);
-  MPG_HIP(hipGetLastError());
-  return MPG_SUCCESS;
-}
-
-// src_type / dst_type: MPG_TYPE_* of include/mpassit_amd.h; epi = false: float64 both sides, no epilogue (mpg_regrid_dev)
-int mpg_k_apply3_lfw(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale, double offset,
-                     hipStream_t s, bool epi) {
-  int rc = lfu_build_shape(h, 64, 8, s);
-  if (rc) return rc;
-  const int sbe = (src_type & MPG_TYPE_BE) != 0, dbe = (dst_type & MPG_TYPE_BE) != 0, sf32 = src_type & MPG_TYPE_F32, df32 = dst_type & MPG_TYPE_F32;
-  if (!epi) return launch_lfw<double, double, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s);
-  if (sf32 && df32) return launch_lfw<float, float, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (sf32) return launch_lfw<float, double, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (df32) return launch_lfw<double, float, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  return launch_lfw<double, double, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
 }

@@ -365,11 +365,6 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout
       lfv = MPG_LF_ROWS;
       if (long_bundle && (rc = mpg_lfu_auto(h, s, &lfv))) return rc;
     }
-    if (lfv == MPG_LF_RESIDENT) {
-      rc = mpg_k_apply3_lfw(h, src, src_type, nlev, nfields, dst, dst_type, scale, offset, s);
-      if (rc != MPG_ERR_UNSUPPORTED) return rc;
-      lfv = MPG_LF_STAGED;
-    }
     if (lfv == MPG_LF_STAGED) {
       rc = mpg_k_apply3_lfu_typed(h, src, src_type, nlev, nfields, dst, dst_type, scale, offset, s);
       if (rc != MPG_ERR_UNSUPPORTED) return rc;

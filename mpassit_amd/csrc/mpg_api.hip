@@ -12,6 +12,12 @@ static bool g_init = false;
 static int g_device = -1;
 static hipStream_t g_stream = nullptr;
 static std::map<HandleKey, mpg_handle_s *> g_cache;
+// Released handles stay in the cache ("parked", refcount 0) until their mesh or grid is destroyed, the library is finalized
+// or more than MPG_MAX_PARKED of them wait: the reference stores the SAME element -> CENTER bilinear weights in
+// interp_diag_data and again in interp_hist_data with a release in between (interp.F90:123,148 and :207), and a second
+// mpg_regrid_store of a released 5-tuple was a second run of the rasteriser (r02j: 2 x k_tri_raster in one job).
+#define MPG_MAX_PARKED 8
+static uint64_t g_park_clock = 0;
 
 void mpg_set_error(const char *fmt, ...) {
   va_list ap;
@@ -49,8 +55,22 @@ int mpg_init(int device) {
   return MPG_SUCCESS;
 }
 
+static void handle_free(mpg_handle_s *h);
+static void drop_parked(void *obj) {   // obj == nullptr: all of them
+  for (auto it = g_cache.begin(); it != g_cache.end();) {
+    mpg_handle_s *h = it->second;
+    if (h->refcount == 0 && (!obj || std::get<0>(it->first) == obj || std::get<2>(it->first) == obj)) {
+      it = g_cache.erase(it);
+      handle_free(h);
+    } else {
+      ++it;
+    }
+  }
+}
+
 int mpg_finalize(void) {
   if (!g_init) return MPG_SUCCESS;
+  drop_parked(nullptr);
   mpg_fileio_release();
   mpg_hostpipe_release();
   (void)hipStreamSynchronize(g_stream);
@@ -108,6 +128,7 @@ int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const doubl
 
 // handles outlive neither their mesh nor their grid in the cache: a recycled address must never hit
 static void cache_purge(void *obj) {
+  drop_parked(obj);
   for (auto it = g_cache.begin(); it != g_cache.end();) {
     if (std::get<0>(it->first) == obj || std::get<2>(it->first) == obj) {
       it->second->cached = false;
@@ -288,7 +309,7 @@ static void handle_free(mpg_handle_s *h) {
 
 static int store_common(HandleKey key, mpg_handle *out, int (*build)(mpg_handle_s *, void *), void *ctx) {
   auto it = g_cache.find(key);
-  if (it != g_cache.end()) {
+  if (it != g_cache.end()) {   // in use elsewhere, or parked by an earlier release: the same weights, no device work
     it->second->refcount++;
     *out = it->second;
     return MPG_SUCCESS;
@@ -368,8 +389,22 @@ int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc,
 int mpg_handle_release(mpg_handle h) {
   if (!h) return MPG_SUCCESS;
   if (--h->refcount > 0) return MPG_SUCCESS;
-  if (h->cached) g_cache.erase(h->key);
-  handle_free(h);
+  if (!h->cached) {
+    handle_free(h);
+    return MPG_SUCCESS;
+  }
+  h->parked_at = ++g_park_clock;   // stays in the cache with refcount 0
+  int nparked = 0;
+  for (auto &kv : g_cache) nparked += kv.second->refcount == 0;
+  while (nparked > MPG_MAX_PARKED) {   // drop the one released longest ago
+    auto old = g_cache.end();
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+      if (it->second->refcount == 0 && (old == g_cache.end() || it->second->parked_at < old->second->parked_at)) old = it;
+    mpg_handle_s *victim = old->second;
+    g_cache.erase(old);
+    handle_free(victim);
+    --nparked;
+  }
   return MPG_SUCCESS;
 }
 

@@ -210,6 +210,7 @@ struct mpg_handle_s {
   int64_t nnz = 0;
   int refcount = 1;
   bool cached = false;
+  uint64_t parked_at = 0;   // release order of a handle waiting in the cache with refcount 0 (mpg_api.hip)
   HandleKey key;
   float store_ms = 0.f;
   bool localized = false;
@@ -266,7 +267,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
 int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,
                       double scale, double offset, hipStream_t s);
 // "lf_variant" numbering of the level-fast 3-point Regrid
-enum { MPG_LF_ROWS = 0, MPG_LF_STAGED = 1, MPG_LF_ROWTILES = 2, MPG_LF_RESIDENT = 3 };
+enum { MPG_LF_ROWS = 0, MPG_LF_STAGED = 1, MPG_LF_ROWTILES = 2 };
 #ifndef MPG_LF_STAGED_DEFAULT
 #define MPG_LF_STAGED_DEFAULT MPG_LF_STAGED   // what the per-handle choice takes when staging pays
 #endif
@@ -280,8 +281,6 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32,
 int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
                            double offset, hipStream_t s);
-int mpg_k_apply3_lfw(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale, double offset,
-                     hipStream_t s, bool epi = true);
 int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_a3_staged();  // current "a3_staged" knob
 int mpg_lf_variant(); // current "lf_variant" knob

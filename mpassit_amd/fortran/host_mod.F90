@@ -65,6 +65,9 @@ contains
     end if
     call get_environment_variable("MPASSIT_RUN_ID", buf)
     if (len_trim(buf) > 0) run_id = buf
+    ! the images find each other through marker files named after the run id: a constant default would let the markers of
+    ! a killed earlier run release this one's images early (tools/mpassit_ranks.py draws a fresh id per launch)
+    if (nranks > 1 .and. len_trim(buf) == 0) call fatal("MPASSIT_NRANKS > 1 needs MPASSIT_RUN_ID, unique per launch", nranks)
   end subroutine setup_ranks
 
   !> row blocks once the target grid's size is known

@@ -381,6 +381,21 @@ contains
     end do
   end subroutine wait_for
 
+  !> the ready marker holds the image count and the size of the file image 0 closed: a marker that does not describe THIS
+  !! run's file (left by another run, or a file truncated since) stops the image instead of letting it write into it
+  subroutine check_ready_marker()
+    real(dp) :: vals(2)
+    integer :: u, ios
+    integer(int64) :: fsize
+    open (newunit=u, file=trim(marker_name("ready", -1)), form='formatted', status='old', action='read', iostat=ios)
+    if (ios /= 0) call fatal("cannot read "//trim(marker_name("ready", -1)), ios)
+    read (u, *, iostat=ios) vals
+    close (u)
+    inquire (file=trim(out_path), size=fsize)
+    if (ios /= 0 .or. nint(vals(1)) /= nranks .or. int(vals(2), int64) /= fsize) &
+      call fatal("the ready marker does not match this run's output file (stale marker?) - "//trim(out_path), myrank)
+  end subroutine check_ready_marker
+
   subroutine write_marker(file, vals)
     character(len=*), intent(in) :: file
     real(dp), intent(in) :: vals(:)
@@ -494,6 +509,7 @@ contains
     character(len=19) :: tstr
     integer(c_int8_t) :: tbytes(19)
     logical :: have_ptop
+    integer(int64) :: closed_size
     ! nz / nzp1 / nsoil from what was read
     if (do_u_interp == 1) nz_input = u_field%nlev
     if (nz_input == 0 .and. hist_3d_nz%n > 0) nz_input = hist_3d_nz%f(1)%nlev
@@ -507,6 +523,7 @@ contains
     if (myrank > 0) then
       ! image 0 has created the file, written header, grid and time variables and its own rows, and closed it
       call wait_for(marker_name("ready", -1))
+      call check_ready_marker()
       call ncio_check(ncio_open(trim(file), nf_out), "opening "//trim(file))
     else
       call remove_file(marker_name("ready", -1))
@@ -679,7 +696,10 @@ contains
     if (id_extra(5) >= 0) call put_zero(id_extra(5))
     call ncio_check(ncio_close(nf_out), "CLOSING FILE")
     if (nranks > 1) then
-      if (myrank == 0) call write_marker(marker_name("ready", -1), [real(nranks, dp)])
+      if (myrank == 0) then
+        inquire (file=trim(out_path), size=closed_size)
+        call write_marker(marker_name("ready", -1), [real(nranks, dp), real(closed_size, dp)])
+      end if
       call finish_ranks(id_ptop, have_ptop)
     end if
     print '(a,f9.3,a)', "   [WRITE DATA: of which inside ncio_put_var] ", put_seconds, " s"

@@ -9,6 +9,20 @@ HISTLIST_3D_NZ = ["theta", "uReconstructZonal", "uReconstructMeridional", "qv", 
                   "pressure", "rho"]
 
 
+# The reference's default variable lists (parm/histlist_2d, histlist_3d, histlist_soil, diaglist: MPAS name -> output name)
+# as a whole-job workload: tools/run_config.py and bench.py's `job` object run interp_data over them
+JOB_HIST_2D = [("xland", "XLAND"), ("skintemp", "TSK"), ("snow", "SNOW"), ("snowh", "SNOWH"), ("sst", "SST")]
+JOB_HIST_3D = [("zgrid", "PHB"), ("w", "W"), ("theta", "T"), ("uReconstructZonal", "U"), ("uReconstructMeridional", "V"), ("qv", "QVAPOR"),
+               ("qc", "QCLOUD"), ("qr", "QRAIN"), ("qi", "QICE"), ("qs", "QSNOW"), ("qg", "QGRAUP"), ("ni", "QNICE"), ("nr", "QNRAIN"),
+               ("pressure", "P_HYD"), ("rho", "MUB")]
+JOB_SOIL = [("tslb", "TSLB"), ("smois", "SMOIS"), ("sh2o", "SH2O")]
+JOB_DIAG = [("rainc", "RAINC"), ("rainnc", "RAINNC"), ("snowncv", "SNOWNCV"), ("rainncv", "RAINNCV"), ("graupelncv", "GRAUPELNCV"),
+            ("prec_acc_c", "PREC_ACC_C"), ("prec_acc_nc", "PREC_ACC_NC"), ("snow_acc_nc", "SNOW_ACC_NC"), ("refl10cm", "REFL_10CM"),
+            ("refl10cm_max", "COMPOSITE_REFL_10CM"), ("refl10cm_1km", "REFL_10CM_1KM"), ("refl10cm_1km_max", "REFL_10CM_1KM_MAX"),
+            ("u10", "U10"), ("v10", "V10"), ("q2", "Q2"), ("t2m", "T2"), ("th2m", "TH2"), ("updraft_helicity_max", "UP_HELI_MAX"),
+            ("w_velocity_max", "W_UP_MAX"), ("surface_pressure", "PSFC")]
+
+
 def conus_lambert_grid(nx=1801, ny=1061, **over):
     """README.md:53-73 namelist: 1801x1061 (staggered) 3-km Lambert grid -> 1800x1060 mass points."""
     p = dict(README_LAMBERT)

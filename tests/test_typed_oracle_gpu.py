@@ -17,7 +17,7 @@ KERNELS = [                    # (a3_staged, lf_variant): which kernel family se
     (-2, 2),                   # lane gather (cell-fast) / row gather on grid-row tiles (level-fast)
     (0, 0),                    # LDS-staged 64x8 tiles / row gather on linear aligned tiles
     (1, 1),                    # LDS-staged 64x16 tiles on 256 threads / LDS-staged in 16-level chunks
-    (2, 3),                    # LDS-staged 64x16 tiles on 512 threads / LDS-staged with rows resident
+    (2, 1),                    # LDS-staged 64x16 tiles on 512 threads
 ]
 
 

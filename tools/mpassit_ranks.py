@@ -9,8 +9,10 @@ import argparse
 import os
 import subprocess
 import sys
+import glob
 import tempfile
 import time
+import uuid
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -19,7 +21,9 @@ def launch(namelist, ranks, gpus=1, exe=None, cwd=None, env=None, timeout=1800):
     """-> list of CompletedProcess-like (returncode, stdout, stderr) per image."""
     exe = exe or os.path.join(ROOT, "mpassit_amd", "fortran", "mpassit")
     base = dict(os.environ if env is None else env)
-    base.update(MPASSIT_NRANKS=str(ranks), MPASSIT_RUN_ID=str(os.getpid()))
+    # unique per LAUNCH (a PID alone repeats; a marker a killed run left behind must never satisfy a later one)
+    run_id = "%d-%s" % (os.getpid(), uuid.uuid4().hex[:16])
+    base.update(MPASSIT_NRANKS=str(ranks), MPASSIT_RUN_ID=run_id)
     procs, logs = [], []
     for r in range(ranks):
         e = dict(base, MPASSIT_RANK=str(r), MPASSIT_DEVICE=str(r % max(1, gpus)))
@@ -42,6 +46,13 @@ def launch(namelist, ranks, gpus=1, exe=None, cwd=None, env=None, timeout=1800):
                 raise subprocess.TimeoutExpired([exe, namelist], timeout)
             break
         time.sleep(0.05)
+    # whatever happened, no marker of this launch survives it (images killed above leave theirs behind)
+    # (harmless if the output lives elsewhere: the id is never used again)
+    for stale in glob.glob(os.path.join(cwd or ".", "*.%s.*" % run_id)):
+        try:
+            os.remove(stale)
+        except OSError:
+            pass
     out = []
     for p, (fo, fe) in zip(procs, logs):
         p.wait()

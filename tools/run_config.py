@@ -18,16 +18,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-HIST_2D = [("xland", "XLAND"), ("skintemp", "TSK"), ("snow", "SNOW"), ("snowh", "SNOWH"), ("sst", "SST")]
-HIST_3D = [("zgrid", "PHB"), ("w", "W"), ("theta", "T"), ("uReconstructZonal", "U"), ("uReconstructMeridional", "V"), ("qv", "QVAPOR"),
-           ("qc", "QCLOUD"), ("qr", "QRAIN"), ("qi", "QICE"), ("qs", "QSNOW"), ("qg", "QGRAUP"), ("ni", "QNICE"), ("nr", "QNRAIN"),
-           ("pressure", "P_HYD"), ("rho", "MUB")]
-SOIL = [("tslb", "TSLB"), ("smois", "SMOIS"), ("sh2o", "SH2O")]
-DIAG = [("rainc", "RAINC"), ("rainnc", "RAINNC"), ("snowncv", "SNOWNCV"), ("rainncv", "RAINNCV"), ("graupelncv", "GRAUPELNCV"),
-        ("prec_acc_c", "PREC_ACC_C"), ("prec_acc_nc", "PREC_ACC_NC"), ("snow_acc_nc", "SNOW_ACC_NC"), ("refl10cm", "REFL_10CM"),
-        ("refl10cm_max", "COMPOSITE_REFL_10CM"), ("refl10cm_1km", "REFL_10CM_1KM"), ("refl10cm_1km_max", "REFL_10CM_1KM_MAX"),
-        ("u10", "U10"), ("v10", "V10"), ("q2", "Q2"), ("t2m", "T2"), ("th2m", "TH2"), ("updraft_helicity_max", "UP_HELI_MAX"),
-        ("w_velocity_max", "W_UP_MAX"), ("surface_pressure", "PSFC")]
+from mpassit_amd.workloads import JOB_DIAG as DIAG, JOB_HIST_2D as HIST_2D, JOB_HIST_3D as HIST_3D, JOB_SOIL as SOIL  # noqa: E402
 
 
 def main():
