@@ -69,7 +69,13 @@ int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void 
  * written (after ncio_enddef) the range of record `rec` is made to exist (the file is extended, numrecs follows). */
 int ncio_var_extent(ncio_file *f, int varid, int64_t rec, int64_t *offset, int64_t *nbytes);
 
-int ncio_close(ncio_file *f);                   /* writer: fills numrecs, flushes */
+int ncio_close(ncio_file *f);                   /* writer: fills numrecs, flushes, sizes the file exactly */
+
+/* Start allocating `nbytes` (an upper bound of the output size) for a file that ncio_create will open shortly: the file is
+ * created / truncated and its pages are allocated on a helper thread while the caller goes on (e.g. reads its inputs);
+ * ncio_create of the same path waits for the helper and keeps the file, ncio_close trims it.  Unwritten ranges read as
+ * zeros either way.  One reservation at a time. */
+int ncio_reserve_start(const char *path, int64_t nbytes);
 
 /* two POSIX helpers for hosts that coordinate several driver images through marker files (sleep; atomic rename) */
 int ncio_msleep(int milliseconds);

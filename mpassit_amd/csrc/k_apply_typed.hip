@@ -226,9 +226,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + lane);
 }
 
-// nearest (NNZ = 1, weights implicit), 4-point destagger (NNZ = 4) and CSR (NNZ = 0): one thread per target point
-template <typename TS, typename TD, bool SWZ>
-__global__ __launch_bounds__(256) void k_apply_generic_t(int nnz_per_row, const int32_t *__restrict__ idx, const double *__restrict__ w,
+// nearest (NNZ = 1, weights implicit), 4-point destagger (NNZ = 4) and CSR (NNZ = 0): one thread per target point.  The
+// fixed forms keep the point's indices and weights in registers for all levels and work on two levels at a time (2 x NNZ
+// independent loads in flight); accumulation order per level as k_applyN / k_apply1 of k_apply.hip -> the same bits.
+template <typename TS, typename TD, bool SWZ, int NNZ>
+__global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                          const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                          const double *__restrict__ val, const TS *__restrict__ src,
                                                          TD *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast, int nblk,
@@ -240,23 +242,53 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(int nnz_per_row, const 
   if (p >= P) return;
   const TS *sf = src + (int64_t)fld * nlev * nsrc;
   TD *df = dst + (int64_t)fld * nlev * P;
-  for (int k = 0; k < nlev; ++k) {
-    double acc = 0.0;
-    if (nnz_per_row == 0) {
+  if constexpr (NNZ == 0) {
+    for (int k = 0; k < nlev; ++k) {
+      double acc = 0.0;
       for (int q = rowptr[p]; q < rowptr[p + 1]; ++q) {
         int32_t c = col[q];
         acc = fma(val[q], (double)swz<SWZ>(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], zs), acc);
       }
-    } else if (nnz_per_row == 1) {
-      int32_t c = idx[p];
-      if (c >= 0) acc = (double)swz<SWZ>(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], zs);
-    } else if (idx[p] >= 0) {
-      for (int q = 0; q < nnz_per_row; ++q) {
-        int32_t c = idx[q * P + p];
-        acc = fma(w[q * P + p], (double)swz<SWZ>(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], zs), acc);
-      }
+      df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(acc, scale, offset), zd);
     }
-    df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(acc, scale, offset), zd);
+  } else {
+    int32_t c[NNZ];
+    double ww[NNZ];
+#pragma unroll
+    for (int q = 0; q < NNZ; ++q) {
+      c[q] = idx[q * P + p];
+      ww[q] = NNZ == 1 ? 1.0 : w[q * P + p];
+    }
+    const bool mapped = c[0] >= 0;
+    int64_t step = lev_fast ? 1 : nsrc, base[NNZ];
+#pragma unroll
+    for (int q = 0; q < NNZ; ++q) base[q] = mapped ? (lev_fast ? (int64_t)c[q] * nlev : (int64_t)c[q]) : 0;
+    auto level = [&](int k, double *v) {
+#pragma unroll
+      for (int q = 0; q < NNZ; ++q) v[q] = (double)swz<SWZ>(sf[base[q] + k * step], zs);
+    };
+    auto combine = [&](const double *v) -> double {
+      double acc = 0.0;
+      if (NNZ == 1) acc = v[0];
+      else {
+#pragma unroll
+        for (int q = 0; q < NNZ; ++q) acc = fma(ww[q], v[q], acc);
+      }
+      return mapped ? acc : 0.0;
+    };
+    int k = 0;
+    for (; k + 1 < nlev; k += 2) {
+      double v0[NNZ], v1[NNZ];
+      level(k, v0);
+      level(k + 1, v1);
+      df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(combine(v0), scale, offset), zd);
+      df[(int64_t)(k + 1) * P + p] = swz<SWZ>((TD)fma(combine(v1), scale, offset), zd);
+    }
+    if (k < nlev) {
+      double v0[NNZ];
+      level(k, v0);
+      df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(combine(v0), scale, offset), zd);
+    }
   }
 }
 
@@ -295,9 +327,14 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
     }
   } else {
     int nblk = (int)((P + 255) / 256);
-    k_apply_generic_t<TS, TD, SWZ><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->kind == MPG_KIND_CSR ? 0 : h->nnz_per_row, h->idx.p, h->w.p,
-                                                                           h->rowptr.p, h->col.p, h->val.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev,
-                                                                           layout == MPG_LAYOUT_LEV_FAST, nblk, scale, offset, sbe, dbe);
+    const int nnz = h->kind == MPG_KIND_CSR ? 0 : h->nnz_per_row;
+    auto fn = nnz == 0 ? k_apply_generic_t<TS, TD, SWZ, 0> : (nnz == 1 ? k_apply_generic_t<TS, TD, SWZ, 1> : k_apply_generic_t<TS, TD, SWZ, 4>);
+    if (nnz != 0 && nnz != 1 && nnz != 4) {
+      mpg_set_error("Regrid: unsupported handle (%d weights per row)", nnz);
+      return MPG_ERR_UNSUPPORTED;
+    }
+    fn<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, h->rowptr.p, h->col.p, h->val.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev,
+                                               layout == MPG_LAYOUT_LEV_FAST, nblk, scale, offset, sbe, dbe);
   }
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;

@@ -109,6 +109,12 @@ module ncio
       integer(c_int32_t), intent(in) :: vals(*)
       integer(c_int) :: rc
     end function ncio_put_att_int_c
+    function ncio_reserve_start_c(path, nbytes) bind(C, name="ncio_reserve_start") result(rc)
+      import :: c_char, c_int, c_int64_t
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int64_t), value :: nbytes
+      integer(c_int) :: rc
+    end function ncio_reserve_start_c
     function ncio_msleep(ms) bind(C, name="ncio_msleep") result(rc)
       import :: c_int
       integer(c_int), value :: ms
@@ -202,6 +208,11 @@ contains
     type(c_ptr), intent(out) :: f
     rc = ncio_open_c(cstr(path), f)
   end function ncio_open
+  integer(c_int) function ncio_reserve_start(path, nbytes) result(rc)
+    character(len=*), intent(in) :: path
+    integer(c_int64_t), intent(in) :: nbytes
+    rc = ncio_reserve_start_c(cstr(path), nbytes)
+  end function ncio_reserve_start
   integer(c_int) function ncio_create(path, fmt, f) result(rc)
     character(len=*), intent(in) :: path
     integer, intent(in) :: fmt

@@ -175,6 +175,12 @@ def main():
         del res
         torch.cuda.empty_cache()
     same = open(os.path.join(d, "out_host.nc"), "rb").read() == open(os.path.join(d, "out_dev.nc"), "rb").read()
+    import hashlib
+    hsh = hashlib.sha256()
+    with open(os.path.join(d, "out_fortran.nc"), "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 24), b""):
+            hsh.update(blk)
+    print("sha256 of the fortran (device flow) output: %s" % hsh.hexdigest())
     print("fortran outputs (host arrays / device flow) identical byte for byte:",
           open(os.path.join(d, "out_fortran_host.nc"), "rb").read() == open(os.path.join(d, "out_fortran.nc"), "rb").read())
     print("python outputs identical byte for byte:", same)
