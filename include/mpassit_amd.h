@@ -252,6 +252,17 @@ int mpg_mesh_get_triangles(mpg_mesh mesh, int32_t *tri_host);
  * references.  Call with ids_host == NULL to get the count.  mpg_handle_localize rewrites the handle's
  * indices to positions in that list so that Regrid reads a compact [nlev][n_unique] halo buffer. */
 int mpg_handle_unique_sources(mpg_handle rh, int64_t *n_unique, int32_t *ids_host);
+/* Source window of a mesh: a host that holds, for every source field, only the contiguous id range [first, first + count)
+ * its target rows reference -- one driver image per GPU reading just that range of every variable (MPAS variables are
+ * [nCells][nLevels]: a cell range is one byte range of the file), where the reference has every rank read everything
+ * (input_data.F90:645) and ESMF redistributes.  mpg_handle_source_range reports the global ids [first, end) a Mesh -> Grid
+ * handle references (first == end: none).  mpg_mesh_set_source_window then declares the window for one mesh location:
+ * every handle of that mesh and location -- existing (in use or parked in the cache) and future -- indexes its sources
+ * relative to `first`, and Regrid reads source slabs of `count` ids ([nlev][count] / [count][nlev]); mpg_handle_info
+ * reports n_src = count.  A handle that references a source outside the window fails the call.  Unlike the two calls
+ * below the handles stay in the Store cache.  The whole mesh (first 0, count nCells / nVertices) resets it. */
+int mpg_handle_source_range(mpg_handle rh, int64_t *first, int64_t *end);
+int mpg_mesh_set_source_window(mpg_mesh mesh, int meshloc, int64_t first, int64_t count);
 /* Both re-index the handle IN PLACE and detach it from the Store cache; a handle that is shared (mpg_regrid_store returned
  * the same pointer twice: refcount 2) is refused with MPG_ERR_INVALID_ARG -- release the other reference first. */
 int mpg_handle_localize(mpg_handle rh);

@@ -74,7 +74,48 @@ __global__ __launch_bounds__(256) void k_rebase(int64_t n, int32_t *__restrict__
   }
 }
 
-int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s) {
+// [first, end) of the source ids a handle references (first == end: none), in its current index space
+__global__ __launch_bounds__(256) void k_src_range(int64_t n, const int32_t *__restrict__ idx, int32_t *__restrict__ lohi) {
+  int32_t lo = 0x7fffffff, hi = -1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t c = idx[i];
+    if (c >= 0) {
+      lo = min(lo, c);
+      hi = max(hi, c);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_down(lo, o));
+    hi = max(hi, __shfl_down(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0 && hi >= 0) {
+    atomicMin(lohi, lo);
+    atomicMax(lohi + 1, hi);
+  }
+}
+
+int mpg_k_source_range(mpg_handle_s *h, int64_t *first, int64_t *end, hipStream_t s) {
+  int rc;
+  int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
+  int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
+  TmpBuf<int32_t> lohi;
+  if ((rc = lohi.alloc(2))) return rc;
+  int32_t init[2] = {0x7fffffff, -1}, out[2];
+  MPG_HIP(hipMemcpyAsync(lohi.p, init, sizeof(init), hipMemcpyHostToDevice, s));
+  int gb = (int)((ni + 255) / 256);
+  if (gb > 8192) gb = 8192;
+  if (gb < 1) gb = 1;
+  if (ni > 0) k_src_range<<<gb, 256, 0, s>>>(ni, ip, lohi.p);
+  MPG_HIP(hipMemcpyAsync(out, lohi.p, sizeof(out), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  *first = out[1] >= 0 ? out[0] : 0;
+  *end = out[1] >= 0 ? (int64_t)out[1] + 1 : 0;
+  return MPG_SUCCESS;
+}
+
+// keep_global: the shift of a mesh-wide source window (mpg_mesh_set_source_window): the handle stays what it was for
+// mpg_handle_unique_sources / the Store cache; otherwise the handle becomes a re-indexed one (mpg_handle_rebase)
+int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s, bool keep_global) {
   int rc;
   int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
   int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
@@ -90,9 +131,9 @@ int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s) 
   MPG_HIP(hipStreamSynchronize(s));
   bad.free();
   h->n_src = n_local;
-  h->localized = true;
+  if (!keep_global) h->localized = true;
   if (nb) {
-    mpg_set_error("mpg_handle_rebase: %d source indices fall outside [base, base+n_local)", nb);
+    mpg_set_error("%d source indices fall outside [base, base+n_local)", nb);
     return MPG_ERR_INVALID_ARG;
   }
   return MPG_SUCCESS;

@@ -363,10 +363,65 @@ int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_stagge
   return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
     StoreCtx *x = (StoreCtx *)c;
     h->method = x->method;
-    if (x->method == MPG_REGRIDMETHOD_BILINEAR) return mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, x->meshloc, h, g_stream);
-    if (x->method == MPG_REGRIDMETHOD_NEAREST_STOD) return mpg_k_store_nearest(x->m, x->g, x->stagger, h, g_stream);
-    return mpg_k_store_conserve(x->m, x->g, h, g_stream);
+    int rc;
+    if (x->method == MPG_REGRIDMETHOD_BILINEAR) rc = mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, x->meshloc, h, g_stream);
+    else if (x->method == MPG_REGRIDMETHOD_NEAREST_STOD) rc = mpg_k_store_nearest(x->m, x->g, x->stagger, h, g_stream);
+    else rc = mpg_k_store_conserve(x->m, x->g, h, g_stream);
+    if (!rc && x->m->win_count[x->meshloc] >= 0)    // the mesh's sources are windowed: index relative to the window from the start
+      rc = mpg_k_rebase(h, x->m->win_first[x->meshloc], x->m->win_count[x->meshloc], g_stream, true);
+    return rc;
   }, &ctx);
+}
+
+// ---- source window of a mesh (a host that holds only the cells its target rows reference) ---------------------------------
+int mpg_handle_source_range(mpg_handle h, int64_t *first, int64_t *end) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && first && end, "mpg_handle_source_range: NULL argument");
+  MPG_ARG(!h->localized, "mpg_handle_source_range: the handle was re-indexed (mpg_handle_localize / mpg_handle_rebase)");
+  int rc = mpg_k_source_range(h, first, end, g_stream);
+  if (rc) return rc;
+  if (h->cached && std::get<1>(h->key) < 100) {   // Mesh -> Grid handle of a windowed mesh: back to global ids
+    mpg_mesh_s *m = (mpg_mesh_s *)std::get<0>(h->key);
+    const int loc = std::get<1>(h->key);
+    if (m->win_count[loc] >= 0 && *end > *first) {
+      *first += m->win_first[loc];
+      *end += m->win_first[loc];
+    }
+  }
+  return MPG_SUCCESS;
+}
+
+int mpg_mesh_set_source_window(mpg_mesh m, int meshloc, int64_t first, int64_t count) {
+  MPG_CHECK_INIT();
+  MPG_ARG(m && (meshloc == MPG_MESHLOC_ELEMENT || meshloc == MPG_MESHLOC_NODE), "mpg_mesh_set_source_window: bad mesh / location");
+  const int64_t n_all = meshloc == MPG_MESHLOC_ELEMENT ? m->nCells : m->nVertices;
+  MPG_ARG(first >= 0 && count >= 0 && first + count <= n_all, "mpg_mesh_set_source_window: the window must lie inside the mesh");
+  const int64_t old_first = m->win_count[meshloc] >= 0 ? m->win_first[meshloc] : 0;
+  // every handle of this mesh and location that exists already (in use or parked) moves to the new window -- after ALL of
+  // them have been checked: one that references a source outside it fails the call and nothing has changed
+  for (auto &kv : g_cache) {
+    if (std::get<0>(kv.first) != (void *)m || std::get<1>(kv.first) != meshloc) continue;
+    int64_t f = 0, e = 0;
+    int rc = mpg_k_source_range(kv.second, &f, &e, g_stream);
+    if (rc) return rc;
+    if (e > f && (f + old_first < first || e + old_first > first + count)) {
+      mpg_set_error("mpg_mesh_set_source_window: a route handle of this mesh references sources [%lld, %lld), outside the window [%lld, %lld)",
+                    (long long)(f + old_first), (long long)(e + old_first), (long long)first, (long long)(first + count));
+      return MPG_ERR_INVALID_ARG;
+    }
+  }
+  for (auto &kv : g_cache) {
+    if (std::get<0>(kv.first) != (void *)m || std::get<1>(kv.first) != meshloc) continue;
+    mpg_handle_s *h = kv.second;
+    h->free_tile_lists();
+    h->lf_choice = 0;
+    h->cf_choice = 0;
+    int rc = mpg_k_rebase(h, first - old_first, count, g_stream, true);
+    if (rc) return rc;
+  }
+  m->win_first[meshloc] = first;
+  m->win_count[meshloc] = count;
+  return MPG_SUCCESS;
 }
 
 int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {

@@ -171,6 +171,9 @@ struct mpg_mesh_s {
   int64_t nTriValid = 0;
   DevBuf<int32_t> fan;          // [3][nCells*(maxEdges-2)] fan triangles of the Voronoi polygons (vertex ids), lazily
   SiteBvh bvh;
+  // source window per mesh location (ELEMENT, NODE): Regrid sources hold ids [win_first, win_first + win_count) only and
+  // every handle of this mesh indexes relative to win_first (mpg_mesh_set_source_window); whole mesh by default
+  int64_t win_first[2] = {0, 0}, win_count[2] = {-1, -1};
 };
 
 struct mpg_grid_s {
@@ -300,5 +303,6 @@ int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, i
 int mpg_k_tune(const char *key, int value);
 int mpg_nearest_variant();
 void mpg_set_nearest_variant(int v);
-int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s);
+int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s, bool keep_global = false);
+int mpg_k_source_range(mpg_handle_s *h, int64_t *first, int64_t *end, hipStream_t s);
 int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap, hipStream_t s);

@@ -41,6 +41,9 @@ module model_data
   !! byte order turned on the device) and every field stays in device buffers (mpg_dev_alloc) in between; the host
   !! arrays of field_t are not used at all
   logical :: dev_flow = .false.
+  !> device flow: the source window of this image (mpg_mesh_set_source_window) -- the cell / vertex ids [win0, win0 + winn)
+  !! its target rows reference; only those rows of every variable are read from the input files.  winn < 0: whole mesh
+  integer(c_int64_t) :: win0_cell = 0, winn_cell = -1, win0_vert = 0, winn_vert = -1
 
 contains
 

@@ -60,6 +60,7 @@ program mpassit
   print *, "- DEFINE INPUT GRID"
   call define_input_grid()
   call lap("DEFINE INPUT GRID")
+  if (dev_flow) call plan_source_window()
   print *, "- READ INPUT DATA"
   call read_input_data()
   call lap("READ INPUT DATA")
@@ -125,6 +126,65 @@ contains
     if (ncio_reserve_start(output_file, (n3*(nz + 1) + ns*max(nso, 1_c_int64_t) + n2)*plane + 1048576) /= 0) &
       print *, "- (output space not reserved ahead of time)"
   end subroutine reserve_output
+
+  !> Device flow: build the weight sets this run will use BEFORE the inputs are read (they stay in the Store cache: the
+  !! Stores of interp_data find them there), ask each which source ids it references, and declare the union as the
+  !! mesh's source window -- then only that range of every variable is read and held in HBM.  With one image the window
+  !! is the part of the mesh under the target grid (configuration 4: 2.48 M of 3.0 M cells); with N images each window is
+  !! what that image's row block references, so the bytes read per image fall with N (the reference: every rank reads
+  !! everything, input_data.F90:645).
+  subroutine plan_source_window()
+    character(len=50), allocatable :: names(:), targets(:)
+    logical :: need_nstd, need_cons, need_node
+    integer :: n, i
+    integer(c_int64_t) :: lo, hi
+    need_nstd = .false.; need_cons = .false.; need_node = .false.
+    if (interp_hist) then
+      call read_varlist('histlist_2d', n, names, targets)
+      do i = 1, n
+        if (any(trim(names(i)) == [character(len=50) :: 'ivgtyp', 'isltyp', 'xland', 'landmask'])) need_nstd = .true.
+        if (any(trim(names(i)) == [character(len=50) :: 'snow', 'snowh'])) need_cons = .true.
+      end do
+      call read_varlist('histlist_3d', n, names, targets)
+      do i = 1, n
+        if (trim(names(i)) == 'vorticity') need_node = .true.
+      end do
+    end if
+    lo = huge(lo); hi = 0
+    call plan_one(MPG_MESHLOC_ELEMENT, MPG_REGRIDMETHOD_BILINEAR, lo, hi)
+    if (need_cons) call plan_one(MPG_MESHLOC_ELEMENT, MPG_REGRIDMETHOD_CONSERVE, lo, hi)
+    if (need_nstd) call plan_one(MPG_MESHLOC_ELEMENT, MPG_REGRIDMETHOD_NEAREST_STOD, lo, hi)
+    if (hi <= lo) then
+      lo = 0; hi = 0
+    end if
+    win0_cell = lo; winn_cell = hi - lo
+    call mpg_check(mpg_mesh_set_source_window(input_grid, MPG_MESHLOC_ELEMENT, win0_cell, winn_cell), "IN MeshSetSourceWindow")
+    if (need_node) then
+      lo = huge(lo); hi = 0
+      call plan_one(MPG_MESHLOC_NODE, MPG_REGRIDMETHOD_BILINEAR, lo, hi)
+      if (hi <= lo) then
+        lo = 0; hi = 0
+      end if
+      win0_vert = lo; winn_vert = hi - lo
+      call mpg_check(mpg_mesh_set_source_window(input_grid, MPG_MESHLOC_NODE, win0_vert, winn_vert), "IN MeshSetSourceWindow")
+    end if
+    print '(a,i0,a,i0,a,i0,a)', " - SOURCE WINDOW: CELLS ", win0_cell + 1, " .. ", win0_cell + winn_cell, " OF ", nCells_input, " ARE READ"
+    call nc_upload_hgt()
+  end subroutine plan_source_window
+
+  !> one weight set of the plan: Store, its source range joined to [lo, hi), Release (it stays parked in the cache)
+  subroutine plan_one(loc, method, lo, hi)
+    integer(c_int), intent(in) :: loc, method
+    integer(c_int64_t), intent(inout) :: lo, hi
+    integer(c_int64_t) :: a, b
+    type(c_ptr) :: rh
+    call mpg_check(mpg_regrid_store(input_grid, loc, target_grid_h, MPG_STAGGERLOC_CENTER, method, rh), "IN FieldBundleRegridStore")
+    call mpg_check(mpg_handle_source_range(rh, a, b), "IN HandleSourceRange")
+    call mpg_check(mpg_handle_release(rh), "IN FieldRegridRelease")
+    if (b > a) then
+      lo = min(lo, a); hi = max(hi, b)
+    end if
+  end subroutine plan_one
 
   subroutine define_target_grid()
     if (target_from_file) then

@@ -177,6 +177,20 @@ module mpg
       type(c_ptr), value :: src_dev, stream
       integer(c_int) :: rc
     end function mpg_dev_to_file_c
+    !> global source ids [first, last) a Mesh -> Grid handle references; source window of a mesh location
+    function mpg_handle_source_range(rh, first, last) bind(C, name="mpg_handle_source_range") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: rh
+      integer(c_int64_t), intent(out) :: first, last
+      integer(c_int) :: rc
+    end function mpg_handle_source_range
+    function mpg_mesh_set_source_window(mesh, meshloc, first, count) bind(C, name="mpg_mesh_set_source_window") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: mesh
+      integer(c_int), value :: meshloc
+      integer(c_int64_t), value :: first, count
+      integer(c_int) :: rc
+    end function mpg_mesh_set_source_window
     function mpg_bswap_dev(buf, n, elem_size, stream) bind(C, name="mpg_bswap_dev") result(rc)
       import :: c_int, c_int64_t, c_ptr
       type(c_ptr), value :: buf, stream

@@ -15,7 +15,7 @@ module ncfiles
   use model_data
   implicit none
   private
-  public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target, nc_read_meta
+  public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target, nc_read_meta, nc_upload_hgt
   ! what the output header takes from the input files (model_grid.F90:34-46,182; read by input_data.F90:219-245,347-389)
   character(len=50), public :: start_time = ""
   real(dp), public :: config_dt = 0.0_dp
@@ -154,14 +154,22 @@ contains
     call get_f64(nf, "ter", hgt%src, nc)
     hgt%name = "ter"; hgt%tname = "HGT"; hgt%nlev = 1
     if (ncio_inq_varid(nf, "zs", id) == 0 .and. ncio_inq_dim(nf, "nSoilLevels", ns) == 0) call get_f64(nf, "zs", zs_input, ns)
-    if (dev_flow) then
-      call mpg_check(mpg_dev_alloc(nc*8, hgt%src_dev), "IN dev_alloc ter")
-      call mpg_check(mpg_dev_upload(hgt%src_dev, hgt%src, nc*8), "IN dev_upload ter")
-      hgt%src_is_f32 = .false.
-      deallocate (hgt%src)
-    end if
     call ncio_check(ncio_close(nf), "closing grid file")
   end subroutine nc_read_grid
+
+  !> device flow: `ter` (read whole with the grid) goes up once the source window is known -- its window only
+  subroutine nc_upload_hgt()
+    integer(c_int64_t) :: i0, n
+    if (.not. allocated(hgt%src)) return
+    i0 = 0; n = size(hgt%src, kind=c_int64_t)
+    if (winn_cell >= 0) then
+      i0 = win0_cell; n = winn_cell
+    end if
+    call mpg_check(mpg_dev_alloc(n*8, hgt%src_dev), "IN dev_alloc ter")
+    if (n > 0) call mpg_check(mpg_dev_upload(hgt%src_dev, hgt%src(i0 + 1:i0 + n), n*8), "IN dev_upload ter")
+    hgt%src_is_f32 = .false.
+    deallocate (hgt%src)
+  end subroutine nc_upload_hgt
 
   subroutine nc_load_field(nf, name, tname, f)
     type(c_ptr), intent(in) :: nf
@@ -183,7 +191,7 @@ contains
       n = shp(d0)*shp(d0 + 1)
     end if
     if (dev_flow) then
-      call load_dev(nf, id, xtype, n, f)
+      call load_dev(nf, id, xtype, n, shp(d0), f)
       return
     end if
     if (xtype == NCIO_FLOAT) then                 ! stays single precision: the Regrid widens it on the GPU
@@ -197,25 +205,35 @@ contains
 
   !> device flow: the variable's bytes go file -> GPU as stored (big-endian) and the Regrid reads them so (MPG_TYPE_BE);
   !! types other than NF90_FLOAT / NF90_DOUBLE are converted by ncio on the host and uploaded as float64
-  subroutine load_dev(nf, id, xtype, n, f)
+  !> Only the rows of this image's source window travel: a variable is [nCells | nVertices][levels] in the file, so the
+  !! window is ONE byte range of it (the reference has every rank read every variable whole, input_data.F90:645).
+  subroutine load_dev(nf, id, xtype, n, nrows, f)
     type(c_ptr), intent(in) :: nf
     integer(c_int), intent(in) :: id, xtype
-    integer(c_int64_t), intent(in) :: n
+    integer(c_int64_t), intent(in) :: n, nrows            ! elements of the variable; its leading (cell / vertex) dimension
     type(field_t), intent(inout) :: f
-    integer(c_int64_t) :: off, nb
+    integer(c_int64_t) :: off, nb, r0, rn, per, es
     real(dp), allocatable :: tmp(:)
+    r0 = 0; rn = nrows
+    if (nrows == nCells_input .and. winn_cell >= 0) then
+      r0 = win0_cell; rn = winn_cell
+    else if (nrows == nVert_input .and. nrows /= nCells_input .and. winn_vert >= 0) then
+      r0 = win0_vert; rn = winn_vert
+    end if
+    per = n/max(nrows, 1_c_int64_t)                        ! elements per row (levels)
     if (xtype == NCIO_FLOAT .or. xtype == NCIO_DOUBLE) then
       call ncio_check(ncio_var_extent(nf, id, 0_c_int64_t, off, nb), "locating "//trim(f%name))
       f%src_is_f32 = xtype == NCIO_FLOAT
-      call mpg_check(mpg_dev_alloc(nb, f%src_dev), "IN dev_alloc "//trim(f%name))
-      call mpg_check(mpg_file_to_dev(trim(nc_in_path), off, nb, f%src_dev), "reading field - "//trim(f%name))
+      es = merge(4, 8, f%src_is_f32)
+      call mpg_check(mpg_dev_alloc(rn*per*es, f%src_dev), "IN dev_alloc "//trim(f%name))
+      if (rn > 0) call mpg_check(mpg_file_to_dev(trim(nc_in_path), off + r0*per*es, rn*per*es, f%src_dev), "reading field - "//trim(f%name))
       f%src_is_be = .true.
     else
       allocate (tmp(n))
       call ncio_check(ncio_get_var(nf, id, 0_c_int64_t, NCIO_DOUBLE, tmp), "reading field - "//trim(f%name))
       f%src_is_f32 = .false.
-      call mpg_check(mpg_dev_alloc(n*8, f%src_dev), "IN dev_alloc "//trim(f%name))
-      call mpg_check(mpg_dev_upload(f%src_dev, tmp, n*8), "IN dev_upload "//trim(f%name))
+      call mpg_check(mpg_dev_alloc(rn*per*8, f%src_dev), "IN dev_alloc "//trim(f%name))
+      if (rn > 0) call mpg_check(mpg_dev_upload(f%src_dev, tmp(r0*per + 1:(r0 + rn)*per), rn*per*8), "IN dev_upload "//trim(f%name))
     end if
   end subroutine load_dev
 

@@ -59,6 +59,12 @@ class Mesh:
     def from_mpas(cls, m):
         return cls(m.latCell, m.lonCell, m.latVertex, m.lonVertex, m.verticesOnCell)
 
+    def set_source_window(self, first, count, meshloc=MESHLOC_ELEMENT):
+        """Every handle of this mesh and location (existing and future) indexes its sources relative to `first`; Regrid
+        then reads slabs of `count` ids (mpg_mesh_set_source_window).  Route handle objects made earlier: call
+        RouteHandle._refresh() (n_src changes)."""
+        check(L.load().mpg_mesh_set_source_window(self._h, C.c_int(meshloc), C.c_int64(first), C.c_int64(count)))
+
     def triangles(self):
         tri = np.empty((self.nVertices, 3), np.int32)
         check(L.load().mpg_mesh_get_triangles(self._h, _ptr(tri)))
@@ -318,6 +324,12 @@ class RouteHandle:
         if n.value:
             check(L.load().mpg_handle_unique_sources(self._h, C.byref(n), _ptr(ids)))
         return ids
+
+    def source_range(self):
+        """(first, end): the global source ids this Mesh -> Grid handle references (mpg_handle_source_range)."""
+        a, b = C.c_int64(), C.c_int64()
+        check(L.load().mpg_handle_source_range(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def localize(self):
         ids = self.unique_sources()
