@@ -126,7 +126,12 @@ def main():
     if layout == R.LAYOUT_LEV_FAST and world > 1:
         raise SystemExit("lev_fast layout is single-GPU only")
 
-    sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object)
+    # MPASSIT_BENCH_TRANSPORT=cabi: the halo schedule and exchange through the C-ABI's own RCCL verbs (mpg_comm_init,
+    # mpg_halo_build, mpg_halo_exchange_dev) instead of torch.distributed; the default stays torch.distributed
+    transport = os.environ.get("MPASSIT_BENCH_TRANSPORT", "torch")
+    import uuid
+    id_file = "/dev/shm/mpassit_bench_%s.rcclid" % all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]   # fresh per run
+    sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file)
     P_local = sr.rh.n_dst
     local = sr.local_buffer(F, nlev, dev)
     c0, c1 = sr.sched.own
@@ -233,7 +238,9 @@ def main():
         per_rank = all_gather_object({"exchange_ms": float(np.mean([a.elapsed_time(b) for a, b in pipe["ev"]])) if pipe["ev"] else None,
                                       "kernel_ms": kern_ms, "sent": int(plan.bytes_sent), "received": int(plan.bytes_received),
                                       "n_local": int(sr.sched.n_local), "needed": int(sr.n_needed), "rows": int(sr.j1 - sr.j0)})
-        halo = {"mode": sr.sched.mode, "transport": "%s all_to_all_single (grouped send/recv, zero-size peers skipped)" % backend,
+        halo = {"mode": sr.sched.mode,
+                "transport": "%s all_to_all_single (grouped send/recv, zero-size peers skipped)" % backend if transport == "torch" else
+                             "C-ABI mpg_halo_exchange_dev (librccl: grouped ncclSend / ncclRecv)",
                 "ranks_in_group": dist.get_world_size(),
                 "exchange_ms_max": max(r["exchange_ms"] or 0.0 for r in per_rank),
                 "kernel_ms_max": max(r["kernel_ms"] for r in per_rank),

@@ -274,6 +274,55 @@ int mpg_handle_rebase(mpg_handle rh, int64_t base, int64_t n_local);
 int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *ids_dev, int64_t n_ids,
                  double *dst_dev, void *hip_stream);
 
+/* ---- several GPUs: one process per GPU, RCCL underneath (ESMF's source exchange and ESMF_FieldGather) -------------------
+ * Target rows are sharded over the ranks (regDecomp = (/1, npets/), model_grid.F90:693) and source cells owned in contiguous
+ * id blocks (model_grid.F90:423-438, 2428-2441); a rank whose rows reference cells of another rank's block receives them in
+ * ONE grouped ncclSend / ncclRecv exchange per field batch -- what ESMF does inside every ESMF_FieldRegrid (interp.F90:134...).
+ * No torch, no MPI: the ranks meet through `id_file` (rank 0 writes the RCCL unique id there; a path all ranks see, fresh per
+ * run), the library loads librccl on first use.  A host that READS its sources from files needs none of this: it reads the
+ * window its rows reference (mpg_mesh_set_source_window above); these verbs serve hosts whose source fields are produced or
+ * held partitioned on the devices (bench.py --gpus N, a coupled model).
+ *   mpg_comm_init / _destroy / _info      communicator of this process (its GPU = the one of mpg_init)
+ *   mpg_comm_allgather                    small host-side metadata, rank order (blocking)
+ *   mpg_halo_build                        the schedule for one Mesh -> Grid handle whose grid is this rank's row block:
+ *                                         asks the handle for its source ids, agrees on the ownership blocks with the other
+ *                                         ranks (ownership 0: block boundaries in the middle of the overlap of neighbouring
+ *                                         ranks' needs -- only the strip along a row-block boundary travels; 1: equal blocks
+ *                                         like the reference's para_range) and RE-INDEXES THE HANDLE IN PLACE to the local
+ *                                         source space of n_local ids (range form: the covering id range, own block in place
+ *                                         at own_pos; compact form for arbitrary numbering: the sorted needed ids) -- the
+ *                                         handle leaves the Store cache, as with mpg_handle_rebase / _localize
+ *   mpg_halo_exchange_dev                 one exchange of nrows rows (nfields * nlev): pack, grouped send / recv, unpack,
+ *                                         enqueued on the stream; buffers allocated at the first call of a batch size
+ *   mpg_gather_rows                       ESMF_FieldGather (write_data.F90:1006-1453): row blocks -> the whole field on root
+ *   mpg_halo_plan_host                    the schedule as a pure function of every rank's needed ids (tests, diagnostics) */
+typedef struct mpg_comm_s *mpg_comm;
+typedef struct mpg_halo_s *mpg_halo;
+int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out);
+int mpg_comm_destroy(mpg_comm comm);
+int mpg_comm_info(mpg_comm comm, int *rank, int *nranks);
+int mpg_comm_allgather(mpg_comm comm, const void *send_host, int64_t nbytes, void *recv_host);
+int mpg_halo_build(mpg_comm comm, mpg_handle rh, int64_t n_cells_global, int ownership, mpg_halo *out);
+/* mode 0 range / 1 compact; own = the global id block [own[0], own[1]) this rank holds; base = global id of local index 0
+ * (range form); own_pos = where the own block sits in the local space (range form); sent / received per row = elements that
+ * cross the links per exchanged row.  Any pointer may be NULL. */
+int mpg_halo_info(mpg_halo halo, int *mode, int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *sent_per_row,
+                  int64_t *received_per_row);
+/* own_dev: nrows rows of the own block, row stride own_ld elements (range form: may point into local_dev at own_pos[0] with
+ * own_ld = n_local -- the own data is then in place and only the neighbours' strips move); local_dev: [nrows][n_local],
+ * filled in place; elem_bytes 4 or 8 */
+int mpg_halo_exchange_dev(mpg_halo halo, const void *own_dev, int64_t own_ld, void *local_dev, int nrows, int elem_bytes, void *hip_stream);
+int mpg_halo_destroy(mpg_halo halo);
+/* rows_dev: this rank's [nlev][j1 - j0][nx] block of an [nlev][ny][nx] field; dst_dev (root only): the whole field */
+int mpg_gather_rows(mpg_comm comm, const void *rows_dev, int64_t j0, int64_t j1, int64_t nx, int64_t ny, int nlev, int elem_bytes,
+                    void *dst_dev, int root, void *hip_stream);
+/* needed[q]: rank q's sorted unique needed ids (n_needed[q] of them).  Outputs for `rank` (arrays of nranks entries unless
+ * noted): send_count; send_a = start of the range inside the own block (range form, -1 in compact form); recv_a / recv_b =
+ * destination range in the local space; compact form: send_ids_flat (capacity send_ids_cap) + send_ids_off [nranks + 1]. */
+int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, const int64_t *n_needed, const int32_t *const *needed, int *mode,
+                       int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *send_count, int64_t *send_a, int64_t *recv_a,
+                       int64_t *recv_b, int32_t *send_ids_flat, int64_t send_ids_cap, int64_t *send_ids_off);
+
 /* kernel-selection knobs for benchmarking and the A/B tests (defaults are the tuned production values; DESIGN.md s4.1 has
  * the measurements behind every default).  They select among kernels that produce identical bits:
  *   "a3_staged"   cell-fast 3-point Regrid: -1 per-handle choice (default), -2 lane-gather kernel, 0 / 1 / 2 the LDS-staged

@@ -1,0 +1,88 @@
+"""ctypes face of the multi-GPU verbs of the C-ABI (include/mpassit_amd.h: mpg_comm_*, mpg_halo_*, mpg_gather_rows): RCCL
+underneath, no torch.distributed.  `dist.py` is the torch.distributed form of the same schedule (bench.py, the gloo tests);
+this module is what a C or Fortran host gets, driven from Python for the tests."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import check
+
+
+def plan_host(rank, needed_lists, n_cells, ownership="aligned"):
+    """mpg_halo_plan_host: the halo schedule of `rank` as a pure function of every rank's sorted needed ids (no GPU)."""
+    world = len(needed_lists)
+    lists = [np.ascontiguousarray(x, np.int32) for x in needed_lists]
+    n_needed = (C.c_int64 * world)(*[int(x.size) for x in lists])
+    ptrs = (C.POINTER(C.c_int32) * world)(*[x.ctypes.data_as(C.POINTER(C.c_int32)) for x in lists])
+    mode, n_local, base = C.c_int(), C.c_int64(), C.c_int64()
+    own, own_pos = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+    arr = lambda: (C.c_int64 * world)()              # noqa: E731
+    send_count, send_a, recv_a, recv_b = arr(), arr(), arr(), arr()
+    cap = int(sum(x.size for x in lists)) + 1
+    flat = (C.c_int32 * cap)()
+    off = (C.c_int64 * (world + 1))()
+    check(L.load().mpg_halo_plan_host(C.c_int(rank), C.c_int(world), C.c_int64(n_cells), C.c_int(0 if ownership == "aligned" else 1), n_needed,
+                                      ptrs, C.byref(mode), C.byref(n_local), own, C.byref(base), own_pos, send_count, send_a, recv_a, recv_b, flat,
+                                      C.c_int64(cap), off))
+    res = dict(mode="range" if mode.value == 0 else "compact", n_local=n_local.value, own=(own[0], own[1]), base=base.value,
+               own_pos=(own_pos[0], own_pos[1]), send_count=list(send_count), send_a=list(send_a), recv_pos=list(zip(recv_a, recv_b)))
+    if mode.value == 1:
+        f = np.frombuffer(flat, dtype=np.int32)
+        res["send_ids"] = [f[off[q]:off[q + 1]].copy() for q in range(world)]
+    return res
+
+
+class Comm:
+    def __init__(self, rank=0, nranks=1, id_file=None):
+        self._h = C.c_void_p()
+        check(L.load().mpg_comm_init(C.c_int(rank), C.c_int(nranks), id_file.encode() if id_file else None, C.byref(self._h)))
+        self.rank, self.nranks = rank, nranks
+
+    def allgather(self, arr):
+        a = np.ascontiguousarray(arr)
+        out = np.empty((self.nranks,) + a.shape, a.dtype)
+        check(L.load().mpg_comm_allgather(self._h, a.ctypes.data_as(C.c_void_p), C.c_int64(a.nbytes), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def gather_rows(self, rows, j0, j1, ny, root=0):
+        """rows: CUDA tensor [nlev][j1 - j0][nx] -> [nlev][ny][nx] on root (None elsewhere)."""
+        import torch
+        nlev, nx = rows.shape[0], rows.shape[-1]
+        dst = torch.empty((nlev, ny, nx), dtype=rows.dtype, device=rows.device) if self.rank == root else None
+        check(L.load().mpg_gather_rows(self._h, C.c_void_p(rows.data_ptr()), C.c_int64(j0), C.c_int64(j1), C.c_int64(nx), C.c_int64(ny), C.c_int(nlev),
+                                       C.c_int(rows.element_size()), C.c_void_p(dst.data_ptr() if dst is not None else 0), C.c_int(root),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return dst
+
+    def destroy(self):
+        if self._h:
+            check(L.load().mpg_comm_destroy(self._h))
+            self._h = C.c_void_p()
+
+
+class Halo:
+    """mpg_halo_build on a route handle (re-indexed in place to the local source space) + the exchange."""
+
+    def __init__(self, comm, rh, n_cells, ownership="aligned"):
+        self._h = C.c_void_p()
+        check(L.load().mpg_halo_build(comm._h, rh._h, C.c_int64(n_cells), C.c_int(0 if ownership == "aligned" else 1), C.byref(self._h)))
+        rh._refresh()
+        mode, n_local, base, sent, recv = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        own, own_pos = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+        check(L.load().mpg_halo_info(self._h, C.byref(mode), C.byref(n_local), own, C.byref(base), own_pos, C.byref(sent), C.byref(recv)))
+        self.mode, self.n_local, self.base = ("range", "compact")[mode.value], n_local.value, base.value
+        self.own, self.own_pos, self.sent_per_row, self.received_per_row = (own[0], own[1]), (own_pos[0], own_pos[1]), sent.value, recv.value
+
+    def exchange(self, own_rows, local_rows):
+        """own_rows: CUDA tensor [R][>= own block] (may be a view into local_rows in range form); local_rows [R][n_local]."""
+        import torch
+        check(L.load().mpg_halo_exchange_dev(self._h, C.c_void_p(own_rows.data_ptr()), C.c_int64(own_rows.stride(0)),
+                                             C.c_void_p(local_rows.data_ptr()), C.c_int(local_rows.shape[0]), C.c_int(local_rows.element_size()),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return local_rows
+
+    def destroy(self):
+        if self._h:
+            check(L.load().mpg_halo_destroy(self._h))
+            self._h = C.c_void_p()

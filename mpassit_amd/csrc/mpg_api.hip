@@ -29,6 +29,13 @@ bool mpg_is_initialized() { return g_init; }
 hipStream_t mpg_setup_stream() { return g_stream; }
 int mpg_device_index() { return g_device; }
 
+void mpg_cache_detach(mpg_handle_s *h) {
+  if (h->cached) {
+    g_cache.erase(h->key);
+    h->cached = false;
+  }
+}
+
 extern "C" {
 
 const char *mpg_last_error(void) { return g_err; }

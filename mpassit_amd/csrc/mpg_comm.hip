@@ -1,0 +1,530 @@
+// Multi-GPU verbs of the C-ABI, on librccl directly (no torch, no MPI): one process per GPU, the images find each other
+// through a file that carries the RCCL unique id.
+//
+// What they replace: ESMF's per-Regrid source exchange (hidden in the route handle) and ESMF_FieldGather
+// (write_data.F90:1006-1453) -- with target rows sharded over the GPUs (regDecomp = (/1, npets/), model_grid.F90:693) and
+// source cells owned in contiguous id blocks (model_grid.F90:423-438), every rank needs the cells its rows reference that
+// another rank owns: one grouped ncclSend / ncclRecv exchange per field batch (point-to-point over xGMI; with banded cell
+// numbering only the two row-block neighbours have anything to send).  The schedule is the one of mpassit_amd/dist.py
+// (HaloSchedule.build), restated here so that a C or Fortran host has it without Python; tests/test_comm_plan.py checks
+// the two against each other on the CPU, tests/test_comm_gpu.py runs the RCCL path with a world of one on the GPU box.
+//
+// RCCL is loaded with dlopen at mpg_comm_init: the library itself keeps no link-time dependency on it (single-GPU hosts
+// never touch it), and in a process that already holds a RCCL (PyTorch's) the same image is used.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <rccl/rccl.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+
+#include "mpg_internal.h"
+
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} R;
+
+int rccl_load() {
+  if (R.lib) return MPG_SUCCESS;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names)
+    if ((R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!R.lib) {
+    mpg_set_error("mpg_comm_init: cannot load librccl (%s)", dlerror());
+    return MPG_ERR_UNSUPPORTED;
+  }
+#define SYM(field, name)                                                      \
+  if (!(*(void **)(&R.field) = dlsym(R.lib, name))) {                         \
+    mpg_set_error("mpg_comm_init: librccl lacks %s", name);                   \
+    R.lib = nullptr;                                                          \
+    return MPG_ERR_UNSUPPORTED;                                               \
+  }
+  SYM(GetUniqueId, "ncclGetUniqueId")
+  SYM(CommInitRank, "ncclCommInitRank")
+  SYM(CommDestroy, "ncclCommDestroy")
+  SYM(Send, "ncclSend")
+  SYM(Recv, "ncclRecv")
+  SYM(GroupStart, "ncclGroupStart")
+  SYM(GroupEnd, "ncclGroupEnd")
+  SYM(AllGather, "ncclAllGather")
+  SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  return MPG_SUCCESS;
+}
+
+#define MPG_NCCL(call)                                                                             \
+  do {                                                                                             \
+    ncclResult_t r_ = (call);                                                                      \
+    if (r_ != ncclSuccess) {                                                                       \
+      mpg_set_error("%s failed: %s (%s:%d)", #call, R.GetErrorString(r_), __FILE__, __LINE__);     \
+      return MPG_ERR_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+}  // namespace
+
+struct mpg_comm_s {
+  int rank = 0, nranks = 1;
+  ncclComm_t comm = nullptr;
+};
+
+// ---- the schedule (pure host logic; mirrors dist.HaloSchedule.build) ------------------------------------------------------
+struct HaloPlan {
+  int rank = 0, nranks = 1, mode = 0;       // mode 0: range, 1: compact
+  int64_t n_local = 0, own0 = 0, own1 = 0, base = 0, own_pos0 = 0, own_pos1 = 0;
+  std::vector<int64_t> send_a, send_b;      // range: per peer, offsets [a, b) inside the own block
+  std::vector<std::vector<int32_t>> send_ids;   // compact: per peer (self included), offsets inside the own block
+  std::vector<int64_t> recv_a, recv_b;      // per peer: destination range in the local index space
+  int64_t send_count(int q) const { return mode == 0 ? send_b[q] - send_a[q] : (int64_t)send_ids[q].size(); }
+  int64_t recv_count(int q) const { return recv_b[q] - recv_a[q]; }
+};
+
+static void para_block(int64_t n, int world, int r, int64_t *a, int64_t *b) {   // model_grid.F90:2428-2441, 0-based half-open
+  const int64_t w1 = n / world, w2 = n % world;
+  *a = r * w1 + std::min<int64_t>(r, w2);
+  *b = *a + w1 + (w2 > r ? 1 : 0);
+}
+
+struct Vote { int64_t want_range, nlo, nhi, empty; };
+
+// votes: what every rank's needed ids look like; -> mode and the ownership blocks
+static void plan_blocks(int world, int64_t n_cells, int ownership, const std::vector<Vote> &votes, int *mode,
+                        std::vector<std::pair<int64_t, int64_t>> &blocks) {
+  bool all_range = true;
+  for (auto &v : votes) all_range = all_range && v.want_range;
+  *mode = all_range ? 0 : 1;
+  blocks.resize(world);
+  bool aligned = *mode == 0 && ownership == 0;
+  std::vector<int64_t> los(world), his(world);
+  if (aligned) {
+    int64_t prev = 0;
+    bool any = false;
+    for (auto &v : votes)
+      if (!v.empty) {
+        prev = any ? std::min(prev, v.nlo) : v.nlo;
+        any = true;
+      }
+    for (int q = 0; q < world; ++q) {
+      los[q] = votes[q].nlo;
+      his[q] = votes[q].nhi;
+      if (votes[q].empty) los[q] = his[q] = prev;   // a rank that needs nothing owns an empty block right after its predecessor
+      prev = his[q];
+    }
+    for (int q = 1; q < world; ++q)
+      if (los[q] < los[q - 1] || his[q] < his[q - 1]) aligned = false;   // row blocks do not map to increasing id ranges
+  }
+  if (aligned) {
+    std::vector<int64_t> bnd(1, los[0]);
+    for (int q = 1; q < world; ++q) {
+      int64_t b = los[q] < his[q - 1] ? (los[q] + his[q - 1]) / 2 : los[q];
+      bnd.push_back(std::max(b, bnd.back()));
+    }
+    bnd.push_back(std::max(his[world - 1], bnd.back()));
+    for (int q = 0; q < world; ++q) blocks[q] = {bnd[q], bnd[q + 1]};
+  } else {
+    for (int q = 0; q < world; ++q) para_block(n_cells, world, q, &blocks[q].first, &blocks[q].second);
+  }
+}
+
+static Vote make_vote(const int32_t *needed, int64_t n, int64_t n_cells, int world, int rank) {
+  int64_t a, b;
+  para_block(n_cells, world, rank, &a, &b);
+  Vote v;
+  v.empty = n == 0;
+  v.nlo = n ? needed[0] : a;
+  v.nhi = n ? (int64_t)needed[n - 1] + 1 : a;
+  v.want_range = v.empty || (double)(v.nhi - v.nlo) <= 1.25 * (double)n;   // banded numbering: covering range ~ count
+  return v;
+}
+
+static void span_of(const Vote &v, const std::pair<int64_t, int64_t> &blk, int64_t *lo, int64_t *hi) {
+  *lo = std::min(v.nlo, blk.first);
+  *hi = std::max(v.nhi, blk.second);
+  if (v.empty) {
+    *lo = blk.first;
+    *hi = blk.second;
+  }
+}
+
+// range mode: everything follows from the votes (a rank's span is a function of its vote and block)
+static void plan_range(HaloPlan &p, const std::vector<Vote> &votes, const std::vector<std::pair<int64_t, int64_t>> &blocks) {
+  const int world = p.nranks, rank = p.rank;
+  int64_t lo, hi;
+  span_of(votes[rank], blocks[rank], &lo, &hi);
+  const int64_t c0 = blocks[rank].first, c1 = blocks[rank].second;
+  p.own0 = c0; p.own1 = c1; p.base = lo; p.n_local = hi - lo; p.own_pos0 = c0 - lo; p.own_pos1 = c1 - lo;
+  p.send_a.assign(world, 0); p.send_b.assign(world, 0); p.recv_a.assign(world, 0); p.recv_b.assign(world, 0);
+  for (int q = 0; q < world; ++q) {
+    if (q == rank) continue;
+    int64_t qlo, qhi;
+    span_of(votes[q], blocks[q], &qlo, &qhi);
+    int64_t a = std::max(qlo, c0), b = std::min(qhi, c1);          // what q wants from my block
+    if (b > a) { p.send_a[q] = a - c0; p.send_b[q] = b - c0; }
+    a = std::max(lo, blocks[q].first); b = std::min(hi, blocks[q].second);   // what I want from q's block
+    if (b > a) { p.recv_a[q] = a - lo; p.recv_b[q] = b - lo; }
+  }
+}
+
+// compact mode: needs every rank's id list
+static void plan_compact(HaloPlan &p, const std::vector<std::pair<int64_t, int64_t>> &blocks, const int64_t *n_needed,
+                         const int32_t *const *needed) {
+  const int world = p.nranks, rank = p.rank;
+  const int64_t c0 = blocks[rank].first, c1 = blocks[rank].second;
+  p.own0 = c0; p.own1 = c1; p.base = 0; p.n_local = n_needed[rank]; p.own_pos0 = p.own_pos1 = 0;
+  p.send_ids.assign(world, {});
+  p.recv_a.assign(world, 0); p.recv_b.assign(world, 0);
+  const int32_t *mine = needed[rank];
+  for (int q = 0; q < world; ++q) {
+    const int32_t *th = needed[q], *e = th + n_needed[q];
+    const int32_t *a = std::lower_bound(th, e, (int32_t)std::min<int64_t>(c0, 0x7fffffff));
+    const int32_t *b = std::lower_bound(th, e, (int32_t)std::min<int64_t>(c1, 0x7fffffff));
+    for (const int32_t *it = a; it < b; ++it) p.send_ids[q].push_back((int32_t)(*it - c0));
+    p.recv_a[q] = std::lower_bound(mine, mine + n_needed[rank], (int32_t)std::min<int64_t>(blocks[q].first, 0x7fffffff)) - mine;
+    p.recv_b[q] = std::lower_bound(mine, mine + n_needed[rank], (int32_t)std::min<int64_t>(blocks[q].second, 0x7fffffff)) - mine;
+  }
+}
+
+struct mpg_halo_s {
+  mpg_comm_s *comm = nullptr;
+  HaloPlan plan;
+  std::vector<int64_t> soff, roff;          // per peer element offsets (per row) inside the packed buffers
+  int64_t stot = 0, rtot = 0;
+  DevBuf<int32_t> send_ids_dev;             // compact: all peers' offset lists back to back
+  std::vector<int64_t> ids_off;
+  DevBuf<char> sendbuf, recvbuf;            // sized for buf_rows rows of buf_es bytes per element
+  int64_t buf_bytes = 0;
+};
+
+// dst[k][i] = src[k * ld + ids[i]] for elements of 4 or 8 bytes
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_ids(const T *__restrict__ src, int64_t ld, int nrows, const int32_t *__restrict__ ids, int64_t n,
+                                                  T *__restrict__ dst) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = ids[i];
+  for (int k = 0; k < nrows; ++k) dst[(int64_t)k * n + i] = src[(int64_t)k * ld + c];
+}
+
+extern "C" {
+
+int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(out && nranks >= 1 && rank >= 0 && rank < nranks, "mpg_comm_init: bad rank / nranks");
+  MPG_ARG(nranks == 1 || (id_file && *id_file), "mpg_comm_init: nranks > 1 needs the path of the id file");
+  int rc = rccl_load();
+  if (rc) return rc;
+  ncclUniqueId id;
+  memset(&id, 0, sizeof(id));
+  if (rank == 0) {
+    MPG_NCCL(R.GetUniqueId(&id));
+    if (nranks > 1) {   // under a temporary name, then renamed: a reader never sees half an id
+      std::string tmp = std::string(id_file) + ".tmp";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(&id, 1, sizeof(id), f) != sizeof(id) || fclose(f) || rename(tmp.c_str(), id_file)) {
+        mpg_set_error("mpg_comm_init: cannot write the id file %s", id_file);
+        return MPG_ERR_INVALID_ARG;
+      }
+    }
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 60000 && !got; ++tries) {   // up to 10 minutes
+      FILE *f = fopen(id_file, "rb");
+      if (f) {
+        got = fread(&id, 1, sizeof(id), f) == sizeof(id);
+        fclose(f);
+      }
+      if (!got) usleep(10000);
+    }
+    if (!got) {
+      mpg_set_error("mpg_comm_init: timed out waiting for the id file %s", id_file);
+      return MPG_ERR_INVALID_ARG;
+    }
+  }
+  mpg_comm_s *c = new mpg_comm_s();
+  c->rank = rank;
+  c->nranks = nranks;
+  ncclResult_t r = R.CommInitRank(&c->comm, nranks, id, rank);
+  if (r != ncclSuccess) {
+    mpg_set_error("ncclCommInitRank failed: %s", R.GetErrorString(r));
+    delete c;
+    return MPG_ERR_HIP;
+  }
+  *out = c;
+  return MPG_SUCCESS;
+}
+
+int mpg_comm_destroy(mpg_comm c) {
+  if (!c) return MPG_SUCCESS;
+  if (c->comm) (void)R.CommDestroy(c->comm);
+  delete c;
+  return MPG_SUCCESS;
+}
+
+int mpg_comm_info(mpg_comm c, int *rank, int *nranks) {
+  MPG_ARG(c, "mpg_comm_info: NULL communicator");
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = c->nranks;
+  return MPG_SUCCESS;
+}
+
+// every rank contributes nbytes from send_host; recv_host gets nranks * nbytes in rank order (small host-side metadata)
+int mpg_comm_allgather(mpg_comm c, const void *send_host, int64_t nbytes, void *recv_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(c && send_host && recv_host && nbytes > 0, "mpg_comm_allgather: bad argument");
+  hipStream_t s = mpg_setup_stream();
+  TmpBuf<char> sb, rb;
+  int rc;
+  if ((rc = sb.alloc((size_t)nbytes)) || (rc = rb.alloc((size_t)nbytes * c->nranks))) return rc;
+  MPG_HIP(hipMemcpyAsync(sb.p, send_host, (size_t)nbytes, hipMemcpyHostToDevice, s));
+  MPG_NCCL(R.AllGather(sb.p, rb.p, (size_t)nbytes, ncclChar, c->comm, s));
+  MPG_HIP(hipMemcpyAsync(recv_host, rb.p, (size_t)nbytes * c->nranks, hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  return MPG_SUCCESS;
+}
+
+// The schedule as a pure function of every rank's needed ids (diagnostics / tests; mpg_halo_build obtains the same inputs
+// with two all-gathers).  send_ids_flat / send_ids_off: compact mode only (offsets inside the own block, per peer).
+int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, const int64_t *n_needed, const int32_t *const *needed, int *mode,
+                       int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *send_count, int64_t *send_a, int64_t *recv_a,
+                       int64_t *recv_b, int32_t *send_ids_flat, int64_t send_ids_cap, int64_t *send_ids_off) {
+  MPG_ARG(nranks >= 1 && rank >= 0 && rank < nranks && n_cells >= 0 && n_needed && needed, "mpg_halo_plan_host: bad argument");
+  std::vector<Vote> votes(nranks);
+  for (int q = 0; q < nranks; ++q) votes[q] = make_vote(needed[q], n_needed[q], n_cells, nranks, q);
+  HaloPlan p;
+  p.rank = rank;
+  p.nranks = nranks;
+  std::vector<std::pair<int64_t, int64_t>> blocks;
+  plan_blocks(nranks, n_cells, ownership, votes, &p.mode, blocks);
+  if (p.mode == 0) plan_range(p, votes, blocks);
+  else plan_compact(p, blocks, n_needed, needed);
+  if (mode) *mode = p.mode;
+  if (n_local) *n_local = p.n_local;
+  if (own) { own[0] = p.own0; own[1] = p.own1; }
+  if (base) *base = p.base;
+  if (own_pos) { own_pos[0] = p.own_pos0; own_pos[1] = p.own_pos1; }
+  int64_t off = 0;
+  for (int q = 0; q < nranks; ++q) {
+    if (send_count) send_count[q] = p.send_count(q);
+    if (send_a) send_a[q] = p.mode == 0 ? p.send_a[q] : -1;
+    if (recv_a) recv_a[q] = p.recv_a[q];
+    if (recv_b) recv_b[q] = p.recv_b[q];
+    if (send_ids_off) send_ids_off[q] = off;
+    if (p.mode == 1) {
+      if (send_ids_flat) {
+        MPG_ARG(off + (int64_t)p.send_ids[q].size() <= send_ids_cap, "mpg_halo_plan_host: send_ids_flat too small");
+        std::copy(p.send_ids[q].begin(), p.send_ids[q].end(), send_ids_flat + off);
+      }
+      off += (int64_t)p.send_ids[q].size();
+    }
+  }
+  if (send_ids_off) send_ids_off[nranks] = off;
+  return MPG_SUCCESS;
+}
+
+int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg_halo *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(c && h && out && n_cells > 0 && n_cells < 0x7fffffff, "mpg_halo_build: bad argument");
+  MPG_ARG(!h->localized && h->n_pole == 0, "mpg_halo_build: the handle was re-indexed already, or carries pole terms");
+  MPG_ARG(h->refcount <= 1, "mpg_halo_build: the handle is shared; re-indexing it in place would corrupt the other holder's indices");
+  hipStream_t s = mpg_setup_stream();
+  std::vector<int32_t> ids;
+  int rc = mpg_k_unique_sources(h, ids, false, s);
+  if (rc) return rc;
+  const int world = c->nranks, rank = c->rank;
+  Vote mine = make_vote(ids.data(), (int64_t)ids.size(), n_cells, world, rank);
+  std::vector<Vote> votes(world);
+  int64_t cnt = (int64_t)ids.size();
+  std::vector<int64_t> counts(world);
+  if (world > 1) {
+    if ((rc = mpg_comm_allgather(c, &mine, sizeof(Vote), votes.data()))) return rc;
+    if ((rc = mpg_comm_allgather(c, &cnt, sizeof(int64_t), counts.data()))) return rc;
+  } else {
+    votes[0] = mine;
+    counts[0] = cnt;
+  }
+  mpg_halo_s *H = new mpg_halo_s();
+  H->comm = c;
+  HaloPlan &p = H->plan;
+  p.rank = rank;
+  p.nranks = world;
+  std::vector<std::pair<int64_t, int64_t>> blocks;
+  plan_blocks(world, n_cells, ownership, votes, &p.mode, blocks);
+  if (p.mode == 0) {
+    plan_range(p, votes, blocks);
+  } else {   // arbitrary numbering: every rank's id list travels once
+    const int64_t mx = *std::max_element(counts.begin(), counts.end());
+    std::vector<int32_t> padded((size_t)std::max<int64_t>(mx, 1), 0x7fffffff), all((size_t)std::max<int64_t>(mx, 1) * world);
+    std::copy(ids.begin(), ids.end(), padded.begin());
+    if (world > 1) {
+      if ((rc = mpg_comm_allgather(c, padded.data(), (int64_t)padded.size() * 4, all.data()))) { delete H; return rc; }
+    } else {
+      all = padded;
+    }
+    std::vector<const int32_t *> lists(world);
+    for (int q = 0; q < world; ++q) lists[q] = all.data() + (size_t)q * padded.size();
+    plan_compact(p, blocks, counts.data(), lists.data());
+  }
+  // detach from the Store cache and re-index in place, as mpg_handle_rebase / mpg_handle_localize do
+  mpg_cache_detach(h);
+  h->free_tile_lists();
+  h->lf_choice = h->cf_choice = 0;
+  if (p.mode == 0) rc = mpg_k_rebase(h, p.base, p.n_local, s);
+  else rc = mpg_k_unique_sources(h, ids, true, s);
+  if (rc) { delete H; return rc; }
+  H->soff.assign(world + 1, 0);
+  H->roff.assign(world + 1, 0);
+  H->ids_off.assign(world + 1, 0);
+  for (int q = 0; q < world; ++q) {
+    H->soff[q + 1] = H->soff[q] + p.send_count(q);
+    H->roff[q + 1] = H->roff[q] + p.recv_count(q);
+    H->ids_off[q + 1] = H->ids_off[q] + (p.mode == 1 ? (int64_t)p.send_ids[q].size() : 0);
+  }
+  H->stot = H->soff[world];
+  H->rtot = H->roff[world];
+  if (p.mode == 1 && H->ids_off[world] > 0) {
+    if ((rc = H->send_ids_dev.alloc((size_t)H->ids_off[world]))) { delete H; return rc; }
+    for (int q = 0; q < world; ++q)
+      if (!p.send_ids[q].empty())
+        MPG_HIP(hipMemcpy(H->send_ids_dev.p + H->ids_off[q], p.send_ids[q].data(), sizeof(int32_t) * p.send_ids[q].size(), hipMemcpyHostToDevice));
+  }
+  *out = H;
+  return MPG_SUCCESS;
+}
+
+int mpg_halo_info(mpg_halo H, int *mode, int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *sent_per_row,
+                  int64_t *received_per_row) {
+  MPG_ARG(H, "mpg_halo_info: NULL schedule");
+  const HaloPlan &p = H->plan;
+  if (mode) *mode = p.mode;
+  if (n_local) *n_local = p.n_local;
+  if (own) { own[0] = p.own0; own[1] = p.own1; }
+  if (base) *base = p.base;
+  if (own_pos) { own_pos[0] = p.own_pos0; own_pos[1] = p.own_pos1; }
+  if (sent_per_row) *sent_per_row = H->stot - (p.mode == 1 ? p.send_count(p.rank) : 0);
+  if (received_per_row) *received_per_row = H->rtot - (p.mode == 1 ? p.recv_count(p.rank) : 0);
+  return MPG_SUCCESS;
+}
+
+int mpg_halo_destroy(mpg_halo H) {
+  if (!H) return MPG_SUCCESS;
+  H->send_ids_dev.free();
+  H->sendbuf.free();
+  H->recvbuf.free();
+  delete H;
+  return MPG_SUCCESS;
+}
+
+// own_dev: nrows rows of this rank's own block (own[1] - own[0] elements used, row stride own_ld elements); local_dev: nrows
+// rows of n_local elements, filled in place.  Range mode: own_dev may point INTO local_dev (own data in place at own_pos[0],
+// own_ld = n_local) -- then only the neighbours' strips move.  elem_bytes 4 or 8.  Enqueued on hip_stream.
+int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void *local_dev, int nrows, int elem_bytes, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(H && local_dev && nrows >= 1 && (elem_bytes == 4 || elem_bytes == 8), "mpg_halo_exchange_dev: bad argument");
+  const HaloPlan &p = H->plan;
+  MPG_ARG(own_dev || p.own1 == p.own0, "mpg_halo_exchange_dev: own_dev is NULL");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int world = p.nranks, rank = p.rank;
+  const size_t es = (size_t)elem_bytes, need = (size_t)nrows * es * (size_t)std::max(H->stot, H->rtot);
+  if ((int64_t)need > H->buf_bytes) {   // first use for this batch size: the packed buffers (kept afterwards)
+    H->sendbuf.free();
+    H->recvbuf.free();
+    int rc;
+    if ((rc = H->sendbuf.alloc(need + 16)) || (rc = H->recvbuf.alloc(need + 16))) return rc;
+    H->buf_bytes = (int64_t)need;
+  }
+  const size_t n_local = (size_t)p.n_local;
+  // 1. pack what each peer wants from the own block: [nrows][count] per peer
+  for (int q = 0; q < world; ++q) {
+    const int64_t n = p.send_count(q);
+    if (!n) continue;
+    char *dst = H->sendbuf.p + (size_t)nrows * es * (size_t)H->soff[q];
+    if (p.mode == 0) {
+      MPG_HIP(hipMemcpy2DAsync(dst, (size_t)n * es, (const char *)own_dev + (size_t)p.send_a[q] * es, (size_t)own_ld * es, (size_t)n * es, (size_t)nrows,
+                               hipMemcpyDeviceToDevice, s));
+    } else if (elem_bytes == 8) {
+      k_pack_ids<unsigned long long><<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const unsigned long long *)own_dev, own_ld, nrows,
+                                                                                H->send_ids_dev.p + H->ids_off[q], n, (unsigned long long *)dst);
+    } else {
+      k_pack_ids<uint32_t><<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint32_t *)own_dev, own_ld, nrows, H->send_ids_dev.p + H->ids_off[q], n,
+                                                                      (uint32_t *)dst);
+    }
+  }
+  MPG_HIP(hipGetLastError());
+  // 2. one grouped exchange: ncclSend / ncclRecv with every peer that has something (point-to-point over xGMI)
+  if (world > 1) {
+    MPG_NCCL(R.GroupStart());
+    for (int q = 0; q < world; ++q) {
+      if (q == rank) continue;
+      const size_t ns = (size_t)p.send_count(q) * nrows * es, nr = (size_t)p.recv_count(q) * nrows * es;
+      if (ns) MPG_NCCL(R.Send(H->sendbuf.p + (size_t)nrows * es * (size_t)H->soff[q], ns, ncclChar, q, H->comm->comm, s));
+      if (nr) MPG_NCCL(R.Recv(H->recvbuf.p + (size_t)nrows * es * (size_t)H->roff[q], nr, ncclChar, q, H->comm->comm, s));
+    }
+    MPG_NCCL(R.GroupEnd());
+  }
+  // 3. unpack into the local index space (the rank's own share of a compact schedule never leaves the device)
+  for (int q = 0; q < world; ++q) {
+    const int64_t n = p.recv_count(q);
+    if (!n) continue;
+    const char *src = q == rank ? H->sendbuf.p + (size_t)nrows * es * (size_t)H->soff[q] : H->recvbuf.p + (size_t)nrows * es * (size_t)H->roff[q];
+    MPG_HIP(hipMemcpy2DAsync((char *)local_dev + (size_t)p.recv_a[q] * es, n_local * es, src, (size_t)n * es, (size_t)n * es, (size_t)nrows,
+                             hipMemcpyDeviceToDevice, s));
+  }
+  return MPG_SUCCESS;
+}
+
+// ESMF_FieldGather (write_data.F90:1006-1453): every rank holds rows [j0, j1) of an [nlev][ny][nx] field as
+// [nlev][j1 - j0][nx]; `root` receives the whole field.  Row blocks may be any partition of 0 .. ny (j0 / j1 of every rank
+// are exchanged inside).  dst_dev is read on the root only.
+int mpg_gather_rows(mpg_comm c, const void *rows_dev, int64_t j0, int64_t j1, int64_t nx, int64_t ny, int nlev, int elem_bytes, void *dst_dev,
+                    int root, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(c && nx > 0 && ny > 0 && nlev >= 1 && j0 >= 0 && j1 >= j0 && j1 <= ny && elem_bytes > 0 && root >= 0 && root < c->nranks,
+          "mpg_gather_rows: bad argument");
+  MPG_ARG(rows_dev || j1 == j0, "mpg_gather_rows: rows_dev is NULL");
+  MPG_ARG(c->rank != root || dst_dev, "mpg_gather_rows: dst_dev is NULL on the root");
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int world = c->nranks;
+  std::vector<int64_t> blk(2 * (size_t)world);
+  int64_t mine[2] = {j0, j1};
+  if (world > 1) {
+    int rc = mpg_comm_allgather(c, mine, sizeof(mine), blk.data());
+    if (rc) return rc;
+  } else {
+    blk[0] = j0;
+    blk[1] = j1;
+  }
+  const size_t es = (size_t)elem_bytes, row = (size_t)nx * es;
+  if (c->rank == root && j1 > j0)   // the root's own rows: a strided device copy
+    MPG_HIP(hipMemcpy2DAsync((char *)dst_dev + (size_t)j0 * row, (size_t)ny * row, rows_dev, (size_t)(j1 - j0) * row, (size_t)(j1 - j0) * row,
+                             (size_t)nlev, hipMemcpyDeviceToDevice, s));
+  if (world > 1) {
+    MPG_NCCL(R.GroupStart());
+    for (int k = 0; k < nlev; ++k) {
+      if (c->rank != root) {
+        if (j1 > j0) MPG_NCCL(R.Send((const char *)rows_dev + (size_t)k * (size_t)(j1 - j0) * row, (size_t)(j1 - j0) * row, ncclChar, root, c->comm, s));
+      } else {
+        for (int q = 0; q < world; ++q) {
+          const int64_t a = blk[2 * q], b = blk[2 * q + 1];
+          if (q == root || b <= a) continue;
+          MPG_NCCL(R.Recv((char *)dst_dev + ((size_t)k * (size_t)ny + (size_t)a) * row, (size_t)(b - a) * row, ncclChar, q, c->comm, s));
+        }
+      }
+    }
+    MPG_NCCL(R.GroupEnd());
+  }
+  return MPG_SUCCESS;
+}
+
+}  // extern "C"

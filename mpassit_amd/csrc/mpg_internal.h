@@ -249,6 +249,7 @@ struct mpg_handle_s {
 };
 
 void mpg_lfu_set_min_reuse_x10(int v);  // k_apply_lfu.hip
+void mpg_cache_detach(mpg_handle_s *h);  // mpg_api.hip: a handle about to be re-indexed in place leaves the Store cache
 void mpg_hostpipe_release();  // mpg_hostpipe.hip: device slots / streams of the host-pointer Regrid pipeline, dropped by mpg_finalize
 void mpg_fileio_release();  // mpg_fileio.hip: staging buffers / streams of mpg_file_to_dev, dropped by mpg_finalize
 

@@ -213,7 +213,10 @@ class _HaloPlan:
 class ShardedRegrid:
     """Rank-local piece of a row-sharded Mesh -> Grid regrid on this rank's GPU."""
 
-    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object, ownership="aligned"):
+    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object, ownership="aligned", transport="torch", id_file=None):
+        """transport "torch": schedule and exchange through torch.distributed (RCCL under the nccl backend, gloo in the CPU
+        tests).  transport "cabi": the C-ABI's own verbs (mpg_comm_init / mpg_halo_build / mpg_halo_exchange_dev: librccl
+        directly, what a C or Fortran host uses); the ranks meet through `id_file`."""
         from . import regrid as R
         self.rank, self.world = rank, world
         self.j0, self.j1 = row_block(target.ny, world, rank)
@@ -223,12 +226,15 @@ class ShardedRegrid:
         self.store_ms = self.rh.store_ms
         needed = self.rh.unique_sources()
         self.n_needed = int(needed.size)
+        self._ids_dev = {}
+        if transport == "cabi":
+            self.sched = CabiSchedule(self.rh, mpas_mesh.nCells, rank, world, id_file, ownership)
+            return
         self.sched = HaloSchedule.build(needed, mpas_mesh.nCells, rank, world, all_gather_object, ownership=ownership)
         if self.sched.mode == "range":
             self.rh.rebase(self.sched.base, self.sched.n_local)
         else:
             self.rh.localize()
-        self._ids_dev = {}
 
     def _pack(self, own_rows, ids, out=None):
         """HIP gather of owned columns (mpg_pack_dev) into `out` [R][len(ids)] (contiguous)."""
@@ -263,9 +269,39 @@ class ShardedRegrid:
         return self.rh.regrid(local_rows.view(-1), nlev=nlev, nfields=nfields, out=out)
 
     def destroy(self):
+        if isinstance(self.sched, CabiSchedule):
+            self.sched.destroy()
         self.rh.release()
         self.mesh.destroy()
         self.grid.destroy()
+
+
+class CabiSchedule:
+    """The halo schedule and exchange of the C-ABI (csrc/mpg_comm.hip) behind the attributes ShardedRegrid / bench.py read
+    from a HaloSchedule."""
+
+    class _Bytes:
+        bytes_sent = bytes_received = 0
+
+    def __init__(self, rh, n_cells, rank, world, id_file, ownership):
+        from . import comm as MC
+        self.comm = MC.Comm(rank, world, id_file)
+        self.halo = MC.Halo(self.comm, rh, n_cells, ownership)
+        self.rank, self.world, self.mode = rank, world, self.halo.mode
+        self.n_local, self.own, self.base, self.own_pos = self.halo.n_local, self.halo.own, self.halo.base, self.halo.own_pos
+
+    def exchange(self, own_rows, local_rows, pack_fn=None):
+        return self.halo.exchange(own_rows, local_rows)
+
+    def plan(self, R, like):
+        b = CabiSchedule._Bytes()
+        b.bytes_sent = R * self.halo.sent_per_row * like.element_size()
+        b.bytes_received = R * self.halo.received_per_row * like.element_size()
+        return b
+
+    def destroy(self):
+        self.halo.destroy()
+        self.comm.destroy()
 
 
 class ShardedInterp:

@@ -28,6 +28,7 @@ program mpassit
   type(c_ptr) :: nf_in = c_null_ptr
   integer :: nargs, gpu
   character(len=16) :: envbuf
+  logical :: no_reserve, no_window
   integer(int64) :: clk0, clk_prev, clk_now, clk_rate
 
   nargs = command_argument_count()
@@ -51,7 +52,11 @@ program mpassit
   call get_environment_variable("MPASSIT_DEVICE", envbuf)
   gpu = 0
   if (len_trim(envbuf) > 0) read (envbuf, *) gpu
-  if (dev_flow .and. myrank == 0) call reserve_output()      ! the output file's pages are allocated while the inputs are read
+  call get_environment_variable("MPASSIT_NO_RESERVE", envbuf)   ! A/B switches for measurements (tools/config4_file_job.py)
+  no_reserve = len_trim(envbuf) > 0
+  call get_environment_variable("MPASSIT_NO_WINDOW", envbuf)
+  no_window = len_trim(envbuf) > 0
+  if (dev_flow .and. myrank == 0 .and. .not. no_reserve) call reserve_output()   ! the output file's pages are allocated while the inputs are read
   call mpg_check(mpg_init(int(gpu, c_int)), "INITIALIZING GPU RUNTIME")
   call lap("SETUP + GPU RUNTIME")
   print *, "- DEFINE TARGET GRID"
@@ -60,7 +65,12 @@ program mpassit
   print *, "- DEFINE INPUT GRID"
   call define_input_grid()
   call lap("DEFINE INPUT GRID")
-  if (dev_flow) call plan_source_window()
+  if (dev_flow .and. .not. no_window) then
+    call plan_source_window()
+    call lap("PLAN WEIGHT SETS + SOURCE WINDOW")
+  else if (dev_flow) then
+    call nc_upload_hgt()
+  end if
   print *, "- READ INPUT DATA"
   call read_input_data()
   call lap("READ INPUT DATA")

@@ -191,6 +191,54 @@ module mpg
       integer(c_int64_t), value :: first, count
       integer(c_int) :: rc
     end function mpg_mesh_set_source_window
+    !> several GPUs, one image per GPU, RCCL underneath (include/mpassit_amd.h): communicator, halo schedule of a route
+    !! handle + its exchange, ESMF_FieldGather.  id_file: a path all images see, fresh per run (image 0 writes the id).
+    function mpg_comm_init(rank, nranks, id_file, comm) bind(C, name="mpg_comm_init") result(rc)
+      import :: c_int, c_char, c_ptr
+      integer(c_int), value :: rank, nranks
+      character(kind=c_char), intent(in) :: id_file(*)
+      type(c_ptr), intent(out) :: comm
+      integer(c_int) :: rc
+    end function mpg_comm_init
+    function mpg_comm_destroy(comm) bind(C, name="mpg_comm_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: comm
+      integer(c_int) :: rc
+    end function mpg_comm_destroy
+    function mpg_halo_build(comm, rh, n_cells_global, ownership, halo) bind(C, name="mpg_halo_build") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: comm, rh
+      integer(c_int64_t), value :: n_cells_global
+      integer(c_int), value :: ownership
+      type(c_ptr), intent(out) :: halo
+      integer(c_int) :: rc
+    end function mpg_halo_build
+    function mpg_halo_info(halo, mode, n_local, own, base, own_pos, sent_per_row, received_per_row) bind(C, name="mpg_halo_info") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: halo
+      integer(c_int), intent(out) :: mode
+      integer(c_int64_t), intent(out) :: n_local, own(2), base, own_pos(2), sent_per_row, received_per_row
+      integer(c_int) :: rc
+    end function mpg_halo_info
+    function mpg_halo_exchange_dev(halo, own_dev, own_ld, local_dev, nrows, elem_bytes, stream) bind(C, name="mpg_halo_exchange_dev") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: halo, own_dev, local_dev, stream
+      integer(c_int64_t), value :: own_ld
+      integer(c_int), value :: nrows, elem_bytes
+      integer(c_int) :: rc
+    end function mpg_halo_exchange_dev
+    function mpg_halo_destroy(halo) bind(C, name="mpg_halo_destroy") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: halo
+      integer(c_int) :: rc
+    end function mpg_halo_destroy
+    function mpg_gather_rows(comm, rows_dev, j0, j1, nx, ny, nlev, elem_bytes, dst_dev, root, stream) bind(C, name="mpg_gather_rows") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: comm, rows_dev, dst_dev, stream
+      integer(c_int64_t), value :: j0, j1, nx, ny
+      integer(c_int), value :: nlev, elem_bytes, root
+      integer(c_int) :: rc
+    end function mpg_gather_rows
     function mpg_bswap_dev(buf, n, elem_size, stream) bind(C, name="mpg_bswap_dev") result(rc)
       import :: c_int, c_int64_t, c_ptr
       type(c_ptr), value :: buf, stream
