@@ -330,6 +330,10 @@ int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, con
  *   "lf_variant"  level-fast (file-order) 3-point Regrid: -1 per-handle choice (default), 0 row gather on linear aligned
  *                 tiles, 1 LDS-staged in 16-level chunks, 2 row gather on grid-row tiles (the capacity fallback)
  *   "nn_variant"  nearest-neighbour search: 1 wave-cooperative (default), 0 one thread per point
+ * and one that does NOT (it selects between two readings of ESMF's undocumented-here behaviour):
+ *   "bilinear_linetype"   Mesh -> Grid bilinear Store: 0 (default) the target point meets the plane of its source triangle
+ *                 along the ray from the sphere's centre; 1 along the plane's normal (ESMF_LINETYPE_CART read literally).
+ *                 In force at mpg_regrid_store time; the two differ by O(h^2) of the triangle size
  *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice (default 35)
  * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */
 int mpg_tune(const char *key, int value);

@@ -35,6 +35,26 @@ __device__ __forceinline__ bool tri_weights(dv3 P, dv3 A, dv3 B, dv3 C, double t
   return w[0] >= -tol && w[1] >= -tol && w[2] >= -tol;
 }
 
+// The other reading of "straight cell edges on a sphere": P is dropped onto the triangle's plane along the plane's NORMAL
+// (ESMF_LINETYPE_CART taken literally: the element is a flat triangle of 3-D space and the point is located in its local
+// coordinates) instead of along the ray from the sphere's centre as above, and takes the barycentric coordinates of its
+// foot.  The two differ by O(h^2) of the triangle size; selected per Store with mpg_tune("bilinear_linetype", 1).
+__device__ __forceinline__ bool tri_weights_normal(dv3 P, dv3 A, dv3 B, dv3 C, double tol, double *w) {
+  dv3 n = cross3(B - A, C - A);
+  double nn = dot3(n, n);
+  if (!(nn > 0.0) || !(dot3(n, P) > 0.0)) return false;
+  double d = dot3(P - A, n) / nn;
+  dv3 F = P - n * d;
+  dv3 a = A - F, b = B - F, c = C - F;
+  double dA = dot3(n, cross3(b, c)), dB = dot3(n, cross3(c, a)), dC = dot3(n, cross3(a, b));
+  double S = dA + dB + dC;
+  if (!(S > 0.0)) return false;
+  w[0] = dA / S;
+  w[1] = dB / S;
+  w[2] = dC / S;
+  return w[0] >= -tol && w[1] >= -tol && w[2] >= -tol;
+}
+
 // A6: squared chord distance, evaluated as ((dx^2 + dy^2) + dz^2) WITHOUT fma so that host (oracle) and
 // device agree bit for bit and box lower bounds stay monotone.
 __device__ __forceinline__ double dist2_nofma(double px, double py, double pz, double cx, double cy, double cz) {

@@ -17,6 +17,7 @@
 
 #define RASTER_STACK 64
 
+template <bool NORMAL>
 __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t *__restrict__ tri, int64_t triStride,
                                                     const double *__restrict__ cx, const double *__restrict__ cy,
                                                     const double *__restrict__ cz, PyramidView pyr, int npx, int npy,
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
           dv3 P = dv3{px[p], py[p], pz[p]};
           if (P.x < lo[0] || P.x > hi[0] || P.y < lo[1] || P.y > hi[1] || P.z < lo[2] || P.z > hi[2]) continue;
           double w[3];
-          if (tri_weights(P, A, B, C, MPG_TOL, w)) atomicMin(&owner[p], (int32_t)t);
+          if (NORMAL ? tri_weights_normal(P, A, B, C, MPG_TOL, w) : tri_weights(P, A, B, C, MPG_TOL, w)) atomicMin(&owner[p], (int32_t)t);
         }
     } else {
       int cnx = pyr.nx[lev - 1], cny = pyr.ny[lev - 1];
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
 }
 
 // one thread per target point: weights of the owning triangle, SoA output
+template <bool NORMAL>
 __global__ __launch_bounds__(256) void k_tri_finalize(int64_t P, const int32_t *__restrict__ owner,
                                                       const int32_t *__restrict__ tri, int64_t triStride,
                                                       const double *__restrict__ cx, const double *__restrict__ cy,
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(256) void k_tri_finalize(int64_t P, const int32_t *
     i1 = tri[triStride + t];
     i2 = tri[2 * triStride + t];
     dv3 Pt = dv3{px[p], py[p], pz[p]};
-    tri_weights(Pt, ld3(cx, cy, cz, i0), ld3(cx, cy, cz, i1), ld3(cx, cy, cz, i2), MPG_TOL, ww);
+    if (NORMAL) tri_weights_normal(Pt, ld3(cx, cy, cz, i0), ld3(cx, cy, cz, i1), ld3(cx, cy, cz, i2), MPG_TOL, ww);
+    else tri_weights(Pt, ld3(cx, cy, cz, i0), ld3(cx, cy, cz, i1), ld3(cx, cy, cz, i2), MPG_TOL, ww);
   }
   idx[p] = i0;
   idx[P + p] = i1;
@@ -192,11 +195,12 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   if ((rc = ovf.alloc(1))) return rc;
   MPG_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
   k_fill_i32<<<fb, 256, 0, s>>>(P, 0x7fffffff, owner.p);
-  k_tri_raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sp->x.p, sp->y.p, sp->z.p,
-                                                           mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p,
-                                                           pts.z.p, owner.p, ovf.p);
-  k_tri_finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sp->x.p, sp->y.p, sp->z.p, pts.x.p, pts.y.p,
-                                                            pts.z.p, h->idx.p, h->w.p);
+  auto raster = mpg_bilinear_linetype() ? k_tri_raster<true> : k_tri_raster<false>;
+  auto finalize = mpg_bilinear_linetype() ? k_tri_finalize<true> : k_tri_finalize<false>;
+  raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sp->x.p, sp->y.p, sp->z.p, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p,
+                                                     pts.y.p, pts.z.p, owner.p, ovf.p);
+  finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sp->x.p, sp->y.p, sp->z.p, pts.x.p, pts.y.p, pts.z.p, h->idx.p,
+                                                      h->w.p);
   MPG_HIP(hipGetLastError());
   int32_t h_ovf = 0;
   MPG_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));

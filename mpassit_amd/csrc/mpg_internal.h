@@ -302,6 +302,7 @@ int mpg_k_post_ptop_parts(const double *src, int nlev, int64_t P, double *vmax_h
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);
+int mpg_bilinear_linetype();   // "bilinear_linetype" knob: 0 ray from the centre (default), 1 along the triangle's normal
 int mpg_nearest_variant();
 void mpg_set_nearest_variant(int v);
 int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s, bool keep_global = false);

@@ -207,6 +207,29 @@ static inline int tri_weights(v3 P, v3 A, v3 B, v3 C, double tol, double *w) {
   return (w[0] >= -tol && w[1] >= -tol && w[2] >= -tol);
 }
 
+/* The other reading of "straight cell edges on a sphere" (ESMF_LINETYPE_CART taken literally): the destination point is
+ * dropped onto the triangle's plane along the plane's NORMAL instead of along the ray from the sphere's centre, and takes
+ * the barycentric coordinates of its foot.  The two differ by O(h^2) of the triangle size h; orc_set_linetype(1) selects
+ * this form for orc_bilinear_weights (Mesh -> Grid only) so that the difference can be measured. */
+static int g_orc_linetype = 0;
+void orc_set_linetype(int v) { g_orc_linetype = v; }
+static inline int tri_weights_normal(v3 P, v3 A, v3 B, v3 C, double tol, double *w) {
+  v3 n = v3cross(v3sub(B, A), v3sub(C, A));
+  double nn = v3dot(n, n);
+  if (!(nn > 0) || !(v3dot(n, P) > 0)) return 0;
+  double d = v3dot(v3sub(P, A), n) / nn;
+  v3 F = {P.x - d * n.x, P.y - d * n.y, P.z - d * n.z};
+  v3 a = v3sub(A, F), b = v3sub(B, F), c = v3sub(C, F);
+  double dA = v3dot(n, v3cross(b, c)), dB = v3dot(n, v3cross(c, a)), dC = v3dot(n, v3cross(a, b));
+  double S = dA + dB + dC;
+  if (!(S > 0)) return 0;
+  w[0] = dA / S; w[1] = dB / S; w[2] = dC / S;
+  return (w[0] >= -tol && w[1] >= -tol && w[2] >= -tol);
+}
+static inline int tri_weights_lt(v3 P, v3 A, v3 B, v3 C, double tol, double *w) {
+  return g_orc_linetype ? tri_weights_normal(P, A, B, C, tol, w) : tri_weights(P, A, B, C, tol, w);
+}
+
 static double tri_maxedge(v3 A, v3 B, v3 C) {
   v3 ab = v3sub(B, A), bc = v3sub(C, B), ca = v3sub(A, C);
   double e = fmax(v3dot(ab, ab), fmax(v3dot(bc, bc), v3dot(ca, ca)));
@@ -246,14 +269,14 @@ void orc_bilinear_weights(int64_t nCells, const double *cell_xyz, int64_t nTri, 
       int32_t t = h.items[q];
       if (best >= 0 && t >= best) continue;
       if (Pt.x < lo[3 * t] || Pt.x > hi[3 * t] || Pt.y < lo[3 * t + 1] || Pt.y > hi[3 * t + 1] || Pt.z < lo[3 * t + 2] || Pt.z > hi[3 * t + 2]) continue;
-      if (tri_weights(Pt, v3load(cell_xyz, tri[3 * t]), v3load(cell_xyz, tri[3 * t + 1]), v3load(cell_xyz, tri[3 * t + 2]), ORC_TOL, wt)) {
+      if (tri_weights_lt(Pt, v3load(cell_xyz, tri[3 * t]), v3load(cell_xyz, tri[3 * t + 1]), v3load(cell_xyz, tri[3 * t + 2]), ORC_TOL, wt)) {
         best = t; bw[0] = wt[0]; bw[1] = wt[1]; bw[2] = wt[2];
       }
     }
     for (int64_t q = 0; q < h.nbig; ++q) {
       int32_t t = h.big[q];
       if (best >= 0 && t >= best) continue;
-      if (tri_weights(Pt, v3load(cell_xyz, tri[3 * t]), v3load(cell_xyz, tri[3 * t + 1]), v3load(cell_xyz, tri[3 * t + 2]), ORC_TOL, wt)) {
+      if (tri_weights_lt(Pt, v3load(cell_xyz, tri[3 * t]), v3load(cell_xyz, tri[3 * t + 1]), v3load(cell_xyz, tri[3 * t + 2]), ORC_TOL, wt)) {
         best = t; bw[0] = wt[0]; bw[1] = wt[1]; bw[2] = wt[2];
       }
     }

@@ -79,12 +79,18 @@ def fan_triangles(voc, vert_xyz):
     return ftri, int(n)
 
 
-def bilinear_weights(cell_xyz, tri, pt_xyz):
+def bilinear_weights(cell_xyz, tri, pt_xyz, linetype=0):
+    """linetype 0: the destination point meets the triangle's plane along the ray from the sphere's centre (the default of
+    oracle and kernels); 1: along the plane's normal (ESMF_LINETYPE_CART read literally) -- DESIGN.md s2."""
     cell_xyz, tri, pt_xyz = _c(cell_xyz, np.float64), _c(tri, np.int32), _c(pt_xyz, np.float64)
     P = pt_xyz.shape[0]
     idx, w = np.empty((P, 3), np.int32), np.empty((P, 3))
-    lib().orc_bilinear_weights(C.c_int64(cell_xyz.shape[0]), cell_xyz.ctypes, C.c_int64(tri.shape[0]), tri.ctypes,
-                               C.c_int64(P), pt_xyz.ctypes, idx.ctypes, w.ctypes)
+    lib().orc_set_linetype(C.c_int(int(linetype)))
+    try:
+        lib().orc_bilinear_weights(C.c_int64(cell_xyz.shape[0]), cell_xyz.ctypes, C.c_int64(tri.shape[0]), tri.ctypes,
+                                   C.c_int64(P), pt_xyz.ctypes, idx.ctypes, w.ctypes)
+    finally:
+        lib().orc_set_linetype(C.c_int(0))
     return idx, w
 
 

@@ -7,7 +7,9 @@ DIFFERENT route at 50 digits (mpmath):
 
 * bilinear on a dual triangle (A2): the weights of target point P in triangle (A, B, C) of unit vectors are the solution of
   A + u (B - A) + v (C - A) = t P, w = (1 - u - v, u, v) -- here by solving the 3 x 3 linear system for (u, v, t) (the code
-  under test uses the determinant closed form in difference form);
+  under test uses the determinant closed form in difference form); and `w_normal`, the barycentric coordinates of the foot
+  of P on the triangle's plane along the plane's normal -- the other reading of straight cell edges on a sphere
+  ("bilinear_linetype" 1), by a second 3 x 3 solve;
 * first-order conservative (A5): w = Area(src ^ dst) / Area(dst) with great-circle sides -- here the intersection polygon
   from Sutherland-Hodgman clipping carried out at 50 digits, and areas from GIRARD's theorem (sum of the interior angles
   minus (n - 2) pi) instead of the code's triangle fan with the Van Oosterom-Strackee formula.
@@ -67,6 +69,16 @@ def tri_weights(A, B, C, P):
     rhs = mp.matrix([-A[0], -A[1], -A[2]])
     u, v, t = mp.lu_solve(M, rhs)
     return [1 - u - v, u, v], t
+
+
+# ---- the same triangle with the point dropped along the plane's NORMAL (ESMF_LINETYPE_CART read literally; the code's
+# "bilinear_linetype" 1): solve [B-A, C-A, n] (u, v, s)^T = P - A with n = (B - A) x (C - A)
+def tri_weights_normal(A, B, C, P):
+    n = cross(sub(B, A), sub(C, A))
+    M = mp.matrix([[B[0] - A[0], C[0] - A[0], n[0]], [B[1] - A[1], C[1] - A[1], n[1]], [B[2] - A[2], C[2] - A[2], n[2]]])
+    rhs = mp.matrix([P[0] - A[0], P[1] - A[1], P[2] - A[2]])
+    u, v, _ = mp.lu_solve(M, rhs)
+    return [1 - u - v, u, v]
 
 
 # ---- conservative: great-circle clipping + Girard ----------------------------------------------------------------------
@@ -138,7 +150,8 @@ def main():
             P = as_f64(unit([A[i] * (1 - a - b) + B[i] * a + C[i] * b for i in range(3)]))
             w, t = tri_weights(A, B, C, lift(P))
             assert t > 0 and all(x > 0 for x in w)
-            bil.append(dict(scale_km=scale_km, tri=tri, p=P, w=as_f64(w)))
+            wn = tri_weights_normal(A, B, C, lift(P))
+            bil.append(dict(scale_km=scale_km, tri=tri, p=P, w=as_f64(w), w_normal=as_f64(wn)))
     cons = []
     for scale_km, ratio in ((3.0, 1.0), (30.0, 0.1), (30.0, 1.3), (120.0, 0.4), (500.0, 0.05)):
         for _ in range(6):

@@ -12,15 +12,18 @@ import pytest
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "weights_hp.json")))
 
 
-def test_bilinear_triangle_weights(oracle):
+@pytest.mark.parametrize("linetype", [0, 1])
+def test_bilinear_triangle_weights(oracle, linetype):
+    """linetype 0: the point meets the triangle's plane along the ray from the centre (golden `w`); 1: along the plane's
+    normal (golden `w_normal`) -- the two readings of straight cell edges on a sphere, DESIGN.md s2."""
     worst = {}
     for c in GOLD["bilinear"]:
         tri = np.array(c["tri"])
-        idx, w = oracle.bilinear_weights(tri, np.array([[0, 1, 2]], np.int32), np.array([c["p"]]))
+        idx, w = oracle.bilinear_weights(tri, np.array([[0, 1, 2]], np.int32), np.array([c["p"]]), linetype=linetype)
         assert sorted(idx[0].tolist()) == [0, 1, 2], c
         got = np.empty(3)
         got[idx[0]] = w[0]                                   # weight of vertex k, whatever order the triangle is stored in
-        err = np.abs(got - np.array(c["w"])).max()
+        err = np.abs(got - np.array(c["w_normal" if linetype else "w"])).max()
         worst[c["scale_km"]] = max(worst.get(c["scale_km"], 0.0), err)
         assert abs(got.sum() - 1) < 4e-16
     # the difference form keeps km-scale triangles as accurate as continental ones
@@ -77,7 +80,8 @@ def _latlon_rad(xyz):
 
 
 @pytest.mark.gpu
-def test_bilinear_goldens_through_the_c_abi(gpu_lib):
+@pytest.mark.parametrize("linetype", [0, 1])
+def test_bilinear_goldens_through_the_c_abi(gpu_lib, linetype):
     from mpassit_amd import regrid as R
     cases = GOLD["bilinear"]
     n = len(cases)
@@ -92,7 +96,11 @@ def test_bilinear_goldens_through_the_c_abi(gpu_lib):
     lat, lon = np.degrees(latp)[None, :], np.degrees(lonp)[None, :]          # a 1 x n "grid" of the target points
     pad = lambda a, ny, nx: np.resize(a, (ny, nx))                           # the staggered companions are not used by this Store
     grid = R.Grid(lon, lat, pad(lon, 2, n + 1), pad(lat, 2, n + 1), pad(lon, 1, n + 1), pad(lat, 1, n + 1), pad(lon, 2, n), pad(lat, 2, n))
-    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    gpu_lib.tune("bilinear_linetype", linetype)
+    try:
+        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    finally:
+        gpu_lib.tune("bilinear_linetype", 0)
     idx, w = rh.weights()
     checked, worst = 0, 0.0
     for v, c in enumerate(cases):
@@ -100,9 +108,9 @@ def test_bilinear_goldens_through_the_c_abi(gpu_lib):
             continue                 # the point also lies in another, lower-numbered random triangle: that one wins, by design
         got = np.empty(3)
         got[idx[v] - 3 * v] = w[v]
-        worst = max(worst, np.abs(got - np.array(c["w"])).max())
+        worst = max(worst, np.abs(got - np.array(c["w_normal" if linetype else "w"])).max())
         checked += 1
-    print("bilinear through the C-ABI: %d triangles checked, worst |dw| %.2e" % (checked, worst))
+    print("bilinear (linetype %d) through the C-ABI: %d triangles checked, worst |dw| %.2e" % (linetype, checked, worst))
     assert checked >= n - 4 and worst < 5e-12, (checked, worst)
     rh.release()
     mesh.destroy()
