@@ -442,29 +442,37 @@ def production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint):
 def store_leg(R, sr, m, g):
     """RegridStore of the three methods on the headline mesh and grid (weights are data: built once per run, cached), as
     points/s with the algorithmic bytes of SURVEY s8(d): P*16 (target coordinates) + T*(3*4 + 48) (elements: ids + box) +
-    the weights written."""
+    the weights written.  Two repetitions on fresh mesh / grid objects (nothing from the handle cache); ms = the faster,
+    ms_first = the process's very first Store of that method (search-structure allocations included)."""
     P = int(g.nx * g.ny)
-    res = {}
-    mesh, grid = sr.mesh, sr.grid
     nT, nC, nE = int(m.nVertices), int(m.nCells), int(m.verticesOnCell.shape[1])
-    for name, code in (("bilinear", R.REGRIDMETHOD_BILINEAR), ("nearest", R.REGRIDMETHOD_NEAREST_STOD), ("conserve", R.REGRIDMETHOD_CONSERVE)):
-        if name == "bilinear":
-            rh, ms = sr.rh, sr.store_ms
-        else:
+    codes = (("bilinear", R.REGRIDMETHOD_BILINEAR), ("nearest", R.REGRIDMETHOD_NEAREST_STOD), ("conserve", R.REGRIDMETHOD_CONSERVE))
+    ms = {name: [] for name, _ in codes}
+    nnz = {}
+    ms["bilinear"].append(sr.store_ms)
+    for rep in range(2):
+        mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+        for name, code in codes:
             rh = R.regrid_store(mesh, grid, code)
-            ms = rh.store_ms
+            ms[name].append(rh.store_ms)
+            nnz[name] = int(rh.nnz)
+            rh.release()
+        mesh.destroy()
+        grid.destroy()
+    res = {}
+    for name, _ in codes:
         if name == "bilinear":
             alg = P * 16.0 + nT * (12.0 + 48.0) + P * 36.0
         elif name == "nearest":
             alg = P * 16.0 + nC * (24.0 + 4.0) + P * 4.0
         else:
-            alg = (P + g.nx + g.ny + 1) * 16.0 + nC * (nE * 4.0 + 48.0) + nT * 16.0 + rh.nnz * 12.0 + (P + 1) * 4.0
-        res[name] = {"ms": ms, "points_per_s": P / (ms * 1e-3), "alg_bytes": alg, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "nnz": int(rh.nnz)}
-        if name != "bilinear":
-            rh.release()
-    res["what"] = ("mpg_handle_store_ms of a cold Store (search structure + search + weights), %d target points; not memory-bound: what binds "
-                   "each kernel is in profiles/r03_store_pmc.md" % P)
+            alg = (P + g.nx + g.ny + 1) * 16.0 + nC * (nE * 4.0 + 48.0) + nT * 16.0 + nnz[name] * 12.0 + (P + 1) * 4.0
+        best = min(ms[name])
+        res[name] = {"ms": best, "ms_first": ms[name][0], "points_per_s": P / (best * 1e-3), "alg_bytes": alg,
+                     "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "nnz": nnz[name]}
+    res["what"] = ("mpg_handle_store_ms of a cold Store (search structure + search + weights), %d target points; none of them is "
+                   "memory-bound: what binds each kernel (wave cycles parked / issue-stalled / active, lane utilisation, scratch) is in "
+                   "profiles/r03_store_pmc.md" % P)
     return res
 
 

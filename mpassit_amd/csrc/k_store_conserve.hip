@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void k_csr_sort_rows(int64_t P, const int32_t 
 // the candidate pairs (source cell, destination cell) that survive the box / bounding-sphere tests (k_conserve_raster<3>),
 // and one thread per PAIR clips it (balanced: no lane waits for a neighbour with more candidates) with both polygon
 // buffers in LDS, laid out [buffer][vertex][component][lane] so that any per-lane vertex index is conflict-free.
-// Same arithmetic in the same order as clip_area / clip_halfspace above -> bit-identical weights.
+// The arithmetic is the oracle's (oracle/mpassit_oracle.c, clip planes with normals in difference form a x (b - a)): that
+// is the stated reference of the weights, not the round-1 kernel.
 __global__ __launch_bounds__(256) void k_conserve_clamp_counts(int64_t nCells, const int32_t *__restrict__ cnt_src, int32_t *__restrict__ npair) {
   int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c > nCells) return;
@@ -281,20 +282,28 @@ struct LdsPoly {   // vertex i of polygon buffer `buf` of this lane
     p[2 * CLIP_NT] = v.z;
   }
 };
-// clip_halfspace with the buffers in LDS: the same operations in the same order (cap = CONS_BUF of the private version)
-__device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, int in, dv3 nrm, int out, int cap) {
+// Sutherland-Hodgman step with the buffers in LDS.  A CONVEX polygon gains at most one vertex per half-space, so `cap` =
+// maxEdges + 6 slots always hold it; a non-convex cell can gain more, and a vertex that does not fit is reported through
+// *trunc (the Store then fails with MPG_ERR_OVERFLOW), never dropped silently.
+__device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, int in, dv3 nrm, int out, int cap, int *trunc = nullptr) {
   int m = 0;
   double eps = 1e-15 * sqrt(dot3(nrm, nrm));
   for (int i = 0; i < n; ++i) {
     dv3 X1 = L.get(in, i), X2 = L.get(in, (i + 1 == n) ? 0 : i + 1);
     double d1 = dot3(nrm, X1), d2 = dot3(nrm, X2);
     bool in1 = d1 >= -eps, in2 = d2 >= -eps;
-    if (in1 && m < cap) L.set(out, m++, X1);
-    if (in1 != in2 && m < cap) {
+    if (in1) {
+      if (m < cap) L.set(out, m++, X1);
+      else if (trunc) *trunc = 1;
+    }
+    if (in1 != in2) {
       dv3 X = X1 * d2 - X2 * d1;
       double sgn = (d2 - d1) > 0.0 ? 1.0 : -1.0;
       double nn = sqrt(dot3(X, X));
-      if (nn > 0.0) L.set(out, m++, X * (sgn / nn));
+      if (nn > 0.0) {
+        if (m < cap) L.set(out, m++, X * (sgn / nn));
+        else if (trunc) *trunc = 1;
+      }
     }
   }
   return m;
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
                                                                  const uint8_t *__restrict__ flip, int nx, const double *__restrict__ qx,
                                                                  const double *__restrict__ qy, const double *__restrict__ qz,
                                                                  const double *__restrict__ qarea, int cb, double *__restrict__ pair_val,
-                                                                 int32_t *__restrict__ count) {
+                                                                 int32_t *__restrict__ count, int32_t *__restrict__ truncated) {
   extern __shared__ double clip_lds[];   // [2][cb][3][CLIP_NT]
   const int64_t t = blockIdx.x * (int64_t)CLIP_NT + threadIdx.x;
   if (t >= npairs) return;
@@ -330,6 +339,7 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
   double aq = qarea[p];
   if (aq < 0.0) { dv3 tq = q[1]; q[1] = q[3]; q[3] = tq; aq = -aq; }
   double ar = 0.0;
+  int trunc = 0;
   if (aq > 0.0) {
     int cur = 0;
     for (int e = 0; e < 4 && n >= 3; ++e) {
@@ -338,7 +348,7 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
       dv3 side = qb - qa;
       if (dot3(side, side) < 1e-24) continue;     // collapsed side (pole): bounds nothing
       // a x (b - a) = a x b in difference form: the direct product's rounding would shift the plane by 1e-16 / |b - a| radians
-      n = clip_halfspace_lds(n, L, cur, cross3(qa, side), cur ^ 1, cb);
+      n = clip_halfspace_lds(n, L, cur, cross3(qa, side), cur ^ 1, cb, &trunc);
       cur ^= 1;
     }
     if (n >= 3) {
@@ -354,6 +364,7 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
     atomicAdd(&count[p], 1);
   }
   pair_val[t] = ratio;
+  if (trunc) atomicOr(truncated, 1);
 }
 __global__ __launch_bounds__(256) void k_conserve_scatter_pairs(int64_t npairs, const int32_t *__restrict__ pair_c, const int32_t *__restrict__ pair_p,
                                                                 const double *__restrict__ pair_val, const int32_t *__restrict__ rowptr,
@@ -425,9 +436,21 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   int32_t npairs = 0;
   MPG_HIP(hipMemcpyAsync(&npairs, poff.p + nC, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
-  if (npairs < 0) {
-    mpg_set_error("conservative RegridStore: more than 2^31 candidate pairs");
-    return MPG_ERR_OVERFLOW;
+  {   // the int32 scan could wrap more than once: the pair count again as a 64-bit sum
+    TmpBuf<long long> tot;
+    TmpBuf<char> t2;
+    size_t b3 = 0;
+    if ((rc = tot.alloc(1))) return rc;
+    MPG_HIP(rocprim::reduce(nullptr, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
+    if ((rc = t2.alloc(b3 + 16))) return rc;
+    MPG_HIP(rocprim::reduce((void *)t2.p, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
+    long long total = 0;
+    MPG_HIP(hipMemcpyAsync(&total, tot.p, sizeof(total), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    if (npairs < 0 || total != (long long)npairs) {
+      mpg_set_error("conservative RegridStore: %lld candidate pairs exceed 2^31", total);
+      return MPG_ERR_OVERFLOW;
+    }
   }
   if ((rc = pair_c.alloc((size_t)npairs + 1)) || (rc = pair_p.alloc((size_t)npairs + 1)) || (rc = pair_val.alloc((size_t)npairs + 1))) return rc;
   k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
@@ -442,16 +465,24 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   const size_t clip_lds_bytes = sizeof(double) * 2 * cb * 3 * CLIP_NT;
   if (clip_lds_bytes > 48 * 1024)
     MPG_HIP(hipFuncSetAttribute((const void *)k_conserve_clip_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clip_lds_bytes));
+  TmpBuf<int32_t> truncated;
+  if ((rc = truncated.alloc(1))) return rc;
+  MPG_HIP(hipMemsetAsync(truncated.p, 0, sizeof(int32_t), s));
   if (npairs > 0)
     k_conserve_clip_pairs<<<(unsigned)(((int64_t)npairs + CLIP_NT - 1) / CLIP_NT), CLIP_NT, clip_lds_bytes, s>>>(
         npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
-        pair_val.p, count.p);
+        pair_val.p, count.p, truncated.p);
   MPG_HIP(hipGetLastError());
   tmp_bytes = b2;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
-  int32_t nnz = 0;
+  int32_t nnz = 0, was_truncated = 0;
   MPG_HIP(hipMemcpyAsync(&nnz, h->rowptr.p + P, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipMemcpyAsync(&was_truncated, truncated.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
+  if (was_truncated) {
+    mpg_set_error("conservative RegridStore: a clipped polygon outgrew its %d vertex slots (a non-convex source cell?)", cb);
+    return MPG_ERR_OVERFLOW;
+  }
   if (nnz < 0) {
     mpg_set_error("conservative weight matrix exceeds 2^31 entries");
     return MPG_ERR_OVERFLOW;

@@ -193,17 +193,23 @@ def read_file_meta(r, meta, diag=False):
     return meta
 
 
-def xtime_minutes(start_time, valid_time):
-    """XTIME as write_target_data computes it (write_data.F90:1211-1227): datetime(start) - datetime(valid), in minutes --
-    the reference subtracts in THIS order, so a valid time after the start gives a negative XTIME; kept as written."""
+def xtime_seconds(start_time, valid_time):
+    """datetime(start) - datetime(valid) in whole seconds, as write_target_data has it (write_data.F90:1211-1227): the
+    reference subtracts in THIS order, so a valid time after the start gives a negative value; kept as written.  XTIME is
+    this / 60 and ITIMESTEP int(this / config_dt) (:1233-1240) -- both from the seconds, like the reference and the Fortran
+    host (seconds -> minutes -> seconds can land one ulp below a multiple of config_dt and truncate one step short)."""
     import datetime as dtm
 
     def parse(s):
         return dtm.datetime(int(s[0:4]), int(s[5:7]), int(s[8:10]), int(s[11:13]), int(s[14:16]), int(s[17:19]))
     try:
-        return (parse(start_time) - parse(valid_time)).total_seconds() / 60.0
+        return (parse(start_time) - parse(valid_time)).total_seconds()
     except ValueError:
         return 0.0
+
+
+def xtime_minutes(start_time, valid_time):
+    return xtime_seconds(start_time, valid_time) / 60.0
 
 
 def read_input_data(hist_path, cfg, ter, diag_path=None, device=None):
@@ -370,10 +376,10 @@ def write_target_data(path, target, grid, res, cfg, nz, nzp1, nsoil, valid_time=
             w.put("COSALPHA", cosa, rec=0)
         w.put("ZS", np.zeros(max(nsoil, 1), np.float32) if zs is None else np.asarray(zs, np.float32), rec=0)
         w.put("Times", valid_time.encode()[:DATESTRLEN].ljust(DATESTRLEN), rec=0)
-        xt = xtime_minutes(start_time, valid_time)                                                                          # :1211-1240
+        xs = xtime_seconds(start_time, valid_time)                                                                          # :1211-1240
         dt_cfg = float(meta.get("config_dt", 0.0))
-        w.put("XTIME", np.array([xt], np.float32), rec=0)
-        w.put("ITIMESTEP", np.array([int(xt * 60.0 / dt_cfg) if dt_cfg > 0.0 else 0], np.int32), rec=0)
+        w.put("XTIME", np.array([xs / 60.0], np.float32), rec=0)
+        w.put("ITIMESTEP", np.array([int(xs / dt_cfg) if dt_cfg > 0.0 else 0], np.int32), rec=0)
         for name, a in arrays.items():
             if _is_dev(a):
                 _put_dev(w, name, a)
