@@ -121,6 +121,12 @@ class Reader:
         self.close()
 
 
+def reserve_start(path, nbytes):
+    """Start allocating `nbytes` (an upper bound) for an output file on a helper thread; the next Writer(path) keeps that
+    file instead of truncating it and close() trims it (ncio_reserve_start)."""
+    _check(lib().ncio_reserve_start(str(path).encode(), C.c_int64(int(nbytes))))
+
+
 class Writer:
     """nf90_create ... nf90_close.  Define dimensions / variables / attributes, then put()."""
 

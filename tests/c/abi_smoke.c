@@ -2,7 +2,9 @@
  * proves the boundary is a real C-ABI.  Mesh = the 4-cell "tetrahedral" Voronoi diagram of the sphere
  * (cells at the tetrahedron vertices, Voronoi vertices at their antipodes, 3 cells per vertex), target = a
  * 12 x 6 global lat-lon grid.  Checks: constants are reproduced by bilinear and conservative regridding, nearest
- * returns one of the 4 source values bit for bit, the handle cache returns the same handle, errors are reported. */
+ * returns one of the 4 source values bit for bit, the handle cache returns the same handle, errors are reported; the
+ * device-resident typed Regrid takes and produces big-endian float32 (the bytes of a NetCDF classic variable); the source
+ * range of a handle and the mesh's source window; a one-rank communicator, halo schedule, exchange and row gather (RCCL). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -87,6 +89,85 @@ int main(void) {
         }
       }
     CHECK(mpg_handle_release(rh));
+  }
+  /* ---- fused ingest / egress on device buffers: big-endian float32 in, big-endian float32 out (T - 300 fused) ---- */
+  {
+    mpg_handle rh;
+    CHECK(mpg_regrid_store(mesh, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_NEAREST_STOD, &rh));
+    const float f32[4] = {301.0f, 302.0f, 303.0f, 304.0f};
+    unsigned char be_in[16], be_out[NY * NX * 4];
+    for (int i = 0; i < 4; ++i) {
+      unsigned char raw[4];
+      memcpy(raw, &f32[i], 4);
+      for (int b = 0; b < 4; ++b) be_in[4 * i + b] = raw[3 - b];   /* as a classic NetCDF file stores it (this host is little-endian) */
+    }
+    void *s_dev, *d_dev;
+    CHECK(mpg_dev_alloc(16, &s_dev));
+    CHECK(mpg_dev_alloc(NY * NX * 4, &d_dev));
+    CHECK(mpg_dev_upload(s_dev, be_in, 16));
+    CHECK(mpg_regrid_typed_dev(rh, s_dev, MPG_TYPE_F32 | MPG_TYPE_BE, MPG_LAYOUT_CELL_FAST, 1, 1, d_dev, MPG_TYPE_F32 | MPG_TYPE_BE, 1.0, -300.0, NULL));
+    CHECK(mpg_dev_download(be_out, d_dev, NY * NX * 4));
+    for (int p = 0; p < NY * NX; ++p) {
+      unsigned char raw[4];
+      float v;
+      for (int b = 0; b < 4; ++b) raw[b] = be_out[4 * p + 3 - b];
+      memcpy(&v, raw, 4);
+      if (v != 1.0f && v != 2.0f && v != 3.0f && v != 4.0f) {
+        fprintf(stderr, "FAIL big-endian typed Regrid: point %d = %.9g\n", p, v);
+        return 1;
+      }
+    }
+    /* ---- source range and source window: all four cells are referenced; the whole mesh is the only window that fits ---- */
+    int64_t first = -1, end = -1;
+    CHECK(mpg_handle_source_range(rh, &first, &end));
+    if (first != 0 || end != 4) {
+      fprintf(stderr, "FAIL source range [%lld, %lld)\n", (long long)first, (long long)end);
+      return 1;
+    }
+    if (mpg_mesh_set_source_window(mesh, MPG_MESHLOC_ELEMENT, 1, 3) == MPG_SUCCESS) {
+      fprintf(stderr, "FAIL: a window that cuts into a handle must be refused\n");
+      return 1;
+    }
+    CHECK(mpg_mesh_set_source_window(mesh, MPG_MESHLOC_ELEMENT, 0, 4));
+    /* ---- one rank of the multi-GPU verbs: communicator, halo schedule of this handle, exchange, row gather ---- */
+    mpg_comm comm;
+    mpg_halo halo;
+    CHECK(mpg_comm_init(0, 1, NULL, &comm));
+    CHECK(mpg_handle_release(rh));                 /* parked in the cache; a fresh Store below must hand it out again */
+    CHECK(mpg_regrid_store(mesh, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_NEAREST_STOD, &rh));
+    CHECK(mpg_halo_build(comm, rh, 4, 0, &halo));
+    int mode;
+    int64_t n_local, own[2], base, own_pos[2], sent, received;
+    CHECK(mpg_halo_info(halo, &mode, &n_local, own, &base, own_pos, &sent, &received));
+    if (n_local != 4 || own[0] != 0 || own[1] != 4 || sent != 0 || received != 0) {
+      fprintf(stderr, "FAIL halo of one rank: n_local %lld own [%lld, %lld) sent %lld\n", (long long)n_local, (long long)own[0], (long long)own[1],
+              (long long)sent);
+      return 1;
+    }
+    void *src_dev, *loc_dev, *dst_dev, *all_dev;
+    CHECK(mpg_dev_alloc(2 * 4 * 8, &src_dev));
+    CHECK(mpg_dev_alloc(2 * 4 * 8, &loc_dev));
+    CHECK(mpg_dev_alloc(2 * NY * NX * 8, &dst_dev));
+    CHECK(mpg_dev_alloc(2 * NY * NX * 8, &all_dev));
+    CHECK(mpg_dev_upload(src_dev, &src[0][0], 2 * 4 * 8));
+    /* range form: the own block sits in the local buffer at own_pos[0]; here the local space IS the own block */
+    CHECK(mpg_dev_upload((char *)loc_dev + own_pos[0] * 8, &src[0][0], 4 * 8));
+    CHECK(mpg_dev_upload((char *)loc_dev + (4 + own_pos[0]) * 8, &src[1][0], 4 * 8));
+    CHECK(mpg_halo_exchange_dev(halo, (char *)loc_dev + own_pos[0] * 8, n_local, loc_dev, 2, 8, NULL));
+    CHECK(mpg_regrid_dev(rh, (const double *)loc_dev, MPG_LAYOUT_CELL_FAST, 2, 1, (double *)dst_dev, NULL));
+    CHECK(mpg_gather_rows(comm, dst_dev, 0, NY, NX, NY, 2, 8, all_dev, 0, NULL));
+    CHECK(mpg_dev_download(&dst[0][0][0], all_dev, 2 * NY * NX * 8));
+    for (int j = 0; j < NY; ++j)
+      for (int i = 0; i < NX; ++i)
+        if (dst[0][j][i] != 7.5 || (dst[1][j][i] != 1.0 && dst[1][j][i] != 2.0 && dst[1][j][i] != 3.0 && dst[1][j][i] != 4.0)) {
+          fprintf(stderr, "FAIL halo + gather path at (%d,%d): %.17g %.17g\n", i, j, dst[0][j][i], dst[1][j][i]);
+          return 1;
+        }
+    CHECK(mpg_halo_destroy(halo));
+    CHECK(mpg_comm_destroy(comm));
+    CHECK(mpg_handle_release(rh));
+    CHECK(mpg_dev_free(s_dev)); CHECK(mpg_dev_free(d_dev)); CHECK(mpg_dev_free(src_dev)); CHECK(mpg_dev_free(loc_dev));
+    CHECK(mpg_dev_free(dst_dev)); CHECK(mpg_dev_free(all_dev));
   }
   /* error contract: bad argument -> rc != 0 and a message */
   mpg_handle bad;

@@ -175,3 +175,40 @@ def test_large_variables_take_the_threaded_path(ncio, tmp_path):
     f.close()
     with ncio.Reader(q) as r:
         assert np.array_equal(r.get("d"), a) and np.array_equal(r.get("d", dtype=np.float32), a.astype(np.float32))
+
+
+def test_reserved_output_space_gives_the_same_file(tmp_path):
+    """ncio_reserve_start: the file is created / truncated and allocated on a helper thread, ncio_create of the same path
+    keeps it, ncio_close trims it -- the bytes are those of an unreserved write, holes read as zeros, stale content of an
+    older file at that path is gone, and a Writer on ANOTHER path still truncates as always."""
+    from mpassit_amd import ncio
+
+    def write(path, reserve):
+        if reserve:
+            ncio.reserve_start(path, 5_000_000)
+        with ncio.Writer(path, format=5) as w:
+            w.def_dim("Time", None)
+            w.def_dim("x", 1000)
+            w.def_var("a", ncio.FLOAT, ("Time", "x"))
+            w.def_var("hole", ncio.FLOAT, ("Time", "x"))
+            w.def_var("b", ncio.DOUBLE, ("x",))
+            w.enddef()
+            w.put("a", np.arange(1000, dtype=np.float32), rec=0)
+            w.put("b", np.linspace(0, 1, 1000))
+            w.extent("hole", rec=0)                       # the record exists, nothing is written into it
+    plain, res = tmp_path / "plain.nc", tmp_path / "reserved.nc"
+    res.write_bytes(b"\xff" * 3_000_000)                  # an older, larger file full of non-zero bytes at the reserved path
+    write(plain, False)
+    write(res, True)
+    assert res.read_bytes() == plain.read_bytes()
+    with ncio.Reader(res) as r:
+        assert not r.get("hole", rec=0).any() and r.get("a", rec=0)[999] == 999.0
+    other = tmp_path / "other.nc"
+    ncio.reserve_start(tmp_path / "unused.nc", 1_000_000)  # a reservation nobody claims does not leak into other paths
+    other.write_bytes(b"\xff" * 2_000_000)
+    write(other, False)
+    assert other.read_bytes() == plain.read_bytes()
+    with pytest.raises(ncio.NcioError):
+        ncio.reserve_start(tmp_path / "second.nc", 10)     # one reservation at a time (the unused one is still pending)
+    write(tmp_path / "unused.nc", False)                   # claims it
+    assert (tmp_path / "unused.nc").read_bytes() == plain.read_bytes()
