@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k_rebase(int64_t n, int32_t *__restrict__
 
 // [first, end) of the source ids a handle references (first == end: none), in its current index space
 __global__ __launch_bounds__(256) void k_src_range(int64_t n, const int32_t *__restrict__ idx, int32_t *__restrict__ lohi) {
+  __shared__ int32_t slo[4], shi[4];
   int32_t lo = 0x7fffffff, hi = -1;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int32_t c = idx[i];
@@ -88,9 +89,18 @@ __global__ __launch_bounds__(256) void k_src_range(int64_t n, const int32_t *__r
     lo = min(lo, __shfl_down(lo, o));
     hi = max(hi, __shfl_down(hi, o));
   }
-  if ((threadIdx.x & 63) == 0 && hi >= 0) {
-    atomicMin(lohi, lo);
-    atomicMax(lohi + 1, hi);
+  if ((threadIdx.x & 63) == 0) {
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one pair of atomics per workgroup, a few hundred workgroups: nothing queues on the two addresses
+    lo = min(min(slo[0], slo[1]), min(slo[2], slo[3]));
+    hi = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+    if (hi >= 0) {
+      atomicMin(lohi, lo);
+      atomicMax(lohi + 1, hi);
+    }
   }
 }
 
@@ -103,7 +113,7 @@ int mpg_k_source_range(mpg_handle_s *h, int64_t *first, int64_t *end, hipStream_
   int32_t init[2] = {0x7fffffff, -1}, out[2];
   MPG_HIP(hipMemcpyAsync(lohi.p, init, sizeof(init), hipMemcpyHostToDevice, s));
   int gb = (int)((ni + 255) / 256);
-  if (gb > 8192) gb = 8192;
+  if (gb > 1024) gb = 1024;
   if (gb < 1) gb = 1;
   if (ni > 0) k_src_range<<<gb, 256, 0, s>>>(ni, ip, lohi.p);
   MPG_HIP(hipMemcpyAsync(out, lohi.p, sizeof(out), hipMemcpyDeviceToHost, s));

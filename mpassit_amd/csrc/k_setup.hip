@@ -96,9 +96,10 @@ __global__ __launch_bounds__(256) void k_tri_canon(int64_t nVertices, const int3
                                                    int32_t *__restrict__ tri, const double *__restrict__ cx,
                                                    const double *__restrict__ cy, const double *__restrict__ cz,
                                                    unsigned long long *__restrict__ nvalid) {
-  int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  bool ok = false;
-  if (v < nVertices) {
+  __shared__ int swave[4];
+  int mine = 0;
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nVertices; v += (int64_t)gridDim.x * blockDim.x) {
+    bool ok = false;
     int32_t a = tri[v], b = tri[nVertices + v], c = tri[2 * nVertices + v];
     if (cnt[v] == 3) {
       int32_t t;
@@ -114,9 +115,16 @@ __global__ __launch_bounds__(256) void k_tri_canon(int64_t nVertices, const int3
     tri[v] = a;
     tri[nVertices + v] = b;
     tri[2 * nVertices + v] = c;
+    mine += ok;
   }
-  unsigned long long m = __ballot(ok);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(nvalid, (unsigned long long)__popcll(m));
+  // one atomic per workgroup (a few thousand in all): per-wave atomics on the one counter queued behind each other
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if ((threadIdx.x & 63) == 0) swave[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = swave[0] + swave[1] + swave[2] + swave[3];
+    if (tot) atomicAdd(nvalid, (unsigned long long)tot);
+  }
 }
 
 int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s) {
@@ -131,7 +139,11 @@ int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s) {
   if ((rc = nv.alloc(1))) return rc;
   MPG_HIP(hipMemsetAsync(nv.p, 0, sizeof(unsigned long long), s));
   k_tri_scatter<<<grid_for(m->nCells * m->maxEdges), 256, 0, s>>>(m->nCells, m->maxEdges, nV, m->voc.p, cnt.p, m->tri.p);
-  k_tri_canon<<<(unsigned)((nV + 255) / 256), 256, 0, s>>>(nV, cnt.p, m->tri.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nv.p);
+  {
+    int64_t nb = (nV + 255) / 256;
+    if (nb > 4096) nb = 4096;   // grid-stride: 16 waves per CU in flight, a handful of vertices per thread
+    k_tri_canon<<<(unsigned)nb, 256, 0, s>>>(nV, cnt.p, m->tri.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nv.p);
+  }
   MPG_HIP(hipGetLastError());
   unsigned long long h = 0;
   MPG_HIP(hipMemcpyAsync(&h, nv.p, sizeof(h), hipMemcpyDeviceToHost, s));
