@@ -37,16 +37,22 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
   double lo[3] = {fmin(A.x, fmin(B.x, C.x)) - pad, fmin(A.y, fmin(B.y, C.y)) - pad, fmin(A.z, fmin(B.z, C.z)) - pad};
   double hi[3] = {fmax(A.x, fmax(B.x, C.x)) + pad, fmax(A.y, fmax(B.y, C.y)) + pad, fmax(A.z, fmax(B.z, C.z)) + pad};
 
+  // Depth-first walk.  A node's four children are box-tested BEFORE they are pushed -- their 4 x 6 bounds are fetched in one
+  // round trip and only the ones the triangle's box meets go on the stack -- so the walk makes one iteration per node
+  // that meets the triangle (one or two per level for a triangle smaller than a leaf), not four per level, each of which
+  // was a dependent pop + box load (round 2; 82 % of this kernel's wave cycles were parked on those, profiles/r03_store_pmc.md).
+  auto meets = [&](int lev, int node) -> bool {
+    const double *bx = pyr.box + 6 * (pyr.off[lev] + node);
+    return !(bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]);
+  };
   int stack[RASTER_STACK];
   int sp = 0;
   int top = pyr.nlev - 1;
-  stack[sp++] = (top << 26);  // node 0 of the top level; node index < 2^26 per level
+  if (meets(top, 0)) stack[sp++] = (top << 26);  // node 0 of the top level; node index < 2^26 per level
   while (sp > 0) {
     int e = stack[--sp];
     int lev = e >> 26;
     int node = e & ((1 << 26) - 1);
-    const double *bx = pyr.box + 6 * (pyr.off[lev] + node);
-    if (bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]) continue;
     int nxl = pyr.nx[lev];
     int bi = node % nxl, bj = node / nxl;
     if (lev == 0) {
@@ -62,17 +68,19 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
         }
     } else {
       int cnx = pyr.nx[lev - 1], cny = pyr.ny[lev - 1];
+      bool go[4];
 #pragma unroll
-      for (int dj = 0; dj < 2; ++dj)
+      for (int ch = 0; ch < 4; ++ch) {
+        int ci = 2 * bi + (ch & 1), cj = 2 * bj + (ch >> 1);
+        go[ch] = ci < cnx && cj < cny && meets(lev - 1, cj * cnx + ci);
+      }
 #pragma unroll
-        for (int di = 0; di < 2; ++di) {
-          int ci = 2 * bi + di, cj = 2 * bj + dj;
-          if (ci < cnx && cj < cny) {
-            // depth-first with four children per node needs 3 * levels + 1 slots (49 at MPG_PYR_MAXLEV = 16): a full stack
-            // cannot happen, and if it ever did it is reported (MPG_ERR_OVERFLOW), never a silently unmapped point
-            if (sp < RASTER_STACK) stack[sp++] = ((lev - 1) << 26) | (cj * cnx + ci);
-            else atomicOr(overflow, 1);
-          }
+      for (int ch = 0; ch < 4; ++ch)
+        if (go[ch]) {
+          // only nodes that meet the triangle are stacked: a full stack cannot happen for a triangle smaller than the grid,
+          // and if it ever did it is reported (MPG_ERR_OVERFLOW), never a silently unmapped point
+          if (sp < RASTER_STACK) stack[sp++] = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
+          else atomicOr(overflow, 1);
         }
     }
   }

@@ -116,13 +116,17 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   for (int sk = COOP ? (int)threadIdx.x : 0; sk < nseed; sk += COOP ? (int)blockDim.x : 1) {
   const int seed = COOP ? q_nodes[cur][sk] : 0;
   int sp = 0;
-  stack[sp++] = (seed_lev << 26) | seed;
+  // node boxes of the cell pyramid already include the destination cells' own bulge (k_pyr_leaf, halo mode).  Children are
+  // box-tested before they are pushed (their bounds fetched together), as in k_tri_raster: one iteration per node that
+  // meets the polygon's box instead of four per level; the cooperative modes' seeds were tested when they were queued.
+  auto meets = [&](int lev_, int node_) -> bool {
+    const double *bx = pyr.box + 6 * (pyr.off[lev_] + node_);
+    return !(bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]);
+  };
+  if (COOP || meets(seed_lev, seed)) stack[sp++] = (seed_lev << 26) | seed;
   while (sp > 0) {
     int e = stack[--sp];
     int lev = e >> 26, node = e & ((1 << 26) - 1);
-    const double *bx = pyr.box + 6 * (pyr.off[lev] + node);
-    // node boxes of the cell pyramid already include the destination cells' own bulge (k_pyr_leaf, halo mode)
-    if (bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]) continue;
     int nxl = pyr.nx[lev];
     int bi = node % nxl, bj = node / nxl;
     if (lev == 0) {
@@ -175,13 +179,15 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
         }
     } else {
       int cnx = pyr.nx[lev - 1], cny = pyr.ny[lev - 1];
+      bool go[4];
 #pragma unroll
-      for (int dj = 0; dj < 2; ++dj)
+      for (int ch = 0; ch < 4; ++ch) {
+        int ci = 2 * bi + (ch & 1), cj = 2 * bj + (ch >> 1);
+        go[ch] = ci < cnx && cj < cny && meets(lev - 1, cj * cnx + ci);
+      }
 #pragma unroll
-        for (int di = 0; di < 2; ++di) {
-          int ci = 2 * bi + di, cj = 2 * bj + dj;
-          if (ci < cnx && cj < cny && sp < CONS_STACK) stack[sp++] = ((lev - 1) << 26) | (cj * cnx + ci);
-        }
+      for (int ch = 0; ch < 4; ++ch)
+        if (go[ch] && sp < CONS_STACK) stack[sp++] = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
     }
   }
   }
