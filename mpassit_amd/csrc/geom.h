@@ -129,3 +129,29 @@ __device__ __forceinline__ double swz(double v, const Swz &z) {
   const uint32_t nlo = __builtin_amdgcn_perm(hi, lo, z.lo64), nhi = __builtin_amdgcn_perm(hi, lo, z.hi64);
   return __longlong_as_double((long long)(((unsigned long long)nhi << 32) | nlo));
 }
+
+// ---- buffer addressing (scalar base + 32-bit lane offset) -------------------------------------------------------------
+// A raw buffer descriptor gives the staged kernels two things the flat form cannot: no 64-bit address arithmetic per
+// access (the base and a per-chunk / per-level offset live in scalar registers) and hardware range checking -- a lane
+// whose offset is >= the descriptor's size loads 0 and its store is dropped, so lanes without a target point need no
+// branch around their stores (a branch there makes the compiler wait for ALL outstanding stores before the next chunk's
+// loads can be consumed: loads and stores share one counter on gfx950).  Sizes are bytes and must stay below 4 GB.
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned buf_u32x2 __attribute__((ext_vector_type(2)));
+#define MPG_BUF_NONE 0xFFFFFFFFu   // lane offset of a lane that must not touch memory
+__device__ __forceinline__ BufRsrc buf_rsrc(const void *base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load(float &v, BufRsrc r, uint32_t lane_off, uint32_t wave_off) {
+  v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)wave_off, 0));
+}
+__device__ __forceinline__ void buf_load(double &v, BufRsrc r, uint32_t lane_off, uint32_t wave_off) {
+  v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)wave_off, 0));
+}
+// non-temporal (aux = 2: the "nt" bit of gfx94x / gfx950)
+__device__ __forceinline__ void buf_store_nt(float v, BufRsrc r, uint32_t lane_off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)lane_off, 0, 2);
+}
+__device__ __forceinline__ void buf_store_nt(double v, BufRsrc r, uint32_t lane_off) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u32x2, v), r, (int)lane_off, 0, 2);
+}

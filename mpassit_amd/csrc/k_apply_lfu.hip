@@ -7,8 +7,8 @@
 //   k_apply3_cfu      cell-fastest source [nlev][ncell] (the reference's in-memory order, input_data.F90:653-655): lanes
 //                     along the sorted cell list (neighbouring ids, coalesced), 4 levels per chunk, chunk c+1 prefetched
 //                     into registers while chunk c is combined; three tile shapes (g_cfu_variants)
-//   k_apply3_lfu      level-fastest source [ncell][nlev] (MPAS file order, :630,645), 64 x 4-point tiles, 16 levels per
-//                     chunk, lanes along the levels, the same register prefetch
+//   k_apply3_lfu      level-fastest source [ncell][nlev] (MPAS file order, :630,645), 64 x 8-point tiles, 16 levels per
+//                     chunk, lanes along the levels, the same register prefetch; branch-free body on buffer addressing
 //
 // Why staging: with 2.5-2.9 target points per source cell (BASELINE configs 2, 3, 5) the gather kernels fetch every
 // value ~3x through L2 -> CU and end up latency / issue bound at 2.6-3.3 TB/s; staged, the same workloads run at the HBM
@@ -21,8 +21,8 @@
 // Shapes measured in rounds 1-2 and dropped from the library in round 3 (two-phase form without prefetch, 32- and
 // 16-wide tiles, 64 x 32 tiles on 512 / 1024 threads, 2 / 8 / 16 levels per chunk, several fields per workgroup, banded
 // tile order, rows-resident 32 x 4 and 64 x 1 / 2 / 4 tiles with deep prefetch; round 3: rows-resident 64 x 8 tiles with a
-// per-tile level chunk, two levels per lane in k_apply3_lfu, 128-byte level chunks with the slab in the source type -- all
-// slower on configuration 5): profiles/r01_sweep_cfu.txt, r01_sweep_lfu.txt, r02_sweep_cfu_compact.txt,
+// per-tile level chunk, two levels per lane in k_apply3_lfu, 128-byte level chunks with the slab in the source type,
+// vertical tile bands -- all slower or equal on configuration 5): profiles/r01_sweep_cfu.txt, r01_sweep_lfu.txt, r02_sweep_cfu_compact.txt,
 // r02_sweep_cfu_fpw.txt, r02_tile_order_and_height.txt, r02_lfs_*.txt, r03_lf_experiments.txt.
 #include <limits.h>
 #include <string.h>
@@ -33,6 +33,7 @@
 #include "mpg_internal.h"
 
 #define LFU_THREADS 256
+#define LFU_LIST_PAD 512   // every tile's list is padded with its last cell up to min(stride, this many) entries
 #define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two
 
 // ---- per-tile unique cell lists (set-up, runtime tile shape) --------------------------------------------------
@@ -106,6 +107,13 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
     out[base + q] = mine[q];
   }
   __syncthreads();
+  // entries total .. LFU_LIST_PAD-1 repeat the last cell (cell 0 for an empty tile): k_apply3_lfu reads a fixed number of
+  // entries per tile without looking at the count first
+  {
+    const int32_t last = total > 0 ? keys[total - 1] : 0;
+    const int pad_to = stride < LFU_LIST_PAD ? stride : LFU_LIST_PAD;
+    for (int e = total + t; e < pad_to; e += LFU_THREADS) out[e] = last;
+  }
   // locality statistic: distinct groups of 16 consecutive ids (= 128-byte lines of a cell-fast float64 field) in the list
   {
     int nl = 0;
@@ -266,7 +274,7 @@ static int launch_build(bool fill, mpg_handle_s *h, int talign, int txu, int tyu
 
 // The key of a set of lists: tile shape, alignment rule and the capacity they were judged against (a list that fits 2048
 // cells per tile with shifted rows may have to be rebuilt unshifted for a 1024-cell kernel).
-static int lists_key(int txu, int tyu, int cap, int dmax) { return (txu * 1024 + tyu) | (dmax > 8 ? 1 << 24 : 0) | ((cap > 1024 ? 1 : 0) << 25); }
+static int lists_key(int txu, int tyu, int cap, int dmax) { return (txu * 1024 + tyu) | (dmax > 8 ? 1 << 24 : 0) | (((cap >> 8) & 15) << 25); }
 
 // tile lists for tiles of txu x tyu target points (cached in the handle, keyed by shape / alignment rule / capacity class)
 static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int cap, int dmax) {
@@ -484,95 +492,132 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32,
 
 // ---- level-fast, level chunks --------------------------------------------------------------------------------
 // float32 rows as the MPAS history file stores them ([nCells][nVertLevels], 220 bytes per cell at 55 levels) or float64
-// rows, either byte order; float64 arithmetic; dst = (TD)(value * scale + offset).  64 x 4-point tiles, 16 levels per
-// chunk (lanes along the levels: one 64- / 128-byte segment per row), LDS slab [row][17] doubles (odd stride:
-// conflict-free column reads), chunk c+1 prefetched into registers (16 rows per thread) while chunk c is combined.
-template <typename TS, typename TD, bool EPI, bool SWZ>
-__global__ __launch_bounds__(LFU_THREADS) void k_apply3_lfu(const int32_t *__restrict__ ut_cnt, const int32_t *__restrict__ ut_cells, int stride,
-                                                            const uint16_t *__restrict__ lidx, const double *__restrict__ w,
-                                                            const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
-                                                            int nlev, int ntx, int nty, int ut_max, double scale, double offset, int sbe, int dbe) {
-  constexpr int LC = 16, NPF = 16, LS = LC + 1, RPP = LFU_THREADS / LC;
-  extern __shared__ double lds[];
-  int32_t *cells = (int32_t *)(lds + (size_t)ut_max * LS);
+// rows, either byte order; float64 arithmetic; dst = (TD)(value * scale + offset).  64 x (NT/64)-point tiles, 16 levels
+// per chunk (lanes along the levels: one 64- / 128-byte segment per row), LDS slab [row][17] in the SOURCE type (odd
+// stride: conflict-free column reads; widening to float64 happens in the combine), chunk c+1 prefetched into registers
+// (16 rows per thread) while chunk c is combined.
+// The body is free of divergent branches on purpose: gfx950 counts loads and stores in ONE counter (vmcnt), and the
+// compiler can only wait for "the prefetched rows, not the 16 stores issued after them" when it can count the memory
+// instructions between the two on every path (the branchy form waited for vmcnt(0) before every chunk).  Hence: rows
+// past the end of a tile's list re-load its last row (same address for the whole wave: one L1 line), levels past the end
+// of a row are clamped and the last chunk starts at nlev - 16, unmapped points combine a zero row with zero weights
+// (+0.0, as the masked form gave), and lanes without a target point store through an out-of-range buffer offset, which
+// the hardware drops (geom.h).  All addresses are scalar base + 32-bit lane offset: no address arithmetic per access.
+template <typename TS, typename TD, int NT, bool EPI, bool SWZ>
+__global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ ut_cells, int stride,
+                                                   const uint16_t *__restrict__ lidx, const double *__restrict__ w, const TS *__restrict__ src,
+                                                   TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc, int nlev, int ntx, int nty,
+                                                   double scale, double offset, int sbe, int dbe) {
+  constexpr int LC = 16, NPF = 16, LS = LC + 1, RPP = NT / LC, TY = NT / 64, ZROW = NPF * RPP;
+  extern __shared__ double lds_raw[];
+  TS *slab = (TS *)lds_raw;                                  // [ZROW + 1][LS]; row ZROW stays zero
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   const unsigned tile = lin % ntile;
   const int f = lin / ntile;
-  const int t = threadIdx.x;
-  const int nU = ut_cnt[tile];
-  const int32_t *list = ut_cells + (int64_t)tile * stride;
-  for (int r = t; r < nU; r += LFU_THREADS) cells[r] = list[r];
-  LfuPoints<1, LFU_THREADS> pts;
-  pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, LS);
-  const TS *sf = src + (int64_t)f * nlev * nsrc;
-  TD *df = dst + (int64_t)f * nlev * P;
-  const int lrow = t / LC, llev = t % LC;
-  __syncthreads();  // cells[] visible
-  // this thread's rows: element offsets of (cell, level llev) inside the field, -1 = none
-  int64_t roff[NPF];
+  const int t = threadIdx.x, lrow = t / LC, llev = t % LC;
+  const int32_t *list = ut_cells + (int64_t)tile * stride;   // padded with its last cell up to LFU_LIST_PAD entries
+  // this thread's 16 rows: byte offsets of (cell, level llev) inside the field
+  uint32_t rb[NPF];
+  {
+    const uint32_t lv = (uint32_t)min(llev, nlev - 1);
 #pragma unroll
-  for (int u = 0; u < NPF; ++u) {
-    int row = lrow + u * RPP;
-    roff[u] = row < nU ? (int64_t)cells[row] * nlev + llev : -1;
+    for (int u = 0; u < NPF; ++u) rb[u] = ((uint32_t)list[lrow + u * RPP] * (uint32_t)nlev + lv) * (uint32_t)sizeof(TS);
   }
+  // this thread's target point
+  const int j = (int)(tile / ntx) * TY + t / 64, i = (int)(tile % ntx) * 64 + t % 64 - mpg_tile_shift(j, nx, talign);
+  const bool act = i >= 0 && i < nx && j < ny;
+  const int64_t p = act ? (int64_t)j * nx + i : 0;
+  int l0 = lidx[p], l1 = lidx[P + p], l2 = lidx[2 * P + p];
+  double w0 = w[p], w1 = w[P + p], w2 = w[2 * P + p];
+  {
+    const bool mapped = act && l0 != 0xFFFF;
+    l0 = mapped ? l0 * LS : ZROW * LS;
+    l1 = mapped ? l1 * LS : ZROW * LS;
+    l2 = mapped ? l2 * LS : ZROW * LS;
+    w0 = mapped ? w0 : 0.0;
+    w1 = mapped ? w1 : 0.0;
+    w2 = mapped ? w2 : 0.0;
+  }
+  const uint32_t pb = act ? (uint32_t)p * (uint32_t)sizeof(TD) : MPG_BUF_NONE;
+  const BufRsrc rs = buf_rsrc(src + (int64_t)f * nlev * nsrc, (uint32_t)((uint64_t)nsrc * nlev * sizeof(TS)));
+  TD *dlev = dst + (int64_t)f * nlev * P;                    // the level plane the next store goes to
+  const uint32_t plane = (uint32_t)(P * sizeof(TD));
+  const int nch = (nlev + LC - 1) / LC, k0_last = max(nlev - LC, 0);
+  if (t < LS) slab[ZROW * LS + t] = (TS)0;
   TS pf[NPF];
+  auto fetch = [&](int k0) {
 #pragma unroll
-  for (int u = 0; u < NPF; ++u) pf[u] = (roff[u] >= 0 && llev < nlev) ? sf[roff[u]] : (TS)0;
-  for (int k0 = 0; k0 < nlev; k0 += LC) {
+    for (int u = 0; u < NPF; ++u) buf_load(pf[u], rs, rb[u], (uint32_t)k0 * (uint32_t)sizeof(TS));
+  };
+  auto park = [&]() {
 #pragma unroll
-    for (int u = 0; u < NPF; ++u)
-      if (roff[u] >= 0) lds[(lrow + u * RPP) * LS + llev] = (double)swz<SWZ>(pf[u], zs);
-    for (int row = lrow + NPF * RPP; row < nU; row += RPP)  // surplus rows of an unusually large tile
-      lds[row * LS + llev] = (k0 + llev < nlev) ? (double)swz<SWZ>(sf[(int64_t)cells[row] * nlev + k0 + llev], zs) : 0.0;
+    for (int u = 0; u < NPF; ++u) slab[(lrow + u * RPP) * LS + llev] = swz<SWZ>(pf[u], zs);
+  };
+  auto level = [&](int col) {
+    const double a = (double)slab[l0 + col], b = (double)slab[l1 + col], e = (double)slab[l2 + col];
+    double val = wsum3(w0, a, w1, b, w2, e);
+    if constexpr (EPI) val = fma(val, scale, offset);
+    buf_store_nt(swz<SWZ>((TD)val, zd), buf_rsrc(dlev, plane), pb);
+    dlev += P;
+  };
+  fetch(nch > 1 ? 0 : k0_last);
+  park();
+  __syncthreads();
+  if (nch > 1) fetch(nch > 2 ? LC : k0_last);
+  for (int c = 0; c + 1 < nch; ++c) {   // full chunks
+#pragma unroll
+    for (int kk = 0; kk < LC; ++kk) level(kk);
     __syncthreads();
-    const int kn1 = k0 + LC;
-    if (kn1 < nlev) {
-      const bool ok = kn1 + llev < nlev;
-#pragma unroll
-      for (int u = 0; u < NPF; ++u) pf[u] = (roff[u] >= 0 && ok) ? sf[roff[u] + kn1] : (TS)0;
-    }
-    const int kn = min(LC, nlev - k0);
-    for (int kk = 0; kk < kn; ++kk) {
-      double a = lds[pts.l[0][0] + kk], b = lds[pts.l[0][1] + kk], e = lds[pts.l[0][2] + kk];
-      double val = pts.mapped[0] ? wsum3(pts.ww[0][0], a, pts.ww[0][1], b, pts.ww[0][2], e) : 0.0;
-      if constexpr (EPI) val = fma(val, scale, offset);
-      if (pts.act[0]) __builtin_nontemporal_store(swz<SWZ>((TD)val, zd), df + (int64_t)(k0 + kk) * P + pts.off[0]);
-    }
+    park();
     __syncthreads();
+    if (c + 2 < nch) fetch(c + 3 < nch ? (c + 2) * LC : k0_last);
+  }
+  // last chunk: levels (nch-1)*16 .. nlev-1 sit in columns shift .. of the slab
+  const int shift = (nch - 1) * LC - (nch > 1 ? k0_last : 0), kn = nlev - (nch - 1) * LC;
+  l0 += shift;
+  l1 += shift;
+  l2 += shift;
+#pragma unroll
+  for (int kk = 0; kk < LC; ++kk) {
+    if (kk >= kn) break;
+    level(kk);
   }
 }
 
-template <typename TS, typename TD, bool EPI>
+template <typename TS, typename TD, int NT, bool EPI>
 static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
                       hipStream_t s) {
-  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + 3) / 4;
-  const size_t um = h->ut_max > 0 ? h->ut_max : 1;
-  size_t lds = sizeof(double) * um * 17 + sizeof(int32_t) * um + 16;
-  if (lds > 160 * 1024) return MPG_ERR_UNSUPPORTED;
-  auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, EPI, true> : k_apply3_lfu<TS, TD, EPI, false>;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + NT / 64 - 1) / (NT / 64);
+  const size_t lds = sizeof(TS) * (NT + 1) * 17;
+  if (h->ut_max > NT || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
+    return MPG_ERR_UNSUPPORTED;
+  auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true> : k_apply3_lfu<TS, TD, NT, EPI, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fn<<<(unsigned)ntx * nty * nfields, LFU_THREADS, lds, s>>>(h->ut_cnt.p, h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
-                                                            h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset, sbe, dbe);
+  static_assert(NT <= LFU_LIST_PAD, "the kernel reads NT list entries of every tile");
+  fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
+                                                   h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
 
-// -> MPG_ERR_UNSUPPORTED when a tile's list does not fit the LDS (the caller takes the row gather)
+#define LFU_NT 512   // 64 x 8-point tiles; float32 rows: 35 KB of LDS, four workgroups of eight waves per CU; float64: 70 KB, two
+
+// -> MPG_ERR_UNSUPPORTED when a tile's list does not fit the slab (the caller takes the row gather)
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
                            double offset, hipStream_t s) {
-  int rc = lfu_build_shape(h, 64, 4, s);
-  if (rc) return rc;
   const int sbe = (src_type & MPG_TYPE_BE) != 0, dbe = (dst_type & MPG_TYPE_BE) != 0, sf32 = src_type & MPG_TYPE_F32, df32 = dst_type & MPG_TYPE_F32;
-  if (sf32 && df32) return launch_lfu<float, float, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (sf32) return launch_lfu<float, double, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (df32) return launch_lfu<double, float, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  return launch_lfu<double, double, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
+  int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_NT);
+  if (rc) return rc;
+  if (sf32 && df32) return launch_lfu<float, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
+  if (sf32) return launch_lfu<float, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
+  if (df32) return launch_lfu<double, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
+  return launch_lfu<double, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
 }
 int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
-  int rc = lfu_build_shape(h, 64, 4, s);
+  int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_NT);
   if (rc) return rc;
-  return launch_lfu<double, double, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s);
+  return launch_lfu<double, double, LFU_NT, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s);
 }
