@@ -592,7 +592,7 @@ static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
                       hipStream_t s) {
   const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + NT / 64 - 1) / (NT / 64);
   const size_t lds = sizeof(TS) * (NT + 1) * 17;
-  if (h->ut_max > NT || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
+  if (h->ut_max > NT || h->ut_stride < NT || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
     return MPG_ERR_UNSUPPORTED;
   auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true> : k_apply3_lfu<TS, TD, NT, EPI, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
