@@ -8,6 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 TAG=$1; shift
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+[ -f "$REPO/$1" ] && { S="$REPO/$1"; shift; set -- "$S" "$@"; }   # the passes run from /tmp: a script path relative to the repo is made absolute
 cd /tmp && export TMPDIR=/tmp
 CMD="$*"
 timeout -k 10 ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $CMD > $OUT/trace.log 2>&1
