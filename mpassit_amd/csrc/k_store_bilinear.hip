@@ -13,9 +13,12 @@
 // stores them SoA ([3][P]) for the coalesced apply kernel.  No sort, no hash, no fallback path:
 // cost is O(T log P + P) and the traversal is exact for any mesh (no Delaunay assumption).
 #include "geom.h"
+#include <algorithm>
+
 #include "mpg_internal.h"
 
 #define RASTER_STACK 64
+#define RASTER_BIG_LEAVES 16   // 4 x 4-point leaves a lane rasterises by itself before it hands its triangle over
 
 template <bool NORMAL>
 __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t *__restrict__ tri, int64_t triStride,
@@ -23,7 +26,8 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
                                                     const double *__restrict__ cz, PyramidView pyr, int npx, int npy,
                                                     const double *__restrict__ px, const double *__restrict__ py,
                                                     const double *__restrict__ pz, int32_t *__restrict__ owner,
-                                                    int32_t *__restrict__ overflow) {
+                                                    int32_t *__restrict__ overflow, int32_t *__restrict__ big, int32_t *__restrict__ nbig,
+                                                    int big_cap) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= nTri) return;
   int32_t ia = tri[t];
@@ -48,6 +52,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
   int stack[RASTER_STACK];
   int sp = 0;
   int top = pyr.nlev - 1;
+  int nleaf = 0;
   if (meets(top, 0)) stack[sp++] = (top << 26);  // node 0 of the top level; node index < 2^26 per level
   while (sp > 0) {
     int e = stack[--sp];
@@ -56,6 +61,17 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
     int nxl = pyr.nx[lev];
     int bi = node % nxl, bj = node / nxl;
     if (lev == 0) {
+      // A triangle that spreads over many leaves (the cells around the pole of a lat-lon grid cover thousands of points each;
+      // every triangle of a mesh much coarser than the grid) is handed to k_tri_raster_big, one wavefront per triangle:
+      // here it would keep one lane busy for milliseconds.  What this lane has already marked stays valid (atomicMin).
+      if (++nleaf > RASTER_BIG_LEAVES && big_cap > 0) {
+        int slot = atomicAdd(nbig, 1);
+        if (slot < big_cap) {
+          big[slot] = (int32_t)t;
+          return;
+        }
+        big_cap = 0;   // queue full: finish here
+      }
       int i0 = bi * MPG_PYR_B0, j0 = bj * MPG_PYR_B0;
       int i1 = min(i0 + MPG_PYR_B0, npx), j1 = min(j0 + MPG_PYR_B0, npy);
       for (int j = j0; j < j1; ++j)
@@ -82,6 +98,70 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
           if (sp < RASTER_STACK) stack[sp++] = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
           else atomicOr(overflow, 1);
         }
+    }
+  }
+}
+
+
+// One wavefront per handed-over triangle: the same walk with a per-wave stack in LDS; four lanes test a node's children,
+// and a level-1 node (8 x 8 points; a lone level 0 of a tiny grid: 4 x 4) is tested one point per lane.
+template <bool NORMAL>
+__global__ __launch_bounds__(256) void k_tri_raster_big(const int32_t *__restrict__ big, const int32_t *__restrict__ nbig, int big_cap,
+                                                        const int32_t *__restrict__ tri, int64_t triStride, const double *__restrict__ cx,
+                                                        const double *__restrict__ cy, const double *__restrict__ cz, PyramidView pyr, int npx,
+                                                        int npy, const double *__restrict__ px, const double *__restrict__ py,
+                                                        const double *__restrict__ pz, int32_t *__restrict__ owner,
+                                                        int32_t *__restrict__ overflow) {
+  __shared__ int stk[4][RASTER_STACK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = min(*nbig, big_cap);
+  for (int b = blockIdx.x * 4 + wv; b < n; b += gridDim.x * 4) {
+    const int32_t t = big[b];
+    const int32_t ia = tri[t], ib = tri[triStride + t], ic = tri[2 * triStride + t];
+    const dv3 A = ld3(cx, cy, cz, ia), B = ld3(cx, cy, cz, ib), C = ld3(cx, cy, cz, ic);
+    const dv3 ab = B - A, bc = C - B, ca = A - C;
+    const double e2 = fmax(dot3(ab, ab), fmax(dot3(bc, bc), dot3(ca, ca)));
+    const double pad = 0.5 * e2 + 1e-9;
+    const double lo[3] = {fmin(A.x, fmin(B.x, C.x)) - pad, fmin(A.y, fmin(B.y, C.y)) - pad, fmin(A.z, fmin(B.z, C.z)) - pad};
+    const double hi[3] = {fmax(A.x, fmax(B.x, C.x)) + pad, fmax(A.y, fmax(B.y, C.y)) + pad, fmax(A.z, fmax(B.z, C.z)) + pad};
+    auto meets = [&](int lev, int node) -> bool {
+      const double *bx = pyr.box + 6 * (pyr.off[lev] + node);
+      return !(bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]);
+    };
+    int sp = 0;   // wave-uniform
+    const int top = pyr.nlev - 1;
+    if (meets(top, 0)) {
+      if (lane == 0) stk[wv][0] = top << 26;
+      sp = 1;
+    }
+    while (sp > 0) {
+      const int e = stk[wv][--sp];
+      const int lev = e >> 26, node = e & ((1 << 26) - 1);
+      const int nxl = pyr.nx[lev];
+      const int bi = node % nxl, bj = node / nxl;
+      if (lev <= 1) {
+        const int side = MPG_PYR_B0 << lev;
+        const int i = bi * side + lane % side, j = bj * side + lane / side;
+        if (lane < side * side && i < npx && j < npy) {
+          const int64_t p = (int64_t)j * npx + i;
+          const dv3 Pt = dv3{px[p], py[p], pz[p]};
+          if (!(Pt.x < lo[0] || Pt.x > hi[0] || Pt.y < lo[1] || Pt.y > hi[1] || Pt.z < lo[2] || Pt.z > hi[2])) {
+            double w[3];
+            if (NORMAL ? tri_weights_normal(Pt, A, B, C, MPG_TOL, w) : tri_weights(Pt, A, B, C, MPG_TOL, w)) atomicMin(&owner[p], t);
+          }
+        }
+      } else {
+        const int cnx = pyr.nx[lev - 1], cny = pyr.ny[lev - 1];
+        const int ci = 2 * bi + (lane & 1), cj = 2 * bj + ((lane >> 1) & 1);
+        const bool go = lane < 4 && ci < cnx && cj < cny && meets(lev - 1, cj * cnx + ci);
+        const unsigned long long m = __ballot(go);
+        if (sp + 4 > RASTER_STACK) {
+          if (lane == 0) atomicOr(overflow, 1);
+        } else {
+          if (go) stk[wv][sp + __popcll(m & ((1ull << lane) - 1))] = ((lev - 1) << 26) | (cj * cnx + ci);
+          sp += __popcll(m);
+        }
+      }
     }
   }
 }
@@ -199,14 +279,20 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   if ((rc = owner.alloc((size_t)P))) return rc;
   int fb = (int)((P + 255) / 256);
   if (fb > 8192) fb = 8192;
+  // one scratch allocation: [0] overflow flag, [1] length of the queue of handed-over triangles, [2 ...] the queue (nobody
+  // reads the length on the host)
+  const int big_cap = (int)std::min<int64_t>(nT, 1 << 18);
   TmpBuf<int32_t> ovf;
-  if ((rc = ovf.alloc(1))) return rc;
-  MPG_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
+  if ((rc = ovf.alloc((size_t)big_cap + 2))) return rc;
+  MPG_HIP(hipMemsetAsync(ovf.p, 0, 2 * sizeof(int32_t), s));
   k_fill_i32<<<fb, 256, 0, s>>>(P, 0x7fffffff, owner.p);
   auto raster = mpg_bilinear_linetype() ? k_tri_raster<true> : k_tri_raster<false>;
+  auto raster_big = mpg_bilinear_linetype() ? k_tri_raster_big<true> : k_tri_raster_big<false>;
   auto finalize = mpg_bilinear_linetype() ? k_tri_finalize<true> : k_tri_finalize<false>;
   raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sp->x.p, sp->y.p, sp->z.p, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p,
-                                                     pts.y.p, pts.z.p, owner.p, ovf.p);
+                                                     pts.y.p, pts.z.p, owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap);
+  raster_big<<<1024, 256, 0, s>>>(ovf.p + 2, ovf.p + 1, big_cap, trip, nT, sp->x.p, sp->y.p, sp->z.p, mpg_pyr_view(g->pyr[stagger]), npx, npy,
+                                 pts.x.p, pts.y.p, pts.z.p, owner.p, ovf.p);
   finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sp->x.p, sp->y.p, sp->z.p, pts.x.p, pts.y.p, pts.z.p, h->idx.p,
                                                       h->w.p);
   MPG_HIP(hipGetLastError());
