@@ -326,7 +326,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
   const int nty = (h->ny_dst + tyu - 1) / tyu;
   const int stride = (3 * txu * tyu + 31) & ~31;
   TmpBuf<unsigned long long> stats;
-  if ((rc = stats.alloc(3))) return rc;
+  if ((rc = stats.alloc(3, s))) return rc;
   if (!h->lidx.p && (rc = h->lidx.alloc(3 * (size_t)h->n_dst))) return rc;
   unsigned long long hs[3] = {0, 0, 0};
   for (;;) {
@@ -368,7 +368,7 @@ static int sampled_reuse(mpg_handle_s *h, int tyu, hipStream_t s, float *reuse) 
   const int64_t nb = (ntile + step - 1) / step;
   TmpBuf<unsigned long long> stats;
   int rc;
-  if ((rc = stats.alloc(3))) return rc;
+  if ((rc = stats.alloc(3, s))) return rc;
   MPG_HIP(hipMemsetAsync(stats.p, 0, 3 * sizeof(unsigned long long), s));
   if ((rc = launch_build<LFU_SORT>(false, h, align, 64, tyu, ntx, nb, step, nullptr, nullptr, 0, nullptr, stats.p, s))) return rc;
   unsigned long long hs[3];

@@ -58,7 +58,7 @@ static int coords_common(bool mesh, int64_t n, const double *lon, const double *
   if ((rc = out.alloc(n))) return rc;
   if (n == 0) return MPG_SUCCESS;
   TmpBuf<double> tmp;
-  if ((rc = tmp.alloc(2 * (size_t)n))) return rc;
+  if ((rc = tmp.alloc(2 * (size_t)n, s))) return rc;
   MPG_HIP(hipMemcpyAsync(tmp.p, lon, sizeof(double) * n, hipMemcpyHostToDevice, s));
   MPG_HIP(hipMemcpyAsync(tmp.p + n, lat, sizeof(double) * n, hipMemcpyHostToDevice, s));
   if (mesh)
@@ -132,11 +132,11 @@ int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s) {
   int64_t nV = m->nVertices;
   if ((rc = m->tri.alloc(3 * (size_t)nV))) return rc;
   TmpBuf<int32_t> cnt;
-  if ((rc = cnt.alloc((size_t)nV))) return rc;
+  if ((rc = cnt.alloc((size_t)nV, s))) return rc;
   MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * nV, s));
   MPG_HIP(hipMemsetAsync(m->tri.p, 0xff, sizeof(int32_t) * 3 * nV, s));
   TmpBuf<unsigned long long> nv;
-  if ((rc = nv.alloc(1))) return rc;
+  if ((rc = nv.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(nv.p, 0, sizeof(unsigned long long), s));
   k_tri_scatter<<<grid_for(m->nCells * m->maxEdges), 256, 0, s>>>(m->nCells, m->maxEdges, nV, m->voc.p, cnt.p, m->tri.p);
   {

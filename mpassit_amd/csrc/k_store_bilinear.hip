@@ -276,14 +276,14 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   if ((rc = h->idx.alloc(3 * (size_t)P))) return rc;
   if ((rc = h->w.alloc(3 * (size_t)P))) return rc;
   TmpBuf<int32_t> owner;
-  if ((rc = owner.alloc((size_t)P))) return rc;
+  if ((rc = owner.alloc((size_t)P, s))) return rc;
   int fb = (int)((P + 255) / 256);
   if (fb > 8192) fb = 8192;
   // one scratch allocation: [0] overflow flag, [1] length of the queue of handed-over triangles, [2 ...] the queue (nobody
   // reads the length on the host)
   const int big_cap = (int)std::min<int64_t>(nT, 1 << 18);
   TmpBuf<int32_t> ovf;
-  if ((rc = ovf.alloc((size_t)big_cap + 2))) return rc;
+  if ((rc = ovf.alloc((size_t)big_cap + 2, s))) return rc;
   MPG_HIP(hipMemsetAsync(ovf.p, 0, 2 * sizeof(int32_t), s));
   k_fill_i32<<<fb, 256, 0, s>>>(P, 0x7fffffff, owner.p);
   auto raster = mpg_bilinear_linetype() ? k_tri_raster<true> : k_tri_raster<false>;

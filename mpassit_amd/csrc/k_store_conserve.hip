@@ -409,9 +409,9 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   TmpBuf<double> qarea, qsph, pair_val;
   TmpBuf<uint8_t> flip;
   const int64_t nC = m->nCells;
-  if ((rc = count.alloc((size_t)P + 1)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P)) || (rc = qsph.alloc(4 * (size_t)P)) ||
-      (rc = cnt_src.alloc((size_t)nC)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP)) || (rc = ovf.alloc((size_t)nC)) || (rc = n_ovf.alloc(1)) ||
-      (rc = npair.alloc((size_t)nC + 1)) || (rc = poff.alloc((size_t)nC + 1)) || (rc = flip.alloc((size_t)nC)))
+  if ((rc = count.alloc((size_t)P + 1, s)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P, s)) || (rc = qsph.alloc(4 * (size_t)P, s)) ||
+      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(1, s)) ||
+      (rc = npair.alloc((size_t)nC + 1, s)) || (rc = poff.alloc((size_t)nC + 1, s)) || (rc = flip.alloc((size_t)nC, s)))
     return rc;
   MPG_HIP(hipMemsetAsync(n_ovf.p, 0, sizeof(int32_t), s));
   MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)nC, s));  // degenerate cells leave early
@@ -437,7 +437,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
   MPG_HIP(rocprim::exclusive_scan(nullptr, b2, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
   TmpBuf<char> tmp;
-  if ((rc = tmp.alloc((tmp_bytes > b2 ? tmp_bytes : b2) + 16))) return rc;
+  if ((rc = tmp.alloc((tmp_bytes > b2 ? tmp_bytes : b2) + 16, s))) return rc;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
   int32_t npairs = 0;
   MPG_HIP(hipMemcpyAsync(&npairs, poff.p + nC, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -446,9 +446,9 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     TmpBuf<long long> tot;
     TmpBuf<char> t2;
     size_t b3 = 0;
-    if ((rc = tot.alloc(1))) return rc;
+    if ((rc = tot.alloc(1, s))) return rc;
     MPG_HIP(rocprim::reduce(nullptr, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
-    if ((rc = t2.alloc(b3 + 16))) return rc;
+    if ((rc = t2.alloc(b3 + 16, s))) return rc;
     MPG_HIP(rocprim::reduce((void *)t2.p, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
     long long total = 0;
     MPG_HIP(hipMemcpyAsync(&total, tot.p, sizeof(total), hipMemcpyDeviceToHost, s));
@@ -458,7 +458,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
       return MPG_ERR_OVERFLOW;
     }
   }
-  if ((rc = pair_c.alloc((size_t)npairs + 1)) || (rc = pair_p.alloc((size_t)npairs + 1)) || (rc = pair_val.alloc((size_t)npairs + 1))) return rc;
+  if ((rc = pair_c.alloc((size_t)npairs + 1, s)) || (rc = pair_p.alloc((size_t)npairs + 1, s)) || (rc = pair_val.alloc((size_t)npairs + 1, s))) return rc;
   k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
   if (novf > 0)
     k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
@@ -472,7 +472,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (clip_lds_bytes > 48 * 1024)
     MPG_HIP(hipFuncSetAttribute((const void *)k_conserve_clip_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clip_lds_bytes));
   TmpBuf<int32_t> truncated;
-  if ((rc = truncated.alloc(1))) return rc;
+  if ((rc = truncated.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(truncated.p, 0, sizeof(int32_t), s));
   if (npairs > 0)
     k_conserve_clip_pairs<<<(unsigned)(((int64_t)npairs + CLIP_NT - 1) / CLIP_NT), CLIP_NT, clip_lds_bytes, s>>>(

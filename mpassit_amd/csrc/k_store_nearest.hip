@@ -89,14 +89,14 @@ int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s) {
   b.n = n;
   TmpBuf<unsigned long long> key_in, key_out;
   TmpBuf<int32_t> id_in;
-  if ((rc = key_in.alloc(n)) || (rc = key_out.alloc(n)) || (rc = id_in.alloc(n)) || (rc = b.sorted_id.alloc(n))) return rc;
+  if ((rc = key_in.alloc(n, s)) || (rc = key_out.alloc(n, s)) || (rc = id_in.alloc(n, s)) || (rc = b.sorted_id.alloc(n))) return rc;
   if ((rc = b.sorted.alloc(n))) return rc;
   unsigned nb = (unsigned)((n + 255) / 256);
   k_morton<<<nb, 256, 0, s>>>(n, m->cell.x.p, m->cell.y.p, m->cell.z.p, key_in.p, id_in.p);
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
   TmpBuf<char> tmp;
-  if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
+  if ((rc = tmp.alloc(tmp_bytes + 16, s))) return rc;
   MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
   k_gather_sites<<<nb, 256, 0, s>>>(n, b.sorted_id.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, b.sorted.x.p, b.sorted.y.p, b.sorted.z.p);
   // level sizes
@@ -294,7 +294,7 @@ int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s 
     return MPG_SUCCESS;
   }
   TmpBuf<int32_t> ovf;
-  if ((rc = ovf.alloc(1))) return rc;
+  if ((rc = ovf.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
   const int64_t npatch = (int64_t)((npx + 7) / 8) * ((npy + 7) / 8);
   k_nearest_query_w<<<(unsigned)((npatch + NNW_WAVES - 1) / NNW_WAVES), 64 * NNW_WAVES, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p,

@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 #include "mpg_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -35,6 +39,75 @@ void mpg_cache_detach(mpg_handle_s *h) {
     h->cached = false;
   }
 }
+
+// ---- cache of temporary device blocks (TmpBuf::alloc(count, stream), mpg_internal.h) ------------------------------------
+namespace {
+struct PoolBlock { void *p; size_t bytes; hipStream_t stream; };
+std::vector<PoolBlock> g_pool;
+std::mutex g_pool_mu;
+size_t g_pool_bytes = 0;
+const size_t POOL_CAP_BYTES = (size_t)4 << 30;   // beyond this a returned block goes straight back to the driver
+}  // namespace
+
+void *mpg_pool_get(size_t bytes, hipStream_t s) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_pool.size(); ++i) {
+      const PoolBlock &b = g_pool[i];
+      if (b.stream != s || b.bytes < bytes || b.bytes > 2 * bytes + (1 << 20)) continue;   // same stream only; bounded waste
+      if (best < 0 || b.bytes < g_pool[best].bytes) best = i;
+    }
+    if (best >= 0) {
+      void *p = g_pool[best].p;
+      g_pool_bytes -= g_pool[best].bytes;
+      g_pool.erase(g_pool.begin() + best);
+      return p;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {   // the cache may be what fills the device: drop it and try once more
+    mpg_pool_release();
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) {
+    mpg_set_error("HIP error %s allocating %zu bytes of scratch", hipGetErrorString(e), bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+// The size a block is cached under is the size it was ASKED with, rounded as mpg_pool_get rounds: a block found in the
+// cache for a smaller request keeps its real size only if the caller returns it under that request's size -- so the cache
+// tracks the real size itself.
+static std::unordered_map<void *, size_t> g_pool_real;
+
+void mpg_pool_put(void *p, size_t bytes, hipStream_t s) {
+  if (!p) return;
+  bytes = (bytes + 255) & ~(size_t)255;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool_real.find(p);
+  if (it != g_pool_real.end()) bytes = it->second;
+  else g_pool_real[p] = bytes;
+  if (g_pool_bytes + bytes > POOL_CAP_BYTES) {
+    g_pool_real.erase(p);
+    (void)hipFree(p);
+    return;
+  }
+  g_pool.push_back(PoolBlock{p, bytes, s});
+  g_pool_bytes += bytes;
+}
+
+void mpg_pool_release() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (const PoolBlock &b : g_pool) (void)hipFree(b.p);
+  g_pool.clear();
+  g_pool_real.clear();
+  g_pool_bytes = 0;
+}
+
 
 extern "C" {
 
@@ -81,6 +154,7 @@ int mpg_finalize(void) {
   mpg_fileio_release();
   mpg_hostpipe_release();
   (void)hipStreamSynchronize(g_stream);
+  mpg_pool_release();
   (void)hipStreamDestroy(g_stream);
   g_stream = nullptr;
   g_init = false;
