@@ -300,3 +300,32 @@ def test_stores_on_polar_stereographic_and_mercator_grids(gpu_lib, oracle, kind)
     rc.release()
     mesh.destroy()
     grid.destroy()
+
+
+def test_coarse_mesh_under_a_fine_global_grid(gpu_lib, oracle):
+    """642 cells (about 900 km apart) under a 0.5-degree global lat-lon grid: every dual triangle covers thousands of
+    target points and spreads over hundreds of pyramid leaves, so the whole bilinear Store runs through the
+    wavefront-per-triangle rasteriser (k_tri_raster_big), pole caps included; weights against the oracle entry by entry, and
+    for both line types."""
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    m = synth.icosahedral_mesh(3)
+    g = T.define_target_grid_params("lat-lon", nx=721, ny=361, stand_lon=0.0, is_regional=False)
+    assert m.nCells == 642 and (g.nx, g.ny) == (720, 360)
+    osd = OracleSide(oracle, m, g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    st = check_stores(R, mesh, grid, osd, ("bilinear",))
+    assert st["mapped"].all() and st["unique_sources"] == 642
+    try:   # the other line type (projection along the triangle's normal): on 900 km triangles neighbouring planes leave slits
+        # along the shared edges, in the oracle exactly as here -- the same points unmapped, the same weights elsewhere
+        gpu_lib.tune("bilinear_linetype", 1)
+        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+        idx, w = rh.weights()
+        idx_o, w_o = oracle.bilinear_weights(osd.cxyz, osd.tri, osd.pxyz, linetype=1)
+        assert_fixed_weights_equal(idx_o, w_o, idx, w, tol=1e-11)
+        mapped = idx[:, 0] >= 0
+        assert mapped.mean() > 0.99 and np.abs(w[mapped].sum(1) - 1).max() < 1e-13
+        rh.release()
+    finally:
+        gpu_lib.tune("bilinear_linetype", 0)
+    mesh.destroy()
+    grid.destroy()
