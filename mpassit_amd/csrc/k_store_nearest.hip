@@ -208,6 +208,36 @@ __global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int
   const double X = px[p], Y = py[p], Z = pz[p];
   double best = act ? INFINITY : -1.0;      // an inactive lane admits nothing
   int32_t best_id = 0x7fffffff;
+  // Seed: every lane first descends by itself to the leaf whose boxes are nearest to ITS point (neighbouring lanes take the
+  // same path: the loads coalesce to a few lines) and takes the best of that leaf's sites.  The shared walk below then
+  // starts with a bound of about one cell spacing per lane instead of infinity -- without it the walk opened ~100 leaves per
+  // patch, because the bounds of the lanes far from the first leaf stayed wide for most of the search.  A seed is a real
+  // site with its real (distance, id), so the exact search that follows returns the same lexicographic minimum.
+  if (act) {
+    int64_t node = 0;
+    for (int lev = b.nlev - 1; lev > 0; --lev) {
+      const int64_t c0 = node * MPG_BVH_FAN, c1 = min(b.nnodes[lev - 1], c0 + MPG_BVH_FAN);
+      double dmin = INFINITY;
+      int64_t cmin = c0;
+      for (int64_t c = c0; c < c1; ++c) {
+        const double d = boxdist2_nofma(X, Y, Z, b.box + 6 * (b.off[lev - 1] + c));
+        if (d < dmin) {
+          dmin = d;
+          cmin = c;
+        }
+      }
+      node = cmin;
+    }
+    const int64_t e1 = min(b.n, (node + 1) * MPG_BVH_LEAF);
+    for (int64_t q = node * MPG_BVH_LEAF; q < e1; ++q) {
+      const double d = dist2_nofma(X, Y, Z, b.sx[q], b.sy[q], b.sz[q]);
+      const int32_t id = b.sid[q];
+      if (d < best || (d == best && id < best_id)) {
+        best = d;
+        best_id = id;
+      }
+    }
+  }
   int *st = stk[wave];
   int sp = 0;
   st[sp++] = (b.nlev - 1) << 27;
