@@ -288,29 +288,36 @@ struct LdsPoly {   // vertex i of polygon buffer `buf` of this lane
     p[2 * CLIP_NT] = v.z;
   }
 };
-// Sutherland-Hodgman step with the buffers in LDS.  A CONVEX polygon gains at most one vertex per half-space, so `cap` =
-// maxEdges + 6 slots always hold it; a non-convex cell can gain more, and a vertex that does not fit is reported through
-// *trunc (the Store then fails with MPG_ERR_OVERFLOW), never dropped silently.
-__device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, int in, dv3 nrm, int out, int cap, int *trunc = nullptr) {
+// Sutherland-Hodgman step IN PLACE, the polygon in LDS.  The output of edge i goes to slots <= i + 1 and those have been
+// read by then: vertex i+1 is in registers as X2, and a CONVEX polygon meets the plane at most twice with at least one
+// vertex outside between the two crossings, so the write index never passes i + 1 (the first vertex, needed again for the
+// closing edge, is kept in registers).  One buffer instead of two halves the LDS of the clip kernel: 8 instead of 4
+// wavefronts per CU.  The arithmetic and its order are those of the two-buffer form: the same bits.  A non-convex cell can
+// break the bound or outgrow `cap` = maxEdges + 6 slots; either is reported through *trunc (the Store then fails with
+// MPG_ERR_OVERFLOW), never a silently wrong polygon.
+__device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, dv3 nrm, int cap, int *trunc) {
   int m = 0;
   double eps = 1e-15 * sqrt(dot3(nrm, nrm));
+  const dv3 first = L.get(0, 0);
+  dv3 X1 = first;
   for (int i = 0; i < n; ++i) {
-    dv3 X1 = L.get(in, i), X2 = L.get(in, (i + 1 == n) ? 0 : i + 1);
+    const dv3 X2 = (i + 1 == n) ? first : L.get(0, i + 1);
     double d1 = dot3(nrm, X1), d2 = dot3(nrm, X2);
     bool in1 = d1 >= -eps, in2 = d2 >= -eps;
     if (in1) {
-      if (m < cap) L.set(out, m++, X1);
-      else if (trunc) *trunc = 1;
+      if (m < cap && m <= i + 1) L.set(0, m++, X1);
+      else *trunc = 1;
     }
     if (in1 != in2) {
       dv3 X = X1 * d2 - X2 * d1;
       double sgn = (d2 - d1) > 0.0 ? 1.0 : -1.0;
       double nn = sqrt(dot3(X, X));
       if (nn > 0.0) {
-        if (m < cap) L.set(out, m++, X * (sgn / nn));
-        else if (trunc) *trunc = 1;
+        if (m < cap && m <= i + 1) L.set(0, m++, X * (sgn / nn));
+        else *trunc = 1;
       }
     }
+    X1 = X2;
   }
   return m;
 }
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
                                                                  const double *__restrict__ qy, const double *__restrict__ qz,
                                                                  const double *__restrict__ qarea, int cb, double *__restrict__ pair_val,
                                                                  int32_t *__restrict__ count, int32_t *__restrict__ truncated) {
-  extern __shared__ double clip_lds[];   // [2][cb][3][CLIP_NT]
+  extern __shared__ double clip_lds[];   // [cb][3][CLIP_NT]
   const int64_t t = blockIdx.x * (int64_t)CLIP_NT + threadIdx.x;
   if (t >= npairs) return;
   const LdsPoly L{clip_lds + threadIdx.x, cb};
@@ -347,15 +354,14 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
   double ar = 0.0;
   int trunc = 0;
   if (aq > 0.0) {
-    int cur = 0;
+    const int cur = 0;
     for (int e = 0; e < 4 && n >= 3; ++e) {
       const dv3 qa = e == 0 ? q[0] : e == 1 ? q[1] : e == 2 ? q[2] : q[3];
       const dv3 qb = e == 0 ? q[1] : e == 1 ? q[2] : e == 2 ? q[3] : q[0];
       dv3 side = qb - qa;
       if (dot3(side, side) < 1e-24) continue;     // collapsed side (pole): bounds nothing
       // a x (b - a) = a x b in difference form: the direct product's rounding would shift the plane by 1e-16 / |b - a| radians
-      n = clip_halfspace_lds(n, L, cur, cross3(qa, side), cur ^ 1, cb, &trunc);
-      cur ^= 1;
+      n = clip_halfspace_lds(n, L, cross3(qa, side), cb, &trunc);
     }
     if (n >= 3) {
       double sa = 0.0;
@@ -468,7 +474,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12
   const int cb = m->maxEdges + 6 < CONS_BUF ? m->maxEdges + 6 : CONS_BUF;
-  const size_t clip_lds_bytes = sizeof(double) * 2 * cb * 3 * CLIP_NT;
+  const size_t clip_lds_bytes = sizeof(double) * cb * 3 * CLIP_NT;
   if (clip_lds_bytes > 48 * 1024)
     MPG_HIP(hipFuncSetAttribute((const void *)k_conserve_clip_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clip_lds_bytes));
   TmpBuf<int32_t> truncated;
