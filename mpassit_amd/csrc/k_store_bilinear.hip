@@ -49,13 +49,21 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
     const double *bx = pyr.box + 6 * (pyr.off[lev] + node);
     return !(bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]);
   };
+  // The node to visit next lives in a register (`cur`); only the SIBLINGS that also meet the triangle go on the stack, which
+  // is a run-time-indexed private array, i.e. scratch memory: a triangle smaller than a leaf descends all ten levels without
+  // touching it.
   int stack[RASTER_STACK];
   int sp = 0;
   int top = pyr.nlev - 1;
   int nleaf = 0;
-  if (meets(top, 0)) stack[sp++] = (top << 26);  // node 0 of the top level; node index < 2^26 per level
-  while (sp > 0) {
-    int e = stack[--sp];
+  int cur = meets(top, 0) ? (top << 26) : -1;  // node 0 of the top level; node index < 2^26 per level
+  for (;;) {
+    if (cur < 0) {
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+    const int e = cur;
+    cur = -1;
     int lev = e >> 26;
     int node = e & ((1 << 26) - 1);
     int nxl = pyr.nx[lev];
@@ -93,15 +101,16 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch)
         if (go[ch]) {
-          // only nodes that meet the triangle are stacked: a full stack cannot happen for a triangle smaller than the grid,
+          const int child = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
+          // only nodes that meet the triangle are kept: a full stack cannot happen for a triangle smaller than the grid,
           // and if it ever did it is reported (MPG_ERR_OVERFLOW), never a silently unmapped point
-          if (sp < RASTER_STACK) stack[sp++] = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
+          if (cur < 0) cur = child;
+          else if (sp < RASTER_STACK) stack[sp++] = child;
           else atomicOr(overflow, 1);
         }
     }
   }
 }
-
 
 // One wavefront per handed-over triangle: the same walk with a per-wave stack in LDS; four lanes test a node's children,
 // and a level-1 node (8 x 8 points; a lone level 0 of a tiny grid: 4 x 4) is tested one point per lane.

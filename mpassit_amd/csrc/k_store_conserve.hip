@@ -123,9 +123,15 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
     const double *bx = pyr.box + 6 * (pyr.off[lev_] + node_);
     return !(bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]);
   };
-  if (COOP || meets(seed_lev, seed)) stack[sp++] = (seed_lev << 26) | seed;
-  while (sp > 0) {
-    int e = stack[--sp];
+  // the node to visit next stays in a register; only siblings that also meet the polygon's box go on the (scratch) stack
+  int cur = (COOP || meets(seed_lev, seed)) ? ((seed_lev << 26) | seed) : -1;
+  for (;;) {
+    if (cur < 0) {
+      if (sp == 0) break;
+      cur = stack[--sp];
+    }
+    const int e = cur;
+    cur = -1;
     int lev = e >> 26, node = e & ((1 << 26) - 1);
     int nxl = pyr.nx[lev];
     int bi = node % nxl, bj = node / nxl;
@@ -187,7 +193,11 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
       }
 #pragma unroll
       for (int ch = 0; ch < 4; ++ch)
-        if (go[ch] && sp < CONS_STACK) stack[sp++] = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
+        if (go[ch]) {
+          const int child = ((lev - 1) << 26) | ((2 * bj + (ch >> 1)) * cnx + 2 * bi + (ch & 1));
+          if (cur < 0) cur = child;
+          else if (sp < CONS_STACK) stack[sp++] = child;
+        }
     }
   }
   }
