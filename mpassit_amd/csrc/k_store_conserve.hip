@@ -142,9 +142,10 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
         for (int i = i0; i < i1; ++i) {
           // bounding sphere of the destination cell (k_cell_areas) against the source polygon's padded box: 4 loads decide
           // most candidates of a 4 x 4 leaf block before the 12 corner coordinates are touched
-          const int64_t pc = (int64_t)j * nx + i, PP = (int64_t)nx * ny;
+          const int64_t pc = (int64_t)j * nx + i;
           {
-            double sx = qsph[pc], sy = qsph[PP + pc], sz = qsph[2 * PP + pc], r2 = qsph[3 * PP + pc];
+            const double4 sph = *reinterpret_cast<const double4 *>(qsph + 4 * pc);   // one 32-byte record per cell: one line, not four
+            double sx = sph.x, sy = sph.y, sz = sph.z, r2 = sph.w;
             double ddx = fmax(fmax(lo[0] - sx, sx - hi[0]), 0.0), ddy = fmax(fmax(lo[1] - sy, sy - hi[1]), 0.0),
                    ddz = fmax(fmax(lo[2] - sz, sz - hi[2]), 0.0);
             if (ddx * ddx + ddy * ddy + ddz * ddz > r2) continue;
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
 // signed area of every destination cell (corner order i,j -> i+1,j -> i+1,j+1 -> i,j+1), once per grid
 __global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double *__restrict__ qx, const double *__restrict__ qy,
                                                     const double *__restrict__ qz, double *__restrict__ qarea,
-                                                    double *__restrict__ qsph /* [4][P]: centre xyz, radius^2 */) {
+                                                    double *__restrict__ qsph /* [P][4]: centre xyz, radius^2 */) {
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (p >= (int64_t)nx * ny) return;
   int i = (int)(p % nx), j = (int)(p / nx), nxc = nx + 1;
@@ -229,11 +230,7 @@ __global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double
   d = q1 - cen; r2 = fmax(r2, dot3(d, d));
   d = q2 - cen; r2 = fmax(r2, dot3(d, d));
   d = q3 - cen; r2 = fmax(r2, dot3(d, d));
-  const int64_t P = (int64_t)nx * ny;
-  qsph[p] = cen.x;
-  qsph[P + p] = cen.y;
-  qsph[2 * P + p] = cen.z;
-  qsph[3 * P + p] = r2 * (1.0 + 1e-9) + 1e-18;
+  *reinterpret_cast<double4 *>(qsph + 4 * p) = double4{cen.x, cen.y, cen.z, r2 * (1.0 + 1e-9) + 1e-18};
 }
 
 __global__ __launch_bounds__(256) void k_csr_sort_rows(int64_t P, const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
