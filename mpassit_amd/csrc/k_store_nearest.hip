@@ -209,10 +209,10 @@ __global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int
   double best = act ? INFINITY : -1.0;      // an inactive lane admits nothing
   int32_t best_id = 0x7fffffff;
   // Seed: every lane first descends by itself to the leaf whose boxes are nearest to ITS point (neighbouring lanes take the
-  // same path: the loads coalesce to a few lines) and takes the best of that leaf's sites.  The shared walk below then
-  // starts with a bound of about one cell spacing per lane instead of infinity -- without it the walk opened ~100 leaves per
-  // patch, because the bounds of the lanes far from the first leaf stayed wide for most of the search.  A seed is a real
-  // site with its real (distance, id), so the exact search that follows returns the same lexicographic minimum.
+  // same path: the loads coalesce to a few lines) ...  A seed is a real site with its real (distance, id), so the exact search
+  // that follows returns the same lexicographic minimum; what it buys is the bound the shared walk starts from (without any
+  // seed the walk opened ~190 nodes per patch, because the bounds of the lanes far from the first leaf stayed wide).
+  int64_t seed_leaf = -1;
   if (act) {
     int64_t node = 0;
     for (int lev = b.nlev - 1; lev > 0; --lev) {
@@ -228,15 +228,25 @@ __global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int
       }
       node = cmin;
     }
-    const int64_t e1 = min(b.n, (node + 1) * MPG_BVH_LEAF);
-    for (int64_t q = node * MPG_BVH_LEAF; q < e1; ++q) {
+    seed_leaf = node;
+  }
+  // ... and every lane then tries the sites of ALL the distinct leaves the patch's lanes arrived at (about ten of them, each
+  // fetched once with wave-uniform loads): a lane's true nearest site is almost always in its own leaf or a neighbour's, so
+  // the shared walk starts from bounds that are exact for nearly every lane and only has to confirm them.
+  for (unsigned long long todo = __ballot(seed_leaf >= 0); todo;) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int64_t leaf = ((int64_t)__builtin_amdgcn_readlane((int)(seed_leaf >> 32), leader) << 32) |
+                         (unsigned)__builtin_amdgcn_readlane((int)seed_leaf, leader);
+    const int64_t e1 = min(b.n, (leaf + 1) * MPG_BVH_LEAF);
+    for (int64_t q = leaf * MPG_BVH_LEAF; q < e1; ++q) {
       const double d = dist2_nofma(X, Y, Z, b.sx[q], b.sy[q], b.sz[q]);
       const int32_t id = b.sid[q];
-      if (d < best || (d == best && id < best_id)) {
+      if (d < best || (d == best && id < best_id)) {   // an inactive lane has best = -1: nothing is below it
         best = d;
         best_id = id;
       }
     }
+    todo &= ~__ballot(seed_leaf == leaf);
   }
   int *st = stk[wave];
   int sp = 0;
