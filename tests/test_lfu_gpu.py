@@ -106,3 +106,41 @@ def test_typed_staged_paths_agree(gpu_lib):
     rh.release()
     mesh.destroy()
     grid.destroy()
+
+
+@pytest.mark.parametrize("nlev", [2, 7, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 80])
+def test_staged_level_fast_kernel_at_every_chunk_boundary(gpu_lib, nlev):
+    """k_apply3_lfu walks the levels in chunks of 16 with the last chunk moved back to nlev - 16 and a clamped level index
+    below 16 levels: every remainder (and the bundles too short to be staged, which fall to the gather) must give the row
+    gather's bits, in float32 and float64, host and big-endian byte order."""
+    import torch
+
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    g = T.define_target_grid_params("lat-lon", nx=181, ny=91, stand_lon=0.0, is_regional=False)
+    m = synth.icosahedral_mesh(4)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    s64 = torch.randn((2, m.nCells, nlev), dtype=torch.float64, device="cuda") * 30 + 280
+    try:
+        for dt in (torch.float32, torch.float64):
+            src = s64.to(dt).contiguous()
+            for be in (False, True):
+                outs = []
+                for v in (0, 1):
+                    gpu_lib.tune("lf_variant", v)
+                    outs.append(rh.regrid_typed(src.view(-1), nlev=nlev, nfields=2, layout=R.LAYOUT_LEV_FAST, out_dtype=dt, scale=9.81,
+                                                offset=-300.0, src_be=be, dst_be=be))
+                assert torch.equal(outs[0].view(torch.uint8), outs[1].view(torch.uint8)), (nlev, dt, be)
+        gpu_lib.tune("lf_variant", 1)
+        a = rh.regrid(s64.view(-1), nlev=nlev, nfields=2, layout=R.LAYOUT_LEV_FAST)
+        gpu_lib.tune("lf_variant", 0)
+        b = rh.regrid(s64.view(-1), nlev=nlev, nfields=2, layout=R.LAYOUT_LEV_FAST)
+        assert torch.equal(torch.as_tensor(a), torch.as_tensor(b))
+        if nlev >= 8:   # the staged kernel did run: 64 x 8-point tile lists are in use and fit its 512 rows
+            st = rh.tile_stats()
+            assert st is not None and st[:2] == (64, 8) and 0 < rh.kernel_choice()[2] <= 512
+    finally:
+        gpu_lib.tune("lf_variant", -1)
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
