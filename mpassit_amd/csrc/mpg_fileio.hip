@@ -8,6 +8,7 @@
 // do at PCIe speed, so a range is cut into chunks that a few threads move independently, each with two pinned staging
 // buffers and its own stream (DMA of one chunk overlaps the page-cache copy of the next).
 #include <fcntl.h>
+#include <stdlib.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -17,7 +18,7 @@
 #include "mpg_internal.h"
 
 namespace {
-constexpr int NTHREAD = 4;
+constexpr int NTHREAD = 8;   // most a direction uses; how many it does use: Lane::nt
 constexpr size_t CHUNK = (size_t)32 << 20;
 
 // Staging of one direction: NTHREAD x 2 pinned buffers and NTHREAD streams, created on first use and kept for the
@@ -26,6 +27,7 @@ constexpr size_t CHUNK = (size_t)32 << 20;
 struct Lane {
   std::mutex mu;
   bool ready = false;
+  int nt = 4;   // worker threads of this direction (read: 8, the page-cache copy of pread scales; write: 4, pwrite into one tmpfs file does not)
   void *buf[NTHREAD][2] = {};
   hipStream_t stream[NTHREAD] = {};
   hipEvent_t done[NTHREAD][2] = {};
@@ -68,6 +70,7 @@ struct Lane {
   }
 };
 Lane g_read, g_write;
+struct LaneSetup { LaneSetup() { g_read.nt = 8; const char *e = getenv("MPG_IO_READ_THREADS"); if (e && atoi(e) >= 1 && atoi(e) <= NTHREAD) g_read.nt = atoi(e); } } g_lane_setup;
 
 int xfer_full(int fd, bool writing, char *p, size_t n, off_t off) {
   while (n > 0) {
@@ -110,7 +113,7 @@ int transfer(Lane &L, int device, int fd, bool to_dev, int64_t offset, int64_t n
     }
     if (hipStreamSynchronize(L.stream[t]) != hipSuccess) err = 2;
   };
-  const int nt = nchunk < NTHREAD ? (int)nchunk : NTHREAD;
+  const int nt = nchunk < L.nt ? (int)nchunk : L.nt;
   std::thread th[NTHREAD];
   for (int t = 1; t < nt; ++t) th[t] = std::thread(work, t);
   work(0);
