@@ -191,7 +191,7 @@ int mpg_dev_download(void *dst_host, const void *src_dev, int64_t nbytes);
 int mpg_bswap_dev(void *buf_dev, int64_t n, int elem_size, void *hip_stream);
 /* The transport of such a variable: bytes [offset, offset + nbytes) of a file -> device memory and back, untouched,
  * through pinned staging buffers and a few pread / pwrite threads (the page-cache side of the copy is what limits a
- * single core).  Replaces the nf90_get_var / nf90_put_var data movement of input_data.F90:630 and
+ * single core: eight readers -- MPG_IO_READ_THREADS=1..8 in the environment overrides --, four writers).  Replaces the nf90_get_var / nf90_put_var data movement of input_data.F90:630 and
  * write_data.F90:1008-1475 for NetCDF classic files; offset / nbytes come from ncio_var_extent.  Blocking: hip_stream is
  * synchronised first (earlier users / the producer of the device buffer), the range is complete on return.  The file
  * must already have the size (ncio_var_extent extends a file being written).  One read and one write may run
