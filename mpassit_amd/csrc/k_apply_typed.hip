@@ -276,18 +276,37 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
       }
       return mapped ? acc : 0.0;
     };
+    // Two levels per step, and the loads of the NEXT two are issued before the stores of the current two: loads and stores
+    // share one in-order counter on gfx950, so a load issued after a store cannot be consumed before that store has been
+    // acknowledged -- with the loads in front, a step waits for its own data only (s_waitcnt vmcnt(2): the two stores stay
+    // in flight).
+    auto put = [&](int k, const double *v) { df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(combine(v), scale, offset), zd); };
+    double a0[NNZ], a1[NNZ];
+    level(0, a0);
+    level(nlev > 1 ? 1 : 0, a1);
     int k = 0;
-    for (; k + 1 < nlev; k += 2) {
-      double v0[NNZ], v1[NNZ];
-      level(k, v0);
-      level(k + 1, v1);
-      df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(combine(v0), scale, offset), zd);
-      df[(int64_t)(k + 1) * P + p] = swz<SWZ>((TD)fma(combine(v1), scale, offset), zd);
+    for (; k + 3 < nlev; k += 2) {
+      double b0[NNZ], b1[NNZ];
+      level(k + 2, b0);
+      level(k + 3, b1);
+      put(k, a0);
+      put(k + 1, a1);
+#pragma unroll
+      for (int q = 0; q < NNZ; ++q) {
+        a0[q] = b0[q];
+        a1[q] = b1[q];
+      }
     }
-    if (k < nlev) {
-      double v0[NNZ];
-      level(k, v0);
-      df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(combine(v0), scale, offset), zd);
+    // a0 / a1 hold levels k, k + 1; at most one more level (k + 2) is left
+    if (k + 2 < nlev) {
+      double b0[NNZ];
+      level(k + 2, b0);
+      put(k, a0);
+      put(k + 1, a1);
+      put(k + 2, b0);
+    } else {
+      put(k, a0);
+      if (k + 1 < nlev) put(k + 1, a1);
     }
   }
 }
