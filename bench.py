@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip production_path / store / job / cell_numbering / end_to_end_pcie")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--calib", action="store_true", help="also launch a known-byte-count streaming kernel (PMC calibration)")
+    ap.add_argument("--leg", default=None, choices=["job", "store"],
+                    help="internal: run only this leg in THIS (fresh) process and print its JSON object -- the default run starts one "
+                         "child process per leg so that its first-call numbers are first-in-process ones")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="kernel knob for experiments (mpg_tune), e.g. a3_staged=0; the default run sets none")
     return ap.parse_args()
@@ -76,11 +79,68 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", "4")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # Wall-clock watchdog: a rank that never arrives (a dead GPU, a stale rendezvous) must end the job, not hang it.  The
+    # children live in their own process group; on the deadline exactly that group is killed and the exit code is non-zero.
+    limit = float(os.environ.get("MPASSIT_BENCH_TIMEOUT_S", "900"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        sys.stderr.write("bench.py: the %d-rank child job did not finish within %.0f s (MPASSIT_BENCH_TIMEOUT_S); killing its process group\n" % (args.gpus, limit))
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        return 124
+
+
+def fresh_process_leg(name, args):
+    """Run one leg (`job`, `store`) in a FRESH child process and return its JSON object: MPASSIT is a single-shot tool
+    (mpassit.F90:105-137), so what a run pays for its Stores and its first time level are the first-in-process values, and
+    by the time this process gets to those legs it has loaded every code object and warmed every allocation.  A child is
+    started (never an exec: this process has initialised the GPU), bounded by a timeout, and only its last stdout line is
+    read; a leg that fails is reported as an error string, it does not take the bench line with it."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, "--workload", args.workload] + sum((["--tune", kv] for kv in args.tune), [])
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("MPASSIT_BENCH_LEG_TIMEOUT_S", "420")))
+    except subprocess.TimeoutExpired:
+        return {"error": "leg %s timed out" % name}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "leg %s failed rc %d: %s" % (name, r.returncode, r.stderr[-300:])}
+    return json.loads(lines[-1])
+
+
+def run_leg(args):
+    """`--leg job|store`: this process IS the fresh process; nothing but mpg_init has touched the device before the leg."""
+    import torch
+    from mpassit_amd import _lib, regrid as R, workloads
+    t0 = time.perf_counter()
+    _lib.init(0)
+    init_ms = (time.perf_counter() - t0) * 1e3
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.tune(k, int(v))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if args.leg == "store":
+        m, g, _, _ = workloads.workload(args.workload)
+        res = store_leg(R, m, g)
+    else:
+        res = job_leg(torch, R, workloads, args, dev)
+    if res is not None:
+        res["mpg_init_ms"] = round(init_ms, 1)
+    print(json.dumps(res), flush=True)
+    _lib.finalize()
 
 
 def main():
     args = parse()
+    if args.leg:
+        return run_leg(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
     import torch
@@ -300,9 +360,7 @@ def main():
                 sr.rh.regrid_typed_host(hs, nlev=nlev, out=ho)
                 ts.append(time.perf_counter() - t0)
             e2e[name + "_fields_per_s"] = 1.0 / min(ts)
-        e2e["what"] = ("one 3-D field, host -> device -> host through mpg_regrid_typed (chunked: upload and download as asynchronous copies "
-                       "on two streams from two threads = both PCIe directions at once; device slots kept between calls), f64 or f32 on both "
-                       "sides of the link, float64 arithmetic; pageable host buffers, reused across the repetitions")
+        # one 3-D field, pageable host -> device -> pageable host through mpg_regrid_typed (chunked, both PCIe directions at once)
 
     # The headline mesh numbers its cells row by row -- the best case for a cell-fast gather.  Beside it: the SAME 3.0 M cells
     # renumbered along a Morton curve (workload c4_3m_morton), what a production mesh reordered by a space-filling curve
@@ -314,14 +372,28 @@ def main():
     production = store = job = None
     if extras and not io32 and layout == R.LAYOUT_CELL_FAST:
         production = production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint=sr.n_needed)
-        del out
-        store = store_leg(R, sr, m, g)
-        del local, src_for_kernel, own
+        del out, local, src_for_kernel, own
         torch.cuda.empty_cache()
-        job = job_leg(torch, R, workloads, args, dev)
+        store = fresh_process_leg("store", args)      # one fresh child process per leg: first-in-process numbers
+        job = fresh_process_leg("job", args) if args.workload == "c4_3m_regional" else None
 
     if rank == 0:
         fields_per_s = F * args.steps / dt
+        # What the driver's record keeps whole is `roofline` and `config`: the numbers of the paths a run of the shipped
+        # driver actually takes (float32 file order; the whole job; the Stores) ride inside `roofline.paths`.  Cold values
+        # are FIRST-IN-PROCESS ones: MPASSIT is a single-shot tool (mpassit.F90:105-137).
+        paths = None
+        if production or job or store:
+            paths = {}
+            if production:
+                paths["f32_lev_fast_%s" % args.workload.split("_")[0]] = {
+                    "kernel": production["kernel"].split(" (")[0], "kernel_ms": round(production["kernel_ms"], 4),
+                    "frac": round(production["roofline_frac"], 4), "frac_big_endian": round(production["roofline_frac_big_endian"], 4),
+                    "traffic_ratio": round(production["traffic"] / production["alg_bytes_per_launch"], 3) if production.get("traffic") else None}
+            if job and "error" not in job:
+                paths["job"] = {k: job[k] for k in ("cold_first_ms", "cold_ms", "warm_ms", "alg_bytes_warm", "frac_warm", "geometry_first_ms", "geometry_ms")}
+            if store and "error" not in store:
+                paths["store"] = {k: {"ms_first": round(v["ms_first"], 3), "ms": round(v["ms"], 3)} for k, v in store.items() if isinstance(v, dict)}
         rec = {
             "metric": "interpolated 3-D fields/sec (nCells x nLev -> nx x ny)",
             "value": fields_per_s, "unit": "fields/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -335,7 +407,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
-                         "device_copy_GBs": copy_gbs},
+                         "device_copy_GBs": copy_gbs, "paths": paths},
             "cpu_baseline": cpu,
             "end_to_end_pcie": e2e,
             "production_path": production,
@@ -376,12 +448,10 @@ def realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, rh_r
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     alg = F * nlev * 8.0 * (U + rh.n_dst) + rh.n_dst * 36.0
-    res = {"workload": "c4_3m_morton: %s" % desc, "fields_per_s": F / ms * 1e3, "kernel_ms": ms, "steps": steps,
-           "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg, "kernel": kernel_label(rh, layout, R),
+    res = {"workload": "c4_3m_morton", "fields_per_s": F / ms * 1e3, "kernel_ms": ms, "steps": steps,
+           "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel_label(rh, layout, R),
            "tile_stats": dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh.tile_stats() or ())),
-           "tile_stats_row_numbered": dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh_rows.tile_stats() or ())),
-           "what": "the same 3.0 M cells and target grid, cells renumbered along a Morton curve (locality-preserving, not row-banded); "
-                   "line_fill = used fraction of the 128-byte source lines a tile touches"}
+           "tile_stats_row_numbered": dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh_rows.tile_stats() or ()))}
     rh.release()
     mesh.destroy()
     grid.destroy()
@@ -439,18 +509,18 @@ def production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint):
     return res
 
 
-def store_leg(R, sr, m, g):
+def store_leg(R, m, g):
     """RegridStore of the three methods on the headline mesh and grid (weights are data: built once per run, cached), as
     points/s with the algorithmic bytes of SURVEY s8(d): P*16 (target coordinates) + T*(3*4 + 48) (elements: ids + box) +
-    the weights written.  Two repetitions on fresh mesh / grid objects (nothing from the handle cache); ms = the faster,
-    ms_first = the process's very first Store of that method (search-structure allocations included)."""
+    the weights written.  ms_first = the process's very FIRST Store of that method -- what a single-shot run pays
+    (mpassit.F90:105-137) -- and the headline; ms = the fastest of the later repetitions on fresh mesh / grid objects (nothing
+    from the handle cache).  None is memory-bound: what binds each kernel is in profiles/r03_store_pmc.md."""
     P = int(g.nx * g.ny)
     nT, nC, nE = int(m.nVertices), int(m.nCells), int(m.verticesOnCell.shape[1])
     codes = (("bilinear", R.REGRIDMETHOD_BILINEAR), ("nearest", R.REGRIDMETHOD_NEAREST_STOD), ("conserve", R.REGRIDMETHOD_CONSERVE))
     ms = {name: [] for name, _ in codes}
     nnz = {}
-    ms["bilinear"].append(sr.store_ms)
-    for rep in range(2):
+    for rep in range(3):
         mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
         for name, code in codes:
             rh = R.regrid_store(mesh, grid, code)
@@ -467,12 +537,9 @@ def store_leg(R, sr, m, g):
             alg = P * 16.0 + nC * (24.0 + 4.0) + P * 4.0
         else:
             alg = (P + g.nx + g.ny + 1) * 16.0 + nC * (nE * 4.0 + 48.0) + nT * 16.0 + nnz[name] * 12.0 + (P + 1) * 4.0
-        best = min(ms[name])
-        res[name] = {"ms": best, "ms_first": ms[name][0], "points_per_s": P / (best * 1e-3), "alg_bytes": alg,
-                     "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "nnz": nnz[name]}
-    res["what"] = ("mpg_handle_store_ms of a cold Store (search structure + search + weights), %d target points; none of them is "
-                   "memory-bound: what binds each kernel (wave cycles parked / issue-stalled / active, lane utilisation, scratch) is in "
-                   "profiles/r03_store_pmc.md" % P)
+        best, first = min(ms[name][1:]), ms[name][0]
+        res[name] = {"ms_first": first, "ms": best, "points_per_s_first": P / (first * 1e-3), "alg_bytes": alg,
+                     "frac_of_hbm_peak_first": alg / (first * 1e-3) / 1e9 / HBM_PEAK_GBS, "nnz": nnz[name]}
     return res
 
 
@@ -480,8 +547,11 @@ def job_leg(torch, R, workloads, args, dev):
     """The whole hot path of one run, through the C-ABI: interp_data (interp.F90:92-465) over the reference's default
     diag + hist lists with wrf_mod_vars=.true. -- every RegridStore, every Regrid, the wind rotation and the destaggering --
     on device-resident float32 fields in MPAS file order, target grid generated on the device.  cold = fresh mesh / grid
-    objects (every Store and every tile-list build inside the timed region); warm = the weights of the same objects kept
-    (a second time level)."""
+    objects (every Store and every tile-list build inside the timed region), cold_first = the first such pass of the
+    PROCESS -- what a single-shot run pays; warm = the weights of the same objects kept (a second time level); host wall ms
+    between two device synchronisations.  alg_bytes_warm = the algorithmic bytes of the warm level's Regrids and rotations
+    (U*L*e_src + P*L*e_dst per field + indices and weights per call), frac_warm = those over warm_ms over the HBM peak.
+    geometry_* = mpg_mesh_create (upload + dual triangles) + mpg_grid_create_proj, not part of cold_ms."""
     from mpassit_amd import interp as I
     if args.workload != "c4_3m_regional":
         return None
@@ -526,6 +596,13 @@ def job_leg(torch, R, workloads, args, dev):
             (cold if k == 0 else warm).append(((time.perf_counter() - t0) * 1e3, e0.elapsed_time(e1)))
             n3d, nout = sum(1 for v in out.values() if v.ndim == 3 and v.shape[0] >= nz), len(out)
             del out
+        if rep == 0:   # algorithmic bytes of one warm time level (SURVEY s8(d) per call, regrid.ACCOUNT), in an untimed pass
+            R.ACCOUNT = []
+            del_out = I.interp_data(mesh, grid, g, inp, cfg)
+            torch.cuda.synchronize()
+            alg_warm = float(sum(b for _, b in R.ACCOUNT))
+            R.ACCOUNT = None
+            del del_out
         graph_ms = None
         if rep == 1:   # the same time level as ONE hipGraph (interp.GraphedInterp): what is left without the per-launch host cost
             gi = I.GraphedInterp(mesh, grid, g, inp, cfg)
@@ -541,15 +618,12 @@ def job_leg(torch, R, workloads, args, dev):
             del gi
         mesh.destroy()
         grid.destroy()
-    return {"workload": "%s: %s" % (args.workload, desc), "outputs": nout, "fields_3d": n3d, "warm_graph_replay_ms": graph_ms,
-            "cold_ms": min(c[0] for c in cold), "warm_ms": min(w[0] for w in warm), "geometry_ingest_ms": min(geom),
-            "cold_ms_all": [round(c[0], 2) for c in cold], "warm_ms_all": [round(w[0], 2) for w in warm],
-            "fields_3d_per_s_cold": n3d / (min(c[0] for c in cold) * 1e-3), "fields_3d_per_s_warm": n3d / (min(w[0] for w in warm) * 1e-3),
-            "what": "interp_data over the reference's default lists (wrf_mod_vars=.true.: rotation, U/V destaggering), float32 file-order "
-                    "sources resident in HBM, float64 results; host wall ms between two device synchronisations; cold = every "
-                    "RegridStore (bilinear element + nearest + conservative + 2 grid-to-grid) inside; warm_graph_replay = the warm time "
-                    "level captured into one hipGraph and replayed; geometry_ingest = "
-                    "mpg_mesh_create (upload + dual triangles) + mpg_grid_create_proj, not part of cold_ms"}
+    warm_ms = min(w[0] for w in warm)
+    return {"outputs": nout, "fields_3d": n3d, "warm_graph_replay_ms": graph_ms,
+            "cold_first_ms": round(cold[0][0], 3), "cold_ms": round(min(c[0] for c in cold), 3), "warm_ms": round(warm_ms, 3),
+            "geometry_first_ms": round(geom[0], 3), "geometry_ms": round(min(geom), 3),
+            "alg_bytes_warm": alg_warm, "frac_warm": round(alg_warm / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "fields_3d_per_s_cold_first": n3d / (cold[0][0] * 1e-3), "fields_3d_per_s_warm": n3d / (warm_ms * 1e-3)}
 
 
 def cpu_baseline(sr, local_rows, nlev, seconds, m, g):

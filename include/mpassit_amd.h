@@ -33,7 +33,8 @@ enum {
   MPG_ERR_INVALID_ARG = 2,
   MPG_ERR_HIP = 3,
   MPG_ERR_UNSUPPORTED = 4,
-  MPG_ERR_OVERFLOW = 5
+  MPG_ERR_OVERFLOW = 5,
+  MPG_ERR_TIMEOUT = 6   /* a wait on another rank hit its deadline (mpg_comm_*): exit the process, do not retry in it */
 };
 
 /* ESMF_REGRIDMETHOD_* (interp.F90:119,204,370,420) */
@@ -296,9 +297,16 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
  *                                         enqueued on the stream; buffers allocated at the first call of a batch size
  *   mpg_gather_rows                       ESMF_FieldGather (write_data.F90:1006-1453): row blocks -> the whole field on root
  *   mpg_halo_plan_host                    the schedule as a pure function of every rank's needed ids (tests, diagnostics) */
+/* The id file and its deadlines: rank 0 removes whatever is at `id_file`, writes {magic, launch tag = hash of the
+ * environment's MPASSIT_RUN_ID (0 without), wall-clock time, nranks, id} and removes the file again once ncclCommInitRank
+ * has returned; the other ranks ignore a file with another tag / nranks or written more than MPG_COMM_STALE_S (300) seconds
+ * before they loaded the library.  Waiting for the file, ncclCommInitRank (run on a helper thread) and the blocking
+ * all-gathers give up after MPG_COMM_TIMEOUT_S (120) seconds with MPG_ERR_TIMEOUT: a dead or missing peer is an error exit,
+ * never a hang.  mpg_comm_idfile_verdict is that acceptance rule as a pure function (NULL = accepted; CPU tests). */
 typedef struct mpg_comm_s *mpg_comm;
 typedef struct mpg_halo_s *mpg_halo;
 int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out);
+const char *mpg_comm_idfile_verdict(const void *bytes, int64_t nbytes, int nranks, uint64_t tag, int64_t reader_loaded_ns, double stale_s);
 int mpg_comm_destroy(mpg_comm comm);
 int mpg_comm_info(mpg_comm comm, int *rank, int *nranks);
 int mpg_comm_allgather(mpg_comm comm, const void *send_host, int64_t nbytes, void *recv_host);
@@ -308,9 +316,10 @@ int mpg_halo_build(mpg_comm comm, mpg_handle rh, int64_t n_cells_global, int own
  * cross the links per exchanged row.  Any pointer may be NULL. */
 int mpg_halo_info(mpg_halo halo, int *mode, int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *sent_per_row,
                   int64_t *received_per_row);
-/* own_dev: nrows rows of the own block, row stride own_ld elements (range form: may point into local_dev at own_pos[0] with
- * own_ld = n_local -- the own data is then in place and only the neighbours' strips move); local_dev: [nrows][n_local],
- * filled in place; elem_bytes 4 or 8 */
+/* own_dev: nrows rows of the own block, row stride own_ld elements; local_dev: [nrows][n_local], filled in place; elem_bytes
+ * 4 or 8.  Range form: own_dev may be the in-place view (local_dev + own_pos[0] elements, own_ld = n_local) -- the own
+ * data is then where Regrid reads it and only the neighbours' strips move -- or a separate buffer, which is copied to
+ * its place first; any other overlap with local_dev is refused.  Compact form: own_dev is always a separate buffer. */
 int mpg_halo_exchange_dev(mpg_halo halo, const void *own_dev, int64_t own_ld, void *local_dev, int nrows, int elem_bytes, void *hip_stream);
 int mpg_halo_destroy(mpg_halo halo);
 /* rows_dev: this rank's [nlev][j1 - j0][nx] block of an [nlev][ny][nx] field; dst_dev (root only): the whole field */

@@ -431,3 +431,6 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout
   if (rc == MPG_SUCCESS && h->n_pole) rc = mpg_k_pole_fix(h, src, src_type, layout, nlev, nfields, dst, dst_type, scale, offset, s);
   return rc;
 }
+
+// mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
+const void *mpg_anchor_k_apply_typed() { return (const void *)&k_apply3_cf_t<float, float, false>; }

@@ -316,3 +316,6 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   }
   return MPG_SUCCESS;
 }
+
+// mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
+const void *mpg_anchor_k_store_bilinear() { return (const void *)&k_tri_raster<false>; }

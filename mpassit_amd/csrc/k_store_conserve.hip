@@ -517,3 +517,6 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipStreamSynchronize(s));
   return MPG_SUCCESS;
 }
+
+// mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
+const void *mpg_anchor_k_store_conserve() { return (const void *)k_cell_areas; }

@@ -140,3 +140,6 @@ int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, h
   MPG_HIP(hipStreamSynchronize(s));
   return MPG_SUCCESS;
 }
+
+// mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
+const void *mpg_anchor_k_store_gridbil() { return (const void *)k_grid_bilinear; }

@@ -3,9 +3,11 @@
 // in the k_*.hip kernels; there is deliberately no CPU code path.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -109,6 +111,57 @@ void mpg_pool_release() {
 }
 
 
+// ---- first-call costs paid at mpg_init ---------------------------------------------------------------------------------
+// The HIP runtime loads a translation unit's code object at the first launch of one of its kernels: measured on MI355X
+// (tools/first_call_probe.py, profiles/r04_first_call.txt) the first nearest Store of a process took 8.0 ms against 3.1 ms
+// for the second, the first conservative Store 14.5 against 4.5, the first mpg_mesh_create 12.5 against 4.5 -- MPASSIT is
+// a single-shot tool (mpassit.F90:105-137), so the first values are what a run pays.  mpg_init therefore starts a helper
+// thread that asks the runtime for one kernel of every translation unit (hipFuncGetAttributes loads the module) and
+// creates the pinned staging of the host-array upload path, while the caller goes on (reading its namelist, opening its
+// files); a call that needs a module before the helper got to it simply loads it itself (the runtime serialises that).
+#define MPG_ANCHORS(X) X(k_setup) X(k_target_grid) X(k_store_bilinear) X(k_store_nearest) X(k_store_conserve) X(k_store_gridbil) \
+  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_pole) X(k_post) X(k_halo) X(mpg_comm)
+#define X(n) const void *mpg_anchor_##n();
+MPG_ANCHORS(X)
+#undef X
+static std::thread *g_warm = nullptr;   // on the heap: a process that exits without mpg_finalize must not meet ~thread of a joinable thread
+static void warm_modules(int device) {
+  if (hipSetDevice(device) != hipSuccess) return;
+  hipFuncAttributes a;
+#define X(n) (void)hipFuncGetAttributes(&a, mpg_anchor_##n());
+  MPG_ANCHORS(X)
+#undef X
+  // the runtime builds its staging for copies from pageable host memory at the first such copy (9.5 ms in front of the first
+  // mpg_mesh_create, rocprofv3 --hip-trace): one throw-away 32 MB upload does that here
+  const size_t n = (size_t)32 << 20;
+  void *h = malloc(n), *d = nullptr;
+  hipStream_t s = nullptr;
+  if (h && hipMalloc(&d, n) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) {
+    memset(h, 0, n);
+    (void)hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
+  }
+  if (s) (void)hipStreamDestroy(s);
+  if (d) (void)hipFree(d);
+  free(h);
+}
+static void warm_join() {   // mpg_finalize, and atexit (registered after the HIP runtime's own handlers: runs before them)
+  if (g_warm) {
+    if (g_warm->joinable()) g_warm->join();
+    delete g_warm;
+    g_warm = nullptr;
+  }
+}
+
+// Everything the library holds only as a cache goes back to the driver: parked handles, scratch blocks.  Called when an
+// allocation fails, before it is tried once more (DevBuf::alloc, mpg_dev_alloc).
+static void drop_parked(void *obj);
+static bool g_cache_busy = false;   // a caller is walking g_cache (mpg_mesh_set_source_window): its entries must stay
+void mpg_release_caches() {
+  if (!g_cache_busy) drop_parked(nullptr);
+  mpg_pool_release();
+}
+
 extern "C" {
 
 const char *mpg_last_error(void) { return g_err; }
@@ -129,7 +182,18 @@ int mpg_init(int device) {
     return MPG_ERR_INVALID_ARG;
   }
   MPG_HIP(hipSetDevice(device));
-  if (!g_init) MPG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  if (!g_init) {
+    MPG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    const char *e = getenv("MPG_NO_WARMUP");   // A/B runs of the first-call probe
+    if (!(e && *e == '1')) {
+      g_warm = new std::thread(warm_modules, device);
+      static bool registered = false;
+      if (!registered) {
+        atexit(warm_join);
+        registered = true;
+      }
+    }
+  }
   g_device = device;
   g_init = true;
   return MPG_SUCCESS;
@@ -150,6 +214,7 @@ static void drop_parked(void *obj) {   // obj == nullptr: all of them
 
 int mpg_finalize(void) {
   if (!g_init) return MPG_SUCCESS;
+  warm_join();
   drop_parked(nullptr);
   mpg_fileio_release();
   mpg_hostpipe_release();
@@ -479,6 +544,7 @@ int mpg_mesh_set_source_window(mpg_mesh m, int meshloc, int64_t first, int64_t c
   const int64_t n_all = meshloc == MPG_MESHLOC_ELEMENT ? m->nCells : m->nVertices;
   MPG_ARG(first >= 0 && count >= 0 && first + count <= n_all, "mpg_mesh_set_source_window: the window must lie inside the mesh");
   const int64_t old_first = m->win_count[meshloc] >= 0 ? m->win_first[meshloc] : 0;
+  struct Busy { Busy() { g_cache_busy = true; } ~Busy() { g_cache_busy = false; } } busy;
   // every handle of this mesh and location that exists already (in use or parked) moves to the new window -- after ALL of
   // them have been checked: one that references a source outside it fails the call and nothing has changed
   for (auto &kv : g_cache) {
@@ -780,6 +846,26 @@ static void lf_invalidate(mpg_handle_s *h) {
 }
 
 // ---- multi-GPU halo support (kernels in k_halo.hip) ----------------------------------------------------
+// The source window of a mesh (mpg_mesh_set_source_window) and the in-place re-indexing verbs below are two answers to the
+// same question -- which sources does this rank hold -- and do not compose: a handle of a windowed mesh indexes relative to
+// the window, which mpg_handle_rebase / _localize / mpg_halo_build would take for global ids.  They refuse such a handle;
+// mpg_handle_unique_sources and mpg_handle_source_range report GLOBAL ids whatever the window is.
+}  // extern "C"
+int64_t mpg_handle_window_first(const mpg_handle_s *h) {   // > 0 offset of the handle's indices, 0 when its mesh is not windowed
+  if (!h->cached || std::get<1>(h->key) >= 100) return 0;
+  const mpg_mesh_s *m = (const mpg_mesh_s *)std::get<0>(h->key);
+  const int loc = std::get<1>(h->key);
+  return m->win_count[loc] >= 0 ? m->win_first[loc] : 0;
+}
+bool mpg_handle_is_windowed(const mpg_handle_s *h) {
+  if (!h->cached || std::get<1>(h->key) >= 100) return false;
+  return ((const mpg_mesh_s *)std::get<0>(h->key))->win_count[std::get<1>(h->key)] >= 0;
+}
+extern "C" {
+#define MPG_NOT_WINDOWED(h, what)                                                                                                  \
+  MPG_ARG(!mpg_handle_is_windowed(h), what ": the handle's mesh has a source window (mpg_mesh_set_source_window); a windowed mesh and " \
+                                           "in-place re-indexing are alternatives -- reset the window to the whole mesh first")
+
 int mpg_handle_unique_sources(mpg_handle h, int64_t *n_unique, int32_t *ids_host) {
   MPG_CHECK_INIT();
   MPG_ARG(h && n_unique, "mpg_handle_unique_sources: NULL argument");
@@ -788,6 +874,9 @@ int mpg_handle_unique_sources(mpg_handle h, int64_t *n_unique, int32_t *ids_host
   std::vector<int32_t> ids;
   int rc = mpg_k_unique_sources(h, ids, false, g_stream);
   if (rc) return rc;
+  const int32_t w0 = (int32_t)mpg_handle_window_first(h);   // window-relative -> global
+  if (w0)
+    for (int32_t &c : ids) c += w0;
   *n_unique = (int64_t)ids.size();
   if (ids_host && !ids.empty()) memcpy(ids_host, ids.data(), sizeof(int32_t) * ids.size());
   return MPG_SUCCESS;
@@ -800,6 +889,7 @@ int mpg_handle_localize(mpg_handle h) {
   MPG_ARG(h->refcount <= 1, "mpg_handle_localize: the handle is shared (a second mpg_regrid_store returned it from the cache); "
                             "re-indexing it in place would corrupt the other holder's indices -- release the other reference first");
   MPG_ARG(h->n_pole == 0, "mpg_handle_localize: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
+  MPG_NOT_WINDOWED(h, "mpg_handle_localize");
   // a localized handle no longer matches its cache key: detach it
   if (h->cached) {
     g_cache.erase(h->key);
@@ -818,6 +908,7 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
                             "re-indexing it in place would corrupt the other holder's indices -- release the other reference first");
   MPG_ARG(h->n_pole == 0, "mpg_handle_rebase: handles with pole terms (periodic Grid -> Grid) cannot be re-indexed");
   MPG_ARG(base >= 0 && n_local >= 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
+  MPG_NOT_WINDOWED(h, "mpg_handle_rebase");
   if (h->cached) {
     g_cache.erase(h->key);
     h->cached = false;
@@ -846,7 +937,11 @@ int mpg_dev_alloc(int64_t nbytes, void **out_dev) {
   MPG_ARG(out_dev && nbytes >= 0, "mpg_dev_alloc: bad argument");
   *out_dev = nullptr;
   if (nbytes == 0) return MPG_SUCCESS;
-  MPG_HIP(hipMalloc(out_dev, (size_t)nbytes));
+  if (hipMalloc(out_dev, (size_t)nbytes) != hipSuccess) {   // the library's own caches may be what fills the device
+    (void)hipGetLastError();
+    mpg_release_caches();
+    MPG_HIP(hipMalloc(out_dev, (size_t)nbytes));
+  }
   return MPG_SUCCESS;
 }
 

@@ -14,12 +14,18 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "mpg_internal.h"
 
@@ -217,6 +223,59 @@ __global__ __launch_bounds__(256) void k_pack_ids(const T *__restrict__ src, int
   for (int k = 0; k < nrows; ++k) dst[(int64_t)k * n + i] = src[(int64_t)k * ld + c];
 }
 
+// The id file: rank 0 writes {magic, launch tag, wall-clock time, nranks, RCCL unique id} under a temporary name and renames
+// it; the others poll for it.  What can go wrong is a file LEFT BEHIND by an earlier launch that died before rank 0 could
+// remove it: a rank reading that id would sit in ncclCommInitRank for ever.  Hence
+//   * rank 0 removes whatever is at `id_file` before it writes, and removes its own file once ncclCommInitRank has returned
+//     (every rank has read it by then: the call is collective);
+//   * a reader only accepts a file with the right magic and nranks, with ITS launch tag (a hash of MPASSIT_RUN_ID when
+//     the launcher sets one -- tools/mpassit_ranks.py, bench.py do), and written no longer than MPG_COMM_STALE_S (300 s)
+//     before this process loaded the library; anything else is ignored and the wait goes on;
+//   * every wait has a deadline (MPG_COMM_TIMEOUT_S, default 120 s) -- for the file, and for ncclCommInitRank itself, which
+//     runs on a helper thread: a peer that never arrives gives MPG_ERR_TIMEOUT, not a hang.  After a timeout the process
+//     must exit (the helper thread is still inside RCCL); never restart a process that has touched the GPU.
+namespace {
+struct IdFile {
+  char magic[8];
+  uint64_t tag;
+  int64_t written_ns;
+  int32_t nranks, pad;
+  ncclUniqueId id;
+};
+const char ID_MAGIC[8] = {'M', 'P', 'G', 'R', 'C', 'C', 'L', '2'};
+int64_t wall_ns() {
+  struct timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+const int64_t g_loaded_ns = wall_ns();   // when this process loaded the library
+uint64_t launch_tag() {                  // FNV-1a of MPASSIT_RUN_ID; 0 without one
+  const char *e = getenv("MPASSIT_RUN_ID");
+  if (!e || !*e) return 0;
+  uint64_t h = 1469598103934665603ull;
+  for (; *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ull;
+  return h ? h : 1;
+}
+double env_seconds(const char *name, double dflt) {
+  const char *e = getenv(name);
+  if (!e || !*e) return dflt;
+  const double v = atof(e);
+  return v > 0.0 ? v : dflt;
+}
+}  // namespace
+double mpg_comm_timeout_s() { return env_seconds("MPG_COMM_TIMEOUT_S", 120.0); }
+
+// Why a candidate id file is not this launch's (nullptr: it is).  Pure host logic, exported for the CPU tests.
+extern "C" const char *mpg_comm_idfile_verdict(const void *bytes, int64_t nbytes, int nranks, uint64_t tag, int64_t reader_loaded_ns, double stale_s) {
+  if (nbytes != (int64_t)sizeof(IdFile)) return "wrong size";
+  const IdFile *f = (const IdFile *)bytes;
+  if (memcmp(f->magic, ID_MAGIC, 8)) return "wrong magic";
+  if (f->nranks != nranks) return "written for another number of ranks";
+  if (f->tag != tag) return "written by another launch (MPASSIT_RUN_ID differs)";
+  if ((double)(reader_loaded_ns - f->written_ns) * 1e-9 > stale_s) return "older than this process: left behind by an earlier launch";
+  return nullptr;
+}
+
 extern "C" {
 
 int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
@@ -225,42 +284,89 @@ int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
   MPG_ARG(nranks == 1 || (id_file && *id_file), "mpg_comm_init: nranks > 1 needs the path of the id file");
   int rc = rccl_load();
   if (rc) return rc;
-  ncclUniqueId id;
-  memset(&id, 0, sizeof(id));
+  const double timeout_s = mpg_comm_timeout_s(), stale_s = env_seconds("MPG_COMM_STALE_S", 300.0);
+  const int64_t t_start = wall_ns();
+  IdFile f;
+  memset(&f, 0, sizeof(f));
   if (rank == 0) {
-    MPG_NCCL(R.GetUniqueId(&id));
-    if (nranks > 1) {   // under a temporary name, then renamed: a reader never sees half an id
+    MPG_NCCL(R.GetUniqueId(&f.id));
+    if (nranks > 1) {   // under a temporary name, then renamed: a reader never sees half a file
+      memcpy(f.magic, ID_MAGIC, 8);
+      f.tag = launch_tag();
+      f.written_ns = wall_ns();
+      f.nranks = nranks;
+      (void)unlink(id_file);   // whatever an earlier launch left there
       std::string tmp = std::string(id_file) + ".tmp";
-      FILE *f = fopen(tmp.c_str(), "wb");
-      if (!f || fwrite(&id, 1, sizeof(id), f) != sizeof(id) || fclose(f) || rename(tmp.c_str(), id_file)) {
+      FILE *fp = fopen(tmp.c_str(), "wb");
+      if (!fp || fwrite(&f, 1, sizeof(f), fp) != sizeof(f) || fclose(fp) || rename(tmp.c_str(), id_file)) {
         mpg_set_error("mpg_comm_init: cannot write the id file %s", id_file);
         return MPG_ERR_INVALID_ARG;
       }
     }
   } else {
     bool got = false;
-    for (int tries = 0; tries < 60000 && !got; ++tries) {   // up to 10 minutes
-      FILE *f = fopen(id_file, "rb");
-      if (f) {
-        got = fread(&id, 1, sizeof(id), f) == sizeof(id);
-        fclose(f);
+    const char *why = "no file";
+    while (!got && (double)(wall_ns() - t_start) * 1e-9 < timeout_s) {
+      IdFile cand;
+      FILE *fp = fopen(id_file, "rb");
+      if (fp) {
+        const size_t n = fread(&cand, 1, sizeof(cand), fp);
+        fclose(fp);
+        why = mpg_comm_idfile_verdict(&cand, (int64_t)n, nranks, launch_tag(), g_loaded_ns, stale_s);
+        if (!why) {
+          f = cand;
+          got = true;
+        }
       }
-      if (!got) usleep(10000);
+      if (!got) usleep(5000);
     }
     if (!got) {
-      mpg_set_error("mpg_comm_init: timed out waiting for the id file %s", id_file);
-      return MPG_ERR_INVALID_ARG;
+      mpg_set_error("mpg_comm_init: rank %d gave up after %.0f s waiting for this launch's id file %s (last candidate: %s)", rank, timeout_s, id_file, why);
+      return MPG_ERR_TIMEOUT;
     }
+  }
+  // ncclCommInitRank blocks until every rank has joined: on a helper thread, so that a missing peer is an error after
+  // timeout_s instead of a hang
+  struct Join {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t res = ncclSuccess;
+    ncclComm_t comm = nullptr;
+  };
+  auto join = std::make_shared<Join>();
+  int device = 0;
+  MPG_HIP(hipGetDevice(&device));
+  const ncclUniqueId id = f.id;
+  std::thread([join, device, nranks, id, rank]() {
+    ncclComm_t c = nullptr;
+    ncclResult_t r = hipSetDevice(device) == hipSuccess ? R.CommInitRank(&c, nranks, id, rank) : ncclUnhandledCudaError;
+    std::lock_guard<std::mutex> lk(join->mu);
+    join->res = r;
+    join->comm = c;
+    join->done = true;
+    join->cv.notify_all();
+  }).detach();
+  bool joined;
+  {
+    std::unique_lock<std::mutex> lk(join->mu);
+    const double left = timeout_s - (double)(wall_ns() - t_start) * 1e-9;
+    joined = join->cv.wait_for(lk, std::chrono::duration<double>(left > 1.0 ? left : 1.0), [&] { return join->done; });
+  }
+  if (rank == 0 && nranks > 1) (void)unlink(id_file);   // read by everyone who joined; never left for a later launch
+  if (!joined) {
+    mpg_set_error("mpg_comm_init: rank %d of %d: ncclCommInitRank did not return within %.0f s (a peer is missing or read another launch's id); "
+                  "exit this process", rank, nranks, timeout_s);
+    return MPG_ERR_TIMEOUT;
+  }
+  if (join->res != ncclSuccess) {
+    mpg_set_error("ncclCommInitRank failed: %s", R.GetErrorString(join->res));
+    return MPG_ERR_HIP;
   }
   mpg_comm_s *c = new mpg_comm_s();
   c->rank = rank;
   c->nranks = nranks;
-  ncclResult_t r = R.CommInitRank(&c->comm, nranks, id, rank);
-  if (r != ncclSuccess) {
-    mpg_set_error("ncclCommInitRank failed: %s", R.GetErrorString(r));
-    delete c;
-    return MPG_ERR_HIP;
-  }
+  c->comm = join->comm;
   *out = c;
   return MPG_SUCCESS;
 }
@@ -279,6 +385,25 @@ int mpg_comm_info(mpg_comm c, int *rank, int *nranks) {
   return MPG_SUCCESS;
 }
 
+// hipStreamSynchronize with a deadline: a collective whose peer died never completes
+static int stream_wait_deadline(hipStream_t s, const char *what) {
+  const double timeout_s = mpg_comm_timeout_s();
+  const int64_t t0 = wall_ns();
+  for (;;) {
+    hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return MPG_SUCCESS;
+    if (e != hipErrorNotReady) {
+      mpg_set_error("%s: %s", what, hipGetErrorString(e));
+      return MPG_ERR_HIP;
+    }
+    if ((double)(wall_ns() - t0) * 1e-9 > timeout_s) {
+      mpg_set_error("%s: the exchange did not complete within %.0f s (a peer is gone); exit this process", what, timeout_s);
+      return MPG_ERR_TIMEOUT;
+    }
+    usleep(50);
+  }
+}
+
 // every rank contributes nbytes from send_host; recv_host gets nranks * nbytes in rank order (small host-side metadata)
 int mpg_comm_allgather(mpg_comm c, const void *send_host, int64_t nbytes, void *recv_host) {
   MPG_CHECK_INIT();
@@ -290,8 +415,7 @@ int mpg_comm_allgather(mpg_comm c, const void *send_host, int64_t nbytes, void *
   MPG_HIP(hipMemcpyAsync(sb.p, send_host, (size_t)nbytes, hipMemcpyHostToDevice, s));
   MPG_NCCL(R.AllGather(sb.p, rb.p, (size_t)nbytes, ncclChar, c->comm, s));
   MPG_HIP(hipMemcpyAsync(recv_host, rb.p, (size_t)nbytes * c->nranks, hipMemcpyDeviceToHost, s));
-  MPG_HIP(hipStreamSynchronize(s));
-  return MPG_SUCCESS;
+  return stream_wait_deadline(s, "mpg_comm_allgather");
 }
 
 // The schedule as a pure function of every rank's needed ids (diagnostics / tests; mpg_halo_build obtains the same inputs
@@ -338,6 +462,8 @@ int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg
   MPG_ARG(c && h && out && n_cells > 0 && n_cells < 0x7fffffff, "mpg_halo_build: bad argument");
   MPG_ARG(!h->localized && h->n_pole == 0, "mpg_halo_build: the handle was re-indexed already, or carries pole terms");
   MPG_ARG(h->refcount <= 1, "mpg_halo_build: the handle is shared; re-indexing it in place would corrupt the other holder's indices");
+  MPG_ARG(!mpg_handle_is_windowed(h), "mpg_halo_build: the handle's mesh has a source window (mpg_mesh_set_source_window): its indices are "
+                                      "window-relative; a windowed mesh and a halo exchange are alternatives -- reset the window first");
   hipStream_t s = mpg_setup_stream();
   std::vector<int32_t> ids;
   int rc = mpg_k_unique_sources(h, ids, false, s);
@@ -394,10 +520,14 @@ int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg
   H->stot = H->soff[world];
   H->rtot = H->roff[world];
   if (p.mode == 1 && H->ids_off[world] > 0) {
-    if ((rc = H->send_ids_dev.alloc((size_t)H->ids_off[world]))) { delete H; return rc; }
+    if ((rc = H->send_ids_dev.alloc((size_t)H->ids_off[world]))) { mpg_halo_destroy(H); return rc; }
     for (int q = 0; q < world; ++q)
       if (!p.send_ids[q].empty())
-        MPG_HIP(hipMemcpy(H->send_ids_dev.p + H->ids_off[q], p.send_ids[q].data(), sizeof(int32_t) * p.send_ids[q].size(), hipMemcpyHostToDevice));
+        if (hipMemcpy(H->send_ids_dev.p + H->ids_off[q], p.send_ids[q].data(), sizeof(int32_t) * p.send_ids[q].size(), hipMemcpyHostToDevice) != hipSuccess) {
+          mpg_set_error("mpg_halo_build: uploading the send lists failed");
+          mpg_halo_destroy(H);
+          return MPG_ERR_HIP;
+        }
   }
   *out = H;
   return MPG_SUCCESS;
@@ -473,6 +603,18 @@ int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void 
     }
     MPG_NCCL(R.GroupEnd());
   }
+  // range form with the own block held elsewhere: it goes to its place in the local space first (in place when own_dev
+  // already IS that place)
+  if (p.mode == 0 && p.own1 > p.own0) {
+    char *home = (char *)local_dev + (size_t)p.own_pos0 * es;
+    const bool in_place = (const char *)own_dev == home && (size_t)own_ld == n_local;
+    const char *lo = (const char *)local_dev, *hi = lo + (size_t)nrows * n_local * es;
+    const char *olo = (const char *)own_dev, *ohi = olo + ((size_t)(nrows - 1) * (size_t)own_ld + (size_t)(p.own1 - p.own0)) * es;
+    MPG_ARG(in_place || ohi <= lo || olo >= hi, "mpg_halo_exchange_dev: own_dev overlaps local_dev without being the in-place view "
+                                                 "(local_dev + own_pos[0] elements, own_ld = n_local)");
+    if (!in_place)
+      MPG_HIP(hipMemcpy2DAsync(home, n_local * es, own_dev, (size_t)own_ld * es, (size_t)(p.own1 - p.own0) * es, (size_t)nrows, hipMemcpyDeviceToDevice, s));
+  }
   // 3. unpack into the local index space (the rank's own share of a compact schedule never leaves the device)
   for (int q = 0; q < world; ++q) {
     const int64_t n = p.recv_count(q);
@@ -528,3 +670,6 @@ int mpg_gather_rows(mpg_comm c, const void *rows_dev, int64_t j0, int64_t j1, in
 }
 
 }  // extern "C"
+
+// mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
+const void *mpg_anchor_mpg_comm() { return (const void *)&k_pack_ids<uint32_t>; }

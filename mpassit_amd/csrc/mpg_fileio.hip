@@ -9,6 +9,7 @@
 // buffers and its own stream (DMA of one chunk overlaps the page-cache copy of the next).
 #include <fcntl.h>
 #include <stdlib.h>
+#include <string.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -27,15 +28,16 @@ constexpr size_t CHUNK = (size_t)32 << 20;
 struct Lane {
   std::mutex mu;
   bool ready = false;
+  size_t bufsize = CHUNK;   // bytes of each pinned staging buffer
   int nt = 4;   // worker threads of this direction (read: 8, the page-cache copy of pread scales; write: 4, pwrite into one tmpfs file does not)
   void *buf[NTHREAD][2] = {};
   hipStream_t stream[NTHREAD] = {};
   hipEvent_t done[NTHREAD][2] = {};
   int init_all() {
-    for (int t = 0; t < NTHREAD; ++t) {
+    for (int t = 0; t < nt; ++t) {   // only the lanes this direction uses: 2 x 32 MB of pinned memory each
       MPG_HIP(hipStreamCreateWithFlags(&stream[t], hipStreamNonBlocking));
       for (int b = 0; b < 2; ++b) {
-        MPG_HIP(hipHostMalloc(&buf[t][b], CHUNK, hipHostMallocDefault));
+        MPG_HIP(hipHostMalloc(&buf[t][b], bufsize, hipHostMallocDefault));
         MPG_HIP(hipEventCreateWithFlags(&done[t][b], hipEventDisableTiming));
       }
     }
@@ -85,7 +87,8 @@ int xfer_full(int fd, bool writing, char *p, size_t n, off_t off) {
 
 // error codes of a worker: 0 ok, 1 file I/O, 2 HIP
 int transfer(Lane &L, int device, int fd, bool to_dev, int64_t offset, int64_t nbytes, char *dev) {
-  const int64_t nchunk = (nbytes + (int64_t)CHUNK - 1) / (int64_t)CHUNK;
+  const size_t chunk = CHUNK;
+  const int64_t nchunk = (nbytes + (int64_t)chunk - 1) / (int64_t)chunk;
   std::atomic<int64_t> next(0);
   std::atomic<int> err(0);
   auto work = [&](int t) {
@@ -98,7 +101,7 @@ int transfer(Lane &L, int device, int fd, bool to_dev, int64_t offset, int64_t n
       const int64_t c = next.fetch_add(1);
       if (c >= nchunk || err.load()) break;
       const int b = turn & 1;
-      const size_t lo = (size_t)c * CHUNK, n = (size_t)(nbytes - (int64_t)lo < (int64_t)CHUNK ? nbytes - (int64_t)lo : (int64_t)CHUNK);
+      const size_t lo = (size_t)c * chunk, n = (size_t)(nbytes - (int64_t)lo < (int64_t)chunk ? nbytes - (int64_t)lo : (int64_t)chunk);
       if (used[b] && hipEventSynchronize(L.done[t][b]) != hipSuccess) { err = 2; break; }  // the buffer's previous DMA
       if (to_dev) {
         if (xfer_full(fd, false, (char *)L.buf[t][b], n, (off_t)(offset + (int64_t)lo))) { err = 1; break; }

@@ -73,6 +73,8 @@ hipStream_t mpg_setup_stream();
     }                              \
   } while (0)
 
+void mpg_release_caches();   // mpg_api.hip: parked handles + scratch blocks back to the driver (an allocation failed)
+
 // RAII-less device buffer helper (explicit free keeps object lifetimes obvious)
 template <typename T>
 struct DevBuf {
@@ -81,7 +83,12 @@ struct DevBuf {
   int alloc(size_t count) {
     n = count;
     if (count == 0) return MPG_SUCCESS;
-    MPG_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    if (hipMalloc((void **)&p, count * sizeof(T)) != hipSuccess) {
+      // up to 8 parked handles and 4 GB of scratch blocks are kept only as caches: give them back and try once more
+      (void)hipGetLastError();
+      mpg_release_caches();
+      MPG_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    }
     return MPG_SUCCESS;
   }
   void free() {
@@ -281,6 +288,7 @@ struct mpg_handle_s {
 };
 
 void mpg_lfu_set_min_reuse_x10(int v);  // k_apply_lfu.hip
+bool mpg_handle_is_windowed(const mpg_handle_s *h);   // mpg_api.hip: its mesh carries a source window (indices are window-relative)
 void mpg_cache_detach(mpg_handle_s *h);  // mpg_api.hip: a handle about to be re-indexed in place leaves the Store cache
 void mpg_hostpipe_release();  // mpg_hostpipe.hip: device slots / streams of the host-pointer Regrid pipeline, dropped by mpg_finalize
 void mpg_fileio_release();  // mpg_fileio.hip: staging buffers / streams of mpg_file_to_dev, dropped by mpg_finalize

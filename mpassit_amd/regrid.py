@@ -40,6 +40,25 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Algorithmic-byte accounting of a sequence of device calls (bench.py's `job` leg): while ACCOUNT is a list, every
+# device-side Regrid / rotation appends (what, bytes) with the bytes of SURVEY s8(d) -- U*L*e_src + P*L*e_dst per field plus
+# the handle's indices and weights once per call (U = the sources the handle references).  Off (None) by default: looking
+# up U synchronises.
+ACCOUNT = None
+
+
+def _account_regrid(rh, nlev, nfields, src_elem, dst_elem):
+    if ACCOUNT is None:
+        return
+    if getattr(rh, "_acc_U", None) is None:
+        try:
+            rh._acc_U = int(rh.unique_sources().size)
+        except L.MpgError:                      # handles with pole terms: every source of the grid
+            rh._acc_U = int(rh.n_src)
+    wbytes = (rh.nnz * 12 + (rh.n_dst + 1) * 4) if rh.nnz_per_row == 0 else rh.n_dst * (4 if rh.nnz_per_row == 1 else 12 * rh.nnz_per_row)
+    ACCOUNT.append(("regrid nnz%d L%d x%d" % (rh.nnz_per_row, nlev, nfields), nfields * nlev * (rh._acc_U * src_elem + rh.n_dst * dst_elem) + wbytes))
+
+
 class Mesh:
     """MPAS mesh as the reference hands it to ESMF: elements = cells, nodes = vertices.
     lat/lon in radians (file convention), verticesOnCell [nCells][maxEdges] 1-based, 0-padded."""
@@ -196,6 +215,7 @@ class RouteHandle:
                 raise ValueError("source has %d elements, handle expects %d" % (src.numel(), need))
             if out is None:
                 out = torch.empty(shape, dtype=torch.float64, device=src.device)
+            _account_regrid(self, nlev, nfields, 8, 8)
             check(L.load().mpg_regrid_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(layout), C.c_int(nlev), C.c_int(nfields),
                                           C.c_void_p(out.data_ptr()), _stream_ptr()))
             return out
@@ -222,6 +242,7 @@ class RouteHandle:
         out_dtype = out_dtype or src.dtype
         if out is None:
             out = torch.empty((nfields, nlev, self.ny_dst, self.nx_dst), dtype=out_dtype, device=src.device)
+        _account_regrid(self, nlev, nfields, src.element_size(), out.element_size())
         check(L.load().mpg_regrid_typed_dev(self._h, C.c_void_p(src.data_ptr()), C.c_int(int(src.dtype == torch.float32) | (2 if src_be else 0)),
                                             C.c_int(layout), C.c_int(nlev), C.c_int(nfields), C.c_void_p(out.data_ptr()),
                                             C.c_int(int(out.dtype == torch.float32) | (2 if dst_be else 0)), C.c_double(scale), C.c_double(offset),
@@ -367,6 +388,8 @@ def rotate_winds_cgrid(cosa, sina, u, v):
     if _is_torch(u):
         npts = cosa.numel()
         nlev = u.numel() // npts
+        if ACCOUNT is not None:                 # u, v read and written once, cos / sin(alpha) read once
+            ACCOUNT.append(("rotate L%d" % nlev, npts * (nlev * 32 + 16)))
         check(L.load().mpg_rotate_winds_dev(C.c_int64(npts), C.c_int(nlev), C.c_void_p(cosa.data_ptr()), C.c_void_p(sina.data_ptr()),
                                             C.c_void_p(u.data_ptr()), C.c_void_p(v.data_ptr()), _stream_ptr()))
         return u, v

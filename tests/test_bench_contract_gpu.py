@@ -52,3 +52,31 @@ def test_bench_gpus2_launches_itself(gpu_lib):
     assert sum(p["rows"] for p in h["per_rank"]) == 1060
     # aligned ownership: only the strips straddling the row-block boundary travel -- a few lattice rows of 13 x 55 values
     assert 0 < h["halo_bytes_per_step"] < 200e6 and h["exchange_ms_max"] > 0
+
+
+def test_default_line_carries_the_production_numbers_inside_roofline(gpu_lib):
+    """The driver's record keeps `roofline` and `config` whole and only the NAMES of the other objects, so what the shipped
+    driver's paths measure rides in `roofline.paths`: the float32 file-order Regrid, the whole job (cold = FIRST-IN-PROCESS,
+    from a fresh child process; warm; the warm level's algorithmic bytes and fraction of the HBM peak) and the three Stores
+    (first-in-process and warm).  The default command on the headline workload, a short CPU leg."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=1100, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                 # ONE line, whatever the child legs printed
+    rec = json.loads(lines[0])
+    paths = rec["roofline"]["paths"]
+    f32 = paths["f32_lev_fast_c4"]
+    assert set(f32) >= {"kernel", "kernel_ms", "frac", "traffic_ratio"} and 0.3 < f32["frac"] < 1.0 and f32["kernel"].startswith("k_apply3_lf")
+    job = paths["job"]
+    assert set(job) >= {"cold_first_ms", "cold_ms", "warm_ms", "alg_bytes_warm", "frac_warm", "geometry_first_ms"}
+    assert job["cold_first_ms"] >= job["cold_ms"] > job["warm_ms"] > 0 and 0.1 < job["frac_warm"] < 1.0
+    assert abs(job["frac_warm"] - job["alg_bytes_warm"] / (job["warm_ms"] * 1e-3) / 1e9 / 8000.0) < 2e-4
+    st = paths["store"]
+    assert set(st) == {"bilinear", "nearest", "conserve"}
+    for v in st.values():
+        assert v["ms_first"] >= v["ms"] > 0
+    # the single-shot costs this round brought down (code objects loaded by mpg_init's helper thread): first-in-process
+    # Stores within reach of the warm ones
+    assert st["nearest"]["ms_first"] < 5.0 and st["conserve"]["ms_first"] < 7.0, st
+    assert len(lines[0]) < 8000                                   # short enough that no evidence hangs on a cut-off tail

@@ -37,6 +37,18 @@ def _one(gpu_lib, m, g, expect_mode, rows=None):
         h.exchange(own, local)
         torch.cuda.synchronize()
         assert not torch.isnan(local).any()
+        if h.mode == "range":
+            # the own block held in a SEPARATE buffer (what INTEGRATION.md's Fortran sequence passes): it is copied to its
+            # place in the local slab; round 3 left those columns untouched and the Regrid read uninitialised memory
+            own2 = s[:, h.own[0]:h.own[1]].contiguous()
+            local2 = torch.full_like(local, float("nan"))
+            h.exchange(own2, local2)
+            torch.cuda.synchronize()
+            assert torch.equal(local2, local)
+            if h.own[1] - h.own[0] > 2 and nf * nlev > 1:        # a view into the slab that is NOT the in-place one: refused
+                from mpassit_amd import _lib
+                with pytest.raises(_lib.MpgError, match="overlaps"):
+                    h.exchange(local2[:, h.own_pos[0] + 1:h.own_pos[1] + 1], local2)
         got = rh.regrid_typed(local.view(-1), nlev=nlev, nfields=nf, out_dtype=torch.float64)
         ref = want if dt == torch.float64 else None
         if ref is None:                                          # float32 sources: against the same values widened on the host side

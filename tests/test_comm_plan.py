@@ -68,3 +68,67 @@ def test_c_schedule_equals_the_torch_distributed_one(ownership):
             else:
                 for q in range(len(lists)):
                     assert np.array_equal(got["send_ids"][q], s.send_ids[q]), what + (q,)
+
+
+# ---- the id-file acceptance rule of mpg_comm_init (pure host logic, no GPU, no RCCL) --------------------------------------
+def _idfile(magic=b"MPGRCCL2", tag=0, written_ns=0, nranks=2, size=None):
+    import struct
+    b = struct.pack("<8sQqii", magic, tag, written_ns, nranks, 0) + bytes(128)          # ncclUniqueId: 128 opaque bytes
+    return b if size is None else b[:size]
+
+
+def test_stale_or_foreign_id_files_are_refused():
+    """A reader accepts only THIS launch's id file: right size / magic / nranks / launch tag, and not written long before
+    the reader itself started (a file left behind by a killed launch made ncclCommInitRank hang for ever)."""
+    import ctypes as C
+
+    from mpassit_amd import _lib
+    lib = _lib.load()
+
+    def verdict(b, nranks=2, tag=0, loaded_ns=10 ** 12, stale_s=300.0):
+        r = lib.mpg_comm_idfile_verdict(b, C.c_int64(len(b)), C.c_int(nranks), C.c_uint64(tag), C.c_int64(loaded_ns), C.c_double(stale_s))
+        return None if r is None else r.decode()
+
+    now = 10 ** 12
+    assert verdict(_idfile(written_ns=now)) is None
+    assert verdict(_idfile(written_ns=now - 299 * 10 ** 9)) is None                        # rank 0 was up a few minutes earlier
+    assert verdict(_idfile(written_ns=now + 5 * 10 ** 9)) is None                          # rank 0 arrives after this reader
+    assert "older" in verdict(_idfile(written_ns=now - 301 * 10 ** 9))                     # left behind by an earlier launch
+    assert "size" in verdict(_idfile(written_ns=now, size=128))                            # the round-3 format: a bare unique id
+    assert "magic" in verdict(_idfile(magic=b"MPGRCCL1", written_ns=now))
+    assert "ranks" in verdict(_idfile(written_ns=now, nranks=4))
+    assert "launch" in verdict(_idfile(written_ns=now, tag=7), tag=9)
+    assert verdict(_idfile(written_ns=now, tag=9), tag=9) is None
+
+
+def test_world8_schedule_on_configuration_4_moves_what_design_says():
+    """DESIGN s5: with the rows of the 1800 x 1060 grid split over 8 ranks and banded cell numbering only the strip of
+    cells along a row-block boundary travels -- about 1.5 lattice rows, ~18 MB per neighbour for a batch of 13 fields x
+    55 levels of float64.  The needed sets come from the geometry (every cell within one lattice spacing of the block's
+    rows, through the projection); the schedule from mpg_halo_plan_host, world 8."""
+    from mpassit_amd import comm, dist, synth, workloads
+    g = workloads.conus_lambert_grid()
+    m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
+    ci, cj = g.proj.latlon_to_ij(np.degrees(m.latCell), np.degrees(m.lonCell))               # mass point (i, j) = (1, 1) first
+    spacing = ((1800 * 1.1) * (1060 * 1.1) / (3.0e6 * (3 ** 0.5 / 2))) ** 0.5                  # synth.regional_mesh_for_lambert
+    world, lists = 8, []
+    for r in range(world):
+        j0, j1 = dist.row_block(g.ny, world, r)
+        keep = (cj >= j0 + 1 - spacing) & (cj <= j1 + spacing) & (ci >= 1 - spacing) & (ci <= g.nx + spacing)
+        lists.append(np.flatnonzero(keep))
+    rows, es = 13 * 55, 8
+    for r in range(world):
+        p = comm.plan_host(r, lists, m.nCells, "aligned")
+        assert p["mode"] == "range"
+        recv = [b - a for a, b in p["recv_pos"]]
+        talk = [q for q in range(world) if recv[q] or p["send_count"][q]]
+        assert set(talk) <= {r - 1, r + 1}                                                    # row-block neighbours only
+        for q in talk:
+            mb = recv[q] * rows * es / 1e6
+            assert 4.0 < mb < 30.0, (r, q, mb)             # half / one / one and a half lattice rows of 2 101 cells: 5.5 / 11.5 / 17.5 MB
+        # a rank holds its own eighth plus the two strips, not the mesh
+        assert p["n_local"] < 1.15 * m.nCells / world + 4 * 2200
+    # para_range ownership (the reference's equal blocks) on the same needs: far more travels
+    # (the outer ranks: the mesh's margin shifts their equal block away from their rows; the middle ranks nearly coincide)
+    worst = max(sum(b - a for a, b in comm.plan_host(r, lists, m.nCells, "para_range")["recv_pos"]) for r in range(world))
+    assert worst * rows * es / 1e6 > 100.0

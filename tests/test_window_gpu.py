@@ -41,6 +41,13 @@ def test_windowed_regrid_equals_whole_mesh_regrid(gpu_lib, regional_case):
         h._refresh()
         assert h.n_src == hi - lo
         assert h.source_range()[0] >= lo and h.source_range()[1] <= hi      # still reported as global ids
+    # ids at the boundary stay GLOBAL whatever the window is; the in-place re-indexing verbs (the halo route) and a window
+    # are alternatives and refuse each other instead of mixing window-relative with global ids
+    assert np.array_equal(hs[0].unique_sources(), ids)
+    with pytest.raises(MpgError, match="source window"):
+        hs[0].rebase(lo, hi - lo)
+    with pytest.raises(MpgError, match="source window"):
+        hs[0].localize()
     slab, slab_lf = np.ascontiguousarray(src[:, lo:hi]), np.ascontiguousarray(src_lf[lo:hi])
     for h, w in zip(hs, want):
         assert np.array_equal(h.regrid(slab.reshape(-1), nlev=nlev), w)
