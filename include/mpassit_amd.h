@@ -66,6 +66,21 @@ int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const doubl
                     const double *lonCell, const double *latVertex, const double *lonVertex,
                     const int32_t *verticesOnCell, mpg_mesh *out);
 int mpg_mesh_destroy(mpg_mesh mesh); /* ESMF_MeshDestroy model_grid.F90:2154 */
+/* The same for ONE rank of a job whose target rows are sharded over several GPUs: `grid` is this rank's row block (with the
+ * halo rows it regrids itself), and only the part of the mesh that grid can see is brought to the device -- where the
+ * reference hands every rank 1/N of the cells (para_range, model_grid.F90:423-438, 2428-2441) and ESMF redistributes.  The
+ * host passes the same whole arrays; all cell CENTRES are uploaded (16 B per cell) and classified against the grid on the
+ * device, then verticesOnCell, the vertex coordinates, the dual triangles and the nearest-neighbour BVH exist for the
+ * covering id range of the cells within a margin of the grid only (spatially banded numbering makes that range tight;
+ * arbitrary numbering degrades towards the whole mesh, never towards a wrong answer).  Ids stay GLOBAL: handles, source
+ * ranges, windows and halo schedules are those of mpg_mesh_create, and every RegridStore of this mesh onto `grid` gives
+ * bit-identical weights -- the window's closure is verified on the device and widened until it holds
+ * (csrc/k_mesh_window.hip).  Stores onto any other grid are refused; `grid` must outlive the mesh's Stores.
+ * mpg_mesh_window_info: the cell rows [cell_first, +cell_count) and vertices [vertex_first, +vertex_count) that are
+ * resident, and the chord distance `margin` from the grid within which every cell is (any pointer may be NULL). */
+int mpg_mesh_create_window(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell, const double *lonCell,
+                           const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, mpg_grid grid, mpg_mesh *out);
+int mpg_mesh_window_info(mpg_mesh mesh, int64_t *cell_first, int64_t *cell_count, int64_t *vertex_first, int64_t *vertex_count, double *margin);
 
 /* ---- ESMF_GridCreateNoPeriDim / 1PeriDim + GridAddCoord x4 (model_grid.F90:684-728,736-1038) ------
  * nx, ny = mass (CENTER) point counts (i_target, j_target).  Coordinates in DEGREES, C order with i

@@ -72,6 +72,11 @@ static int coords_common(bool mesh, int64_t n, const double *lon, const double *
   tmp.free();
   return MPG_SUCCESS;
 }
+int mpg_k_mesh_coords_dev(int64_t n, const double *lon_rad_dev, const double *lat_rad_dev, double *x, double *y, double *z, hipStream_t s) {
+  if (n > 0) k_mesh_coords<<<grid_for(n), 256, 0, s>>>(n, lon_rad_dev, lat_rad_dev, x, y, z);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
 int mpg_k_mesh_coords(int64_t n, const double *lon_rad, const double *lat_rad, PointSet &out, hipStream_t s) {
   return coords_common(true, n, lon_rad, lat_rad, out, s);
 }
@@ -81,16 +86,19 @@ int mpg_k_grid_coords(int64_t n, const double *lon_deg, const double *lat_deg, P
 
 // ---- dual triangles ---------------------------------------------------------------
 // pass 1: every (cell, vertex) incidence claims a slot of its vertex with an atomic counter
+// voc: the rows of cells cell0 .. cell0 + nCells - 1; cnt / tri: the vertices vert0 .. vert0 + nVertices - 1 (the mesh's
+// geometry window: everything for mpg_mesh_create); tri holds GLOBAL cell ids
 __global__ __launch_bounds__(256) void k_tri_scatter(int64_t nCells, int maxEdges, int64_t nVertices,
                                                      const int32_t *__restrict__ voc, int32_t *__restrict__ cnt,
-                                                     int32_t *__restrict__ tri /*[3][nV]*/) {
+                                                     int32_t *__restrict__ tri /*[3][nV]*/, int64_t cell0, int64_t vert0) {
   int64_t total = nCells * maxEdges;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    int32_t v = voc[e];
-    if (v <= 0 || v > nVertices) continue;  // 0 = padding (model_grid.F90:448)
-    v -= 1;
+    int64_t v = voc[e];
+    if (v <= 0) continue;  // 0 = padding (model_grid.F90:448)
+    v -= 1 + vert0;
+    if (v < 0 || v >= nVertices) continue;
     int slot = atomicAdd(&cnt[v], 1);
-    if (slot < 3) tri[(int64_t)slot * nVertices + v] = (int32_t)(e / maxEdges);
+    if (slot < 3) tri[(int64_t)slot * nVertices + v] = (int32_t)(cell0 + e / maxEdges);
   }
 }
 // pass 2: canonical order (ascending ids, then CCW) so the result is independent of atomic ordering
@@ -129,31 +137,46 @@ __global__ __launch_bounds__(256) void k_tri_canon(int64_t nVertices, const int3
   }
 }
 
-int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s) {
-  int rc;
-  int64_t nV = m->nVertices;
-  if ((rc = m->tri.alloc(3 * (size_t)nV))) return rc;
-  TmpBuf<int32_t> cnt;
-  if ((rc = cnt.alloc((size_t)nV, s))) return rc;
-  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * nV, s));
+// Two steps so that mpg_mesh_create_window can look at the raw incidence counts in between (k_mesh_window.hip: which
+// vertices of the window miss a cell that exists outside it): scatter leaves cnt[v] = number of cells of the window's rows
+// touching vertex v and their ids in tri's slots; canon turns complete vertices into canonical triangles and clears the rest.
+int mpg_k_tri_scatter(mpg_mesh_s *m, int32_t *cnt, hipStream_t s) {
+  const int64_t nV = m->vwn;
+  if (nV == 0) return MPG_SUCCESS;
+  MPG_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * nV, s));
   MPG_HIP(hipMemsetAsync(m->tri.p, 0xff, sizeof(int32_t) * 3 * nV, s));
+  if (m->cwn > 0)
+    k_tri_scatter<<<grid_for(m->cwn * m->maxEdges), 256, 0, s>>>(m->cwn, m->maxEdges, nV, m->voc.p, cnt, m->tri.p, m->cw0, m->vw0);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+int mpg_k_tri_canon(mpg_mesh_s *m, const int32_t *cnt, hipStream_t s) {
+  int rc;
+  const int64_t nV = m->vwn;
+  m->nTriValid = 0;
+  if (nV == 0) return MPG_SUCCESS;
   TmpBuf<unsigned long long> nv;
   if ((rc = nv.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(nv.p, 0, sizeof(unsigned long long), s));
-  k_tri_scatter<<<grid_for(m->nCells * m->maxEdges), 256, 0, s>>>(m->nCells, m->maxEdges, nV, m->voc.p, cnt.p, m->tri.p);
-  {
-    int64_t nb = (nV + 255) / 256;
-    if (nb > 4096) nb = 4096;   // grid-stride: 16 waves per CU in flight, a handful of vertices per thread
-    k_tri_canon<<<(unsigned)nb, 256, 0, s>>>(nV, cnt.p, m->tri.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nv.p);
-  }
+  int64_t nb = (nV + 255) / 256;
+  if (nb > 4096) nb = 4096;   // grid-stride: 16 waves per CU in flight, a handful of vertices per thread
+  k_tri_canon<<<(unsigned)nb, 256, 0, s>>>(nV, cnt, m->tri.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nv.p);
   MPG_HIP(hipGetLastError());
   unsigned long long h = 0;
   MPG_HIP(hipMemcpyAsync(&h, nv.p, sizeof(h), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   m->nTriValid = (int64_t)h;
-  cnt.free();
-  nv.free();
   return MPG_SUCCESS;
+}
+int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s) {
+  int rc;
+  m->nTriValid = 0;
+  if (m->vwn == 0) return MPG_SUCCESS;
+  if ((rc = m->tri.alloc(3 * (size_t)m->vwn))) return rc;
+  TmpBuf<int32_t> cnt;
+  if ((rc = cnt.alloc((size_t)m->vwn, s))) return rc;
+  if ((rc = mpg_k_tri_scatter(m, cnt.p, s))) return rc;
+  return mpg_k_tri_canon(m, cnt.p, s);
 }
 
 // ---- AABB pyramid over a structured point set --------------------------------------------------------

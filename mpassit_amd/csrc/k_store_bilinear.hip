@@ -246,22 +246,24 @@ __global__ __launch_bounds__(256) void k_fan_triangles(int64_t nCells, int maxEd
 
 int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int meshloc, mpg_handle_s *h, hipStream_t s) {
   int rc;
+  // Triangles = those of the mesh's geometry window (everything unless the mesh was cut to this grid): the dual triangles of
+  // its vertices, or the fan triangles of its cell rows; triangle NUMBERS are local to the window (their order -- lowest wins
+  // on a shared edge -- is that of the global numbers), the ids INSIDE them are global.
   const int32_t *trip = m->tri.p;
-  int64_t nT = m->nVertices;
-  const PointSet *sp = &m->cell;
+  int64_t nT = m->vwn;
+  const double *sx = m->cell.x.p, *sy = m->cell.y.p, *sz = m->cell.z.p;
   if (meshloc == MPG_MESHLOC_NODE) {
-    nT = m->nCells * (int64_t)(m->maxEdges - 2);
+    nT = m->cwn * (int64_t)(m->maxEdges - 2);
     if (nT >= 0x7fffffff) {
       mpg_set_error("mesh too large for the node-located fan triangulation");
       return MPG_ERR_OVERFLOW;
     }
-    if (!m->fan.p) {
+    sx = m->vx_g(); sy = m->vy_g(); sz = m->vz_g();
+    if (!m->fan.p && nT > 0) {
       if ((rc = m->fan.alloc(3 * (size_t)nT))) return rc;
-      k_fan_triangles<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(m->nCells, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p,
-                                                                  m->vert.z.p, m->fan.p);
+      k_fan_triangles<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(m->cwn, m->maxEdges, m->voc.p, sx, sy, sz, m->fan.p);
     }
     trip = m->fan.p;
-    sp = &m->vert;
   }
   PointSet &pts = g->pts[stagger];
   int npx = g->snx[stagger], npy = g->sny[stagger];
@@ -277,7 +279,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   }
   h->kind = MPG_KIND_FIXED;
   h->nnz_per_row = 3;
-  h->n_src = sp->n;
+  h->n_src = meshloc == MPG_MESHLOC_NODE ? m->nVertices : m->nCells;
   h->n_dst = P;
   h->nx_dst = npx;
   h->ny_dst = npy;
@@ -290,7 +292,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   if (fb > 8192) fb = 8192;
   // one scratch allocation: [0] overflow flag, [1] length of the queue of handed-over triangles, [2 ...] the queue (nobody
   // reads the length on the host)
-  const int big_cap = (int)std::min<int64_t>(nT, 1 << 18);
+  const int big_cap = (int)std::min<int64_t>(nT, 1 << 18);   // 0 for an empty window: nothing is handed over
   TmpBuf<int32_t> ovf;
   if ((rc = ovf.alloc((size_t)big_cap + 2, s))) return rc;
   MPG_HIP(hipMemsetAsync(ovf.p, 0, 2 * sizeof(int32_t), s));
@@ -298,12 +300,13 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   auto raster = mpg_bilinear_linetype() ? k_tri_raster<true> : k_tri_raster<false>;
   auto raster_big = mpg_bilinear_linetype() ? k_tri_raster_big<true> : k_tri_raster_big<false>;
   auto finalize = mpg_bilinear_linetype() ? k_tri_finalize<true> : k_tri_finalize<false>;
-  raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sp->x.p, sp->y.p, sp->z.p, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p,
-                                                     pts.y.p, pts.z.p, owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap);
-  raster_big<<<1024, 256, 0, s>>>(ovf.p + 2, ovf.p + 1, big_cap, trip, nT, sp->x.p, sp->y.p, sp->z.p, mpg_pyr_view(g->pyr[stagger]), npx, npy,
-                                 pts.x.p, pts.y.p, pts.z.p, owner.p, ovf.p);
-  finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sp->x.p, sp->y.p, sp->z.p, pts.x.p, pts.y.p, pts.z.p, h->idx.p,
-                                                      h->w.p);
+  if (nT > 0) {
+    raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p, pts.z.p,
+                                                       owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap);
+    raster_big<<<1024, 256, 0, s>>>(ovf.p + 2, ovf.p + 1, big_cap, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p,
+                                   pts.z.p, owner.p, ovf.p);
+  }
+  finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sx, sy, sz, pts.x.p, pts.y.p, pts.z.p, h->idx.p, h->w.p);
   MPG_HIP(hipGetLastError());
   int32_t h_ovf = 0;
   MPG_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));

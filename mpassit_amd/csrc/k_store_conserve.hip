@@ -387,14 +387,15 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
 }
 __global__ __launch_bounds__(256) void k_conserve_scatter_pairs(int64_t npairs, const int32_t *__restrict__ pair_c, const int32_t *__restrict__ pair_p,
                                                                 const double *__restrict__ pair_val, const int32_t *__restrict__ rowptr,
-                                                                int32_t *__restrict__ cursor, int32_t *__restrict__ col, double *__restrict__ val) {
+                                                                int32_t *__restrict__ cursor, int32_t *__restrict__ col, double *__restrict__ val,
+                                                                int32_t cell0) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= npairs) return;
   const double r = pair_val[t];
   if (!(r > 0.0)) return;
   const int32_t p = pair_p[t];
   const int slot = atomicAdd(&cursor[p], 1);
-  col[rowptr[p] + slot] = pair_c[t];
+  col[rowptr[p] + slot] = pair_c[t] + cell0;   // the walk and the clip work on the rows of the mesh's geometry window; the matrix holds global ids
   val[rowptr[p] + slot] = r;
 }
 
@@ -421,7 +422,17 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   TmpBuf<int32_t> count, cnt_src, tmp_dst, ovf, n_ovf, npair, poff, pair_c, pair_p;
   TmpBuf<double> qarea, qsph, pair_val;
   TmpBuf<uint8_t> flip;
-  const int64_t nC = m->nCells;
+  // source cells = the rows of the mesh's geometry window (all of them unless the mesh was cut to this grid, mpg_mesh_create_window);
+  // the kernels number them 0 .. nC - 1, vertex coordinates are reached through pointers biased by the window's first vertex
+  const int64_t nC = m->cwn;
+  const double *vx = m->vx_g(), *vy = m->vy_g(), *vz = m->vz_g();
+  if (nC == 0) {   // a window without cells (the grid lies off the mesh): the empty matrix
+    if ((rc = h->rowptr.alloc((size_t)P + 1)) || (rc = h->col.alloc(1)) || (rc = h->val.alloc(1))) return rc;
+    MPG_HIP(hipMemsetAsync(h->rowptr.p, 0, sizeof(int32_t) * (P + 1), s));
+    MPG_HIP(hipStreamSynchronize(s));
+    h->nnz = 0;
+    return MPG_SUCCESS;
+  }
   if ((rc = count.alloc((size_t)P + 1, s)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P, s)) || (rc = qsph.alloc(4 * (size_t)P, s)) ||
       (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(1, s)) ||
       (rc = npair.alloc((size_t)nC + 1, s)) || (rc = poff.alloc((size_t)nC + 1, s)) || (rc = flip.alloc((size_t)nC, s)))
@@ -434,14 +445,14 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   PyramidView pv = mpg_pyr_view(g->cellpyr);
   k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
-  k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
+  k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
                                         qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
   MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
-    k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
+    k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
                                                        nullptr, nullptr);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
@@ -474,7 +485,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if ((rc = pair_c.alloc((size_t)npairs + 1, s)) || (rc = pair_p.alloc((size_t)npairs + 1, s)) || (rc = pair_val.alloc((size_t)npairs + 1, s))) return rc;
   k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
   if (novf > 0)
-    k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, pv, nx, ny, cor.x.p,
+    k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
                                                        pair_c.p, pair_p.p);
   MPG_HIP(hipGetLastError());
@@ -489,7 +500,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipMemsetAsync(truncated.p, 0, sizeof(int32_t), s));
   if (npairs > 0)
     k_conserve_clip_pairs<<<(unsigned)(((int64_t)npairs + CLIP_NT - 1) / CLIP_NT), CLIP_NT, clip_lds_bytes, s>>>(
-        npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
+        npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, vx, vy, vz, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
         pair_val.p, count.p, truncated.p);
   MPG_HIP(hipGetLastError());
   tmp_bytes = b2;
@@ -511,7 +522,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
   if (npairs > 0)
     k_conserve_scatter_pairs<<<(unsigned)(((int64_t)npairs + 255) / 256), 256, 0, s>>>(npairs, pair_c.p, pair_p.p, pair_val.p, h->rowptr.p, count.p,
-                                                                                      h->col.p, h->val.p);
+                                                                                      h->col.p, h->val.p, (int32_t)m->cw0);
   k_csr_sort_rows<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, h->rowptr.p, h->col.p, h->val.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));

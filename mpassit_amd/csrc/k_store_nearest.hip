@@ -14,6 +14,10 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <string.h>
+
+#include <algorithm>
+
 #include "geom.h"
 #include "mpg_internal.h"
 
@@ -28,15 +32,16 @@ __device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
 }
 __global__ __launch_bounds__(256) void k_morton(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
                                                 const double *__restrict__ z, unsigned long long *__restrict__ key,
-                                                int32_t *__restrict__ id) {
+                                                int32_t *__restrict__ id, int64_t first) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
+  x += first; y += first; z += first;   // sites = cells first .. first + n - 1 (the mesh's geometry window)
   const double sc = 2097151.0 * 0.5;  // (2^21 - 1) / 2
   unsigned long long qx = (unsigned long long)fmin(fmax((x[i] + 1.0) * sc, 0.0), 2097151.0);
   unsigned long long qy = (unsigned long long)fmin(fmax((y[i] + 1.0) * sc, 0.0), 2097151.0);
   unsigned long long qz = (unsigned long long)fmin(fmax((z[i] + 1.0) * sc, 0.0), 2097151.0);
   key[i] = spread21(qx) | (spread21(qy) << 1) | (spread21(qz) << 2);
-  id[i] = (int32_t)i;
+  id[i] = (int32_t)(first + i);
 }
 __global__ __launch_bounds__(256) void k_gather_sites(int64_t n, const int32_t *__restrict__ id, const double *__restrict__ x,
                                                       const double *__restrict__ y, const double *__restrict__ z,
@@ -81,18 +86,28 @@ __global__ __launch_bounds__(256) void k_bvh_up(int64_t nchild, int64_t nparent,
   o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
 }
 
-int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s) {
+// whole = false: only the cells of the mesh's geometry window are sites (a mesh cut to one rank's grid,
+// mpg_mesh_create_window); every cell centre is on the device in either case, so a search that turns out to need the
+// cells outside the window (mpg_k_store_nearest checks) rebuilds with whole = true
+int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s, bool whole) {
   SiteBvh &b = m->bvh;
-  if (b.built) return MPG_SUCCESS;
+  if (b.built && (m->bvh_whole || !whole)) return MPG_SUCCESS;
+  if (b.built) b.free();
   int rc;
-  int64_t n = m->nCells;
+  const int64_t first = whole ? 0 : m->cw0;
+  int64_t n = whole ? m->nCells : m->cwn;
+  if (n == 0) {   // an empty window: the whole mesh it is
+    whole = true;
+    n = m->nCells;
+  }
+  m->bvh_whole = whole;
   b.n = n;
   TmpBuf<unsigned long long> key_in, key_out;
   TmpBuf<int32_t> id_in;
   if ((rc = key_in.alloc(n, s)) || (rc = key_out.alloc(n, s)) || (rc = id_in.alloc(n, s)) || (rc = b.sorted_id.alloc(n))) return rc;
   if ((rc = b.sorted.alloc(n))) return rc;
   unsigned nb = (unsigned)((n + 255) / 256);
-  k_morton<<<nb, 256, 0, s>>>(n, m->cell.x.p, m->cell.y.p, m->cell.z.p, key_in.p, id_in.p);
+  k_morton<<<nb, 256, 0, s>>>(n, m->cell.x.p, m->cell.y.p, m->cell.z.p, key_in.p, id_in.p, first);
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
   TmpBuf<char> tmp;
@@ -296,29 +311,31 @@ __global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int
   if (act) out[p] = best_id;
 }
 
-int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s) {
-  int rc;
-  if ((rc = mpg_k_build_bvh(m, s))) return rc;
-  PointSet &pts = g->pts[stagger];
-  int npx = g->snx[stagger], npy = g->sny[stagger];
-  int64_t P = (int64_t)npx * npy;
-  if (pts.n != P) {
-    mpg_set_error("RegridStore: destination stagger %d has no coordinates", stagger);
-    return MPG_ERR_INVALID_ARG;
+// largest squared distance between a target point and the site found for it (one atomic per workgroup; distances are
+// non-negative doubles, whose bit patterns order like the values)
+__global__ __launch_bounds__(256) void k_nn_max_d2(int64_t P, const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+                                                   const int32_t *__restrict__ idx, const double *__restrict__ cx, const double *__restrict__ cy,
+                                                   const double *__restrict__ cz, unsigned long long *__restrict__ out) {
+  __shared__ double sw[4];
+  double mx = 0.0;
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P; p += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t c = idx[p];
+    mx = fmax(mx, dist2_nofma(px[p], py[p], pz[p], cx[c], cy[c], cz[c]));
   }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o));
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(fmax(fmax(sw[0], sw[1]), fmax(sw[2], sw[3]))));
+}
+
+static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, mpg_handle_s *h, hipStream_t s) {
+  int rc;
+  const int64_t P = (int64_t)npx * npy;
   SiteBvh &b = m->bvh;
   if (b.nnodes[0] >= (1 << 27)) {
     mpg_set_error("mesh too large for the nearest-neighbour BVH");
     return MPG_ERR_OVERFLOW;
   }
-  h->kind = MPG_KIND_FIXED;
-  h->nnz_per_row = 1;
-  h->n_src = m->nCells;
-  h->n_dst = P;
-  h->nx_dst = npx;
-  h->ny_dst = npy;
-  h->nnz = P;
-  if ((rc = h->idx.alloc((size_t)P))) return rc;
   SiteBvhView v;
   v.n = b.n;
   v.sx = b.sorted.x.p; v.sy = b.sorted.y.p; v.sz = b.sorted.z.p;
@@ -346,6 +363,51 @@ int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s 
   if (h_ovf) {
     mpg_set_error("RegridStore(nearest): traversal stack of the wave-cooperative search overflowed");
     return MPG_ERR_OVERFLOW;
+  }
+  return MPG_SUCCESS;
+}
+
+int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s) {
+  int rc;
+  // a mesh cut to this grid (mpg_mesh_create_window) searches the cells of its window first
+  const bool windowed = m->geo_grid != nullptr && m->cwn > 0 && m->cwn < m->nCells;
+  if ((rc = mpg_k_build_bvh(m, s, !windowed))) return rc;
+  PointSet &pts = g->pts[stagger];
+  int npx = g->snx[stagger], npy = g->sny[stagger];
+  int64_t P = (int64_t)npx * npy;
+  if (pts.n != P) {
+    mpg_set_error("RegridStore: destination stagger %d has no coordinates", stagger);
+    return MPG_ERR_INVALID_ARG;
+  }
+  h->kind = MPG_KIND_FIXED;
+  h->nnz_per_row = 1;
+  h->n_src = m->nCells;
+  h->n_dst = P;
+  h->nx_dst = npx;
+  h->ny_dst = npy;
+  h->nnz = P;
+  if ((rc = h->idx.alloc((size_t)P))) return rc;
+  if ((rc = nearest_search(m, npx, npy, pts, h, s))) return rc;
+  if (!m->bvh_whole) {
+    // Exact?  Every cell that is NOT a site lies further than geo_margin from every point of the grid (that is how the window
+    // was cut), so a point whose nearest site is within geo_margin has its true nearest cell -- ties included: a cell at the
+    // same distance is within the margin too and therefore a site.  A point further from the mesh than that (a grid that
+    // sticks far out of the mesh's footprint) sends the Store to the whole mesh: all cell centres are on the device.
+    TmpBuf<unsigned long long> mx;
+    if ((rc = mx.alloc(1, s))) return rc;
+    MPG_HIP(hipMemsetAsync(mx.p, 0, sizeof(unsigned long long), s));
+    k_nn_max_d2<<<(unsigned)std::min<int64_t>((P + 255) / 256, 2048), 256, 0, s>>>(P, pts.x.p, pts.y.p, pts.z.p, h->idx.p, m->cell.x.p, m->cell.y.p,
+                                                                                  m->cell.z.p, mx.p);
+    MPG_HIP(hipGetLastError());
+    unsigned long long bits = 0;
+    MPG_HIP(hipMemcpyAsync(&bits, mx.p, sizeof(bits), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    double d2;
+    memcpy(&d2, &bits, sizeof(d2));
+    if (!(d2 <= m->geo_margin * m->geo_margin)) {
+      if ((rc = mpg_k_build_bvh(m, s, true))) return rc;
+      if ((rc = nearest_search(m, npx, npy, pts, h, s))) return rc;
+    }
   }
   return MPG_SUCCESS;
 }

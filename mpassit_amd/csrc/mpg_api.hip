@@ -120,7 +120,7 @@ void mpg_pool_release() {
 // creates the pinned staging of the host-array upload path, while the caller goes on (reading its namelist, opening its
 // files); a call that needs a module before the helper got to it simply loads it itself (the runtime serialises that).
 #define MPG_ANCHORS(X) X(k_setup) X(k_target_grid) X(k_store_bilinear) X(k_store_nearest) X(k_store_conserve) X(k_store_gridbil) \
-  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_pole) X(k_post) X(k_halo) X(mpg_comm)
+  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_pole) X(k_post) X(k_halo) X(mpg_comm) X(k_mesh_window)
 #define X(n) const void *mpg_anchor_##n();
 MPG_ANCHORS(X)
 #undef X
@@ -240,17 +240,65 @@ int mpg_device_info(char *arch_buf, int buf_len, int *n_cu, int64_t *hbm_bytes) 
 }
 
 // ---- mesh -----------------------------------------------------------------------------------------
-int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell, const double *lonCell,
-                    const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, mpg_mesh *out) {
+static std::vector<mpg_mesh_s *> g_meshes;   // live meshes: a grid that goes away tells the meshes cut to it (geo_grid)
+
+static int mesh_common_checks(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell, const double *lonCell, const double *latVertex,
+                              const double *lonVertex, const int32_t *verticesOnCell, mpg_mesh *out, const char *who) {
+  if (!out) { mpg_set_error("%s: out is NULL", who); return MPG_ERR_INVALID_ARG; }
+  if (!(nCells > 0 && nVertices > 0 && maxEdges >= 3)) { mpg_set_error("%s: nCells, nVertices must be > 0 and maxEdges >= 3", who); return MPG_ERR_INVALID_ARG; }
+  if (!(nCells < 0x7fffffff && nVertices < 0x7fffffff)) { mpg_set_error("%s: sizes must fit int32 ids", who); return MPG_ERR_INVALID_ARG; }
+  if (!(latCell && lonCell && latVertex && lonVertex && verticesOnCell)) { mpg_set_error("%s: NULL array", who); return MPG_ERR_INVALID_ARG; }
+  return MPG_SUCCESS;
+}
+
+// ESMF_MeshCreate for ONE rank of a row-sharded job (include/mpassit_amd.h; k_mesh_window.hip has the method and the argument
+// why the weights equal those of the whole mesh)
+int mpg_mesh_create_window(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell, const double *lonCell, const double *latVertex,
+                           const double *lonVertex, const int32_t *verticesOnCell, mpg_grid grid, mpg_mesh *out) {
   MPG_CHECK_INIT();
-  MPG_ARG(out, "mpg_mesh_create: out is NULL");
-  MPG_ARG(nCells > 0 && nVertices > 0 && maxEdges >= 3, "mpg_mesh_create: nCells, nVertices must be > 0 and maxEdges >= 3");
-  MPG_ARG(nCells < 0x7fffffff && nVertices < 0x7fffffff, "mpg_mesh_create: sizes must fit int32 ids");
-  MPG_ARG(latCell && lonCell && latVertex && lonVertex && verticesOnCell, "mpg_mesh_create: NULL array");
+  int rc = mesh_common_checks(nCells, nVertices, maxEdges, latCell, lonCell, latVertex, lonVertex, verticesOnCell, out, "mpg_mesh_create_window");
+  if (rc) return rc;
+  MPG_ARG(grid, "mpg_mesh_create_window: NULL grid");
   mpg_mesh_s *m = new mpg_mesh_s();
   m->nCells = nCells;
   m->nVertices = nVertices;
   m->maxEdges = maxEdges;
+  m->geo_grid = grid;
+  g_meshes.push_back(m);
+  if ((rc = mpg_k_mesh_coords(nCells, lonCell, latCell, m->cell, g_stream)) ||
+      (rc = mpg_k_mesh_window(m, grid, latVertex, lonVertex, verticesOnCell, g_stream))) {
+    mpg_mesh_destroy(m);
+    return rc;
+  }
+  *out = m;
+  return MPG_SUCCESS;
+}
+
+int mpg_mesh_window_info(mpg_mesh m, int64_t *cell_first, int64_t *cell_count, int64_t *vertex_first, int64_t *vertex_count, double *margin) {
+  MPG_ARG(m, "mpg_mesh_window_info: NULL mesh");
+  if (cell_first) *cell_first = m->cw0;
+  if (cell_count) *cell_count = m->cwn;
+  if (vertex_first) *vertex_first = m->vw0;
+  if (vertex_count) *vertex_count = m->vwn;
+  if (margin) *margin = m->geo_margin;
+  return MPG_SUCCESS;
+}
+
+int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell, const double *lonCell,
+                    const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, mpg_mesh *out) {
+  MPG_CHECK_INIT();
+  {
+    int rc0 = mesh_common_checks(nCells, nVertices, maxEdges, latCell, lonCell, latVertex, lonVertex, verticesOnCell, out, "mpg_mesh_create");
+    if (rc0) return rc0;
+  }
+  mpg_mesh_s *m = new mpg_mesh_s();
+  m->nCells = nCells;
+  m->nVertices = nVertices;
+  m->maxEdges = maxEdges;
+  m->cwn = nCells;      // geometry window = the whole mesh
+  m->vwn = nVertices;
+  m->geo_margin = 4.0;
+  g_meshes.push_back(m);
   int rc;
   hipStream_t s = g_stream;
   if ((rc = mpg_k_mesh_coords(nCells, lonCell, latCell, m->cell, s)) || (rc = mpg_k_mesh_coords(nVertices, lonVertex, latVertex, m->vert, s)) ||
@@ -288,6 +336,11 @@ static void cache_purge(void *obj) {
 int mpg_mesh_destroy(mpg_mesh m) {
   if (!m) return MPG_SUCCESS;
   cache_purge(m);
+  for (size_t i = 0; i < g_meshes.size(); ++i)
+    if (g_meshes[i] == m) {
+      g_meshes.erase(g_meshes.begin() + (long)i);
+      break;
+    }
   m->cell.free();
   m->vert.free();
   m->voc.free();
@@ -301,11 +354,13 @@ int mpg_mesh_destroy(mpg_mesh m) {
 int mpg_mesh_get_triangles(mpg_mesh m, int32_t *tri_host) {
   MPG_CHECK_INIT();
   MPG_ARG(m && tri_host, "mpg_mesh_get_triangles: NULL argument");
-  int64_t nV = m->nVertices;
+  const int64_t nV = m->vwn;   // vertices outside the geometry window of a mesh cut to a grid have no triangle here
+  for (int64_t i = 0; i < 3 * m->nVertices; ++i) tri_host[i] = -1;
+  if (nV == 0) return MPG_SUCCESS;
   std::vector<int32_t> tmp(3 * (size_t)nV);
   MPG_HIP(hipMemcpy(tmp.data(), m->tri.p, sizeof(int32_t) * 3 * nV, hipMemcpyDeviceToHost));
   for (int64_t v = 0; v < nV; ++v)
-    for (int k = 0; k < 3; ++k) tri_host[3 * v + k] = tmp[(size_t)k * nV + v];
+    for (int k = 0; k < 3; ++k) tri_host[3 * (m->vw0 + v) + k] = tmp[(size_t)k * nV + v];
   return MPG_SUCCESS;
 }
 
@@ -345,6 +400,8 @@ int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, co
 int mpg_grid_destroy(mpg_grid g) {
   if (!g) return MPG_SUCCESS;
   cache_purge(g);
+  for (mpg_mesh_s *m : g_meshes)   // a mesh cut to this grid serves no other: a recycled address must never pass for it
+    if (m->geo_grid == g) m->geo_grid_gone = true;
   for (int st = 0; st < 4; ++st) {
     g->pts[st].free();
     g->pyr[st].free();
@@ -500,6 +557,11 @@ int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_stagge
     return MPG_ERR_UNSUPPORTED;
   }
   MPG_ARG(regridmethod >= 0 && regridmethod <= 2, "mpg_regrid_store: unknown regrid method");
+  if (src->geo_grid && (src->geo_grid != dst || src->geo_grid_gone)) {
+    mpg_set_error("mpg_regrid_store: the mesh was cut to another grid (mpg_mesh_create_window%s); it holds only the cells that grid can see",
+                  src->geo_grid_gone ? ", which has been destroyed" : "");
+    return MPG_ERR_INVALID_ARG;
+  }
   if (regridmethod == MPG_REGRIDMETHOD_CONSERVE && dst_staggerloc != MPG_STAGGERLOC_CENTER) {
     mpg_set_error("mpg_regrid_store: conservative regridding is defined on the CENTER stagger only");
     return MPG_ERR_UNSUPPORTED;
@@ -568,7 +630,7 @@ int mpg_mesh_set_source_window(mpg_mesh m, int meshloc, int64_t first, int64_t c
     if (rc) return rc;
   }
   m->win_first[meshloc] = first;
-  m->win_count[meshloc] = count;
+  m->win_count[meshloc] = first == 0 && count == n_all ? -1 : count;   // the whole mesh: no window any more
   return MPG_SUCCESS;
 }
 

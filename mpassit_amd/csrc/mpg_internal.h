@@ -199,6 +199,7 @@ struct SiteBvhView {
 };
 
 struct mpg_handle_s;
+struct mpg_grid_s;
 typedef std::tuple<void *, int, void *, int, int> HandleKey;
 
 struct mpg_mesh_s {
@@ -213,6 +214,19 @@ struct mpg_mesh_s {
   // source window per mesh location (ELEMENT, NODE): Regrid sources hold ids [win_first, win_first + win_count) only and
   // every handle of this mesh indexes relative to win_first (mpg_mesh_set_source_window); whole mesh by default
   int64_t win_first[2] = {0, 0}, win_count[2] = {-1, -1};
+  // GEOMETRY window (mpg_mesh_create_window; the whole mesh after mpg_mesh_create): `voc` holds the rows of cells
+  // [cw0, cw0 + cwn) only, `vert` and `tri` the vertices [vw0, vw0 + vwn) only; `cell` always holds every cell centre
+  // (handles, triangles and the BVH carry GLOBAL cell ids).  Kernels index the windowed arrays through the biased
+  // pointers below with global ids, or loop over the local ranges.
+  int64_t cw0 = 0, cwn = 0, vw0 = 0, vwn = 0;
+  mpg_grid_s *geo_grid = nullptr;   // the grid the window was cut for (Stores onto any other grid are refused); nullptr: whole mesh
+  bool geo_grid_gone = false;       // that grid has been destroyed
+  double geo_margin = 0.0;          // chord distance from the grid within which every cell is present
+  bool bvh_whole = true;            // the BVH covers every cell (false: the cells of the window only)
+  const int32_t *voc_g() const { return voc.p - cw0 * maxEdges; }
+  const double *vx_g() const { return vert.x.p - vw0; }
+  const double *vy_g() const { return vert.y.p - vw0; }
+  const double *vz_g() const { return vert.z.p - vw0; }
 };
 
 struct mpg_grid_s {
@@ -298,6 +312,11 @@ int mpg_k_mesh_coords(int64_t n, const double *lon_rad, const double *lat_rad, P
 int mpg_k_grid_coords(int64_t n, const double *lon_deg, const double *lat_deg, PointSet &out, hipStream_t s);
 int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s);
 int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s);
+int mpg_k_tri_scatter(mpg_mesh_s *m, int32_t *cnt, hipStream_t s);
+int mpg_k_tri_canon(mpg_mesh_s *m, const int32_t *cnt, hipStream_t s);
+// k_mesh_window.hip: cuts the mesh to what grid `g` can see (fills cw0 .. geo_margin, voc, vert, tri of `m`, whose `cell` holds all centres)
+int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, hipStream_t s);
+int mpg_k_mesh_coords_dev(int64_t n, const double *lon_rad_dev, const double *lat_rad_dev, double *x, double *y, double *z, hipStream_t s);
 int mpg_k_build_pyramid(const PointSet &pts, int nx, int ny, Pyramid &pyr, hipStream_t s);
 int mpg_k_build_cell_pyramid(const PointSet &corner, int nx, int ny, Pyramid &pyr, hipStream_t s);
 PyramidView mpg_pyr_view(const Pyramid &p);
@@ -305,7 +324,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
 int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s);
 int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStream_t s);
 int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, hipStream_t s);
-int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s);
+int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s, bool whole = true);
 int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s);
 // src_type / dst_type below: MPG_TYPE_F64 / MPG_TYPE_F32, optionally | MPG_TYPE_BE (include/mpassit_amd.h)
 int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,

@@ -63,20 +63,32 @@ class Mesh:
     """MPAS mesh as the reference hands it to ESMF: elements = cells, nodes = vertices.
     lat/lon in radians (file convention), verticesOnCell [nCells][maxEdges] 1-based, 0-padded."""
 
-    def __init__(self, latCell, lonCell, latVertex, lonVertex, verticesOnCell):
+    def __init__(self, latCell, lonCell, latVertex, lonVertex, verticesOnCell, window_grid=None):
+        """window_grid: a Grid (one rank's row block) -- only the part of the mesh that grid can see is brought to the
+        device (mpg_mesh_create_window); ids stay global, Stores onto that grid give the weights of the whole mesh."""
         latCell, lonCell, latVertex, lonVertex = map(_f64, (latCell, lonCell, latVertex, lonVertex))
         voc = np.ascontiguousarray(verticesOnCell, dtype=np.int32)
         if voc.ndim != 2 or voc.shape[0] != latCell.size:
             raise ValueError("verticesOnCell must be [nCells][maxEdges]")
         self.nCells, self.nVertices, self.maxEdges = int(latCell.size), int(latVertex.size), int(voc.shape[1])
         self._h = C.c_void_p()
-        check(L.load().mpg_mesh_create(C.c_int64(self.nCells), C.c_int64(self.nVertices), C.c_int(self.maxEdges),
-                                       _ptr(latCell), _ptr(lonCell), _ptr(latVertex), _ptr(lonVertex), _ptr(voc),
-                                       C.byref(self._h)))
+        args = (C.c_int64(self.nCells), C.c_int64(self.nVertices), C.c_int(self.maxEdges), _ptr(latCell), _ptr(lonCell), _ptr(latVertex),
+                _ptr(lonVertex), _ptr(voc))
+        if window_grid is None:
+            check(L.load().mpg_mesh_create(*args, C.byref(self._h)))
+        else:
+            check(L.load().mpg_mesh_create_window(*args, window_grid._h, C.byref(self._h)))
 
     @classmethod
-    def from_mpas(cls, m):
-        return cls(m.latCell, m.lonCell, m.latVertex, m.lonVertex, m.verticesOnCell)
+    def from_mpas(cls, m, window_grid=None):
+        return cls(m.latCell, m.lonCell, m.latVertex, m.lonVertex, m.verticesOnCell, window_grid=window_grid)
+
+    def window_info(self):
+        """(cell_first, cell_count, vertex_first, vertex_count, margin): the resident part of the geometry (the whole mesh
+        unless it was made with window_grid) and the chord distance from the grid within which every cell is present."""
+        a, b, c, d, mg = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        check(L.load().mpg_mesh_window_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(mg)))
+        return a.value, b.value, c.value, d.value, mg.value
 
     def set_source_window(self, first, count, meshloc=MESHLOC_ELEMENT):
         """Every handle of this mesh and location (existing and future) indexes its sources relative to `first`; Regrid
