@@ -193,22 +193,36 @@ def main():
     id_file = "/dev/shm/mpassit_bench_%s.rcclid" % all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]   # fresh per run
     sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file)
     P_local = sr.rh.n_dst
-    local = sr.local_buffer(F, nlev, dev)
-    c0, c1 = sr.sched.own
-    if sr.sched.mode == "range":
-        own = sr.own_view(local)
-    else:
-        own = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
-    synth_fields_device(torch, m.latCell[c0:c1], m.lonCell[c0:c1], nlev, F, own)
-    src_for_kernel = local
-    if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
-        src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()
     io32 = args.io == "f32"
-    if io32:  # fused ingest/egress variant: float32 in HBM on both sides, float64 arithmetic (not the headline)
-        if world > 1:
-            raise SystemExit("--io f32 is single-GPU only")
-        src_for_kernel = src_for_kernel.float()
-        del local
+    if io32 and world > 1:
+        raise SystemExit("--io f32 is single-GPU only")
+    c0, c1 = sr.sched.own
+    big_bundle = io32 and world == 1 and F * nlev * 8.0 * sr.sched.n_local > 40e9
+    if big_bundle:
+        # BASELINE configs[4] as written ("100+ 3-D fields" in ONE bundle, interp.F90:240-254): the float64 staging copies of the
+        # generic path below would not fit beside 58 GB of sources + 143 GB of results; the source goes straight into its final
+        # form, field by field: float32, file order or cell-fast
+        own = local = None
+        src_for_kernel = torch.empty((F, sr.sched.n_local, nlev) if layout == R.LAYOUT_LEV_FAST else (F, nlev, sr.sched.n_local),
+                                     dtype=torch.float32, device=dev)
+        one = torch.empty((nlev, sr.sched.n_local), dtype=torch.float64, device=dev)
+        for f in range(F):
+            synth_fields_device(torch, m.latCell, m.lonCell, nlev, 1, one, seed=20240807 + f)
+            src_for_kernel[f].copy_(one.t() if layout == R.LAYOUT_LEV_FAST else one)
+        del one
+    else:
+        local = sr.local_buffer(F, nlev, dev)
+        if sr.sched.mode == "range":
+            own = sr.own_view(local)
+        else:
+            own = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
+        synth_fields_device(torch, m.latCell[c0:c1], m.lonCell[c0:c1], nlev, F, own)
+        src_for_kernel = local
+        if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
+            src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()
+        if io32:  # fused ingest/egress variant: float32 in HBM on both sides, float64 arithmetic (not the headline)
+            src_for_kernel = src_for_kernel.float()
+            del local
     out = torch.empty((F, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dtype=torch.float32 if io32 else torch.float64, device=dev)
     torch.cuda.synchronize()
 
@@ -319,6 +333,19 @@ def main():
     if bad:
         raise SystemExit("bench self-check failed: %d points off" % bad)
 
+    # a bundle's first and last field against the same fields regridded alone (any 32-bit overflow in field * level * point
+    # offsets would show in the last one): bit for bit
+    bundle_check = None
+    if world == 1:
+        bundle_check = True
+        for f in sorted({0, F - 1}):
+            sf = src_for_kernel.view(F, -1)[f]
+            alone = sr.rh.regrid_typed(sf, nlev=nlev, nfields=1, layout=layout) if io32 else sr.rh.regrid(sf, nlev=nlev, nfields=1, layout=layout)
+            if not torch.equal(alone[0], out[f]):
+                raise SystemExit("bench self-check failed: field %d of the %d-field bundle differs from the same field regridded alone" % (f, F))
+            del alone
+    torch.cuda.synchronize()
+
     # live streaming reference of THIS device (boxes differ by >10 %): plain 2 GiB -> 2 GiB device copy
     cp_a = torch.empty(1 << 28, dtype=torch.float64, device=dev)
     cp_b = torch.empty_like(cp_a)
@@ -403,7 +430,7 @@ def main():
                        "target_points": int(g.nx * g.ny), "method": "bilinear", "src_layout": args.layout,
                        "io_dtype": "f32 (fused ingest/egress, f64 arithmetic)" if io32 else "f64",
                        "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
-                       "unmapped_points_rank0": n_unmapped},
+                       "unmapped_points_rank0": n_unmapped, "first_and_last_field_equal_single_field_regrid": bundle_check},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
                          "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),

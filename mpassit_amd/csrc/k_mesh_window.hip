@@ -214,17 +214,19 @@ static int pyr_ready(mpg_grid_s *g, int st, hipStream_t s) {
 // m: nCells / nVertices / maxEdges set, m->cell holding every cell centre.  Fills the geometry window.
 int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, hipStream_t s) {
   int rc;
-  // the grid as a set of boxes: the point pyramids of the staggers it has + the cell pyramid of its CORNER mesh
+  // the grid as a set of boxes: the padded 4 x 4-cell boxes of its CORNER mesh when it has one (they cover the points of every
+  // stagger, without gaps), else the 4 x 4-point boxes of the point staggers it has
   WinPyrs pyrs;
   pyrs.n = 0;
-  for (int st : {MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, MPG_STAGGERLOC_EDGE2}) {
-    if (g->pts[st].n == 0) continue;
-    if ((rc = pyr_ready(g, st, s))) return rc;
-    pyrs.v[pyrs.n++] = mpg_pyr_view(g->pyr[st]);
-  }
   if (g->pts[MPG_STAGGERLOC_CORNER].n == (int64_t)(g->nx + 1) * (g->ny + 1)) {
     if (!g->cellpyr.built && (rc = mpg_k_build_cell_pyramid(g->pts[MPG_STAGGERLOC_CORNER], g->nx, g->ny, g->cellpyr, s))) return rc;
     pyrs.v[pyrs.n++] = mpg_pyr_view(g->cellpyr);
+  } else {
+    for (int st : {MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, MPG_STAGGERLOC_EDGE2}) {
+      if (g->pts[st].n == 0) continue;
+      if ((rc = pyr_ready(g, st, s))) return rc;
+      pyrs.v[pyrs.n++] = mpg_pyr_view(g->pyr[st]);
+    }
   }
   const int64_t nC = m->nCells, nV = m->nVertices;
   const unsigned nbC = (unsigned)((nC + 255) / 256);
@@ -232,24 +234,22 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
   TmpBuf<float> D;
   if ((rc = stats.alloc(8, s)) || (rc = D.alloc((size_t)nC, s))) return rc;
   unsigned long long hs[8];
-  // grid spacing h, and how many cells sit inside the grid's boxes -> a first guess of the mesh spacing there
-  MPG_HIP(hipMemsetAsync(stats.p, 0, 8 * sizeof(unsigned long long), s));
-  MPG_HIP(hipMemsetAsync(stats.p + 2, 0xff, sizeof(unsigned long long), s));
+  // grid spacing h: the first margin is 6 h (a mesh as fine as the grid or finer); the first cut also counts the cells inside
+  // the grid's boxes, and a mesh that turns out COARSER than the grid -- spacing ~ h * sqrt(points / cells inside) -- is cut again
+  MPG_HIP(hipMemsetAsync(stats.p + 4, 0, sizeof(unsigned long long), s));
   {
     const PointSet &ctr = g->pts[MPG_STAGGERLOC_CENTER];
     k_grid_spacing<<<1, 64, 0, s>>>(g->nx, g->ny, ctr.x.p, ctr.y.p, ctr.z.p, stats.p + 4);
-    k_cell_dist<<<nbC, 256, 0, s>>>(nC, m->cell.x.p, m->cell.y.p, m->cell.z.p, pyrs, 0.0, 0.0, nullptr, stats.p);
   }
   MPG_HIP(hipGetLastError());
-  MPG_HIP(hipMemcpyAsync(hs, stats.p, sizeof(hs), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipMemcpyAsync(hs + 4, stats.p + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   double h_grid;
   memcpy(&h_grid, &hs[4], sizeof(double));
   if (!(h_grid > 0.0)) h_grid = 1e-4;   // a 1 x 1 grid
-  const double n_in = (double)hs[0], P = (double)g->nx * (double)g->ny;
-  // cells per grid point inside the boxes -> mesh spacing ~ h * sqrt(P / n_in); without a cell inside, start wide
-  const double s_mesh = n_in > 0.0 ? h_grid * sqrt(P / n_in) : 8.0 * h_grid;
-  double delta = 6.0 * (s_mesh > h_grid ? s_mesh : h_grid);
+  const double P = (double)g->nx * (double)g->ny;
+  double delta = 6.0 * h_grid;
+  bool spacing_known = false;
   for (int attempt = 0;; ++attempt) {
     bool whole = attempt >= 6 || delta >= 2.0;
     int64_t c0 = 0, c1 = nC;
@@ -260,6 +260,15 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
       MPG_HIP(hipGetLastError());
       MPG_HIP(hipMemcpyAsync(hs, stats.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       MPG_HIP(hipStreamSynchronize(s));
+      if (!spacing_known && hs[0] > 0) {   // cells per grid point inside the boxes -> the mesh's spacing there
+        spacing_known = true;
+        const double s_mesh = h_grid * sqrt(P / (double)hs[0]);
+        if (6.0 * s_mesh > 1.5 * delta) {   // a mesh coarser than the grid: the margin follows the MESH's spacing
+          delta = 6.0 * s_mesh;
+          --attempt;
+          continue;
+        }
+      }
       if (hs[1] == 0) {   // no cell within delta of the grid
         if (attempt < 3 && delta < 0.5) {   // ... yet: a grid inside one large cell, or off the mesh -- look further (up to half a
           delta = fmin(4.0 * delta, 0.5);   // radian) before concluding that the grid sees no cell
@@ -307,7 +316,10 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
     }
     m->vw0 = v0;
     m->vwn = v1 - v0;
-    if (m->vwn == 0) return MPG_SUCCESS;
+    if (m->vwn == 0) {   // rows of padding only
+      MPG_HIP(hipStreamSynchronize(s));
+      return MPG_SUCCESS;
+    }
     if ((rc = m->vert.alloc(m->vwn))) return rc;
     {
       TmpBuf<double> tmp;
@@ -315,8 +327,7 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
       MPG_HIP(hipMemcpyAsync(tmp.p, lonVertex + v0, sizeof(double) * m->vwn, hipMemcpyHostToDevice, s));
       MPG_HIP(hipMemcpyAsync(tmp.p + m->vwn, latVertex + v0, sizeof(double) * m->vwn, hipMemcpyHostToDevice, s));
       if ((rc = mpg_k_mesh_coords_dev(m->vwn, tmp.p, tmp.p + m->vwn, m->vert.x.p, m->vert.y.p, m->vert.z.p, s))) return rc;
-      MPG_HIP(hipStreamSynchronize(s));   // tmp goes back to the pool; the host arrays may be released by the caller
-    }
+    }   // tmp goes back to the pool in stream order; the host arrays are in use until the synchronisation that ends every path below
     if ((rc = m->tri.alloc(3 * (size_t)m->vwn))) return rc;
     TmpBuf<int32_t> cnt;
     if ((rc = cnt.alloc((size_t)m->vwn, s))) return rc;

@@ -220,8 +220,10 @@ class ShardedRegrid:
         from . import regrid as R
         self.rank, self.world = rank, world
         self.j0, self.j1 = row_block(target.ny, world, rank)
-        self.mesh = R.Mesh.from_mpas(mpas_mesh)
         self.grid = R.Grid.from_target(target, rows=(self.j0, self.j1))
+        # with several ranks a rank's mesh holds only what its row block can see (mpg_mesh_create_window: same weights, geometry
+        # ingest and Stores that shrink with the block; the reference gives every rank 1/N of the cells, model_grid.F90:423-438)
+        self.mesh = R.Mesh.from_mpas(mpas_mesh, window_grid=self.grid if world > 1 else None)
         self.rh = R.regrid_store(self.mesh, self.grid, regridmethod)
         self.store_ms = self.rh.store_ms
         needed = self.rh.unique_sources()
@@ -322,8 +324,8 @@ class ShardedInterp:
         self.rank, self.world, self.ny = rank, world, target.ny
         self.j0, self.j1 = row_block(target.ny, world, rank)
         self.e0, self.e1 = max(self.j0 - 1, 0), min(self.j1 + 1, target.ny)
-        self.mesh = R.Mesh.from_mpas(mpas_mesh)
         self.grid = R.Grid.from_target(target, rows=(self.j0, self.j1))
+        self.mesh = R.Mesh.from_mpas(mpas_mesh, window_grid=self.grid if world > 1 else None)   # only what this row block can see
         self.grid_ext = R.Grid.from_target(target, rows=(self.e0, self.e1))
         self.target = copy.copy(target)               # rotation angles of the own rows
         if target.cosa is not None:

@@ -235,8 +235,7 @@ contains
       call nc_read_grid(grid_file_input_grid, latCell, lonCell, latVertex, lonVertex, voc)
       print *, "- NUMBER OF CELLS ON INPUT GRID ", nCells_input
       print *, "- CREATE MESH -"
-      call mpg_check(mpg_mesh_create(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &
-                                     latCell, lonCell, latVertex, lonVertex, voc, input_grid), "IN MeshCreate")
+      call create_mesh(latCell, lonCell, latVertex, lonVertex, voc)
       return
     end if
     call raw_open_read(grid_file_input_grid, u)
@@ -258,9 +257,29 @@ contains
     print *, "- NUMBER OF CELLS ON INPUT GRID ", nCells_input
     print *, "- NUMBER OF NODES ON INPUT GRID ", nVert_input
     print *, "- CREATE MESH -"
-    call mpg_check(mpg_mesh_create(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &
-                                   latCell, lonCell, latVertex, lonVertex, voc, input_grid), "IN MeshCreate")
+    call create_mesh(latCell, lonCell, latVertex, lonVertex, voc)
   end subroutine define_input_grid
+
+  !> ESMF_MeshCreate (model_grid.F90:488-497).  One image of several holds only the part of the mesh its rows of the target
+  !! grid can see (mpg_mesh_create_window; the reference hands every PET 1/N of the cells, model_grid.F90:423-438): the same
+  !! weights, a geometry ingest and Stores that shrink with the row block.  MPASSIT_WHOLE_MESH=1 keeps the whole mesh (A/B).
+  subroutine create_mesh(latCell, lonCell, latVertex, lonVertex, voc)
+    real(dp), intent(in) :: latCell(:), lonCell(:), latVertex(:), lonVertex(:)
+    integer(c_int32_t), intent(in) :: voc(:)
+    character(len=16) :: buf
+    integer(c_int64_t) :: c0, cn, v0, vn
+    real(c_double) :: margin
+    call get_environment_variable("MPASSIT_WHOLE_MESH", buf)
+    if (nranks > 1 .and. len_trim(buf) == 0) then
+      call mpg_check(mpg_mesh_create_window(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &
+                                            latCell, lonCell, latVertex, lonVertex, voc, target_grid_h, input_grid), "IN MeshCreate")
+      call mpg_check(mpg_mesh_window_info(input_grid, c0, cn, v0, vn, margin), "IN MeshWindowInfo")
+      print '(a,i0,a,i0,a,i0,a)', " - MESH WINDOW OF THIS IMAGE: ", cn, " OF ", nCells_input, " CELLS, ", vn, " VERTICES"
+    else
+      call mpg_check(mpg_mesh_create(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &
+                                     latCell, lonCell, latVertex, lonVertex, voc, input_grid), "IN MeshCreate")
+    end if
+  end subroutine create_mesh
 
   subroutine load_field(u, name, tname, f)
     integer, intent(in) :: u

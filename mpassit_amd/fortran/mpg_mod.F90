@@ -63,6 +63,28 @@ module mpg
       integer(c_int) :: rc
     end function mpg_mesh_create
 
+    !> ESMF_MeshCreate for ONE image of a job whose target rows are split over several GPUs: only the part of the mesh that
+    !! `grid` (this image's row block) can see is brought to the device; ids stay global, weights are those of the whole mesh
+    function mpg_mesh_create_window(nCells, nVertices, maxEdges, latCell, lonCell, latVertex, lonVertex, verticesOnCell, grid, mesh) &
+        bind(C, name="mpg_mesh_create_window") result(rc)
+      import :: c_int, c_int64_t, c_int32_t, c_double, c_ptr
+      integer(c_int64_t), value :: nCells, nVertices
+      integer(c_int), value :: maxEdges
+      real(c_double), intent(in) :: latCell(*), lonCell(*), latVertex(*), lonVertex(*)
+      integer(c_int32_t), intent(in) :: verticesOnCell(*)
+      type(c_ptr), value :: grid
+      type(c_ptr), intent(out) :: mesh
+      integer(c_int) :: rc
+    end function mpg_mesh_create_window
+
+    function mpg_mesh_window_info(mesh, cell_first, cell_count, vertex_first, vertex_count, margin) bind(C, name="mpg_mesh_window_info") result(rc)
+      import :: c_int, c_int64_t, c_double, c_ptr
+      type(c_ptr), value :: mesh
+      integer(c_int64_t), intent(out) :: cell_first, cell_count, vertex_first, vertex_count
+      real(c_double), intent(out) :: margin
+      integer(c_int) :: rc
+    end function mpg_mesh_window_info
+
     function mpg_mesh_destroy(mesh) bind(C, name="mpg_mesh_destroy") result(rc)
       import :: c_int, c_ptr
       type(c_ptr), value :: mesh

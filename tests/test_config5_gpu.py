@@ -180,3 +180,48 @@ def test_c5_full_size_oracle_parity(c5, oracle):
     want = o.apply_csr(rp_o, col_o, val_o, snow, 1)[0]
     assert np.abs(got - want).max() < 1e-9 * np.abs(want).max() < 1e-6
     rh.release()
+
+
+def test_c5_hundred_field_bundle_as_baseline_states_it(c5, oracle):
+    """BASELINE configs[4] as written: "3 M-cell mesh -> 3600 x 1800 global lat-lon, 100+ 3-D fields" -- ONE bundle Regrid of
+    100 float32 file-order fields x 55 levels (interp.F90:240-254 regrids every listed nz field in one FieldBundleRegrid):
+    57.7 GB of sources, 142.6 GB of results, 1.3 M workgroups.  (The mesh is the 2 621 442-cell icosahedral one, 10 * 4^9 + 2:
+    the nearest quasi-uniform global MPAS size to "3 M"; a 3.0 M-cell GLOBAL mesh does not exist in that family.)
+    What is checked: the first and the LAST field of the bundle -- where a 32-bit overflow in field * level * point offsets
+    would land -- against the oracle's widen -> apply chain narrowed to float32 (equal except where the two float64 values,
+    <= 1e-12 apart, straddle a float32 rounding boundary: one float32 ulp on a vanishing fraction of the points, the bar of
+    tests/test_typed_oracle_gpu.py), a constant field in the middle, and that no field is left unwritten."""
+    from mpassit_amd import regrid as R
+    torch, m, g, nlev = c5["torch"], c5["m"], c5["g"], c5["nlev"]
+    F = 100
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    need = F * nlev * 4 * (m.nCells + g.nx * g.ny) + 8e9
+    if free < need:
+        pytest.skip("needs %.0f GB of free HBM, %.0f free" % (need / 1e9, free / 1e9))
+    rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_BILINEAR)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    src = torch.empty((F, m.nCells, nlev), dtype=torch.float32, device="cuda")
+    for f in range(F):
+        src[f].uniform_(-1.0, 1.0, generator=gen)
+    src[F // 2].fill_(3.25)
+    out = torch.full((F, nlev, g.ny, g.nx), float("nan"), dtype=torch.float32, device="cuda")
+    rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=R.LAYOUT_LEV_FAST, out=out)
+    torch.cuda.synchronize()
+    assert rh.kernel_choice()[1] > 0                               # the staged file-order kernel (k_apply3_lfu) serves configuration 5
+    for f in range(F):
+        assert not torch.isnan(out[f, ::18, ::60, ::60]).any(), f   # a sample of every field: all written
+    assert not torch.isnan(out[F - 1]).any() and not torch.isnan(out[0]).any()
+    assert bool((out[F // 2] == 3.25).all())                       # sum of the weights is 1 on a closed sphere; float32(3.25) exact
+    idx, w = rh.weights()
+    for f in (0, F - 1):
+        want = oracle.apply_fixed(idx, w, src[f].cpu().numpy().astype(np.float64), nlev, lev_fast=True).astype(np.float32)
+        got = out[f].cpu().numpy().reshape(nlev, -1)
+        ne = got != want
+        assert ne.mean() < 1e-5, (f, ne.mean())
+        if ne.any():
+            assert (np.abs(got[ne].astype(np.float64) - want[ne]) <= np.spacing(np.abs(want[ne])).astype(np.float64)).all(), f
+    rh.release()
+    del src, out
+    torch.cuda.empty_cache()

@@ -184,3 +184,27 @@ def test_c4_morton_numbering_same_answer(c4):
     rn_r.release()
     rn_m.release()
     mesh_m.destroy()
+
+
+def test_c4_row_blocks_on_windowed_meshes_equal_the_whole_mesh(c4):
+    """Configuration 4 as its 8-GPU run sees it: a rank's mesh is cut to its block of target rows (mpg_mesh_create_window) --
+    380 k of the 3.0 M cells resident for an eighth of the rows -- and every Store on it gives the weights the whole mesh gives,
+    bit for bit: three of the eight blocks (first, a middle one, last), all three methods, on the one card."""
+    from mpassit_amd import dist, regrid as R
+    m, g = c4["m"], c4["g"]
+    for rank in (0, 3, 7):
+        j0, j1 = dist.row_block(g.ny, 8, rank)
+        grid = R.Grid.from_target(g, rows=(j0, j1))
+        cut = R.Mesh.from_mpas(m, window_grid=grid)
+        c0, cn, v0, vn, margin = cut.window_info()
+        assert 0.10 * m.nCells < cn < 0.16 * m.nCells and 0.10 * m.nVertices < vn < 0.16 * m.nVertices, (rank, cn, vn)
+        for method in (R.REGRIDMETHOD_BILINEAR, R.REGRIDMETHOD_NEAREST_STOD, R.REGRIDMETHOD_CONSERVE):
+            a, b = R.regrid_store(c4["mesh"], grid, method), R.regrid_store(cut, grid, method)
+            wa, wb = (a.csr(), b.csr()) if method == R.REGRIDMETHOD_CONSERVE else (a.weights(), b.weights())
+            assert a.n_src == b.n_src == m.nCells
+            for x, y in zip(wa, wb):
+                assert np.array_equal(x, y), (rank, method)
+            a.release()
+            b.release()
+        cut.destroy()
+        grid.destroy()
