@@ -490,7 +490,7 @@ def kernel_label(rh, layout, R):
     cf, lf, mu = rh.kernel_choice()
     if layout == R.LAYOUT_CELL_FAST:
         return "k_apply3_cfu (staged, a3_staged %d, <= %d cells per tile)" % (cf - 1, mu) if cf > 0 else "k_apply3_cf (lane gather)"
-    return "k_apply3_lfu / k_apply3_lfw (staged, <= %d cells per tile)" % mu if lf > 0 else "k_apply3_lf_rows (row gather, linear tiles)"
+    return "k_apply3_lfu (staged, <= %d cells per tile)" % mu if lf > 0 else "k_apply3_lf_rows (row gather, linear tiles)"
 
 
 def recorded_traffic(workload, F, layout, io32):

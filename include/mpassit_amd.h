@@ -354,6 +354,9 @@ int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, con
  *   "lf_variant"  level-fast (file-order) 3-point Regrid: -1 per-handle choice (default), 0 row gather on linear aligned
  *                 tiles, 1 LDS-staged in 16-level chunks, 2 row gather on grid-row tiles (the capacity fallback)
  *   "nn_variant"  nearest-neighbour search: 1 wave-cooperative (default), 0 one thread per point
+ *   "field_band"  order of the (field, tile) work items of a bundle Regrid: -1 each kernel's own choice (default: bands of
+ *                 1024 tiles for the level-fast row gather, field-major for the staged kernels), 0 field-major, n > 0 all
+ *                 fields of a band of n tiles before the next band
  * and one that does NOT (it selects between two readings of ESMF's undocumented-here behaviour):
  *   "bilinear_linetype"   Mesh -> Grid bilinear Store: 0 (default) the target point meets the plane of its source triangle
  *                 along the ray from the sphere's centre; 1 along the plane's normal (ESMF_LINETYPE_CART read literally).

@@ -99,6 +99,28 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Order of the (field, tile) work items of a bundle Regrid.  band == 0: field-major (all tiles of field 0, then field 1 ...).
+// band > 0: the tiles are taken in bands of `band`, and ALL FIELDS of a band come before the next band -- the band's
+// indices, weights and tile lists (the same for every field: 30-36 B per point) are then re-read from L2 by the next
+// field instead of from HBM a whole field later ("field_band" knob; measurements in profiles/r04_lf_experiments.txt).
+__device__ __forceinline__ void band_map(unsigned lin, unsigned ntile, unsigned nf, unsigned band, unsigned &tile, int &f) {
+  if (band == 0) {
+    tile = lin % ntile;
+    f = (int)(lin / ntile);
+    return;
+  }
+  const unsigned nb = ntile / band, rem = ntile - nb * band, full = nb * band * nf;
+  if (lin < full) {
+    const unsigned per = band * nf, b = lin / per, r = lin - b * per;
+    f = (int)(r / band);
+    tile = b * band + (r - (unsigned)f * band);
+  } else {
+    const unsigned r = lin - full;
+    f = (int)(r / rem);
+    tile = nb * band + (r - (unsigned)f * rem);
+  }
+}
+
 // ---- element access of the fused ingest / egress kernels ------------------------------------------------------------
 // A NetCDF classic variable is big-endian (the files MPASSIT reads, input_data.F90:630, and writes, write_data.F90:779,
 // when they are CDF-1/2/5): the typed Regrid and the post-op kernels take and produce such values as they are stored, so

@@ -284,6 +284,11 @@ int mpg_k_tune(const char *key, int value) {
     mpg_set_nearest_variant(value);
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "field_band")) {
+    if (value < -1 || value > 65536) return MPG_ERR_INVALID_ARG;
+    mpg_set_field_band(value);
+    return MPG_SUCCESS;
+  }
   if (!strcmp(key, "lfu_min_reuse_x10")) {
     if (value < 0 || value > 1000) return MPG_ERR_INVALID_ARG;
     mpg_lfu_set_min_reuse_x10(value);

@@ -32,6 +32,7 @@
 #include "geom.h"
 #include "mpg_internal.h"
 
+int mpg_field_band(int kernel_default);
 #define LFU_THREADS 256
 #define LFU_LIST_PAD 512   // every tile's list is padded with its last cell up to min(stride, this many) entries
 #define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two
@@ -180,15 +181,16 @@ template <typename TS, typename TD, int RPT, int NT, bool EPI>
 __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ ut_cnt, const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                    const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
-                                                   int nlev, int ntx, int nty, int ut_max, double scale, double offset) {
+                                                   int nlev, int ntx, int nty, int ut_max, double scale, double offset, int band) {
   constexpr int LC = 4, UPT = 4, NPF = LC * UPT;
   extern __shared__ double lds[];  // [LC][nup]
   const int nup = ut_max;
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned tile = lin % ntile;
-  const int f = lin / ntile;
+  unsigned tile;
+  int f;
+  band_map(lin, ntile, gridDim.x / ntile, (unsigned)band, tile, f);
   const int t = threadIdx.x;
   const int nU = ut_cnt[tile];
   const int32_t *cells = ut_cells + (int64_t)tile * stride;
@@ -391,6 +393,15 @@ static int sampled_reuse(mpg_handle_s *h, int tyu, hipStream_t s, float *reuse) 
 #define LFU_AUTO_MIN_REUSE 3.5f
 static float g_lfu_min_reuse = LFU_AUTO_MIN_REUSE;  // "lfu_min_reuse_x10" knob (level-fast choice only; decided at a handle's first call)
 void mpg_lfu_set_min_reuse_x10(int v) { g_lfu_min_reuse = 0.1f * (float)v; }
+// "field_band" knob (geom.h band_map): -1 each kernel's own default, 0 field-major, > 0 tiles per band.  Measured (13 fields x
+// 55 levels, profiles/r04_lf_experiments.txt): the level-fast row gather gains 4 % from bands of 1024 tiles (its 36 B of
+// indices and weights per point are 7 % of its traffic and a band's 2.4 MB stay in the XCD's L2 from one field to the
+// next); the staged kernels LOSE 12-17 % on configuration 5 (thirteen fields' source rows then compete for the L2 that
+// serves the re-read ring of neighbouring tiles) and are level on configuration 4: they stay field-major.
+static int g_field_band = -1;
+int mpg_field_band(int kernel_default) { return g_field_band < 0 ? kernel_default : g_field_band; }
+void mpg_set_field_band(int v) { g_field_band = v; }
+
 // -> *lf_variant = MPG_LF_STAGED or MPG_LF_ROWS ("lf_variant" numbering, mpg_internal.h)
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lf_variant) {
   if (h->lf_choice == 0) {
@@ -463,7 +474,7 @@ static int launch_cfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   auto fn = k_apply3_cfu<TS, TD, RPT, NT, EPI>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cnt.p, h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
-                                                   h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset);
+                                                   h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset, mpg_field_band(0));
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -503,11 +514,15 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32,
 // of a row are clamped and the last chunk starts at nlev - 16, unmapped points combine a zero row with zero weights
 // (+0.0, as the masked form gave), and lanes without a target point store through an out-of-range buffer offset, which
 // the hardware drops (geom.h).  All addresses are scalar base + 32-bit lane offset: no address arithmetic per access.
+// Round 4 split the workgroup into producer waves (row loads -> a second slab) and consumer waves (combine + store), one
+// barrier per chunk, so that no wave's in-order counter sees both kinds: bit-identical and EQUAL in time (configuration 5
+// float32 6.545 against 6.517 ms, configuration 2 level; profiles/r04_lf_experiments.txt) -- the coupling of a wave's loads
+// and stores is not what holds this kernel back, and the form was not kept.
 template <typename TS, typename TD, int NT, bool EPI, bool SWZ>
 __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w, const TS *__restrict__ src,
                                                    TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc, int nlev, int ntx, int nty,
-                                                   double scale, double offset, int sbe, int dbe) {
+                                                   double scale, double offset, int sbe, int dbe, int band) {
   constexpr int LC = 16, NPF = 16, LS = LC + 1, RPP = NT / LC, TY = NT / 64, ZROW = NPF * RPP;
   extern __shared__ double lds_raw[];
   TS *slab = (TS *)lds_raw;                                  // [ZROW + 1][LS]; row ZROW stays zero
@@ -515,8 +530,9 @@ __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ u
   const int64_t P = (int64_t)nx * ny;
   const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned tile = lin % ntile;
-  const int f = lin / ntile;
+  unsigned tile;
+  int f;
+  band_map(lin, ntile, gridDim.x / ntile, (unsigned)band, tile, f);
   const int t = threadIdx.x, lrow = t / LC, llev = t % LC;
   const int32_t *list = ut_cells + (int64_t)tile * stride;   // padded with its last cell up to LFU_LIST_PAD entries
   // this thread's 16 rows: byte offsets of (cell, level llev) inside the field
@@ -594,11 +610,11 @@ static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   const size_t lds = sizeof(TS) * (NT + 1) * 17;
   if (h->ut_max > NT || h->ut_stride < NT || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
     return MPG_ERR_UNSUPPORTED;
+  static_assert(NT <= LFU_LIST_PAD, "the kernel reads NT list entries of every tile");
   auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true> : k_apply3_lfu<TS, TD, NT, EPI, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  static_assert(NT <= LFU_LIST_PAD, "the kernel reads NT list entries of every tile");
   fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
-                                                   h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe);
+                                                   h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe, mpg_field_band(0));
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

@@ -153,15 +153,16 @@ template <> struct Row2<double> { typedef f64x2_u type; };
 template <typename TS, typename TD, int UNR, bool EPI, bool SWZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_apply3_lf_rows(
     const int32_t *__restrict__ idx, const double *__restrict__ w, const TS *__restrict__ src, TD *__restrict__ dst, int64_t P, int64_t nsrc,
-    int nlev, unsigned ntile, double scale, double offset, int sbe, int dbe) {
+    int nlev, unsigned ntile, double scale, double offset, int sbe, int dbe, int band) {
   typedef typename Row2<TS>::type row2;
   extern __shared__ double sw[];                    // sw[3][64] | soff[3][64] | tile[nlev][65] in the destination type
   uint32_t *soff = (uint32_t *)(sw + 192);
   TD *tile = (TD *)(soff + 192);
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
-  const unsigned tl = lin % ntile;
-  const int f = (int)(lin / ntile);
+  unsigned tl;
+  int f;
+  band_map(lin, ntile, gridDim.x / ntile, (unsigned)band, tl, f);
   const int64_t p0 = (int64_t)tl * 64;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t < 192) {
@@ -311,6 +312,9 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
   }
 }
 
+// the (field, tile) order of the row gather: bands of 1024 tiles (64 K points, 2.4 MB of indices + weights: they stay in the
+// XCD's L2 from one field of the bundle to the next), all fields of a band before the next band -- 4 % on configuration 4
+#define LF_ROWS_BAND 1024
 static size_t lf_rows_lds(size_t dst_size, int nlev) { return dst_size * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192; }
 static bool lf_rows_fits(const mpg_handle_s *h, size_t dst_size, int nlev) {
   return nlev >= 2 && (uint64_t)h->n_src * (uint64_t)nlev < 0xFFFFFFFFull && lf_rows_lds(dst_size, nlev) <= 160 * 1024;
@@ -327,7 +331,7 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
       const unsigned ntile = (unsigned)((P + 63) / 64);
       auto fn = k_apply3_lf_rows<TS, TD, sizeof(TS) == 4 ? 2 : 1, true, SWZ>;   // measured: unroll 2 for float32 rows, 1 for float64
       if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, scale, offset, sbe, dbe);
+      fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, scale, offset, sbe, dbe, mpg_field_band(LF_ROWS_BAND));
     } else if (lev_fast) {
       size_t lds = sizeof(TD) * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192;
       if (lds > 160 * 1024) {
@@ -368,7 +372,7 @@ int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfiel
   const unsigned ntile = (unsigned)((P + 63) / 64);
   auto fn = k_apply3_lf_rows<double, double, 1, false, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, 1.0, 0.0, 0, 0);
+  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, 1.0, 0.0, 0, 0, mpg_field_band(LF_ROWS_BAND));
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

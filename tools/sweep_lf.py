@@ -64,7 +64,7 @@ def main():
             if rnd == 0:
                 if ref is None:
                     ref = out.clone()
-                elif not torch.equal(out, ref):
+                elif not torch.equal(out.view(torch.int32), ref.view(torch.int32)):   # bit patterns (big-endian results read as floats hold NaNs)
                     print("# variant %d DIFFERS from variant %d: max abs %g" % (v, variants[0], float((out.double() - ref.double()).abs().max())))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -74,7 +74,7 @@ def main():
             torch.cuda.synchronize()
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1) / 3)
-    _lib.tune(knob, 1 if knob == "nn_variant" else -1)
+    _lib.tune(knob, {"nn_variant": 1}.get(knob, -1))
     res = []
     for v, ts in times.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
