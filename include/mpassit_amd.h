@@ -124,6 +124,14 @@ typedef struct mpg_proj {
   double dlat_deg, dlon_deg;                     /* PROJ_LATLON: latinc, loninc */
 } mpg_proj;
 int mpg_grid_create_proj(const mpg_proj *proj, int nx, int ny, int periodic_i, mpg_grid *out);
+/* A grid made from coordinate ARRAYS (mpg_grid_create) whose arrays are rows row0 .. row0 + ny - 1 of the grid `proj` describes
+ * (a rank's block of target rows, model_grid.F90:693): the Stores of Mesh -> Grid handles then find a source triangle's /
+ * cell's target points through the inverse projection in O(1) instead of descending the box pyramid (PROJ_LC and PROJ_LATLON;
+ * other projections are accepted and change nothing).  Every candidate is still tested exactly as before: the weights are
+ * those of the pyramid search.  The claim is checked -- a sample of the grid's own CENTER points must fall on their own
+ * indices -- and a projection that does not fit is refused with MPG_ERR_INVALID_ARG.  Grids of mpg_grid_create_proj have
+ * their inverse from the start. */
+int mpg_grid_attach_proj(mpg_grid grid, const mpg_proj *proj, int row0);
 int mpg_grid_get_coords(mpg_grid grid, int staggerloc, double *lon_host, double *lat_host);
 int mpg_grid_get_rotang(mpg_grid grid, double *cosa_host, double *sina_host);
 int mpg_grid_get_mapfac(mpg_grid grid, int staggerloc, double *mapfac_host);

@@ -258,6 +258,8 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
   for (int k = 0; k < nlev; ++k) dst[(int64_t)k * nids + i] = src[(int64_t)k * nsrc + c];
 }
 
+static int g_store_boxes = 1;
+int mpg_store_boxes() { return g_store_boxes; }
 static int g_bilinear_linetype = 0;
 int mpg_bilinear_linetype() { return g_bilinear_linetype; }
 int mpg_a3_staged() { return g_a3_staged; }
@@ -277,6 +279,11 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "bilinear_linetype")) {   // Mesh -> Grid bilinear Store: where the target point meets the triangle's plane
     if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
     g_bilinear_linetype = value;
+    return MPG_SUCCESS;
+  }
+  if (!strcmp(key, "store_boxes")) {   // Stores on projection-built grids: candidates from the inverse projection (1) or the pyramid walk (0)
+    if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
+    g_store_boxes = value;
     return MPG_SUCCESS;
   }
   if (!strcmp(key, "nn_variant")) {   // nearest-neighbour Store: 1 = wave-cooperative search, 0 = one thread per point

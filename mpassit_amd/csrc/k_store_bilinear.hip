@@ -27,13 +27,47 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
                                                     const double *__restrict__ px, const double *__restrict__ py,
                                                     const double *__restrict__ pz, int32_t *__restrict__ owner,
                                                     int32_t *__restrict__ overflow, int32_t *__restrict__ big, int32_t *__restrict__ nbig,
-                                                    int big_cap) {
+                                                    int big_cap, const float *__restrict__ sij, float di, float dj, float pad_coef) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= nTri) return;
   int32_t ia = tri[t];
   if (ia < 0) return;
   int32_t ib = tri[triStride + t], ic = tri[2 * triStride + t];
   dv3 A = ld3(cx, cy, cz, ia), B = ld3(cx, cy, cz, ib), C = ld3(cx, cy, cz, ic);
+  // O(1) candidates on a projection-built grid (round 4): the triangle's corners in the grid's own index space (sij: the inverse
+  // projection of every source point, k_target_grid.hip; di / dj: offset of this stagger's point indices) bound the target points
+  // it can hold -- a box of a few points around it, padded for the bend of its edges on the map and for the float32 indices.
+  // Every point of the box gets the very test of the pyramid's leaves below, so the owners are the same; a triangle whose
+  // corners have no usable index (near the projection's pole or cut, poleward of 75 degrees on a lat-lon grid), that spans more
+  // than six index units or whose box holds more than 64 points takes the walk.
+  if (sij) {
+    const float ai = sij[2 * ia], aj = sij[2 * ia + 1], bi_ = sij[2 * ib], bj_ = sij[2 * ib + 1], ci_ = sij[2 * ic], cj_ = sij[2 * ic + 1];
+    const float imin = fminf(ai, fminf(bi_, ci_)), imax = fmaxf(ai, fmaxf(bi_, ci_)), jmin = fminf(aj, fminf(bj_, cj_)), jmax = fmaxf(aj, fmaxf(bj_, cj_));
+    const float E = fmaxf(imax - imin, jmax - jmin);
+    const bool usable = ai == ai && aj == aj && bi_ == bi_ && bj_ == bj_ && ci_ == ci_ && cj_ == cj_;   // fminf / fmaxf skip a NaN corner
+    if (usable && E <= 6.0f) {
+      const float pad = 1.01f + pad_coef * E * E;
+      const int i0 = max((int)ceilf(imin + di - pad), 0), i1 = min((int)floorf(imax + di + pad), npx - 1);
+      const int j0 = max((int)ceilf(jmin + dj - pad), 0), j1 = min((int)floorf(jmax + dj + pad), npy - 1);
+      if (i0 > i1 || j0 > j1) return;   // off the grid
+      if ((i1 - i0 + 1) * (j1 - j0 + 1) <= 64) {
+        dv3 ab = B - A, bc = C - B, ca = A - C;
+        double e2 = fmax(dot3(ab, ab), fmax(dot3(bc, bc), dot3(ca, ca)));
+        double pad3 = 0.5 * e2 + 1e-9;
+        double lo[3] = {fmin(A.x, fmin(B.x, C.x)) - pad3, fmin(A.y, fmin(B.y, C.y)) - pad3, fmin(A.z, fmin(B.z, C.z)) - pad3};
+        double hi[3] = {fmax(A.x, fmax(B.x, C.x)) + pad3, fmax(A.y, fmax(B.y, C.y)) + pad3, fmax(A.z, fmax(B.z, C.z)) + pad3};
+        for (int j = j0; j <= j1; ++j)
+          for (int i = i0; i <= i1; ++i) {
+            int64_t p = (int64_t)j * npx + i;
+            dv3 P = dv3{px[p], py[p], pz[p]};
+            if (P.x < lo[0] || P.x > hi[0] || P.y < lo[1] || P.y > hi[1] || P.z < lo[2] || P.z > hi[2]) continue;
+            double w[3];
+            if (NORMAL ? tri_weights_normal(P, A, B, C, MPG_TOL, w) : tri_weights(P, A, B, C, MPG_TOL, w)) atomicMin(&owner[p], (int32_t)t);
+          }
+        return;
+      }
+    }
+  }
   // AABB of the spherical triangle: planar AABB inflated by the bulge bound e^2/2 (e = longest edge)
   dv3 ab = B - A, bc = C - B, ca = A - C;
   double e2 = fmax(dot3(ab, ab), fmax(dot3(bc, bc), dot3(ca, ca)));
@@ -300,9 +334,22 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   auto raster = mpg_bilinear_linetype() ? k_tri_raster<true> : k_tri_raster<false>;
   auto raster_big = mpg_bilinear_linetype() ? k_tri_raster_big<true> : k_tri_raster_big<false>;
   auto finalize = mpg_bilinear_linetype() ? k_tri_finalize<true> : k_tri_finalize<false>;
+  // a grid built from its projection: the source points' places in its index space (one inverse projection per point, shared by
+  // the six triangles around it) give every triangle its candidate points in O(1); "store_boxes" 0 keeps the pyramid walk (A/B)
+  TmpBuf<float> sij;
+  const float *sijp = nullptr;
+  float di = 0.f, dj = 0.f;
+  if (mpg_grid_has_inverse(g) && mpg_store_boxes() && nT > 0) {
+    const int64_t s0 = meshloc == MPG_MESHLOC_NODE ? m->vw0 : m->cw0, sn = meshloc == MPG_MESHLOC_NODE ? m->vwn : m->cwn;
+    if ((rc = sij.alloc(2 * (size_t)sn, s))) return rc;
+    if ((rc = mpg_k_points_ij(g, sn, sx + s0, sy + s0, sz + s0, sij.p, s))) return rc;
+    sijp = sij.p - 2 * s0;   // indexed with global ids, like sx / sy / sz
+    di = stagger == MPG_STAGGERLOC_EDGE1 ? 0.5f : 0.f;
+    dj = stagger == MPG_STAGGERLOC_EDGE2 ? 0.5f : 0.f;
+  }
   if (nT > 0) {
     raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p, pts.z.p,
-                                                       owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap);
+                                                       owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap, sijp, di, dj, (float)mpg_grid_box_pad_coef(g));
     raster_big<<<1024, 256, 0, s>>>(ovf.p + 2, ovf.p + 1, big_cap, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p,
                                    pts.z.p, owner.p, ovf.p);
   }

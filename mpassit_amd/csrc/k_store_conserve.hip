@@ -45,7 +45,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          const double *__restrict__ qsph, int32_t *__restrict__ cnt_src,
                                                          int32_t *__restrict__ tmp_dst, int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
                                                          uint8_t *__restrict__ flip, const int32_t *__restrict__ poff,
-                                                         int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p) {
+                                                         int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p, const float *__restrict__ vij,
+                                                         float pad_coef) {
   // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
   constexpr bool COOP = MODE == 5 || MODE == 6;
   int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -79,6 +80,75 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   for (int k = 0; k < 3; ++k) { lo[k] -= pad; hi[k] += pad; }
 
   int nxc = nx + 1;
+  // Is destination cell (i, j) a candidate for this polygon?  Bounding sphere of the cell (k_cell_areas) against the polygon's
+  // padded box -- 4 loads decide most cells before the 12 corner coordinates are touched --, then box against box, then a
+  // non-degenerate cell.  The one test of the pyramid's leaves AND of the index-space boxes below.
+  auto candidate = [&](int i, int j) -> bool {
+    const int64_t pc = (int64_t)j * nx + i;
+    {
+      const double4 sph = *reinterpret_cast<const double4 *>(qsph + 4 * pc);   // one 32-byte record per cell: one line, not four
+      double sx = sph.x, sy = sph.y, sz = sph.z, r2 = sph.w;
+      double ddx = fmax(fmax(lo[0] - sx, sx - hi[0]), 0.0), ddy = fmax(fmax(lo[1] - sy, sy - hi[1]), 0.0),
+             ddz = fmax(fmax(lo[2] - sz, sz - hi[2]), 0.0);
+      if (ddx * ddx + ddy * ddy + ddz * ddz > r2) return false;
+    }
+    int64_t k00 = (int64_t)j * nxc + i;
+    dv3 q[4] = {dv3{qx[k00], qy[k00], qz[k00]}, dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
+                dv3{qx[k00 + nxc + 1], qy[k00 + nxc + 1], qz[k00 + nxc + 1]}, dv3{qx[k00 + nxc], qy[k00 + nxc], qz[k00 + nxc]}};
+    double ql[3] = {2, 2, 2}, qh[3] = {-2, -2, -2}, qe2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ql[0] = fmin(ql[0], q[k].x); qh[0] = fmax(qh[0], q[k].x);
+      ql[1] = fmin(ql[1], q[k].y); qh[1] = fmax(qh[1], q[k].y);
+      ql[2] = fmin(ql[2], q[k].z); qh[2] = fmax(qh[2], q[k].z);
+      dv3 d = q[k] - q[0];
+      qe2 = fmax(qe2, dot3(d, d));
+    }
+    double qp = 2.0 * qe2 + 1e-9;
+    if (ql[0] - qp > hi[0] || qh[0] + qp < lo[0] || ql[1] - qp > hi[1] || qh[1] + qp < lo[1] || ql[2] - qp > hi[2] || qh[2] + qp < lo[2]) return false;
+    return fabs(qarea[pc]) > 0.0;   // signed area of the destination quad, computed once per grid (k_cell_areas)
+  };
+  // O(1) candidates on a projection-built grid (round 4; MODE 3 only): the polygon's corners in the grid's index space (vij:
+  // the inverse projection of every vertex, k_target_grid.hip) bound the destination cells it can meet -- cell (i, j) covers
+  // index coordinates i - 0.5 .. i + 0.5 -- and every cell of that padded box takes the test above.  More candidates than the
+  // list holds, a polygon near the projection's pole / cut or wider than six index units: the walk (and the overflow passes).
+  if (MODE == 3 && vij) {
+    float imin = 1e30f, imax = -1e30f, jmin = 1e30f, jmax = -1e30f;
+    bool ok = true;
+    for (int j = 0, k = 0; j < maxEdges && k < CONS_MAXV; ++j) {
+      int32_t v = voc[c * maxEdges + j];
+      if (v <= 0) continue;
+      ++k;
+      const float vi = vij[2 * (int64_t)(v - 1)], vj = vij[2 * (int64_t)(v - 1) + 1];
+      ok = ok && vi == vi && vj == vj;
+      imin = fminf(imin, vi); imax = fmaxf(imax, vi);
+      jmin = fminf(jmin, vj); jmax = fmaxf(jmax, vj);
+    }
+    const float E = fmaxf(imax - imin, jmax - jmin);
+    if (ok && E <= 6.0f) {
+      const float pad = 1.01f + pad_coef * E * E;
+      const int i0 = max((int)ceilf(imin - pad - 0.5f), 0), i1 = min((int)floorf(imax + pad + 0.5f), nx - 1);
+      const int j0 = max((int)ceilf(jmin - pad - 0.5f), 0), j1 = min((int)floorf(jmax + pad + 0.5f), ny - 1);
+      bool over = false;
+      for (int j = j0; j <= j1 && !over; ++j)
+        for (int i = i0; i <= i1; ++i) {
+          if (!candidate(i, j)) continue;
+          if (found == CAND_CAP) {
+            over = true;
+            break;
+          }
+          tmp_dst[c * CAND_CAP + found] = (int32_t)((int64_t)j * nx + i);
+          ++found;
+        }
+      if (!over) {
+        cnt_src[c] = found;
+        return;
+      }
+      cnt_src[c] = CAND_CAP + 1;
+      ovf[atomicAdd(n_ovf, 1)] = (int32_t)c;
+      return;
+    }
+  }
   int stack[CONS_STACK];
   // Seeds of the depth-first walk.  MODE 0: the root.  Cooperative modes: the workgroup first expands the pyramid
   // breadth-first in LDS (one node per thread and level) down to 8 x 8-cell nodes, then every thread walks its share.
@@ -140,34 +210,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
       int i1 = min(i0 + MPG_PYR_B0, nx), j1 = min(j0 + MPG_PYR_B0, ny);
       for (int j = j0; j < j1; ++j)
         for (int i = i0; i < i1; ++i) {
-          // bounding sphere of the destination cell (k_cell_areas) against the source polygon's padded box: 4 loads decide
-          // most candidates of a 4 x 4 leaf block before the 12 corner coordinates are touched
-          const int64_t pc = (int64_t)j * nx + i;
-          {
-            const double4 sph = *reinterpret_cast<const double4 *>(qsph + 4 * pc);   // one 32-byte record per cell: one line, not four
-            double sx = sph.x, sy = sph.y, sz = sph.z, r2 = sph.w;
-            double ddx = fmax(fmax(lo[0] - sx, sx - hi[0]), 0.0), ddy = fmax(fmax(lo[1] - sy, sy - hi[1]), 0.0),
-                   ddz = fmax(fmax(lo[2] - sz, sz - hi[2]), 0.0);
-            if (ddx * ddx + ddy * ddy + ddz * ddz > r2) continue;
-          }
-          int64_t k00 = (int64_t)j * nxc + i;
-          dv3 q[4] = {dv3{qx[k00], qy[k00], qz[k00]}, dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
-                      dv3{qx[k00 + nxc + 1], qy[k00 + nxc + 1], qz[k00 + nxc + 1]}, dv3{qx[k00 + nxc], qy[k00 + nxc], qz[k00 + nxc]}};
-          double ql[3] = {2, 2, 2}, qh[3] = {-2, -2, -2}, qe2 = 0.0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            ql[0] = fmin(ql[0], q[k].x); qh[0] = fmax(qh[0], q[k].x);
-            ql[1] = fmin(ql[1], q[k].y); qh[1] = fmax(qh[1], q[k].y);
-            ql[2] = fmin(ql[2], q[k].z); qh[2] = fmax(qh[2], q[k].z);
-            dv3 d = q[k] - q[0];
-            qe2 = fmax(qe2, dot3(d, d));
-          }
-          double qp = 2.0 * qe2 + 1e-9;
-          if (ql[0] - qp > hi[0] || qh[0] + qp < lo[0] || ql[1] - qp > hi[1] || qh[1] + qp < lo[1] || ql[2] - qp > hi[2] || qh[2] + qp < lo[2]) continue;
-          int64_t p = (int64_t)j * nx + i;
-          double aq = qarea[p];   // signed area of the destination quad, computed once per grid (k_cell_areas)
-          if (aq < 0.0) { dv3 t = q[1]; q[1] = q[3]; q[3] = t; aq = -aq; }
-          if (!(aq > 0.0)) continue;
+          if (!candidate(i, j)) continue;
+          const int64_t p = (int64_t)j * nx + i;
           if (MODE == 3) {   // candidate pass: the pair (c, p) is clipped later by k_conserve_clip_pairs, one thread per PAIR
             if (found == CAND_CAP) {
               cnt_src[c] = CAND_CAP + 1;
@@ -443,10 +487,20 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
   unsigned nb = (unsigned)((nC + 127) / 128);
   PyramidView pv = mpg_pyr_view(g->cellpyr);
+  // a grid built from its projection: the vertices' places in its index space (one inverse projection per vertex, shared by the
+  // three cells around it) give every polygon its candidate cells in O(1); "store_boxes" 0 keeps the pyramid walk (A/B)
+  TmpBuf<float> vij;
+  const float *vijp = nullptr;
+  if (mpg_grid_has_inverse(g) && mpg_store_boxes() && m->vwn > 0) {
+    if ((rc = vij.alloc(2 * (size_t)m->vwn, s))) return rc;
+    if ((rc = mpg_k_points_ij(g, m->vwn, m->vert.x.p, m->vert.y.p, m->vert.z.p, vij.p, s))) return rc;
+    vijp = vij.p - 2 * m->vw0;   // indexed with global vertex ids, like vx / vy / vz
+  }
   k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
-                                        qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr);
+                                        qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
+                                        (float)mpg_grid_box_pad_coef(g));
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
   MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -454,7 +508,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
     k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr);
+                                                       nullptr, nullptr, nullptr, 0.f);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
   size_t tmp_bytes = 0, b2 = 0;
@@ -487,7 +541,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (novf > 0)
     k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
-                                                       pair_c.p, pair_p.p);
+                                                       pair_c.p, pair_p.p, nullptr, 0.f);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12

@@ -107,6 +107,70 @@ __device__ __forceinline__ double map_factor(const ProjDev &p, double lat) {
   return sin(colat0) / sin(colat) * pow(tan(colat / 2.0) / tan(colat0 / 2.0), cos(colat0));
 }
 
+// ---- the inverse: where on the grid does a point of the sphere fall?  (round 4) --------------------------------------------
+// latlon_to_ij for the two projections the BASELINE configurations use (llij_lc, module_map_utils.F90:1236-1290; llij_latlon,
+// :1365-1392), in the 0-based CENTER index space (projection coordinate - 1).  The Stores use it to find the handful of target
+// points around a source triangle / polygon directly instead of descending ten levels of the box pyramid; it only has to be
+// good to a fraction of a grid length (the callers pad their boxes and test every candidate point exactly as before).
+// Not usable -> NaN: within 1 degree of the Lambert pole or beyond 60 degrees into the other hemisphere; poleward of 75
+// degrees on a lat-lon grid (great circles bend too much in index space there).
+__global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, float *__restrict__ ij) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const double lat = asin(fmin(fmax(z[q], -1.0), 1.0)) * TG_DEG_PER_RAD, lon = atan2(y[q], x[q]) * TG_DEG_PER_RAD;
+  double i = NAN, j = NAN;
+  if (p.code == MPG_PROJ_LC) {
+    if (p.hemi * lat < 89.0 && p.hemi * lat > -60.0) {
+      double dl = lon - p.stdlon;
+      if (dl > 180.0) dl -= 360.0;
+      if (dl < -180.0) dl += 360.0;
+      const double rm = p.rebydx * cos(p.truelat1 * TG_RAD_PER_DEG) / p.cone *
+                        pow(tan((90.0 * p.hemi - lat) * TG_RAD_PER_DEG / 2.0) / tan((90.0 * p.hemi - p.truelat1) * TG_RAD_PER_DEG / 2.0), p.cone);
+      const double arg = p.cone * (dl * TG_RAD_PER_DEG);
+      i = p.hemi * (p.polei + p.hemi * rm * sin(arg));
+      j = p.hemi * (p.polej - rm * cos(arg));
+    }
+  } else if (p.code == MPG_PROJ_LATLON) {
+    if (fabs(lat) < 75.0) {
+      i = (lon - p.lon1) / p.loninc + p.knowni;
+      j = (lat - p.lat1) / p.latinc + p.knownj;
+      const double span = (double)(p.nxmax - p.nxmin + 1);
+      if (i < p.nxmin - 0.5) i += span;
+      if (i >= p.nxmax + 0.5) i -= span;
+    }
+  }
+  ij[2 * q] = (float)(i - 1.0);
+  ij[2 * q + 1] = (float)(j - 1.0 - (double)row0);
+}
+
+bool mpg_grid_has_inverse(const mpg_grid_s *g) { return g->has_inverse && (g->proj.code == MPG_PROJ_LC || g->proj.code == MPG_PROJ_LATLON); }
+
+int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s) {
+  if (n > 0) k_points_ij<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->proj, g->proj_row0, n, x, y, z, ij);
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+// does the inverse projection put the grid's own CENTER points where they are?  A sample of up to 4096 of them; bad += points
+// that land more than 0.02 index units off (points in the zones where the inverse is not used are skipped)
+__global__ __launch_bounds__(256) void k_check_inverse(int nx, int ny, int64_t step, const float *__restrict__ ij, int32_t *__restrict__ bad) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, p = k * step;
+  if (p >= (int64_t)nx * ny) return;
+  const float i = ij[2 * k], j = ij[2 * k + 1];
+  if (i != i || j != j) return;
+  if (fabsf(i - (float)(p % nx)) > 0.02f || fabsf(j - (float)(p / nx)) > 0.02f) atomicAdd(bad, 1);
+}
+
+// How far the image of a figure can bulge out of the index-space box of its vertices, per squared index extent E^2: a
+// great-circle arc L grid lengths long bends by ~ L^2 * (grid length / earth radius) / 8 * (a factor below 1 from the map
+// scale's gradient) on the conformal Lambert map -- the coefficient below is four times that; on the lat-lon grid (equatorward
+// of 75 degrees, extents of a few points) the callers' constant pad of one index unit covers it.
+double mpg_grid_box_pad_coef(const mpg_grid_s *g) {
+  if (g->proj.code == MPG_PROJ_LC) return 0.5 / g->proj.rebydx;
+  return 0.25 * fmax(fabs(g->proj.loninc), fabs(g->proj.latinc)) * TG_RAD_PER_DEG;
+}
+
 // stagger: MPG_STAGGERLOC_*; snx x sny points of that stagger
 __global__ __launch_bounds__(256) void k_target_points(ProjDev p, int stagger, int snx, int sny, double *__restrict__ lon,
                                                        double *__restrict__ lat, double *__restrict__ x, double *__restrict__ y,
@@ -248,6 +312,9 @@ int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s) {
   if (rc) return rc;
   g->from_proj = true;
   g->proj_code = p.code;
+  g->proj = p;
+  g->has_inverse = true;
+  g->proj_row0 = 0;
   for (int st = 0; st < 4; ++st) {
     int64_t n = (int64_t)g->snx[st] * g->sny[st];
     if ((rc = g->pts[st].alloc(n)) || (rc = g->lon[st].alloc(n)) || (rc = g->lat[st].alloc(n))) return rc;
@@ -272,3 +339,46 @@ int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s) {
 
 // mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
 const void *mpg_anchor_k_target_grid() { return (const void *)k_target_points; }
+
+// mpg_grid_attach_proj: a grid made from coordinate ARRAYS (mpg_grid_create) is told which projection those arrays came from
+// -- rows row0 .. of that projection's grid, e.g. a rank's block of target rows -- so that the Stores can use the inverse
+// projection as their candidate search.  The claim is CHECKED: a sample of the grid's own CENTER points must land on their own
+// indices; a projection that does not fit is refused (a wrong one would make the Stores miss candidates).
+__global__ __launch_bounds__(256) void k_sample_points(int64_t n, int64_t step, const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ z, double *__restrict__ sx, double *__restrict__ sy,
+                                                       double *__restrict__ sz) {
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k * step >= n) return;
+  sx[k] = x[k * step];
+  sy[k] = y[k * step];
+  sz[k] = z[k * step];
+}
+int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t s) {
+  ProjDev p;
+  int rc = derive(proj, &p);
+  if (rc) return rc;
+  if (p.code != MPG_PROJ_LC && p.code != MPG_PROJ_LATLON) return MPG_SUCCESS;   // no inverse here for it: the grid stays on the pyramid
+  const int64_t n = (int64_t)g->nx * g->ny, step = n > 4096 ? n / 4096 : 1, ns = (n + step - 1) / step;
+  const PointSet &c = g->pts[MPG_STAGGERLOC_CENTER];
+  TmpBuf<double> sp;
+  TmpBuf<float> ij;
+  TmpBuf<int32_t> bad;
+  if ((rc = sp.alloc(3 * (size_t)ns, s)) || (rc = ij.alloc(2 * (size_t)ns, s)) || (rc = bad.alloc(1, s))) return rc;
+  MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
+  k_sample_points<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(n, step, c.x.p, c.y.p, c.z.p, sp.p, sp.p + ns, sp.p + 2 * ns);
+  k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
+  k_check_inverse<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(g->nx, g->ny, step, ij.p, bad.p);
+  MPG_HIP(hipGetLastError());
+  int32_t hbad = 0;
+  MPG_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  if (hbad) {
+    mpg_set_error("mpg_grid_attach_proj: the projection does not reproduce the grid's own points (%d of %lld sampled CENTER points land elsewhere)",
+                  hbad, (long long)ns);
+    return MPG_ERR_INVALID_ARG;
+  }
+  g->proj = p;
+  g->proj_row0 = row0;
+  g->has_inverse = true;
+  return MPG_SUCCESS;
+}

@@ -446,6 +446,13 @@ int mpg_grid_create_proj(const mpg_proj *proj, int nx, int ny, int periodic_i, m
   return MPG_SUCCESS;
 }
 
+int mpg_grid_attach_proj(mpg_grid g, const mpg_proj *proj, int row0) {
+  MPG_CHECK_INIT();
+  MPG_ARG(g && proj, "mpg_grid_attach_proj: NULL argument");
+  MPG_ARG(row0 >= 0, "mpg_grid_attach_proj: row0 must be >= 0");
+  return mpg_k_attach_proj(g, proj, row0, g_stream);
+}
+
 #define MPG_PROJ_GRID(g, what)                                                                  \
   do {                                                                                          \
     MPG_ARG(g, what ": NULL grid");                                                             \

@@ -229,6 +229,14 @@ struct mpg_mesh_s {
   const double *vz_g() const { return vert.z.p - vw0; }
 };
 
+// projection constants handed to the kernels by value (proj_info subset, module_map_utils.F90:140-192)
+struct ProjDev {
+  int code;
+  double hemi, truelat1, truelat2, stdlon, cone, polei, polej, rebydx, lat1, lon1, knowni, knownj, latinc, loninc;
+  double rsw, dlon;   // PROJ_PS / PROJ_MERC (set_ps, set_merc)
+  int nxmin, nxmax;
+};
+
 struct mpg_grid_s {
   int nx = 0, ny = 0, periodic = 0;
   PointSet pts[4];  // indexed by MPG_STAGGERLOC_*
@@ -238,17 +246,13 @@ struct mpg_grid_s {
   // grids created from a projection (mpg_grid_create_proj) also keep what the output file needs
   bool from_proj = false;
   int proj_code = 0;
+  ProjDev proj;                   // the projection itself: Stores on such a grid find a triangle's / a cell's target points through its
+                                  // inverse in O(1) (k_target_grid.hip mpg_k_points_ij) instead of descending the box pyramid
+  bool has_inverse = false;       // `proj` is set and checked against the grid's own points (mpg_grid_create_proj, mpg_grid_attach_proj)
+  int proj_row0 = 0;              // the grid's first row is row proj_row0 of the projection's grid (a rank's row block)
   DevBuf<double> lon[4], lat[4];  // degrees, per stagger
   DevBuf<double> mapfac[3];       // CENTER, EDGE1, EDGE2
   DevBuf<double> cosa, sina;      // CENTER, PROJ_LC only
-};
-
-// projection constants handed to the kernels by value (proj_info subset, module_map_utils.F90:140-192)
-struct ProjDev {
-  int code;
-  double hemi, truelat1, truelat2, stdlon, cone, polei, polej, rebydx, lat1, lon1, knowni, knownj, latinc, loninc;
-  double rsw, dlon;   // PROJ_PS / PROJ_MERC (set_ps, set_merc)
-  int nxmin, nxmax;
 };
 
 enum { MPG_KIND_FIXED = 0, MPG_KIND_CSR = 1 };
@@ -313,6 +317,14 @@ void mpg_fileio_release();  // mpg_fileio.hip: staging buffers / streams of mpg_
 int mpg_k_mesh_coords(int64_t n, const double *lon_rad, const double *lat_rad, PointSet &out, hipStream_t s);
 int mpg_k_grid_coords(int64_t n, const double *lon_deg, const double *lat_deg, PointSet &out, hipStream_t s);
 int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s);
+// (i, j) of n points on the unit sphere in the 0-based CENTER index space of a projection-built grid, float2 per point; NaN where
+// the inverse projection is not safely usable (near its pole / cut, other projections): callers fall back to the pyramid there.
+// false: this grid has no usable inverse at all (made from arrays, or a projection without one here)
+bool mpg_grid_has_inverse(const mpg_grid_s *g);
+int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t s);
+int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s);
+// safety margin (index units) around the index-space box of a figure whose vertices span `extent` index units
+double mpg_grid_box_pad_coef(const mpg_grid_s *g);
 int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s);
 int mpg_k_tri_scatter(mpg_mesh_s *m, int32_t *cnt, hipStream_t s);
 int mpg_k_tri_canon(mpg_mesh_s *m, const int32_t *cnt, hipStream_t s);
@@ -363,6 +375,7 @@ int mpg_k_post_ptop_parts(const double *src, int nlev, int64_t P, double *vmax_h
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);
+int mpg_store_boxes();         // "store_boxes" knob: 1 (default) index-space candidate boxes on projection-built grids, 0 pyramid walk only
 int mpg_bilinear_linetype();   // "bilinear_linetype" knob: 0 ray from the centre (default), 1 along the triangle's normal
 int mpg_nearest_variant();
 void mpg_set_nearest_variant(int v);

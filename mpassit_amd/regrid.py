@@ -131,19 +131,33 @@ class Grid:
                                        *[_ptr(a) for a in arrs], C.byref(self._h)))
 
     @classmethod
-    def from_target(cls, g, rows=None):
+    def from_target(cls, g, rows=None, attach_proj=True):
         """From target_grid.TargetGrid; rows=(j0, j1) keeps only mass rows [j0, j1) (multi-GPU row shard,
         mirrors the reference's regDecomp=(/1,npets/) split along j, model_grid.F90:693).  A global grid
         (is_regional=.false.) is periodic in i with monopole caps (model_grid.F90:685-694); a row block keeps only
         the caps it touches."""
         flags = 0 if g.is_regional else L.GRID_PERIODIC_I
         if rows is None:
-            return cls(g.lon, g.lat, g.lon_c, g.lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v, periodic=flags)
-        j0, j1 = rows
-        if flags:
-            flags |= (L.GRID_NO_SOUTH_POLE if j0 > 0 else 0) | (L.GRID_NO_NORTH_POLE if j1 < g.ny else 0)
-        return cls(g.lon[j0:j1], g.lat[j0:j1], g.lon_c[j0:j1 + 1], g.lat_c[j0:j1 + 1], g.lon_u[j0:j1], g.lat_u[j0:j1],
-                   g.lon_v[j0:j1 + 1], g.lat_v[j0:j1 + 1], periodic=flags)
+            self = cls(g.lon, g.lat, g.lon_c, g.lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v, periodic=flags)
+            j0 = 0
+        else:
+            j0, j1 = rows
+            if flags:
+                flags |= (L.GRID_NO_SOUTH_POLE if j0 > 0 else 0) | (L.GRID_NO_NORTH_POLE if j1 < g.ny else 0)
+            self = cls(g.lon[j0:j1], g.lat[j0:j1], g.lon_c[j0:j1 + 1], g.lat_c[j0:j1 + 1], g.lon_u[j0:j1], g.lat_u[j0:j1],
+                       g.lon_v[j0:j1 + 1], g.lat_v[j0:j1 + 1], periodic=flags)
+        if attach_proj and getattr(g, "proj", None) is not None:
+            try:                               # the arrays came from this projection: the Stores may search through its inverse.
+                self.attach_proj(g.proj, j0)   # The library checks the claim on the grid's own points; a projection that does not
+            except L.MpgError:                 # reproduce them (a grid read from a file, whose Proj is incomplete) is refused and
+                pass                           # the grid keeps the pyramid search
+        return self
+
+    def attach_proj(self, p, row0=0):
+        """mpg_grid_attach_proj: the coordinate arrays of this grid are rows row0 .. of projection `p` (target_grid.Proj)."""
+        c = _Proj(code=p.code, known_lat=p.lat1, known_lon=p.lon1, known_x=p.knowni, known_y=p.knownj, dx_m=p.dx,
+                  stand_lon=p.stdlon, truelat1=p.truelat1, truelat2=p.truelat2, dlat_deg=p.latinc, dlon_deg=p.loninc)
+        check(L.load().mpg_grid_attach_proj(self._h, C.byref(c), C.c_int(int(row0))))
 
     @classmethod
     def from_proj(cls, g, fill_target=True):

@@ -1,0 +1,125 @@
+"""O(1) candidate boxes of the Stores on projection-built grids (mpg_grid_create_proj): a source triangle's / polygon's target
+points are found through the inverse projection instead of the box pyramid.  Same per-point / per-cell tests on a superset
+of the candidates, so the owners, the weights and the conservative matrix must be IDENTICAL to the pyramid walk's
+("store_boxes" 0) -- on Lambert and lat-lon grids, CENTER and staggered points, element- and node-located sources, a mesh
+much coarser than the grid (every triangle exceeds the box limit and takes the walk), a global grid with its seam and the
+caps poleward of 75 degrees (walk) -- and to the same grid built from coordinate ARRAYS, which has no inverse at all."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _stores(gpu_lib, R, mesh, grid, boxes, staggers=(0,), node=True, conserve=True):
+    gpu_lib.tune("store_boxes", boxes)
+    out = {}
+    try:
+        for st in staggers:
+            rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR, staggerloc=st)
+            out["bil%d" % st] = rh.weights()
+            rh.release()
+        if node:
+            rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)
+            out["node"] = rh.weights()
+            rh.release()
+        if conserve:
+            rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+            out["cons"] = rh.csr()
+            rh.release()
+    finally:
+        gpu_lib.tune("store_boxes", 1)
+    return out
+
+
+def _same(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        for x, y in zip(a[k], b[k]):
+            assert np.array_equal(x, y), k
+
+
+def _case(gpu_lib, m, tgt, **kw):
+    from mpassit_amd import regrid as R
+    res = []
+    for boxes in (1, 0):
+        mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(tgt, fill_target=False)      # fresh objects: nothing from the handle cache
+        res.append(_stores(gpu_lib, R, mesh, grid, boxes, **kw))
+        mesh.destroy()
+        grid.destroy()
+    _same(res[0], res[1])
+    return res[0]
+
+
+def test_lambert_grid_all_staggers_and_locations(gpu_lib):
+    from mpassit_amd import workloads
+    m, g, _, _ = workloads.workload("tiny")
+    got = _case(gpu_lib, m, g, staggers=(0, 1, 2))
+    assert (got["bil0"][0] >= 0).mean() > 0.9 and got["cons"][1].size > 0
+    # the same grid from coordinate arrays (no inverse: pyramid only) holds the same CENTER weights
+    from mpassit_amd import regrid as R
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    ref = _stores(gpu_lib, R, mesh, grid, 1, staggers=(0,), node=False)
+    mesh.destroy()
+    grid.destroy()
+    assert np.array_equal(ref["bil0"][0], got["bil0"][0])          # owners; the weights agree to the last bits of the coordinates
+    assert np.abs(ref["bil0"][1] - got["bil0"][1]).max() < 1e-9
+
+
+def test_regional_mesh_smaller_than_the_grid(gpu_lib, regional_case):
+    m, g = regional_case                                             # rim + unmapped strip: boxes clipped at the grid's edge
+    got = _case(gpu_lib, m, g)
+    assert (got["bil0"][0][:, 0] < 0).any()
+
+
+def test_global_latlon_grid_seam_and_polar_caps(gpu_lib):
+    from mpassit_amd import workloads
+    m, g, _, _ = workloads.workload("c5_small")                      # 40 962 cells -> 360 x 180 global lat-lon, periodic, poles
+    got = _case(gpu_lib, m, g, node=False)
+    assert (got["bil0"][0] >= 0).all()
+
+
+def test_mesh_much_coarser_than_the_grid(gpu_lib):
+    from mpassit_amd import synth, target_grid as tg
+    fine = tg.define_target_grid_params("lambert", 121, 81, dx=10000.0, dy=10000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5,
+                                        stand_lon=-97.5)
+    got = _case(gpu_lib, synth.icosahedral_mesh(3), fine, node=False)   # 480-km cells: every triangle spans > 6 index units
+    assert (got["bil0"][0] >= 0).all()
+    got = _case(gpu_lib, synth.icosahedral_mesh(6), fine, node=False)   # 60-km cells: boxes of up to 8 x 8 points, some over the limit
+    assert (got["bil0"][0] >= 0).all()
+
+
+def test_southern_lambert_and_two_true_latitudes(gpu_lib, global_mesh):
+    from mpassit_amd import target_grid as tg
+    for kw in (dict(ref_lat=-35.0, ref_lon=140.0, truelat1=-30.0, truelat2=-60.0, stand_lon=140.0),
+               dict(ref_lat=60.0, ref_lon=10.0, truelat1=30.0, truelat2=60.0, stand_lon=0.0)):
+        g = tg.define_target_grid_params("lambert", 101, 91, dx=40000.0, dy=40000.0, **kw)
+        got = _case(gpu_lib, global_mesh, g, node=False)
+        assert (got["bil0"][0] >= 0).all()
+
+
+def test_row_block_from_arrays_with_its_projection_attached(gpu_lib, regional_case):
+    """mpg_grid_attach_proj: a rank's block of target rows, made from coordinate arrays, is told its projection and row offset --
+    the Stores then search through the inverse.  Same weights as the pyramid search; a projection that does not fit the
+    arrays (wrong row offset, wrong grid length) is refused and changes nothing."""
+    from mpassit_amd import regrid as R, target_grid as tg
+    m, g = regional_case
+    rows = (17, 49)
+    res = []
+    for attach in (True, False):
+        mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g, rows=rows, attach_proj=attach)
+        res.append(_stores(gpu_lib, R, mesh, grid, 1, staggers=(0, 1, 2)))
+        mesh.destroy()
+        grid.destroy()
+    _same(res[0], res[1])
+    grid = R.Grid.from_target(g, rows=rows, attach_proj=False)
+    with pytest.raises(gpu_lib.MpgError, match="does not reproduce"):
+        grid.attach_proj(g.proj, rows[0] + 1)                       # one row off
+    other = tg.define_target_grid_params("lambert", g.nx + 1, g.ny + 1, dx=31000.0, dy=31000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
+                                         truelat2=38.5, stand_lon=-97.5)
+    with pytest.raises(gpu_lib.MpgError, match="does not reproduce"):
+        grid.attach_proj(other.proj, rows[0])                       # another grid length
+    grid.attach_proj(g.proj, rows[0])                               # the right one is accepted
+    mesh = R.Mesh.from_mpas(m)
+    _same(_stores(gpu_lib, R, mesh, grid, 1), {k: v for k, v in res[1].items() if k in ("bil0", "node", "cons")})
+    mesh.destroy()
+    grid.destroy()
