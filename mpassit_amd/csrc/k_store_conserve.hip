@@ -517,10 +517,10 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   TmpBuf<char> tmp;
   if ((rc = tmp.alloc((tmp_bytes > b2 ? tmp_bytes : b2) + 16, s))) return rc;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
+  // the pair count twice -- the int32 scan's last entry and a 64-bit sum (the scan could wrap more than once) -- in ONE round trip
   int32_t npairs = 0;
-  MPG_HIP(hipMemcpyAsync(&npairs, poff.p + nC, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MPG_HIP(hipStreamSynchronize(s));
-  {   // the int32 scan could wrap more than once: the pair count again as a 64-bit sum
+  long long total = 0;
+  {
     TmpBuf<long long> tot;
     TmpBuf<char> t2;
     size_t b3 = 0;
@@ -528,7 +528,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     MPG_HIP(rocprim::reduce(nullptr, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
     if ((rc = t2.alloc(b3 + 16, s))) return rc;
     MPG_HIP(rocprim::reduce((void *)t2.p, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
-    long long total = 0;
+    MPG_HIP(hipMemcpyAsync(&npairs, poff.p + nC, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MPG_HIP(hipMemcpyAsync(&total, tot.p, sizeof(total), hipMemcpyDeviceToHost, s));
     MPG_HIP(hipStreamSynchronize(s));
     if (npairs < 0 || total != (long long)npairs) {

@@ -265,6 +265,9 @@ contains
       call mpg_check(mpg_grid_get_coords(grid_h, MPG_STAGGERLOC_CORNER, lon_c, lat_c), "IN GridGetCoord")
       call mpg_check(mpg_grid_destroy(grid_h), "IN GridDestroy")
       call create_row_block_grid(lat_c, lon_c, grid_h)
+      ! the block's arrays are rows je_lo .. of this projection's grid: its Stores may search through the inverse projection
+      ! (the library checks the claim on the grid's own points)
+      call mpg_check(mpg_grid_attach_proj(grid_h, p, int(je_lo - 1, c_int)), "IN GridAttachProj")
     end if
   end subroutine define_target_grid_params
 

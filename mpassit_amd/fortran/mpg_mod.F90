@@ -328,6 +328,16 @@ module mpg
     end function mpg_handle_info
 
     !> Target grid straight from the projection (define_target_grid_params' host loops on the GPU, model_grid.F90:736-1038).
+    !> a grid made from coordinate arrays that are rows row0 .. of the grid `proj` describes (an image's row block): its Stores
+    !! search through the inverse projection; refused when the projection does not reproduce the grid's own points
+    function mpg_grid_attach_proj(grid, proj, row0) bind(C, name="mpg_grid_attach_proj") result(rc)
+      import :: c_int, c_ptr, mpg_proj
+      type(c_ptr), value :: grid
+      type(mpg_proj), intent(in) :: proj
+      integer(c_int), value :: row0
+      integer(c_int) :: rc
+    end function mpg_grid_attach_proj
+
     function mpg_grid_create_proj(proj, nx, ny, periodic_i, grid) bind(C, name="mpg_grid_create_proj") result(rc)
       import :: c_int, c_ptr, mpg_proj
       type(mpg_proj), intent(in) :: proj
