@@ -685,10 +685,12 @@ def cpu_baseline(sr, local_rows, nlev, seconds, m, g):
     tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
     o.bilinear_weights(cxyz, tri, o.lonlat_deg_to_xyz(g.lon, g.lat))
     store_s = time.perf_counter() - t0
-    return {"value": reps / el, "unit": "fields/s", "cores": cores, "kind": "port", "store_ms": store_s * 1e3,
-            "sample": "%d full 3-D fields (%d levels, all %d target points) through the oracle's OpenMP apply loop, "
-                      "weights taken from the GPU handle; store_ms = the oracle's bilinear RegridStore of the same mesh and grid, once; "
-                      "CPU restatement, not ESMF (ESMF unavailable)" % (reps, nlev, idx.shape[0])}
+    alg_field = nlev * 8.0 * (int(np.unique(idx[idx >= 0]).size) + idx.shape[0]) + idx.shape[0] * 36.0   # SURVEY s8(d), one float64 field
+    return {"value": reps / el, "unit": "fields/s", "cores": cores, "kind": "port", "GBs": round(alg_field * reps / el / 1e9, 1),
+            "store_ms": store_s * 1e3,
+            "sample": "%d full 3-D fields (%d levels, all %d target points) through the oracle's OpenMP apply loop (blocked by target "
+                      "tile), weights from the GPU handle; GBs = algorithmic bytes moved per second; store_ms = the oracle's bilinear "
+                      "RegridStore once; a CPU restatement, not ESMF (unavailable): do not read the ratio as a speed-up" % (reps, nlev, idx.shape[0])}
 
 
 if __name__ == "__main__":

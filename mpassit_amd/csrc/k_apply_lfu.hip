@@ -517,7 +517,9 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32,
 // Round 4 split the workgroup into producer waves (row loads -> a second slab) and consumer waves (combine + store), one
 // barrier per chunk, so that no wave's in-order counter sees both kinds: bit-identical and EQUAL in time (configuration 5
 // float32 6.545 against 6.517 ms, configuration 2 level; profiles/r04_lf_experiments.txt) -- the coupling of a wave's loads
-// and stores is not what holds this kernel back, and the form was not kept.
+// and stores is not what holds this kernel back, and the form was not kept.  Nor is occupancy: the float32 form holds 94 VGPRs
+// (two workgroups = 16 waves per CU); asked to fit 80 / 64 registers (three / four workgroups, no scratch) it ran 6.39 / 6.59
+// ms against 6.40-6.45.
 template <typename TS, typename TD, int NT, bool EPI, bool SWZ>
 __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w, const TS *__restrict__ src,

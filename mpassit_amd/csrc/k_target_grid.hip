@@ -144,7 +144,23 @@ __global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, int64_t 
   ij[2 * q + 1] = (float)(j - 1.0 - (double)row0);
 }
 
-bool mpg_grid_has_inverse(const mpg_grid_s *g) { return g->has_inverse && (g->proj.code == MPG_PROJ_LC || g->proj.code == MPG_PROJ_LATLON); }
+// The index-space search rests on small-angle geometry: a figure a few index units across must span a few degrees at most, and a
+// destination cell's own great-circle edges must stay inside its index band (the edge between two lat-lon corners 90 degrees
+// of longitude apart rises by several degrees in between).  Grids coarser than 2 degrees / 200 km per cell, or whose cells'
+// edges bulge by more than 0.05 index units at 75 degrees, keep the pyramid search: it makes no such assumption.
+bool mpg_grid_has_inverse(const mpg_grid_s *g) {
+  if (!g->has_inverse) return false;
+  const ProjDev &p = g->proj;
+  if (p.code == MPG_PROJ_LC) return TG_EARTH_RADIUS_M / p.rebydx <= 200e3;
+  if (p.code == MPG_PROJ_LATLON) {
+    const double dlon = fabs(p.loninc), dlat = fabs(p.latinc);
+    if (dlon > 2.0 || dlat > 2.0) return false;
+    const double phi = 75.0 * TG_RAD_PER_DEG;
+    const double bulge = (atan(tan(phi) / cos(0.5 * dlon * TG_RAD_PER_DEG)) - phi) * TG_DEG_PER_RAD / dlat;
+    return bulge <= 0.05;
+  }
+  return false;
+}
 
 int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s) {
   if (n > 0) k_points_ij<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->proj, g->proj_row0, n, x, y, z, ij);
