@@ -367,11 +367,165 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
   return MPG_SUCCESS;
 }
 
+// ---- nearest cell through the grid's own index space (round 4) --------------------------------------------------------------
+// On a grid that knows its projection every cell centre has a place (i, j) in the grid's index space (k_points_ij,
+// k_target_grid.hip); binned there, the cells around a target point are the contents of the few bins around the point's OWN
+// index -- no tree, no sort.  Exactness does not rest on the map being isometric, only on a lower bound h of the chord length
+// of one index unit (mpg_grid_min_index_chord: the map factor's maximum over the grid's latitudes and a margin): after the
+// bins within r rings have been looked at, every cell not looked at is at least r * NB_BIN index units away, i.e. at least
+// 0.8 * r * NB_BIN * h on the sphere, so a best distance below that is final -- ties included (an equally near cell is inside
+// the bound and was compared: lowest id wins, with the distance arithmetic of the BVH search and the oracle).  A point that
+// finds nothing final within NB_RINGS rings (the grid sticks far out of the mesh), a cell whose index is not usable (NaN: the
+// projection's pole / cut / far side, polar caps of a lat-lon grid) or a grid without a usable bound send the whole Store to
+// the BVH search below: never a different answer, only a slower one.
+#define NB_BIN 2       // index units (grid points) per bin side
+#define NB_RINGS 4     // rings of bins a point may look at; the bin grid extends that far beyond the grid's points
+__global__ __launch_bounds__(256) void k_nb_count(int64_t n, const float *__restrict__ ij, float di, float dj, int nbx, int nby,
+                                                  int32_t *__restrict__ cnt, int32_t *__restrict__ flags) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const float u = ij[2 * c] + di + (float)(NB_RINGS * NB_BIN), v = ij[2 * c + 1] + dj + (float)(NB_RINGS * NB_BIN);
+  if (!(u == u) || !(v == v)) {   // no usable index: the search cannot vouch for this cell
+    atomicOr(flags, 1);
+    return;
+  }
+  const int bx = (int)floorf(u / NB_BIN), by = (int)floorf(v / NB_BIN);
+  if (u < 0.f || v < 0.f || bx >= nbx || by >= nby) return;   // beyond the margin: further than any accepted answer
+  atomicAdd(&cnt[(int64_t)by * nbx + bx], 1);
+}
+__global__ __launch_bounds__(256) void k_nb_fill(int64_t n, int64_t first, const float *__restrict__ ij, float di, float dj, int nbx, int nby,
+                                                 const int32_t *__restrict__ off, int32_t *__restrict__ cur, int32_t *__restrict__ ids) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const float u = ij[2 * c] + di + (float)(NB_RINGS * NB_BIN), v = ij[2 * c + 1] + dj + (float)(NB_RINGS * NB_BIN);
+  if (!(u == u) || !(v == v) || u < 0.f || v < 0.f) return;
+  const int bx = (int)floorf(u / NB_BIN), by = (int)floorf(v / NB_BIN);
+  if (bx >= nbx || by >= nby) return;
+  const int64_t b = (int64_t)by * nbx + bx;
+  ids[off[b] + atomicAdd(&cur[b], 1)] = (int32_t)(first + c);
+}
+// one thread per target point; h = chord length bound of one index unit (already times the safety factor)
+__global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double *__restrict__ px, const double *__restrict__ py,
+                                                  const double *__restrict__ pz, const double *__restrict__ cx, const double *__restrict__ cy,
+                                                  const double *__restrict__ cz, int nbx, int nby, const int32_t *__restrict__ off,
+                                                  const int32_t *__restrict__ ids, double h, int32_t *__restrict__ out, int32_t *__restrict__ flags) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= (int64_t)npx * npy) return;
+  const int i = (int)(p % npx), j = (int)(p / npx);
+  const double X = px[p], Y = py[p], Z = pz[p];
+  const int bx = (i + NB_RINGS * NB_BIN) / NB_BIN, by = (j + NB_RINGS * NB_BIN) / NB_BIN;
+  double best = INFINITY;
+  int32_t best_id = 0x7fffffff;
+  bool done = false;
+  for (int r = 0; r <= NB_RINGS && !done; ++r) {
+    // the bins of ring r: the square of half-width r without the square of half-width r - 1
+    for (int yy = by - r; yy <= by + r; ++yy) {
+      if (yy < 0 || yy >= nby) continue;
+      const bool edge_row = yy == by - r || yy == by + r;
+      for (int xx = bx - r; xx <= bx + r; xx += (edge_row || r == 0) ? 1 : 2 * r) {
+        if (xx < 0 || xx >= nbx) continue;
+        const int64_t b = (int64_t)yy * nbx + xx;
+        for (int32_t k = off[b]; k < off[b + 1]; ++k) {
+          const int32_t id = ids[k];
+          const double d = dist2_nofma(X, Y, Z, cx[id], cy[id], cz[id]);
+          if (d < best || (d == best && id < best_id)) {
+            best = d;
+            best_id = id;
+          }
+        }
+      }
+    }
+    // every cell not seen so far is at least (r * NB_BIN) index units from the point (it sits in its own bin: the distance to the
+    // edge of the block of rings 0 .. r is at least r bins), less the rounding of the float32 indices
+    const double lim = ((double)(r * NB_BIN) - 2e-3) * h;
+    done = r > 0 && best <= lim * lim;
+  }
+  if (!done) atomicOr(flags, 2);
+  out[p] = best_id;
+}
+__global__ __launch_bounds__(256) void k_zrange(int64_t n, const double *__restrict__ z, unsigned long long *__restrict__ out) {
+  __shared__ double slo[4], shi[4];
+  double lo = 2.0, hi = -2.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    lo = fmin(lo, z[i]);
+    hi = fmax(hi, z[i]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, o));
+    hi = fmax(hi, __shfl_down(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {   // z + 2 is positive: its bit pattern orders like the value
+    atomicMin(out, (unsigned long long)__double_as_longlong(fmin(fmin(slo[0], slo[1]), fmin(slo[2], slo[3])) + 2.0));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(fmax(fmax(shi[0], shi[1]), fmax(shi[2], shi[3])) + 2.0));
+  }
+}
+
+// -> *used = true when h->idx holds the exact answer; false: nothing usable came out, take the BVH search
+static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, int npy, const PointSet &pts, mpg_handle_s *h, hipStream_t s,
+                           bool *used) {
+  *used = false;
+  int rc;
+  const int64_t P = (int64_t)npx * npy, n = m->cwn, first = m->cw0;
+  if (!mpg_grid_has_inverse(g) || !mpg_store_boxes() || n == 0 || stagger == MPG_STAGGERLOC_CORNER) return MPG_SUCCESS;
+  if (g->periodic & MPG_GRID_PERIODIC_I) return MPG_SUCCESS;   // a global lat-lon grid: its polar cells have no usable index, do not even try
+  const int nbx = (npx + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN, nby = (npy + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN;
+  const int64_t nbins = (int64_t)nbx * nby;
+  if (nbins + 1 >= 0x7fffffff) return MPG_SUCCESS;
+  TmpBuf<float> ij;
+  TmpBuf<int32_t> cnt, off, ids, flags;
+  TmpBuf<unsigned long long> zr;
+  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = cnt.alloc((size_t)nbins + 1, s)) || (rc = off.alloc((size_t)nbins + 1, s)) ||
+      (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(1, s)) || (rc = zr.alloc(2, s)))
+    return rc;
+  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
+  MPG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t), s));
+  MPG_HIP(hipMemsetAsync(zr.p, 0xff, sizeof(unsigned long long), s));
+  MPG_HIP(hipMemsetAsync(zr.p + 1, 0, sizeof(unsigned long long), s));
+  if ((rc = mpg_k_points_ij(g, n, m->cell.x.p + first, m->cell.y.p + first, m->cell.z.p + first, ij.p, s))) return rc;
+  const float di = stagger == MPG_STAGGERLOC_EDGE1 ? 0.5f : 0.f, dj = stagger == MPG_STAGGERLOC_EDGE2 ? 0.5f : 0.f;
+  const unsigned nbc = (unsigned)((n + 255) / 256);
+  k_nb_count<<<nbc, 256, 0, s>>>(n, ij.p, di, dj, nbx, nby, cnt.p, flags.p);
+  k_zrange<<<(unsigned)std::min<int64_t>((P + 255) / 256, 1024), 256, 0, s>>>(P, pts.z.p, zr.p);
+  size_t tmp_bytes = 0;
+  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.p, off.p, (int32_t)0, (size_t)nbins + 1, rocprim::plus<int32_t>(), s));
+  TmpBuf<char> tmp;
+  if ((rc = tmp.alloc(tmp_bytes + 16, s))) return rc;
+  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, cnt.p, off.p, (int32_t)0, (size_t)nbins + 1, rocprim::plus<int32_t>(), s));
+  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));   // now the fill cursors
+  k_nb_fill<<<nbc, 256, 0, s>>>(n, first, ij.p, di, dj, nbx, nby, off.p, cnt.p, ids.p);
+  MPG_HIP(hipGetLastError());
+  // the bound needs the latitudes the grid spans (one small read-back; the count pass's verdict on unusable cells comes with it)
+  unsigned long long hz[2];
+  int32_t hflags = 0;
+  MPG_HIP(hipMemcpyAsync(hz, zr.p, sizeof(hz), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipMemcpyAsync(&hflags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  if (hflags & 1) return MPG_SUCCESS;   // a cell without a usable index
+  double zlo, zhi;
+  memcpy(&zlo, &hz[0], sizeof(double));
+  memcpy(&zhi, &hz[1], sizeof(double));
+  const double r2d = 180.0 / 3.141592653589793;
+  const double lat_lo = asin(fmin(fmax(zlo - 2.0, -1.0), 1.0)) * r2d, lat_hi = asin(fmin(fmax(zhi - 2.0, -1.0), 1.0)) * r2d;
+  const double hmin = 0.8 * mpg_grid_min_index_chord(g, lat_lo, lat_hi, (double)(NB_RINGS * NB_BIN + 1));
+  if (!(hmin > 0.0)) return MPG_SUCCESS;
+  k_nb_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nbx, nby, off.p,
+                                                        ids.p, hmin, h->idx.p, flags.p);
+  MPG_HIP(hipGetLastError());
+  MPG_HIP(hipMemcpyAsync(&hflags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  *used = !(hflags & 2);   // a point that could not be settled within its rings: the BVH search answers for all
+  return MPG_SUCCESS;
+}
+
 int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s *h, hipStream_t s) {
   int rc;
   // a mesh cut to this grid (mpg_mesh_create_window) searches the cells of its window first
   const bool windowed = m->geo_grid != nullptr && m->cwn > 0 && m->cwn < m->nCells;
-  if ((rc = mpg_k_build_bvh(m, s, !windowed))) return rc;
   PointSet &pts = g->pts[stagger];
   int npx = g->snx[stagger], npy = g->sny[stagger];
   int64_t P = (int64_t)npx * npy;
@@ -387,6 +541,12 @@ int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s 
   h->ny_dst = npy;
   h->nnz = P;
   if ((rc = h->idx.alloc((size_t)P))) return rc;
+  {   // a grid that knows its projection: through its index space, when that search can vouch for its answer
+    bool used = false;
+    if ((rc = nearest_by_bins(m, g, stagger, npx, npy, pts, h, s, &used))) return rc;
+    if (used) return MPG_SUCCESS;
+  }
+  if ((rc = mpg_k_build_bvh(m, s, !windowed))) return rc;
   if ((rc = nearest_search(m, npx, npy, pts, h, s))) return rc;
   if (!m->bvh_whole) {
     // Exact?  Every cell that is NOT a site lies further than geo_margin from every point of the grid (that is how the window

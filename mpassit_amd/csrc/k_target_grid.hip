@@ -88,7 +88,7 @@ __device__ __forceinline__ void ij_to_latlon(const ProjDev &p, double i, double 
   }
 }
 
-__device__ __forceinline__ double map_factor(const ProjDev &p, double lat) {
+__host__ __device__ __forceinline__ double map_factor(const ProjDev &p, double lat) {
 #pragma clang fp contract(off)
   if (p.code == MPG_PROJ_PS)       // model_grid.F90:2279-2286
     return (1.0 + sin(TG_RAD_PER_DEG * fabs(p.truelat1))) / (1.0 + sin(TG_RAD_PER_DEG * copysign(1.0, p.truelat1) * lat));
@@ -176,6 +176,29 @@ __global__ __launch_bounds__(256) void k_check_inverse(int nx, int ny, int64_t s
   const float i = ij[2 * k], j = ij[2 * k + 1];
   if (i != i || j != j) return;
   if (fabsf(i - (float)(p % nx)) > 0.02f || fabsf(j - (float)(p / nx)) > 0.02f) atomicAdd(bad, 1);
+}
+
+// Lower bound of the chord length (unit sphere) of ONE index unit of the grid, anywhere within `margin` index units of the
+// latitudes lat_lo .. lat_hi (degrees) the grid's points span: the nearest-neighbour search in index space turns "every cell
+// not looked at is at least r index units away" into "... at least r * h away on the sphere" with it (k_store_nearest.hip).
+// Lambert: ground length per index unit = dx / m(lat), m the map factor (convex in latitude: its maximum over an interval
+// sits at an end); lat-lon: min(dlat, dlon * cos(lat)) at the poleward end, capped at the 75 degrees beyond which the
+// inverse is not used.  0: no bound (the caller keeps the BVH search).
+double mpg_grid_min_index_chord(const mpg_grid_s *g, double lat_lo, double lat_hi, double margin) {
+  const ProjDev &p = g->proj;
+  if (p.code == MPG_PROJ_LC) {
+    const double dlat = margin / p.rebydx * TG_DEG_PER_RAD * 1.5;   // index units -> degrees of latitude, generously
+    const double a = fmax(lat_lo - dlat, -89.0), b = fmin(lat_hi + dlat, 89.0);
+    const double m = fmax(map_factor(p, a), map_factor(p, b));
+    if (!(m > 0.0) || !(m < 50.0)) return 0.0;
+    return 1.0 / (p.rebydx * m);
+  }
+  if (p.code == MPG_PROJ_LATLON) {
+    const double dlat = fabs(p.latinc), dlon = fabs(p.loninc);
+    const double top = fmin(fmax(fabs(lat_lo - margin * dlat), fabs(lat_hi + margin * dlat)), 75.0);
+    return fmin(dlat, dlon * cos(top * TG_RAD_PER_DEG)) * TG_RAD_PER_DEG;
+  }
+  return 0.0;
 }
 
 // How far the image of a figure can bulge out of the index-space box of its vertices, per squared index extent E^2: a

@@ -123,3 +123,54 @@ def test_row_block_from_arrays_with_its_projection_attached(gpu_lib, regional_ca
     _same(_stores(gpu_lib, R, mesh, grid, 1), {k: v for k, v in res[1].items() if k in ("bil0", "node", "cons")})
     mesh.destroy()
     grid.destroy()
+
+
+def _nearest(gpu_lib, R, m, grid_fn, boxes, staggers=(0,), window=False):
+    gpu_lib.tune("store_boxes", boxes)
+    try:
+        grid = grid_fn()
+        mesh = R.Mesh.from_mpas(m, window_grid=grid if window else None)
+        out = []
+        for st in staggers:
+            rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD, staggerloc=st)
+            out.append(rh.weights()[0][:, 0].copy())
+            rh.release()
+        mesh.destroy()
+        grid.destroy()
+    finally:
+        gpu_lib.tune("store_boxes", 1)
+    return out
+
+
+def test_nearest_through_index_bins_equals_the_bvh_search(gpu_lib, oracle, regional_case):
+    """Nearest-neighbour Store on a grid that knows its projection: cells binned in the grid's index space, a few bins around
+    every target point, exactness from a lower bound of the chord length of one index unit -- must give the BVH search's (= the
+    oracle's brute-force) indices, ties to the lowest id included: a regional mesh under a Lambert grid that sticks out of it
+    (the far points cannot be settled within the rings: the whole Store goes back to the BVH), a row block on a windowed mesh,
+    staggered points, a fine mesh under a coarse grid (many cells per bin), a mesh coarser than the grid (empty bins)."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg, workloads
+    from conftest import mesh_xyz
+    m, g = regional_case
+    for grid_fn, kw in ((lambda: R.Grid.from_target(g), {}), (lambda: R.Grid.from_target(g, rows=(25, 60)), dict(window=True)),
+                        (lambda: R.Grid.from_target(g, rows=(30, 50)), dict(staggers=(0, 1, 2)))):
+        a, b = _nearest(gpu_lib, R, m, grid_fn, 1, **kw), _nearest(gpu_lib, R, m, grid_fn, 0, **kw)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    # the tiny workload: grid inside the mesh -> the bins settle every point; against the oracle's brute force
+    mt, gt, _, _ = workloads.workload("tiny")
+    got = _nearest(gpu_lib, R, mt, lambda: R.Grid.from_proj(gt, fill_target=False), 1)[0]
+    cxyz, _ = mesh_xyz(oracle, mt)
+    want = oracle.nearest(cxyz, oracle.lonlat_deg_to_xyz(gt.lon, gt.lat))
+    diff = got != want
+    if diff.any():                                                # distance ties between the two sin / cos implementations only
+        pts = oracle.lonlat_deg_to_xyz(gt.lon, gt.lat).reshape(-1, 3)
+        assert np.abs(((cxyz[got[diff]] - pts[diff]) ** 2).sum(1) - ((cxyz[want[diff]] - pts[diff]) ** 2).sum(1)).max() <= 1e-14
+    assert diff.mean() < 1e-3
+    # constructed exact ties: two cells mirrored about a row of target points would need an exactly symmetric mesh; the lattice of
+    # `tiny` has many near-ties instead, which the comparison above covers.  Coarse and fine extremes:
+    coarse_grid = tg.define_target_grid_params("lambert", 31, 21, dx=150000.0, dy=150000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5,
+                                               stand_lon=-97.5)
+    for mesh_, grid_ in ((mt, coarse_grid), (synth.regional_mesh_for_lambert(gt.proj, 181, 107, 1500), gt)):
+        a = _nearest(gpu_lib, R, mesh_, lambda: R.Grid.from_target(grid_), 1)[0]
+        b = _nearest(gpu_lib, R, mesh_, lambda: R.Grid.from_target(grid_), 0)[0]
+        assert np.array_equal(a, b)
