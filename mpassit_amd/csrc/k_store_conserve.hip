@@ -46,7 +46,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          int32_t *__restrict__ tmp_dst, int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
                                                          uint8_t *__restrict__ flip, const int32_t *__restrict__ poff,
                                                          int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p, const float *__restrict__ vij,
-                                                         float pad_coef) {
+                                                         float pad_coef, float e_max) {
   // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
   constexpr bool COOP = MODE == 5 || MODE == 6;
   int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
   // O(1) candidates on a projection-built grid (round 4; MODE 3 only): the polygon's corners in the grid's index space (vij:
   // the inverse projection of every vertex, k_target_grid.hip) bound the destination cells it can meet -- cell (i, j) covers
   // index coordinates i - 0.5 .. i + 0.5 -- and every cell of that padded box takes the test above.  More candidates than the
-  // list holds, a polygon near the projection's pole / cut or wider than six index units: the walk (and the overflow passes).
+  // list holds, a polygon near the projection's pole / cut or wider than e_max index units: the walk (and the overflow passes).
   if (MODE == 3 && vij) {
     float imin = 1e30f, imax = -1e30f, jmin = 1e30f, jmax = -1e30f;
     bool ok = true;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
       jmin = fminf(jmin, vj); jmax = fmaxf(jmax, vj);
     }
     const float E = fmaxf(imax - imin, jmax - jmin);
-    if (ok && E <= 6.0f) {
+    if (ok && E <= e_max) {
       const float pad = 1.01f + pad_coef * E * E;
       const int i0 = max((int)ceilf(imin - pad - 0.5f), 0), i1 = min((int)floorf(imax + pad + 0.5f), nx - 1);
       const int j0 = max((int)ceilf(jmin - pad - 0.5f), 0), j1 = min((int)floorf(jmax + pad + 0.5f), ny - 1);
@@ -500,7 +500,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
                                         qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
-                                        (float)mpg_grid_box_pad_coef(g));
+                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_emax(g));
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
   MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -508,7 +508,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
     k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr, nullptr, 0.f);
+                                                       nullptr, nullptr, nullptr, 0.f, 0.f);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
   size_t tmp_bytes = 0, b2 = 0;
@@ -541,7 +541,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (novf > 0)
     k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
-                                                       pair_c.p, pair_p.p, nullptr, 0.f);
+                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12

@@ -201,6 +201,14 @@ double mpg_grid_min_index_chord(const mpg_grid_s *g, double lat_lo, double lat_h
   return 0.0;
 }
 
+// The widest figure (index units) the Stores send through its index box: six degrees / 600 km across at most (the pads are
+// small-angle bounds), and never more than 16 index units (beyond that the box holds hundreds of candidates and the walk wins)
+double mpg_grid_box_emax(const mpg_grid_s *g) {
+  const ProjDev &p = g->proj;
+  const double cell_deg = p.code == MPG_PROJ_LC ? (1.0 / p.rebydx) * TG_DEG_PER_RAD : fmax(fabs(p.loninc), fabs(p.latinc));
+  return fmin(16.0, 6.0 / cell_deg);
+}
+
 // How far the image of a figure can bulge out of the index-space box of its vertices, per squared index extent E^2: a
 // great-circle arc L grid lengths long bends by ~ L^2 * (grid length / earth radius) / 8 * (a factor below 1 from the map
 // scale's gradient) on the conformal Lambert map -- the coefficient below is four times that; on the lat-lon grid (equatorward

@@ -325,6 +325,7 @@ int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t
 int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s);
 // safety margin (index units) around the index-space box of a figure whose vertices span `extent` index units
 double mpg_grid_box_pad_coef(const mpg_grid_s *g);
+double mpg_grid_box_emax(const mpg_grid_s *g);
 double mpg_grid_min_index_chord(const mpg_grid_s *g, double lat_lo, double lat_hi, double margin);
 int mpg_k_dual_triangles(mpg_mesh_s *m, hipStream_t s);
 int mpg_k_tri_scatter(mpg_mesh_s *m, int32_t *cnt, hipStream_t s);
