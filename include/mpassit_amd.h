@@ -51,7 +51,11 @@ enum {
 
 /* ---- runtime: ESMF_Initialize / ESMF_Finalize (mpassit.F90:84,140) ------------------------------ */
 /* mpg_init may be repeated with the SAME device index (no-op); a different index while initialised is refused with
- * MPG_ERR_INVALID_ARG (streams and pinned staging belong to the first device): mpg_finalize first. */
+ * MPG_ERR_INVALID_ARG (streams and pinned staging belong to the first device): mpg_finalize first.
+ * MPASSIT is a single-shot tool (mpassit.F90:105-137), so what a run pays are FIRST calls: mpg_init starts a helper thread that
+ * loads the library's code objects and warms the runtime's pageable-copy staging while the caller goes on reading its
+ * namelist and opening its files (the HIP runtime would otherwise load each translation unit at the first launch of one of
+ * its kernels: 5-10 ms in front of the first Store of each method).  MPG_NO_WARMUP=1 in the environment switches it off. */
 int mpg_init(int device);
 int mpg_finalize(void);
 const char *mpg_last_error(void);
