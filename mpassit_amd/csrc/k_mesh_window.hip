@@ -314,6 +314,11 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
         return MPG_ERR_INVALID_ARG;
       }
     }
+    if (!whole && (v1 - v0) > (nV * 7) / 10) {   // numbering without bands (e.g. a Morton-ordered global mesh): the covering ranges are
+      delta = 4.0;                               // most of the mesh, the vertex arrays -- the larger upload -- would hardly shrink:
+      attempt = 6;                               // take the whole mesh (next pass of the loop)
+      continue;
+    }
     m->vw0 = v0;
     m->vwn = v1 - v0;
     if (m->vwn == 0) {   // rows of padding only

@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void k_nb_fill(int64_t n, int64_t first, const
 __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double *__restrict__ px, const double *__restrict__ py,
                                                   const double *__restrict__ pz, const double *__restrict__ cx, const double *__restrict__ cy,
                                                   const double *__restrict__ cz, int nbx, int nby, const int32_t *__restrict__ off,
-                                                  const int32_t *__restrict__ ids, double h, int32_t *__restrict__ out, int32_t *__restrict__ flags) {
+                                                  const int32_t *__restrict__ ids, double h, double cap, int32_t *__restrict__ out,
+                                                  int32_t *__restrict__ flags) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (p >= (int64_t)npx * npy) return;
   const int i = (int)(p % npx), j = (int)(p / npx);
@@ -437,7 +438,9 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
     }
     // every cell not seen so far is at least (r * NB_BIN) index units from the point (it sits in its own bin: the distance to the
     // edge of the block of rings 0 .. r is at least r bins), less the rounding of the float32 indices
-    const double lim = ((double)(r * NB_BIN) - 2e-3) * h;
+    // (cap: on a mesh cut to the grid only the window's cells are binned; the others are further than the window's margin from
+    // every grid point, so nothing beyond that margin can be called final here)
+    const double lim = fmin(((double)(r * NB_BIN) - 2e-3) * h, cap);
     done = r > 0 && best <= lim * lim;
   }
   if (!done) atomicOr(flags, 2);
@@ -514,7 +517,7 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   const double hmin = 0.8 * mpg_grid_min_index_chord(g, lat_lo, lat_hi, (double)(NB_RINGS * NB_BIN + 1));
   if (!(hmin > 0.0)) return MPG_SUCCESS;
   k_nb_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nbx, nby, off.p,
-                                                        ids.p, hmin, h->idx.p, flags.p);
+                                                        ids.p, hmin, m->cwn < m->nCells ? m->geo_margin : 4.0, h->idx.p, flags.p);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipMemcpyAsync(&hflags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
