@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
     const float E = fmaxf(imax - imin, jmax - jmin);
     const bool usable = ai == ai && aj == aj && bi_ == bi_ && bj_ == bj_ && ci_ == ci_ && cj_ == cj_;   // fminf / fmaxf skip a NaN corner
     if (usable && E <= e_max) {
-      const float pad = 1.01f + pad_coef * E * E;
+      const float pad = 0.05f + pad_coef * E * E;
       const int i0 = max((int)ceilf(imin + di - pad), 0), i1 = min((int)floorf(imax + di + pad), npx - 1);
       const int j0 = max((int)ceilf(jmin + dj - pad), 0), j1 = min((int)floorf(jmax + dj + pad), npy - 1);
       if (i0 > i1 || j0 > j1) return;   // off the grid

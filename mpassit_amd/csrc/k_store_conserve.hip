@@ -125,8 +125,21 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
       jmin = fminf(jmin, vj); jmax = fmaxf(jmax, vj);
     }
     const float E = fmaxf(imax - imin, jmax - jmin);
-    if (ok && E <= e_max) {
-      const float pad = 1.01f + pad_coef * E * E;
+    if (!ok) {
+      // no usable index (poleward of 75 degrees on a lat-lon grid, the projection's pole / cut): such a polygon meets MANY thin
+      // destination cells, and one lane walking the pyramid for it kept its whole wavefront resident for milliseconds (C5: 4.5 ms
+      // of this kernel at 15 waves per CU).  A workgroup each does it in the cooperative passes.
+      const double *bx = pyr.box + 6 * pyr.off[pyr.nlev - 1];   // ... unless it does not even meet the grid's bounding box
+      if (bx[0] > hi[0] || bx[3] < lo[0] || bx[1] > hi[1] || bx[4] < lo[1] || bx[2] > hi[2] || bx[5] < lo[2]) {
+        cnt_src[c] = 0;
+        return;
+      }
+      cnt_src[c] = CAND_CAP + 1;
+      ovf[atomicAdd(n_ovf, 1)] = (int32_t)c;
+      return;
+    }
+    if (E <= e_max) {
+      const float pad = 0.05f + pad_coef * E * E;
       const int i0 = max((int)ceilf(imin - pad - 0.5f), 0), i1 = min((int)floorf(imax + pad + 0.5f), nx - 1);
       const int j0 = max((int)ceilf(jmin - pad - 0.5f), 0), j1 = min((int)floorf(jmax + pad + 0.5f), ny - 1);
       bool over = false;

@@ -209,13 +209,15 @@ double mpg_grid_box_emax(const mpg_grid_s *g) {
   return fmin(16.0, 6.0 / cell_deg);
 }
 
-// How far the image of a figure can bulge out of the index-space box of its vertices, per squared index extent E^2: a
-// great-circle arc L grid lengths long bends by ~ L^2 * (grid length / earth radius) / 8 * (a factor below 1 from the map
-// scale's gradient) on the conformal Lambert map -- the coefficient below is four times that; on the lat-lon grid (equatorward
-// of 75 degrees, extents of a few points) the callers' constant pad of one index unit covers it.
+// How far the image of a figure can bulge out of the index-space box of its vertices, per squared index extent E^2 (the callers
+// pad their boxes by 0.05 + coef * E^2 index units; 0.05 covers the float32 indices).  Lambert (conformal): a great-circle arc L
+// grid lengths long bends by ~ L^2 * (grid length / earth radius) / 8 times a factor below 1 from the map scale's gradient --
+// the coefficient is four times that.  Lat-lon (not conformal): the image of a great circle has coordinate curvature up to
+// ~ 2 tan(lat) * (dlon/ds) * (dlat/ds); over an arc spanning E_i x E_j index units that is a deviation of ~ tan(lat) * E_i * E_j *
+// delta / 4 radians = 0.93 * E^2 * delta index units at the 75 degrees the inverse is used to -- the coefficient is twice that.
 double mpg_grid_box_pad_coef(const mpg_grid_s *g) {
   if (g->proj.code == MPG_PROJ_LC) return 0.5 / g->proj.rebydx;
-  return 0.25 * fmax(fabs(g->proj.loninc), fabs(g->proj.latinc)) * TG_RAD_PER_DEG;
+  return 2.0 * fmax(fabs(g->proj.loninc), fabs(g->proj.latinc)) * TG_RAD_PER_DEG;
 }
 
 // stagger: MPG_STAGGERLOC_*; snx x sny points of that stagger
