@@ -169,6 +169,44 @@ int main(void) {
     CHECK(mpg_dev_free(s_dev)); CHECK(mpg_dev_free(d_dev)); CHECK(mpg_dev_free(src_dev)); CHECK(mpg_dev_free(loc_dev));
     CHECK(mpg_dev_free(dst_dev)); CHECK(mpg_dev_free(all_dev));
   }
+  /* ---- round-4 verbs: a mesh cut to a grid gives the whole mesh's weights; a projection that does not fit a grid is refused ---- */
+  {
+    mpg_mesh cut;
+    mpg_handle ra, rb;
+    CHECK(mpg_mesh_create_window(4, 4, 3, latC, lonC, latV, lonV, &voc[0][0], grid, &cut));
+    int64_t c0, cn, v0, vn;
+    double margin;
+    CHECK(mpg_mesh_window_info(cut, &c0, &cn, &v0, &vn, &margin));
+    if (c0 != 0 || cn != 4 || vn != 4) {   /* a global grid sees all four cells of the tetrahedron */
+      fprintf(stderr, "FAIL mesh window [%lld, +%lld) vertices +%lld\n", (long long)c0, (long long)cn, (long long)vn);
+      return 1;
+    }
+    CHECK(mpg_regrid_store(mesh, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_BILINEAR, &ra));
+    CHECK(mpg_regrid_store(cut, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_BILINEAR, &rb));
+    int32_t ia[NY * NX * 3], ib[NY * NX * 3];
+    double wa[NY * NX * 3], wb[NY * NX * 3];
+    CHECK(mpg_handle_get_weights(ra, ia, wa));
+    CHECK(mpg_handle_get_weights(rb, ib, wb));
+    if (memcmp(ia, ib, sizeof ia) || memcmp(wa, wb, sizeof wa)) {
+      fprintf(stderr, "FAIL: the mesh cut to the grid gives other weights than the whole mesh\n");
+      return 1;
+    }
+    CHECK(mpg_handle_release(ra));
+    CHECK(mpg_handle_release(rb));
+    CHECK(mpg_mesh_destroy(cut));
+    mpg_proj pr;
+    memset(&pr, 0, sizeof pr);
+    pr.code = MPG_PROJ_LATLON;
+    pr.known_lat = -75.0; pr.known_lon = -165.0; pr.known_x = 1.0; pr.known_y = 1.0;
+    pr.dlat_deg = 30.0; pr.dlon_deg = 30.0;
+    CHECK(mpg_grid_attach_proj(grid, &pr, 0));            /* the grid's own projection (30-degree cells: accepted, the search stays on the pyramid) */
+    pr.dlon_deg = 1.0; pr.dlat_deg = 1.0;                  /* a fine projection that does not reproduce this grid's points */
+    if (mpg_grid_attach_proj(grid, &pr, 0) != MPG_ERR_INVALID_ARG || strlen(mpg_last_error()) == 0) {
+      fprintf(stderr, "FAIL: a projection that does not fit the grid must be refused with a message\n");
+      return 1;
+    }
+    if (MPG_ERR_TIMEOUT != 6) return 1;                    /* the multi-rank waits' error code is part of the ABI */
+  }
   /* error contract: bad argument -> rc != 0 and a message */
   mpg_handle bad;
   if (mpg_regrid_store(mesh, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_EDGE1, MPG_REGRIDMETHOD_BILINEAR, &bad) == MPG_SUCCESS ||
