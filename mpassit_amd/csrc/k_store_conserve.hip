@@ -36,6 +36,7 @@
 // (Round 2 first clipped the overflowed cells inside this walk, polygon buffers in scratch memory: 28 ms for configuration
 // 2, where all 22 204 referenced 30-km cells overflow under the 3-km grid.)
 #define CAND_CAP 24   // candidate destination cells per source cell kept by the candidate pass
+#define CONS_SPILL 256   // candidates per overflowed cell the cooperative count pass keeps for the list pass
 template <int MODE>
 __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
                                                          const double *__restrict__ vx, const double *__restrict__ vy,
@@ -46,11 +47,23 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          int32_t *__restrict__ tmp_dst, int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
                                                          uint8_t *__restrict__ flip, const int32_t *__restrict__ poff,
                                                          int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p, const float *__restrict__ vij,
-                                                         float pad_coef, float e_max) {
+                                                         float pad_coef, float e_max, int32_t *__restrict__ spill) {
   // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
   constexpr bool COOP = MODE == 5 || MODE == 6;
   int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
+  if (MODE == 6 && spill) {
+    // the count pass (MODE 5) kept the first CONS_SPILL candidates of this cell: when that was all of them the list is copied,
+    // not walked for again (configuration 5: the second walk of the polar polygons was a quarter of the whole Store)
+    const int n = poff[c + 1] - poff[c];
+    if (n <= CONS_SPILL) {
+      for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        pair_c[poff[c] + k] = (int32_t)c;
+        pair_p[poff[c] + k] = spill[(int64_t)blockIdx.x * CONS_SPILL + k];
+      }
+      return;
+    }
+  }
   int found = 0;
   dv3 poly[CONS_MAXV];
   int n = 0;
@@ -234,7 +247,8 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
             tmp_dst[c * CAND_CAP + found] = (int32_t)p;
             ++found;
           } else if (MODE == 5) {
-            atomicAdd(&s_found, 1);
+            const int slot = atomicAdd(&s_found, 1);
+            if (spill && slot < CONS_SPILL) spill[(int64_t)blockIdx.x * CONS_SPILL + slot] = (int32_t)p;
           } else {
             const int slot = atomicAdd(&s_found, 1);
             pair_c[poff[c] + slot] = (int32_t)c;
@@ -513,15 +527,17 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
                                         qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
-                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_emax(g));
+                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_emax(g), nullptr);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0;
   MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
+  TmpBuf<int32_t> spill;
+  if (novf > 0 && (rc = spill.alloc((size_t)novf * CONS_SPILL, s))) return rc;
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
     k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr, nullptr, 0.f, 0.f);
+                                                       nullptr, nullptr, nullptr, 0.f, 0.f, spill.p);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
   size_t tmp_bytes = 0, b2 = 0;
@@ -554,7 +570,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (novf > 0)
     k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
-                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f);
+                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f, spill.p);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12
