@@ -88,3 +88,36 @@ def test_random_configuration(oracle, gpu_lib, case):
     rc.release()
     mesh.destroy()
     grid.destroy()
+
+
+@pytest.mark.parametrize("case", list(range(24)))
+def test_random_row_block_on_a_cut_mesh(gpu_lib, case):
+    """The same random meshes and grids, a random block of target rows: the mesh cut to that block (mpg_mesh_create_window), with
+    the index-space searches the block grid's projection allows, must give the weights of the whole mesh on the pyramid / BVH
+    searches bit for bit -- bilinear (element- and node-located), nearest, conservative."""
+    from mpassit_amd import regrid as R
+    rng = np.random.default_rng(5000 + case)
+    m = _mesh(rng, case % 4)
+    g = _grid(rng)
+    j0 = int(rng.integers(0, max(1, g.ny - 2)))
+    j1 = int(rng.integers(j0 + 1, g.ny + 1))
+    res = []
+    for cut in (False, True):
+        gpu_lib.tune("store_boxes", 1 if cut else 0)
+        try:
+            grid = R.Grid.from_target(g, rows=(j0, j1), attach_proj=cut)
+            mesh = R.Mesh.from_mpas(m, window_grid=grid if cut else None)
+            out = []
+            for kw in (dict(regridmethod=R.REGRIDMETHOD_BILINEAR), dict(regridmethod=R.REGRIDMETHOD_NEAREST_STOD),
+                       dict(regridmethod=R.REGRIDMETHOD_CONSERVE), dict(regridmethod=R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)):
+                rh = R.regrid_store(mesh, grid, **kw)
+                out.append(rh.csr() if kw["regridmethod"] == R.REGRIDMETHOD_CONSERVE else rh.weights())
+                rh.release()
+            res.append(out)
+            mesh.destroy()
+            grid.destroy()
+        finally:
+            gpu_lib.tune("store_boxes", 1)
+    for a, b in zip(*res):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (case, j0, j1)
