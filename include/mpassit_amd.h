@@ -369,6 +369,8 @@ int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, con
  *   "field_band"  order of the (field, tile) work items of a bundle Regrid: -1 each kernel's own choice (default: bands of
  *                 1024 tiles for the level-fast row gather, field-major for the staged kernels), 0 field-major, n > 0 all
  *                 fields of a band of n tiles before the next band
+ *   "store_boxes" Stores on a grid that knows its projection: 1 (default) candidates through the grid's index space, 0 the
+ *                 hierarchical search always
  * and one that does NOT (it selects between two readings of ESMF's undocumented-here behaviour):
  *   "bilinear_linetype"   Mesh -> Grid bilinear Store: 0 (default) the target point meets the plane of its source triangle
  *                 along the ray from the sphere's centre; 1 along the plane's normal (ESMF_LINETYPE_CART read literally).
@@ -379,6 +381,11 @@ int mpg_tune(const char *key, int value);
 
 /* timing of the last Store phases in ms (search build, search, finalize); any pointer may be NULL */
 int mpg_handle_store_ms(mpg_handle rh, float *ms_total);
+/* How the Store found its candidates: 0 = the hierarchical search (pyramid walk over the grid / BVH over the mesh);
+ * 1 = through the grid's index space (a grid that knows its projection, mpg_grid_create_proj / mpg_grid_attach_proj, fine
+ * enough for the claim to hold -- DESIGN.md s4.2); 2 = nearest only: index space for the points it can vouch for, the BVH for
+ * the others.  The weights are the same bits either way; diagnostics only. */
+int mpg_handle_store_path(mpg_handle rh, int *candidates);
 
 #ifdef __cplusplus
 }

@@ -346,6 +346,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
     sijp = sij.p - 2 * s0;   // indexed with global ids, like sx / sy / sz
     di = stagger == MPG_STAGGERLOC_EDGE1 ? 0.5f : 0.f;
     dj = stagger == MPG_STAGGERLOC_EDGE2 ? 0.5f : 0.f;
+    h->store_path = 1;
   }
   if (nT > 0) {
     raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p, pts.z.p,

@@ -522,6 +522,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     if ((rc = vij.alloc(2 * (size_t)m->vwn, s))) return rc;
     if ((rc = mpg_k_points_ij(g, m->vwn, m->vert.x.p, m->vert.y.p, m->vert.z.p, vij.p, s))) return rc;
     vijp = vij.p - 2 * m->vw0;   // indexed with global vertex ids, like vx / vy / vz
+    h->store_path = 1;
   }
   k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests

@@ -148,10 +148,12 @@ int mpg_nearest_variant() { return g_nn_variant; }
 void mpg_set_nearest_variant(int v) { g_nn_variant = v; }
 
 #define NN_STACK 96
+// masked != 0: only the points whose out[] entry is negative are searched (the ones the index-space search could not settle)
 __global__ __launch_bounds__(256) void k_nearest_query(int64_t P, const double *__restrict__ px, const double *__restrict__ py,
-                                                       const double *__restrict__ pz, SiteBvhView b, int32_t *__restrict__ out) {
+                                                       const double *__restrict__ pz, SiteBvhView b, int32_t *__restrict__ out, int masked) {
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (p >= P) return;
+  if (masked && out[p] >= 0) return;
   double X = px[p], Y = py[p], Z = pz[p];
   double best = INFINITY;
   int32_t best_id = 0x7fffffff;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void k_nearest_query(int64_t P, const double *
 #define NNW_WAVES 4
 __global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int npy, const double *__restrict__ px,
                                                                    const double *__restrict__ py, const double *__restrict__ pz,
-                                                                   SiteBvhView b, int32_t *__restrict__ out, int32_t *__restrict__ overflow) {
+                                                                   SiteBvhView b, int32_t *__restrict__ out, int32_t *__restrict__ overflow, int masked) {
   __shared__ int stk[NNW_WAVES][NNW_STACK];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nbx = (npx + 7) >> 3;
@@ -218,8 +220,10 @@ __global__ __launch_bounds__(64 * NNW_WAVES) void k_nearest_query_w(int npx, int
   const int64_t npatch = (int64_t)nbx * ((npy + 7) >> 3);
   if (patch >= npatch) return;
   const int i = (int)(patch % nbx) * 8 + (lane & 7), j = (int)(patch / nbx) * 8 + (lane >> 3);
-  const bool act = i < npx && j < npy;
+  bool act = i < npx && j < npy;
   const int64_t p = act ? (int64_t)j * npx + i : 0;
+  if (masked) act = act && out[p] < 0;      // settled already by the index-space search: this lane only rides along
+  if (__ballot(act) == 0) return;
   const double X = px[p], Y = py[p], Z = pz[p];
   double best = act ? INFINITY : -1.0;      // an inactive lane admits nothing
   int32_t best_id = 0x7fffffff;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void k_nn_max_d2(int64_t P, const double *__re
   if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__double_as_longlong(fmax(fmax(sw[0], sw[1]), fmax(sw[2], sw[3]))));
 }
 
-static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, mpg_handle_s *h, hipStream_t s) {
+static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, mpg_handle_s *h, hipStream_t s, int masked = 0) {
   int rc;
   const int64_t P = (int64_t)npx * npy;
   SiteBvh &b = m->bvh;
@@ -345,7 +349,7 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
   for (int i = 0; i <= MPG_BVH_MAXLEV; ++i) v.off[i] = b.off[i];
   v.box = b.box.p;
   if (mpg_nearest_variant() == 0) {   // "nn_variant" knob 0: the one-thread-per-point search (kept as the cross-check of the tests)
-    k_nearest_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p);
+    k_nearest_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p, masked);
     MPG_HIP(hipGetLastError());
     MPG_HIP(hipStreamSynchronize(s));
     return MPG_SUCCESS;
@@ -355,7 +359,7 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
   MPG_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int32_t), s));
   const int64_t npatch = (int64_t)((npx + 7) / 8) * ((npy + 7) / 8);
   k_nearest_query_w<<<(unsigned)((npatch + NNW_WAVES - 1) / NNW_WAVES), 64 * NNW_WAVES, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, v, h->idx.p,
-                                                                                                ovf.p);
+                                                                                                ovf.p, masked);
   MPG_HIP(hipGetLastError());
   int32_t h_ovf = 0;
   MPG_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -380,52 +384,87 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
 // the BVH search below: never a different answer, only a slower one.
 #define NB_BIN 2       // index units (grid points) per bin side
 #define NB_RINGS 4     // rings of bins a point may look at; the bin grid extends that far beyond the grid's points
-__global__ __launch_bounds__(256) void k_nb_count(int64_t n, const float *__restrict__ ij, float di, float dj, int nbx, int nby,
-                                                  int32_t *__restrict__ cnt, int32_t *__restrict__ flags) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= n) return;
-  const float u = ij[2 * c] + di + (float)(NB_RINGS * NB_BIN), v = ij[2 * c + 1] + dj + (float)(NB_RINGS * NB_BIN);
-  if (!(u == u) || !(v == v)) {   // no usable index: the search cannot vouch for this cell
-    atomicOr(flags, 1);
-    return;
+struct NbParams {
+  int nbx, nby;        // bins
+  int per, nxp;        // periodic in i (a global lat-lon grid): the index wraps at nxp, no margin in i
+  float di, dj;        // stagger offsets of the point indices
+  double h;            // chord length of one index unit, lower bound, times the safety factor (non-local form)
+  double cap;          // nothing beyond this chord distance is final (cut meshes: the window's margin)
+  int local;           // lat-lon: the bound is taken per point, h = 0.8 * min(dlat, dlon * cos(|lat| + what the rings span))
+  double dlat, dlon;   // radians per index unit (lat-lon)
+  int zone;            // 0 none; 1 lat-lon: no usable index beyond +-zlim degrees; 2 Lambert: beyond hemi * lat >= 89 or <= -60, and
+  double zlim, hemi;   //   the index jumps across the cut meridian stdlon + 180
+  double stdlon;
+};
+__device__ __forceinline__ bool nb_bin_of(const NbParams &q, float ci, float cj, int *bx, int *by) {
+  float u = ci + q.di, v = cj + q.dj + (float)(NB_RINGS * NB_BIN);
+  if (!(u == u) || !(v == v)) return false;
+  if (q.per) {
+    if (u < 0.f) u += (float)q.nxp;
+    if (u >= (float)q.nxp) u -= (float)q.nxp;
+  } else {
+    u += (float)(NB_RINGS * NB_BIN);
   }
-  const int bx = (int)floorf(u / NB_BIN), by = (int)floorf(v / NB_BIN);
-  if (u < 0.f || v < 0.f || bx >= nbx || by >= nby) return;   // beyond the margin: further than any accepted answer
-  atomicAdd(&cnt[(int64_t)by * nbx + bx], 1);
+  if (u < 0.f || v < 0.f) return false;
+  *bx = (int)floorf(u / NB_BIN);
+  *by = (int)floorf(v / NB_BIN);
+  return *bx < q.nbx && *by < q.nby;   // beyond the margin: further than any answer that is called final
 }
-__global__ __launch_bounds__(256) void k_nb_fill(int64_t n, int64_t first, const float *__restrict__ ij, float di, float dj, int nbx, int nby,
-                                                 const int32_t *__restrict__ off, int32_t *__restrict__ cur, int32_t *__restrict__ ids) {
+__global__ __launch_bounds__(256) void k_nb_count(int64_t n, const float *__restrict__ ij, NbParams q, int32_t *__restrict__ cnt) {
   const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= n) return;
-  const float u = ij[2 * c] + di + (float)(NB_RINGS * NB_BIN), v = ij[2 * c + 1] + dj + (float)(NB_RINGS * NB_BIN);
-  if (!(u == u) || !(v == v) || u < 0.f || v < 0.f) return;
-  const int bx = (int)floorf(u / NB_BIN), by = (int)floorf(v / NB_BIN);
-  if (bx >= nbx || by >= nby) return;
-  const int64_t b = (int64_t)by * nbx + bx;
+  int bx, by;
+  if (nb_bin_of(q, ij[2 * c], ij[2 * c + 1], &bx, &by)) atomicAdd(&cnt[(int64_t)by * q.nbx + bx], 1);
+}
+__global__ __launch_bounds__(256) void k_nb_fill(int64_t n, int64_t first, const float *__restrict__ ij, NbParams q, const int32_t *__restrict__ off,
+                                                 int32_t *__restrict__ cur, int32_t *__restrict__ ids) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  int bx, by;
+  if (!nb_bin_of(q, ij[2 * c], ij[2 * c + 1], &bx, &by)) return;
+  const int64_t b = (int64_t)by * q.nbx + bx;
   ids[off[b] + atomicAdd(&cur[b], 1)] = (int32_t)(first + c);
 }
-// one thread per target point; h = chord length bound of one index unit (already times the safety factor)
+// one thread per target point.  out[p] = the nearest cell when that is final, -1 when the point is left to the BVH search
 __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double *__restrict__ px, const double *__restrict__ py,
                                                   const double *__restrict__ pz, const double *__restrict__ cx, const double *__restrict__ cy,
-                                                  const double *__restrict__ cz, int nbx, int nby, const int32_t *__restrict__ off,
-                                                  const int32_t *__restrict__ ids, double h, double cap, int32_t *__restrict__ out,
-                                                  int32_t *__restrict__ flags) {
+                                                  const double *__restrict__ cz, NbParams q, const int32_t *__restrict__ off,
+                                                  const int32_t *__restrict__ ids, int32_t *__restrict__ out, int32_t *__restrict__ flags) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (p >= (int64_t)npx * npy) return;
   const int i = (int)(p % npx), j = (int)(p / npx);
   const double X = px[p], Y = py[p], Z = pz[p];
-  const int bx = (i + NB_RINGS * NB_BIN) / NB_BIN, by = (j + NB_RINGS * NB_BIN) / NB_BIN;
+  const int bx = q.per ? (i % q.nxp) / NB_BIN : (i + NB_RINGS * NB_BIN) / NB_BIN, by = (j + NB_RINGS * NB_BIN) / NB_BIN;
+  const double r2d = 57.29577951308232, alat = fabs(asin(fmin(fmax(Z, -1.0), 1.0)));   // the point's |latitude|, radians
+  // cells WITHOUT a usable index are not binned: nothing as far as they can be is final.  They sit beyond zlim degrees (lat-lon)
+  // resp. within a degree of the Lambert pole or more than 60 degrees into the other hemisphere.
+  double cap = q.cap;
+  if (q.zone == 1) cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * fmax(q.zlim / r2d - alat, 0.0)));
+  if (q.zone == 2) {
+    const double hl = q.hemi * asin(fmin(fmax(Z, -1.0), 1.0)) * r2d;   // degrees towards the projection's pole
+    cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * fmax(fmin(89.0 - hl, hl + 60.0), 0.0) / r2d));
+    // ... and a cell across the projection's cut (the meridian opposite the standard longitude) sits far away in index space
+    // however near it is on the sphere: nothing as far as the cut is final
+    double dl = atan2(Y, X) * r2d - q.stdlon;
+    dl -= 360.0 * floor((dl + 180.0) / 360.0);
+    if (fabs(dl) > 90.0) {
+      const double ang = asin(fmin(cos(alat) * sin((180.0 - fabs(dl)) / r2d), 1.0));   // angular distance to the cut meridian
+      cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * ang));
+    }
+  }
   double best = INFINITY;
   int32_t best_id = 0x7fffffff;
   bool done = false;
   for (int r = 0; r <= NB_RINGS && !done; ++r) {
     // the bins of ring r: the square of half-width r without the square of half-width r - 1
     for (int yy = by - r; yy <= by + r; ++yy) {
-      if (yy < 0 || yy >= nby) continue;
+      if (yy < 0 || yy >= q.nby) continue;
       const bool edge_row = yy == by - r || yy == by + r;
       for (int xx = bx - r; xx <= bx + r; xx += (edge_row || r == 0) ? 1 : 2 * r) {
-        if (xx < 0 || xx >= nbx) continue;
-        const int64_t b = (int64_t)yy * nbx + xx;
+        int xw = xx;
+        if (q.per) xw = (xx % q.nbx + q.nbx) % q.nbx;
+        else if (xx < 0 || xx >= q.nbx) continue;
+        const int64_t b = (int64_t)yy * q.nbx + xw;
         for (int32_t k = off[b]; k < off[b + 1]; ++k) {
           const int32_t id = ids[k];
           const double d = dist2_nofma(X, Y, Z, cx[id], cy[id], cz[id]);
@@ -437,14 +476,15 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
       }
     }
     // every cell not seen so far is at least (r * NB_BIN) index units from the point (it sits in its own bin: the distance to the
-    // edge of the block of rings 0 .. r is at least r bins), less the rounding of the float32 indices
-    // (cap: on a mesh cut to the grid only the window's cells are binned; the others are further than the window's margin from
-    // every grid point, so nothing beyond that margin can be called final here)
+    // edge of the block of rings 0 .. r is at least r bins), less the rounding of the float32 indices; on the sphere that is at
+    // least that many times the chord length of an index unit -- on a lat-lon grid taken where the rings reach furthest poleward
+    double h = q.h;
+    if (q.local) h = 0.8 * fmin(q.dlat, q.dlon * cos(fmin(alat + (double)(r * NB_BIN + 1) * q.dlat, 1.5707)));
     const double lim = fmin(((double)(r * NB_BIN) - 2e-3) * h, cap);
     done = r > 0 && best <= lim * lim;
   }
   if (!done) atomicOr(flags, 2);
-  out[p] = best_id;
+  out[p] = done ? best_id : -1;
 }
 __global__ __launch_bounds__(256) void k_zrange(int64_t n, const double *__restrict__ z, unsigned long long *__restrict__ out) {
   __shared__ double slo[4], shi[4];
@@ -468,17 +508,44 @@ __global__ __launch_bounds__(256) void k_zrange(int64_t n, const double *__restr
   }
 }
 
-// -> *used = true when h->idx holds the exact answer; false: nothing usable came out, take the BVH search
+// -> *state: 0 nothing usable came out (take the BVH search for all points), 1 every point settled, 2 the points whose h->idx
+// entry is -1 are left to the BVH search (masked)
 static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, int npy, const PointSet &pts, mpg_handle_s *h, hipStream_t s,
-                           bool *used) {
-  *used = false;
+                           int *state) {
+  *state = 0;
   int rc;
   const int64_t P = (int64_t)npx * npy, n = m->cwn, first = m->cw0;
   if (!mpg_grid_has_inverse(g) || !mpg_store_boxes() || n == 0 || stagger == MPG_STAGGERLOC_CORNER) return MPG_SUCCESS;
-  if (g->periodic & MPG_GRID_PERIODIC_I) return MPG_SUCCESS;   // a global lat-lon grid: its polar cells have no usable index, do not even try
-  const int nbx = (npx + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN, nby = (npy + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN;
-  const int64_t nbins = (int64_t)nbx * nby;
+  const ProjDev &pr = g->proj;
+  NbParams q;
+  memset(&q, 0, sizeof(q));
+  q.per = (g->periodic & MPG_GRID_PERIODIC_I) != 0;
+  if (q.per) {   // a global lat-lon grid: the index wraps; needs the full circle in whole bins and no duplicated column
+    q.nxp = pr.nxmax - pr.nxmin + 1;
+    if (pr.code != MPG_PROJ_LATLON || npx != q.nxp || g->nx != q.nxp || q.nxp % NB_BIN) return MPG_SUCCESS;
+  }
+  q.nbx = q.per ? q.nxp / NB_BIN : (npx + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN;
+  q.nby = (npy + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN;
+  q.di = stagger == MPG_STAGGERLOC_EDGE1 ? 0.5f : 0.f;
+  q.dj = stagger == MPG_STAGGERLOC_EDGE2 ? 0.5f : 0.f;
+  q.cap = m->cwn < m->nCells ? m->geo_margin : 4.0;
+  const int64_t nbins = (int64_t)q.nbx * q.nby;
   if (nbins + 1 >= 0x7fffffff) return MPG_SUCCESS;
+  const double latlon_limit = 89.0;   // the nearest search only PLACES points: the lat-lon inverse is good up to the last degree
+  if (pr.code == MPG_PROJ_LATLON) {
+    // a regional lat-lon grid: cell indices are unwrapped around its middle column, which is only unambiguous while the grid
+    // and its margin stay well short of the full circle
+    if (!q.per && (double)(npx + 2 * NB_RINGS * NB_BIN) * fabs(pr.loninc) > 300.0) return MPG_SUCCESS;
+    q.local = 1;
+    q.dlat = fabs(pr.latinc) * 3.141592653589793 / 180.0;
+    q.dlon = fabs(pr.loninc) * 3.141592653589793 / 180.0;
+    q.zone = 1;
+    q.zlim = latlon_limit;
+  } else {
+    q.zone = 2;
+    q.hemi = pr.hemi;
+    q.stdlon = pr.stdlon;
+  }
   TmpBuf<float> ij;
   TmpBuf<int32_t> cnt, off, ids, flags;
   TmpBuf<unsigned long long> zr;
@@ -487,41 +554,38 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
     return rc;
   MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
   MPG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t), s));
-  MPG_HIP(hipMemsetAsync(zr.p, 0xff, sizeof(unsigned long long), s));
-  MPG_HIP(hipMemsetAsync(zr.p + 1, 0, sizeof(unsigned long long), s));
-  if ((rc = mpg_k_points_ij(g, n, m->cell.x.p + first, m->cell.y.p + first, m->cell.z.p + first, ij.p, s))) return rc;
-  const float di = stagger == MPG_STAGGERLOC_EDGE1 ? 0.5f : 0.f, dj = stagger == MPG_STAGGERLOC_EDGE2 ? 0.5f : 0.f;
+  if ((rc = mpg_k_points_ij(g, n, m->cell.x.p + first, m->cell.y.p + first, m->cell.z.p + first, ij.p, s, latlon_limit, !q.per))) return rc;
   const unsigned nbc = (unsigned)((n + 255) / 256);
-  k_nb_count<<<nbc, 256, 0, s>>>(n, ij.p, di, dj, nbx, nby, cnt.p, flags.p);
-  k_zrange<<<(unsigned)std::min<int64_t>((P + 255) / 256, 1024), 256, 0, s>>>(P, pts.z.p, zr.p);
+  if (!q.local) {   // Lambert: one bound for the grid, from the latitudes its points span (one small read-back)
+    MPG_HIP(hipMemsetAsync(zr.p, 0xff, sizeof(unsigned long long), s));
+    MPG_HIP(hipMemsetAsync(zr.p + 1, 0, sizeof(unsigned long long), s));
+    k_zrange<<<(unsigned)std::min<int64_t>((P + 255) / 256, 1024), 256, 0, s>>>(P, pts.z.p, zr.p);
+    unsigned long long hz[2];
+    MPG_HIP(hipMemcpyAsync(hz, zr.p, sizeof(hz), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    double zlo, zhi;
+    memcpy(&zlo, &hz[0], sizeof(double));
+    memcpy(&zhi, &hz[1], sizeof(double));
+    const double r2d = 180.0 / 3.141592653589793;
+    const double lat_lo = asin(fmin(fmax(zlo - 2.0, -1.0), 1.0)) * r2d, lat_hi = asin(fmin(fmax(zhi - 2.0, -1.0), 1.0)) * r2d;
+    q.h = 0.8 * mpg_grid_min_index_chord(g, lat_lo, lat_hi, (double)(NB_RINGS * NB_BIN + 1));
+    if (!(q.h > 0.0)) return MPG_SUCCESS;
+  }
+  k_nb_count<<<nbc, 256, 0, s>>>(n, ij.p, q, cnt.p);
   size_t tmp_bytes = 0;
   MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.p, off.p, (int32_t)0, (size_t)nbins + 1, rocprim::plus<int32_t>(), s));
   TmpBuf<char> tmp;
   if ((rc = tmp.alloc(tmp_bytes + 16, s))) return rc;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, cnt.p, off.p, (int32_t)0, (size_t)nbins + 1, rocprim::plus<int32_t>(), s));
   MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));   // now the fill cursors
-  k_nb_fill<<<nbc, 256, 0, s>>>(n, first, ij.p, di, dj, nbx, nby, off.p, cnt.p, ids.p);
+  k_nb_fill<<<nbc, 256, 0, s>>>(n, first, ij.p, q, off.p, cnt.p, ids.p);
+  k_nb_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, q, off.p, ids.p,
+                                                        h->idx.p, flags.p);
   MPG_HIP(hipGetLastError());
-  // the bound needs the latitudes the grid spans (one small read-back; the count pass's verdict on unusable cells comes with it)
-  unsigned long long hz[2];
   int32_t hflags = 0;
-  MPG_HIP(hipMemcpyAsync(hz, zr.p, sizeof(hz), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipMemcpyAsync(&hflags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
-  if (hflags & 1) return MPG_SUCCESS;   // a cell without a usable index
-  double zlo, zhi;
-  memcpy(&zlo, &hz[0], sizeof(double));
-  memcpy(&zhi, &hz[1], sizeof(double));
-  const double r2d = 180.0 / 3.141592653589793;
-  const double lat_lo = asin(fmin(fmax(zlo - 2.0, -1.0), 1.0)) * r2d, lat_hi = asin(fmin(fmax(zhi - 2.0, -1.0), 1.0)) * r2d;
-  const double hmin = 0.8 * mpg_grid_min_index_chord(g, lat_lo, lat_hi, (double)(NB_RINGS * NB_BIN + 1));
-  if (!(hmin > 0.0)) return MPG_SUCCESS;
-  k_nb_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, nbx, nby, off.p,
-                                                        ids.p, hmin, m->cwn < m->nCells ? m->geo_margin : 4.0, h->idx.p, flags.p);
-  MPG_HIP(hipGetLastError());
-  MPG_HIP(hipMemcpyAsync(&hflags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MPG_HIP(hipStreamSynchronize(s));
-  *used = !(hflags & 2);   // a point that could not be settled within its rings: the BVH search answers for all
+  *state = (hflags & 2) ? 2 : 1;
   return MPG_SUCCESS;
 }
 
@@ -544,13 +608,14 @@ int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s 
   h->ny_dst = npy;
   h->nnz = P;
   if ((rc = h->idx.alloc((size_t)P))) return rc;
-  {   // a grid that knows its projection: through its index space, when that search can vouch for its answer
-    bool used = false;
-    if ((rc = nearest_by_bins(m, g, stagger, npx, npy, pts, h, s, &used))) return rc;
-    if (used) return MPG_SUCCESS;
-  }
+  // a grid that knows its projection: through its index space, for every point that search can vouch for; the others (a grid
+  // sticking far out of the mesh, the polar rows of a global lat-lon grid) are left to the BVH search, masked
+  int state = 0;
+  if ((rc = nearest_by_bins(m, g, stagger, npx, npy, pts, h, s, &state))) return rc;
+  h->store_path = state;
+  if (state == 1) return MPG_SUCCESS;
   if ((rc = mpg_k_build_bvh(m, s, !windowed))) return rc;
-  if ((rc = nearest_search(m, npx, npy, pts, h, s))) return rc;
+  if ((rc = nearest_search(m, npx, npy, pts, h, s, state == 2))) return rc;
   if (!m->bvh_whole) {
     // Exact?  Every cell that is NOT a site lies further than geo_margin from every point of the grid (that is how the window
     // was cut), so a point whose nearest site is within geo_margin has its true nearest cell -- ties included: a cell at the
@@ -567,7 +632,7 @@ int mpg_k_store_nearest(mpg_mesh_s *m, mpg_grid_s *g, int stagger, mpg_handle_s 
     MPG_HIP(hipStreamSynchronize(s));
     double d2;
     memcpy(&d2, &bits, sizeof(d2));
-    if (!(d2 <= m->geo_margin * m->geo_margin)) {
+    if (!(d2 <= m->geo_margin * m->geo_margin)) {   // (the points the index search settled are within the margin by its own cap)
       if ((rc = mpg_k_build_bvh(m, s, true))) return rc;
       if ((rc = nearest_search(m, npx, npy, pts, h, s))) return rc;
     }

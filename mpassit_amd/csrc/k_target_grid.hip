@@ -114,8 +114,9 @@ __host__ __device__ __forceinline__ double map_factor(const ProjDev &p, double l
 // good to a fraction of a grid length (the callers pad their boxes and test every candidate point exactly as before).
 // Not usable -> NaN: within 1 degree of the Lambert pole or beyond 60 degrees into the other hemisphere; poleward of 75
 // degrees on a lat-lon grid (great circles bend too much in index space there).
-__global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, int64_t n, const double *__restrict__ x, const double *__restrict__ y,
-                                                   const double *__restrict__ z, float *__restrict__ ij) {
+__global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, double latlon_limit, double i_center, int64_t n,
+                                                   const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                   float *__restrict__ ij) {
   const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (q >= n) return;
   const double lat = asin(fmin(fmax(z[q], -1.0), 1.0)) * TG_DEG_PER_RAD, lon = atan2(y[q], x[q]) * TG_DEG_PER_RAD;
@@ -132,12 +133,19 @@ __global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, int64_t 
       j = p.hemi * (p.polej - rm * cos(arg));
     }
   } else if (p.code == MPG_PROJ_LATLON) {
-    if (fabs(lat) < 75.0) {
+    if (fabs(lat) < latlon_limit) {
       i = (lon - p.lon1) / p.loninc + p.knowni;
       j = (lat - p.lat1) / p.latinc + p.knownj;
-      const double span = (double)(p.nxmax - p.nxmin + 1);
-      if (i < p.nxmin - 0.5) i += span;
-      if (i >= p.nxmax + 0.5) i -= span;
+      if (i_center == i_center) {
+        // a REGIONAL lat-lon grid asked for the index nearest to its own columns (the nearest search bins cells by it): the
+        // reference's wrap below sends a longitude just west of the first column a whole circle east
+        const double period = 360.0 / p.loninc;
+        i -= nearbyint((i - i_center) / period) * period;
+      } else {
+        const double span = (double)(p.nxmax - p.nxmin + 1);
+        if (i < p.nxmin - 0.5) i += span;
+        if (i >= p.nxmax + 0.5) i -= span;
+      }
     }
   }
   ij[2 * q] = (float)(i - 1.0);
@@ -162,8 +170,13 @@ bool mpg_grid_has_inverse(const mpg_grid_s *g) {
   return false;
 }
 
-int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s) {
-  if (n > 0) k_points_ij<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->proj, g->proj_row0, n, x, y, z, ij);
+// latlon_limit: the latitude (degrees) up to which a lat-lon grid's inverse is handed out -- 75 for the index BOXES of the Stores
+// (great-circle edges bend too much in index space beyond), higher for the nearest search, which only places points
+// unwrap_i: lat-lon indices are taken on the branch nearest to the grid's middle column instead of the reference's wrap rule
+int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit,
+                    bool unwrap_i) {
+  const double i_center = unwrap_i ? 1.0 + 0.5 * (double)g->nx : (double)NAN;
+  if (n > 0) k_points_ij<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->proj, g->proj_row0, latlon_limit, i_center, n, x, y, z, ij);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -415,7 +428,7 @@ int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t
   if ((rc = sp.alloc(3 * (size_t)ns, s)) || (rc = ij.alloc(2 * (size_t)ns, s)) || (rc = bad.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
   k_sample_points<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(n, step, c.x.p, c.y.p, c.z.p, sp.p, sp.p + ns, sp.p + 2 * ns);
-  k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
+  k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, 75.0, (double)NAN, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
   k_check_inverse<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(g->nx, g->ny, step, ij.p, bad.p);
   MPG_HIP(hipGetLastError());
   int32_t hbad = 0;

@@ -834,6 +834,12 @@ int mpg_handle_store_ms(mpg_handle h, float *ms_total) {
   return MPG_SUCCESS;
 }
 
+int mpg_handle_store_path(mpg_handle h, int *candidates) {
+  MPG_ARG(h, "mpg_handle_store_path: NULL handle");
+  if (candidates) *candidates = h->store_path;
+  return MPG_SUCCESS;
+}
+
 int mpg_handle_get_weights(mpg_handle h, int32_t *idx_host, double *w_host) {
   MPG_CHECK_INIT();
   MPG_ARG(h && idx_host, "mpg_handle_get_weights: NULL argument");

@@ -273,6 +273,7 @@ struct mpg_handle_s {
   uint64_t parked_at = 0;   // release order of a handle waiting in the cache with refcount 0 (mpg_api.hip)
   HandleKey key;
   float store_ms = 0.f;
+  int store_path = 0;       // candidate search of the Store: 0 hierarchical (pyramid walk / BVH), 1 the grid's index space, 2 index space + BVH for the rest
   bool localized = false;
   // pole caps of a periodic (monopole) source grid: destination point pole_dst[q] adds pole_w[q] * mean of the
   // pole_len sources starting at pole_src0[q].  Dense over the candidate rows, pole_w == 0 where not in a cap.
@@ -322,7 +323,8 @@ int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s);
 // false: this grid has no usable inverse at all (made from arrays, or a projection without one here)
 bool mpg_grid_has_inverse(const mpg_grid_s *g);
 int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t s);
-int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s);
+int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit = 75.0,
+                    bool unwrap_i = false);
 // safety margin (index units) around the index-space box of a figure whose vertices span `extent` index units
 double mpg_grid_box_pad_coef(const mpg_grid_s *g);
 double mpg_grid_box_emax(const mpg_grid_s *g);

@@ -219,6 +219,13 @@ class RouteHandle:
         check(L.load().mpg_handle_store_ms(self._h, C.byref(ms)))
         return ms.value
 
+    @property
+    def store_path(self):
+        """0 hierarchical candidate search, 1 through the grid's index space, 2 index space + BVH for the rest (nearest)."""
+        v = C.c_int()
+        check(L.load().mpg_handle_store_path(self._h, C.byref(v)))
+        return v.value
+
     def _refresh(self):
         self.__init__(self._h)
 

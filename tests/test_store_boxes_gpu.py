@@ -125,7 +125,7 @@ def test_row_block_from_arrays_with_its_projection_attached(gpu_lib, regional_ca
     grid.destroy()
 
 
-def _nearest(gpu_lib, R, m, grid_fn, boxes, staggers=(0,), window=False):
+def _nearest(gpu_lib, R, m, grid_fn, boxes, staggers=(0,), window=False, paths=None):
     gpu_lib.tune("store_boxes", boxes)
     try:
         grid = grid_fn()
@@ -134,6 +134,8 @@ def _nearest(gpu_lib, R, m, grid_fn, boxes, staggers=(0,), window=False):
         for st in staggers:
             rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD, staggerloc=st)
             out.append(rh.weights()[0][:, 0].copy())
+            if paths is not None:
+                paths.append(rh.store_path)
             rh.release()
         mesh.destroy()
         grid.destroy()
@@ -166,6 +168,17 @@ def test_nearest_through_index_bins_equals_the_bvh_search(gpu_lib, oracle, regio
         pts = oracle.lonlat_deg_to_xyz(gt.lon, gt.lat).reshape(-1, 3)
         assert np.abs(((cxyz[got[diff]] - pts[diff]) ** 2).sum(1) - ((cxyz[want[diff]] - pts[diff]) ** 2).sum(1)).max() <= 1e-14
     assert diff.mean() < 1e-3
+    # a GLOBAL lat-lon grid (periodic index, polar rows left to the masked BVH search, cells within a degree of the poles without
+    # an index) and a global mesh under a Lambert grid (cells beyond 60 S have no Lambert index: capped, never binned)
+    mg, gg, _, _ = workloads.workload("c5_small")
+    for st in ((0,), (0, 2)):
+        a = _nearest(gpu_lib, R, mg, lambda: R.Grid.from_proj(gg, fill_target=False), 1, staggers=st)
+        b = _nearest(gpu_lib, R, mg, lambda: R.Grid.from_proj(gg, fill_target=False), 0, staggers=st)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    a = _nearest(gpu_lib, R, mg, lambda: R.Grid.from_proj(gt, fill_target=False), 1)[0]
+    b = _nearest(gpu_lib, R, mg, lambda: R.Grid.from_proj(gt, fill_target=False), 0)[0]
+    assert np.array_equal(a, b)
     # constructed exact ties: two cells mirrored about a row of target points would need an exactly symmetric mesh; the lattice of
     # `tiny` has many near-ties instead, which the comparison above covers.  Coarse and fine extremes:
     coarse_grid = tg.define_target_grid_params("lambert", 31, 21, dx=150000.0, dy=150000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5,
@@ -174,3 +187,30 @@ def test_nearest_through_index_bins_equals_the_bvh_search(gpu_lib, oracle, regio
         a = _nearest(gpu_lib, R, mesh_, lambda: R.Grid.from_target(grid_), 1)[0]
         b = _nearest(gpu_lib, R, mesh_, lambda: R.Grid.from_target(grid_), 0)[0]
         assert np.array_equal(a, b)
+
+
+def test_nearest_bins_at_the_lambert_cut_and_on_wide_regional_latlon_grids(gpu_lib):
+    """Places where a cell near a point on the sphere sits far from it in index space: the cut of a Lambert projection (the
+    meridian opposite its standard longitude, here crossed by a grid centred 150 degrees away from it), and the index seam of
+    a regional lat-lon grid (indices unwrapped about the middle column; a grid too wide for that uses the tree).  A global
+    mesh under each; the bins' answer equals the tree's."""
+    from mpassit_amd import regrid as R, target_grid as tg, workloads
+    mg, _, _, _ = workloads.workload("c5_small")
+    # (the east edges of both Lambert grids come within a degree or two of the cut at 82 E without crossing it: a grid ACROSS the cut maps
+    # a wedge of the plane to no place on the sphere and is no grid at all)
+    grids = [tg.define_target_grid_params("lambert", 61, 41, dx=40000.0, dy=40000.0, ref_lat=45.0, ref_lon=63.5, truelat1=30.0, truelat2=60.0,
+                                          stand_lon=-98.0),
+             tg.define_target_grid_params("lambert", 51, 51, dx=30000.0, dy=30000.0, ref_lat=50.0, ref_lon=64.0, truelat1=50.0, truelat2=50.0,
+                                          stand_lon=-98.0),
+             tg.define_target_grid_params("lat-lon", 281, 61, dx=0.5, dy=0.5, ref_lat=10.0, ref_lon=170.0),     # 140 degrees wide, across 180 E
+             tg.define_target_grid_params("lat-lon", 331, 41, dx=1.0, dy=1.0, ref_lat=-20.0, ref_lon=10.0)]    # 330 degrees wide: too wide to unwrap
+    seen = []
+    for g, want in zip(grids, ((1, 2), (1, 2), (1,), (0,))):
+        pa, pb = [], []
+        a = _nearest(gpu_lib, R, mg, lambda: R.Grid.from_target(g), 1, staggers=(0, 1), paths=pa)
+        b = _nearest(gpu_lib, R, mg, lambda: R.Grid.from_target(g), 0, staggers=(0, 1), paths=pb)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert pb == [0, 0] and pa[0] in want and pa[1] in want, (pa, pb)      # the search under test did run (and stood aside where it must)
+        seen += pa
+    assert 2 in seen                                              # ... and the points next to the cut were handed to the tree
