@@ -379,9 +379,12 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
 // bins within r rings have been looked at, every cell not looked at is at least r * NB_BIN index units away, i.e. at least
 // 0.8 * r * NB_BIN * h on the sphere, so a best distance below that is final -- ties included (an equally near cell is inside
 // the bound and was compared: lowest id wins, with the distance arithmetic of the BVH search and the oracle).  A point that
-// finds nothing final within NB_RINGS rings (the grid sticks far out of the mesh), a cell whose index is not usable (NaN: the
-// projection's pole / cut / far side, polar caps of a lat-lon grid) or a grid without a usable bound send the whole Store to
-// the BVH search below: never a different answer, only a slower one.
+// finds nothing final within NB_RINGS rings (the grid sticks far out of the mesh, the polar rows of a global grid) is left at
+// -1 and the BVH search above finishes exactly those points (masked): never a different answer, only a slower one.  Cells
+// whose index is not usable (NaN: the projection's pole / far side, the last degree before the poles on a lat-lon grid) are
+// not binned, and no answer as far away as such a cell could be -- or as far away as the Lambert cut, across which index
+// distance says nothing about distance on the sphere -- is called final (`cap` in k_nb_query).  Lat-lon grids take the bound h
+// per point, global ones wrap their bins in i, regional ones unwrap the cells' indices about the grid's middle column.
 #define NB_BIN 2       // index units (grid points) per bin side
 #define NB_RINGS 4     // rings of bins a point may look at; the bin grid extends that far beyond the grid's points
 struct NbParams {
