@@ -288,6 +288,7 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
     m->cw0 = c0;
     m->cwn = c1 - c0;
     m->voc.free();
+    m->max_valence = -1;
     m->vert.free();
     m->tri.free();
     m->vw0 = m->vwn = 0;

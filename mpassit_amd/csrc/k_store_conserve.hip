@@ -24,7 +24,7 @@
 #include "mpg_internal.h"
 
 #define CONS_MAXV 12   // max source polygon vertices handled (MPAS maxEdges is 6..10)
-#define CONS_BUF (CONS_MAXV + 6)
+#define CONS_BUF (CONS_MAXV + 4)   // a convex polygon gains at most one vertex per clip plane
 #define CONS_STACK 64
 #define CONS_QUEUE 2048  // breadth-first node queue of the cooperative passes
 
@@ -304,6 +304,23 @@ __global__ __launch_bounds__(256) void k_cell_areas(int nx, int ny, const double
   *reinterpret_cast<double4 *>(qsph + 4 * p) = double4{cen.x, cen.y, cen.z, r2 * (1.0 + 1e-9) + 1e-18};
 }
 
+// most vertices of any cell (verticesOnCell is maxEdges wide -- 10 in MPAS's own files -- whatever the cells have: 6 or 7): the
+// clip kernel sizes its LDS polygons by this, not by the array's width
+__global__ __launch_bounds__(256) void k_max_valence(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc, int32_t *__restrict__ out) {
+  __shared__ int smax;
+  if (threadIdx.x == 0) smax = 0;
+  __syncthreads();
+  int mx = 0;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < nCells; c += (int64_t)gridDim.x * blockDim.x) {
+    int n = 0;
+    for (int j = 0; j < maxEdges; ++j) n += voc[c * maxEdges + j] > 0;
+    mx = max(mx, n);
+  }
+  atomicMax(&smax, mx);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(out, smax);
+}
+
 __global__ __launch_bounds__(256) void k_csr_sort_rows(int64_t P, const int32_t *__restrict__ rowptr, int32_t *__restrict__ col,
                                                        double *__restrict__ val) {
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -371,16 +388,18 @@ struct LdsPoly {   // vertex i of polygon buffer `buf` of this lane
 // vertex outside between the two crossings, so the write index never passes i + 1 (the first vertex, needed again for the
 // closing edge, is kept in registers).  One buffer instead of two halves the LDS of the clip kernel: 8 instead of 4
 // wavefronts per CU.  The arithmetic and its order are those of the two-buffer form: the same bits.  A non-convex cell can
-// break the bound or outgrow `cap` = maxEdges + 6 slots; either is reported through *trunc (the Store then fails with
+// break the bound or outgrow `cap` = maxEdges + 4 slots; either is reported through *trunc (the Store then fails with
 // MPG_ERR_OVERFLOW), never a silently wrong polygon.
 __device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, dv3 nrm, int cap, int *trunc) {
   int m = 0;
   double eps = 1e-15 * sqrt(dot3(nrm, nrm));
   const dv3 first = L.get(0, 0);
   dv3 X1 = first;
+  const double dfirst = dot3(nrm, first);
+  double d1 = dfirst;
   for (int i = 0; i < n; ++i) {
     const dv3 X2 = (i + 1 == n) ? first : L.get(0, i + 1);
-    double d1 = dot3(nrm, X1), d2 = dot3(nrm, X2);
+    const double d2 = (i + 1 == n) ? dfirst : dot3(nrm, X2);   // (the same product as the next edge's d1: computed once)
     bool in1 = d1 >= -eps, in2 = d2 >= -eps;
     if (in1) {
       if (m < cap && m <= i + 1) L.set(0, m++, X1);
@@ -396,6 +415,7 @@ __device__ __forceinline__ int clip_halfspace_lds(int n, const LdsPoly &L, dv3 n
       }
     }
     X1 = X2;
+    d1 = d2;
   }
   return m;
 }
@@ -411,18 +431,37 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
   if (t >= npairs) return;
   const LdsPoly L{clip_lds + threadIdx.x, cb};
   const int64_t c = pair_c[t], p = pair_p[t];
-  // the source polygon, counter-clockwise seen from outside (orientation decided once per cell by the candidate pass)
-  int n = 0;
-  for (int j = 0; j < maxEdges && n < CONS_MAXV; ++j) {
-    int32_t v = voc[c * maxEdges + j];
-    if (v > 0) L.set(0, n++, dv3{vx[v - 1], vy[v - 1], vz[v - 1]});
-  }
-  if (flip[c])
-    for (int i = 0; i < n / 2; ++i) {
-      dv3 a = L.get(0, i), b = L.get(0, n - 1 - i);
-      L.set(0, i, b);
-      L.set(0, n - 1 - i, a);
+  // the source polygon, counter-clockwise seen from outside (orientation decided once per cell by the candidate pass).  All of a
+  // cell's vertex numbers are fetched before any coordinate and all coordinates before the first is used: written as a loop over
+  // the vertices (number, then coordinates, then the next number) the gather was a chain of two memory latencies per vertex, a
+  // dozen in a row, in a kernel that holds two or three wavefronts per SIMD.  Padding entries re-load the cell's first vertex.
+  int32_t vid[CONS_MAXV];
+#pragma unroll
+  for (int k = 0; k < CONS_MAXV; ++k) vid[k] = k < maxEdges ? voc[c * maxEdges + k] : 0;
+  const bool rev = flip[c] != 0;
+  int ntot = 0, vsafe = 0;
+#pragma unroll
+  for (int k = 0; k < CONS_MAXV; ++k) {
+    if (vid[k] > 0) {
+      ++ntot;
+      if (vsafe == 0) vsafe = vid[k];
     }
+  }
+  int n = 0;
+  if (vsafe > 0) {
+    dv3 vc[CONS_MAXV];
+#pragma unroll
+    for (int k = 0; k < CONS_MAXV; ++k) {
+      const int64_t v = (vid[k] > 0 ? vid[k] : vsafe) - 1;
+      vc[k] = dv3{vx[v], vy[v], vz[v]};
+    }
+#pragma unroll
+    for (int k = 0; k < CONS_MAXV; ++k)
+      if (vid[k] > 0) {
+        L.set(0, rev ? ntot - 1 - n : n, vc[k]);
+        ++n;
+      }
+  }
   const int i = (int)(p % nx), j = (int)(p / nx), nxc = nx + 1;
   const int64_t k00 = (int64_t)j * nxc + i;
   dv3 q[4] = {dv3{qx[k00], qy[k00], qz[k00]}, dv3{qx[k00 + 1], qy[k00 + 1], qz[k00 + 1]},
@@ -505,10 +544,10 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     return MPG_SUCCESS;
   }
   if ((rc = count.alloc((size_t)P + 1, s)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P, s)) || (rc = qsph.alloc(4 * (size_t)P, s)) ||
-      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(1, s)) ||
+      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(2, s)) ||
       (rc = npair.alloc((size_t)nC + 1, s)) || (rc = poff.alloc((size_t)nC + 1, s)) || (rc = flip.alloc((size_t)nC, s)))
     return rc;
-  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, sizeof(int32_t), s));
+  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, 2 * sizeof(int32_t), s));   // [0] overflowed cells, [1] the largest vertex count of a cell
   MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)nC, s));  // degenerate cells leave early
   MPG_HIP(hipMemsetAsync(flip.p, 0, (size_t)nC, s));
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
@@ -529,10 +568,13 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
                                         qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
                                         (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_emax(g), nullptr);
+  if (m->max_valence < 0) k_max_valence<<<(unsigned)std::min<int64_t>((nC + 255) / 256, 2048), 256, 0, s>>>(nC, m->maxEdges, m->voc.p, n_ovf.p + 1);
   MPG_HIP(hipGetLastError());
-  int32_t novf = 0;
-  MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t novf = 0, hv[2] = {0, 0};
+  MPG_HIP(hipMemcpyAsync(hv, n_ovf.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
+  novf = hv[0];
+  if (m->max_valence < 0) m->max_valence = hv[1];
   TmpBuf<int32_t> spill;
   if (novf > 0 && (rc = spill.alloc((size_t)novf * CONS_SPILL, s))) return rc;
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
@@ -574,8 +616,11 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
                                                        pair_c.p, pair_p.p, nullptr, 0.f, 0.f, spill.p);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
-  // buffer slots per polygon: a convex polygon gains at most one vertex per half-space (<= maxEdges + 4); CONS_BUF for maxEdges = 12
-  const int cb = m->maxEdges + 6 < CONS_BUF ? m->maxEdges + 6 : CONS_BUF;
+  // buffer slots per polygon: the in-place step never lets a polygon gain more than one vertex per half-space (it reports the
+  // polygon otherwise), so the cells' largest vertex count + 4 is all that can be used; 24 bytes x 64 lanes each, and the slots
+  // decide how many wavefronts a CU holds (10 slots: ten, 16: six -- configuration 4's clip 1.55 -> 1.3 ms from 12 to 10)
+  const int nv = std::max(3, std::min(m->max_valence, m->maxEdges));
+  const int cb = nv + 4 < CONS_BUF ? nv + 4 : CONS_BUF;
   const size_t clip_lds_bytes = sizeof(double) * cb * 3 * CLIP_NT;
   if (clip_lds_bytes > 48 * 1024)
     MPG_HIP(hipFuncSetAttribute((const void *)k_conserve_clip_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clip_lds_bytes));

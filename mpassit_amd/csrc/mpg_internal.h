@@ -222,6 +222,7 @@ struct mpg_mesh_s {
   mpg_grid_s *geo_grid = nullptr;   // the grid the window was cut for (Stores onto any other grid are refused); nullptr: whole mesh
   bool geo_grid_gone = false;       // that grid has been destroyed
   double geo_margin = 0.0;          // chord distance from the grid within which every cell is present
+  int max_valence = -1;             // most vertices any resident cell has (<= maxEdges, the width of verticesOnCell); -1 = not counted yet
   bool bvh_whole = true;            // the BVH covers every cell (false: the cells of the window only)
   const int32_t *voc_g() const { return voc.p - cw0 * maxEdges; }
   const double *vx_g() const { return vert.x.p - vw0; }

@@ -203,3 +203,30 @@ def test_conservative_store_of_a_very_coarse_mesh(gpu_lib, oracle, level):
     rh.release()
     mesh.destroy()
     grid.destroy()
+
+
+def test_vertices_on_cell_as_wide_as_mpas_writes_it(gpu_lib, regional_case):
+    """MPAS files carry verticesOnCell ten columns wide (maxEdges) whatever the cells have -- six or seven vertices, the rest
+    padded with 0.  The Stores size their per-cell work by the vertices present (the conservative clip its LDS polygons), not
+    by the array's width: the same weights, bit for bit, from the array as the synthetic meshes hold it and from a padded one."""
+    from mpassit_amd import regrid as R, synth
+    m, g = regional_case
+    wide = np.zeros((m.nCells, 10), np.int32)
+    wide[:, :m.maxEdges] = m.verticesOnCell
+    mw = synth.MpasMesh(m.latCell, m.lonCell, m.latVertex, m.lonVertex, wide)
+    res = []
+    for mm in (m, mw):
+        mesh, grid = R.Mesh.from_mpas(mm), R.Grid.from_target(g)
+        out = []
+        for kw in (dict(regridmethod=R.REGRIDMETHOD_CONSERVE), dict(regridmethod=R.REGRIDMETHOD_BILINEAR),
+                   dict(regridmethod=R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)):
+            rh = R.regrid_store(mesh, grid, **kw)
+            out.append(rh.csr() if kw["regridmethod"] == R.REGRIDMETHOD_CONSERVE else rh.weights())
+            rh.release()
+        res.append(out)
+        mesh.destroy()
+        grid.destroy()
+    for a, b in zip(*res):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert res[0][0][1].size > 0
