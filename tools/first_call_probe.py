@@ -15,12 +15,14 @@ def main():
     ap.add_argument("--workload", default="c4_3m_regional")
     ap.add_argument("--order", default="nearest,conserve,bilinear")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--settle", type=float, default=0.5, help="seconds between mpg_init and the first call (a driver reads its namelist and grid file there)")
     args = ap.parse_args()
     from mpassit_amd import _lib, regrid as R, workloads
     m, g, nlev, desc = workloads.workload(args.workload)
     t0 = time.perf_counter()
     _lib.init(0)
     print("# %s\nmpg_init %.2f ms" % (desc, 1e3 * (time.perf_counter() - t0)))
+    time.sleep(args.settle)
     codes = {"bilinear": R.REGRIDMETHOD_BILINEAR, "nearest": R.REGRIDMETHOD_NEAREST_STOD, "conserve": R.REGRIDMETHOD_CONSERVE}
     for rep in range(args.reps):
         t0 = time.perf_counter()
