@@ -181,7 +181,7 @@ template <typename TS, typename TD, int RPT, int NT, bool EPI>
 __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ ut_cnt, const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                    const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
-                                                   int nlev, int ntx, int nty, int ut_max, double scale, double offset, int band) {
+                                                   int nlev, int ntx, int nty, int ut_max, double scale, double offset, int band, FieldTab tab) {
   constexpr int LC = 4, UPT = 4, NPF = LC * UPT;
   extern __shared__ double lds[];  // [LC][nup]
   const int nup = ut_max;
@@ -196,8 +196,9 @@ __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ u
   const int32_t *cells = ut_cells + (int64_t)tile * stride;
   LfuPoints<RPT, NT> pts;
   pts.load(lidx, w, nx, ny, talign, tile % ntx, tile / ntx, 1);
-  const TS *sf = src + (int64_t)f * nlev * nsrc;
-  TD *df = dst + (int64_t)f * nlev * P;
+  const TS *sf = mpg_field_src(tab, src, f, (int64_t)nlev * nsrc);
+  TD *df = mpg_field_dst(tab, dst, f, (int64_t)nlev * P);
+  if constexpr (EPI) offset = mpg_field_off(tab, f, offset);
   int32_t cell[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
@@ -462,7 +463,8 @@ int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits) {
 }
 
 template <typename TS, typename TD, int RPT, int NT, bool EPI>
-static int launch_cfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s) {
+static int launch_cfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, hipStream_t s,
+                      const FieldTab &tab) {
   constexpr int TYU = NT * RPT / 64;
   const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + TYU - 1) / TYU;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;   // unmapped points read slot 0
@@ -474,31 +476,31 @@ static int launch_cfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   auto fn = k_apply3_cfu<TS, TD, RPT, NT, EPI>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cnt.p, h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
-                                                   h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset, mpg_field_band(0));
+                                                   h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset, mpg_field_band(0), tab);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
 
 template <int RPT, int NT>
 static int launch_cfu_types(mpg_handle_s *h, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, bool epi, double scale,
-                            double offset, hipStream_t s) {
-  if (!epi) return launch_cfu<double, double, RPT, NT, false>(h, src, nlev, nfields, dst, 1.0, 0.0, s);
-  if (src_f32 && dst_f32) return launch_cfu<float, float, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s);
-  if (src_f32) return launch_cfu<float, double, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s);
-  if (dst_f32) return launch_cfu<double, float, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s);
-  return launch_cfu<double, double, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s);
+                            double offset, hipStream_t s, const FieldTab &tab) {
+  if (!epi) return launch_cfu<double, double, RPT, NT, false>(h, src, nlev, nfields, dst, 1.0, 0.0, s, tab);
+  if (src_f32 && dst_f32) return launch_cfu<float, float, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s, tab);
+  if (src_f32) return launch_cfu<float, double, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s, tab);
+  if (dst_f32) return launch_cfu<double, float, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s, tab);
+  return launch_cfu<double, double, RPT, NT, true>(h, src, nlev, nfields, dst, scale, offset, s, tab);
 }
 
 // The staged cell-fast Regrid of one variant (lists built / swapped in as needed).  epi = false: mpg_regrid_dev (float64
 // both sides, the result as it stands, sign of zero included).
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, bool epi,
-                     double scale, double offset, hipStream_t s) {
+                     double scale, double offset, hipStream_t s, const FieldTab &tab) {
   int rc = cfu_build(h, variant, s);
   if (rc) return rc;
   if (h->ut_max > cfu_capacity(variant) && h->ut_max * 4 * sizeof(double) > 150 * 1024) return MPG_ERR_UNSUPPORTED;
-  if (variant == CFU_TALL) return launch_cfu_types<2, 512>(h, src, src_f32, nlev, nfields, dst, dst_f32, epi, scale, offset, s);
-  if (variant == CFU_WIDE) return launch_cfu_types<4, 256>(h, src, src_f32, nlev, nfields, dst, dst_f32, epi, scale, offset, s);
-  return launch_cfu_types<2, 256>(h, src, src_f32, nlev, nfields, dst, dst_f32, epi, scale, offset, s);
+  if (variant == CFU_TALL) return launch_cfu_types<2, 512>(h, src, src_f32, nlev, nfields, dst, dst_f32, epi, scale, offset, s, tab);
+  if (variant == CFU_WIDE) return launch_cfu_types<4, 256>(h, src, src_f32, nlev, nfields, dst, dst_f32, epi, scale, offset, s, tab);
+  return launch_cfu_types<2, 256>(h, src, src_f32, nlev, nfields, dst, dst_f32, epi, scale, offset, s, tab);
 }
 
 // ---- level-fast, level chunks --------------------------------------------------------------------------------
@@ -524,7 +526,7 @@ template <typename TS, typename TD, int NT, bool EPI, bool SWZ>
 __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w, const TS *__restrict__ src,
                                                    TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc, int nlev, int ntx, int nty,
-                                                   double scale, double offset, int sbe, int dbe, int band) {
+                                                   double scale, double offset, int sbe, int dbe, int band, FieldTab tab) {
   constexpr int LC = 16, NPF = 16, LS = LC + 1, RPP = NT / LC, TY = NT / 64, ZROW = NPF * RPP;
   extern __shared__ double lds_raw[];
   TS *slab = (TS *)lds_raw;                                  // [ZROW + 1][LS]; row ZROW stays zero
@@ -560,8 +562,9 @@ __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ u
     w2 = mapped ? w2 : 0.0;
   }
   const uint32_t pb = act ? (uint32_t)p * (uint32_t)sizeof(TD) : MPG_BUF_NONE;
-  const BufRsrc rs = buf_rsrc(src + (int64_t)f * nlev * nsrc, (uint32_t)((uint64_t)nsrc * nlev * sizeof(TS)));
-  TD *dlev = dst + (int64_t)f * nlev * P;                    // the level plane the next store goes to
+  const BufRsrc rs = buf_rsrc(mpg_field_src(tab, src, f, (int64_t)nlev * nsrc), (uint32_t)((uint64_t)nsrc * nlev * sizeof(TS)));
+  TD *dlev = mpg_field_dst(tab, dst, f, (int64_t)nlev * P);  // the level plane the next store goes to
+  if constexpr (EPI) offset = mpg_field_off(tab, f, offset);
   const uint32_t plane = (uint32_t)(P * sizeof(TD));
   const int nch = (nlev + LC - 1) / LC, k0_last = max(nlev - LC, 0);
   if (t < LS) slab[ZROW * LS + t] = (TS)0;
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ u
 
 template <typename TS, typename TD, int NT, bool EPI>
 static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
-                      hipStream_t s) {
+                      hipStream_t s, const FieldTab &tab) {
   const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + NT / 64 - 1) / (NT / 64);
   const size_t lds = sizeof(TS) * (NT + 1) * 17;
   if (h->ut_max > NT || h->ut_stride < NT || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
@@ -616,7 +619,7 @@ static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true> : k_apply3_lfu<TS, TD, NT, EPI, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
-                                                   h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe, mpg_field_band(0));
+                                                   h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe, mpg_field_band(0), tab);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -625,19 +628,19 @@ static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
 
 // -> MPG_ERR_UNSUPPORTED when a tile's list does not fit the slab (the caller takes the row gather)
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
-                           double offset, hipStream_t s) {
+                           double offset, hipStream_t s, const FieldTab &tab) {
   const int sbe = (src_type & MPG_TYPE_BE) != 0, dbe = (dst_type & MPG_TYPE_BE) != 0, sf32 = src_type & MPG_TYPE_F32, df32 = dst_type & MPG_TYPE_F32;
   int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_NT);
   if (rc) return rc;
-  if (sf32 && df32) return launch_lfu<float, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (sf32) return launch_lfu<float, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (df32) return launch_lfu<double, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  return launch_lfu<double, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s);
+  if (sf32 && df32) return launch_lfu<float, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  if (sf32) return launch_lfu<float, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  if (df32) return launch_lfu<double, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  return launch_lfu<double, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
 }
 int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
   int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_NT);
   if (rc) return rc;
-  return launch_lfu<double, double, LFU_NT, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s);
+  return launch_lfu<double, double, LFU_NT, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s, FieldTab());
 }
 
 // mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)

@@ -22,7 +22,7 @@
 template <typename TS, typename TD, bool SWZ>
 __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                      const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
-                                                     int nlev, int ntx, int nty, double scale, double offset, int sbe, int dbe) {
+                                                     int nlev, int ntx, int nty, double scale, double offset, int sbe, int dbe, FieldTab tab) {
   constexpr int RPT = 2, TY = 4 * RPT;
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
   int64_t P = (int64_t)nx * ny;
@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
 #pragma unroll
     for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
   }
-  const TS *s = src + (int64_t)fld * nlev * nsrc;
-  TD *d = dst + (int64_t)fld * nlev * P;
+  const TS *s = mpg_field_src(tab, src, fld, (int64_t)nlev * nsrc);
+  TD *d = mpg_field_dst(tab, dst, fld, (int64_t)nlev * P);
+  offset = mpg_field_off(tab, fld, offset);
   for (int k = 0; k < nlev; ++k) {
     __syncthreads();
     double v[RPT];
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
 template <typename TS, typename TD, bool SWZ>
 __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                      const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
-                                                     int nlev, int ntx, int nty, double scale, double offset, int sbe, int dbe) {
+                                                     int nlev, int ntx, int nty, double scale, double offset, int sbe, int dbe, FieldTab tab) {
   extern __shared__ double sw[];    // sw[3][64] | sidx[3][64] | tile[nlev][65] in the DESTINATION type (narrowing at the tile
   int32_t *sidx = (int32_t *)(sw + 192);            // write or at the store gives the same bits; float32 halves the LDS -> 8 WGs / CU)
   TD *tile = (TD *)(sidx + 192);
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
     sw[q * 64 + pt] = w[q * P + p];
   }
   __syncthreads();
-  const TS *sf = src + (int64_t)fld * nlev * nsrc;
+  const TS *sf = mpg_field_src(tab, src, fld, (int64_t)nlev * nsrc);
+  offset = mpg_field_off(tab, fld, offset);
   for (int kb = 0; kb < nlev; kb += 64) {
     int k = kb + lane;
     bool kact = k < nlev;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
     }
   }
   __syncthreads();
-  TD *df = dst + (int64_t)fld * nlev * P;
+  TD *df = mpg_field_dst(tab, dst, fld, (int64_t)nlev * P);
   int j = ty, i = tx * 64 + lane - mpg_tile_shift(j, nx);
   if (i >= 0 && i < nx && j < ny) {
     int64_t p = (int64_t)j * nx + i;
@@ -153,7 +155,7 @@ template <> struct Row2<double> { typedef f64x2_u type; };
 template <typename TS, typename TD, int UNR, bool EPI, bool SWZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_apply3_lf_rows(
     const int32_t *__restrict__ idx, const double *__restrict__ w, const TS *__restrict__ src, TD *__restrict__ dst, int64_t P, int64_t nsrc,
-    int nlev, unsigned ntile, double scale, double offset, int sbe, int dbe, int band) {
+    int nlev, unsigned ntile, double scale, double offset, int sbe, int dbe, int band, FieldTab tab) {
   typedef typename Row2<TS>::type row2;
   extern __shared__ double sw[];                    // sw[3][64] | soff[3][64] | tile[nlev][65] in the destination type
   uint32_t *soff = (uint32_t *)(sw + 192);
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
   __syncthreads();
   const int half = lane >> 5, sl = lane & 31;
-  const TS *sf = src + (int64_t)f * nlev * nsrc;
+  const TS *sf = mpg_field_src(tab, src, f, (int64_t)nlev * nsrc);
+  if constexpr (EPI) offset = mpg_field_off(tab, f, offset);
   for (int kb = 0; kb < nlev; kb += 64) {
     // Branch-free body (a divergent `mapped ?` / `level < nlev ?` made the compiler wait for each point's three loads before
     // it issued the next point's): lanes past the end of a row are clamped onto its last two levels and re-write the
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
   }
   __syncthreads();
-  TD *df = dst + (int64_t)f * nlev * P + p0;
+  TD *df = mpg_field_dst(tab, dst, f, (int64_t)nlev * P) + p0;
   if (p0 + lane < P)
     for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + lane);
 }
@@ -235,14 +238,15 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
                                                          const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                          const double *__restrict__ val, const TS *__restrict__ src,
                                                          TD *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast, int nblk,
-                                                         double scale, double offset, int sbe, int dbe) {
+                                                         double scale, double offset, int sbe, int dbe, FieldTab tab) {
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
   unsigned blk = blockIdx.x % nblk;
   int fld = blockIdx.x / nblk;
   int64_t p = (int64_t)blk * 256 + threadIdx.x;
   if (p >= P) return;
-  const TS *sf = src + (int64_t)fld * nlev * nsrc;
-  TD *df = dst + (int64_t)fld * nlev * P;
+  const TS *sf = mpg_field_src(tab, src, fld, (int64_t)nlev * nsrc);
+  TD *df = mpg_field_dst(tab, dst, fld, (int64_t)nlev * P);
+  offset = mpg_field_off(tab, fld, offset);
   if constexpr (NNZ == 0) {
     for (int k = 0; k < nlev; ++k) {
       double acc = 0.0;
@@ -322,7 +326,7 @@ static bool lf_rows_fits(const mpg_handle_s *h, size_t dst_size, int nlev) {
 
 template <typename TS, typename TD, bool SWZ>
 static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, int nfields, void *dst, double scale, double offset, int sbe,
-                        int dbe, hipStream_t s) {
+                        int dbe, hipStream_t s, const FieldTab &tab) {
   int64_t P = h->n_dst;
   int lev_fast = layout == MPG_LAYOUT_LEV_FAST && nlev > 1;
   if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3) {
@@ -331,7 +335,7 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
       const unsigned ntile = (unsigned)((P + 63) / 64);
       auto fn = k_apply3_lf_rows<TS, TD, sizeof(TS) == 4 ? 2 : 1, true, SWZ>;   // measured: unroll 2 for float32 rows, 1 for float64
       if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, scale, offset, sbe, dbe, mpg_field_band(LF_ROWS_BAND));
+      fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, scale, offset, sbe, dbe, mpg_field_band(LF_ROWS_BAND), tab);
     } else if (lev_fast) {
       size_t lds = sizeof(TD) * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192;
       if (lds > 160 * 1024) {
@@ -342,11 +346,11 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
       if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int ntxs = mpg_tile_ntx(h->nx_dst, 64), nty = h->ny_dst;
       fn<<<(unsigned)ntxs * nty * nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst, h->ny_dst, h->n_src, nlev, ntxs, nty,
-                                                         scale, offset, sbe, dbe);
+                                                         scale, offset, sbe, dbe, tab);
     } else {
       int ntx = mpg_tile_ntx(h->nx_dst, 64), nty = (h->ny_dst + 7) / 8;
       k_apply3_cf_t<TS, TD, SWZ><<<(unsigned)ntx * nty * nfields, 256, 0, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst, h->ny_dst,
-                                                                              h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe);
+                                                                              h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe, tab);
     }
   } else {
     int nblk = (int)((P + 255) / 256);
@@ -357,7 +361,7 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
       return MPG_ERR_UNSUPPORTED;
     }
     fn<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, h->rowptr.p, h->col.p, h->val.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev,
-                                               layout == MPG_LAYOUT_LEV_FAST, nblk, scale, offset, sbe, dbe);
+                                               layout == MPG_LAYOUT_LEV_FAST, nblk, scale, offset, sbe, dbe, tab);
   }
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
@@ -372,22 +376,22 @@ int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfiel
   const unsigned ntile = (unsigned)((P + 63) / 64);
   auto fn = k_apply3_lf_rows<double, double, 1, false, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, 1.0, 0.0, 0, 0, mpg_field_band(LF_ROWS_BAND));
+  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, 1.0, 0.0, 0, 0, mpg_field_band(LF_ROWS_BAND), FieldTab());
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
 
 template <bool SWZ>
 static int launch_typed_types(mpg_handle_s *h, const void *src, int sf32, int layout, int nlev, int nfields, void *dst, int df32, double scale,
-                              double offset, int sbe, int dbe, hipStream_t s) {
-  if (sf32 && df32) return launch_typed<float, float, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (sf32) return launch_typed<float, double, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  if (df32) return launch_typed<double, float, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s);
-  return launch_typed<double, double, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s);
+                              double offset, int sbe, int dbe, hipStream_t s, const FieldTab &tab) {
+  if (sf32 && df32) return launch_typed<float, float, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  if (sf32) return launch_typed<float, double, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  if (df32) return launch_typed<double, float, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  return launch_typed<double, double, SWZ>(h, src, layout, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
 }
 
 int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,
-                      double scale, double offset, hipStream_t s) {
+                      double scale, double offset, hipStream_t s, const FieldTab &tab) {
   if (h->n_dst == 0 || nlev == 0 || nfields == 0) return MPG_SUCCESS;
   const int sf32 = src_type & MPG_TYPE_F32, df32 = dst_type & MPG_TYPE_F32;
   const int sbe = (src_type & MPG_TYPE_BE) != 0, dbe = (dst_type & MPG_TYPE_BE) != 0;
@@ -396,6 +400,7 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout
       mpg_set_error("mpg_regrid_typed: handle without sources and a non-zero offset is not supported");
       return MPG_ERR_UNSUPPORTED;
     }
+    if (tab.n) return MPG_ERR_UNSUPPORTED;   // (mpg_regrid_bundle_typed_dev serves such a handle field by field)
     MPG_HIP(hipMemsetAsync(dst, 0, (df32 ? 4 : 8) * (size_t)h->n_dst * nlev * nfields, s));
     return MPG_SUCCESS;
   }
@@ -415,7 +420,7 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout
       if (!fits) staged = -2;
     }
     if (staged >= 0) {
-      rc = mpg_k_apply3_cfu(h, staged, src, sf32, nlev, nfields, dst, df32, true, scale, offset, s);
+      rc = mpg_k_apply3_cfu(h, staged, src, sf32, nlev, nfields, dst, df32, true, scale, offset, s, tab);
       if (rc != MPG_ERR_UNSUPPORTED) return rc;
     }
   }
@@ -426,13 +431,13 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout
       if (long_bundle && (rc = mpg_lfu_auto(h, s, &lfv))) return rc;
     }
     if (lfv == MPG_LF_STAGED) {
-      rc = mpg_k_apply3_lfu_typed(h, src, src_type, nlev, nfields, dst, dst_type, scale, offset, s);
+      rc = mpg_k_apply3_lfu_typed(h, src, src_type, nlev, nfields, dst, dst_type, scale, offset, s, tab);
       if (rc != MPG_ERR_UNSUPPORTED) return rc;
     }
   }
-  int rc = (sbe || dbe) ? launch_typed_types<true>(h, src, sf32, layout, nlev, nfields, dst, df32, scale, offset, sbe, dbe, s)
-                        : launch_typed_types<false>(h, src, sf32, layout, nlev, nfields, dst, df32, scale, offset, 0, 0, s);
-  if (rc == MPG_SUCCESS && h->n_pole) rc = mpg_k_pole_fix(h, src, src_type, layout, nlev, nfields, dst, dst_type, scale, offset, s);
+  int rc = (sbe || dbe) ? launch_typed_types<true>(h, src, sf32, layout, nlev, nfields, dst, df32, scale, offset, sbe, dbe, s, tab)
+                        : launch_typed_types<false>(h, src, sf32, layout, nlev, nfields, dst, df32, scale, offset, 0, 0, s, tab);
+  if (rc == MPG_SUCCESS && h->n_pole) rc = mpg_k_pole_fix(h, src, src_type, layout, nlev, nfields, dst, dst_type, scale, offset, s, tab);
   return rc;
 }
 

@@ -5,6 +5,9 @@
 // (model_grid.F90:446-497 mesh definition: coordinate conversion :450-454,464-468, element corner
 // count :448, connectivity :474-485; grid staggers :736-1038).  The reference's two quadratic host
 // loops (unique_sort :2160-2178, FINDLOC :480) are unnecessary here: node ids are used directly.
+// No floating-point contraction in this translation unit (see k_store_conserve.hip): what it computes -- weights, coordinates --
+// is a function of the source text, not of which product the compiler chooses to fuse; explicit fma() calls stay what they are.
+#pragma clang fp contract(off)
 #include "geom.h"
 #include "mpg_internal.h"
 

@@ -12,6 +12,9 @@
 // A second pass (one thread per target point) recomputes the weights of the winning triangle and
 // stores them SoA ([3][P]) for the coalesced apply kernel.  No sort, no hash, no fallback path:
 // cost is O(T log P + P) and the traversal is exact for any mesh (no Delaunay assumption).
+// No floating-point contraction in this translation unit (see k_store_conserve.hip): what it computes -- weights, coordinates --
+// is a function of the source text, not of which product the compiler chooses to fuse; explicit fma() calls stay what they are.
+#pragma clang fp contract(off)
 #include "geom.h"
 #include <algorithm>
 

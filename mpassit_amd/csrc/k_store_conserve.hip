@@ -20,6 +20,13 @@
 
 #include <rocprim/rocprim.hpp>
 
+// No floating-point contraction in this translation unit (the geometry helpers of geom.h included): a weight is a ratio of
+// areas that moves by 1e-13..1e-12 of itself when ONE product of an intersection point is fused into an FMA or not, and which
+// product the compiler fuses changes with unrelated edits (measured in round 4: carrying a dot product from one polygon edge to
+// the next changed 74 % of configuration 4's weights in their last digits).  With the products and sums as written -- the
+// oracle is compiled the same way, -ffp-contract=off -- the stored matrix is a function of the source text alone.
+#pragma clang fp contract(off)
+
 #include "geom.h"
 #include "mpg_internal.h"
 

@@ -6,6 +6,9 @@
 // unit sphere; stagger points outside the hull of the centres (outer half-cell ring) are unmapped -> 0.
 // The structured source needs no search: a U point (i-1/2, j) can only lie in quads (i-1, j-1) or
 // (i-1, j); a V point (i, j-1/2) in quads (i-1, j-1) or (i, j-1).  Lowest quad id wins on shared edges.
+// No floating-point contraction in this translation unit (see k_store_conserve.hip): what it computes -- weights, coordinates --
+// is a function of the source text, not of which product the compiler chooses to fuse; explicit fma() calls stay what they are.
+#pragma clang fp contract(off)
 #include "geom.h"
 #include "mpg_internal.h"
 

@@ -12,6 +12,9 @@
 // Pure ALU + transcendental work, a few MB written once: nowhere near any roofline, it only has to be off the host.
 // Floating point: contraction is switched off so the arithmetic is the reference's operation for operation; the
 // device libm (atan2/pow/tan/...) may differ from the host's in the last bit, the parity test allows 1e-12 degrees.
+// No floating-point contraction in this translation unit (see k_store_conserve.hip): what it computes -- weights, coordinates --
+// is a function of the source text, not of which product the compiler chooses to fuse; explicit fma() calls stay what they are.
+#pragma clang fp contract(off)
 #include <math.h>
 #include <string.h>
 

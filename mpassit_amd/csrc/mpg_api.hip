@@ -699,6 +699,36 @@ int mpg_regrid_typed_dev(mpg_handle h, const void *src_dev, int src_type, int sr
   return mpg_k_apply_typed(h, src_dev, src_type, src_layout, nlev, nfields, dst_dev, dst_type, scale, offset, (hipStream_t)hip_stream);
 }
 
+int mpg_regrid_bundle_typed_dev(mpg_handle h, int nfields, const void *const *src_dev, int src_type, int src_layout, int nlev,
+                                void *const *dst_dev, int dst_type, double scale, const double *offsets, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h && src_dev && dst_dev, "mpg_regrid_bundle_typed: NULL argument");
+  MPG_ARG(nlev >= 1 && nfields >= 1, "mpg_regrid_bundle_typed: nlev and nfields must be >= 1");
+  MPG_ARG(src_layout == MPG_LAYOUT_CELL_FAST || src_layout == MPG_LAYOUT_LEV_FAST, "mpg_regrid_bundle_typed: bad src_layout");
+  MPG_ARG(src_type >= 0 && src_type <= 3 && dst_type >= 0 && dst_type <= 3, "mpg_regrid_bundle_typed: src_type / dst_type must be MPG_TYPE_F64 or MPG_TYPE_F32, optionally | MPG_TYPE_BE");
+  for (int f = 0; f < nfields; ++f) MPG_ARG(dst_dev[f] && (src_dev[f] || h->n_src == 0), "mpg_regrid_bundle_typed: NULL field pointer");
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (nfields == 1 || h->n_src == 0 || h->n_dst == 0) {   // nothing to share between fields: the plain call, field by field
+    for (int f = 0; f < nfields; ++f) {
+      int rc = mpg_k_apply_typed(h, src_dev[f], src_type, src_layout, nlev, 1, dst_dev[f], dst_type, scale, offsets ? offsets[f] : 0.0, s);
+      if (rc) return rc;
+    }
+    return MPG_SUCCESS;
+  }
+  for (int f0 = 0; f0 < nfields; f0 += MPG_TAB_MAX) {   // the pointers travel in the kernels' argument blocks, MPG_TAB_MAX fields per launch
+    FieldTab tab;
+    tab.n = std::min(MPG_TAB_MAX, nfields - f0);
+    for (int k = 0; k < tab.n; ++k) {
+      tab.src[k] = src_dev[f0 + k];
+      tab.dst[k] = dst_dev[f0 + k];
+      tab.off[k] = offsets ? offsets[f0 + k] : 0.0;
+    }
+    int rc = mpg_k_apply_typed(h, nullptr, src_type, src_layout, nlev, tab.n, nullptr, dst_type, scale, 0.0, s, tab);
+    if (rc) return rc;
+  }
+  return MPG_SUCCESS;
+}
+
 int mpg_regrid(mpg_handle h, const double *src_host, int src_layout, int nlev, int nfields, double *dst_host) {
   MPG_CHECK_INIT();
   MPG_ARG(h && src_host && dst_host, "mpg_regrid: NULL argument");

@@ -345,9 +345,32 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
 int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, hipStream_t s);
 int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s, bool whole = true);
 int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nfields, double *dst, hipStream_t s);
+// The fields of a bundle as separate allocations (mpg_regrid_bundle_typed_dev: an ESMF field bundle holds separate arrays): up
+// to MPG_TAB_MAX device pointers on either side and one epilogue offset per field, handed to the Regrid kernels BY VALUE -- in
+// their argument block, so there is no table in device memory to allocate, to keep alive or to race on, and a launch can be
+// captured in a hipGraph like any other; a longer bundle goes out as several launches of MPG_TAB_MAX fields.  n = 0: the fields
+// are consecutive slabs behind src / dst, as everywhere else.  A kernel reads its own field's entries (scalar loads, the field
+// index is uniform in a workgroup) where it would otherwise have added f * slab to the base.
+#define MPG_TAB_MAX 16
+struct FieldTab {
+  const void *src[MPG_TAB_MAX];
+  void *dst[MPG_TAB_MAX];
+  double off[MPG_TAB_MAX];
+  int n;
+  __host__ __device__ FieldTab() : src{}, dst{}, off{}, n(0) {}
+};
+template <typename TS>
+__device__ __forceinline__ const TS *mpg_field_src(const FieldTab &t, const TS *src, int f, int64_t slab) {
+  return t.n ? (const TS *)t.src[f] : src + (int64_t)f * slab;
+}
+template <typename TD>
+__device__ __forceinline__ TD *mpg_field_dst(const FieldTab &t, TD *dst, int f, int64_t slab) {
+  return t.n ? (TD *)t.dst[f] : dst + (int64_t)f * slab;
+}
+__device__ __forceinline__ double mpg_field_off(const FieldTab &t, int f, double offset) { return t.n ? t.off[f] : offset; }
 // src_type / dst_type below: MPG_TYPE_F64 / MPG_TYPE_F32, optionally | MPG_TYPE_BE (include/mpassit_amd.h)
 int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,
-                      double scale, double offset, hipStream_t s);
+                      double scale, double offset, hipStream_t s, const FieldTab &tab = FieldTab());
 // "lf_variant" numbering of the level-fast 3-point Regrid
 enum { MPG_LF_ROWS = 0, MPG_LF_STAGED = 1, MPG_LF_ROWTILES = 2 };
 #ifndef MPG_LF_STAGED_DEFAULT
@@ -359,10 +382,10 @@ enum { MPG_LF_ROWS = 0, MPG_LF_STAGED = 1, MPG_LF_ROWTILES = 2 };
 #define MPG_STAGE_MIN_LEVELS 8
 int mpg_cfu_num_variants();
 int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32, int nlev, int nfields, void *dst, int dst_f32, bool epi,
-                     double scale, double offset, hipStream_t s);
+                     double scale, double offset, hipStream_t s, const FieldTab &tab = FieldTab());
 int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
-                           double offset, hipStream_t s);
+                           double offset, hipStream_t s, const FieldTab &tab = FieldTab());
 int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s);
 int mpg_a3_staged();  // current "a3_staged" knob
 int mpg_lf_variant(); // current "lf_variant" knob
@@ -371,7 +394,7 @@ int mpg_cfu_fits(mpg_handle_s *h, int variant, hipStream_t s, int *fits);
 int mpg_cfu_auto(mpg_handle_s *h, hipStream_t s, int *cfu_variant);  // -> variant index or -1 (use k_apply3_cf)
 int mpg_lfu_auto(mpg_handle_s *h, hipStream_t s, int *lf_variant);   // -> MPG_LF_ROWS or the staged default
 int mpg_k_pole_fix(mpg_handle_s *h, const void *src, int src_type, int layout, int nlev, int nfields, void *dst, int dst_type,
-                   double scale, double offset, hipStream_t s);
+                   double scale, double offset, hipStream_t s, const FieldTab &tab = FieldTab());
 int mpg_k_bswap(void *buf, int64_t n, int elem_size, hipStream_t s);
 int mpg_k_post_cast(const double *src, int64_t n, double scale, double offset, float *dst, int dst_be, hipStream_t s);
 int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, int dst_be, hipStream_t s);

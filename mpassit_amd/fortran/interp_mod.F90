@@ -99,10 +99,66 @@ contains
     type(c_ptr), intent(in) :: rh
     type(bundle_t), intent(inout) :: b
     integer :: i
+    if (dev_flow .and. b%n > 1) then
+      call regrid_bundle_dev(rh, b)
+      return
+    end if
     do i = 1, b%n
       call regrid_field(rh, b%f(i))
     end do
   end subroutine regrid_bundle
+
+  !> Device flow: the fields of the bundle that agree in level count and element types go through ONE Regrid
+  !! (mpg_regrid_bundle_typed_dev over their separate device arrays, per-field epilogue offsets), as the reference's
+  !! ESMF_FieldBundleRegrid does; the same bits as field-by-field calls, one launch instead of b%n.
+  subroutine regrid_bundle_dev(rh, b)
+    type(c_ptr), intent(in) :: rh
+    type(bundle_t), intent(inout), target :: b
+    integer(c_int64_t) :: n_src, n_dst, nnz
+    integer(c_int) :: nxd, nyd, npr, layout
+    integer :: i, j, ng
+    logical :: done(b%n)
+    type(c_ptr) :: sp(b%n), dp(b%n)
+    real(c_double) :: offs(b%n)
+    type(field_t), pointer :: f, g
+    call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+    do i = 1, b%n                                   ! what regrid_field does before its call
+      f => b%f(i)
+      if (allocated(f%dst)) deallocate (f%dst)
+      if (allocated(f%dst4)) deallocate (f%dst4)
+      if (c_associated(f%dst_dev)) call mpg_check(mpg_dev_free(f%dst_dev), "IN dev_free")
+      f%dst_is_f32 = .not. keeps_r8(f)
+      f%dst_is_be = f%dst_is_f32
+      f%n_dst_elems = n_dst*f%nlev
+      call mpg_check(mpg_dev_alloc(f%n_dst_elems*merge(4, 8, f%dst_is_f32), f%dst_dev), "IN dev_alloc "//trim(f%name))
+    end do
+    done = .false.
+    do i = 1, b%n
+      if (done(i)) cycle
+      f => b%f(i)
+      ng = 0
+      do j = i, b%n
+        g => b%f(j)
+        if (done(j) .or. g%nlev /= f%nlev .or. (g%src_is_f32 .neqv. f%src_is_f32) .or. (g%src_is_be .neqv. f%src_is_be) .or. &
+            (g%dst_is_f32 .neqv. f%dst_is_f32) .or. (g%dst_is_be .neqv. f%dst_is_be)) cycle
+        ng = ng + 1
+        sp(ng) = g%src_dev
+        dp(ng) = g%dst_dev
+        offs(ng) = 0.0_c_double
+        if (g%dst_is_f32 .and. wrf_mod_vars .and. trim(g%tname) == 'T') offs(ng) = -300.0_c_double
+        done(j) = .true.
+      end do
+      layout = MPG_LAYOUT_LEV_FAST
+      if (f%nlev == 1) layout = MPG_LAYOUT_CELL_FAST
+      call mpg_check(mpg_regrid_bundle_typed_dev(rh, int(ng, c_int), sp, elem_type(f%src_is_f32, f%src_is_be), layout, int(f%nlev, c_int), &
+                                                 dp, elem_type(f%dst_is_f32, f%dst_is_be), 1.0_c_double, offs, c_null_ptr), &
+                     "IN FieldBundleRegrid "//trim(f%name))
+    end do
+    do i = 1, b%n                                   ! the sources are not needed again
+      call mpg_check(mpg_dev_free(b%f(i)%src_dev), "IN dev_free")
+      b%f(i)%src_dev = c_null_ptr
+    end do
+  end subroutine regrid_bundle_dev
 
   subroutine regrid_field(rh, f)
     type(c_ptr), intent(in) :: rh

@@ -156,6 +156,19 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid_typed_dev
 
+    !> ESMF_FieldBundleRegrid over the SEPARATE device arrays of a bundle's fields (interp.F90:240-254): one launch for all of
+    !! them, offsets(nfields) = the epilogue offset of each field
+    function mpg_regrid_bundle_typed_dev(rh, nfields, src, src_f32, src_layout, nlev, dst, dst_f32, scale, offsets, stream) &
+      bind(C, name="mpg_regrid_bundle_typed_dev") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: rh, stream
+      integer(c_int), value :: nfields, src_f32, src_layout, nlev, dst_f32
+      type(c_ptr), intent(in) :: src(*), dst(*)
+      real(c_double), value :: scale
+      real(c_double), intent(in) :: offsets(*)
+      integer(c_int) :: rc
+    end function mpg_regrid_bundle_typed_dev
+
     function mpg_rotate_winds_dev(npts, nlev, cosa, sina, u, v, stream) bind(C, name="mpg_rotate_winds_dev") result(rc)
       import :: c_int, c_int64_t, c_ptr
       integer(c_int64_t), value :: npts

@@ -282,6 +282,35 @@ class RouteHandle:
                                             _stream_ptr()))
         return out
 
+    def regrid_bundle(self, srcs, nlev=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offsets=None, outs=None, src_be=False, dst_be=False):
+        """ESMF_FieldBundleRegrid over SEPARATE field arrays (interp.F90:240-254; mpg_regrid_bundle_typed_dev): srcs = device
+        tensors of nlev * n_src elements each, one dtype; one launch for all of them, per-field epilogue offsets.  Returns the
+        list of results [nlev][ny][nx] (outs: tensors to write into)."""
+        import torch
+        nf = len(srcs)
+        if nf == 0:
+            return []
+        dt = srcs[0].dtype
+        for t in srcs:
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == dt and dt in (torch.float32, torch.float64)):
+                raise ValueError("regrid_bundle needs contiguous CUDA tensors of one float32 / float64 dtype")
+            if t.numel() != nlev * self.n_src:
+                raise ValueError("a source has %d elements, handle expects %d" % (t.numel(), nlev * self.n_src))
+        out_dtype = out_dtype or dt
+        if outs is None:
+            outs = [torch.empty((nlev, self.ny_dst, self.nx_dst), dtype=out_dtype, device=srcs[0].device) for _ in range(nf)]
+        for t in outs:
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == outs[0].dtype and t.numel() == nlev * self.n_dst):
+                raise ValueError("regrid_bundle: bad destination tensor")
+        _account_regrid(self, nlev, nf, srcs[0].element_size(), outs[0].element_size())
+        sp = (C.c_void_p * nf)(*[t.data_ptr() for t in srcs])
+        dp = (C.c_void_p * nf)(*[t.data_ptr() for t in outs])
+        op = None if offsets is None else (C.c_double * nf)(*[float(o) for o in offsets])
+        check(L.load().mpg_regrid_bundle_typed_dev(self._h, C.c_int(nf), sp, C.c_int(int(dt == torch.float32) | (2 if src_be else 0)), C.c_int(layout),
+                                                   C.c_int(nlev), dp, C.c_int(int(outs[0].dtype == torch.float32) | (2 if dst_be else 0)),
+                                                   C.c_double(scale), op, _stream_ptr()))
+        return outs
+
     def regrid_typed_host(self, src, nlev=1, nfields=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offset=0.0, out=None):
         """The same on numpy arrays (mpg_regrid_typed): float32 / float64 host buffers cross PCIe as they are, chunks of
         levels are uploaded, regridded and downloaded concurrently.  Returns [nfields][nlev][ny][nx] of out_dtype."""

@@ -117,6 +117,35 @@ int main(void) {
         return 1;
       }
     }
+    /* ---- the same field twice as a bundle of separate arrays, one epilogue offset each (ESMF_FieldBundleRegrid) ---- */
+    {
+      void *d2_dev;
+      unsigned char be2[NY * NX * 4];
+      CHECK(mpg_dev_alloc(NY * NX * 4, &d2_dev));
+      const void *srcs[2] = {s_dev, s_dev};
+      void *dsts[2] = {d_dev, d2_dev};
+      const double offs[2] = {-300.0, -299.0};
+      CHECK(mpg_regrid_bundle_typed_dev(rh, 2, srcs, MPG_TYPE_F32 | MPG_TYPE_BE, MPG_LAYOUT_CELL_FAST, 1, dsts, MPG_TYPE_F32 | MPG_TYPE_BE, 1.0, offs, NULL));
+      CHECK(mpg_dev_download(be2, d_dev, NY * NX * 4));
+      if (memcmp(be2, be_out, NY * NX * 4) != 0) {
+        fprintf(stderr, "FAIL bundle Regrid: field 0 differs from the single call\n");
+        return 1;
+      }
+      CHECK(mpg_dev_download(be2, d2_dev, NY * NX * 4));
+      for (int p = 0; p < NY * NX; ++p) {
+        unsigned char raw[4];
+        float v, v0;
+        for (int b = 0; b < 4; ++b) raw[b] = be2[4 * p + 3 - b];
+        memcpy(&v, raw, 4);
+        for (int b = 0; b < 4; ++b) raw[b] = be_out[4 * p + 3 - b];
+        memcpy(&v0, raw, 4);
+        if (v != v0 + 1.0f) {
+          fprintf(stderr, "FAIL bundle Regrid: point %d = %.9g, expected %.9g\n", p, v, v0 + 1.0f);
+          return 1;
+        }
+      }
+      CHECK(mpg_dev_free(d2_dev));
+    }
     /* ---- source range and source window: all four cells are referenced; the whole mesh is the only window that fits ---- */
     int64_t first = -1, end = -1;
     CHECK(mpg_handle_source_range(rh, &first, &end));
