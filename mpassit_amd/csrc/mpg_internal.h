@@ -351,7 +351,7 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
 // captured in a hipGraph like any other; a longer bundle goes out as several launches of MPG_TAB_MAX fields.  n = 0: the fields
 // are consecutive slabs behind src / dst, as everywhere else.  A kernel reads its own field's entries (scalar loads, the field
 // index is uniform in a workgroup) where it would otherwise have added f * slab to the base.
-#define MPG_TAB_MAX 16
+#define MPG_TAB_MAX 32
 struct FieldTab {
   const void *src[MPG_TAB_MAX];
   void *dst[MPG_TAB_MAX];

@@ -39,7 +39,7 @@ def test_bundle_of_separate_fields_equals_single_calls(gpu_lib, regional_case):
                 gpu_lib.tune("lf_variant", variant)
                 for sdt, ddt in ((f32, f32), (f32, f64), (f64, f32), (f64, f64)):
                     _check(rb, R, torch, 17, 3, layout, sdt, ddt)
-                _check(rb, R, torch, 55, 19, layout, f32, f32, be=True)          # more than one table chunk, big-endian
+                _check(rb, R, torch, 55, 35, layout, f32, f32, be=True)          # more than one table chunk, big-endian
             gpu_lib.tune("lf_variant", -1)
             for staged in (-2, 0, 2):
                 gpu_lib.tune("a3_staged", staged)
