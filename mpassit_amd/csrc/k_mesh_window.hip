@@ -251,7 +251,9 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
   double delta = 6.0 * h_grid;
   bool spacing_known = false;
   for (int attempt = 0;; ++attempt) {
-    bool whole = attempt >= 6 || delta >= 2.0;
+    // (a mesh of a few dozen cells is taken whole: nothing to gain, and a grid inside ONE of its cells can be further than any
+    // margin tried here from every cell centre -- it would look like a grid off the mesh)
+    bool whole = attempt >= 6 || delta >= 2.0 || nC < 64;
     int64_t c0 = 0, c1 = nC;
     if (!whole) {
       MPG_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(unsigned long long), s));

@@ -138,3 +138,24 @@ def test_scattered_numbering_and_a_coarse_mesh_under_a_fine_grid(gpu_lib, global
     assert (want["bilinear"][0] >= 0).all()                        # every point of the fine grid sits in a (huge) triangle
     mesh.destroy()
     grid.destroy()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_a_small_grid_inside_one_cell_of_a_very_coarse_mesh(gpu_lib, level):
+    """12 / 42 / 162 cells on the globe (7 000 / 3 700 / 1 900-km spacing) and a 30 x 20-point grid of 5-km cells placed between
+    cell centres: every centre is further from the grid than any margin a window starts from -- the grid must not be taken to
+    lie off the mesh (an empty window, empty weights) but be served by the cells around it, as on the whole mesh."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    m = synth.icosahedral_mesh(level)
+    for ref_lat, ref_lon in ((31.7, -58.3), (-12.0, 77.0), (64.0, 10.0)):
+        g = tg.define_target_grid_params("lambert", 31, 21, dx=5000.0, dy=5000.0, ref_lat=ref_lat, ref_lon=ref_lon, truelat1=ref_lat, truelat2=ref_lat,
+                                         stand_lon=ref_lon)
+        grid = R.Grid.from_target(g)
+        whole = R.Mesh.from_mpas(m)
+        want = _weights(R, whole, grid)
+        whole.destroy()
+        mesh = R.Mesh.from_mpas(m, window_grid=grid)
+        _same(_weights(R, mesh, grid), want)
+        assert (want["bilinear"][0] >= 0).all() and (want["nearest"][0] >= 0).all() and want["conserve"][1].size > 0
+        mesh.destroy()
+        grid.destroy()
