@@ -74,7 +74,7 @@ def main():
             torch.cuda.synchronize()
             if rnd > 0:
                 times[v].append(e0.elapsed_time(e1) / 3)
-    _lib.tune(knob, {"nn_variant": 1}.get(knob, -1))
+    _lib.tune(knob, {"nn_variant": 1, "store_boxes": 1}.get(knob, -1))
     res = []
     for v, ts in times.items():
         med, mn = float(np.median(ts)), float(np.min(ts))
