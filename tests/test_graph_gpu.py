@@ -65,9 +65,12 @@ def test_regrid_sequence_is_graph_capturable(gpu_lib, regional_case):
     grid.destroy()
 
 
-def test_graphed_interp_replays_a_time_level(gpu_lib, regional_case):
+@pytest.mark.parametrize("file_order", [False, True])
+def test_graphed_interp_replays_a_time_level(gpu_lib, regional_case, file_order):
     """interp.GraphedInterp: the whole interp_data sequence (default lists, wrf_mod_vars, conservative + nearest + soil +
-    diag) as one graph; replays on new field values equal the eager pipeline bit for bit."""
+    diag) as one graph; replays on new field values equal the eager pipeline bit for bit.  file_order: float32 fields in MPAS
+    file order, as a driver holds them -- the bundles then go out as mpg_regrid_bundle_typed_dev launches (pointer tables in the
+    kernels' argument blocks), which must be capturable like any other launch."""
     import torch
 
     from test_fields import HIST_2D, HIST_3D, SOIL
@@ -79,8 +82,12 @@ def test_graphed_interp_replays_a_time_level(gpu_lib, regional_case):
     gen.manual_seed(5)
 
     def rnd(*shape):
-        return torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen)
-    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil, hgt=rnd(m.nCells))
+        t = torch.rand(shape, dtype=torch.float64, device="cuda", generator=gen)
+        if not file_order:
+            return t
+        return (t.t().contiguous() if t.ndim == 2 else t).float()       # [nCells][nlev] float32, as the file stores it
+    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil, hgt=torch.rand(m.nCells, dtype=torch.float64, device="cuda", generator=gen),
+                      layout=R.LAYOUT_LEV_FAST if file_order else R.LAYOUT_CELL_FAST)
     for n, _ in HIST_2D:
         inp.hist[n] = torch.floor(rnd(m.nCells) * 3) if n == "xland" else rnd(m.nCells)
     for n, _ in HIST_3D:
