@@ -74,6 +74,20 @@ __device__ __forceinline__ double boxdist2_nofma(double px, double py, double pz
 
 // A7: the 3-term weighted sum of every bilinear Regrid kernel, with the FMA pattern pinned so that all kernel
 // variants (cell-fast, level-fast, typed) produce bit-identical results
+// Pad (index units) of the index-space box of a figure E index units across whose vertices reach |z| = zmax on the unit sphere
+// (k_target_grid.hip: mpg_grid_box_pad_coef).  coef: Lambert, per E^2.  latlon > 0: a lat-lon grid with cells of `latlon` radians
+// -- the image of a great circle bends by tan(lat) * E_i * E_j * delta / 4 in i and sin cos(lat) * E_i^2 * delta / 8 in j; twice
+// their sum, with the latitude of the figure itself, so that figures at low latitudes get a tight box and figures near the poles
+// a wide one instead of no box at all.  0.05 covers the float32 indices.
+__device__ __forceinline__ float mpg_box_pad(float E, float coef, float latlon, double zmax) {
+  if (latlon > 0.f) {
+    const float z = fminf((float)zmax, 0.99999f);
+    const float tanl = z / sqrtf(1.f - z * z);
+    return 0.05f + E * E * latlon * (0.5f * tanl + 0.125f);
+  }
+  return 0.05f + coef * E * E;
+}
+
 __device__ __forceinline__ double wsum3(double w0, double a, double w1, double b, double w2, double e) {
   return fma(w2, e, fma(w1, b, w0 * a));
 }

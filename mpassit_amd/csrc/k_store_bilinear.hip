@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
                                                     const double *__restrict__ px, const double *__restrict__ py,
                                                     const double *__restrict__ pz, int32_t *__restrict__ owner,
                                                     int32_t *__restrict__ overflow, int32_t *__restrict__ big, int32_t *__restrict__ nbig,
-                                                    int big_cap, const float *__restrict__ sij, float di, float dj, float pad_coef, float e_max) {
+                                                    int big_cap, const float *__restrict__ sij, float di, float dj, float pad_coef, float pad_latlon, float e_max) {
   int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= nTri) return;
   int32_t ia = tri[t];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
   // projection of every source point, k_target_grid.hip; di / dj: offset of this stagger's point indices) bound the target points
   // it can hold -- a box of a few points around it, padded for the bend of its edges on the map and for the float32 indices.
   // Every point of the box gets the very test of the pyramid's leaves below, so the owners are the same; a triangle whose
-  // corners have no usable index (near the projection's pole or cut, poleward of 75 degrees on a lat-lon grid), that spans more
+  // corners have no usable index (near the projection's pole or cut, poleward of 85 degrees on a lat-lon grid), that spans more
   // than e_max index units (six degrees, sixteen units at most) or whose box holds more than 256 points takes the walk.
   if (sij) {
     const float ai = sij[2 * ia], aj = sij[2 * ia + 1], bi_ = sij[2 * ib], bj_ = sij[2 * ib + 1], ci_ = sij[2 * ic], cj_ = sij[2 * ic + 1];
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
     const float E = fmaxf(imax - imin, jmax - jmin);
     const bool usable = ai == ai && aj == aj && bi_ == bi_ && bj_ == bj_ && ci_ == ci_ && cj_ == cj_;   // fminf / fmaxf skip a NaN corner
     if (usable && E <= e_max) {
-      const float pad = 0.05f + pad_coef * E * E;
+      const float pad = mpg_box_pad(E, pad_coef, pad_latlon, fmax(fabs(A.z), fmax(fabs(B.z), fabs(C.z))));
       const int i0 = max((int)ceilf(imin + di - pad), 0), i1 = min((int)floorf(imax + di + pad), npx - 1);
       const int j0 = max((int)ceilf(jmin + dj - pad), 0), j1 = min((int)floorf(jmax + dj + pad), npy - 1);
       if (i0 > i1 || j0 > j1) return;   // off the grid
@@ -353,7 +353,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   }
   if (nT > 0) {
     raster<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(nT, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p, pts.z.p,
-                                                       owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap, sijp, di, dj, (float)mpg_grid_box_pad_coef(g),
+                                                       owner.p, ovf.p, ovf.p + 2, ovf.p + 1, big_cap, sijp, di, dj, (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_pad_latlon(g),
                                                        (float)mpg_grid_box_emax(g));
     raster_big<<<1024, 256, 0, s>>>(ovf.p + 2, ovf.p + 1, big_cap, trip, nT, sx, sy, sz, mpg_pyr_view(g->pyr[stagger]), npx, npy, pts.x.p, pts.y.p,
                                    pts.z.p, owner.p, ovf.p);

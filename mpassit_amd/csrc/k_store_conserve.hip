@@ -44,8 +44,10 @@
 // 2, where all 22 204 referenced 30-km cells overflow under the 3-km grid.)
 #define CAND_CAP 24   // candidate destination cells per source cell kept by the candidate pass
 #define CONS_SPILL 256   // candidates per overflowed cell the cooperative count pass keeps for the list pass
+#define CONS_COOP_NT 64  // threads of a cooperative pass's workgroup.  Measured 64 / 128 / 256 / 512 (round 4): C5 8.31 / 8.46 / 10.3 / 15.4 ms,
+                         // C2 2.27 / 2.36 / 2.98 / 4.89 -- the passes are thousands of light polygons, not a few heavy ones: one wavefront each
 template <int MODE>
-__global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
+__global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_raster(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
                                                          const double *__restrict__ vx, const double *__restrict__ vy,
                                                          const double *__restrict__ vz, PyramidView pyr, int nx, int ny,
                                                          const double *__restrict__ qx, const double *__restrict__ qy,
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
                                                          int32_t *__restrict__ tmp_dst, int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
                                                          uint8_t *__restrict__ flip, const int32_t *__restrict__ poff,
                                                          int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p, const float *__restrict__ vij,
-                                                         float pad_coef, float e_max, int32_t *__restrict__ spill) {
+                                                         float pad_coef, float pad_latlon, float e_max, int32_t *__restrict__ spill) {
   // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
   constexpr bool COOP = MODE == 5 || MODE == 6;
   int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
     }
     const float E = fmaxf(imax - imin, jmax - jmin);
     if (!ok) {
-      // no usable index (poleward of 75 degrees on a lat-lon grid, the projection's pole / cut): such a polygon meets MANY thin
+      // no usable index (poleward of 85 degrees on a lat-lon grid, the projection's pole / cut): such a polygon meets MANY thin
       // destination cells, and one lane walking the pyramid for it kept its whole wavefront resident for milliseconds (C5: 4.5 ms
       // of this kernel at 15 waves per CU).  A workgroup each does it in the cooperative passes.
       const double *bx = pyr.box + 6 * pyr.off[pyr.nlev - 1];   // ... unless it does not even meet the grid's bounding box
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(128) void k_conserve_raster(int64_t nCells, int max
       return;
     }
     if (E <= e_max) {
-      const float pad = 0.05f + pad_coef * E * E;
+      const float pad = mpg_box_pad(E, pad_coef, pad_latlon, fmax(fabs(lo[2]), fabs(hi[2])));   // (the padded z range: a little poleward of the vertices)
       const int i0 = max((int)ceilf(imin - pad - 0.5f), 0), i1 = min((int)floorf(imax + pad + 0.5f), nx - 1);
       const int j0 = max((int)ceilf(jmin - pad - 0.5f), 0), j1 = min((int)floorf(jmax + pad + 0.5f), ny - 1);
       bool over = false;
@@ -574,7 +576,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
                                         qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
-                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_emax(g), nullptr);
+                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_pad_latlon(g), (float)mpg_grid_box_emax(g), nullptr);
   if (m->max_valence < 0) k_max_valence<<<(unsigned)std::min<int64_t>((nC + 255) / 256, 2048), 256, 0, s>>>(nC, m->maxEdges, m->voc.p, n_ovf.p + 1);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0, hv[2] = {0, 0};
@@ -584,10 +586,11 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (m->max_valence < 0) m->max_valence = hv[1];
   TmpBuf<int32_t> spill;
   if (novf > 0 && (rc = spill.alloc((size_t)novf * CONS_SPILL, s))) return rc;
+  const unsigned coop_nt = CONS_COOP_NT;
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
-    k_conserve_raster<5><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
+    k_conserve_raster<5><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr, nullptr, 0.f, 0.f, spill.p);
+                                                       nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, spill.p);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
   size_t tmp_bytes = 0, b2 = 0;
@@ -618,9 +621,9 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if ((rc = pair_c.alloc((size_t)npairs + 1, s)) || (rc = pair_p.alloc((size_t)npairs + 1, s)) || (rc = pair_val.alloc((size_t)npairs + 1, s))) return rc;
   k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
   if (novf > 0)
-    k_conserve_raster<6><<<(unsigned)novf, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
+    k_conserve_raster<6><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
-                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f, spill.p);
+                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f, 0.f, spill.p);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: the in-place step never lets a polygon gain more than one vertex per half-space (it reports the

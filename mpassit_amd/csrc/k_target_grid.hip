@@ -115,8 +115,8 @@ __host__ __device__ __forceinline__ double map_factor(const ProjDev &p, double l
 // :1365-1392), in the 0-based CENTER index space (projection coordinate - 1).  The Stores use it to find the handful of target
 // points around a source triangle / polygon directly instead of descending ten levels of the box pyramid; it only has to be
 // good to a fraction of a grid length (the callers pad their boxes and test every candidate point exactly as before).
-// Not usable -> NaN: within 1 degree of the Lambert pole or beyond 60 degrees into the other hemisphere; poleward of 75
-// degrees on a lat-lon grid (great circles bend too much in index space there).
+// Not usable -> NaN: within 1 degree of the Lambert pole or beyond 60 degrees into the other hemisphere; poleward of
+// latlon_limit degrees on a lat-lon grid (great circles bend too much in index space there).
 __global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, double latlon_limit, double i_center, int64_t n,
                                                    const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                    float *__restrict__ ij) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, double l
 // The index-space search rests on small-angle geometry: a figure a few index units across must span a few degrees at most, and a
 // destination cell's own great-circle edges must stay inside its index band (the edge between two lat-lon corners 90 degrees
 // of longitude apart rises by several degrees in between).  Grids coarser than 2 degrees / 200 km per cell, or whose cells'
-// edges bulge by more than 0.05 index units at 75 degrees, keep the pyramid search: it makes no such assumption.
+// edges bulge by more than 0.05 index units at the latitude the boxes are used to, keep the pyramid search: it makes no such assumption.
 bool mpg_grid_has_inverse(const mpg_grid_s *g) {
   if (!g->has_inverse) return false;
   const ProjDev &p = g->proj;
@@ -166,15 +166,16 @@ bool mpg_grid_has_inverse(const mpg_grid_s *g) {
   if (p.code == MPG_PROJ_LATLON) {
     const double dlon = fabs(p.loninc), dlat = fabs(p.latinc);
     if (dlon > 2.0 || dlat > 2.0) return false;
-    const double phi = 75.0 * TG_RAD_PER_DEG;
+    const double phi = MPG_LATLON_BOX_LIMIT * TG_RAD_PER_DEG;
     const double bulge = (atan(tan(phi) / cos(0.5 * dlon * TG_RAD_PER_DEG)) - phi) * TG_DEG_PER_RAD / dlat;
     return bulge <= 0.05;
   }
   return false;
 }
 
-// latlon_limit: the latitude (degrees) up to which a lat-lon grid's inverse is handed out -- 75 for the index BOXES of the Stores
-// (great-circle edges bend too much in index space beyond), higher for the nearest search, which only places points
+// latlon_limit: the latitude (degrees) up to which a lat-lon grid's inverse is handed out -- MPG_LATLON_BOX_LIMIT (85) for the index
+// BOXES of the Stores, whose pad follows the figure's latitude (geom.h mpg_box_pad); higher for the nearest search, which only
+// places points
 // unwrap_i: lat-lon indices are taken on the branch nearest to the grid's middle column instead of the reference's wrap rule
 int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit,
                     bool unwrap_i) {
@@ -230,10 +231,16 @@ double mpg_grid_box_emax(const mpg_grid_s *g) {
 // grid lengths long bends by ~ L^2 * (grid length / earth radius) / 8 times a factor below 1 from the map scale's gradient --
 // the coefficient is four times that.  Lat-lon (not conformal): the image of a great circle has coordinate curvature up to
 // ~ 2 tan(lat) * (dlon/ds) * (dlat/ds); over an arc spanning E_i x E_j index units that is a deviation of ~ tan(lat) * E_i * E_j *
-// delta / 4 radians = 0.93 * E^2 * delta index units at the 75 degrees the inverse is used to -- the coefficient is twice that.
+// delta / 4 radians -- it depends on the figure's latitude, so the kernels compute it per figure from mpg_grid_box_pad_latlon
+// (geom.h mpg_box_pad) and this coefficient is not used for lat-lon grids.
 double mpg_grid_box_pad_coef(const mpg_grid_s *g) {
   if (g->proj.code == MPG_PROJ_LC) return 0.5 / g->proj.rebydx;
   return 2.0 * fmax(fabs(g->proj.loninc), fabs(g->proj.latinc)) * TG_RAD_PER_DEG;
+}
+// radians per index unit of a lat-lon grid (0 for the other projections): the scale of the per-figure pad
+double mpg_grid_box_pad_latlon(const mpg_grid_s *g) {
+  if (g->proj.code != MPG_PROJ_LATLON) return 0.0;
+  return fmax(fabs(g->proj.loninc), fabs(g->proj.latinc)) * TG_RAD_PER_DEG;
 }
 
 // stagger: MPG_STAGGERLOC_*; snx x sny points of that stagger
@@ -431,7 +438,7 @@ int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t
   if ((rc = sp.alloc(3 * (size_t)ns, s)) || (rc = ij.alloc(2 * (size_t)ns, s)) || (rc = bad.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
   k_sample_points<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(n, step, c.x.p, c.y.p, c.z.p, sp.p, sp.p + ns, sp.p + 2 * ns);
-  k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, 75.0, (double)NAN, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
+  k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, MPG_LATLON_BOX_LIMIT, (double)NAN, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
   k_check_inverse<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(g->nx, g->ny, step, ij.p, bad.p);
   MPG_HIP(hipGetLastError());
   int32_t hbad = 0;

@@ -324,9 +324,11 @@ int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s);
 // false: this grid has no usable inverse at all (made from arrays, or a projection without one here)
 bool mpg_grid_has_inverse(const mpg_grid_s *g);
 int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t s);
-int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit = 75.0,
+#define MPG_LATLON_BOX_LIMIT 85.0   // degrees: up to here a lat-lon grid's index boxes serve the Stores (their pad follows the figure's latitude)
+int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit = MPG_LATLON_BOX_LIMIT,
                     bool unwrap_i = false);
 // safety margin (index units) around the index-space box of a figure whose vertices span `extent` index units
+double mpg_grid_box_pad_latlon(const mpg_grid_s *g);
 double mpg_grid_box_pad_coef(const mpg_grid_s *g);
 double mpg_grid_box_emax(const mpg_grid_s *g);
 double mpg_grid_min_index_chord(const mpg_grid_s *g, double lat_lo, double lat_hi, double margin);
