@@ -272,9 +272,10 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
         }
       }
       if (hs[1] == 0) {   // no cell within delta of the grid
-        if (attempt < 3 && delta < 0.5) {   // ... yet: a grid inside one large cell, or off the mesh -- look further (up to half a
-          delta = fmin(4.0 * delta, 0.5);   // radian) before concluding that the grid sees no cell
-          continue;
+        if (delta < 0.5) {                  // ... yet: a grid inside one large cell, or off the mesh -- look further, up to half a
+          delta = fmin(4.0 * delta, 0.5);   // radian however small the first margin was (a row of a fine polar grid under a coarse
+          --attempt;                        // mesh starts 400 times below the mesh's spacing), before concluding that the grid
+          continue;                         // sees no cell; these steps do not use up the closure's attempts
         }
         c0 = c1 = 0;
       } else {

@@ -159,3 +159,24 @@ def test_a_small_grid_inside_one_cell_of_a_very_coarse_mesh(gpu_lib, level):
         assert (want["bilinear"][0] >= 0).all() and (want["nearest"][0] >= 0).all() and want["conserve"][1].size > 0
         mesh.destroy()
         grid.destroy()
+
+
+def test_one_row_of_a_fine_polar_grid_under_a_coarse_mesh(gpu_lib):
+    """Found by tools/fuzz_soak.py: one row of a 0.11-degree lat-lon grid at 83 N (points 1.5 km apart along the row) under a
+    162-cell mesh (1 900-km spacing).  The window's first margin -- six grid lengths -- is four hundred times below the mesh's
+    spacing; the margin must keep growing (to half a radian) until it finds cells instead of giving up after three steps and
+    declaring the grid off the mesh (an empty window, all points unmapped)."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    for level, nx, ny, d, lat0 in ((2, 188, 27, 0.11, 81.36), (3, 48, 27, 0.117, 84.38)):
+        m = synth.icosahedral_mesh(level)
+        g = tg.define_target_grid_params("lat-lon", nx + 1, ny + 1, dx=d, dy=d, ref_lat=lat0, ref_lon=-40.0, ref_x=1.0, ref_y=1.0, stand_lon=0.0)
+        for rows in ((14, 15), (ny - 1, ny)):
+            grid = R.Grid.from_target(g, rows=rows)
+            whole = R.Mesh.from_mpas(m)
+            want = _weights(R, whole, grid)
+            whole.destroy()
+            mesh = R.Mesh.from_mpas(m, window_grid=grid)
+            _same(_weights(R, mesh, grid), want)
+            assert (want["bilinear"][0] >= 0).all() and want["conserve"][1].size > 0
+            mesh.destroy()
+            grid.destroy()

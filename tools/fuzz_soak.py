@@ -18,8 +18,25 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def random_grid(rng):
     from mpassit_amd import target_grid as T
-    kind = int(rng.integers(5))
+    kind = int(rng.integers(7))
     nx, ny = int(rng.integers(3, 160)), int(rng.integers(3, 100))
+    if kind == 5:      # a fine regional lat-lon grid that reaches the last degrees before a pole (the boxes' pad follows the latitude)
+        d = float(rng.uniform(0.05, 0.4))
+        south = rng.random() < 0.5
+        top = float(rng.uniform(84.0, 89.9))
+        ny = int(rng.integers(20, 120))
+        lat0 = top - d * (ny - 1)
+        if south:
+            lat0 = -top
+        return T.define_target_grid_params("lat-lon", int(rng.integers(40, 300)), ny, dx=d, dy=d, ref_lat=lat0, ref_lon=float(rng.uniform(-180, 180)),
+                                           ref_x=1.0, ref_y=1.0, stand_lon=0.0)
+    if kind == 6:      # a Lambert grid close to its pole
+        dx = float(rng.uniform(8e3, 60e3))
+        stand = float(rng.uniform(-180, 180))
+        lat = float(rng.uniform(70, 86)) * (-1 if rng.random() < 0.3 else 1)
+        t = float(rng.uniform(50, 80)) * (1 if lat > 0 else -1)
+        return T.define_target_grid_params("lambert", nx, ny, dx=dx, dy=dx, ref_lat=lat, ref_lon=stand + float(rng.uniform(-60, 60)), truelat1=t, truelat2=t,
+                                           stand_lon=stand)
     if kind in (0, 3):
         dx = float(rng.uniform(8e3, 150e3))
         stand = float(rng.uniform(-180, 180))
