@@ -90,6 +90,66 @@ def test_random_configuration(oracle, gpu_lib, case):
     grid.destroy()
 
 
+def _polar_grid(rng):
+    """Fine regional grids that reach the last degrees before a pole: lat-lon (the index boxes' pad follows the latitude, the
+    walk takes over beyond 85 degrees) and Lambert close to its pole."""
+    from mpassit_amd import target_grid as T
+    if rng.random() < 0.6:
+        d = float(rng.uniform(0.1, 0.4))
+        ny = int(rng.integers(12, 40))
+        top = float(rng.uniform(84.0, 89.8))
+        lat0 = top - d * (ny - 1)
+        if rng.random() < 0.5:
+            lat0 = -top
+        return T.define_target_grid_params("lat-lon", int(rng.integers(30, 120)), ny, dx=d, dy=d, ref_lat=lat0, ref_lon=float(rng.uniform(-180, 180)),
+                                           ref_x=1.0, ref_y=1.0, stand_lon=0.0)
+    dx = float(rng.uniform(15e3, 60e3))
+    lat = float(rng.uniform(72, 86)) * (-1 if rng.random() < 0.3 else 1)
+    t = float(rng.uniform(50, 80)) * (1 if lat > 0 else -1)
+    stand = float(rng.uniform(-180, 180))
+    return T.define_target_grid_params("lambert", int(rng.integers(20, 90)), int(rng.integers(15, 60)), dx=dx, dy=dx, ref_lat=lat,
+                                       ref_lon=stand + float(rng.uniform(-60, 60)), truelat1=t, truelat2=t, stand_lon=stand)
+
+
+@pytest.mark.parametrize("case", list(range(10)))
+def test_random_polar_configuration(oracle, gpu_lib, case):
+    """Global meshes under grids near a pole, the three weight sets against the oracle (mapped mask identical, weights to the
+    parity tolerances, nearest index identical up to distance ties)."""
+    from _parity_helpers import assert_csr_equal, conserve_tol
+    from mpassit_amd import regrid as R
+    rng = np.random.default_rng(7000 + case)
+    m = _mesh(rng, case % 3)                       # global Voronoi / variable resolution / icosahedral
+    g = _polar_grid(rng)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    cxyz, vxyz = mesh_xyz(oracle, m)
+    pts = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
+    tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    idx, w = oracle.bilinear_weights(cxyz, tri, pts)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    gi, gw = rh.weights()
+    assert np.array_equal(gi[:, 0] < 0, idx[:, 0] < 0)
+    src = rng.normal(size=(1, 3, m.nCells)) * 10 + 250
+    want = oracle.apply_fixed(idx, w, src[0], 3).reshape(3, g.ny, g.nx)
+    got = rh.regrid(src.reshape(-1), nlev=3, nfields=1)[0]
+    assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+    rh.release()
+    rn = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+    near_o, near_g = oracle.nearest(cxyz, pts), rn.weights()[0][:, 0]
+    diff = near_o != near_g
+    if diff.any():
+        assert np.abs(((cxyz[near_g[diff]] - pts[diff]) ** 2).sum(1) - ((cxyz[near_o[diff]] - pts[diff]) ** 2).sum(1)).max() <= 1e-14
+    rn.release()
+    rp, col, val = oracle.conserve(m.verticesOnCell, vxyz, g.nx, g.ny, oracle.lonlat_deg_to_xyz(g.lon_c, g.lat_c))
+    rc = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    snow = np.abs(src[0, :1]) + 1.0
+    want_c = oracle.apply_csr(rp, col, val, snow, 1)[0]
+    got_c = rc.regrid(snow, nlev=1).reshape(-1)
+    assert np.abs(got_c - want_c).max() <= max(1e-9, 10 * conserve_tol(oracle, g)) * max(1.0, np.abs(want_c).max())
+    rc.release()
+    mesh.destroy()
+    grid.destroy()
+
+
 @pytest.mark.parametrize("case", list(range(24)))
 def test_random_row_block_on_a_cut_mesh(gpu_lib, case):
     """The same random meshes and grids, a random block of target rows: the mesh cut to that block (mpg_mesh_create_window), with
