@@ -127,6 +127,17 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
   }
   hipStream_t s_up = g_pipe.s_up, s_k = g_pipe.s_k, s_down = g_pipe.s_down;
   std::vector<hipEvent_t> &up = res.up, &done = res.done;
+  // Only the cells the handle references cross the link: [a, b) = its source range (a regional grid under a global mesh reads a
+  // few per cent of the cells, a regional mesh that is larger than its grid loses its rim).  The device slab keeps its full
+  // pitch -- the kernels index cells as ever -- and what lies outside [a, b) is never read.  (The pole caps of a periodic
+  // Grid -> Grid handle read whole rows beside the indexed points: such a handle uploads everything.)
+  int64_t ra = 0, rb = (int64_t)ns;
+  if (ns > 0 && h->n_pole == 0) {
+    if ((rc = mpg_k_source_range(h, &ra, &rb, s_k))) return rc;
+    if (rb <= ra) ra = rb = 0;                                   // nothing mapped: nothing to upload
+    if ((double)(rb - ra) > 0.97 * (double)ns) { ra = 0; rb = (int64_t)ns; }   // not worth the extra copies
+  }
+  const bool trimmed = ra != 0 || rb != (int64_t)ns;
   std::atomic<int> produced{0}, consumed{0}, err{0};
   const int dev = mpg_device_index();
   std::thread down([&]() {
@@ -150,9 +161,24 @@ extern "C" int mpg_regrid_typed(mpg_handle h, const void *src_host, int src_f32,
   for (size_t c = 0; c < plan.size() && !rc && !err.load(); ++c) {
     const int q = (int)(c % nslot);
     while ((int)c >= nslot && consumed.load(std::memory_order_acquire) <= (int)c - nslot && !err.load()) std::this_thread::yield();
-    if (plan[c].src_n &&
-        hipMemcpyAsync(dsrc[q], (const char *)src_host + plan[c].src_off * es, plan[c].src_n * es, hipMemcpyHostToDevice, s_up) != hipSuccess)
-      rc = MPG_ERR_HIP;
+    if (plan[c].src_n && !trimmed) {
+      if (hipMemcpyAsync(dsrc[q], (const char *)src_host + plan[c].src_off * es, plan[c].src_n * es, hipMemcpyHostToDevice, s_up) != hipSuccess)
+        rc = MPG_ERR_HIP;
+    } else if (plan[c].src_n && rb > ra) {
+      const char *hsrc = (const char *)src_host + plan[c].src_off * es;
+      if (src_layout == MPG_LAYOUT_LEV_FAST) {                   // [cell][lev]: the referenced rows are one block
+        const size_t o = (size_t)ra * (size_t)plan[c].nlev * es, nb = (size_t)(rb - ra) * (size_t)plan[c].nlev * es;
+        for (int f = 0; f < plan[c].nfields && !rc; ++f)
+          if (hipMemcpyAsync(dsrc[q] + (size_t)f * plan[c].nlev * ns * es + o, hsrc + (size_t)f * plan[c].nlev * ns * es + o, nb, hipMemcpyHostToDevice,
+                             s_up) != hipSuccess)
+            rc = MPG_ERR_HIP;
+      } else {                                                   // [lev][cell]: one run per level
+        const size_t o = (size_t)ra * es, nb = (size_t)(rb - ra) * es;
+        for (int l = 0; l < plan[c].nlev * plan[c].nfields && !rc; ++l)
+          if (hipMemcpyAsync(dsrc[q] + (size_t)l * ns * es + o, hsrc + (size_t)l * ns * es + o, nb, hipMemcpyHostToDevice, s_up) != hipSuccess)
+            rc = MPG_ERR_HIP;
+      }
+    }
     if (!rc && (hipEventRecord(up[c], s_up) != hipSuccess || hipStreamWaitEvent(s_k, up[c], 0) != hipSuccess)) rc = MPG_ERR_HIP;
     if (!rc) rc = mpg_k_apply_typed(h, dsrc[q], src_f32, src_layout, plan[c].nlev, plan[c].nfields, ddst[q], dst_f32, scale, offset, s_k);
     if (!rc && hipEventRecord(done[c], s_k) != hipSuccess) rc = MPG_ERR_HIP;

@@ -55,3 +55,34 @@ def test_many_chunks_and_destagger_handle(gpu_lib):
     rh.release()
     mesh.destroy()
     grid.destroy()
+
+
+def test_only_the_referenced_cells_cross_the_link(gpu_lib, conus_grid_30km):
+    """A regional grid under a global mesh references a small id range of the cells: the host path uploads that range only
+    (each level's run in the cell-fast layout, one block of rows in file order).  The result must not depend on anything outside
+    the range -- NaNs there -- and must equal the device path; a second call with other values must not see stale ones."""
+    import torch
+
+    from mpassit_amd import regrid as R, synth
+    mesh, grid = R.Mesh.from_mpas(synth.icosahedral_mesh(6)), R.Grid.from_target(conus_grid_30km)    # 40 962 cells, Morton-numbered
+    for method in (R.REGRIDMETHOD_BILINEAR, R.REGRIDMETHOD_NEAREST_STOD, R.REGRIDMETHOD_CONSERVE):
+        rh = R.regrid_store(mesh, grid, method)
+        a, b = rh.source_range()
+        assert 0 <= a < b <= rh.n_src and (b - a) < 0.6 * rh.n_src       # a range worth trimming
+        rng = np.random.default_rng(11)
+        nlev, nf = 9, 2
+        for trial in range(2):
+            src = rng.normal(280.0, 30.0, (nf, nlev, rh.n_src))
+            want = rh.regrid(src.reshape(-1), nlev=nlev, nfields=nf)
+            holed = src.copy()
+            holed[:, :, :a] = np.nan
+            holed[:, :, b:] = np.nan
+            assert np.array_equal(rh.regrid_typed_host(holed, nlev=nlev, nfields=nf), want)
+            holed_lf = np.ascontiguousarray(holed.transpose(0, 2, 1))
+            assert np.array_equal(rh.regrid_typed_host(holed_lf, nlev=nlev, nfields=nf, layout=R.LAYOUT_LEV_FAST), want)
+            h32 = holed.astype(np.float32)
+            dev = rh.regrid_typed(torch.from_numpy(np.nan_to_num(h32)).cuda().reshape(-1), nlev=nlev, nfields=nf, out_dtype=torch.float32).cpu().numpy()
+            assert np.array_equal(rh.regrid_typed_host(h32, nlev=nlev, nfields=nf, out_dtype=np.float32), dev)
+        rh.release()
+    mesh.destroy()
+    grid.destroy()
