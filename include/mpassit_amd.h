@@ -193,6 +193,12 @@ int mpg_regrid_bundle_typed_dev(mpg_handle rh, int nfields, const void *const *s
  * uploads).  Blocks until dst_host is complete. */
 int mpg_regrid_typed(mpg_handle rh, const void *src_host, int src_type, int src_layout, int nlev, int nfields,
                      void *dst_host, int dst_type, double scale, double offset);
+/* ... and over a bundle whose fields are SEPARATE host arrays (mpg_regrid_bundle_typed_dev's host twin): all fields go through
+ * one pipeline -- the upload of field k + 1, the Regrid of field k and the download of field k - 1 overlap -- where a file-order
+ * field handed over alone is uploaded, regridded and downloaded one step after the other (configuration 4, float64: 39 ms per
+ * field alone, 24 in a bundle).  offsets: one epilogue offset per field, or NULL.  Blocks until every destination is complete. */
+int mpg_regrid_bundle_typed(mpg_handle rh, int nfields, const void *const *src_host, int src_type, int src_layout, int nlev,
+                            void *const *dst_host, int dst_type, double scale, const double *offsets);
 /* ESMF_FieldBundleRegridRelease (interp.F90:450,455,461) */
 int mpg_handle_release(mpg_handle rh);
 

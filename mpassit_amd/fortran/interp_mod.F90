@@ -103,10 +103,70 @@ contains
       call regrid_bundle_dev(rh, b)
       return
     end if
+    if (b%n > 1) then
+      call regrid_bundle_host(rh, b)
+      return
+    end if
     do i = 1, b%n
       call regrid_field(rh, b%f(i))
     end do
   end subroutine regrid_bundle
+
+  !> Host arrays: the fields of the bundle that agree in level count and element types go through ONE pipeline
+  !! (mpg_regrid_bundle_typed): the upload of one field, the Regrid of the one before and the download of the one before that
+  !! overlap, where a file-order field handed over alone runs the three steps one after the other.
+  subroutine regrid_bundle_host(rh, b)
+    type(c_ptr), intent(in) :: rh
+    type(bundle_t), intent(inout), target :: b
+    integer(c_int64_t) :: n_src, n_dst, nnz
+    integer(c_int) :: nxd, nyd, npr, layout
+    integer :: i, j, ng
+    logical :: done(b%n), r8(b%n), s4(b%n)
+    type(c_ptr) :: sp(b%n), dp(b%n)
+    real(c_double) :: offs(b%n)
+    type(field_t), pointer :: f, g
+    call mpg_check(mpg_handle_info(rh, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+    do i = 1, b%n
+      f => b%f(i)
+      if (allocated(f%dst)) deallocate (f%dst)
+      if (allocated(f%dst4)) deallocate (f%dst4)
+      r8(i) = keeps_r8(f)
+      s4(i) = allocated(f%src4)
+      if (r8(i)) then
+        allocate (f%dst(n_dst*f%nlev))
+      else
+        allocate (f%dst4(n_dst*f%nlev))
+      end if
+    end do
+    done = .false.
+    do i = 1, b%n
+      if (done(i)) cycle
+      f => b%f(i)
+      ng = 0
+      do j = i, b%n
+        g => b%f(j)
+        if (done(j) .or. g%nlev /= f%nlev .or. (s4(j) .neqv. s4(i)) .or. (r8(j) .neqv. r8(i))) cycle
+        ng = ng + 1
+        if (s4(j)) then
+          sp(ng) = c_loc(g%src4)
+        else
+          sp(ng) = c_loc(g%src)
+        end if
+        offs(ng) = 0.0_c_double
+        if (r8(j)) then
+          dp(ng) = c_loc(g%dst)
+        else
+          dp(ng) = c_loc(g%dst4)
+          if (wrf_mod_vars .and. trim(g%tname) == 'T') offs(ng) = -300.0_c_double
+        end if
+        done(j) = .true.
+      end do
+      layout = MPG_LAYOUT_LEV_FAST
+      if (f%nlev == 1) layout = MPG_LAYOUT_CELL_FAST
+      call mpg_check(mpg_regrid_bundle_typed(rh, int(ng, c_int), sp, merge(1_c_int, 0_c_int, s4(i)), layout, int(f%nlev, c_int), dp, &
+                                             merge(0_c_int, 1_c_int, r8(i)), 1.0_c_double, offs), "IN FieldBundleRegrid "//trim(f%name))
+    end do
+  end subroutine regrid_bundle_host
 
   !> Device flow: the fields of the bundle that agree in level count and element types go through ONE Regrid
   !! (mpg_regrid_bundle_typed_dev over their separate device arrays, per-field epilogue offsets), as the reference's

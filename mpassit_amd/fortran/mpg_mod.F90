@@ -169,6 +169,18 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid_bundle_typed_dev
 
+    !> the same on separate HOST arrays: every field of the bundle through one upload / Regrid / download pipeline
+    function mpg_regrid_bundle_typed(rh, nfields, src, src_f32, src_layout, nlev, dst, dst_f32, scale, offsets) &
+      bind(C, name="mpg_regrid_bundle_typed") result(rc)
+      import :: c_int, c_double, c_ptr
+      type(c_ptr), value :: rh
+      integer(c_int), value :: nfields, src_f32, src_layout, nlev, dst_f32
+      type(c_ptr), intent(in) :: src(*), dst(*)
+      real(c_double), value :: scale
+      real(c_double), intent(in) :: offsets(*)
+      integer(c_int) :: rc
+    end function mpg_regrid_bundle_typed
+
     function mpg_rotate_winds_dev(npts, nlev, cosa, sina, u, v, stream) bind(C, name="mpg_rotate_winds_dev") result(rc)
       import :: c_int, c_int64_t, c_ptr
       integer(c_int64_t), value :: npts

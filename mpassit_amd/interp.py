@@ -81,6 +81,10 @@ def _bundle_regrid(rh, arrs, nlev, layout):
                 (a0.dtype == torch.float32 or _is_be(arrs[0])) and a0.dtype in (torch.float32, torch.float64):
             return rh.regrid_bundle([t.reshape(-1) for t in ts], nlev=nlev, layout=layout, out_dtype=torch.float64, src_be=_is_be(arrs[0]))
         return [rh.regrid(a.reshape(-1), nlev=nlev, layout=layout, src_be=_is_be(arr))[0] for a, arr in zip(ts, arrs)]
+    a0 = np.asarray(arrs[0])
+    if len(arrs) > 1 and a0.dtype in (np.float32, np.float64) and all(np.asarray(a).dtype == a0.dtype for a in arrs):
+        # separate host arrays, one pipeline for the whole bundle (mpg_regrid_bundle_typed): no stacked copy
+        return rh.regrid_bundle_host([np.asarray(a).reshape(-1) for a in arrs], nlev=nlev, layout=layout, out_dtype=np.float64)
     out = rh.regrid(_stack(arrs).reshape(-1), nlev=nlev, nfields=len(arrs), layout=layout)
     return [out[i] for i in range(len(arrs))]
 

@@ -327,6 +327,29 @@ class RouteHandle:
                                         C.c_int(int(out.dtype == np.float32)), C.c_double(scale), C.c_double(offset)))
         return out
 
+    def regrid_bundle_host(self, srcs, nlev=1, layout=LAYOUT_CELL_FAST, out_dtype=None, scale=1.0, offsets=None, outs=None):
+        """mpg_regrid_bundle_typed: the fields of a bundle as separate numpy arrays (float32 or float64, one dtype), all through
+        ONE upload / Regrid / download pipeline.  Returns the list of results [nlev][ny][nx] of out_dtype."""
+        nf = len(srcs)
+        if nf == 0:
+            return []
+        srcs = [np.ascontiguousarray(a) for a in srcs]
+        dt = srcs[0].dtype
+        if dt not in (np.float32, np.float64) or any(a.dtype != dt for a in srcs):
+            raise ValueError("regrid_bundle_host needs float32 or float64 arrays of one dtype")
+        for a in srcs:
+            if a.size != nlev * self.n_src:
+                raise ValueError("a source has %d elements, handle expects %d" % (a.size, nlev * self.n_src))
+        out_dtype = np.dtype(out_dtype or dt)
+        if outs is None:
+            outs = [np.empty((nlev, self.ny_dst, self.nx_dst), out_dtype) for _ in range(nf)]
+        sp = (C.c_void_p * nf)(*[a.ctypes.data for a in srcs])
+        dp = (C.c_void_p * nf)(*[o.ctypes.data for o in outs])
+        op = None if offsets is None else (C.c_double * nf)(*[float(o) for o in offsets])
+        check(L.load().mpg_regrid_bundle_typed(self._h, C.c_int(nf), sp, C.c_int(int(dt == np.float32)), C.c_int(layout), C.c_int(nlev), dp,
+                                               C.c_int(int(out_dtype == np.float32)), C.c_double(scale), op))
+        return outs
+
     @classmethod
     def from_weights(cls, n_src, nx_dst, ny_dst, row, col, S):
         """Route handle from externally computed weights in ESMF's factorList / factorIndexList form (1-based

@@ -146,6 +146,19 @@ int main(void) {
       }
       CHECK(mpg_dev_free(d2_dev));
     }
+    /* ---- ... and as a bundle of separate HOST arrays through one pipeline ---- */
+    {
+      float h0[NY * NX], h1[NY * NX];
+      const void *hs[2] = {f32, f32};
+      void *hd[2] = {h0, h1};
+      const double hoffs[2] = {0.0, 10.0};
+      CHECK(mpg_regrid_bundle_typed(rh, 2, hs, MPG_TYPE_F32, MPG_LAYOUT_CELL_FAST, 1, hd, MPG_TYPE_F32, 1.0, hoffs));
+      for (int p = 0; p < NY * NX; ++p)
+        if (h0[p] < 301.0f || h0[p] > 304.0f || h1[p] != h0[p] + 10.0f) {
+          fprintf(stderr, "FAIL host bundle Regrid: point %d = %.9g / %.9g\n", p, h0[p], h1[p]);
+          return 1;
+        }
+    }
     /* ---- source range and source window: all four cells are referenced; the whole mesh is the only window that fits ---- */
     int64_t first = -1, end = -1;
     CHECK(mpg_handle_source_range(rh, &first, &end));

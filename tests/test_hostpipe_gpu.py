@@ -86,3 +86,27 @@ def test_only_the_referenced_cells_cross_the_link(gpu_lib, conus_grid_30km):
         rh.release()
     mesh.destroy()
     grid.destroy()
+
+
+def test_bundle_of_separate_host_arrays_equals_single_calls(gpu_lib, regional_case):
+    """mpg_regrid_bundle_typed: the fields of a bundle as separate host arrays through one pipeline == one mpg_regrid_typed per
+    field, bit for bit: both layouts, float32 / float64 on either side, per-field offsets, 2-D fields."""
+    from mpassit_amd import regrid as R
+    m, g = regional_case
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rng = np.random.default_rng(3)
+    for method in (R.REGRIDMETHOD_BILINEAR, R.REGRIDMETHOD_CONSERVE):
+        rh = R.regrid_store(mesh, grid, method)
+        for nlev, nf in ((9, 4), (1, 3), (40, 2)):
+            for layout in (R.LAYOUT_CELL_FAST, R.LAYOUT_LEV_FAST):
+                for sdt, ddt in ((np.float32, np.float32), (np.float64, np.float64), (np.float32, np.float64), (np.float64, np.float32)):
+                    shape = (rh.n_src, nlev) if layout == R.LAYOUT_LEV_FAST else (nlev, rh.n_src)
+                    srcs = [rng.normal(280.0, 30.0, shape).astype(sdt) for _ in range(nf)]
+                    offs = [-300.0 * (f % 2) for f in range(nf)]
+                    got = rh.regrid_bundle_host(srcs, nlev=nlev, layout=layout, out_dtype=ddt, scale=1.5, offsets=offs)
+                    for f in range(nf):
+                        want = rh.regrid_typed_host(srcs[f], nlev=nlev, nfields=1, layout=layout, out_dtype=ddt, scale=1.5, offset=offs[f])[0]
+                        assert got[f].dtype == ddt and np.array_equal(got[f], want), (method, nlev, nf, layout, sdt, ddt, f)
+        rh.release()
+    mesh.destroy()
+    grid.destroy()
