@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void k_tri_raster(int64_t nTri, const int32_t 
     const float imin = fminf(ai, fminf(bi_, ci_)), imax = fmaxf(ai, fmaxf(bi_, ci_)), jmin = fminf(aj, fminf(bj_, cj_)), jmax = fmaxf(aj, fmaxf(bj_, cj_));
     const float E = fmaxf(imax - imin, jmax - jmin);
     const bool usable = ai == ai && aj == aj && bi_ == bi_ && bj_ == bj_ && ci_ == ci_ && cj_ == cj_;   // fminf / fmaxf skip a NaN corner
+    if (!usable && big_cap > 0) {
+      // no usable index on a grid that has one -- the last degrees before a pole, the far side of a Lambert projection: such a
+      // triangle covers hundreds of thin cells or none at all; a wavefront takes it (k_tri_raster_big) unless it misses the grid
+      const double *bx = pyr.box + 6 * pyr.off[pyr.nlev - 1];
+      const double xl = fmin(A.x, fmin(B.x, C.x)), xh = fmax(A.x, fmax(B.x, C.x)), yl = fmin(A.y, fmin(B.y, C.y)), yh = fmax(A.y, fmax(B.y, C.y)),
+                   zl = fmin(A.z, fmin(B.z, C.z)), zh = fmax(A.z, fmax(B.z, C.z));
+      dv3 ab0 = B - A, bc0 = C - B, ca0 = A - C;
+      const double pd = 0.5 * fmax(dot3(ab0, ab0), fmax(dot3(bc0, bc0), dot3(ca0, ca0))) + 1e-9;
+      if (bx[0] > xh + pd || bx[3] < xl - pd || bx[1] > yh + pd || bx[4] < yl - pd || bx[2] > zh + pd || bx[5] < zl - pd) return;
+      const int slot = atomicAdd(nbig, 1);
+      if (slot < big_cap) {
+        big[slot] = (int32_t)t;
+        return;
+      }
+    }
     if (usable && E <= e_max) {
       const float pad = mpg_box_pad(E, pad_coef, pad_latlon, fmax(fabs(A.z), fmax(fabs(B.z), fabs(C.z))));
       const int i0 = max((int)ceilf(imin + di - pad), 0), i1 = min((int)floorf(imax + di + pad), npx - 1);
