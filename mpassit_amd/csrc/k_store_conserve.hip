@@ -56,11 +56,15 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
                                                          int32_t *__restrict__ tmp_dst, int32_t *__restrict__ ovf, int32_t *__restrict__ n_ovf,
                                                          uint8_t *__restrict__ flip, const int32_t *__restrict__ poff,
                                                          int32_t *__restrict__ pair_c, int32_t *__restrict__ pair_p, const float *__restrict__ vij,
-                                                         float pad_coef, float pad_latlon, float e_max, int32_t *__restrict__ spill) {
+                                                         float pad_coef, float pad_latlon, float e_max, int32_t *__restrict__ spill, int spill_cap) {
   // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
   constexpr bool COOP = MODE == 5 || MODE == 6;
   int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
+  // a polygon whose candidates the candidate pass itself spilled (25 .. CONS_SPILL of them, all found through its index box) has
+  // its exact count already: nothing to count
+  if (MODE == 5 && cnt_src[c] != CAND_CAP + 1) return;
+  if (spill && (int)blockIdx.x >= spill_cap && COOP) spill = nullptr;   // beyond the spill area: counted and listed by walking
   if (MODE == 6 && spill) {
     // the count pass (MODE 5) kept the first CONS_SPILL candidates of this cell: when that was all of them the list is copied,
     // not walked for again (configuration 5: the second walk of the polar polygons was a quarter of the whole Store)
@@ -164,23 +168,38 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
       const float pad = mpg_box_pad(E, pad_coef, pad_latlon, fmax(fabs(lo[2]), fabs(hi[2])));   // (the padded z range: a little poleward of the vertices)
       const int i0 = max((int)ceilf(imin - pad - 0.5f), 0), i1 = min((int)floorf(imax + pad + 0.5f), nx - 1);
       const int j0 = max((int)ceilf(jmin - pad - 0.5f), 0), j1 = min((int)floorf(jmax + pad + 0.5f), ny - 1);
-      bool over = false;
-      for (int j = j0; j <= j1 && !over; ++j)
+      // Up to CAND_CAP candidates go to the polygon's own list; a polygon with more (a cell next to the poles of a lat-lon grid, a
+      // cell of a mesh coarser than the grid) takes a slot of the overflow list and SPILLS the rest into that slot's area, still
+      // from its box: with at most CONS_SPILL candidates its count is exact here and the cooperative count pass has nothing to do
+      // for it (the list pass copies the area, as it does for a polygon the count pass spilled).  More than that, or no area
+      // left: the cooperative passes walk for it.
+      int slot = -1;
+      bool complete = true;
+      for (int j = j0; j <= j1; ++j)
         for (int i = i0; i <= i1; ++i) {
           if (!candidate(i, j)) continue;
-          if (found == CAND_CAP) {
-            over = true;
+          const int32_t pc = (int32_t)((int64_t)j * nx + i);
+          if (found < CAND_CAP) {
+            tmp_dst[c * CAND_CAP + found] = pc;
+          } else {
+            if (slot < 0) {
+              slot = atomicAdd(n_ovf, 1);
+              ovf[slot] = (int32_t)c;
+              if (spill && slot < spill_cap)
+                for (int k = 0; k < CAND_CAP; ++k) spill[(int64_t)slot * CONS_SPILL + k] = tmp_dst[c * CAND_CAP + k];
+              else
+                complete = false;
+            }
+            if (complete && found < CONS_SPILL) spill[(int64_t)slot * CONS_SPILL + found] = pc;
+            else complete = false;
+          }
+          ++found;
+          if (!complete) {
+            j = j1;   // leave both loops
             break;
           }
-          tmp_dst[c * CAND_CAP + found] = (int32_t)((int64_t)j * nx + i);
-          ++found;
         }
-      if (!over) {
-        cnt_src[c] = found;
-        return;
-      }
-      cnt_src[c] = CAND_CAP + 1;
-      ovf[atomicAdd(n_ovf, 1)] = (int32_t)c;
+      cnt_src[c] = (slot < 0 || complete) ? found : CAND_CAP + 1;
       return;
     }
   }
@@ -574,9 +593,14 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   }
   k_cell_areas<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(nx, ny, cor.x.p, cor.y.p, cor.z.p, qarea.p, qsph.p);
   // (1) candidate pairs: one thread per source cell walks the pyramid and lists the destination cells that pass the tests
+  // the spill areas of the overflow list's first slots (CONS_SPILL candidates each): filled by the candidate pass for polygons it
+  // can enumerate from their index boxes, by the cooperative count pass for the others
+  const int spill_cap = (int)std::min<int64_t>(nC, 1 << 16);
+  TmpBuf<int32_t> spill;
+  if ((rc = spill.alloc((size_t)spill_cap * CONS_SPILL, s))) return rc;
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
                                         qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
-                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_pad_latlon(g), (float)mpg_grid_box_emax(g), nullptr);
+                                        (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_pad_latlon(g), (float)mpg_grid_box_emax(g), spill.p, spill_cap);
   if (m->max_valence < 0) k_max_valence<<<(unsigned)std::min<int64_t>((nC + 255) / 256, 2048), 256, 0, s>>>(nC, m->maxEdges, m->voc.p, n_ovf.p + 1);
   MPG_HIP(hipGetLastError());
   int32_t novf = 0, hv[2] = {0, 0};
@@ -584,13 +608,11 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipStreamSynchronize(s));
   novf = hv[0];
   if (m->max_valence < 0) m->max_valence = hv[1];
-  TmpBuf<int32_t> spill;
-  if (novf > 0 && (rc = spill.alloc((size_t)novf * CONS_SPILL, s))) return rc;
   const unsigned coop_nt = CONS_COOP_NT;
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
     k_conserve_raster<5><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, spill.p);
+                                                       nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, spill.p, spill_cap);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
   size_t tmp_bytes = 0, b2 = 0;
@@ -623,7 +645,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   if (novf > 0)
     k_conserve_raster<6><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
                                                        cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
-                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f, 0.f, spill.p);
+                                                       pair_c.p, pair_p.p, nullptr, 0.f, 0.f, 0.f, spill.p, spill_cap);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
   // buffer slots per polygon: the in-place step never lets a polygon gain more than one vertex per half-space (it reports the
