@@ -44,6 +44,7 @@
 // 2, where all 22 204 referenced 30-km cells overflow under the 3-km grid.)
 #define CAND_CAP 24   // candidate destination cells per source cell kept by the candidate pass
 #define CONS_SPILL 256   // candidates per overflowed cell the cooperative count pass keeps for the list pass
+#define CONS_BIGBOX 128  // cells in a polygon's index box beyond which a wavefront, not a lane, enumerates it
 #define CONS_COOP_NT 64  // threads of a cooperative pass's workgroup.  Measured 64 / 128 / 256 / 512 (round 4): C5 8.31 / 8.46 / 10.3 / 15.4 ms,
                          // C2 2.27 / 2.36 / 2.98 / 4.89 -- the passes are thousands of light polygons, not a few heavy ones: one wavefront each
 template <int MODE>
@@ -59,7 +60,8 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
                                                          float pad_coef, float pad_latlon, float e_max, int32_t *__restrict__ spill, int spill_cap) {
   // MODE 3: one thread per source cell.  MODE 5 / 6: one WORKGROUP per overflowed source cell (ovf[blockIdx.x]).
   constexpr bool COOP = MODE == 5 || MODE == 6;
-  int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // MODE 7: one WAVEFRONT per polygon of the big-box queue (pair_c doubles as that queue in modes 3 and 7; its length is n_ovf[2])
+  int64_t c = COOP ? (int64_t)ovf[blockIdx.x] : MODE == 7 ? (int64_t)pair_c[blockIdx.x] : blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (c >= nCells) return;
   // a polygon whose candidates the candidate pass itself spilled (25 .. CONS_SPILL of them, all found through its index box) has
   // its exact count already: nothing to count
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
   // the inverse projection of every vertex, k_target_grid.hip) bound the destination cells it can meet -- cell (i, j) covers
   // index coordinates i - 0.5 .. i + 0.5 -- and every cell of that padded box takes the test above.  More candidates than the
   // list holds, a polygon near the projection's pole / cut or wider than e_max index units: the walk (and the overflow passes).
-  if (MODE == 3 && vij) {
+  if ((MODE == 3 || MODE == 7) && vij) {
     float imin = 1e30f, imax = -1e30f, jmin = 1e30f, jmax = -1e30f;
     bool ok = true;
     for (int j = 0, k = 0; j < maxEdges && k < CONS_MAXV; ++j) {
@@ -168,6 +170,62 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
       const float pad = mpg_box_pad(E, pad_coef, pad_latlon, fmax(fabs(lo[2]), fabs(hi[2])));   // (the padded z range: a little poleward of the vertices)
       const int i0 = max((int)ceilf(imin - pad - 0.5f), 0), i1 = min((int)floorf(imax + pad + 0.5f), nx - 1);
       const int j0 = max((int)ceilf(jmin - pad - 0.5f), 0), j1 = min((int)floorf(jmax + pad + 0.5f), ny - 1);
+      // A polygon whose box holds many cells (a cell of a mesh coarser than the grid, a cell next to the poles of a lat-lon grid)
+      // is not enumerated by this one lane -- a few hundred wavefronts would then do all the work of the pass while the rest of
+      // the chip idles (configuration 2: this kernel at 7 resident waves per busy cycle) -- but queued for MODE 7, where the
+      // lanes of a wavefront share the box.
+      const int bw = max(i1 - i0 + 1, 0), bh = max(j1 - j0 + 1, 0);   // (a box off the grid is empty: i0 > i1 or j0 > j1)
+      if (MODE == 3 && pair_c && bw * bh > CONS_BIGBOX) {
+        const int qs = atomicAdd(n_ovf + 2, 1);
+        if (qs < spill_cap) {
+          pair_c[qs] = (int32_t)c;
+          cnt_src[c] = CAND_CAP + 1;   // (until MODE 7 has counted)
+          return;
+        }
+      }
+      if (MODE == 7) {
+        // the box, 64 cells at a time in row-major order; the candidates keep that order (ballot + prefix count), the first
+        // CAND_CAP of them in the polygon's list, all of them in its spill area once there are more -- the rules of the lane form below
+        const int lane = (int)threadIdx.x, total = bw * bh;
+        int slot = -1;
+        bool complete = true;
+        for (int base = 0; base < total && complete; base += 64) {
+          const int q = base + lane;
+          bool is = false;
+          int32_t pc = 0;
+          if (q < total) {
+            const int i = i0 + q % bw, j = j0 + q / bw;
+            is = candidate(i, j);
+            pc = (int32_t)((int64_t)j * nx + i);
+          }
+          const unsigned long long mask = __ballot(is);
+          const int nnew = __popcll(mask);
+          if (nnew == 0) continue;
+          const int pos = found + __popcll(mask & ((1ull << lane) - 1ull));
+          if (found + nnew > CAND_CAP && slot < 0) {
+            int sl = 0;
+            if (lane == 0) {
+              sl = atomicAdd(n_ovf, 1);
+              ovf[sl] = (int32_t)c;
+            }
+            slot = __shfl(sl, 0);
+            if (spill && slot < spill_cap) {
+              __threadfence_block();
+              for (int k = lane; k < min(found, CAND_CAP); k += 64) spill[(int64_t)slot * CONS_SPILL + k] = tmp_dst[c * CAND_CAP + k];
+            } else {
+              complete = false;
+            }
+          }
+          if (is) {
+            if (pos < CAND_CAP) tmp_dst[c * CAND_CAP + pos] = pc;
+            if (slot >= 0 && complete && pos < CONS_SPILL) spill[(int64_t)slot * CONS_SPILL + pos] = pc;
+          }
+          found += nnew;
+          if (slot >= 0 && found > CONS_SPILL) complete = false;
+        }
+        if (lane == 0) cnt_src[c] = (slot < 0 || complete) ? found : CAND_CAP + 1;
+        return;
+      }
       // Up to CAND_CAP candidates go to the polygon's own list; a polygon with more (a cell next to the poles of a lat-lon grid, a
       // cell of a mesh coarser than the grid) takes a slot of the overflow list and SPILLS the rest into that slot's area, still
       // from its box: with at most CONS_SPILL candidates its count is exact here and the cooperative count pass has nothing to do
@@ -203,6 +261,7 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
       return;
     }
   }
+  if (MODE == 7) return;   // (only polygons with a usable box are queued)
   int stack[CONS_STACK];
   // Seeds of the depth-first walk.  MODE 0: the root.  Cooperative modes: the workgroup first expands the pyramid
   // breadth-first in LDS (one node per thread and level) down to 8 x 8-cell nodes, then every thread walks its share.
@@ -572,10 +631,10 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     return MPG_SUCCESS;
   }
   if ((rc = count.alloc((size_t)P + 1, s)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P, s)) || (rc = qsph.alloc(4 * (size_t)P, s)) ||
-      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(2, s)) ||
+      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(3, s)) ||
       (rc = npair.alloc((size_t)nC + 1, s)) || (rc = poff.alloc((size_t)nC + 1, s)) || (rc = flip.alloc((size_t)nC, s)))
     return rc;
-  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, 2 * sizeof(int32_t), s));   // [0] overflowed cells, [1] the largest vertex count of a cell
+  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, 3 * sizeof(int32_t), s));   // [0] overflowed cells, [1] the largest vertex count of a cell, [2] big-box queue
   MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)nC, s));  // degenerate cells leave early
   MPG_HIP(hipMemsetAsync(flip.p, 0, (size_t)nC, s));
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
@@ -596,18 +655,27 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // the spill areas of the overflow list's first slots (CONS_SPILL candidates each): filled by the candidate pass for polygons it
   // can enumerate from their index boxes, by the cooperative count pass for the others
   const int spill_cap = (int)std::min<int64_t>(nC, 1 << 16);
-  TmpBuf<int32_t> spill;
-  if ((rc = spill.alloc((size_t)spill_cap * CONS_SPILL, s))) return rc;
+  TmpBuf<int32_t> spill, bigq;
+  if ((rc = spill.alloc((size_t)spill_cap * CONS_SPILL, s)) || (rc = bigq.alloc((size_t)spill_cap, s))) return rc;
   k_conserve_raster<3><<<nb, 128, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
-                                        qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, nullptr, nullptr, vijp,
+                                        qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, flip.p, nullptr, vijp ? bigq.p : nullptr, nullptr, vijp,
                                         (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_pad_latlon(g), (float)mpg_grid_box_emax(g), spill.p, spill_cap);
   if (m->max_valence < 0) k_max_valence<<<(unsigned)std::min<int64_t>((nC + 255) / 256, 2048), 256, 0, s>>>(nC, m->maxEdges, m->voc.p, n_ovf.p + 1);
   MPG_HIP(hipGetLastError());
-  int32_t novf = 0, hv[2] = {0, 0};
-  MPG_HIP(hipMemcpyAsync(hv, n_ovf.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t novf = 0, hv[3] = {0, 0, 0};
+  MPG_HIP(hipMemcpyAsync(hv, n_ovf.p, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   novf = hv[0];
   if (m->max_valence < 0) m->max_valence = hv[1];
+  if (hv[2] > 0) {   // polygons with big index boxes: a wavefront each (they may add to the overflow list: read its length again)
+    k_conserve_raster<7><<<(unsigned)std::min(hv[2], spill_cap), 64, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p, cor.y.p, cor.z.p,
+                                                                            qarea.p, qsph.p, cnt_src.p, tmp_dst.p, ovf.p, n_ovf.p, nullptr, nullptr, bigq.p, nullptr,
+                                                                            vijp, (float)mpg_grid_box_pad_coef(g), (float)mpg_grid_box_pad_latlon(g),
+                                                                            (float)mpg_grid_box_emax(g), spill.p, spill_cap);
+    MPG_HIP(hipGetLastError());
+    MPG_HIP(hipMemcpyAsync(&novf, n_ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+  }
   const unsigned coop_nt = CONS_COOP_NT;
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
     k_conserve_raster<5><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
