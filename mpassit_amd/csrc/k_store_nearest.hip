@@ -376,8 +376,8 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
 // k_target_grid.hip); binned there, the cells around a target point are the contents of the few bins around the point's OWN
 // index -- no tree, no sort.  Exactness does not rest on the map being isometric, only on a lower bound h of the chord length
 // of one index unit (mpg_grid_min_index_chord: the map factor's maximum over the grid's latitudes and a margin): after the
-// bins within r rings have been looked at, every cell not looked at is at least r * NB_BIN index units away, i.e. at least
-// 0.8 * r * NB_BIN * h on the sphere, so a best distance below that is final -- ties included (an equally near cell is inside
+// bins within r rings have been looked at, every cell not looked at is at least r * bin index units away, i.e. at least
+// 0.8 * r * bin * h on the sphere, so a best distance below that is final -- ties included (an equally near cell is inside
 // the bound and was compared: lowest id wins, with the distance arithmetic of the BVH search and the oracle).  A point that
 // finds nothing final within NB_RINGS rings (the grid sticks far out of the mesh, the polar rows of a global grid) is left at
 // -1 and the BVH search above finishes exactly those points (masked): never a different answer, only a slower one.  Cells
@@ -385,9 +385,11 @@ static int nearest_search(mpg_mesh_s *m, int npx, int npy, const PointSet &pts, 
 // not binned, and no answer as far away as such a cell could be -- or as far away as the Lambert cut, across which index
 // distance says nothing about distance on the sphere -- is called final (`cap` in k_nb_query).  Lat-lon grids take the bound h
 // per point, global ones wrap their bins in i, regional ones unwrap the cells' indices about the grid's middle column.
-#define NB_BIN 2       // index units (grid points) per bin side
-#define NB_RINGS 4     // rings of bins a point may look at; the bin grid extends that far beyond the grid's points
+#define NB_BIN_MIN 2    // index units (grid points) per bin side: 2 when the mesh is as fine as the grid, up to NB_BIN_MAX when it is
+#define NB_BIN_MAX 16   // coarser (about one cell per bin: a 30-km mesh under a 3-km grid takes 9) -- the rings then reach the next cells
+#define NB_RINGS 4      // rings of bins a point may look at; the bin grid extends that far beyond the grid's points
 struct NbParams {
+  int bin;             // index units per bin side
   int nbx, nby;        // bins
   int per, nxp;        // periodic in i (a global lat-lon grid): the index wraps at nxp, no margin in i
   float di, dj;        // stagger offsets of the point indices
@@ -400,17 +402,17 @@ struct NbParams {
   double stdlon;
 };
 __device__ __forceinline__ bool nb_bin_of(const NbParams &q, float ci, float cj, int *bx, int *by) {
-  float u = ci + q.di, v = cj + q.dj + (float)(NB_RINGS * NB_BIN);
+  float u = ci + q.di, v = cj + q.dj + (float)(NB_RINGS * q.bin);
   if (!(u == u) || !(v == v)) return false;
   if (q.per) {
     if (u < 0.f) u += (float)q.nxp;
     if (u >= (float)q.nxp) u -= (float)q.nxp;
   } else {
-    u += (float)(NB_RINGS * NB_BIN);
+    u += (float)(NB_RINGS * q.bin);
   }
   if (u < 0.f || v < 0.f) return false;
-  *bx = (int)floorf(u / NB_BIN);
-  *by = (int)floorf(v / NB_BIN);
+  *bx = (int)floorf(u / (float)q.bin);
+  *by = (int)floorf(v / (float)q.bin);
   return *bx < q.nbx && *by < q.nby;   // beyond the margin: further than any answer that is called final
 }
 __global__ __launch_bounds__(256) void k_nb_count(int64_t n, const float *__restrict__ ij, NbParams q, int32_t *__restrict__ cnt) {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
   if (p >= (int64_t)npx * npy) return;
   const int i = (int)(p % npx), j = (int)(p / npx);
   const double X = px[p], Y = py[p], Z = pz[p];
-  const int bx = q.per ? (i % q.nxp) / NB_BIN : (i + NB_RINGS * NB_BIN) / NB_BIN, by = (j + NB_RINGS * NB_BIN) / NB_BIN;
+  const int bx = q.per ? (i % q.nxp) / q.bin : (i + NB_RINGS * q.bin) / q.bin, by = (j + NB_RINGS * q.bin) / q.bin;
   const double r2d = 57.29577951308232, alat = fabs(asin(fmin(fmax(Z, -1.0), 1.0)));   // the point's |latitude|, radians
   // cells WITHOUT a usable index are not binned: nothing as far as they can be is final.  They sit beyond zlim degrees (lat-lon)
   // resp. within a degree of the Lambert pole or more than 60 degrees into the other hemisphere.
@@ -478,16 +480,31 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
         }
       }
     }
-    // every cell not seen so far is at least (r * NB_BIN) index units from the point (it sits in its own bin: the distance to the
+    // every cell not seen so far is at least (r * bin) index units from the point (it sits in its own bin: the distance to the
     // edge of the block of rings 0 .. r is at least r bins), less the rounding of the float32 indices; on the sphere that is at
     // least that many times the chord length of an index unit -- on a lat-lon grid taken where the rings reach furthest poleward
     double h = q.h;
-    if (q.local) h = 0.8 * fmin(q.dlat, q.dlon * cos(fmin(alat + (double)(r * NB_BIN + 1) * q.dlat, 1.5707)));
-    const double lim = fmin(((double)(r * NB_BIN) - 2e-3) * h, cap);
+    if (q.local) h = 0.8 * fmin(q.dlat, q.dlon * cos(fmin(alat + (double)(r * q.bin + 1) * q.dlat, 1.5707)));
+    const double lim = fmin(((double)(r * q.bin) - 2e-3) * h, cap);
     done = r > 0 && best <= lim * lim;
   }
   if (!done) atomicOr(flags, 2);
   out[p] = done ? best_id : -1;
+}
+// cells with a usable index on the grid or within `margin` index units of it
+__global__ __launch_bounds__(256) void k_nb_inside(int64_t n, const float *__restrict__ ij, float margin, float npx, float npy,
+                                                   unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long sn;
+  if (threadIdx.x == 0) sn = 0;
+  __syncthreads();
+  unsigned long long k = 0;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) {
+    const float i = ij[2 * c], j = ij[2 * c + 1];
+    k += (i >= -margin && i <= npx + margin && j >= -margin && j <= npy + margin) ? 1ull : 0ull;   // (false for NaN)
+  }
+  if (k) atomicAdd(&sn, k);
+  __syncthreads();
+  if (threadIdx.x == 0 && sn) atomicAdd(out, sn);
 }
 __global__ __launch_bounds__(256) void k_zrange(int64_t n, const double *__restrict__ z, unsigned long long *__restrict__ out) {
   __shared__ double slo[4], shi[4];
@@ -525,20 +542,13 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   q.per = (g->periodic & MPG_GRID_PERIODIC_I) != 0;
   if (q.per) {   // a global lat-lon grid: the index wraps; needs the full circle in whole bins and no duplicated column
     q.nxp = pr.nxmax - pr.nxmin + 1;
-    if (pr.code != MPG_PROJ_LATLON || npx != q.nxp || g->nx != q.nxp || q.nxp % NB_BIN) return MPG_SUCCESS;
+    if (pr.code != MPG_PROJ_LATLON || npx != q.nxp || g->nx != q.nxp || q.nxp % NB_BIN_MIN) return MPG_SUCCESS;
   }
-  q.nbx = q.per ? q.nxp / NB_BIN : (npx + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN;
-  q.nby = (npy + 2 * NB_RINGS * NB_BIN + NB_BIN - 1) / NB_BIN;
   q.di = stagger == MPG_STAGGERLOC_EDGE1 ? 0.5f : 0.f;
   q.dj = stagger == MPG_STAGGERLOC_EDGE2 ? 0.5f : 0.f;
   q.cap = m->cwn < m->nCells ? m->geo_margin : 4.0;
-  const int64_t nbins = (int64_t)q.nbx * q.nby;
-  if (nbins + 1 >= 0x7fffffff) return MPG_SUCCESS;
   const double latlon_limit = 89.0;   // the nearest search only PLACES points: the lat-lon inverse is good up to the last degree
   if (pr.code == MPG_PROJ_LATLON) {
-    // a regional lat-lon grid: cell indices are unwrapped around its middle column, which is only unambiguous while the grid
-    // and its margin stay well short of the full circle
-    if (!q.per && (double)(npx + 2 * NB_RINGS * NB_BIN) * fabs(pr.loninc) > 300.0) return MPG_SUCCESS;
     q.local = 1;
     q.dlat = fabs(pr.latinc) * 3.141592653589793 / 180.0;
     q.dlon = fabs(pr.loninc) * 3.141592653589793 / 180.0;
@@ -552,26 +562,44 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   TmpBuf<float> ij;
   TmpBuf<int32_t> cnt, off, ids, flags;
   TmpBuf<unsigned long long> zr;
-  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = cnt.alloc((size_t)nbins + 1, s)) || (rc = off.alloc((size_t)nbins + 1, s)) ||
-      (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(1, s)) || (rc = zr.alloc(2, s)))
-    return rc;
-  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
+  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(1, s)) || (rc = zr.alloc(3, s))) return rc;
   MPG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t), s));
   if ((rc = mpg_k_points_ij(g, n, m->cell.x.p + first, m->cell.y.p + first, m->cell.z.p + first, ij.p, s, latlon_limit, !q.per))) return rc;
   const unsigned nbc = (unsigned)((n + 255) / 256);
-  if (!q.local) {   // Lambert: one bound for the grid, from the latitudes its points span (one small read-back)
-    MPG_HIP(hipMemsetAsync(zr.p, 0xff, sizeof(unsigned long long), s));
-    MPG_HIP(hipMemsetAsync(zr.p + 1, 0, sizeof(unsigned long long), s));
-    k_zrange<<<(unsigned)std::min<int64_t>((P + 255) / 256, 1024), 256, 0, s>>>(P, pts.z.p, zr.p);
-    unsigned long long hz[2];
-    MPG_HIP(hipMemcpyAsync(hz, zr.p, sizeof(hz), hipMemcpyDeviceToHost, s));
-    MPG_HIP(hipStreamSynchronize(s));
+  // One small read-back: how many cells sit on or around the grid (-> the bin size: about one cell per bin) and, for Lambert, the
+  // latitudes the grid's points span (-> one bound for the grid)
+  MPG_HIP(hipMemsetAsync(zr.p, 0xff, sizeof(unsigned long long), s));
+  MPG_HIP(hipMemsetAsync(zr.p + 1, 0, 2 * sizeof(unsigned long long), s));
+  if (!q.local) k_zrange<<<(unsigned)std::min<int64_t>((P + 255) / 256, 1024), 256, 0, s>>>(P, pts.z.p, zr.p);
+  k_nb_inside<<<(unsigned)std::min<int64_t>(nbc, 2048), 256, 0, s>>>(n, ij.p, (float)(NB_RINGS * NB_BIN_MAX), (float)npx, (float)npy, zr.p + 2);
+  unsigned long long hz[3];
+  MPG_HIP(hipMemcpyAsync(hz, zr.p, sizeof(hz), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  {
+    // about one cell per bin where the cells are: the area the counted cells cover, (npx + 2 M) x (npy + 2 M), over their number
+    const double M = NB_RINGS * NB_BIN_MAX, area = ((double)npx + 2 * M) * ((double)npy + 2 * M);
+    int want = (int)floor(sqrt(area / (double)std::max<unsigned long long>(hz[2], 1)));
+    want = std::max(NB_BIN_MIN, std::min(NB_BIN_MAX, want));
+    if (q.per)   // the full circle in whole bins
+      while (want > NB_BIN_MIN && q.nxp % want) --want;
+    q.bin = want;
+  }
+  // a regional lat-lon grid: cell indices are unwrapped around its middle column, which is only unambiguous while the grid
+  // and its margin stay well short of the full circle
+  if (pr.code == MPG_PROJ_LATLON && !q.per && (double)(npx + 2 * NB_RINGS * q.bin) * fabs(pr.loninc) > 300.0) return MPG_SUCCESS;
+  q.nbx = q.per ? q.nxp / q.bin : (npx + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
+  q.nby = (npy + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
+  const int64_t nbins = (int64_t)q.nbx * q.nby;
+  if (nbins + 1 >= 0x7fffffff) return MPG_SUCCESS;
+  if ((rc = cnt.alloc((size_t)nbins + 1, s)) || (rc = off.alloc((size_t)nbins + 1, s))) return rc;
+  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
+  if (!q.local) {   // Lambert: one bound for the grid, from the latitudes its points span
     double zlo, zhi;
     memcpy(&zlo, &hz[0], sizeof(double));
     memcpy(&zhi, &hz[1], sizeof(double));
     const double r2d = 180.0 / 3.141592653589793;
     const double lat_lo = asin(fmin(fmax(zlo - 2.0, -1.0), 1.0)) * r2d, lat_hi = asin(fmin(fmax(zhi - 2.0, -1.0), 1.0)) * r2d;
-    q.h = 0.8 * mpg_grid_min_index_chord(g, lat_lo, lat_hi, (double)(NB_RINGS * NB_BIN + 1));
+    q.h = 0.8 * mpg_grid_min_index_chord(g, lat_lo, lat_hi, (double)(NB_RINGS * q.bin + 1));
     if (!(q.h > 0.0)) return MPG_SUCCESS;
   }
   k_nb_count<<<nbc, 256, 0, s>>>(n, ij.p, q, cnt.p);
