@@ -562,8 +562,15 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   TmpBuf<float> ij;
   TmpBuf<int32_t> cnt, off, ids, flags;
   TmpBuf<unsigned long long> zr;
-  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(1, s)) || (rc = zr.alloc(3, s))) return rc;
+  // (the bin counters are sized and cleared for the smallest bins before the read-back below, so that nothing but the count waits for it)
+  const int64_t nbins_max = (int64_t)(q.per ? q.nxp / NB_BIN_MIN : (npx + 2 * NB_RINGS * NB_BIN_MIN + NB_BIN_MIN - 1) / NB_BIN_MIN) *
+                            ((npy + 2 * NB_RINGS * NB_BIN_MIN + NB_BIN_MIN - 1) / NB_BIN_MIN);
+  if (nbins_max + 1 >= 0x7fffffff) return MPG_SUCCESS;
+  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(1, s)) || (rc = zr.alloc(3, s)) ||
+      (rc = cnt.alloc((size_t)nbins_max + 1, s)) || (rc = off.alloc((size_t)nbins_max + 1, s)))
+    return rc;
   MPG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t), s));
+  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins_max + 1), s));
   if ((rc = mpg_k_points_ij(g, n, m->cell.x.p + first, m->cell.y.p + first, m->cell.z.p + first, ij.p, s, latlon_limit, !q.per))) return rc;
   const unsigned nbc = (unsigned)((n + 255) / 256);
   // One small read-back: how many cells sit on or around the grid (-> the bin size: about one cell per bin) and, for Lambert, the
@@ -572,6 +579,7 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   MPG_HIP(hipMemsetAsync(zr.p + 1, 0, 2 * sizeof(unsigned long long), s));
   if (!q.local) k_zrange<<<(unsigned)std::min<int64_t>((P + 255) / 256, 1024), 256, 0, s>>>(P, pts.z.p, zr.p);
   k_nb_inside<<<(unsigned)std::min<int64_t>(nbc, 2048), 256, 0, s>>>(n, ij.p, (float)(NB_RINGS * NB_BIN_MAX), (float)npx, (float)npy, zr.p + 2);
+  MPG_HIP(hipGetLastError());
   unsigned long long hz[3];
   MPG_HIP(hipMemcpyAsync(hz, zr.p, sizeof(hz), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
@@ -590,9 +598,10 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   q.nbx = q.per ? q.nxp / q.bin : (npx + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
   q.nby = (npy + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
   const int64_t nbins = (int64_t)q.nbx * q.nby;
-  if (nbins + 1 >= 0x7fffffff) return MPG_SUCCESS;
-  if ((rc = cnt.alloc((size_t)nbins + 1, s)) || (rc = off.alloc((size_t)nbins + 1, s))) return rc;
-  MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
+  if (nbins > nbins_max) {   // (a grid of a few points: larger bins bring a larger margin)
+    if ((rc = cnt.alloc((size_t)nbins + 1, s)) || (rc = off.alloc((size_t)nbins + 1, s))) return rc;
+    MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
+  }
   if (!q.local) {   // Lambert: one bound for the grid, from the latitudes its points span
     double zlo, zhi;
     memcpy(&zlo, &hz[0], sizeof(double));
