@@ -183,19 +183,17 @@ def main():
     t_gen = time.time() - t0
     F = args.fields
     layout = R.LAYOUT_CELL_FAST if args.layout == "cell_fast" else R.LAYOUT_LEV_FAST
-    if layout == R.LAYOUT_LEV_FAST and world > 1:
-        raise SystemExit("lev_fast layout is single-GPU only")
 
     # MPASSIT_BENCH_TRANSPORT=cabi: the halo schedule and exchange through the C-ABI's own RCCL verbs (mpg_comm_init,
     # mpg_halo_build, mpg_halo_exchange_dev) instead of torch.distributed; the default stays torch.distributed
     transport = os.environ.get("MPASSIT_BENCH_TRANSPORT", "torch")
     import uuid
-    id_file = "/dev/shm/mpassit_bench_%s.rcclid" % all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]   # fresh per run
+    run_id = all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]
+    id_file = "/dev/shm/mpassit_bench_%s.rcclid" % run_id   # fresh per run
+    os.environ.setdefault("MPASSIT_RUN_ID", run_id)          # tags the id file of the C-ABI transport: several ranks without one are refused
     sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file)
     P_local = sr.rh.n_dst
     io32 = args.io == "f32"
-    if io32 and world > 1:
-        raise SystemExit("--io f32 is single-GPU only")
     c0, c1 = sr.sched.own
     big_bundle = io32 and world == 1 and F * nlev * 8.0 * sr.sched.n_local > 40e9
     if big_bundle:
@@ -210,6 +208,21 @@ def main():
             synth_fields_device(torch, m.latCell, m.lonCell, nlev, 1, one, seed=20240807 + f)
             src_for_kernel[f].copy_(one.t() if layout == R.LAYOUT_LEV_FAST else one)
         del one
+    elif world > 1 and (io32 or layout == R.LAYOUT_LEV_FAST):
+        # sharded run on the sources as the driver holds them (float32 and / or MPAS file order, input_data.F90:630-655): the local
+        # slab exists in its final form only -- [F][n_local][L] in file order, where a neighbour's strip is one byte range per field --
+        # and the halo exchange moves that element type
+        local = sr.local_buffer(F, nlev, dev, dtype=torch.float32 if io32 else torch.float64, layout=layout)
+        lev_fast = layout == R.LAYOUT_LEV_FAST
+        if sr.sched.mode == "range":
+            own = sr.own_view(local)
+        else:
+            own = torch.empty((F, c1 - c0, nlev) if lev_fast else (F * nlev, c1 - c0), dtype=local.dtype, device=dev)
+        gen = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
+        synth_fields_device(torch, m.latCell[c0:c1], m.lonCell[c0:c1], nlev, F, gen)
+        own.copy_(gen.view(F, nlev, -1).permute(0, 2, 1) if lev_fast else gen)
+        del gen
+        src_for_kernel = local
     else:
         local = sr.local_buffer(F, nlev, dev)
         if sr.sched.mode == "range":
@@ -308,7 +321,7 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
     halo = None
     if world > 1:   # the exchange as the halo stream saw it (it overlaps the Regrid of the previous batch), and what it moved
-        plan = sr.sched.plan(F * nlev, local)
+        plan = sr.sched.plan(local.shape[0], local)
         per_rank = all_gather_object({"exchange_ms": float(np.mean([a.elapsed_time(b) for a, b in pipe["ev"]])) if pipe["ev"] else None,
                                       "kernel_ms": kern_ms, "sent": int(plan.bytes_sent), "received": int(plan.bytes_received),
                                       "n_local": int(sr.sched.n_local), "needed": int(sr.n_needed), "rows": int(sr.j1 - sr.j0)})
@@ -407,20 +420,26 @@ def main():
     if rank == 0:
         fields_per_s = F * args.steps / dt
         # What the driver's record keeps whole is `roofline` and `config`: the numbers of the paths a run of the shipped
-        # driver actually takes (float32 file order; the whole job; the Stores) ride inside `roofline.paths`.  Cold values
+        # driver actually takes (float32 file order; the whole job; the Stores) ride inside `roofline` as flat scalars.  Cold values
         # are FIRST-IN-PROCESS ones: MPASSIT is a single-shot tool (mpassit.F90:105-137).
-        paths = None
-        if production or job or store:
-            paths = {}
-            if production:
-                paths["f32_lev_fast_%s" % args.workload.split("_")[0]] = {
-                    "kernel": production["kernel"].split(" (")[0], "kernel_ms": round(production["kernel_ms"], 4),
-                    "frac": round(production["roofline_frac"], 4), "frac_big_endian": round(production["roofline_frac_big_endian"], 4),
-                    "traffic_ratio": round(production["traffic"] / production["alg_bytes_per_launch"], 3) if production.get("traffic") else None}
-            if job and "error" not in job:
-                paths["job"] = {k: job[k] for k in ("cold_first_ms", "cold_ms", "warm_ms", "alg_bytes_warm", "frac_warm", "geometry_first_ms", "geometry_ms")}
-            if store and "error" not in store:
-                paths["store"] = {k: {"ms_first": round(v["ms_first"], 3), "ms": round(v["ms"], 3)} for k, v in store.items() if isinstance(v, dict)}
+        # ... as FLAT scalars with short keys: the driver's record flattens `roofline` (a nested object inside it was dropped in
+        # round 4) and cuts keys at 40 and strings at 120 characters.  The full objects stay at the top level of the line.
+        flat = {}
+        if production:
+            flat.update(f32_lev_fast_ms=round(production["kernel_ms"], 4), f32_lev_fast_frac=round(production["roofline_frac"], 4),
+                        f32_lev_fast_frac_be=round(production["roofline_frac_big_endian"], 4),
+                        f32_lev_fast_traffic_ratio=round(production["traffic"] / production["alg_bytes_per_launch"], 3) if production.get("traffic") else None)
+        if job and "error" not in job:
+            flat.update(job_cold_first_ms=job["cold_first_ms"], job_cold_ms=job["cold_ms"], job_warm_ms=job["warm_ms"], job_warm_frac=job["frac_warm"],
+                        job_geometry_first_ms=job["geometry_first_ms"], job_mpg_init_ms=job.get("mpg_init_ms"))
+        if store and "error" not in store:
+            st = {k: v for k, v in store.items() if isinstance(v, dict)}
+            flat.update(store_first_ms_sum=round(sum(v["ms_first"] for v in st.values()), 3), store_ms_sum=round(sum(v["ms"] for v in st.values()), 3),
+                        store_mpg_init_ms=store.get("mpg_init_ms"))
+            for k, v in st.items():
+                flat["store_%s_first_ms" % k] = round(v["ms_first"], 3)
+        if traffic:
+            flat["traffic_ratio"] = round(traffic / alg_bytes, 3)
         rec = {
             "metric": "interpolated 3-D fields/sec (nCells x nLev -> nx x ny)",
             "value": fields_per_s, "unit": "fields/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -430,11 +449,11 @@ def main():
                        "target_points": int(g.nx * g.ny), "method": "bilinear", "src_layout": args.layout,
                        "io_dtype": "f32 (fused ingest/egress, f64 arithmetic)" if io32 else "f64",
                        "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
-                       "unmapped_points_rank0": n_unmapped, "first_and_last_field_equal_single_field_regrid": bundle_check},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
-                         "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
-                         "device_copy_GBs": copy_gbs, "paths": paths},
+                       "unmapped_points_rank0": n_unmapped, "bundle_ends_equal_single": bundle_check},
+            "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
+                              "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
+                              "device_copy_GBs": copy_gbs}, **flat),
             "cpu_baseline": cpu,
             "end_to_end_pcie": e2e,
             "production_path": production,
@@ -688,9 +707,9 @@ def cpu_baseline(sr, local_rows, nlev, seconds, m, g):
     alg_field = nlev * 8.0 * (int(np.unique(idx[idx >= 0]).size) + idx.shape[0]) + idx.shape[0] * 36.0   # SURVEY s8(d), one float64 field
     return {"value": reps / el, "unit": "fields/s", "cores": cores, "kind": "port", "GBs": round(alg_field * reps / el / 1e9, 1),
             "store_ms": store_s * 1e3,
-            "sample": "%d full 3-D fields (%d levels, all %d target points) through the oracle's OpenMP apply loop (blocked by target "
-                      "tile), weights from the GPU handle; GBs = algorithmic bytes moved per second; store_ms = the oracle's bilinear "
-                      "RegridStore once; a CPU restatement, not ESMF (unavailable): do not read the ratio as a speed-up" % (reps, nlev, idx.shape[0])}
+            "sample": "%d whole 3-D fields (%d lev x %d pts), oracle OpenMP apply loop; a CPU restatement, NOT ESMF" % (reps, nlev, idx.shape[0]),
+            "note": "weights from the GPU handle; GBs = algorithmic bytes per second; store_ms = the oracle's bilinear RegridStore once; "
+                    "ESMF is unavailable here: do not read the ratio as a speed-up"}
 
 
 if __name__ == "__main__":

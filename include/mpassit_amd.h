@@ -341,7 +341,9 @@ int mpg_pack_dev(const double *src_dev, int64_t n_src, int nlev, const int32_t *
 /* The id file and its deadlines: rank 0 removes whatever is at `id_file`, writes {magic, launch tag = hash of the
  * environment's MPASSIT_RUN_ID (0 without), wall-clock time, nranks, id} and removes the file again once ncclCommInitRank
  * has returned; the other ranks ignore a file with another tag / nranks or written more than MPG_COMM_STALE_S (300) seconds
- * before they loaded the library.  Waiting for the file, ncclCommInitRank (run on a helper thread) and the blocking
+ * before they loaded the library.  Several ranks WITHOUT MPASSIT_RUN_ID are refused (MPG_ERR_INVALID_ARG: an untagged launch cannot
+ * tell its file from one a crashed launch left behind); MPG_COMM_ALLOW_UNTAGGED=1 overrides, a reader then takes only a file at most
+ * 30 s older than itself whose bytes are unchanged one second later.  Waiting for the file, ncclCommInitRank (run on a helper thread) and the blocking
  * all-gathers give up after MPG_COMM_TIMEOUT_S (120) seconds with MPG_ERR_TIMEOUT: a dead or missing peer is an error exit,
  * never a hang.  mpg_comm_idfile_verdict is that acceptance rule as a pure function (NULL = accepted; CPU tests). */
 typedef struct mpg_comm_s *mpg_comm;
@@ -357,12 +359,31 @@ int mpg_halo_build(mpg_comm comm, mpg_handle rh, int64_t n_cells_global, int own
  * cross the links per exchanged row.  Any pointer may be NULL. */
 int mpg_halo_info(mpg_halo halo, int *mode, int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *sent_per_row,
                   int64_t *received_per_row);
-/* own_dev: nrows rows of the own block, row stride own_ld elements; local_dev: [nrows][n_local], filled in place; elem_bytes
- * 4 or 8.  Range form: own_dev may be the in-place view (local_dev + own_pos[0] elements, own_ld = n_local) -- the own
+/* own_dev: nrows rows of the own block, row stride own_ld elements; local_dev: [nrows][n_local], filled in place.
+ * elem_bytes: 4 or 8 for sources held cell-fast ([level][cell], input_data.F90:653-655: nrows = nfields * nlev), or the bytes of
+ * one whole source row for sources held in MPAS file order ([cell][level], input_data.F90:630,645: nrows = nfields, elem_bytes =
+ * nlev * 4 for float32, nlev * 8 for float64; any multiple of 4) -- in range form a neighbour's strip of a file-order slab is
+ * ONE contiguous byte range per field, no pack step at all.
+ * Range form: own_dev may be the in-place view (local_dev + own_pos[0] elements, own_ld = n_local) -- the own
  * data is then where Regrid reads it and only the neighbours' strips move -- or a separate buffer, which is copied to
  * its place first; any other overlap with local_dev is refused.  Compact form: own_dev is always a separate buffer. */
 int mpg_halo_exchange_dev(mpg_halo halo, const void *own_dev, int64_t own_ld, void *local_dev, int nrows, int elem_bytes, void *hip_stream);
 int mpg_halo_destroy(mpg_halo halo);
+/* dst[k][i] = src[k * ld + ids[i]], nrows rows of elements of elem_bytes bytes (as above): the pack step of the compact halo
+ * form on its own, for a host that runs the exchange through its own transport (mpassit_amd/dist.py on torch.distributed). */
+int mpg_pack_rows_dev(const void *src_dev, int64_t ld, int nrows, int elem_bytes, const int32_t *ids_dev, int64_t n_ids, void *dst_dev, void *hip_stream);
+/* REHEARSAL ON ONE GPU (tests and tools; never a production path).  RCCL refuses two ranks on one card, but it accepts
+ * ncclSend / ncclRecv with peer == self inside one group.  mpg_comm_virtual makes virtual rank v_rank of v_nranks on top of
+ * `real`, the ONE-rank communicator of the process; every virtual rank is driven by its own host thread and makes the calls a
+ * real rank makes (mpg_comm_allgather, mpg_halo_build, mpg_halo_exchange_dev, mpg_gather_rows).  Each collective step is a
+ * rendezvous of those threads; the last to arrive issues, for all of them, the very RCCL calls the real ranks would issue --
+ * same entry points, same device pointers and byte counts from each rank's own schedule, each transfer on its rank's stream --
+ * with every peer mapped to rank 0 of the real communicator.  Two ranks whose schedules disagree (a send that meets a receive
+ * of another size) fail the step.  What it cannot show is bytes crossing xGMI.  A thread that never arrives ends the others'
+ * wait with MPG_ERR_TIMEOUT after MPG_COMM_TIMEOUT_S.  mpg_comm_virtual_stats: groups, sends, receives and all-gathers the
+ * group has really put through RCCL (any pointer may be NULL).  Destroy the virtual ranks before `real`. */
+int mpg_comm_virtual(mpg_comm real, int v_rank, int v_nranks, mpg_comm *out);
+int mpg_comm_virtual_stats(mpg_comm comm, int64_t *groups, int64_t *sends, int64_t *recvs, int64_t *allgathers);
 /* rows_dev: this rank's [nlev][j1 - j0][nx] block of an [nlev][ny][nx] field; dst_dev (root only): the whole field */
 int mpg_gather_rows(mpg_comm comm, const void *rows_dev, int64_t j0, int64_t j1, int64_t nx, int64_t ny, int nlev, int elem_bytes,
                     void *dst_dev, int root, void *hip_stream);

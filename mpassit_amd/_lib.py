@@ -19,7 +19,8 @@ SYMBOLS = [
     "mpg_handle_get_pole", "mpg_bswap_dev", "mpg_file_to_dev", "mpg_dev_to_file", "mpg_dev_alloc", "mpg_dev_free", "mpg_dev_upload", "mpg_dev_download", "mpg_post_cast_dev", "mpg_post_layer_mean_dev", "mpg_post_ptop_dev", "mpg_post_ptop_parts_dev", "mpg_grid_create_proj", "mpg_grid_get_coords",
     "mpg_grid_get_rotang", "mpg_grid_get_mapfac", "mpg_grid_rotang_dev", "mpg_handle_source_range", "mpg_mesh_set_source_window",
     "mpg_comm_init", "mpg_comm_destroy", "mpg_comm_info", "mpg_comm_allgather", "mpg_halo_build", "mpg_halo_info", "mpg_halo_exchange_dev",
-    "mpg_halo_destroy", "mpg_gather_rows", "mpg_halo_plan_host", "mpg_comm_idfile_verdict",
+    "mpg_halo_destroy", "mpg_gather_rows", "mpg_halo_plan_host", "mpg_comm_idfile_verdict", "mpg_pack_rows_dev", "mpg_comm_virtual",
+    "mpg_comm_virtual_stats",
 ]
 
 MPG_SUCCESS = 0

@@ -81,9 +81,48 @@ int rccl_load() {
   } while (0)
 }  // namespace
 
+// One transfer of a grouped exchange as a rank states it: `ns` bytes from sbuf to `peer`, `nr` bytes from `peer` into rbuf
+// (either may be 0).  A real communicator turns the list into ONE ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd.
+struct P2P {
+  int peer;
+  const void *sbuf;
+  size_t ns;
+  void *rbuf;
+  size_t nr;
+};
+
+// Rehearsal on ONE GPU (mpg_comm_virtual; tests and tools only): V virtual ranks, one host thread each, share the ONE-rank
+// RCCL communicator of the process.  RCCL refuses two ranks on one card, but it accepts ncclSend / ncclRecv with peer == self
+// inside one group, matched in issue order.  So every collective step of the verbs below is a rendezvous of the V threads;
+// the last one to arrive issues, for all of them, the very calls a real rank would issue -- the same dlsym'd entry points,
+// the same device pointers and byte counts out of each rank's own schedule, each transfer on its rank's stream -- with every
+// peer mapped to rank 0 of the real communicator: sends in (source rank, list order), each followed by the receive the
+// DESTINATION rank listed for that source.  A send whose size differs from the receive it meets is a schedule bug and is
+// reported as one.  What this cannot show is bytes crossing xGMI.
+struct VGroup {
+  int V = 0;
+  ncclComm_t comm = nullptr;
+  std::mutex mu;                 // rendezvous state
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  int rc = MPG_SUCCESS;
+  std::string err;
+  std::mutex work_mu;            // device work of the virtual ranks' threads outside the rendezvous runs one at a time
+  std::vector<const void *> ag_send;
+  int64_t ag_nbytes = 0;
+  std::vector<char> ag_all;
+  std::vector<std::vector<P2P>> ops;
+  std::vector<hipStream_t> streams;
+  int refs = 0;
+  int64_t n_send_calls = 0, n_recv_calls = 0, n_groups = 0, n_allgathers = 0;   // what really went through RCCL
+};
+
 struct mpg_comm_s {
   int rank = 0, nranks = 1;
   ncclComm_t comm = nullptr;
+  VGroup *vg = nullptr;          // set on a virtual rank (and on the real communicator that owns the group)
+  bool is_virtual = false;
 };
 
 // ---- the schedule (pure host logic; mirrors dist.HaloSchedule.build) ------------------------------------------------------
@@ -223,6 +262,32 @@ __global__ __launch_bounds__(256) void k_pack_ids(const T *__restrict__ src, int
   for (int k = 0; k < nrows; ++k) dst[(int64_t)k * n + i] = src[(int64_t)k * ld + c];
 }
 
+// the same for elements of `ew` 4-byte words (a file-order source row [nlev] of float32 / float64 is one element: the strip a
+// peer wants is then whole rows of the [cell][nlev] slab); one thread per word, consecutive lanes on consecutive words
+__global__ __launch_bounds__(256) void k_pack_ids_w(const uint32_t *__restrict__ src, int64_t ld, int nrows, const int32_t *__restrict__ ids, int64_t n, int ew,
+                                                    uint32_t *__restrict__ dst) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * ew) return;
+  const int64_t i = t / ew;
+  const int w = (int)(t - i * ew);
+  const int64_t c = ids[i];
+  for (int k = 0; k < nrows; ++k) dst[((int64_t)k * n + i) * ew + w] = src[((int64_t)k * ld + c) * ew + w];
+}
+
+static int pack_ids(const void *src, int64_t ld, int nrows, int elem_bytes, const int32_t *ids, int64_t n, void *dst, hipStream_t s) {
+  if (n <= 0 || nrows <= 0) return MPG_SUCCESS;
+  if (elem_bytes == 8) {
+    k_pack_ids<unsigned long long><<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const unsigned long long *)src, ld, nrows, ids, n, (unsigned long long *)dst);
+  } else if (elem_bytes == 4) {
+    k_pack_ids<uint32_t><<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint32_t *)src, ld, nrows, ids, n, (uint32_t *)dst);
+  } else {
+    const int ew = elem_bytes / 4;
+    k_pack_ids_w<<<(unsigned)((n * ew + 255) / 256), 256, 0, s>>>((const uint32_t *)src, ld, nrows, ids, n, ew, (uint32_t *)dst);
+  }
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
 // The id file: rank 0 writes {magic, launch tag, wall-clock time, nranks, RCCL unique id} under a temporary name and renames
 // it; the others poll for it.  What can go wrong is a file LEFT BEHIND by an earlier launch that died before rank 0 could
 // remove it: a rank reading that id would sit in ncclCommInitRank for ever.  Hence
@@ -231,6 +296,11 @@ __global__ __launch_bounds__(256) void k_pack_ids(const T *__restrict__ src, int
 //   * a reader only accepts a file with the right magic and nranks, with ITS launch tag (a hash of MPASSIT_RUN_ID when
 //     the launcher sets one -- tools/mpassit_ranks.py, bench.py do), and written no longer than MPG_COMM_STALE_S (300 s)
 //     before this process loaded the library; anything else is ignored and the wait goes on;
+//   * a launch WITHOUT a tag cannot tell its own file from one a crashed launch left behind minutes ago (a reader that starts
+//     before its rank 0 would take the old id and sit in ncclCommInitRank until the deadline): several ranks without
+//     MPASSIT_RUN_ID are refused.  MPG_COMM_ALLOW_UNTAGGED=1 overrides that for hosts that guarantee a fresh path per launch;
+//     a reader then accepts only a file written at most MPG_COMM_STALE_S (then 30 s by default) before it loaded the library
+//     whose bytes are still the same one second later (rank 0 replaces a stale file as soon as it starts);
 //   * every wait has a deadline (MPG_COMM_TIMEOUT_S, default 120 s) -- for the file, and for ncclCommInitRank itself, which
 //     runs on a helper thread: a peer that never arrives gives MPG_ERR_TIMEOUT, not a hang.  After a timeout the process
 //     must exit (the helper thread is still inside RCCL); never restart a process that has touched the GPU.
@@ -284,7 +354,17 @@ int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
   MPG_ARG(nranks == 1 || (id_file && *id_file), "mpg_comm_init: nranks > 1 needs the path of the id file");
   int rc = rccl_load();
   if (rc) return rc;
-  const double timeout_s = mpg_comm_timeout_s(), stale_s = env_seconds("MPG_COMM_STALE_S", 300.0);
+  const uint64_t tag = launch_tag();
+  const bool untagged = nranks > 1 && tag == 0;
+  if (untagged) {
+    const char *ok = getenv("MPG_COMM_ALLOW_UNTAGGED");
+    if (!ok || !*ok || *ok == '0') {
+      mpg_set_error("mpg_comm_init: %d ranks need MPASSIT_RUN_ID in the environment, unique per launch (it tags the id file: without it a file left by a "
+                    "crashed launch cannot be told from this launch's); MPG_COMM_ALLOW_UNTAGGED=1 overrides", nranks);
+      return MPG_ERR_INVALID_ARG;
+    }
+  }
+  const double timeout_s = mpg_comm_timeout_s(), stale_s = env_seconds("MPG_COMM_STALE_S", untagged ? 30.0 : 300.0);
   const int64_t t_start = wall_ns();
   IdFile f;
   memset(&f, 0, sizeof(f));
@@ -292,7 +372,7 @@ int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
     MPG_NCCL(R.GetUniqueId(&f.id));
     if (nranks > 1) {   // under a temporary name, then renamed: a reader never sees half a file
       memcpy(f.magic, ID_MAGIC, 8);
-      f.tag = launch_tag();
+      f.tag = tag;
       f.written_ns = wall_ns();
       f.nranks = nranks;
       (void)unlink(id_file);   // whatever an earlier launch left there
@@ -312,7 +392,15 @@ int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
       if (fp) {
         const size_t n = fread(&cand, 1, sizeof(cand), fp);
         fclose(fp);
-        why = mpg_comm_idfile_verdict(&cand, (int64_t)n, nranks, launch_tag(), g_loaded_ns, stale_s);
+        why = mpg_comm_idfile_verdict(&cand, (int64_t)n, nranks, tag, g_loaded_ns, stale_s);
+        if (!why && untagged) {   // no tag to tell launches apart: the file must survive a second look (rank 0 replaces what it finds)
+          usleep(1000000);
+          IdFile again;
+          FILE *f2 = fopen(id_file, "rb");
+          const size_t n2 = f2 ? fread(&again, 1, sizeof(again), f2) : 0;
+          if (f2) fclose(f2);
+          if (n2 != sizeof(again) || memcmp(&again, &cand, sizeof(cand))) why = "replaced while it was being read (an earlier launch's file)";
+        }
         if (!why) {
           f = cand;
           got = true;
@@ -373,8 +461,62 @@ int mpg_comm_init(int rank, int nranks, const char *id_file, mpg_comm *out) {
 
 int mpg_comm_destroy(mpg_comm c) {
   if (!c) return MPG_SUCCESS;
+  if (c->is_virtual) {   // a virtual rank borrows the real communicator
+    std::lock_guard<std::mutex> lk(c->vg->mu);
+    --c->vg->refs;
+    delete c;
+    return MPG_SUCCESS;
+  }
+  if (c->vg) {
+    MPG_ARG(c->vg->refs == 0, "mpg_comm_destroy: virtual ranks of this communicator are still alive (destroy them first)");
+    delete c->vg;
+  }
   if (c->comm) (void)R.CommDestroy(c->comm);
   delete c;
+  return MPG_SUCCESS;
+}
+
+// Rehearsal only (struct VGroup above): virtual rank v_rank of v_nranks on top of `real`, the ONE-rank communicator of this
+// process.  Every virtual rank is driven by its own host thread; the collective verbs (mpg_comm_allgather, mpg_halo_build,
+// mpg_halo_exchange_dev, mpg_gather_rows) must be called by all of them, as on real ranks.
+int mpg_comm_virtual(mpg_comm real, int v_rank, int v_nranks, mpg_comm *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(real && out && !real->is_virtual && real->nranks == 1, "mpg_comm_virtual: needs the one-rank communicator of this process (mpg_comm_init(0, 1, ...))");
+  MPG_ARG(v_nranks >= 1 && v_nranks <= 64 && v_rank >= 0 && v_rank < v_nranks, "mpg_comm_virtual: bad rank / number of virtual ranks");
+  static std::mutex mk;
+  std::lock_guard<std::mutex> lk(mk);
+  if (!real->vg) {
+    VGroup *g = new VGroup();
+    g->V = v_nranks;
+    g->comm = real->comm;
+    g->ag_send.assign(v_nranks, nullptr);
+    g->ops.resize(v_nranks);
+    g->streams.assign(v_nranks, nullptr);
+    real->vg = g;
+  }
+  MPG_ARG(real->vg->V == v_nranks, "mpg_comm_virtual: this communicator already carries a virtual group of another size");
+  mpg_comm_s *c = new mpg_comm_s();
+  c->rank = v_rank;
+  c->nranks = v_nranks;
+  c->comm = real->comm;
+  c->vg = real->vg;
+  c->is_virtual = true;
+  {
+    std::lock_guard<std::mutex> l2(c->vg->mu);
+    ++c->vg->refs;
+  }
+  *out = c;
+  return MPG_SUCCESS;
+}
+
+// what the virtual ranks of `c`'s group have really put through RCCL so far (any pointer may be NULL)
+int mpg_comm_virtual_stats(mpg_comm c, int64_t *groups, int64_t *sends, int64_t *recvs, int64_t *allgathers) {
+  MPG_ARG(c && c->vg, "mpg_comm_virtual_stats: not a virtual rank (nor the communicator under one)");
+  std::lock_guard<std::mutex> lk(c->vg->mu);
+  if (groups) *groups = c->vg->n_groups;
+  if (sends) *sends = c->vg->n_send_calls;
+  if (recvs) *recvs = c->vg->n_recv_calls;
+  if (allgathers) *allgathers = c->vg->n_allgathers;
   return MPG_SUCCESS;
 }
 
@@ -404,10 +546,161 @@ static int stream_wait_deadline(hipStream_t s, const char *what) {
   }
 }
 
+}  // extern "C"
+
+// Rendezvous of the virtual ranks' threads: `deposit` runs under the group's lock as a thread arrives, `leader_work` once,
+// in the last thread to arrive, while the others wait; every thread returns the leader's rc (and error text).
+template <typename FD, typename FL>
+static int vg_rendezvous(VGroup *g, FD &&deposit, FL &&leader_work) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  const uint64_t my_gen = g->gen;
+  deposit();
+  if (++g->arrived == g->V) {
+    g->rc = leader_work();
+    g->err = g->rc ? mpg_last_error() : "";
+    g->arrived = 0;
+    ++g->gen;
+    g->cv.notify_all();
+    return g->rc;
+  }
+  const double t = mpg_comm_timeout_s();
+  if (!g->cv.wait_for(lk, std::chrono::duration<double>(t), [&] { return g->gen != my_gen; })) {
+    mpg_set_error("virtual ranks: %d of %d arrived at a collective step within %.0f s (every virtual rank needs its own thread, and all of them "
+                  "must make the same calls)", g->arrived, g->V, t);
+    --g->arrived;
+    return MPG_ERR_TIMEOUT;
+  }
+  if (g->rc) mpg_set_error("%s", g->err.c_str());
+  return g->rc;
+}
+
+// the metadata all-gather of V virtual ranks: their contributions, in rank order, travel through ONE ncclAllGather of the
+// one-rank communicator on the set-up stream (the call a real rank makes, on the stream it makes it on)
+static int vg_allgather(mpg_comm_s *c, const void *send_host, int64_t nbytes, void *recv_host) {
+  VGroup *g = c->vg;
+  const int V = g->V;
+  int rc = vg_rendezvous(
+      g,
+      [&] {
+        g->ag_send[c->rank] = send_host;
+        if (g->arrived == 0) g->ag_nbytes = nbytes;
+        else if (g->ag_nbytes != nbytes) g->ag_nbytes = -1;
+      },
+      [&]() -> int {
+        MPG_ARG(g->ag_nbytes == nbytes, "mpg_comm_allgather: the virtual ranks contribute different byte counts");
+        hipStream_t s = mpg_setup_stream();
+        const size_t tot = (size_t)nbytes * V;
+        std::vector<char> cat(tot);
+        for (int q = 0; q < V; ++q) memcpy(cat.data() + (size_t)q * nbytes, g->ag_send[q], (size_t)nbytes);
+        TmpBuf<char> sb, rb;
+        int r;
+        if ((r = sb.alloc(tot)) || (r = rb.alloc(tot))) return r;
+        g->ag_all.resize(tot);
+        MPG_HIP(hipMemcpyAsync(sb.p, cat.data(), tot, hipMemcpyHostToDevice, s));
+        MPG_NCCL(R.AllGather(sb.p, rb.p, tot, ncclChar, g->comm, s));
+        ++g->n_allgathers;
+        MPG_HIP(hipMemcpyAsync(g->ag_all.data(), rb.p, tot, hipMemcpyDeviceToHost, s));
+        return stream_wait_deadline(s, "mpg_comm_allgather (virtual ranks)");
+      });
+  if (rc) return rc;
+  memcpy(recv_host, g->ag_all.data(), (size_t)nbytes * V);   // stays valid until every rank has arrived at the NEXT step
+  return MPG_SUCCESS;
+}
+
+// One grouped exchange.  A real rank: ncclGroupStart, its sends and receives, ncclGroupEnd, on its stream.  Virtual ranks:
+// the lists of all V threads are matched (a send of rank r to rank q with the next receive rank q lists for r; equal sizes
+// required -- the two ranks' schedules must agree) and go out as ONE group of sends and receives to self, each on the
+// stream of the rank it belongs to.  MPG_VRANK_ONE_STREAM=1 puts the whole group on rank 0's stream with event edges from and
+// to the other ranks' streams instead.
+static int comm_exchange(mpg_comm_s *c, const std::vector<P2P> &ops, hipStream_t s) {
+  if (!c->is_virtual) {
+    if (c->nranks == 1) return MPG_SUCCESS;
+    MPG_NCCL(R.GroupStart());
+    for (const P2P &o : ops) {
+      if (o.ns) MPG_NCCL(R.Send(o.sbuf, o.ns, ncclChar, o.peer, c->comm, s));
+      if (o.nr) MPG_NCCL(R.Recv(o.rbuf, o.nr, ncclChar, o.peer, c->comm, s));
+    }
+    MPG_NCCL(R.GroupEnd());
+    return MPG_SUCCESS;
+  }
+  VGroup *g = c->vg;
+  const int V = g->V;
+  return vg_rendezvous(
+      g,
+      [&] {
+        g->ops[c->rank] = ops;
+        g->streams[c->rank] = s;
+      },
+      [&]() -> int {
+        struct Pair { const P2P *snd, *rcv; int src, dst; };
+        std::vector<Pair> pairs;
+        std::vector<size_t> cur((size_t)V * V, 0);
+        auto next_recv = [&](int dst, int src) -> const P2P * {
+          const std::vector<P2P> &L = g->ops[dst];
+          size_t &k = cur[(size_t)dst * V + src];
+          while (k < L.size() && !(L[k].peer == src && L[k].nr)) ++k;
+          return k < L.size() ? &L[k++] : nullptr;
+        };
+        for (int src = 0; src < V; ++src)
+          for (const P2P &o : g->ops[src]) {
+            if (!o.ns) continue;
+            if (o.peer < 0 || o.peer >= V || o.peer == src) {
+              mpg_set_error("virtual ranks: rank %d lists a send to rank %d", src, o.peer);
+              return MPG_ERR_INVALID_ARG;
+            }
+            const P2P *r = next_recv(o.peer, src);
+            if (!r || r->nr != o.ns) {
+              mpg_set_error("virtual ranks: rank %d sends %zu bytes to rank %d, which expects %zu from it: the two schedules disagree", src, o.ns, o.peer,
+                            r ? r->nr : (size_t)0);
+              return MPG_ERR_INVALID_ARG;
+            }
+            pairs.push_back({&o, r, src, o.peer});
+          }
+        for (int dst = 0; dst < V; ++dst)
+          for (int src = 0; src < V; ++src)
+            if (const P2P *r = next_recv(dst, src)) {
+              mpg_set_error("virtual ranks: rank %d expects %zu bytes from rank %d, which sends nothing more", dst, r->nr, src);
+              return MPG_ERR_INVALID_ARG;
+            }
+        if (pairs.empty()) return MPG_SUCCESS;
+        const char *e = getenv("MPG_VRANK_ONE_STREAM");
+        const bool one = e && *e && *e != '0';
+        hipStream_t lead = g->streams[0];
+        hipEvent_t ev = nullptr;
+        if (one) {
+          MPG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          for (int q = 1; q < V; ++q)
+            if (g->streams[q] != lead) {
+              MPG_HIP(hipEventRecord(ev, g->streams[q]));
+              MPG_HIP(hipStreamWaitEvent(lead, ev, 0));
+            }
+        }
+        MPG_NCCL(R.GroupStart());
+        for (const Pair &p : pairs) {
+          MPG_NCCL(R.Send(p.snd->sbuf, p.snd->ns, ncclChar, 0, g->comm, one ? lead : g->streams[p.src]));
+          MPG_NCCL(R.Recv(p.rcv->rbuf, p.rcv->nr, ncclChar, 0, g->comm, one ? lead : g->streams[p.dst]));
+        }
+        MPG_NCCL(R.GroupEnd());
+        ++g->n_groups;
+        g->n_send_calls += (int64_t)pairs.size();
+        g->n_recv_calls += (int64_t)pairs.size();
+        if (one) {
+          MPG_HIP(hipEventRecord(ev, lead));
+          for (int q = 1; q < V; ++q)
+            if (g->streams[q] != lead) MPG_HIP(hipStreamWaitEvent(g->streams[q], ev, 0));
+          MPG_HIP(hipEventDestroy(ev));
+        }
+        return MPG_SUCCESS;
+      });
+}
+
+extern "C" {
+
 // every rank contributes nbytes from send_host; recv_host gets nranks * nbytes in rank order (small host-side metadata)
 int mpg_comm_allgather(mpg_comm c, const void *send_host, int64_t nbytes, void *recv_host) {
   MPG_CHECK_INIT();
   MPG_ARG(c && send_host && recv_host && nbytes > 0, "mpg_comm_allgather: bad argument");
+  if (c->is_virtual) return vg_allgather(c, send_host, nbytes, recv_host);
   hipStream_t s = mpg_setup_stream();
   TmpBuf<char> sb, rb;
   int rc;
@@ -465,6 +758,16 @@ int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg
   MPG_ARG(!mpg_handle_is_windowed(h), "mpg_halo_build: the handle's mesh has a source window (mpg_mesh_set_source_window): its indices are "
                                       "window-relative; a windowed mesh and a halo exchange are alternatives -- reset the window first");
   hipStream_t s = mpg_setup_stream();
+  // virtual ranks (rehearsal): the threads' device work on the shared set-up stream and the Store cache runs one at a time;
+  // the lock is dropped around every collective step
+  std::unique_lock<std::mutex> work;
+  if (c->is_virtual) work = std::unique_lock<std::mutex>(c->vg->work_mu);
+  auto allgather = [&](const void *snd, int64_t nb, void *rcv) {
+    if (work.owns_lock()) work.unlock();
+    const int r = mpg_comm_allgather(c, snd, nb, rcv);
+    if (c->is_virtual) work.lock();
+    return r;
+  };
   std::vector<int32_t> ids;
   int rc = mpg_k_unique_sources(h, ids, false, s);
   if (rc) return rc;
@@ -474,8 +777,8 @@ int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg
   int64_t cnt = (int64_t)ids.size();
   std::vector<int64_t> counts(world);
   if (world > 1) {
-    if ((rc = mpg_comm_allgather(c, &mine, sizeof(Vote), votes.data()))) return rc;
-    if ((rc = mpg_comm_allgather(c, &cnt, sizeof(int64_t), counts.data()))) return rc;
+    if ((rc = allgather(&mine, sizeof(Vote), votes.data()))) return rc;
+    if ((rc = allgather(&cnt, sizeof(int64_t), counts.data()))) return rc;
   } else {
     votes[0] = mine;
     counts[0] = cnt;
@@ -494,7 +797,7 @@ int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg
     std::vector<int32_t> padded((size_t)std::max<int64_t>(mx, 1), 0x7fffffff), all((size_t)std::max<int64_t>(mx, 1) * world);
     std::copy(ids.begin(), ids.end(), padded.begin());
     if (world > 1) {
-      if ((rc = mpg_comm_allgather(c, padded.data(), (int64_t)padded.size() * 4, all.data()))) { delete H; return rc; }
+      if ((rc = allgather(padded.data(), (int64_t)padded.size() * 4, all.data()))) { delete H; return rc; }
     } else {
       all = padded;
     }
@@ -558,10 +861,13 @@ int mpg_halo_destroy(mpg_halo H) {
 
 // own_dev: nrows rows of this rank's own block (own[1] - own[0] elements used, row stride own_ld elements); local_dev: nrows
 // rows of n_local elements, filled in place.  Range mode: own_dev may point INTO local_dev (own data in place at own_pos[0],
-// own_ld = n_local) -- then only the neighbours' strips move.  elem_bytes 4 or 8.  Enqueued on hip_stream.
+// own_ld = n_local) -- then only the neighbours' strips move.  elem_bytes: 4 or 8 for cell-fast slabs ([level][cell]: nrows =
+// nfields * nlev), or the bytes of one whole source ROW for slabs in file order ([cell][level]: nrows = nfields, elem_bytes =
+// nlev * 4 or nlev * 8 -- in range form a neighbour's strip of such a slab is ONE contiguous byte range per field).
+// Enqueued on hip_stream.
 int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void *local_dev, int nrows, int elem_bytes, void *hip_stream) {
   MPG_CHECK_INIT();
-  MPG_ARG(H && local_dev && nrows >= 1 && (elem_bytes == 4 || elem_bytes == 8), "mpg_halo_exchange_dev: bad argument");
+  MPG_ARG(H && local_dev && nrows >= 1 && elem_bytes >= 4 && elem_bytes % 4 == 0 && elem_bytes <= (1 << 20), "mpg_halo_exchange_dev: bad argument");
   const HaloPlan &p = H->plan;
   MPG_ARG(own_dev || p.own1 == p.own0, "mpg_halo_exchange_dev: own_dev is NULL");
   hipStream_t s = (hipStream_t)hip_stream;
@@ -583,25 +889,21 @@ int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void 
     if (p.mode == 0) {
       MPG_HIP(hipMemcpy2DAsync(dst, (size_t)n * es, (const char *)own_dev + (size_t)p.send_a[q] * es, (size_t)own_ld * es, (size_t)n * es, (size_t)nrows,
                                hipMemcpyDeviceToDevice, s));
-    } else if (elem_bytes == 8) {
-      k_pack_ids<unsigned long long><<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const unsigned long long *)own_dev, own_ld, nrows,
-                                                                                H->send_ids_dev.p + H->ids_off[q], n, (unsigned long long *)dst);
     } else {
-      k_pack_ids<uint32_t><<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint32_t *)own_dev, own_ld, nrows, H->send_ids_dev.p + H->ids_off[q], n,
-                                                                      (uint32_t *)dst);
+      const int rc = pack_ids(own_dev, own_ld, nrows, elem_bytes, H->send_ids_dev.p + H->ids_off[q], n, dst, s);
+      if (rc) return rc;
     }
   }
-  MPG_HIP(hipGetLastError());
   // 2. one grouped exchange: ncclSend / ncclRecv with every peer that has something (point-to-point over xGMI)
   if (world > 1) {
-    MPG_NCCL(R.GroupStart());
+    std::vector<P2P> ops;
     for (int q = 0; q < world; ++q) {
       if (q == rank) continue;
       const size_t ns = (size_t)p.send_count(q) * nrows * es, nr = (size_t)p.recv_count(q) * nrows * es;
-      if (ns) MPG_NCCL(R.Send(H->sendbuf.p + (size_t)nrows * es * (size_t)H->soff[q], ns, ncclChar, q, H->comm->comm, s));
-      if (nr) MPG_NCCL(R.Recv(H->recvbuf.p + (size_t)nrows * es * (size_t)H->roff[q], nr, ncclChar, q, H->comm->comm, s));
+      if (ns || nr) ops.push_back({q, H->sendbuf.p + (size_t)nrows * es * (size_t)H->soff[q], ns, H->recvbuf.p + (size_t)nrows * es * (size_t)H->roff[q], nr});
     }
-    MPG_NCCL(R.GroupEnd());
+    const int rc = comm_exchange(H->comm, ops, s);
+    if (rc) return rc;
   }
   // range form with the own block held elsewhere: it goes to its place in the local space first (in place when own_dev
   // already IS that place)
@@ -624,6 +926,15 @@ int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void 
                              hipMemcpyDeviceToDevice, s));
   }
   return MPG_SUCCESS;
+}
+
+// dst[k][i] = src[k * ld + ids[i]] for nrows rows of elements of elem_bytes bytes (a multiple of 4): the pack step of the compact
+// halo form for hosts that run the exchange themselves (mpassit_amd/dist.py over torch.distributed); device pointers
+int mpg_pack_rows_dev(const void *src_dev, int64_t ld, int nrows, int elem_bytes, const int32_t *ids_dev, int64_t n_ids, void *dst_dev, void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(src_dev && dst_dev && ids_dev && nrows >= 1 && n_ids >= 0 && ld >= 0 && elem_bytes >= 4 && elem_bytes % 4 == 0 && elem_bytes <= (1 << 20),
+          "mpg_pack_rows_dev: bad argument");
+  return pack_ids(src_dev, ld, nrows, elem_bytes, ids_dev, n_ids, dst_dev, (hipStream_t)hip_stream);
 }
 
 // ESMF_FieldGather (write_data.F90:1006-1453): every rank holds rows [j0, j1) of an [nlev][ny][nx] field as
@@ -651,20 +962,20 @@ int mpg_gather_rows(mpg_comm c, const void *rows_dev, int64_t j0, int64_t j1, in
   if (c->rank == root && j1 > j0)   // the root's own rows: a strided device copy
     MPG_HIP(hipMemcpy2DAsync((char *)dst_dev + (size_t)j0 * row, (size_t)ny * row, rows_dev, (size_t)(j1 - j0) * row, (size_t)(j1 - j0) * row,
                              (size_t)nlev, hipMemcpyDeviceToDevice, s));
-  if (world > 1) {
-    MPG_NCCL(R.GroupStart());
+  if (world > 1) {   // one group: a rank's block travels as nlev segments, each to its level of the root's field
+    std::vector<P2P> ops;
     for (int k = 0; k < nlev; ++k) {
       if (c->rank != root) {
-        if (j1 > j0) MPG_NCCL(R.Send((const char *)rows_dev + (size_t)k * (size_t)(j1 - j0) * row, (size_t)(j1 - j0) * row, ncclChar, root, c->comm, s));
+        if (j1 > j0) ops.push_back({root, (const char *)rows_dev + (size_t)k * (size_t)(j1 - j0) * row, (size_t)(j1 - j0) * row, nullptr, 0});
       } else {
         for (int q = 0; q < world; ++q) {
           const int64_t a = blk[2 * q], b = blk[2 * q + 1];
           if (q == root || b <= a) continue;
-          MPG_NCCL(R.Recv((char *)dst_dev + ((size_t)k * (size_t)ny + (size_t)a) * row, (size_t)(b - a) * row, ncclChar, q, c->comm, s));
+          ops.push_back({q, nullptr, 0, (char *)dst_dev + ((size_t)k * (size_t)ny + (size_t)a) * row, (size_t)(b - a) * row});
         }
       }
     }
-    MPG_NCCL(R.GroupEnd());
+    return comm_exchange(c, ops, s);
   }
   return MPG_SUCCESS;
 }

@@ -139,33 +139,40 @@ class HaloSchedule:
         only) pinned host staging.  The per-step path then consists of copy launches and one collective -- no allocation,
         no list building, no torch.cat."""
         import torch
-        key = (int(R), like.dtype, like.device)
+        # sources held cell-fast: rows [R][n] of scalars; in MPAS file order: [F][n][L] -- the exchanged element is one whole row of L
+        # values (input_data.F90:630,645), so a neighbour's strip is one contiguous piece per field
+        L = int(like.shape[2]) if like.dim() == 3 else 1
+        key = (int(R), L if like.dim() == 3 else 0, like.dtype, like.device)
         p = self._plans.get(key)
         if p is not None:
             return p
         send_n, recv_n = self.counts()
         p = _HaloPlan()
-        p.sendbuf = torch.empty(R * sum(send_n), dtype=like.dtype, device=like.device)
-        p.recvbuf = torch.empty(R * sum(recv_n), dtype=like.dtype, device=like.device)
-        p.in_splits, p.out_splits = [R * n for n in recv_n], [R * n for n in send_n]
+        p.sendbuf = torch.empty(R * L * sum(send_n), dtype=like.dtype, device=like.device)
+        p.recvbuf = torch.empty(R * L * sum(recv_n), dtype=like.dtype, device=like.device)
+        p.in_splits, p.out_splits = [R * L * n for n in recv_n], [R * L * n for n in send_n]
         p.send_views, p.recv_views = [], []
+
+        def shaped(buf, off, n):
+            v = buf[off:off + R * L * n]
+            return v.view(R, n, L) if like.dim() == 3 else v.view(R, n)
         off = 0
         for q in range(self.world):
             n = send_n[q]
             if n:
-                view = p.sendbuf[off:off + R * n].view(R, n)
+                view = shaped(p.sendbuf, off, n)
                 if self.mode == "range":
                     p.send_views.append((view, self.send_ids[q], None))
                 else:
                     ids = self.send_ids[q]
                     p.send_views.append((view, ids, torch.as_tensor(ids, dtype=torch.long, device=like.device)))
-                off += R * n
+                off += R * L * n
         off = 0
         for q in range(self.world):
             n = recv_n[q]
             if n:
-                p.recv_views.append((p.recvbuf[off:off + R * n].view(R, n), self.recv_pos[q]))
-                off += R * n
+                p.recv_views.append((shaped(p.recvbuf, off, n), self.recv_pos[q]))
+                off += R * L * n
         p.host_send = p.host_recv = None
         p.bytes_sent = p.sendbuf.numel() * p.sendbuf.element_size()
         p.bytes_received = p.recvbuf.numel() * p.recvbuf.element_size()
@@ -173,9 +180,10 @@ class HaloSchedule:
         return p
 
     def exchange(self, own_rows, local_rows, pack_fn=None):
-        """own_rows: tensor [R][n_own] of this rank's block (R = nfields*nlev rows);
-        local_rows: tensor [R][n_local], filled in place.  In range mode `own_rows` may be a view of
-        `local_rows` (own data already in place).  pack_fn(own_rows, ids, out) gathers columns into `out` [R][len(ids)]
+        """own_rows: tensor [R][n_own] of this rank's block (R = nfields*nlev rows) for sources held cell-fast, or
+        [F][n_own][L] for sources in MPAS file order (any element type either way);
+        local_rows: tensor [R][n_local] / [F][n_local][L], filled in place.  In range mode `own_rows` may be a view of
+        `local_rows` (own data already in place).  pack_fn(own_rows, ids, out) gathers columns into `out` [R][len(ids)]([L])
         (HIP pack kernel on the GPU; index_select in the CPU tests when pack_fn is None)."""
         import torch
         import torch.distributed as dist
@@ -239,26 +247,28 @@ class ShardedRegrid:
             self.rh.localize()
 
     def _pack(self, own_rows, ids, out=None):
-        """HIP gather of owned columns (mpg_pack_dev) into `out` [R][len(ids)] (contiguous)."""
-        import ctypes as C
-
+        """HIP gather of owned columns (mpg_pack_rows_dev) into `out` [R][len(ids)] / [F][len(ids)][L] (contiguous)."""
         import torch
 
-        from . import _lib as L
+        from . import comm as MC
         key = ids.ctypes.data
         if key not in self._ids_dev:
             self._ids_dev[key] = torch.as_tensor(ids, device=own_rows.device)
         ids_d = self._ids_dev[key]
         if out is None:
-            out = torch.empty((own_rows.shape[0], ids.size), dtype=own_rows.dtype, device=own_rows.device)
-        L.check(L.load().mpg_pack_dev(C.c_void_p(own_rows.data_ptr()), C.c_int64(own_rows.shape[1]), C.c_int(own_rows.shape[0]),
-                                      C.c_void_p(ids_d.data_ptr()), C.c_int64(ids.size), C.c_void_p(out.data_ptr()),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        return out
+            out = torch.empty((own_rows.shape[0], ids.size) + tuple(own_rows.shape[2:]), dtype=own_rows.dtype, device=own_rows.device)
+        return MC.pack_rows(own_rows, ids_d, out)
 
-    def local_buffer(self, nfields, nlev, device):
+    def local_buffer(self, nfields, nlev, device, dtype=None, layout=None):
+        """The rank's local source slab: [nfields * nlev][n_local] (cell-fast, input_data.F90:653-655) or [nfields][n_local][nlev]
+        (MPAS file order, :630,645), float64 or float32."""
         import torch
-        return torch.empty((nfields * nlev, self.sched.n_local), dtype=torch.float64, device=device)
+
+        from . import regrid as R
+        dtype = dtype or torch.float64
+        if layout == R.LAYOUT_LEV_FAST:
+            return torch.empty((nfields, self.sched.n_local, nlev), dtype=dtype, device=device)
+        return torch.empty((nfields * nlev, self.sched.n_local), dtype=dtype, device=device)
 
     def own_view(self, local_rows):
         """Range mode: the slice of the local buffer that holds this rank's own cells (fill it in place)."""
@@ -266,9 +276,16 @@ class ShardedRegrid:
         return local_rows[:, a:b]
 
     def step(self, own_rows, local_rows, nlev, nfields, out=None):
-        """Halo exchange + Regrid of one field batch.  Returns dst [nfields][nlev][rows][nx]."""
+        """Halo exchange + Regrid of one field batch.  Returns dst [nfields][nlev][rows][nx] (float64 from float64 sources, the
+        sources' own type from float32 ones, as the Fortran driver's Regrid)."""
+        import torch
+
+        from . import regrid as R
         self.sched.exchange(own_rows, local_rows, pack_fn=self._pack if own_rows.is_cuda else None)
-        return self.rh.regrid(local_rows.view(-1), nlev=nlev, nfields=nfields, out=out)
+        layout = R.LAYOUT_LEV_FAST if local_rows.dim() == 3 else R.LAYOUT_CELL_FAST
+        if local_rows.dtype == torch.float64:
+            return self.rh.regrid(local_rows.view(-1), nlev=nlev, nfields=nfields, layout=layout, out=out)
+        return self.rh.regrid_typed(local_rows.view(-1), nlev=nlev, nfields=nfields, layout=layout, out=out)
 
     def destroy(self):
         if isinstance(self.sched, CabiSchedule):
@@ -297,8 +314,9 @@ class CabiSchedule:
 
     def plan(self, R, like):
         b = CabiSchedule._Bytes()
-        b.bytes_sent = R * self.halo.sent_per_row * like.element_size()
-        b.bytes_received = R * self.halo.received_per_row * like.element_size()
+        es = like.element_size() * (like.shape[2] if like.dim() == 3 else 1)     # file order: one whole row is the element
+        b.bytes_sent = R * self.halo.sent_per_row * es
+        b.bytes_received = R * self.halo.received_per_row * es
         return b
 
     def destroy(self):

@@ -95,6 +95,72 @@ def test_row_sharded_halo_exchange(world, shuffle, ownership):
         assert sum(r[2] for r in res) < 0.25 * 4000
 
 
+def _worker_file_order(rank, world, port, shuffle, q):
+    """float32 sources in MPAS file order [field][cell][level] (input_data.F90:630,645): the exchanged element is one whole row."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=90))
+    try:
+        from mpassit_amd import dist as mdist, synth, target_grid as tg
+        from oracle import oracle as o
+        g = tg.define_target_grid_params("lambert", 61, 41, dx=60000.0, dy=60000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
+                                         truelat2=38.5, stand_lon=-97.5)
+        m = synth.regional_mesh_for_lambert(g.proj, 61, 41, 4000)
+        perm = np.random.default_rng(7).permutation(m.nCells) if shuffle else np.arange(m.nCells)
+        cxyz, _ = mesh_xyz(o, m)
+        tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(m.nCells)
+        j0, j1 = mdist.row_block(g.ny, world, rank)
+        idx, w = o.bilinear_weights(cxyz, tri, o.lonlat_deg_to_xyz(g.lon[j0:j1], g.lat[j0:j1]))
+        idx = np.where(idx >= 0, inv[np.maximum(idx, 0)], -1).astype(np.int32)
+        needed = np.unique(idx[idx >= 0])
+
+        def ago(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        sched = mdist.HaloSchedule.build(needed, m.nCells, rank, world, ago)
+        assert sched.mode == ("compact" if shuffle else "range")
+        nlev, nf = 5, 2
+        full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=3 + f)[:, perm] for f in range(nf)])     # [F][L][n]
+        full32 = np.ascontiguousarray(full.transpose(0, 2, 1)).astype(np.float32)                                        # [F][n][L]
+        c0, c1 = sched.own
+        local = torch.full((nf, sched.n_local, nlev), float("nan"), dtype=torch.float32)
+        if sched.mode == "range":
+            a, b = sched.own_pos
+            own = local[:, a:b]
+            own.copy_(torch.from_numpy(full32[:, c0:c1]))
+            ids_local = np.arange(sched.base, sched.base + sched.n_local)
+        else:
+            own = torch.from_numpy(np.ascontiguousarray(full32[:, c0:c1]))
+            ids_local = needed
+        sched.exchange(own, local)
+        got = local.numpy()
+        # every cell this rank's rows reference holds exactly the bytes of the whole field; what nobody needs may stay NaN
+        pos = np.searchsorted(ids_local, needed)
+        assert np.array_equal(got[:, pos], full32[:, needed])
+        plan = sched.plan(nf, local)
+        q.put((rank, sched.mode, plan.bytes_sent, plan.bytes_received))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shuffle", [(2, False), (3, False), (2, True)])
+def test_file_order_float32_halo(world, shuffle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_file_order, args=(r, world, port, shuffle, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert sum(r[2] for r in res) == sum(r[3] for r in res) > 0
+    assert all(r[2] % (5 * 4) == 0 for r in res)        # whole rows of 5 float32 levels travel
+
+
 def test_row_and_cell_blocks():
     from mpassit_amd import dist as mdist
     assert [mdist.row_block(1060, 8, r) for r in range(8)][:2] == [(0, 133), (133, 266)]

@@ -83,3 +83,74 @@ def test_rank_without_sources(gpu_lib):
     assert all(r[4] == "range" for r in res)
     got = np.concatenate([r[3] for r in res], axis=2)
     assert np.array_equal(got, want)
+
+
+def _rank_file_order(rank, world, port, shuffle, q):
+    """float32 sources in MPAS file order on every rank's GPU (what the shipped driver holds, input_data.F90:630-655)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=90))
+    try:
+        from mpassit_amd import _lib, dist as mdist, regrid as R, synth
+        _lib.init(0)
+        m, g = _case()
+        if shuffle:
+            m = synth.shuffle_cells(m, seed=3)
+
+        def ago(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, ago)
+        nlev, nf = 5, 2
+        full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5 + f) for f in range(nf)]).transpose(0, 2, 1).astype(np.float32)
+        c0, c1 = sr.sched.own
+        local = sr.local_buffer(nf, nlev, "cuda", dtype=torch.float32, layout=R.LAYOUT_LEV_FAST)
+        local.fill_(float("nan"))
+        mine = torch.as_tensor(np.ascontiguousarray(full[:, c0:c1]), device="cuda")
+        if sr.sched.mode == "range":
+            own = sr.own_view(local)
+            own.copy_(mine)
+        else:
+            own = mine
+        out = sr.step(own, local, nlev, nf)
+        torch.cuda.synchronize()
+        q.put((rank, sr.j0, sr.j1, out.cpu().numpy(), sr.sched.mode))
+        sr.destroy()
+        _lib.finalize()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shuffle", [(2, False), (3, False), (3, True)])
+def test_file_order_float32_sources_sharded(gpu_lib, world, shuffle):
+    """The halo exchange on [field][cell][level] float32 slabs (range form: one byte range per neighbour and field; compact form:
+    mpg_pack_rows_dev on whole rows): the row blocks of 2 / 3 ranks equal the single-GPU float32 file-order Regrid bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    from mpassit_amd import regrid as R, synth
+    m, g = _case()
+    if shuffle:
+        m = synth.shuffle_cells(m, seed=3)
+    nlev, nf = 5, 2
+    full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5 + f) for f in range(nf)]).transpose(0, 2, 1).astype(np.float32)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    want = rh.regrid_typed(torch.as_tensor(np.ascontiguousarray(full), device="cuda").view(-1), nlev=nlev, nfields=nf, layout=R.LAYOUT_LEV_FAST).cpu().numpy()
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_file_order, args=(r, world, port, shuffle, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[4] == ("compact" if shuffle else "range") for r in res)
+    got = np.concatenate([r[3] for r in res], axis=2)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
