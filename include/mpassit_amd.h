@@ -377,8 +377,8 @@ int mpg_pack_rows_dev(const void *src_dev, int64_t ld, int nrows, int elem_bytes
  * `real`, the ONE-rank communicator of the process; every virtual rank is driven by its own host thread and makes the calls a
  * real rank makes (mpg_comm_allgather, mpg_halo_build, mpg_halo_exchange_dev, mpg_gather_rows).  Each collective step is a
  * rendezvous of those threads; the last to arrive issues, for all of them, the very RCCL calls the real ranks would issue --
- * same entry points, same device pointers and byte counts from each rank's own schedule, each transfer on its rank's stream --
- * with every peer mapped to rank 0 of the real communicator.  Two ranks whose schedules disagree (a send that meets a receive
+ * same entry points, same device pointers and byte counts from each rank's own schedule, ordered against each rank's stream
+ * by events -- with every peer mapped to rank 0 of the real communicator.  Two ranks whose schedules disagree (a send that meets a receive
  * of another size) fail the step.  What it cannot show is bytes crossing xGMI.  A thread that never arrives ends the others'
  * wait with MPG_ERR_TIMEOUT after MPG_COMM_TIMEOUT_S.  mpg_comm_virtual_stats: groups, sends, receives and all-gathers the
  * group has really put through RCCL (any pointer may be NULL).  Destroy the virtual ranks before `real`. */
@@ -421,6 +421,18 @@ int mpg_handle_store_ms(mpg_handle rh, float *ms_total);
  * enough for the claim to hold -- DESIGN.md s4.2); 2 = nearest only: index space for the points it can vouch for, the BVH for
  * the others.  The weights are the same bits either way; diagnostics only. */
 int mpg_handle_store_path(mpg_handle rh, int *candidates);
+/* Which data-dependent branches the Store of a Mesh -> Grid handle took: n values (up to 8; the rest 0) into stats_host.  [0] = the
+ * store path above.  Then by method --
+ *   bilinear:     [1] triangles handed to the wave-per-triangle rasteriser (no usable index near a pole / the projection's cut, or
+ *                 more than 16 leaves of the pyramid), [2] triangles in all
+ *   nearest:      [1] bin side in grid points (2 where the mesh is as fine as the grid .. 16), [2] bins, [3] points the bins could not
+ *                 vouch for (settled by the tree), [4] cells on and around the grid the bin side was sized from
+ *   conservative: [1] (cell, destination cell) pairs clipped, [2] polygons with more candidates than their 24-entry list (spilled
+ *                 past it into their overflow slot, or counted and listed by a workgroup), [3] polygons whose index box a wavefront
+ *                 enumerated (more than 128 box cells), [4] polygons the cooperative count pass walked the pyramid for, [5] lists
+ *                 the list pass copied from the spill area instead of walking again, [6] vertex slots per polygon of the clip
+ * Diagnostics (the tests use them to assert that a case built to force a branch did take it); the weights do not depend on them. */
+int mpg_handle_store_stats(mpg_handle rh, int64_t *stats_host, int n);
 
 #ifdef __cplusplus
 }

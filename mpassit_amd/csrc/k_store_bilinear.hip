@@ -375,10 +375,13 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   }
   finalize<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(P, owner.p, trip, nT, sx, sy, sz, pts.x.p, pts.y.p, pts.z.p, h->idx.p, h->w.p);
   MPG_HIP(hipGetLastError());
-  int32_t h_ovf = 0;
-  MPG_HIP(hipMemcpyAsync(&h_ovf, ovf.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t h2[2] = {0, 0};
+  MPG_HIP(hipMemcpyAsync(h2, ovf.p, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   owner.free();
+  const int32_t h_ovf = h2[0];
+  h->store_stats[1] = std::min<int64_t>(h2[1], big_cap);   // triangles a wavefront rasterised (k_tri_raster_big)
+  h->store_stats[2] = nT;
   if (h_ovf) {
     mpg_set_error("RegridStore(bilinear): traversal stack of the triangle rasteriser overflowed (pyramid deeper than %d levels)",
                   (RASTER_STACK - 1) / 3);

@@ -66,12 +66,14 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
   // a polygon whose candidates the candidate pass itself spilled (25 .. CONS_SPILL of them, all found through its index box) has
   // its exact count already: nothing to count
   if (MODE == 5 && cnt_src[c] != CAND_CAP + 1) return;
+  if (MODE == 5 && n_ovf && threadIdx.x == 0) atomicAdd(n_ovf + 3, 1);   // (statistics: polygons the count pass walks for)
   if (spill && (int)blockIdx.x >= spill_cap && COOP) spill = nullptr;   // beyond the spill area: counted and listed by walking
   if (MODE == 6 && spill) {
     // the count pass (MODE 5) kept the first CONS_SPILL candidates of this cell: when that was all of them the list is copied,
     // not walked for again (configuration 5: the second walk of the polar polygons was a quarter of the whole Store)
     const int n = poff[c + 1] - poff[c];
     if (n <= CONS_SPILL) {
+      if (n_ovf && threadIdx.x == 0) atomicAdd(n_ovf + 4, 1);   // (statistics: lists copied from the spill area)
       for (int k = threadIdx.x; k < n; k += blockDim.x) {
         pair_c[poff[c] + k] = (int32_t)c;
         pair_p[poff[c] + k] = spill[(int64_t)blockIdx.x * CONS_SPILL + k];
@@ -134,7 +136,34 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
     }
     double qp = 2.0 * qe2 + 1e-9;
     if (ql[0] - qp > hi[0] || qh[0] + qp < lo[0] || ql[1] - qp > hi[1] || qh[1] + qp < lo[1] || ql[2] - qp > hi[2] || qh[2] + qp < lo[2]) return false;
-    return fabs(qarea[pc]) > 0.0;   // signed area of the destination quad, computed once per grid (k_cell_areas)
+    const double aq = qarea[pc];   // signed area of the destination quad, computed once per grid (k_cell_areas)
+    if (!(fabs(aq) > 0.0)) return false;
+    // A SEPARATING SIDE (round 5).  Half of the pairs the boxes let through do not overlap at all (configuration 4: 2.2 of 4.3 per
+    // destination cell), and each of them cost the clip kernel a lane that emptied its polygon at some side while its wavefront
+    // went on (VALU lane use 0.49).  The clip cuts with the planes qa x (qb - qa) of the counter-clockwise quad; a pair whose
+    // polygon has EVERY vertex outside one of them -- by 1e-12 of the normal's length, a thousand times the clip's own tolerance
+    // -- leaves the clip with nothing whatever the earlier sides did (what they produce lies on arcs between those vertices: the
+    // same side of the plane, by at least the same margin), i.e. it never was an entry of the matrix.  Such a pair is not listed.
+    // The planes are the clip's own (same expressions, same orientation rule, collapsed sides skipped), the stored matrix is
+    // unchanged bit for bit; pairs within the margin still go to the clip.
+    {
+      const dv3 c1 = aq < 0.0 ? q[3] : q[1], c3 = aq < 0.0 ? q[1] : q[3];
+      const dv3 s0 = c1 - q[0], s1 = q[2] - c1, s2 = c3 - q[2], s3 = q[0] - c3;
+      const bool u0 = !(dot3(s0, s0) < 1e-24), u1 = !(dot3(s1, s1) < 1e-24), u2 = !(dot3(s2, s2) < 1e-24), u3 = !(dot3(s3, s3) < 1e-24);
+      const dv3 n0 = cross3(q[0], s0), n1 = cross3(c1, s1), n2 = cross3(q[2], s2), n3 = cross3(c3, s3);
+      const double m0 = 1e-24 * dot3(n0, n0), m1 = 1e-24 * dot3(n1, n1), m2 = 1e-24 * dot3(n2, n2), m3 = 1e-24 * dot3(n3, n3);
+      bool o0 = u0, o1 = u1, o2 = u2, o3 = u3;   // "every vertex so far is clearly outside side e"
+      for (int v = 0; v < n; ++v) {
+        const dv3 X = poly[v];
+        const double d0 = dot3(n0, X), d1 = dot3(n1, X), d2 = dot3(n2, X), d3 = dot3(n3, X);
+        o0 = o0 && d0 < 0.0 && d0 * d0 > m0;
+        o1 = o1 && d1 < 0.0 && d1 * d1 > m1;
+        o2 = o2 && d2 < 0.0 && d2 * d2 > m2;
+        o3 = o3 && d3 < 0.0 && d3 * d3 > m3;
+      }
+      if (o0 || o1 || o2 || o3) return false;
+    }
+    return true;
   };
   // O(1) candidates on a projection-built grid (round 4; MODE 3 only): the polygon's corners in the grid's index space (vij:
   // the inverse projection of every vertex, k_target_grid.hip) bound the destination cells it can meet -- cell (i, j) covers
@@ -631,10 +660,11 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     return MPG_SUCCESS;
   }
   if ((rc = count.alloc((size_t)P + 1, s)) || (rc = h->rowptr.alloc((size_t)P + 1)) || (rc = qarea.alloc((size_t)P, s)) || (rc = qsph.alloc(4 * (size_t)P, s)) ||
-      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(3, s)) ||
+      (rc = cnt_src.alloc((size_t)nC, s)) || (rc = tmp_dst.alloc((size_t)nC * CAND_CAP, s)) || (rc = ovf.alloc((size_t)nC, s)) || (rc = n_ovf.alloc(5, s)) ||
       (rc = npair.alloc((size_t)nC + 1, s)) || (rc = poff.alloc((size_t)nC + 1, s)) || (rc = flip.alloc((size_t)nC, s)))
     return rc;
-  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, 3 * sizeof(int32_t), s));   // [0] overflowed cells, [1] the largest vertex count of a cell, [2] big-box queue
+  MPG_HIP(hipMemsetAsync(n_ovf.p, 0, 5 * sizeof(int32_t), s));   // [0] overflowed cells, [1] the largest vertex count of a cell, [2] big-box queue,
+                                                                  // [3] polygons the count pass walked for, [4] lists the list pass copied (statistics)
   MPG_HIP(hipMemsetAsync(cnt_src.p, 0, sizeof(int32_t) * (size_t)nC, s));  // degenerate cells leave early
   MPG_HIP(hipMemsetAsync(flip.p, 0, (size_t)nC, s));
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
@@ -679,7 +709,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   const unsigned coop_nt = CONS_COOP_NT;
   if (novf > 0)   // cells with more candidates than their list holds: one workgroup each counts them exactly
     k_conserve_raster<5><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
-                                                       cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, nullptr, nullptr, nullptr,
+                                                       cor.y.p, cor.z.p, qarea.p, qsph.p, cnt_src.p, nullptr, ovf.p, n_ovf.p, nullptr, nullptr,
                                                        nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, spill.p, spill_cap);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
@@ -712,7 +742,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   k_conserve_fill_pairs<<<(unsigned)((nC + 255) / 256), 256, 0, s>>>(nC, npair.p, poff.p, tmp_dst.p, pair_c.p, pair_p.p);
   if (novf > 0)
     k_conserve_raster<6><<<(unsigned)novf, coop_nt, 0, s>>>(nC, m->maxEdges, m->voc.p, vx, vy, vz, pv, nx, ny, cor.x.p,
-                                                       cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, nullptr, nullptr, poff.p,
+                                                       cor.y.p, cor.z.p, qarea.p, qsph.p, nullptr, nullptr, ovf.p, n_ovf.p, nullptr, poff.p,
                                                        pair_c.p, pair_p.p, nullptr, 0.f, 0.f, 0.f, spill.p, spill_cap);
   MPG_HIP(hipGetLastError());
   // (3) clip: one thread per pair, polygon buffers in LDS; counts the entries per destination cell
@@ -734,7 +764,8 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   MPG_HIP(hipGetLastError());
   tmp_bytes = b2;
   MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
-  int32_t nnz = 0, was_truncated = 0;
+  int32_t nnz = 0, was_truncated = 0, hs[5] = {0, 0, 0, 0, 0};
+  MPG_HIP(hipMemcpyAsync(hs, n_ovf.p, sizeof(hs), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipMemcpyAsync(&nnz, h->rowptr.p + P, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipMemcpyAsync(&was_truncated, truncated.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
@@ -747,6 +778,10 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
     return MPG_ERR_OVERFLOW;
   }
   h->nnz = nnz;
+  // mpg_handle_store_stats: [1] pairs clipped, [2] polygons that outgrew their list, [3] polygons enumerated by a wavefront,
+  // [4] polygons the cooperative count pass walked the pyramid for, [5] lists copied from the spill area, [6] polygon slots of the clip
+  h->store_stats[1] = npairs; h->store_stats[2] = novf; h->store_stats[3] = std::min(hv[2], spill_cap); h->store_stats[4] = hs[3];
+  h->store_stats[5] = hs[4]; h->store_stats[6] = cb;
   if ((rc = h->col.alloc((size_t)nnz + 1)) || (rc = h->val.alloc((size_t)nnz + 1))) return rc;
   MPG_HIP(hipMemsetAsync(count.p, 0, sizeof(int32_t) * (P + 1), s));
   if (npairs > 0)

@@ -436,7 +436,9 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
                                                   const double *__restrict__ cz, NbParams q, const int32_t *__restrict__ off,
                                                   const int32_t *__restrict__ ids, int32_t *__restrict__ out, int32_t *__restrict__ flags) {
   const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (p >= (int64_t)npx * npy) return;
+  const bool live = p < (int64_t)npx * npy;
+  bool done = false;
+  if (live) {
   const int i = (int)(p % npx), j = (int)(p / npx);
   const double X = px[p], Y = py[p], Z = pz[p];
   const int bx = q.per ? (i % q.nxp) / q.bin : (i + NB_RINGS * q.bin) / q.bin, by = (j + NB_RINGS * q.bin) / q.bin;
@@ -459,7 +461,6 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
   }
   double best = INFINITY;
   int32_t best_id = 0x7fffffff;
-  bool done = false;
   for (int r = 0; r <= NB_RINGS && !done; ++r) {
     // the bins of ring r: the square of half-width r without the square of half-width r - 1
     for (int yy = by - r; yy <= by + r; ++yy) {
@@ -488,8 +489,14 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
     const double lim = fmin(((double)(r * q.bin) - 2e-3) * h, cap);
     done = r > 0 && best <= lim * lim;
   }
-  if (!done) atomicOr(flags, 2);
   out[p] = done ? best_id : -1;
+  }
+  // points left to the tree: bit 1 of flags[0], their number in flags[1] (one atomic per workgroup)
+  const int nleft = __syncthreads_count(live && !done);
+  if (threadIdx.x == 0 && nleft) {
+    atomicOr(flags, 2);
+    atomicAdd(flags + 1, nleft);
+  }
 }
 // cells with a usable index on the grid or within `margin` index units of it
 __global__ __launch_bounds__(256) void k_nb_inside(int64_t n, const float *__restrict__ ij, float margin, float npx, float npy,
@@ -566,10 +573,10 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   const int64_t nbins_max = (int64_t)(q.per ? q.nxp / NB_BIN_MIN : (npx + 2 * NB_RINGS * NB_BIN_MIN + NB_BIN_MIN - 1) / NB_BIN_MIN) *
                             ((npy + 2 * NB_RINGS * NB_BIN_MIN + NB_BIN_MIN - 1) / NB_BIN_MIN);
   if (nbins_max + 1 >= 0x7fffffff) return MPG_SUCCESS;
-  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(1, s)) || (rc = zr.alloc(3, s)) ||
+  if ((rc = ij.alloc(2 * (size_t)n, s)) || (rc = ids.alloc((size_t)n + 1, s)) || (rc = flags.alloc(2, s)) || (rc = zr.alloc(3, s)) ||
       (rc = cnt.alloc((size_t)nbins_max + 1, s)) || (rc = off.alloc((size_t)nbins_max + 1, s)))
     return rc;
-  MPG_HIP(hipMemsetAsync(flags.p, 0, sizeof(int32_t), s));
+  MPG_HIP(hipMemsetAsync(flags.p, 0, 2 * sizeof(int32_t), s));
   MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins_max + 1), s));
   if ((rc = mpg_k_points_ij(g, n, m->cell.x.p + first, m->cell.y.p + first, m->cell.z.p + first, ij.p, s, latlon_limit, !q.per))) return rc;
   const unsigned nbc = (unsigned)((n + 255) / 256);
@@ -598,10 +605,9 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   q.nbx = q.per ? q.nxp / q.bin : (npx + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
   q.nby = (npy + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
   const int64_t nbins = (int64_t)q.nbx * q.nby;
-  if (nbins > nbins_max) {   // (a grid of a few points: larger bins bring a larger margin)
-    if ((rc = cnt.alloc((size_t)nbins + 1, s)) || (rc = off.alloc((size_t)nbins + 1, s))) return rc;
-    MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));
-  }
+  // (larger bins never need more counters than the smallest ones the buffers were sized for: the bin grid is npx / bin + 2 *
+  // NB_RINGS + 1 bins wide at most, which falls with the bin side for every npx; a guard, not a branch anybody takes)
+  if (nbins > nbins_max) return MPG_SUCCESS;
   if (!q.local) {   // Lambert: one bound for the grid, from the latitudes its points span
     double zlo, zhi;
     memcpy(&zlo, &hz[0], sizeof(double));
@@ -622,10 +628,13 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   k_nb_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, q, off.p, ids.p,
                                                         h->idx.p, flags.p);
   MPG_HIP(hipGetLastError());
-  int32_t hflags = 0;
-  MPG_HIP(hipMemcpyAsync(&hflags, flags.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  int32_t hflags[2] = {0, 0};
+  MPG_HIP(hipMemcpyAsync(hflags, flags.p, sizeof(hflags), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
-  *state = (hflags & 2) ? 2 : 1;
+  *state = (hflags[0] & 2) ? 2 : 1;
+  // mpg_handle_store_stats: [1] bin side in grid points, [2] bins, [3] points the bins could not vouch for (left to the tree),
+  // [4] cells on and around the grid the bin side was sized from
+  h->store_stats[1] = q.bin; h->store_stats[2] = nbins; h->store_stats[3] = hflags[1]; h->store_stats[4] = (int64_t)hz[2];
   return MPG_SUCCESS;
 }
 

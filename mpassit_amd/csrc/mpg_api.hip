@@ -870,6 +870,12 @@ int mpg_handle_store_path(mpg_handle h, int *candidates) {
   return MPG_SUCCESS;
 }
 
+int mpg_handle_store_stats(mpg_handle h, int64_t *stats_host, int n) {
+  MPG_ARG(h && stats_host && n >= 1, "mpg_handle_store_stats: bad argument");
+  for (int k = 0; k < n; ++k) stats_host[k] = k == 0 ? (int64_t)h->store_path : k < 8 ? h->store_stats[k] : 0;
+  return MPG_SUCCESS;
+}
+
 int mpg_handle_get_weights(mpg_handle h, int32_t *idx_host, double *w_host) {
   MPG_CHECK_INIT();
   MPG_ARG(h && idx_host, "mpg_handle_get_weights: NULL argument");

@@ -609,9 +609,8 @@ static int vg_allgather(mpg_comm_s *c, const void *send_host, int64_t nbytes, vo
 
 // One grouped exchange.  A real rank: ncclGroupStart, its sends and receives, ncclGroupEnd, on its stream.  Virtual ranks:
 // the lists of all V threads are matched (a send of rank r to rank q with the next receive rank q lists for r; equal sizes
-// required -- the two ranks' schedules must agree) and go out as ONE group of sends and receives to self, each on the
-// stream of the rank it belongs to.  MPG_VRANK_ONE_STREAM=1 puts the whole group on rank 0's stream with event edges from and
-// to the other ranks' streams instead.
+// required -- the two ranks' schedules must agree) and go out as ONE group of sends and receives to self on rank 0's stream,
+// with event edges from and to the other ranks' streams.
 static int comm_exchange(mpg_comm_s *c, const std::vector<P2P> &ops, hipStream_t s) {
   if (!c->is_virtual) {
     if (c->nranks == 1) return MPG_SUCCESS;
@@ -663,33 +662,31 @@ static int comm_exchange(mpg_comm_s *c, const std::vector<P2P> &ops, hipStream_t
               return MPG_ERR_INVALID_ARG;
             }
         if (pairs.empty()) return MPG_SUCCESS;
-        const char *e = getenv("MPG_VRANK_ONE_STREAM");
-        const bool one = e && *e && *e != '0';
+        // One communicator launches a group on ONE stream.  The group goes on rank 0's stream, with event edges from every
+        // other rank's stream (its pack is complete before its bytes are sent) and back (its unpack waits for its receives).
+        // (Measured, round 5: handing RCCL each transfer on its own rank's stream inside one group left the receiving ranks'
+        // streams unordered against the copy -- their unpack read the receive buffer before the data had landed.)
         hipStream_t lead = g->streams[0];
         hipEvent_t ev = nullptr;
-        if (one) {
-          MPG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-          for (int q = 1; q < V; ++q)
-            if (g->streams[q] != lead) {
-              MPG_HIP(hipEventRecord(ev, g->streams[q]));
-              MPG_HIP(hipStreamWaitEvent(lead, ev, 0));
-            }
-        }
+        MPG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (int q = 1; q < V; ++q)
+          if (g->streams[q] != lead) {
+            MPG_HIP(hipEventRecord(ev, g->streams[q]));
+            MPG_HIP(hipStreamWaitEvent(lead, ev, 0));
+          }
         MPG_NCCL(R.GroupStart());
         for (const Pair &p : pairs) {
-          MPG_NCCL(R.Send(p.snd->sbuf, p.snd->ns, ncclChar, 0, g->comm, one ? lead : g->streams[p.src]));
-          MPG_NCCL(R.Recv(p.rcv->rbuf, p.rcv->nr, ncclChar, 0, g->comm, one ? lead : g->streams[p.dst]));
+          MPG_NCCL(R.Send(p.snd->sbuf, p.snd->ns, ncclChar, 0, g->comm, lead));
+          MPG_NCCL(R.Recv(p.rcv->rbuf, p.rcv->nr, ncclChar, 0, g->comm, lead));
         }
         MPG_NCCL(R.GroupEnd());
         ++g->n_groups;
         g->n_send_calls += (int64_t)pairs.size();
         g->n_recv_calls += (int64_t)pairs.size();
-        if (one) {
-          MPG_HIP(hipEventRecord(ev, lead));
-          for (int q = 1; q < V; ++q)
-            if (g->streams[q] != lead) MPG_HIP(hipStreamWaitEvent(g->streams[q], ev, 0));
-          MPG_HIP(hipEventDestroy(ev));
-        }
+        MPG_HIP(hipEventRecord(ev, lead));
+        for (int q = 1; q < V; ++q)
+          if (g->streams[q] != lead) MPG_HIP(hipStreamWaitEvent(g->streams[q], ev, 0));
+        MPG_HIP(hipEventDestroy(ev));
         return MPG_SUCCESS;
       });
 }

@@ -274,6 +274,7 @@ struct mpg_handle_s {
   uint64_t parked_at = 0;   // release order of a handle waiting in the cache with refcount 0 (mpg_api.hip)
   HandleKey key;
   float store_ms = 0.f;
+  int64_t store_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // which branches the Store took (mpg_handle_store_stats; [0] is store_path)
   int store_path = 0;       // candidate search of the Store: 0 hierarchical (pyramid walk / BVH), 1 the grid's index space, 2 index space + BVH for the rest
   bool localized = false;
   // pole caps of a periodic (monopole) source grid: destination point pole_dst[q] adds pole_w[q] * mean of the

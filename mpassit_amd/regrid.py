@@ -226,6 +226,13 @@ class RouteHandle:
         check(L.load().mpg_handle_store_path(self._h, C.byref(v)))
         return v.value
 
+    @property
+    def store_stats(self):
+        """mpg_handle_store_stats: which data-dependent branches the Store took (layout by method: include/mpassit_amd.h)."""
+        v = (C.c_int64 * 8)()
+        check(L.load().mpg_handle_store_stats(self._h, v, C.c_int(8)))
+        return [int(x) for x in v]
+
     def _refresh(self):
         self.__init__(self._h)
 

@@ -2,7 +2,7 @@
 make the calls V real ranks make -- mpg_halo_build (votes and counts through ncclAllGather on the set-up stream), then
 mpg_halo_exchange_dev and mpg_gather_rows, whose transfers go out as ONE ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd
 to self with each rank's own device pointers (sendbuf + soff * nrows * es, recvbuf + roff * nrows * es, the recv_a pitches of the
-unpack), each on its rank's stream.  Checked: every rank's local slab holds the whole field's bytes at every id its rows reference,
+unpack), ordered against each rank's stream by events.  Checked: every rank's local slab holds the whole field's bytes at every id its rows reference,
 the Regrid of the slabs equals the single-GPU Regrid bit for bit, the gathered field equals it too, the schedules equal
 mpg_halo_plan_host's (itself checked against dist.HaloSchedule on the CPU, tests/test_comm_plan.py), and the group's counters say
 the sends and receives were really issued.  What this cannot show: bytes crossing xGMI (the box has one card)."""
@@ -132,10 +132,9 @@ def test_para_range_ownership(gpu_lib):
     _rehearse(m, g, 3, "range", torch.float32, lev_fast=False, own_streams=True, ownership="para_range")
 
 
-def test_one_event_ordered_stream(gpu_lib, monkeypatch):
-    """MPG_VRANK_ONE_STREAM=1: the whole group on rank 0's stream, event edges from and to the others'."""
+def test_file_order_float64_on_separate_streams(gpu_lib):
+    """Every virtual rank on a stream of its own: the group runs on rank 0's stream with event edges from and to the others'."""
     import torch
-    monkeypatch.setenv("MPG_VRANK_ONE_STREAM", "1")
     m, g = _case()
     _rehearse(m, g, 3, "range", torch.float64, lev_fast=True, own_streams=True)
 

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""ESMF pin kit, command line (mpassit_amd/esmf_pin.py holds the formats and the comparison).
+
+Three commands turn "parity unpinned at the ESMF boundary"  into a number on a site that has ESMF:
+
+  1. python tools/esmf_pin.py export c2_655k_global --out pin_c2          # here or anywhere: no GPU, no ESMF
+        (or: export --mpas-grid x1.655362.grid.nc --target-grid-type lambert --nx 1801 --ny 1061 --dx 3000 --dy 3000 --ref-lat 38.5
+         --ref-lon -97.5 --truelat1 38.5 --truelat2 38.5 --stand-lon -97.5 --out pin_c2      # the site's own mesh + namelist values)
+     writes the mesh as an ESMF unstructured-mesh file, the target grid's staggers as SCRIP files and run_esmf_regridweightgen.sh
+  2. (cd pin_c2 && sh run_esmf_regridweightgen.sh)                          # where ESMF lives: six ESMF_RegridWeightGen runs
+  3. python tools/esmf_pin.py compare pin_c2                                # on the GPU box: builds the same six handles with this
+        library, compares every weights_*.nc entry by entry ((row, col) sets, max |dS|, mapped masks, which bilinear line type
+        matches), applies ESMF's weights with the library's Regrid kernels next to its own, exits non-zero beyond the north-star
+        tolerances (nearest: identical; bilinear / conservative: 1e-6)
+
+`selftest DIR` (GPU) writes the library's OWN weights in ESMF's weight-file layout and runs `compare` on them: the round trip
+through the file format must report zero difference (tests/test_esmf_pin_gpu.py).
+References: interp.F90:123-136 (unmappedaction = IGNORE, srcTermProcessing = 1), model_grid.F90:446-497 (mesh), :784-794 (corners)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cmd_export(args):
+    from mpassit_amd import esmf_pin as E, target_grid as tg
+    if args.workload:
+        from mpassit_amd import workloads
+        m, g, _, desc = workloads.workload(args.workload)
+        name = "%s: %s" % (args.workload, desc)
+    else:
+        if not args.mpas_grid:
+            raise SystemExit("export needs a workload name or --mpas-grid FILE with the target grid's namelist values")
+        from mpassit_amd import ncio
+        from types import SimpleNamespace
+        with ncio.Reader(args.mpas_grid) as r:      # model_grid.F90:341-349; NetCDF-4 files: nccopy -k cdf5 first
+            m = SimpleNamespace(**{k: r.get(k) for k in ("latCell", "lonCell", "latVertex", "lonVertex", "verticesOnCell")})
+        kw = dict(dx=args.dx, dy=args.dy, ref_lat=args.ref_lat, ref_lon=args.ref_lon, ref_x=args.ref_x, ref_y=args.ref_y, truelat1=args.truelat1,
+                  truelat2=args.truelat2, stand_lon=args.stand_lon)
+        kw = {k: v for k, v in kw.items() if v is not None}
+        g = tg.define_target_grid_params(args.target_grid_type, args.nx, args.ny, is_regional=not args.is_global, **kw)
+        name = "%s -> %s %dx%d" % (os.path.basename(args.mpas_grid), args.target_grid_type, args.nx, args.ny)
+    info = E.export_case(args.out, m, g, name=name)
+    print("wrote %s: %d elements, %d nodes -> %d x %d mass points; next: (cd %s && sh run_esmf_regridweightgen.sh), then "
+          "python tools/esmf_pin.py compare %s" % (args.out, info["mesh"]["elementCount"], info["mesh"]["nodeCount"], info["nx"], info["ny"], args.out, args.out))
+
+
+class _Case:
+    """The library's objects of one exported directory (GPU)."""
+
+    def __init__(self, d):
+        from mpassit_amd import _lib, esmf_pin as E, regrid as R
+        _lib.init(0)
+        self.R, self.E, self.dir = R, E, d
+        self.info = json.load(open(os.path.join(d, "manifest.json")))
+        f = self.info["files"]
+        self.m = E.read_mpas_arrays(os.path.join(d, f["mpas"]))
+        c = E.read_scrip_grid(os.path.join(d, f["grid_center"]))
+        lon_c, lat_c = E.corners_from_scrip(c)
+        u, v = E.read_scrip_grid(os.path.join(d, f["grid_edge1"])), E.read_scrip_grid(os.path.join(d, f["grid_edge2"]))
+        self.nx, self.ny, self.regional = c["ni"], c["nj"], self.info["regional"]
+        lon_u, lat_u = u["lon"], u["lat"]
+        if not self.regional:      # our periodic EDGE1 stagger carries the duplicate column one period later
+            lon_u, lat_u = np.concatenate([lon_u, lon_u[:, :1] + 360.0], axis=1), np.concatenate([lat_u, lat_u[:, :1]], axis=1)
+        self.center = c
+        self.mesh = R.Mesh.from_mpas(self.m)
+        self.grid = R.Grid(c["lon"], c["lat"], lon_c, lat_c, lon_u, lat_u, v["lon"], v["lat"], periodic=0 if self.regional else 1)
+
+    def close(self):
+        self.mesh.destroy()
+        self.grid.destroy()
+
+    def handle(self, case, linetype=0):
+        R = self.R
+        from mpassit_amd import _lib
+        c = self.info["cases"][case]
+        method = {"bilinear": R.REGRIDMETHOD_BILINEAR, "conserve": R.REGRIDMETHOD_CONSERVE, "neareststod": R.REGRIDMETHOD_NEAREST_STOD}[c["method"]]
+        if c["src"] == "mesh":
+            _lib.tune("bilinear_linetype", linetype)
+            try:
+                rh = R.regrid_store(self.mesh, self.grid, method, meshloc=R.MESHLOC_NODE if c["src_loc"] == "corner" else R.MESHLOC_ELEMENT)
+            finally:
+                _lib.tune("bilinear_linetype", 0)
+            n_a = self.m.nVertices if c["src_loc"] == "corner" else self.m.nCells
+        else:
+            rh = R.regrid_store_grid(self.grid, R.STAGGERLOC_EDGE1 if c["dst"] == "grid_edge1" else R.STAGGERLOC_EDGE2)
+            n_a = self.nx * self.ny
+        return rh, n_a
+
+    def ours(self, case, linetype=0):
+        """(row, col, S) of the library in ESMF's numbering of the exported files, n_a, n_b, the handle."""
+        rh, n_a = self.handle(case, linetype)
+        row, col, S = rh.to_esmf_weights()
+        n_b = rh.n_dst
+        if not self.regional and self.info["cases"][case]["dst"] == "grid_edge1":
+            # ESMF's periodic EDGE1 stagger holds nx columns; ours nx + 1 (the last duplicates the first one period later)
+            j, i = np.divmod(row.astype(np.int64) - 1, self.nx + 1)
+            keep = i < self.nx
+            row, col, S = (j[keep] * self.nx + i[keep] + 1).astype(np.int32), col[keep], S[keep]
+            n_b = self.nx * self.ny
+        return (row, col, S), n_a, n_b, rh
+
+    def source_field(self, case, nlev=3):
+        from mpassit_amd import synth
+        c = self.info["cases"][case]
+        if c["src"] != "mesh":
+            return synth.analytic_field(np.deg2rad(self.center["lat"].reshape(-1)), np.deg2rad(self.center["lon"].reshape(-1)), nlev)
+        if c["src_loc"] == "corner":
+            return synth.analytic_field(self.m.latVertex, self.m.lonVertex, nlev)
+        return synth.analytic_field(self.m.latCell, self.m.lonCell, nlev)
+
+
+def _compare_case(cs, case, wpath, verbose=True):
+    E, R = cs.E, cs.R
+    theirs = E.read_weight_file(wpath)
+    c = cs.info["cases"][case]
+    ours, n_a, n_b, rh = cs.ours(case)
+    if theirs["n_a"] not in (None, n_a) or theirs["n_b"] not in (None, n_b):
+        raise SystemExit("%s: the weight file is for %s sources x %s destinations, the exported case has %d x %d" % (wpath, theirs["n_a"], theirs["n_b"], n_a, n_b))
+    rep = E.compare_weights(ours, (theirs["row"], theirs["col"], theirs["S"]), n_a, n_b, c["method"])
+    reps = {"linetype 0 (ray from the sphere's centre)": rep}
+    if c["method"] == "bilinear" and c["src"] == "mesh":
+        # the one undocumented choice of the bilinear Store -- which reading does this ESMF follow?
+        ours1, _, _, rh1 = cs.ours(case, linetype=1)
+        rep1 = E.compare_weights(ours1, (theirs["row"], theirs["col"], theirs["S"]), n_a, n_b, c["method"])
+        rh1.release()
+        reps["linetype 1 (along the triangle's normal)"] = rep1
+        if rep1["max_abs_diff_any"] < rep["max_abs_diff_any"]:
+            rep = rep1
+    # (a) of INTEGRATION.md s5: ESMF's weights applied by this library's Regrid kernels, beside its own weights
+    src = cs.source_field(case)
+    nlev = src.shape[0]
+    if n_b == rh.n_dst and theirs["S"].size:
+        rhe = R.RouteHandle.from_weights(n_a, rh.nx_dst, rh.ny_dst, theirs["row"].astype(np.int32), theirs["col"].astype(np.int32), theirs["S"])
+        a, b = rh.regrid(src, nlev=nlev), rhe.regrid(src, nlev=nlev)
+        rep["field_rel_diff"] = float(np.abs(a - b).max() / max(np.abs(a).max(), 1e-300))
+        rhe.release()
+    rh.release()
+    if verbose:
+        print("== %s  (%s)\n   %s" % (case, c["reference"], wpath))
+        for label, r in reps.items():
+            if len(reps) > 1:
+                print(" -- " + label)
+            print(E.report_text(r))
+        if len(reps) > 1:
+            print("  -> closer to: %s" % min(reps, key=lambda k: reps[k]["max_abs_diff_any"]))
+        if "field_rel_diff" in rep:
+            print("  smooth field regridded with either weight set: max difference %.3e of its maximum" % rep["field_rel_diff"])
+    return rep
+
+
+def cmd_compare(args):
+    cs = _Case(args.dir)
+    cases = list(cs.info["cases"]) if args.case in (None, "all") else [args.case]
+    bad = done = 0
+    for case in cases:
+        wpath = args.weights if (args.weights and len(cases) == 1) else os.path.join(args.dir, cs.info["cases"][case]["weights"])
+        if not os.path.exists(wpath):
+            print("== %s: %s not found (run run_esmf_regridweightgen.sh first) -- skipped" % (case, wpath))
+            continue
+        rep = _compare_case(cs, case, wpath)
+        done += 1
+        bad += 0 if rep["ok"] else 1
+    print("%d case(s) compared, %d out of tolerance" % (done, bad))
+    cs.close()
+    if done == 0:
+        raise SystemExit(2)
+    raise SystemExit(1 if bad else 0)
+
+
+def cmd_selftest(args):
+    """The library's own weights -> ESMF's weight-file layout -> compare: zero difference expected in every case."""
+    cs = _Case(args.dir)
+    worst = 0.0
+    for case, c in cs.info["cases"].items():
+        ours, n_a, n_b, rh = cs.ours(case)
+        rh.release()
+        wpath = os.path.join(args.dir, "selftest_" + c["weights"])
+        cs.E.write_weight_file(wpath, *ours, n_a=n_a, n_b=n_b, method=c["method"], title="mpassit_amd's own weights (selftest)")
+        rep = _compare_case(cs, case, wpath, verbose=args.verbose)
+        if not (rep["only_ours"] == rep["only_theirs"] == 0 and rep["max_abs_diff_any"] == 0.0):
+            raise SystemExit("selftest: case %s does not survive the round trip through the weight file: %r" % (case, rep))
+        worst = max(worst, rep.get("field_rel_diff", 0.0))
+        print("selftest %-26s %9d entries: identical after the round trip" % (case, rep["nnz_ours"]))
+    cs.close()
+    print("selftest ok (largest field difference between the handle and its re-imported weights: %.2e)" % worst)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    e = sub.add_parser("export")
+    e.add_argument("workload", nargs="?")
+    e.add_argument("--out", required=True)
+    e.add_argument("--mpas-grid")
+    e.add_argument("--target-grid-type", default="lambert")
+    for k in ("nx", "ny"):
+        e.add_argument("--" + k, type=int)
+    for k in ("dx", "dy", "ref-lat", "ref-lon", "ref-x", "ref-y", "truelat1", "truelat2", "stand-lon"):
+        e.add_argument("--" + k, type=float)
+    e.add_argument("--global", dest="is_global", action="store_true", help="is_regional = .false.")
+    e.set_defaults(fn=cmd_export)
+    c = sub.add_parser("compare")
+    c.add_argument("dir")
+    c.add_argument("--case", default="all")
+    c.add_argument("--weights", help="weight file of the single --case (default: <dir>/weights_<case>.nc)")
+    c.set_defaults(fn=cmd_compare)
+    s = sub.add_parser("selftest")
+    s.add_argument("dir")
+    s.add_argument("--verbose", action="store_true")
+    s.set_defaults(fn=cmd_selftest)
+    args = ap.parse_args()
+    args.fn(args)
+
+
+if __name__ == "__main__":
+    main()
