@@ -357,7 +357,7 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
   TmpBuf<float> sij;
   const float *sijp = nullptr;
   float di = 0.f, dj = 0.f;
-  if (mpg_grid_has_inverse(g) && mpg_store_boxes() && nT > 0) {
+  if (mpg_grid_has_inverse(g, stagger) && mpg_store_boxes() && nT > 0) {
     const int64_t s0 = meshloc == MPG_MESHLOC_NODE ? m->vw0 : m->cw0, sn = meshloc == MPG_MESHLOC_NODE ? m->vwn : m->cwn;
     if ((rc = sij.alloc(2 * (size_t)sn, s))) return rc;
     if ((rc = mpg_k_points_ij(g, sn, sx + s0, sy + s0, sz + s0, sij.p, s))) return rc;

@@ -674,7 +674,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   // three cells around it) give every polygon its candidate cells in O(1); "store_boxes" 0 keeps the pyramid walk (A/B)
   TmpBuf<float> vij;
   const float *vijp = nullptr;
-  if (mpg_grid_has_inverse(g) && mpg_store_boxes() && m->vwn > 0) {
+  if (mpg_grid_has_inverse(g, MPG_STAGGERLOC_CORNER) && mpg_store_boxes() && m->vwn > 0) {
     if ((rc = vij.alloc(2 * (size_t)m->vwn, s))) return rc;
     if ((rc = mpg_k_points_ij(g, m->vwn, m->vert.x.p, m->vert.y.p, m->vert.z.p, vij.p, s))) return rc;
     vijp = vij.p - 2 * m->vw0;   // indexed with global vertex ids, like vx / vy / vz

@@ -398,8 +398,8 @@ struct NbParams {
   int local;           // lat-lon: the bound is taken per point, h = 0.8 * min(dlat, dlon * cos(|lat| + what the rings span))
   double dlat, dlon;   // radians per index unit (lat-lon)
   int zone;            // 0 none; 1 lat-lon: no usable index beyond +-zlim degrees; 2 Lambert: beyond hemi * lat >= 89 or <= -60, and
-  double zlim, hemi;   //   the index jumps across the cut meridian stdlon + 180
-  double stdlon;
+  double zlim, hemi;   //   the index jumps across the cut meridian stdlon + 180; 3 polar stereographic: beyond hemi * lat <= -60 only;
+  double stdlon;       //   4 Mercator: beyond +-zlim degrees and across the cut opposite the grid's middle column (stdlon = its longitude)
 };
 __device__ __forceinline__ bool nb_bin_of(const NbParams &q, float ci, float cj, int *bx, int *by) {
   float u = ci + q.di, v = cj + q.dj + (float)(NB_RINGS * q.bin);
@@ -446,10 +446,13 @@ __global__ __launch_bounds__(256) void k_nb_query(int npx, int npy, const double
   // cells WITHOUT a usable index are not binned: nothing as far as they can be is final.  They sit beyond zlim degrees (lat-lon)
   // resp. within a degree of the Lambert pole or more than 60 degrees into the other hemisphere.
   double cap = q.cap;
-  if (q.zone == 1) cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * fmax(q.zlim / r2d - alat, 0.0)));
-  if (q.zone == 2) {
+  if (q.zone == 1 || q.zone == 4) cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * fmax(q.zlim / r2d - alat, 0.0)));
+  if (q.zone == 2 || q.zone == 3) {
     const double hl = q.hemi * asin(fmin(fmax(Z, -1.0), 1.0)) * r2d;   // degrees towards the projection's pole
-    cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * fmax(fmin(89.0 - hl, hl + 60.0), 0.0) / r2d));
+    // (polar stereographic, zone 3: its own pole is a regular point of the map; only the far limit counts)
+    cap = fmin(cap, 0.9 * 2.0 * sin(0.5 * fmax(q.zone == 2 ? fmin(89.0 - hl, hl + 60.0) : hl + 60.0, 0.0) / r2d));
+  }
+  if (q.zone == 2 || q.zone == 4) {
     // ... and a cell across the projection's cut (the meridian opposite the standard longitude) sits far away in index space
     // however near it is on the sphere: nothing as far as the cut is final
     double dl = atan2(Y, X) * r2d - q.stdlon;
@@ -542,7 +545,7 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   *state = 0;
   int rc;
   const int64_t P = (int64_t)npx * npy, n = m->cwn, first = m->cw0;
-  if (!mpg_grid_has_inverse(g) || !mpg_store_boxes() || n == 0 || stagger == MPG_STAGGERLOC_CORNER) return MPG_SUCCESS;
+  if (!mpg_grid_has_inverse(g, stagger) || !mpg_store_boxes() || n == 0 || stagger == MPG_STAGGERLOC_CORNER) return MPG_SUCCESS;
   const ProjDev &pr = g->proj;
   NbParams q;
   memset(&q, 0, sizeof(q));
@@ -561,6 +564,13 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
     q.dlon = fabs(pr.loninc) * 3.141592653589793 / 180.0;
     q.zone = 1;
     q.zlim = latlon_limit;
+  } else if (pr.code == MPG_PROJ_PS) {
+    q.zone = 3;
+    q.hemi = pr.hemi;
+  } else if (pr.code == MPG_PROJ_MERC) {
+    q.zone = 4;
+    q.zlim = 85.0;
+    q.stdlon = pr.lon1 + (1.0 + 0.5 * (double)g->nx - pr.knowni) * pr.dlon * (180.0 / 3.141592653589793);   // the grid's middle column
   } else {
     q.zone = 2;
     q.hemi = pr.hemi;
@@ -602,6 +612,7 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
   // a regional lat-lon grid: cell indices are unwrapped around its middle column, which is only unambiguous while the grid
   // and its margin stay well short of the full circle
   if (pr.code == MPG_PROJ_LATLON && !q.per && (double)(npx + 2 * NB_RINGS * q.bin) * fabs(pr.loninc) > 300.0) return MPG_SUCCESS;
+  if (pr.code == MPG_PROJ_MERC && (double)(npx + 2 * NB_RINGS * q.bin) * pr.dlon * (180.0 / 3.141592653589793) > 330.0) return MPG_SUCCESS;   // (the same on a Mercator map)
   q.nbx = q.per ? q.nxp / q.bin : (npx + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
   q.nby = (npy + 2 * NB_RINGS * q.bin + q.bin - 1) / q.bin;
   const int64_t nbins = (int64_t)q.nbx * q.nby;

@@ -111,8 +111,8 @@ __host__ __device__ __forceinline__ double map_factor(const ProjDev &p, double l
 }
 
 // ---- the inverse: where on the grid does a point of the sphere fall?  (round 4) --------------------------------------------
-// latlon_to_ij for the two projections the BASELINE configurations use (llij_lc, module_map_utils.F90:1236-1290; llij_latlon,
-// :1365-1392), in the 0-based CENTER index space (projection coordinate - 1).  The Stores use it to find the handful of target
+// latlon_to_ij for the four projections program_setup.F90:166-191 accepts (llij_lc, module_map_utils.F90:1236-1290; llij_latlon,
+// :1365-1392; since round 5 llij_ps :718-760 and llij_merc :1320-1341), in the 0-based CENTER index space (projection coordinate - 1).  The Stores use it to find the handful of target
 // points around a source triangle / polygon directly instead of descending ten levels of the box pyramid; it only has to be
 // good to a fraction of a grid length (the callers pad their boxes and test every candidate point exactly as before).
 // Not usable -> NaN: within 1 degree of the Lambert pole or beyond 60 degrees into the other hemisphere; poleward of
@@ -150,6 +150,31 @@ __global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, double l
         if (i >= p.nxmax + 0.5) i -= span;
       }
     }
+  } else if (p.code == MPG_PROJ_PS) {
+    // llij_ps (module_map_utils.F90:718-760).  The projection's own pole is a regular point of this map (no exclusion there, no
+    // cut: the plane is continuous around it); what is singular is the OTHER pole -- beyond 60 degrees into the other hemisphere the
+    // map factor passes 7 and nothing is handed out
+    if (p.hemi * lat > -60.0) {
+      const double reflon = p.stdlon + 90.0;
+      const double scale_top = 1.0 + p.hemi * sin(p.truelat1 * TG_RAD_PER_DEG);
+      const double ala = lat * TG_RAD_PER_DEG;
+      const double rm = p.rebydx * cos(ala) * scale_top / (1.0 + p.hemi * sin(ala));
+      const double alo = (lon - reflon) * TG_RAD_PER_DEG;
+      i = p.polei + rm * cos(alo);
+      j = p.polej + p.hemi * rm * sin(alo);
+    }
+  } else if (p.code == MPG_PROJ_MERC) {
+    // llij_merc (module_map_utils.F90:1320-1341), with the longitude difference taken on the branch nearest to the grid's own
+    // middle column instead of nearest to the known point (i_center: always given for this projection): the map's cut then sits
+    // opposite the grid, wherever its known point is.  Both poles are singular: nothing beyond 85 degrees.
+    if (fabs(lat) < 85.0) {
+      double dl = lon - p.lon1;
+      i = p.knowni + dl / (p.dlon * TG_DEG_PER_RAD);
+      const double period = 360.0 / (p.dlon * TG_DEG_PER_RAD);
+      const double ic = i_center == i_center ? i_center : p.knowni;
+      i -= nearbyint((i - ic) / period) * period;
+      j = p.knownj + log(tan(0.5 * ((lat + 90.0) * TG_RAD_PER_DEG))) / p.dlon - p.rsw;
+    }
   }
   ij[2 * q] = (float)(i - 1.0);
   ij[2 * q + 1] = (float)(j - 1.0 - (double)row0);
@@ -159,10 +184,12 @@ __global__ __launch_bounds__(256) void k_points_ij(ProjDev p, int row0, double l
 // destination cell's own great-circle edges must stay inside its index band (the edge between two lat-lon corners 90 degrees
 // of longitude apart rises by several degrees in between).  Grids coarser than 2 degrees / 200 km per cell, or whose cells'
 // edges bulge by more than 0.05 index units at the latitude the boxes are used to, keep the pyramid search: it makes no such assumption.
-bool mpg_grid_has_inverse(const mpg_grid_s *g) {
-  if (!g->has_inverse) return false;
+bool mpg_grid_has_inverse(const mpg_grid_s *g, int stagger) {
+  if (!g->has_inverse || stagger < 0 || stagger > 3 || !g->inverse_ok[stagger]) return false;
   const ProjDev &p = g->proj;
-  if (p.code == MPG_PROJ_LC) return TG_EARTH_RADIUS_M / p.rebydx <= 200e3;
+  if (p.code == MPG_PROJ_LC || p.code == MPG_PROJ_PS) return TG_EARTH_RADIUS_M / p.rebydx <= 200e3;
+  if (p.code == MPG_PROJ_MERC)   // ... and a grid well short of the full circle (its cut sits opposite its middle column), true latitude <= 60
+    return TG_EARTH_RADIUS_M / p.rebydx <= 200e3 && fabs(p.truelat1) <= 60.0 && (double)g->nx * p.dlon * TG_DEG_PER_RAD <= 300.0;
   if (p.code == MPG_PROJ_LATLON) {
     const double dlon = fabs(p.loninc), dlat = fabs(p.latinc);
     if (dlon > 2.0 || dlat > 2.0) return false;
@@ -179,20 +206,24 @@ bool mpg_grid_has_inverse(const mpg_grid_s *g) {
 // unwrap_i: lat-lon indices are taken on the branch nearest to the grid's middle column instead of the reference's wrap rule
 int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit,
                     bool unwrap_i) {
-  const double i_center = unwrap_i ? 1.0 + 0.5 * (double)g->nx : (double)NAN;
+  const double i_center = (unwrap_i || g->proj.code == MPG_PROJ_MERC) ? 1.0 + 0.5 * (double)g->nx : (double)NAN;
   if (n > 0) k_points_ij<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(g->proj, g->proj_row0, latlon_limit, i_center, n, x, y, z, ij);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
 
-// does the inverse projection put the grid's own CENTER points where they are?  A sample of up to 4096 of them; bad += points
-// that land more than 0.02 index units off (points in the zones where the inverse is not used are skipped)
-__global__ __launch_bounds__(256) void k_check_inverse(int nx, int ny, int64_t step, const float *__restrict__ ij, int32_t *__restrict__ bad) {
+// does the inverse projection put the grid's own points of one stagger where they are?  A sample of up to 4096 of them (snx points
+// per row); point (ii, jj) of the stagger belongs at CENTER index (ii - oi, jj - oj) -- oi = 0.5 for EDGE1 / CORNER, oj = 0.5 for EDGE2 /
+// CORNER; bad += points that land more than 0.02 index units off (points in the zones where the inverse is not used are skipped, and
+// so is the duplicate last column of a periodic grid's EDGE1 / CORNER stagger)
+__global__ __launch_bounds__(256) void k_check_inverse(int snx, int64_t npts, int64_t step, float oi, float oj, int skip_col, const float *__restrict__ ij,
+                                                       int32_t *__restrict__ bad) {
   const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, p = k * step;
-  if (p >= (int64_t)nx * ny) return;
+  if (p >= npts) return;
   const float i = ij[2 * k], j = ij[2 * k + 1];
   if (i != i || j != j) return;
-  if (fabsf(i - (float)(p % nx)) > 0.02f || fabsf(j - (float)(p / nx)) > 0.02f) atomicAdd(bad, 1);
+  if ((int)(p % snx) == skip_col) return;
+  if (fabsf(i - ((float)(p % snx) - oi)) > 0.02f || fabsf(j - ((float)(p / snx) - oj)) > 0.02f) atomicAdd(bad, 1);
 }
 
 // Lower bound of the chord length (unit sphere) of ONE index unit of the grid, anywhere within `margin` index units of the
@@ -203,8 +234,12 @@ __global__ __launch_bounds__(256) void k_check_inverse(int nx, int ny, int64_t s
 // inverse is not used.  0: no bound (the caller keeps the BVH search).
 double mpg_grid_min_index_chord(const mpg_grid_s *g, double lat_lo, double lat_hi, double margin) {
   const ProjDev &p = g->proj;
-  if (p.code == MPG_PROJ_LC) {
-    const double dlat = margin / p.rebydx * TG_DEG_PER_RAD * 1.5;   // index units -> degrees of latitude, generously
+  if (p.code == MPG_PROJ_LC || p.code == MPG_PROJ_PS || p.code == MPG_PROJ_MERC) {
+    // (polar stereographic: m falls monotonically towards the projection's pole; Mercator: m = cos(truelat) / cos(lat) grows with
+    // |lat| -- either way the largest map factor of a latitude interval sits at one of its ends, as for Lambert.  An index unit is
+    // dx / m on the ground along BOTH axes of these conformal maps.)
+    const double mmin = p.code == MPG_PROJ_LC ? 1.0 : p.code == MPG_PROJ_PS ? 0.5 : cos(p.truelat1 * TG_RAD_PER_DEG);   // lower bound of m: the margin in degrees
+    const double dlat = margin / (p.rebydx * fmax(mmin, 0.25)) * TG_DEG_PER_RAD * 1.5;   // index units -> degrees of latitude, generously
     const double a = fmax(lat_lo - dlat, -89.0), b = fmin(lat_hi + dlat, 89.0);
     const double m = fmax(map_factor(p, a), map_factor(p, b));
     if (!(m > 0.0) || !(m < 50.0)) return 0.0;
@@ -222,7 +257,10 @@ double mpg_grid_min_index_chord(const mpg_grid_s *g, double lat_lo, double lat_h
 // small-angle bounds), and never more than 16 index units (beyond that the box holds hundreds of candidates and the walk wins)
 double mpg_grid_box_emax(const mpg_grid_s *g) {
   const ProjDev &p = g->proj;
-  const double cell_deg = p.code == MPG_PROJ_LC ? (1.0 / p.rebydx) * TG_DEG_PER_RAD : fmax(fabs(p.loninc), fabs(p.latinc));
+  double cell_deg = p.code != MPG_PROJ_LATLON ? (1.0 / p.rebydx) * TG_DEG_PER_RAD : fmax(fabs(p.loninc), fabs(p.latinc));
+  // an index unit is dx / m on the ground; m falls to (1 + sin truelat) / 2 at a stereographic pole and to cos(truelat) on Mercator's equator
+  if (p.code == MPG_PROJ_PS) cell_deg *= 2.0 / (1.0 + sin(fabs(p.truelat1) * TG_RAD_PER_DEG));
+  if (p.code == MPG_PROJ_MERC) cell_deg /= cos(p.truelat1 * TG_RAD_PER_DEG);
   return fmin(16.0, 6.0 / cell_deg);
 }
 
@@ -234,7 +272,11 @@ double mpg_grid_box_emax(const mpg_grid_s *g) {
 // delta / 4 radians -- it depends on the figure's latitude, so the kernels compute it per figure from mpg_grid_box_pad_latlon
 // (geom.h mpg_box_pad) and this coefficient is not used for lat-lon grids.
 double mpg_grid_box_pad_coef(const mpg_grid_s *g) {
-  if (g->proj.code == MPG_PROJ_LC) return 0.5 / g->proj.rebydx;
+  // conformal maps: the image of a great-circle arc of E index units deviates from its chord by (d ln m / d lat) / m * E^2 / (8 rebydx)
+  // index units.  (d ln m / d lat) / m: Lambert below 1 where the inverse is handed out; polar stereographic cos(lat) / (1 + sin truelat)
+  // <= 1; Mercator sin(lat) / cos(truelat) <= 1 / cos(truelat) -- hence its extra factor.  0.5 / rebydx is four times E^2 / (8 rebydx).
+  if (g->proj.code == MPG_PROJ_LC || g->proj.code == MPG_PROJ_PS) return 0.5 / g->proj.rebydx;
+  if (g->proj.code == MPG_PROJ_MERC) return 0.5 / (g->proj.rebydx * cos(g->proj.truelat1 * TG_RAD_PER_DEG));
   return 2.0 * fmax(fabs(g->proj.loninc), fabs(g->proj.latinc)) * TG_RAD_PER_DEG;
 }
 // radians per index unit of a lat-lon grid (0 for the other projections): the scale of the per-figure pad
@@ -429,28 +471,46 @@ int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t
   ProjDev p;
   int rc = derive(proj, &p);
   if (rc) return rc;
-  if (p.code != MPG_PROJ_LC && p.code != MPG_PROJ_LATLON) return MPG_SUCCESS;   // no inverse here for it: the grid stays on the pyramid
-  const int64_t n = (int64_t)g->nx * g->ny, step = n > 4096 ? n / 4096 : 1, ns = (n + step - 1) / step;
-  const PointSet &c = g->pts[MPG_STAGGERLOC_CENTER];
-  TmpBuf<double> sp;
-  TmpBuf<float> ij;
-  TmpBuf<int32_t> bad;
-  if ((rc = sp.alloc(3 * (size_t)ns, s)) || (rc = ij.alloc(2 * (size_t)ns, s)) || (rc = bad.alloc(1, s))) return rc;
-  MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
-  k_sample_points<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(n, step, c.x.p, c.y.p, c.z.p, sp.p, sp.p + ns, sp.p + 2 * ns);
-  k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, MPG_LATLON_BOX_LIMIT, (double)NAN, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
-  k_check_inverse<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(g->nx, g->ny, step, ij.p, bad.p);
-  MPG_HIP(hipGetLastError());
-  int32_t hbad = 0;
-  MPG_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  MPG_HIP(hipStreamSynchronize(s));
-  if (hbad) {
+  const double i_center = p.code == MPG_PROJ_MERC ? 1.0 + 0.5 * (double)g->nx : (double)NAN;
+  bool ok[4] = {true, true, true, true};
+  int32_t nbad_center = 0;
+  int64_t ns_center = 0;
+  // every stagger that has points is checked: CENTER must fit (else the claim is refused); another stagger that does not -- the
+  // CORNER points a file-defined grid gets from get_cell_corners sit a cell east of the projection's -- just keeps the pyramid
+  // search for the Stores onto it
+  for (int st = 0; st < 4; ++st) {
+    const PointSet &c = g->pts[st];
+    const int64_t n = (int64_t)g->snx[st] * g->sny[st];
+    if (c.n != n || n == 0) continue;
+    const int64_t step = n > 4096 ? n / 4096 : 1, ns = (n + step - 1) / step;
+    TmpBuf<double> sp;
+    TmpBuf<float> ij;
+    TmpBuf<int32_t> bad;
+    if ((rc = sp.alloc(3 * (size_t)ns, s)) || (rc = ij.alloc(2 * (size_t)ns, s)) || (rc = bad.alloc(1, s))) return rc;
+    MPG_HIP(hipMemsetAsync(bad.p, 0, sizeof(int32_t), s));
+    k_sample_points<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(n, step, c.x.p, c.y.p, c.z.p, sp.p, sp.p + ns, sp.p + 2 * ns);
+    k_points_ij<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(p, row0, MPG_LATLON_BOX_LIMIT, i_center, ns, sp.p, sp.p + ns, sp.p + 2 * ns, ij.p);
+    const float oi = (st == MPG_STAGGERLOC_EDGE1 || st == MPG_STAGGERLOC_CORNER) ? 0.5f : 0.f, oj = (st == MPG_STAGGERLOC_EDGE2 || st == MPG_STAGGERLOC_CORNER) ? 0.5f : 0.f;
+    const int skip_col = ((g->periodic & MPG_GRID_PERIODIC_I) && oi > 0.f) ? g->nx : -1;
+    k_check_inverse<<<(unsigned)((ns + 255) / 256), 256, 0, s>>>(g->snx[st], n, step, oi, oj, skip_col, ij.p, bad.p);
+    MPG_HIP(hipGetLastError());
+    int32_t hbad = 0;
+    MPG_HIP(hipMemcpyAsync(&hbad, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    ok[st] = hbad == 0;
+    if (st == MPG_STAGGERLOC_CENTER) {
+      nbad_center = hbad;
+      ns_center = ns;
+    }
+  }
+  if (!ok[MPG_STAGGERLOC_CENTER]) {
     mpg_set_error("mpg_grid_attach_proj: the projection does not reproduce the grid's own points (%d of %lld sampled CENTER points land elsewhere)",
-                  hbad, (long long)ns);
+                  nbad_center, (long long)ns_center);
     return MPG_ERR_INVALID_ARG;
   }
   g->proj = p;
   g->proj_row0 = row0;
   g->has_inverse = true;
+  for (int st = 0; st < 4; ++st) g->inverse_ok[st] = ok[st];
   return MPG_SUCCESS;
 }

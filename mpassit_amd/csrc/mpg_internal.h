@@ -250,6 +250,8 @@ struct mpg_grid_s {
   ProjDev proj;                   // the projection itself: Stores on such a grid find a triangle's / a cell's target points through its
                                   // inverse in O(1) (k_target_grid.hip mpg_k_points_ij) instead of descending the box pyramid
   bool has_inverse = false;       // `proj` is set and checked against the grid's own points (mpg_grid_create_proj, mpg_grid_attach_proj)
+  bool inverse_ok[4] = {true, true, true, true};   // ... per stagger: a grid made from ARRAYS may carry staggers that are not the projection's
+                                  // (a file-defined grid's CORNER points come from get_cell_corners, model_grid.F90:1902-1972, a cell off)
   int proj_row0 = 0;              // the grid's first row is row proj_row0 of the projection's grid (a rank's row block)
   DevBuf<double> lon[4], lat[4];  // degrees, per stagger
   DevBuf<double> mapfac[3];       // CENTER, EDGE1, EDGE2
@@ -323,7 +325,7 @@ int mpg_k_target_grid(const mpg_proj *proj, mpg_grid_s *g, hipStream_t s);
 // (i, j) of n points on the unit sphere in the 0-based CENTER index space of a projection-built grid, float2 per point; NaN where
 // the inverse projection is not safely usable (near its pole / cut, other projections): callers fall back to the pyramid there.
 // false: this grid has no usable inverse at all (made from arrays, or a projection without one here)
-bool mpg_grid_has_inverse(const mpg_grid_s *g);
+bool mpg_grid_has_inverse(const mpg_grid_s *g, int stagger = MPG_STAGGERLOC_CENTER);   // ... whose points of `stagger` sit where the projection puts them
 int mpg_k_attach_proj(mpg_grid_s *g, const mpg_proj *proj, int row0, hipStream_t s);
 #define MPG_LATLON_BOX_LIMIT 85.0   // degrees: up to here a lat-lon grid's index boxes serve the Stores (their pad follows the figure's latitude)
 int mpg_k_points_ij(const mpg_grid_s *g, int64_t n, const double *x, const double *y, const double *z, float *ij, hipStream_t s, double latlon_limit = MPG_LATLON_BOX_LIMIT,

@@ -297,6 +297,8 @@ contains
     integer(c_int64_t) :: ni, nj
     real(dp), allocatable :: lat_c(:, :), lon_c(:, :)
     real(dp) :: v
+    type(mpg_proj) :: p
+    integer(c_int) :: rc_attach
     call ncio_check(ncio_open(trim(file_target_grid), nf), "opening "//trim(file_target_grid))
     call ncio_check(ncio_inq_dim(nf, "west_east", ni), "reading west_east")
     call ncio_check(ncio_inq_dim(nf, "south_north", nj), "reading south_north")
@@ -344,6 +346,18 @@ contains
       call mpg_check(mpg_grid_create(int(i_target, c_int), int(j_target, c_int), 0_c_int, lon_m, lat_m, lon_c, lat_c, &
                                      lon_u, lat_u, lon_v, lat_v, grid_h), "IN GridCreate")
     end if
+    ! The file's projection (MAP_PROJ, TRUELAT1/2, STAND_LON, DX; known point = the grid's own first mass point) as a CLAIM the
+    ! library checks on the grid's points: when it holds, the Stores search through the inverse projection instead of the box
+    ! pyramid (same weights, a few times faster); a projection that does not reproduce the grid is refused and nothing changes.
+    p%code = int(proj_code, c_int)
+    p%known_lat = lat_m(1, 1); p%known_lon = lon_m(1, 1); p%known_x = 1.0_dp; p%known_y = 1.0_dp
+    p%dx_m = dxkm; p%stand_lon = stand_lon; p%truelat1 = truelat1; p%truelat2 = truelat2
+    p%dlat_deg = 0.0_dp; p%dlon_deg = 0.0_dp
+    if (proj_code == PROJ_LATLON .and. i_target > 1 .and. j_target > 1) then
+      p%dlat_deg = lat_m(1, 2) - lat_m(1, 1); p%dlon_deg = lon_m(2, 1) - lon_m(1, 1)
+      if (p%dlon_deg < -180.0_dp) p%dlon_deg = p%dlon_deg + 360.0_dp
+    end if
+    rc_attach = mpg_grid_attach_proj(grid_h, p, int(je_lo - 1, c_int))
   contains
     subroutine get2(name, alt, a, n1, n2)
       character(len=*), intent(in) :: name, alt

@@ -391,6 +391,16 @@ def define_target_grid_file(path):
         g.lon_u, g.lat_u = var("XLONG_U"), var("XLAT_U")
         g.lon_v, g.lat_v = var("XLONG_V"), var("XLAT_V")
         g.lat_c, g.lon_c = get_cell_corners(g.lat, g.lon, dx)
+        # The projection as a CLAIM the library checks on the grid's own points (mpg_grid_attach_proj: the Stores may then search
+        # through its inverse instead of the box pyramid): the file's MAP_PROJ / TRUELAT1/2 / STAND_LON / DX with the grid's own first
+        # mass point as the known point.  WRF numbers its projections 1 Lambert, 2 polar stereographic, 3 Mercator, 6 lat-lon
+        # (a rotated lat-lon grid fails the check and keeps the pyramid).
+        proj.lat1, proj.lon1, proj.knowni, proj.knownj = float(g.lat[0, 0]), float(g.lon[0, 0]), 1.0, 1.0
+        if code == 6:
+            proj.code = PROJ_LATLON
+            proj.latinc = float(g.lat[1, 0] - g.lat[0, 0]) if nj > 1 else 0.0
+            dlon = float(g.lon[0, 1] - g.lon[0, 0]) if ni > 1 else 0.0
+            proj.loninc = dlon + 360.0 if dlon < -180.0 else dlon
         for k, names in (("mapfac_m", ("MAPFAC_M",)), ("mapfac_u", ("MAPFAC_U",)), ("mapfac_v", ("MAPFAC_V",)), ("hgt", ("HGT", "HGT_M"))):
             try:
                 g.extra[k] = var(*names)

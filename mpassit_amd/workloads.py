@@ -55,6 +55,16 @@ def workload(name, arrays=True):
         g = conus_lambert_grid(ny=rows + 1)
         m = synth.regional_mesh_for_lambert(conus_lambert_grid().proj, 1801, 1061, 3_000_000)
         return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> a %d-row block of the 1800-wide Lambert grid" % rows
+    if name in ("x_c4_polar", "x_c4_mercator"):
+        # extra (round 5: index-space Stores on the other two projections of the namelist, program_setup.F90:174-182): configuration
+        # 4's sizes -- a 3.0 M-cell regional hex mesh under an 1801x1061 3-km grid -- on a polar stereographic grid with the north pole
+        # inside it and on a Mercator grid across the date line
+        if name == "x_c4_polar":
+            g = tg.define_target_grid_params("polar", 1801, 1061, dx=3000.0, dy=3000.0, ref_lat=89.0, ref_lon=25.0, truelat1=75.0, stand_lon=-100.0)
+        else:
+            g = tg.define_target_grid_params("mercator", 1801, 1061, dx=3000.0, dy=3000.0, ref_lat=-8.0, ref_lon=179.0, truelat1=-15.0, stand_lon=179.0)
+        m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
+        return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1801x1061 %s grid (1800x1060 mass points)" % name[5:]
     if name == "c2_655k_global":
         # BASELINE configs 2 and 3: the GLOBAL quasi-uniform 655 362-cell mesh (10*4^8 + 2 cells = MPAS x1.655362, SURVEY
         # s8(d)) under the README Lambert domain, which touches only 2-3 % of its cells; Morton-numbered.

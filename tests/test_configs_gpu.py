@@ -288,6 +288,10 @@ def test_stores_on_polar_stereographic_and_mercator_grids(gpu_lib, oracle, kind)
     mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
     res = check_stores(R, mesh, grid, osd, ("bilinear", "nearest", "conserve"))
     assert res["mapped"].all()                                   # a global mesh maps every point of a regional grid
+    for code in (R.REGRIDMETHOD_BILINEAR, R.REGRIDMETHOD_NEAREST_STOD, R.REGRIDMETHOD_CONSERVE):    # round 5: through the grid's index space
+        rhp = R.regrid_store(mesh, grid, code)
+        assert rhp.store_path >= 1
+        rhp.release()
     # a field through the bilinear handle, and the conservative one: a constant stays the constant (rows sum to 1)
     L = 3
     src = synth.analytic_field(m.latCell, m.lonCell, L)

@@ -208,3 +208,32 @@ def test_c4_row_blocks_on_windowed_meshes_equal_the_whole_mesh(c4):
             b.release()
         cut.destroy()
         grid.destroy()
+
+
+@pytest.mark.parametrize("workload", ["x_c4_polar", "x_c4_mercator"])
+def test_c4_sized_polar_stereographic_and_mercator_grids(gpu_lib, oracle, workload):
+    """Round 5: configuration 4's sizes (3.0 M cells, 1800 x 1060 mass points at 3 km) on the other two projections of the namelist
+    (program_setup.F90:174-182) -- a polar stereographic grid with the north pole inside it, a Mercator grid across the date line.
+    The three Stores go through the grid's index space (inverses of module_map_utils.F90:718-760 / :1320-1341) and are compared with
+    the ORACLE entry by entry; their times are printed beside the Lambert grid's (0.31 / 0.6 / 2.7 ms at the end of round 4)."""
+    from test_configs_gpu import OracleSide, check_stores
+    from mpassit_amd import regrid as R, workloads
+    m, g, _, _ = workloads.workload(workload)
+    osd = OracleSide(oracle, m, g)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(g)
+    res = check_stores(R, mesh, grid, osd, ("bilinear", "nearest", "conserve"))
+    assert res["mapped"].all()
+    ms = {}
+    for rep in range(2):            # fresh objects: nothing from the handle cache; the second round is the warm figure
+        mesh2, grid2 = R.Mesh.from_mpas(m), R.Grid.from_proj(g)
+        for name, code in (("bilinear", R.REGRIDMETHOD_BILINEAR), ("nearest", R.REGRIDMETHOD_NEAREST_STOD), ("conserve", R.REGRIDMETHOD_CONSERVE)):
+            rh = R.regrid_store(mesh2, grid2, code)
+            assert rh.store_path >= 1, (name, rh.store_stats)          # through the index space, not the pyramid / the tree alone
+            ms[name] = rh.store_ms
+            rh.release()
+        mesh2.destroy()
+        grid2.destroy()
+    print("store_ms %s:" % workload, {k: round(v, 3) for k, v in ms.items()})
+    assert ms["bilinear"] < 1.0 and ms["nearest"] < 1.5 and ms["conserve"] < 5.0, ms       # the pyramid walks took 1.8 / 3.0 / 4.4 ms
+    mesh.destroy()
+    grid.destroy()

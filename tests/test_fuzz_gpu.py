@@ -8,7 +8,7 @@ from conftest import mesh_xyz
 
 pytestmark = pytest.mark.gpu
 
-CASES = list(range(32))
+CASES = list(range(40))       # 32 .. 39 (round 5): polar stereographic and Mercator grids
 
 
 def _mesh(rng, kind):
@@ -24,10 +24,19 @@ def _mesh(rng, kind):
     return synth.regional_mesh_for_lambert(p, 41, 31, int(rng.integers(500, 4000)), margin=float(rng.uniform(-0.1, 0.2)))
 
 
-def _grid(rng):
+def _grid(rng, kind=None):
     from mpassit_amd import target_grid as T
-    kind = int(rng.integers(3))
+    kind = int(rng.integers(3)) if kind is None else kind
     nx, ny = int(rng.integers(3, 140)), int(rng.integers(3, 90))
+    if kind == 3:      # polar stereographic, the pole in or near the grid (program_setup.F90:179-182)
+        dx = float(rng.uniform(20e3, 90e3))
+        sgn = -1.0 if rng.random() < 0.4 else 1.0
+        return T.define_target_grid_params("polar", nx, ny, dx=dx, dy=dx, ref_lat=sgn * float(rng.uniform(60, 90)), ref_lon=float(rng.uniform(-180, 180)),
+                                           truelat1=sgn * float(rng.uniform(50, 90)), stand_lon=float(rng.uniform(-180, 180)))
+    if kind == 4:      # Mercator (program_setup.F90:174-177)
+        dx = float(rng.uniform(20e3, 90e3))
+        return T.define_target_grid_params("mercator", nx, ny, dx=dx, dy=dx, ref_lat=float(rng.uniform(-45, 45)), ref_lon=float(rng.uniform(-180, 180)),
+                                           truelat1=float(rng.uniform(-40, 40)), stand_lon=0.0)
     if kind == 0:
         dx = float(rng.uniform(20e3, 90e3))
         return T.define_target_grid_params("lambert", nx, ny, dx=dx, dy=dx, ref_lat=float(rng.uniform(25, 50)), ref_lon=float(rng.uniform(-120, -75)),
@@ -44,7 +53,7 @@ def test_random_configuration(oracle, gpu_lib, case):
     from mpassit_amd import regrid as R, synth
     rng = np.random.default_rng(1000 + case)
     m = _mesh(rng, case % 4)
-    g = _grid(rng)
+    g = _grid(rng, kind=None if case < 32 else 3 + case % 2)
     nlev = int(rng.choice([1, 2, 3, 5, 8, 17, 33, 55, 70]))
     nf = int(rng.integers(1, 4))
     mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)

@@ -214,3 +214,55 @@ def test_nearest_bins_at_the_lambert_cut_and_on_wide_regional_latlon_grids(gpu_l
         assert pb == [0, 0] and pa[0] in want and pa[1] in want, (pa, pb)      # the search under test did run (and stood aside where it must)
         seen += pa
     assert 2 in seen                                              # ... and the points next to the cut were handed to the tree
+
+
+def test_polar_stereographic_and_mercator_grids(gpu_lib):
+    """Round 5: the inverses of the other two projections of the namelist (llij_ps, module_map_utils.F90:718-760; llij_merc,
+    :1320-1341).  A polar stereographic grid with the NORTH POLE inside it (a regular point of that map: no exclusion zone, no
+    cut), one in the southern hemisphere far from its pole, a Mercator grid across the date line with its known point in a corner
+    (the map's cut is taken opposite the grid's middle column, not opposite the known point): owners, weights and the conservative
+    matrix identical to the pyramid walk's, and the Stores did go through the index space."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    m = synth.icosahedral_mesh(6)
+    grids = [tg.define_target_grid_params("polar", 141, 121, dx=50000.0, dy=50000.0, ref_lat=89.0, ref_lon=25.0, truelat1=75.0, stand_lon=-100.0),
+             tg.define_target_grid_params("polar", 121, 101, dx=40000.0, dy=40000.0, ref_lat=-55.0, ref_lon=140.0, truelat1=-71.0, stand_lon=150.0),
+             tg.define_target_grid_params("mercator", 161, 91, dx=70000.0, dy=70000.0, ref_lat=-8.0, ref_lon=179.0, truelat1=-15.0, stand_lon=179.0),
+             tg.define_target_grid_params("mercator", 201, 81, dx=60000.0, dy=60000.0, ref_lat=20.0, ref_lon=100.0, ref_x=1.0, ref_y=1.0, truelat1=30.0, stand_lon=0.0)]
+    for g in grids:
+        got = _case(gpu_lib, m, g, staggers=(0, 1, 2))
+        assert (got["bil0"][0] >= 0).all() and got["cons"][1].size > 0
+        mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(g, fill_target=False)
+        for kw in (dict(regridmethod=R.REGRIDMETHOD_BILINEAR), dict(regridmethod=R.REGRIDMETHOD_CONSERVE), dict(regridmethod=R.REGRIDMETHOD_NEAREST_STOD)):
+            rh = R.regrid_store(mesh, grid, **kw)
+            assert rh.store_path >= 1, (g.proj.code, kw)
+            rh.release()
+        mesh.destroy()
+        grid.destroy()
+
+
+def test_nearest_on_the_two_projections_equals_the_tree(gpu_lib):
+    """The nearest Store through index bins on polar stereographic / Mercator grids against the tree search ("store_boxes" 0):
+    identical indices, CENTER and EDGE1 points; meshes finer and coarser than the grid."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    grids = [tg.define_target_grid_params("polar", 141, 121, dx=50000.0, dy=50000.0, ref_lat=89.0, ref_lon=25.0, truelat1=75.0, stand_lon=-100.0),
+             tg.define_target_grid_params("mercator", 161, 91, dx=70000.0, dy=70000.0, ref_lat=-8.0, ref_lon=179.0, truelat1=-15.0, stand_lon=179.0)]
+    for level in (4, 7):
+        m = synth.icosahedral_mesh(level)
+        for g in grids:
+            res = []
+            for boxes in (1, 0):
+                gpu_lib.tune("store_boxes", boxes)
+                try:
+                    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(g, fill_target=False)
+                    out = []
+                    for st in (0, 1):
+                        rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD, staggerloc=st)
+                        out.append((rh.weights()[0], rh.store_path))
+                        rh.release()
+                    res.append(out)
+                    mesh.destroy()
+                    grid.destroy()
+                finally:
+                    gpu_lib.tune("store_boxes", 1)
+            for (a, pa), (b, pb) in zip(*res):
+                assert np.array_equal(a, b) and pa >= 1 and pb == 0

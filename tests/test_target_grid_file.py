@@ -65,11 +65,17 @@ def test_regrid_onto_a_file_defined_grid(oracle, gpu_lib, geo_file):
     tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
     f = synth.analytic_field(m.latCell, m.lonCell, 3)
     rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    # round 5: the file's MAP_PROJ / TRUELAT / STAND_LON / DX with its own first mass point as the known point is a claim the library
+    # checked on the grid's points (float32 coordinates and all): the bilinear Store searched through the inverse projection
+    assert t.proj.knowni == 1.0 and t.proj.lat1 == t.lat[0, 0] and rh.store_path == 1
     idx, w = oracle.bilinear_weights(cxyz, tri, oracle.lonlat_deg_to_xyz(t.lon, t.lat))
     np.testing.assert_allclose(rh.regrid(f, nlev=3).reshape(3, -1), oracle.apply_fixed(idx, w, f, 3), rtol=1e-11, atol=1e-11)
     rh.release()
     # conservative onto the corners the reference would build (overlapping / gapped quads and all)
     rc = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    # ... while the CORNER stagger of a file-defined grid is get_cell_corners' (a cell east of the projection's, model_grid.F90:1902-1972):
+    # it failed the same check, and the conservative Store kept the pyramid -- index boxes around the projection's cells would miss these
+    assert rc.store_path == 0
     rp, col, val = oracle.conserve(m.verticesOnCell, vxyz, t.nx, t.ny, oracle.lonlat_deg_to_xyz(t.lon_c, t.lat_c))
     snow = synth.snow_field(m.latCell, m.lonCell) + 1.0
     np.testing.assert_allclose(rc.regrid(snow, nlev=1).reshape(-1), oracle.apply_csr(rp, col, val, snow, 1)[0], rtol=1e-10, atol=1e-12)

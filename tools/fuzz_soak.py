@@ -18,8 +18,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def random_grid(rng):
     from mpassit_amd import target_grid as T
-    kind = int(rng.integers(7))
+    kind = int(rng.integers(9))
     nx, ny = int(rng.integers(3, 160)), int(rng.integers(3, 100))
+    if kind == 7:      # polar stereographic (round 5): either hemisphere, the pole inside the grid, beside it or far from it
+        dx = float(rng.uniform(8e3, 150e3))
+        south = rng.random() < 0.35
+        sgn = -1.0 if south else 1.0
+        lat = sgn * float(rng.choice([rng.uniform(86, 90), rng.uniform(55, 86), rng.uniform(20, 55)]))
+        return T.define_target_grid_params("polar", nx, ny, dx=dx, dy=dx, ref_lat=lat, ref_lon=float(rng.uniform(-180, 180)),
+                                           truelat1=sgn * float(rng.uniform(45, 90)), stand_lon=float(rng.uniform(-180, 180)))
+    if kind == 8:      # Mercator (round 5): the known point anywhere in the grid (the map's cut follows the grid's middle), across the date line
+        dx = float(rng.uniform(8e3, 150e3))
+        kw = {}
+        if rng.random() < 0.5:
+            kw = dict(ref_x=float(rng.uniform(1, nx)), ref_y=float(rng.uniform(1, ny)))
+        return T.define_target_grid_params("mercator", nx, ny, dx=dx, dy=dx, ref_lat=float(rng.uniform(-55, 55)), ref_lon=float(rng.uniform(-180, 180)),
+                                           truelat1=float(rng.uniform(-50, 50)), stand_lon=0.0, **kw)
     if kind == 5:      # a fine regional lat-lon grid that reaches the last degrees before a pole (the boxes' pad follows the latitude)
         d = float(rng.uniform(0.05, 0.4))
         south = rng.random() < 0.5
