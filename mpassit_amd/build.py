@@ -13,11 +13,13 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "_build")
 SO = os.path.join(HERE, "libmpassit_amd.so")
 SOURCES = ["mpg_api.hip", "mpg_comm.hip", "mpg_hostpipe.hip", "mpg_fileio.hip", "k_setup.hip", "k_mesh_window.hip", "k_target_grid.hip", "k_store_bilinear.hip", "k_store_nearest.hip", "k_store_conserve.hip",
-           "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_pole.hip", "k_post.hip", "k_halo.hip"]
+           "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_pole.hip", "k_post.hip", "k_halo.hip", "k_prims.hip", "k_sort.hip"]
 HEADERS = ["mpg_internal.h", "geom.h", os.path.join("..", "..", "include", "mpassit_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+# -Xoffload-linker --strip-all: the device code objects keep their dynamic symbols (the kernels the runtime looks up) and lose the
+# static symbol table and its strings -- 1.2 MB of mangled template names per translation unit that instantiates library templates,
+# all of which the runtime reads when it loads the object (profiles/r05_init_breakdown.md)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", "-Xoffload-linker", "--strip-all"]
 
 
 def _newer(a, deps):

@@ -3,7 +3,6 @@
 // and the pack kernel lives in k_apply.hip.
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include "mpg_internal.h"
 
@@ -37,11 +36,7 @@ int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap,
   if (gb > 8192) gb = 8192;
   if (gb < 1) gb = 1;
   k_mark<<<gb, 256, 0, s>>>(ni, ip, flag.p);
-  size_t tmp_bytes = 0;
-  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, flag.p, pos.p, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), s));
-  TmpBuf<char> tmp;
-  if ((rc = tmp.alloc(tmp_bytes + 16))) return rc;
-  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, flag.p, pos.p, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), s));
+  if ((rc = mpg_scan_excl_i32(flag.p, pos.p, n + 1, s))) return rc;
   int32_t nu = 0;
   MPG_HIP(hipMemcpyAsync(&nu, pos.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
@@ -58,7 +53,7 @@ int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap,
   }
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
-  flag.free(); pos.free(); out.free(); tmp.free();
+  flag.free(); pos.free(); out.free();
   return MPG_SUCCESS;
 }
 

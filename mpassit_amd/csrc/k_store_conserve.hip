@@ -10,7 +10,7 @@
 // AABB pyramid over the CORNER points (same machinery as the bilinear rasteriser), in two steps: (1) one thread per
 // source cell walks the pyramid and LISTS the destination cells that survive the box / bounding-sphere tests;
 // (2) one thread per (source cell, destination cell) PAIR clips it, both polygon buffers in LDS, and bumps the
-// destination cell's counter.  A rocPRIM scan turns the counters into CSR row offsets, a scatter pass moves the pairs
+// destination cell's counter.  A scan (k_prims.hip) turns the counters into CSR row offsets, a scatter pass moves the pairs
 // into place, and every (short) row is sorted by source id so the stored matrix and the summation order are
 // deterministic.  Source cells with more candidates than the fixed-size list of step (1) holds -- polar cells under
 // lat-lon slivers, or every cell of a coarse mesh under a fine grid -- are walked again by one WORKGROUP each, which
@@ -18,7 +18,6 @@
 // Clipping = Sutherland-Hodgman against the 4 great-circle half-spaces.
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 // No floating-point contraction in this translation unit (the geometry helpers of geom.h included): a weight is a ratio of
 // areas that moves by 1e-13..1e-12 of itself when ONE product of an intersection point is fused into an FMA or not, and which
@@ -713,23 +712,14 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
                                                        nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, spill.p, spill_cap);
   // (2) pair list: offsets by scan, then (cell, destination) per pair
   k_conserve_clamp_counts<<<(unsigned)((nC + 256) / 256), 256, 0, s>>>(nC, cnt_src.p, npair.p);
-  size_t tmp_bytes = 0, b2 = 0;
-  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
-  MPG_HIP(rocprim::exclusive_scan(nullptr, b2, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
-  TmpBuf<char> tmp;
-  if ((rc = tmp.alloc((tmp_bytes > b2 ? tmp_bytes : b2) + 16, s))) return rc;
-  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, npair.p, poff.p, (int32_t)0, (size_t)nC + 1, rocprim::plus<int32_t>(), s));
+  if ((rc = mpg_scan_excl_i32(npair.p, poff.p, nC + 1, s))) return rc;
   // the pair count twice -- the int32 scan's last entry and a 64-bit sum (the scan could wrap more than once) -- in ONE round trip
   int32_t npairs = 0;
   long long total = 0;
   {
     TmpBuf<long long> tot;
-    TmpBuf<char> t2;
-    size_t b3 = 0;
     if ((rc = tot.alloc(1, s))) return rc;
-    MPG_HIP(rocprim::reduce(nullptr, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
-    if ((rc = t2.alloc(b3 + 16, s))) return rc;
-    MPG_HIP(rocprim::reduce((void *)t2.p, b3, npair.p, tot.p, (long long)0, (size_t)nC, rocprim::plus<long long>(), s));
+    if ((rc = mpg_sum_i32_i64(npair.p, nC, tot.p, s))) return rc;
     MPG_HIP(hipMemcpyAsync(&npairs, poff.p + nC, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     MPG_HIP(hipMemcpyAsync(&total, tot.p, sizeof(total), hipMemcpyDeviceToHost, s));
     MPG_HIP(hipStreamSynchronize(s));
@@ -762,8 +752,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
         npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, vx, vy, vz, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
         pair_val.p, count.p, truncated.p);
   MPG_HIP(hipGetLastError());
-  tmp_bytes = b2;
-  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, count.p, h->rowptr.p, (int32_t)0, (size_t)P + 1, rocprim::plus<int32_t>(), s));
+  if ((rc = mpg_scan_excl_i32(count.p, h->rowptr.p, P + 1, s))) return rc;
   int32_t nnz = 0, was_truncated = 0, hs[5] = {0, 0, 0, 0, 0};
   MPG_HIP(hipMemcpyAsync(hs, n_ovf.p, sizeof(hs), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipMemcpyAsync(&nnz, h->rowptr.p + P, sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -12,7 +12,6 @@
 // monotone in floating point and the argmin / tie-break is identical to the CPU oracle's.
 #include <cstring>
 
-#include <rocprim/rocprim.hpp>
 
 #include <string.h>
 
@@ -108,11 +107,7 @@ int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s, bool whole) {
   if ((rc = b.sorted.alloc(n))) return rc;
   unsigned nb = (unsigned)((n + 255) / 256);
   k_morton<<<nb, 256, 0, s>>>(n, m->cell.x.p, m->cell.y.p, m->cell.z.p, key_in.p, id_in.p, first);
-  size_t tmp_bytes = 0;
-  MPG_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
-  TmpBuf<char> tmp;
-  if ((rc = tmp.alloc(tmp_bytes + 16, s))) return rc;
-  MPG_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tmp_bytes, key_in.p, key_out.p, id_in.p, b.sorted_id.p, (size_t)n, 0, 63, s));
+  if ((rc = mpg_sort_pairs_u64_i32(key_in.p, key_out.p, id_in.p, b.sorted_id.p, n, s))) return rc;   // (k_sort.hip: rocPRIM's radix sort)
   k_gather_sites<<<nb, 256, 0, s>>>(n, b.sorted_id.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, b.sorted.x.p, b.sorted.y.p, b.sorted.z.p);
   // level sizes
   int nlev = 0;
@@ -138,7 +133,7 @@ int mpg_k_build_bvh(mpg_mesh_s *m, hipStream_t s, bool whole) {
                                                                   b.box.p + 6 * b.off[l]);
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
-  key_in.free(); key_out.free(); id_in.free(); tmp.free();
+  key_in.free(); key_out.free(); id_in.free();
   b.built = true;
   return MPG_SUCCESS;
 }
@@ -629,11 +624,7 @@ static int nearest_by_bins(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int npx, i
     if (!(q.h > 0.0)) return MPG_SUCCESS;
   }
   k_nb_count<<<nbc, 256, 0, s>>>(n, ij.p, q, cnt.p);
-  size_t tmp_bytes = 0;
-  MPG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.p, off.p, (int32_t)0, (size_t)nbins + 1, rocprim::plus<int32_t>(), s));
-  TmpBuf<char> tmp;
-  if ((rc = tmp.alloc(tmp_bytes + 16, s))) return rc;
-  MPG_HIP(rocprim::exclusive_scan((void *)tmp.p, tmp_bytes, cnt.p, off.p, (int32_t)0, (size_t)nbins + 1, rocprim::plus<int32_t>(), s));
+  if ((rc = mpg_scan_excl_i32(cnt.p, off.p, nbins + 1, s))) return rc;
   MPG_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * (nbins + 1), s));   // now the fill cursors
   k_nb_fill<<<nbc, 256, 0, s>>>(n, first, ij.p, q, off.p, cnt.p, ids.p);
   k_nb_query<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(npx, npy, pts.x.p, pts.y.p, pts.z.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, q, off.p, ids.p,

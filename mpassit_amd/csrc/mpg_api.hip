@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <thread>
@@ -120,15 +121,30 @@ void mpg_pool_release() {
 // creates the pinned staging of the host-array upload path, while the caller goes on (reading its namelist, opening its
 // files); a call that needs a module before the helper got to it simply loads it itself (the runtime serialises that).
 #define MPG_ANCHORS(X) X(k_setup) X(k_target_grid) X(k_store_bilinear) X(k_store_nearest) X(k_store_conserve) X(k_store_gridbil) \
-  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_pole) X(k_post) X(k_halo) X(mpg_comm) X(k_mesh_window)
+  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_pole) X(k_post) X(k_halo) X(mpg_comm) X(k_mesh_window) X(k_prims) X(k_sort)
 #define X(n) const void *mpg_anchor_##n();
 MPG_ANCHORS(X)
 #undef X
 static std::thread *g_warm = nullptr;   // on the heap: a process that exits without mpg_finalize must not meet ~thread of a joinable thread
+// MPG_INIT_TRACE=1: where mpg_init's time and the helper thread's go, one line per step on stderr (tools/first_call_probe.py;
+// profiles/r05_init_breakdown.md)
+static bool g_init_trace = false;
+static double now_ms() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
 static void warm_modules(int device) {
   if (hipSetDevice(device) != hipSuccess) return;
   hipFuncAttributes a;
-#define X(n) (void)hipFuncGetAttributes(&a, mpg_anchor_##n());
+  double t0 = now_ms();
+#define X(n)                                                                                                          \
+  (void)hipFuncGetAttributes(&a, mpg_anchor_##n());                                                                   \
+  if (g_init_trace) {                                                                                                 \
+    const double t1 = now_ms();                                                                                       \
+    fprintf(stderr, "mpg_init trace: helper thread: code object of %-18s %8.2f ms\n", #n, t1 - t0);                   \
+    t0 = t1;                                                                                                          \
+  }
   MPG_ANCHORS(X)
 #undef X
   // the runtime builds its staging for copies from pageable host memory at the first such copy (9.5 ms in front of the first
@@ -144,6 +160,7 @@ static void warm_modules(int device) {
   if (s) (void)hipStreamDestroy(s);
   if (d) (void)hipFree(d);
   free(h);
+  if (g_init_trace) fprintf(stderr, "mpg_init trace: helper thread: first pageable 32 MB upload + its buffers %8.2f ms\n", now_ms() - t0);
 }
 static void warm_join() {   // mpg_finalize, and atexit (registered after the HIP runtime's own handlers: runs before them)
   if (g_warm) {
@@ -168,7 +185,13 @@ const char *mpg_last_error(void) { return g_err; }
 
 int mpg_init(int device) {
   int n = 0;
+  {
+    const char *tr = getenv("MPG_INIT_TRACE");
+    g_init_trace = tr && *tr == '1';
+  }
+  const double t_0 = now_ms();
   hipError_t e = hipGetDeviceCount(&n);
+  const double t_1 = now_ms();
   if (e != hipSuccess || n <= 0) {
     mpg_set_error("mpg_init: no HIP device available (%s); this library has no CPU fallback",
                   e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -182,8 +205,12 @@ int mpg_init(int device) {
     return MPG_ERR_INVALID_ARG;
   }
   MPG_HIP(hipSetDevice(device));
+  const double t_2 = now_ms();
   if (!g_init) {
     MPG_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (g_init_trace)
+      fprintf(stderr, "mpg_init trace: hipGetDeviceCount (runtime start) %.2f ms, hipSetDevice %.2f ms, stream %.2f ms\n", t_1 - t_0, t_2 - t_1,
+              now_ms() - t_2);
     const char *e = getenv("MPG_NO_WARMUP");   // A/B runs of the first-call probe
     if (!(e && *e == '1')) {
       g_warm = new std::thread(warm_modules, device);

@@ -415,3 +415,8 @@ void mpg_set_nearest_variant(int v);
 int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s, bool keep_global = false);
 int mpg_k_source_range(mpg_handle_s *h, int64_t *first, int64_t *end, hipStream_t s);
 int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap, hipStream_t s);
+// k_prims.hip / k_sort.hip: the device-wide primitives of the Stores
+int mpg_scan_excl_i32(const int32_t *in, int32_t *out, int64_t n, hipStream_t s);     // out[i] = in[0] + .. + in[i - 1]
+int mpg_sum_i32_i64(const int32_t *in, int64_t n, long long *out_dev, hipStream_t s);
+int mpg_sort_pairs_u64_i32(const unsigned long long *keys_in, unsigned long long *keys_out, const int32_t *vals_in, int32_t *vals_out, int64_t n,
+                           hipStream_t s);

@@ -39,11 +39,12 @@ def _cons_vs_oracle(oracle, m, g, grid=None):
     return st, path, n_common, only_o, only_g
 
 
-@pytest.mark.parametrize("dx_km", [40, 33, 30])
+@pytest.mark.parametrize("dx_km", [40, 45, 50])
 def test_conservative_spill_and_wave_enumeration_from_index_boxes(gpu_lib, oracle, dx_km):
-    """450-km cells (the 2 562-cell icosahedral mesh) under a 30 / 33 / 40-km Lambert grid: a polygon spans 11-15 index units and four
-    degrees, its box holds more than 128 cells (a wavefront enumerates it) and 100-190 of them are candidates (past the 24-entry list,
-    into the spill area, copied by the list pass); nothing walks the pyramid."""
+    """450-km cells (the 2 562-cell icosahedral mesh; 520 km from vertex to vertex) under a 40 / 45 / 50-km Lambert grid: a polygon spans
+    10-13 index units (sixteen is the limit of the boxes) and under five degrees, its box holds more than 128 cells (a wavefront
+    enumerates it) and 70-110 of them are candidates (past the 24-entry list, into the spill area, copied by the list pass); nothing
+    walks the pyramid."""
     from mpassit_amd import synth
     m = synth.icosahedral_mesh(4)
     g = _lambert(121, 91, dx_km * 1000.0)
@@ -83,7 +84,7 @@ def test_conservative_polar_caps_of_a_global_grid(gpu_lib, oracle):
     from mpassit_amd import workloads
     m, g, _, _ = workloads.workload("c5_small")
     st, path, *_ = _cons_vs_oracle(oracle, m, g)
-    assert path == 1 and st[4] > 0 and st[2] >= st[4] and st[1] > 4 * g.nx * g.ny, st     # the caps' polygons walked, the rest through boxes
+    assert path == 1 and st[4] > 0 and st[2] >= st[4] and st[1] > 3 * g.nx * g.ny, st     # the caps' polygons walked, the rest through boxes
 
 
 def test_bilinear_wave_kernel_next_to_the_poles(gpu_lib, oracle):
