@@ -57,6 +57,10 @@ enum {
  * namelist and opening its files (the HIP runtime would otherwise load each translation unit at the first launch of one of
  * its kernels: 5-10 ms in front of the first Store of each method).  MPG_NO_WARMUP=1 in the environment switches it off. */
 int mpg_init(int device);
+/* Blocks until that helper thread is done (a few ms to a few hundred after mpg_init).  The thread allocates, frees and copies while it
+ * runs, which a stream capture in hipStreamCaptureModeGlobal does not tolerate from another thread: a host that starts capturing
+ * right after mpg_init calls this first (mpassit_amd/interp.py GraphedInterp does).  No-op when there is no such thread. */
+int mpg_warmup_wait(void);
 int mpg_finalize(void);
 const char *mpg_last_error(void);
 /* "gfx950" etc.; buf may be NULL */

@@ -16,10 +16,11 @@ SOURCES = ["mpg_api.hip", "mpg_comm.hip", "mpg_hostpipe.hip", "mpg_fileio.hip", 
            "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_pole.hip", "k_post.hip", "k_halo.hip", "k_prims.hip", "k_sort.hip"]
 HEADERS = ["mpg_internal.h", "geom.h", os.path.join("..", "..", "include", "mpassit_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+STRIP = os.environ.get("MPASSIT_STRIP_DEVICE", "").split()   # e.g. "-Xoffload-linker --strip-all" (measured in round 5: see below)
 # -Xoffload-linker --strip-all: the device code objects keep their dynamic symbols (the kernels the runtime looks up) and lose the
 # static symbol table and its strings -- 1.2 MB of mangled template names per translation unit that instantiates library templates,
 # all of which the runtime reads when it loads the object (profiles/r05_init_breakdown.md)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc", "-Xoffload-linker", "--strip-all"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"] + STRIP
 
 
 def _newer(a, deps):

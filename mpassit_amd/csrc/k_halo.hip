@@ -47,6 +47,7 @@ int mpg_k_unique_sources(mpg_handle_s *h, std::vector<int32_t> &ids, bool remap,
   k_compact<<<gn, 256, 0, s>>>(n, flag.p, pos.p, out.p);
   if (nu) MPG_HIP(hipMemcpyAsync(ids.data(), out.p, sizeof(int32_t) * nu, hipMemcpyDeviceToHost, s));
   if (remap) {
+    h->src_range_valid = false;   // the indices change
     k_remap<<<gb, 256, 0, s>>>(ni, ip, pos.p);
     h->n_src = nu;
     h->localized = true;
@@ -101,10 +102,15 @@ __global__ __launch_bounds__(256) void k_src_range(int64_t n, const int32_t *__r
 
 int mpg_k_source_range(mpg_handle_s *h, int64_t *first, int64_t *end, hipStream_t s) {
   int rc;
+  if (h->src_range_valid) {   // a property of the handle's indices: computed once (every host-array Regrid asks, mpg_hostpipe.hip)
+    *first = h->src_range_first;
+    *end = h->src_range_end;
+    return MPG_SUCCESS;
+  }
   int32_t *ip = h->kind == MPG_KIND_CSR ? h->col.p : h->idx.p;
   int64_t ni = h->kind == MPG_KIND_CSR ? h->nnz : (int64_t)h->nnz_per_row * h->n_dst;
   TmpBuf<int32_t> lohi;
-  if ((rc = lohi.alloc(2))) return rc;
+  if ((rc = lohi.alloc(2, s))) return rc;   // (from the stream's block cache: a plain hipFree would synchronise the device)
   int32_t init[2] = {0x7fffffff, -1}, out[2];
   MPG_HIP(hipMemcpyAsync(lohi.p, init, sizeof(init), hipMemcpyHostToDevice, s));
   int gb = (int)((ni + 255) / 256);
@@ -115,6 +121,9 @@ int mpg_k_source_range(mpg_handle_s *h, int64_t *first, int64_t *end, hipStream_
   MPG_HIP(hipStreamSynchronize(s));
   *first = out[1] >= 0 ? out[0] : 0;
   *end = out[1] >= 0 ? (int64_t)out[1] + 1 : 0;
+  h->src_range_first = *first;
+  h->src_range_end = *end;
+  h->src_range_valid = true;
   return MPG_SUCCESS;
 }
 
@@ -130,6 +139,7 @@ int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s, 
   int gb = (int)((ni + 255) / 256);
   if (gb > 8192) gb = 8192;
   if (gb < 1) gb = 1;
+  h->src_range_valid = false;   // the indices change
   k_rebase<<<gb, 256, 0, s>>>(ni, ip, (int32_t)base, (int32_t)n_local, bad.p);
   int32_t nb = 0;
   MPG_HIP(hipMemcpyAsync(&nb, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));

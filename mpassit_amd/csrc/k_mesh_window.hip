@@ -20,8 +20,9 @@
 //      (1 for a Voronoi mesh: the vertex is the circumcentre), a missing cell b of vertex v next to a known cell a has
 //      |b - a| <= (1 + K) r, so it would have been SELECTED if D(a) + (1 + K) r <= delta: such a vertex is PROVEN to be rim.
 //      Every cell whose dual triangles or whose own polygon can reach the grid -- D(a) <= (1 + K) r_a, r_a its largest
-//      vertex distance -- must have all its vertices complete or proven rim.  If one is not, delta doubles and the window
-//      is cut again (six times at most, then the whole mesh is taken);
+//      vertex distance -- must have all its vertices complete or proven rim (a cell beyond the distance pass's cap of 2 delta that
+//      is LARGE enough to reach the grid from there -- a coarse cell of a variable-resolution mesh -- has its distance measured for
+//      this test).  If one is not, delta doubles and the window is cut again (six times at most, then the whole mesh is taken);
 //   4. nearest-neighbour search needs no closure: a cell outside the selection is further than delta from every grid point,
 //      so any point whose nearest SITE is within delta has its true answer, and mpg_k_store_nearest checks exactly that
 //      (k_store_nearest.hip), falling back to a BVH over all centres, which are on the device anyway.
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(256) void k_win_vertex_status(int64_t nV, const int
 __global__ __launch_bounds__(256) void k_win_cell_closed(int64_t nC, int64_t cell0, int64_t vert0, int maxEdges, const int32_t *__restrict__ voc,
                                                          const double *__restrict__ cx, const double *__restrict__ cy, const double *__restrict__ cz,
                                                          const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ vz,
-                                                         const float *__restrict__ D, const uint8_t *__restrict__ status, int32_t *__restrict__ bad) {
+                                                         const float *__restrict__ D, const uint8_t *__restrict__ status, int32_t *__restrict__ bad,
+                                                         WinPyrs pyrs, double dcap) {
   const int64_t cl = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (cl >= nC) return;
   const int64_t a = cell0 + cl;
-  const double d = (double)D[a];
-  if (!(d < INFINITY)) return;   // beyond the cap: not a cell of this grid's neighbourhood (a cell that large is the stated assumption)
+  double d = (double)D[a];   // INFINITY beyond dcap = 2 delta: measured again below for a cell large enough to reach the grid from there
   double rmax = 0.0;
   bool open = false;
   for (int j = 0; j < maxEdges; ++j) {
@@ -203,7 +204,20 @@ __global__ __launch_bounds__(256) void k_win_cell_closed(int64_t nC, int64_t cel
     rmax = fmax(rmax, sqrt(dist2_nofma(cx[a], cy[a], cz[a], vx[v], vy[v], vz[v])));
     open = open || status[v] == 2;
   }
-  if (open && d <= (1.0 + WIN_K) * rmax) atomicOr(bad, 1);
+  if (!open) return;
+  if (!(d < INFINITY)) {
+    // Beyond the cap of the distance pass.  On a quasi-uniform mesh such a cell is a dozen spacings from the grid and cannot reach
+    // it; on a VARIABLE-resolution mesh the window's id range may hold a coarse cell whose own size exceeds the margin that was cut
+    // for the fine cells near the grid (round 5, advisor): its distance is taken for real, up to what it could span
+    const double reach = (1.0 + WIN_K) * rmax;
+    if (reach <= dcap) return;
+    double best2 = reach * reach;
+    bool found = false;
+    for (int q = 0; q < pyrs.n && !(found && best2 == 0.0); ++q) best2 = pyr_dist2(pyrs.v[q], cx[a], cy[a], cz[a], best2, found);
+    if (!found) return;
+    d = sqrt(best2);
+  }
+  if (d <= (1.0 + WIN_K) * rmax) atomicOr(bad, 1);
 }
 
 static int pyr_ready(mpg_grid_s *g, int st, hipStream_t s) {
@@ -350,7 +364,8 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
       k_win_vertex_status<<<(unsigned)((m->vwn + 255) / 256), 256, 0, s>>>(m->vwn, cnt.p, m->tri.p, m->cell.x.p, m->cell.y.p, m->cell.z.p, m->vert.x.p,
                                                                           m->vert.y.p, m->vert.z.p, D.p, delta, status.p);
       k_win_cell_closed<<<(unsigned)((m->cwn + 255) / 256), 256, 0, s>>>(m->cwn, m->cw0, m->vw0, m->maxEdges, m->voc.p, m->cell.x.p, m->cell.y.p,
-                                                                        m->cell.z.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, D.p, status.p, badd.p);
+                                                                        m->cell.z.p, m->vert.x.p, m->vert.y.p, m->vert.z.p, D.p, status.p, badd.p, pyrs,
+                                                                        2.0 * delta);
       MPG_HIP(hipGetLastError());
       MPG_HIP(hipMemcpyAsync(&bad, badd.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
       MPG_HIP(hipStreamSynchronize(s));

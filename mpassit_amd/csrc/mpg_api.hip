@@ -226,6 +226,13 @@ int mpg_init(int device) {
   return MPG_SUCCESS;
 }
 
+// The helper thread of mpg_init allocates, frees and copies while it runs; a caller that starts a GLOBAL-mode stream capture right
+// after mpg_init (hipStreamBeginCapture forbids such calls from other threads while it lasts) waits for it here first.
+int mpg_warmup_wait(void) {
+  warm_join();
+  return MPG_SUCCESS;
+}
+
 static void handle_free(mpg_handle_s *h);
 static void drop_parked(void *obj) {   // obj == nullptr: all of them
   for (auto it = g_cache.begin(); it != g_cache.end();) {

@@ -279,6 +279,10 @@ struct mpg_handle_s {
   int64_t store_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // which branches the Store took (mpg_handle_store_stats; [0] is store_path)
   int store_path = 0;       // candidate search of the Store: 0 hierarchical (pyramid walk / BVH), 1 the grid's index space, 2 index space + BVH for the rest
   bool localized = false;
+  // [first, end) of the source indices the handle references, in its CURRENT index space, once somebody has asked (the host-array
+  // Regrids ask on every call: mpg_hostpipe.hip); dropped whenever the indices are rewritten (rebase, localize, source windows)
+  bool src_range_valid = false;
+  int64_t src_range_first = 0, src_range_end = 0;
   // pole caps of a periodic (monopole) source grid: destination point pole_dst[q] adds pole_w[q] * mean of the
   // pole_len sources starting at pole_src0[q].  Dense over the candidate rows, pole_w == 0 where not in a cap.
   int64_t n_pole = 0;

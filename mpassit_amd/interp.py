@@ -219,6 +219,8 @@ class GraphedInterp:
         self.inp = inp
         interp_data(mesh, grid, target, inp, cfg)              # eager pass: kernel choices, tile lists, rotation angles
         torch.cuda.synchronize()
+        from ._lib import check, load
+        check(load().mpg_warmup_wait())                        # mpg_init's helper thread allocates and copies: done before a capture starts
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

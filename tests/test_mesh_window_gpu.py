@@ -180,3 +180,36 @@ def test_one_row_of_a_fine_polar_grid_under_a_coarse_mesh(gpu_lib):
             assert (want["bilinear"][0] >= 0).all() and want["conserve"][1].size > 0
             mesh.destroy()
             grid.destroy()
+
+
+def _banded(m):
+    """Cells AND vertices renumbered by latitude (then longitude): the spatially banded numbering windows rely on."""
+    from mpassit_amd import synth
+    pc = np.lexsort((m.lonCell, np.round(m.latCell, 3)))
+    pv = np.lexsort((m.lonVertex, np.round(m.latVertex, 3)))
+    inv = np.empty(m.nVertices + 1, np.int32)
+    inv[0] = 0
+    inv[pv + 1] = np.arange(1, m.nVertices + 1, dtype=np.int32)
+    return synth.MpasMesh(m.latCell[pc], m.lonCell[pc], m.latVertex[pv], m.lonVertex[pv], inv[m.verticesOnCell[pc]])
+
+
+@pytest.mark.parametrize("rows", [(0, 30), (30, 61), (61, 90)])
+def test_variable_resolution_mesh_with_coarse_cells_beside_the_grid(gpu_lib, rows):
+    """A 60-3 km style mesh (cells 16 times larger outside a cap than inside it), banded numbering, under a fine grid that
+    straddles the cap's edge: the margin is sized from the FINE cells the grid lies on, while the rows' id range also holds
+    coarse cells many margins wide.  The closure check measures such a cell's distance for real (it lies beyond the distance pass's
+    cap but can reach the grid) -- the weights of the cut mesh are those of the whole mesh, bit for bit."""
+    from mpassit_amd import regrid as R, synth, target_grid as tg
+    m = _banded(synth.variable_resolution_mesh(14000, lat0_deg=40.0, lon0_deg=-100.0, ratio=16.0, radius_deg=6.0, seed=5))
+    g = tg.define_target_grid_params("lambert", 151, 91, dx=12000.0, dy=12000.0, ref_lat=44.5, ref_lon=-100.0, truelat1=40.0, truelat2=40.0, stand_lon=-100.0)
+    grid = R.Grid.from_target(g, rows=rows)
+    whole = R.Mesh.from_mpas(m)
+    want = _weights(R, whole, grid)
+    whole.destroy()
+    mesh = R.Mesh.from_mpas(m, window_grid=grid)
+    c0, cn, v0, vn, margin = mesh.window_info()
+    _same(_weights(R, mesh, grid), want)
+    assert (want["bilinear"][0][:, 0] >= 0).all()                  # a global mesh: every point mapped
+    print("rows", rows, "window cells", cn, "of", m.nCells, "margin", margin)
+    mesh.destroy()
+    grid.destroy()
