@@ -135,34 +135,9 @@ __global__ __launch_bounds__(MODE == 3 ? 128 : CONS_COOP_NT) void k_conserve_ras
     }
     double qp = 2.0 * qe2 + 1e-9;
     if (ql[0] - qp > hi[0] || qh[0] + qp < lo[0] || ql[1] - qp > hi[1] || qh[1] + qp < lo[1] || ql[2] - qp > hi[2] || qh[2] + qp < lo[2]) return false;
-    const double aq = qarea[pc];   // signed area of the destination quad, computed once per grid (k_cell_areas)
-    if (!(fabs(aq) > 0.0)) return false;
-    // A SEPARATING SIDE (round 5).  Half of the pairs the boxes let through do not overlap at all (configuration 4: 2.2 of 4.3 per
-    // destination cell), and each of them cost the clip kernel a lane that emptied its polygon at some side while its wavefront
-    // went on (VALU lane use 0.49).  The clip cuts with the planes qa x (qb - qa) of the counter-clockwise quad; a pair whose
-    // polygon has EVERY vertex outside one of them -- by 1e-12 of the normal's length, a thousand times the clip's own tolerance
-    // -- leaves the clip with nothing whatever the earlier sides did (what they produce lies on arcs between those vertices: the
-    // same side of the plane, by at least the same margin), i.e. it never was an entry of the matrix.  Such a pair is not listed.
-    // The planes are the clip's own (same expressions, same orientation rule, collapsed sides skipped), the stored matrix is
-    // unchanged bit for bit; pairs within the margin still go to the clip.
-    {
-      const dv3 c1 = aq < 0.0 ? q[3] : q[1], c3 = aq < 0.0 ? q[1] : q[3];
-      const dv3 s0 = c1 - q[0], s1 = q[2] - c1, s2 = c3 - q[2], s3 = q[0] - c3;
-      const bool u0 = !(dot3(s0, s0) < 1e-24), u1 = !(dot3(s1, s1) < 1e-24), u2 = !(dot3(s2, s2) < 1e-24), u3 = !(dot3(s3, s3) < 1e-24);
-      const dv3 n0 = cross3(q[0], s0), n1 = cross3(c1, s1), n2 = cross3(q[2], s2), n3 = cross3(c3, s3);
-      const double m0 = 1e-24 * dot3(n0, n0), m1 = 1e-24 * dot3(n1, n1), m2 = 1e-24 * dot3(n2, n2), m3 = 1e-24 * dot3(n3, n3);
-      bool o0 = u0, o1 = u1, o2 = u2, o3 = u3;   // "every vertex so far is clearly outside side e"
-      for (int v = 0; v < n; ++v) {
-        const dv3 X = poly[v];
-        const double d0 = dot3(n0, X), d1 = dot3(n1, X), d2 = dot3(n2, X), d3 = dot3(n3, X);
-        o0 = o0 && d0 < 0.0 && d0 * d0 > m0;
-        o1 = o1 && d1 < 0.0 && d1 * d1 > m1;
-        o2 = o2 && d2 < 0.0 && d2 * d2 > m2;
-        o3 = o3 && d3 < 0.0 && d3 * d3 > m3;
-      }
-      if (o0 || o1 || o2 || o3) return false;
-    }
-    return true;
+    // (Round 5 tried a SEPARATING-SIDE test here -- a pair whose polygon lies wholly outside one side of the quad never becomes an
+    // entry -- to keep such pairs out of the clip: the boxes above already reject them; same-box A/B in profiles/r05_conserve_prefilter.md)
+    return fabs(qarea[pc]) > 0.0;   // signed area of the destination quad, computed once per grid (k_cell_areas)
   };
   // O(1) candidates on a projection-built grid (round 4; MODE 3 only): the polygon's corners in the grid's index space (vij:
   // the inverse projection of every vertex, k_target_grid.hip) bound the destination cells it can meet -- cell (i, j) covers
