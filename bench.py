@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--leg", default=None, choices=["job", "store"],
                     help="internal: run only this leg in THIS (fresh) process and print its JSON object -- the default run starts one "
                          "child process per leg so that its first-call numbers are first-in-process ones")
+    ap.add_argument("--ownership", default="auto", choices=["auto", "aligned", "para_range", "need"],
+                    help="N > 1: who owns which source cells -- aligned / para_range: the library's id blocks; need: every cell to the lowest rank whose "
+                         "rows reference it (meshes without banded numbering); auto: aligned when the numbering is banded, else need")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="kernel knob for experiments (mpg_tune), e.g. a3_staged=0; the default run sets none")
     return ap.parse_args()
@@ -191,10 +194,12 @@ def main():
     run_id = all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]
     id_file = "/dev/shm/mpassit_bench_%s.rcclid" % run_id   # fresh per run
     os.environ.setdefault("MPASSIT_RUN_ID", run_id)          # tags the id file of the C-ABI transport: several ranks without one are refused
-    sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file)
+    sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file,
+                             ownership=args.ownership if world > 1 else "aligned")
     P_local = sr.rh.n_dst
     io32 = args.io == "f32"
     c0, c1 = sr.sched.own
+    own_sel = sr.sched.owned_ids if sr.sched.mode == "owned" else slice(c0, c1)     # the cells this rank provides (an id list in the owned form)
     big_bundle = io32 and world == 1 and F * nlev * 8.0 * sr.sched.n_local > 40e9
     if big_bundle:
         # BASELINE configs[4] as written ("100+ 3-D fields" in ONE bundle, interp.F90:240-254): the float64 staging copies of the
@@ -219,7 +224,7 @@ def main():
         else:
             own = torch.empty((F, c1 - c0, nlev) if lev_fast else (F * nlev, c1 - c0), dtype=local.dtype, device=dev)
         gen = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
-        synth_fields_device(torch, m.latCell[c0:c1], m.lonCell[c0:c1], nlev, F, gen)
+        synth_fields_device(torch, m.latCell[own_sel], m.lonCell[own_sel], nlev, F, gen)
         own.copy_(gen.view(F, nlev, -1).permute(0, 2, 1) if lev_fast else gen)
         del gen
         src_for_kernel = local
@@ -229,7 +234,7 @@ def main():
             own = sr.own_view(local)
         else:
             own = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
-        synth_fields_device(torch, m.latCell[c0:c1], m.lonCell[c0:c1], nlev, F, own)
+        synth_fields_device(torch, m.latCell[own_sel], m.lonCell[own_sel], nlev, F, own)
         src_for_kernel = local
         if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
             src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()

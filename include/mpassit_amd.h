@@ -358,7 +358,16 @@ int mpg_comm_destroy(mpg_comm comm);
 int mpg_comm_info(mpg_comm comm, int *rank, int *nranks);
 int mpg_comm_allgather(mpg_comm comm, const void *send_host, int64_t nbytes, void *recv_host);
 int mpg_halo_build(mpg_comm comm, mpg_handle rh, int64_t n_cells_global, int ownership, mpg_halo *out);
-/* mode 0 range / 1 compact; own = the global id block [own[0], own[1]) this rank holds; base = global id of local index 0
+/* The same for a partition of the source cells that is the CALLER's (owned form): owned_ids_host = this rank's sorted unique global
+ * ids, any shape -- the model's own decomposition of a coupled run (MPAS partitions its cells with a graph partitioner, not in id
+ * blocks), or one that follows the target rows of a mesh without banded numbering: bench.py gives every cell to the lowest rank whose
+ * rows reference it, so that only the overlap of neighbouring row blocks travels (equal id blocks of a Morton-numbered global mesh
+ * would move 7/8 of all referenced values at 8 ranks).  The ranks' lists must be disjoint and cover every cell some rank references
+ * (else MPG_ERR_INVALID_ARG).  The handle is re-indexed to the rank's sorted needed ids (n_local of them, as in the compact form);
+ * mpg_halo_info reports mode 2 and own = {0, n_owned}; own_dev of mpg_halo_exchange_dev is [nrows][own_ld >= n_owned] in the order
+ * of owned_ids_host.  What a peer sends arrives in id order and is scattered to its positions among the needed ids. */
+int mpg_halo_build_owned(mpg_comm comm, mpg_handle rh, int64_t n_cells_global, const int32_t *owned_ids_host, int64_t n_owned, mpg_halo *out);
+/* mode 0 range / 1 compact / 2 owned; own = the global id block [own[0], own[1]) this rank holds; base = global id of local index 0
  * (range form); own_pos = where the own block sits in the local space (range form); sent / received per row = elements that
  * cross the links per exchanged row.  Any pointer may be NULL. */
 int mpg_halo_info(mpg_halo halo, int *mode, int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *sent_per_row,
@@ -397,6 +406,11 @@ int mpg_gather_rows(mpg_comm comm, const void *rows_dev, int64_t j0, int64_t j1,
 int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, const int64_t *n_needed, const int32_t *const *needed, int *mode,
                        int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *send_count, int64_t *send_a, int64_t *recv_a,
                        int64_t *recv_b, int32_t *send_ids_flat, int64_t send_ids_cap, int64_t *send_ids_off);
+/* the owned form's schedule as a pure function: per peer q (self included) send_flat[send_off[q] .. send_off[q + 1]) = offsets into
+ * `rank`'s owned list in the order sent, recv_flat[recv_off[q] ..) = destination positions in its local space in the order received */
+int mpg_halo_plan_owned_host(int rank, int nranks, const int64_t *n_needed, const int32_t *const *needed, const int64_t *n_owned,
+                             const int32_t *const *owned, int64_t *n_local, int32_t *send_flat, int64_t send_cap, int64_t *send_off, int32_t *recv_flat,
+                             int64_t recv_cap, int64_t *recv_off);
 
 /* kernel-selection knobs for benchmarking and the A/B tests (defaults are the tuned production values; DESIGN.md s4.1 has
  * the measurements behind every default).  They select among kernels that produce identical bits:

@@ -33,6 +33,27 @@ def plan_host(rank, needed_lists, n_cells, ownership="aligned"):
     return res
 
 
+def plan_owned_host(rank, needed_lists, owned_lists):
+    """mpg_halo_plan_owned_host: the owned-form schedule of `rank` as a pure function of every rank's sorted needed and owned ids
+    (no GPU).  -> dict(n_local, send_ids [per peer: offsets into the rank's owned list], recv_ids [per peer: positions in its local space])."""
+    world = len(needed_lists)
+    nl = [np.ascontiguousarray(x, np.int32) for x in needed_lists]
+    ol = [np.ascontiguousarray(x, np.int32) for x in owned_lists]
+    P32 = C.POINTER(C.c_int32)
+    n_needed = (C.c_int64 * world)(*[int(x.size) for x in nl])
+    n_owned = (C.c_int64 * world)(*[int(x.size) for x in ol])
+    np_ = (P32 * world)(*[x.ctypes.data_as(P32) for x in nl])
+    op_ = (P32 * world)(*[x.ctypes.data_as(P32) for x in ol])
+    cap_s, cap_r = int(ol[rank].size) * world + 1, int(nl[rank].size) + 1
+    sflat, rflat = np.empty(cap_s, np.int32), np.empty(cap_r, np.int32)
+    soff, roff = (C.c_int64 * (world + 1))(), (C.c_int64 * (world + 1))()
+    n_local = C.c_int64()
+    check(L.load().mpg_halo_plan_owned_host(C.c_int(rank), C.c_int(world), n_needed, np_, n_owned, op_, C.byref(n_local), sflat.ctypes.data_as(P32),
+                                            C.c_int64(cap_s), soff, rflat.ctypes.data_as(P32), C.c_int64(cap_r), roff))
+    return dict(n_local=n_local.value, send_ids=[sflat[soff[q]:soff[q + 1]].copy() for q in range(world)],
+                recv_ids=[rflat[roff[q]:roff[q + 1]].copy() for q in range(world)])
+
+
 class Comm:
     def __init__(self, rank=0, nranks=1, id_file=None, _handle=None):
         self._h = C.c_void_p()
@@ -84,14 +105,21 @@ class Comm:
 class Halo:
     """mpg_halo_build on a route handle (re-indexed in place to the local source space) + the exchange."""
 
-    def __init__(self, comm, rh, n_cells, ownership="aligned"):
+    def __init__(self, comm, rh, n_cells, ownership="aligned", owned_ids=None):
+        """owned_ids: this rank's sorted unique global cell ids -- the caller's own partition (mpg_halo_build_owned); else the library
+        partitions by `ownership` ("aligned" | "para_range")."""
         self._h = C.c_void_p()
-        check(L.load().mpg_halo_build(comm._h, rh._h, C.c_int64(n_cells), C.c_int(0 if ownership == "aligned" else 1), C.byref(self._h)))
+        if owned_ids is not None:
+            self.owned_ids = np.ascontiguousarray(owned_ids, np.int32)
+            check(L.load().mpg_halo_build_owned(comm._h, rh._h, C.c_int64(n_cells), self.owned_ids.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                C.c_int64(self.owned_ids.size), C.byref(self._h)))
+        else:
+            check(L.load().mpg_halo_build(comm._h, rh._h, C.c_int64(n_cells), C.c_int(0 if ownership == "aligned" else 1), C.byref(self._h)))
         rh._refresh()
         mode, n_local, base, sent, recv = C.c_int(), C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         own, own_pos = (C.c_int64 * 2)(), (C.c_int64 * 2)()
         check(L.load().mpg_halo_info(self._h, C.byref(mode), C.byref(n_local), own, C.byref(base), own_pos, C.byref(sent), C.byref(recv)))
-        self.mode, self.n_local, self.base = ("range", "compact")[mode.value], n_local.value, base.value
+        self.mode, self.n_local, self.base = ("range", "compact", "owned")[mode.value], n_local.value, base.value
         self.own, self.own_pos, self.sent_per_row, self.received_per_row = (own[0], own[1]), (own_pos[0], own_pos[1]), sent.value, recv.value
 
     def exchange(self, own_rows, local_rows, stream=None):

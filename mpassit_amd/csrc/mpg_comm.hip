@@ -127,13 +127,14 @@ struct mpg_comm_s {
 
 // ---- the schedule (pure host logic; mirrors dist.HaloSchedule.build) ------------------------------------------------------
 struct HaloPlan {
-  int rank = 0, nranks = 1, mode = 0;       // mode 0: range, 1: compact
+  int rank = 0, nranks = 1, mode = 0;       // mode 0: range, 1: compact, 2: owned (the caller's own partition of the cells)
   int64_t n_local = 0, own0 = 0, own1 = 0, base = 0, own_pos0 = 0, own_pos1 = 0;
   std::vector<int64_t> send_a, send_b;      // range: per peer, offsets [a, b) inside the own block
-  std::vector<std::vector<int32_t>> send_ids;   // compact: per peer (self included), offsets inside the own block
-  std::vector<int64_t> recv_a, recv_b;      // per peer: destination range in the local index space
+  std::vector<std::vector<int32_t>> send_ids;   // compact / owned: per peer (self included), offsets inside the own block / owned list
+  std::vector<int64_t> recv_a, recv_b;      // range / compact: per peer, destination range in the local index space
+  std::vector<std::vector<int32_t>> recv_ids;   // owned: per peer (self included), destination positions in the local index space
   int64_t send_count(int q) const { return mode == 0 ? send_b[q] - send_a[q] : (int64_t)send_ids[q].size(); }
-  int64_t recv_count(int q) const { return recv_b[q] - recv_a[q]; }
+  int64_t recv_count(int q) const { return mode == 2 ? (int64_t)recv_ids[q].size() : recv_b[q] - recv_a[q]; }
 };
 
 static void para_block(int64_t n, int world, int r, int64_t *a, int64_t *b) {   // model_grid.F90:2428-2441, 0-based half-open
@@ -241,9 +242,45 @@ static void plan_compact(HaloPlan &p, const std::vector<std::pair<int64_t, int64
   }
 }
 
+// owned mode (round 5): the cells are partitioned by the CALLER -- owned[q] = rank q's sorted ids, disjoint, any shape: the model's own
+// decomposition of a coupled run, or a partition that follows the target rows of a mesh without banded numbering (bench.py gives every
+// cell to the lowest rank that references it: only the overlap of neighbouring row blocks then travels, where equal id blocks of a
+// Morton-numbered mesh send 7/8 of everything at 8 ranks).  Local space = the rank's sorted needed ids (as in compact mode); what a
+// peer sends are its owned cells among them, in id order on both sides.  -> the first needed id that nobody owns, or -1
+static int64_t plan_owned(HaloPlan &p, const int64_t *n_needed, const int32_t *const *needed, const int64_t *n_owned, const int32_t *const *owned) {
+  const int world = p.nranks, rank = p.rank;
+  p.mode = 2;
+  p.own0 = 0; p.own1 = n_owned[rank]; p.base = 0; p.n_local = n_needed[rank]; p.own_pos0 = p.own_pos1 = 0;
+  p.send_ids.assign(world, {});
+  p.recv_ids.assign(world, {});
+  const int32_t *mine = needed[rank], *mown = owned[rank];
+  std::vector<char> found((size_t)n_needed[rank], 0);
+  for (int q = 0; q < world; ++q) {
+    // what q needs of my cells: needed[q] ^ owned[rank], as offsets into my owned list
+    const int32_t *a = needed[q], *ae = a + n_needed[q], *b = mown, *be = mown + n_owned[rank];
+    while (a < ae && b < be) {
+      if (*a < *b) ++a;
+      else if (*b < *a) ++b;
+      else { p.send_ids[q].push_back((int32_t)(b - mown)); ++a; ++b; }
+    }
+    // what I need of q's cells: needed[rank] ^ owned[q], as positions in my local space
+    a = mine; ae = mine + n_needed[rank]; b = owned[q]; be = b + n_owned[q];
+    while (a < ae && b < be) {
+      if (*a < *b) ++a;
+      else if (*b < *a) ++b;
+      else { p.recv_ids[q].push_back((int32_t)(a - mine)); found[(size_t)(a - mine)] = 1; ++a; ++b; }
+    }
+  }
+  for (int64_t i = 0; i < n_needed[rank]; ++i)
+    if (!found[(size_t)i]) return mine[i];
+  return -1;
+}
+
 struct mpg_halo_s {
   mpg_comm_s *comm = nullptr;
   HaloPlan plan;
+  DevBuf<int32_t> recv_ids_dev;             // owned: all peers' destination positions back to back
+  std::vector<int64_t> rids_off;
   std::vector<int64_t> soff, roff;          // per peer element offsets (per row) inside the packed buffers
   int64_t stot = 0, rtot = 0;
   DevBuf<int32_t> send_ids_dev;             // compact: all peers' offset lists back to back
@@ -284,6 +321,25 @@ static int pack_ids(const void *src, int64_t ld, int nrows, int elem_bytes, cons
     const int ew = elem_bytes / 4;
     k_pack_ids_w<<<(unsigned)((n * ew + 255) / 256), 256, 0, s>>>((const uint32_t *)src, ld, nrows, ids, n, ew, (uint32_t *)dst);
   }
+  MPG_HIP(hipGetLastError());
+  return MPG_SUCCESS;
+}
+
+// the inverse of the pack: dst[k * ld + pos[i]] = src[k][i], elements of `ew` 4-byte words (owned mode's unpack: a peer's cells sit
+// anywhere among the rank's sorted needed ids)
+__global__ __launch_bounds__(256) void k_unpack_ids_w(const uint32_t *__restrict__ src, int64_t n, int nrows, const int32_t *__restrict__ pos, int64_t ld, int ew,
+                                                      uint32_t *__restrict__ dst) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= n * ew) return;
+  const int64_t i = t / ew;
+  const int w = (int)(t - i * ew);
+  const int64_t c = pos[i];
+  for (int k = 0; k < nrows; ++k) dst[((int64_t)k * ld + c) * ew + w] = src[((int64_t)k * n + i) * ew + w];
+}
+static int unpack_ids(const void *src, int64_t n, int nrows, int elem_bytes, const int32_t *pos, int64_t ld, void *dst, hipStream_t s) {
+  if (n <= 0 || nrows <= 0) return MPG_SUCCESS;
+  const int ew = elem_bytes / 4;
+  k_unpack_ids_w<<<(unsigned)((n * ew + 255) / 256), 256, 0, s>>>((const uint32_t *)src, n, nrows, pos, ld, ew, (uint32_t *)dst);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -747,6 +803,79 @@ int mpg_halo_plan_host(int rank, int nranks, int64_t n_cells, int ownership, con
   return MPG_SUCCESS;
 }
 
+// The owned-mode schedule as a pure function (tests, diagnostics): needed[q] / owned[q] = rank q's sorted unique ids.  Outputs for
+// `rank`: n_local; per peer (self included) send_off[q] .. send_off[q + 1] into send_flat = offsets into the rank's owned list, in the
+// order sent; recv_off / recv_flat = destination positions in its local space, in the order received.  Returns MPG_ERR_INVALID_ARG
+// when a needed cell is owned by nobody.
+int mpg_halo_plan_owned_host(int rank, int nranks, const int64_t *n_needed, const int32_t *const *needed, const int64_t *n_owned,
+                             const int32_t *const *owned, int64_t *n_local, int32_t *send_flat, int64_t send_cap, int64_t *send_off, int32_t *recv_flat,
+                             int64_t recv_cap, int64_t *recv_off) {
+  MPG_ARG(nranks >= 1 && rank >= 0 && rank < nranks && n_needed && needed && n_owned && owned && send_off && recv_off, "mpg_halo_plan_owned_host: bad argument");
+  HaloPlan p;
+  p.rank = rank;
+  p.nranks = nranks;
+  const int64_t orphan = plan_owned(p, n_needed, needed, n_owned, owned);
+  if (orphan >= 0) {
+    mpg_set_error("mpg_halo_plan_owned_host: rank %d needs cell %lld, which no rank owns", rank, (long long)orphan);
+    return MPG_ERR_INVALID_ARG;
+  }
+  if (n_local) *n_local = p.n_local;
+  int64_t so = 0, ro = 0;
+  for (int q = 0; q < nranks; ++q) {
+    send_off[q] = so;
+    recv_off[q] = ro;
+    MPG_ARG(so + (int64_t)p.send_ids[q].size() <= send_cap && ro + (int64_t)p.recv_ids[q].size() <= recv_cap, "mpg_halo_plan_owned_host: output too small");
+    if (send_flat) std::copy(p.send_ids[q].begin(), p.send_ids[q].end(), send_flat + so);
+    if (recv_flat) std::copy(p.recv_ids[q].begin(), p.recv_ids[q].end(), recv_flat + ro);
+    so += (int64_t)p.send_ids[q].size();
+    ro += (int64_t)p.recv_ids[q].size();
+  }
+  send_off[nranks] = so;
+  recv_off[nranks] = ro;
+  return MPG_SUCCESS;
+}
+
+// the common end of the two builds: the handle leaves the Store cache and is re-indexed in place (as mpg_handle_rebase /
+// mpg_handle_localize do), the packed buffers' offsets are laid out, the index lists go to the device.  Frees H on failure.
+static int halo_finish(mpg_halo_s *H, mpg_handle_s *h, std::vector<int32_t> &ids, hipStream_t s) {
+  HaloPlan &p = H->plan;
+  const int world = p.nranks;
+  int rc;
+  mpg_cache_detach(h);
+  h->free_tile_lists();
+  h->lf_choice = h->cf_choice = 0;
+  if (p.mode == 0) rc = mpg_k_rebase(h, p.base, p.n_local, s);
+  else rc = mpg_k_unique_sources(h, ids, true, s);
+  if (rc) { delete H; return rc; }
+  H->soff.assign(world + 1, 0);
+  H->roff.assign(world + 1, 0);
+  H->ids_off.assign(world + 1, 0);
+  H->rids_off.assign(world + 1, 0);
+  for (int q = 0; q < world; ++q) {
+    H->soff[q + 1] = H->soff[q] + p.send_count(q);
+    H->roff[q + 1] = H->roff[q] + p.recv_count(q);
+    H->ids_off[q + 1] = H->ids_off[q] + (p.mode >= 1 ? (int64_t)p.send_ids[q].size() : 0);
+    H->rids_off[q + 1] = H->rids_off[q] + (p.mode == 2 ? (int64_t)p.recv_ids[q].size() : 0);
+  }
+  H->stot = H->soff[world];
+  H->rtot = H->roff[world];
+  auto upload = [&](DevBuf<int32_t> &dev, const std::vector<std::vector<int32_t>> &lists, const std::vector<int64_t> &off) -> int {
+    if (off[world] == 0) return MPG_SUCCESS;
+    int r = dev.alloc((size_t)off[world]);
+    if (r) return r;
+    for (int q = 0; q < world; ++q)
+      if (!lists[q].empty())
+        if (hipMemcpy(dev.p + off[q], lists[q].data(), sizeof(int32_t) * lists[q].size(), hipMemcpyHostToDevice) != hipSuccess) {
+          mpg_set_error("mpg_halo_build: uploading the index lists failed");
+          return MPG_ERR_HIP;
+        }
+    return MPG_SUCCESS;
+  };
+  if (p.mode >= 1 && (rc = upload(H->send_ids_dev, p.send_ids, H->ids_off))) { mpg_halo_destroy(H); return rc; }
+  if (p.mode == 2 && (rc = upload(H->recv_ids_dev, p.recv_ids, H->rids_off))) { mpg_halo_destroy(H); return rc; }
+  return MPG_SUCCESS;
+}
+
 int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg_halo *out) {
   MPG_CHECK_INIT();
   MPG_ARG(c && h && out && n_cells > 0 && n_cells < 0x7fffffff, "mpg_halo_build: bad argument");
@@ -802,36 +931,102 @@ int mpg_halo_build(mpg_comm c, mpg_handle h, int64_t n_cells, int ownership, mpg
     for (int q = 0; q < world; ++q) lists[q] = all.data() + (size_t)q * padded.size();
     plan_compact(p, blocks, counts.data(), lists.data());
   }
-  // detach from the Store cache and re-index in place, as mpg_handle_rebase / mpg_handle_localize do
-  mpg_cache_detach(h);
-  h->free_tile_lists();
-  h->lf_choice = h->cf_choice = 0;
-  if (p.mode == 0) rc = mpg_k_rebase(h, p.base, p.n_local, s);
-  else rc = mpg_k_unique_sources(h, ids, true, s);
-  if (rc) { delete H; return rc; }
-  H->soff.assign(world + 1, 0);
-  H->roff.assign(world + 1, 0);
-  H->ids_off.assign(world + 1, 0);
-  for (int q = 0; q < world; ++q) {
-    H->soff[q + 1] = H->soff[q] + p.send_count(q);
-    H->roff[q + 1] = H->roff[q] + p.recv_count(q);
-    H->ids_off[q + 1] = H->ids_off[q] + (p.mode == 1 ? (int64_t)p.send_ids[q].size() : 0);
-  }
-  H->stot = H->soff[world];
-  H->rtot = H->roff[world];
-  if (p.mode == 1 && H->ids_off[world] > 0) {
-    if ((rc = H->send_ids_dev.alloc((size_t)H->ids_off[world]))) { mpg_halo_destroy(H); return rc; }
-    for (int q = 0; q < world; ++q)
-      if (!p.send_ids[q].empty())
-        if (hipMemcpy(H->send_ids_dev.p + H->ids_off[q], p.send_ids[q].data(), sizeof(int32_t) * p.send_ids[q].size(), hipMemcpyHostToDevice) != hipSuccess) {
-          mpg_set_error("mpg_halo_build: uploading the send lists failed");
-          mpg_halo_destroy(H);
-          return MPG_ERR_HIP;
-        }
-  }
+  rc = halo_finish(H, h, ids, s);
+  if (rc) return rc;
   *out = H;
   return MPG_SUCCESS;
 }
+
+// The caller's own partition of the source cells (owned mode): owned_ids_host = this rank's sorted unique ids (any shape; the ranks'
+// lists must be disjoint, and every cell some rank's rows reference must be in one of them).
+int mpg_halo_build_owned(mpg_comm c, mpg_handle h, int64_t n_cells, const int32_t *owned_ids_host, int64_t n_owned, mpg_halo *out) {
+  MPG_CHECK_INIT();
+  MPG_ARG(c && h && out && n_cells > 0 && n_cells < 0x7fffffff && n_owned >= 0 && (owned_ids_host || n_owned == 0), "mpg_halo_build_owned: bad argument");
+  MPG_ARG(!h->localized && h->n_pole == 0, "mpg_halo_build_owned: the handle was re-indexed already, or carries pole terms");
+  MPG_ARG(h->refcount <= 1, "mpg_halo_build_owned: the handle is shared; re-indexing it in place would corrupt the other holder's indices");
+  MPG_ARG(!mpg_handle_is_windowed(h), "mpg_halo_build_owned: the handle's mesh has a source window; reset the window first");
+  for (int64_t i = 0; i < n_owned; ++i)
+    MPG_ARG(owned_ids_host[i] >= 0 && owned_ids_host[i] < n_cells && (i == 0 || owned_ids_host[i] > owned_ids_host[i - 1]),
+            "mpg_halo_build_owned: owned_ids must be sorted, unique and within [0, n_cells)");
+  hipStream_t s = mpg_setup_stream();
+  std::unique_lock<std::mutex> work;
+  if (c->is_virtual) work = std::unique_lock<std::mutex>(c->vg->work_mu);
+  auto allgather = [&](const void *snd, int64_t nb, void *rcv) {
+    if (work.owns_lock()) work.unlock();
+    const int r = mpg_comm_allgather(c, snd, nb, rcv);
+    if (c->is_virtual) work.lock();
+    return r;
+  };
+  std::vector<int32_t> ids;
+  int rc = mpg_k_unique_sources(h, ids, false, s);
+  if (rc) return rc;
+  const int world = c->nranks, rank = c->rank;
+  int64_t mine[2] = {(int64_t)ids.size(), n_owned};
+  std::vector<int64_t> cnt(2 * (size_t)world);
+  if (world > 1) {
+    if ((rc = allgather(mine, sizeof(mine), cnt.data()))) return rc;
+  } else {
+    cnt[0] = mine[0];
+    cnt[1] = mine[1];
+  }
+  int64_t mxn = 1, mxo = 1;
+  std::vector<int64_t> n_needed(world), n_own(world);
+  for (int q = 0; q < world; ++q) {
+    n_needed[q] = cnt[2 * q];
+    n_own[q] = cnt[2 * q + 1];
+    mxn = std::max(mxn, n_needed[q]);
+    mxo = std::max(mxo, n_own[q]);
+  }
+  // every rank's needed and owned lists travel once (one all-gather of both, padded to the longest)
+  const size_t stride = (size_t)(mxn + mxo);
+  std::vector<int32_t> padded(stride, 0x7fffffff), all(stride * world);
+  std::copy(ids.begin(), ids.end(), padded.begin());
+  std::copy(owned_ids_host, owned_ids_host + n_owned, padded.begin() + mxn);
+  if (world > 1) {
+    if ((rc = allgather(padded.data(), (int64_t)stride * 4, all.data()))) return rc;
+  } else {
+    all = padded;
+  }
+  std::vector<const int32_t *> nl(world), ol(world);
+  for (int q = 0; q < world; ++q) {
+    nl[q] = all.data() + (size_t)q * stride;
+    ol[q] = nl[q] + mxn;
+  }
+  {   // the partition must be one: no cell owned twice
+    std::vector<int64_t> at(world, 0);
+    int32_t last = -1;
+    for (;;) {
+      int best = -1;
+      for (int q = 0; q < world; ++q)
+        if (at[q] < n_own[q] && (best < 0 || ol[q][at[q]] < ol[best][at[best]])) best = q;
+      if (best < 0) break;
+      const int32_t v = ol[best][at[best]++];
+      if (v == last) {
+        mpg_set_error("mpg_halo_build_owned: cell %d is owned by more than one rank", v);
+        return MPG_ERR_INVALID_ARG;
+      }
+      last = v;
+    }
+  }
+  mpg_halo_s *H = new mpg_halo_s();
+  H->comm = c;
+  HaloPlan &p = H->plan;
+  p.rank = rank;
+  p.nranks = world;
+  const int64_t orphan = plan_owned(p, n_needed.data(), nl.data(), n_own.data(), ol.data());
+  if (orphan >= 0) {
+    mpg_set_error("mpg_halo_build_owned: rank %d's rows reference cell %lld, which no rank owns", rank, (long long)orphan);
+    delete H;
+    return MPG_ERR_INVALID_ARG;
+  }
+  rc = halo_finish(H, h, ids, s);
+  if (rc) return rc;
+  *out = H;
+  return MPG_SUCCESS;
+}
+
+// this rank's sorted owned ids as the schedule holds them are the caller's own; what it needs back: nothing.  (mpg_halo_info reports
+// mode 2, own = {0, n_owned}: own_dev of mpg_halo_exchange_dev is [nrows][own_ld >= n_owned] in the order of owned_ids.)
 
 int mpg_halo_info(mpg_halo H, int *mode, int64_t *n_local, int64_t *own, int64_t *base, int64_t *own_pos, int64_t *sent_per_row,
                   int64_t *received_per_row) {
@@ -842,14 +1037,15 @@ int mpg_halo_info(mpg_halo H, int *mode, int64_t *n_local, int64_t *own, int64_t
   if (own) { own[0] = p.own0; own[1] = p.own1; }
   if (base) *base = p.base;
   if (own_pos) { own_pos[0] = p.own_pos0; own_pos[1] = p.own_pos1; }
-  if (sent_per_row) *sent_per_row = H->stot - (p.mode == 1 ? p.send_count(p.rank) : 0);
-  if (received_per_row) *received_per_row = H->rtot - (p.mode == 1 ? p.recv_count(p.rank) : 0);
+  if (sent_per_row) *sent_per_row = H->stot - (p.mode >= 1 ? p.send_count(p.rank) : 0);
+  if (received_per_row) *received_per_row = H->rtot - (p.mode >= 1 ? p.recv_count(p.rank) : 0);
   return MPG_SUCCESS;
 }
 
 int mpg_halo_destroy(mpg_halo H) {
   if (!H) return MPG_SUCCESS;
   H->send_ids_dev.free();
+  H->recv_ids_dev.free();
   H->sendbuf.free();
   H->recvbuf.free();
   delete H;
@@ -919,6 +1115,11 @@ int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void 
     const int64_t n = p.recv_count(q);
     if (!n) continue;
     const char *src = q == rank ? H->sendbuf.p + (size_t)nrows * es * (size_t)H->soff[q] : H->recvbuf.p + (size_t)nrows * es * (size_t)H->roff[q];
+    if (p.mode == 2) {   // a peer's cells sit anywhere among the sorted needed ids: scattered by position
+      const int rc = unpack_ids(src, n, nrows, elem_bytes, H->recv_ids_dev.p + H->rids_off[q], (int64_t)n_local, local_dev, s);
+      if (rc) return rc;
+      continue;
+    }
     MPG_HIP(hipMemcpy2DAsync((char *)local_dev + (size_t)p.recv_a[q] * es, n_local * es, src, (size_t)n * es, (size_t)n * es, (size_t)nrows,
                              hipMemcpyDeviceToDevice, s));
   }

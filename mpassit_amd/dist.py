@@ -48,13 +48,14 @@ class HaloSchedule:
     device-agnostic (CPU tensors under gloo, CUDA tensors under nccl)."""
     rank: int
     world: int
-    mode: str                      # "range" | "compact"
+    mode: str                      # "range" | "compact" | "owned"
     n_local: int                   # length of the local source index space
     own: tuple                     # global [c0, c1) owned by this rank
     base: int = 0                  # range mode: global id of local index 0
     send_ids: list = field(default_factory=list)   # per peer: owned-slab offsets to send (np.int32) or (a, b) range
     recv_pos: list = field(default_factory=list)   # per peer: (a, b) destination range in the local index space
     own_pos: tuple = (0, 0)        # range mode: where the own block sits in the local index space
+    owned_ids: object = None       # owned mode: this rank's sorted global cell ids (its rows of `own_rows`, in this order)
     _plans: dict = field(default_factory=dict, repr=False)   # (rows, dtype, device) -> preallocated exchange buffers
 
     @staticmethod
@@ -125,11 +126,46 @@ class HaloSchedule:
             s.recv_pos.append((a, b))
         return s
 
+    @staticmethod
+    def build_owned(needed_ids, owned_ids, rank, world, all_gather_object):
+        """The caller's own partition of the source cells (mpg_halo_build_owned): owned_ids = this rank's sorted unique global ids, any
+        shape -- a coupled model's decomposition, or `owned_by_need` below.  Local space = the sorted needed ids (as in compact mode); a
+        peer's cells arrive in id order and are scattered to their positions among them."""
+        needed_ids, owned_ids = np.asarray(needed_ids, np.int32), np.asarray(owned_ids, np.int32)
+        lists = all_gather_object((needed_ids, owned_ids))
+        s = HaloSchedule(rank, world, "owned", int(needed_ids.size), (0, int(owned_ids.size)))
+        s.owned_ids = owned_ids
+        seen = np.zeros(needed_ids.size, bool)
+        for q in range(world):
+            their_needed, their_owned = lists[q]
+            s.send_ids.append(np.searchsorted(owned_ids, np.intersect1d(their_needed, owned_ids, assume_unique=True)).astype(np.int32))
+            pos = np.searchsorted(needed_ids, np.intersect1d(needed_ids, their_owned, assume_unique=True)).astype(np.int32)
+            s.recv_pos.append(pos)
+            seen[pos] = True
+        if not seen.all():
+            raise ValueError("rank %d's rows reference cell %d, which no rank owns" % (rank, int(needed_ids[~seen][0])))
+        return s
+
+    @staticmethod
+    def owned_by_need(needed_ids, rank, world, all_gather_object):
+        """A partition that follows the target rows whatever the cell numbering: every referenced cell belongs to the LOWEST rank whose rows
+        reference it (cells nobody references belong to nobody).  What then travels is only what neighbouring row blocks share -- the
+        `aligned` ownership of the range form, for meshes without banded numbering (a Morton-numbered global mesh in equal id blocks sends
+        (N - 1) / N of every referenced value)."""
+        needed_ids = np.asarray(needed_ids, np.int32)
+        lists = all_gather_object(needed_ids)
+        mine = needed_ids
+        for q in range(rank):
+            mine = np.setdiff1d(mine, lists[q], assume_unique=True)
+        return mine.astype(np.int32)
+
     def counts(self):
         if self.mode == "range":
             send = [b - a for a, b in self.send_ids]
         else:
             send = [int(x.size) for x in self.send_ids]
+        if self.mode == "owned":
+            return send, [int(x.size) for x in self.recv_pos]
         recv = [b - a for a, b in self.recv_pos]
         return send, recv
 
@@ -171,7 +207,10 @@ class HaloSchedule:
         for q in range(self.world):
             n = recv_n[q]
             if n:
-                p.recv_views.append((shaped(p.recvbuf, off, n), self.recv_pos[q]))
+                where = self.recv_pos[q]
+                if self.mode == "owned":      # positions among the needed ids, as an index tensor for the scatter
+                    where = torch.as_tensor(where, dtype=torch.long, device=like.device)
+                p.recv_views.append((shaped(p.recvbuf, off, n), where))
                 off += R * L * n
         p.host_send = p.host_recv = None
         p.bytes_sent = p.sendbuf.numel() * p.sendbuf.element_size()
@@ -208,8 +247,11 @@ class HaloSchedule:
                 dist.all_to_all_single(p.recvbuf, p.sendbuf, p.in_splits, p.out_splits)
         else:
             p.recvbuf.copy_(p.sendbuf)
-        for view, (a, b) in p.recv_views:
-            local_rows[:, a:b].copy_(view)
+        for view, where in p.recv_views:
+            if self.mode == "owned":
+                local_rows.index_copy_(1, where, view)
+            else:
+                local_rows[:, where[0]:where[1]].copy_(view)
         return local_rows
 
 
@@ -222,7 +264,9 @@ class ShardedRegrid:
     """Rank-local piece of a row-sharded Mesh -> Grid regrid on this rank's GPU."""
 
     def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object, ownership="aligned", transport="torch", id_file=None):
-        """transport "torch": schedule and exchange through torch.distributed (RCCL under the nccl backend, gloo in the CPU
+        """ownership: "aligned" / "para_range" (the library's id-block partitions), "need" (every cell to the lowest rank whose rows reference it:
+        a caller-defined partition, the owned halo form), "auto" (aligned when every rank's needed ids are banded, else need).
+        transport "torch": schedule and exchange through torch.distributed (RCCL under the nccl backend, gloo in the CPU
         tests).  transport "cabi": the C-ABI's own verbs (mpg_comm_init / mpg_halo_build / mpg_halo_exchange_dev: librccl
         directly, what a C or Fortran host uses); the ranks meet through `id_file`."""
         from . import regrid as R
@@ -237,8 +281,19 @@ class ShardedRegrid:
         needed = self.rh.unique_sources()
         self.n_needed = int(needed.size)
         self._ids_dev = {}
+        if ownership == "auto":     # banded numbering on every rank: the range form with aligned blocks; else the partition that follows the rows
+            nlo, nhi = (int(needed[0]), int(needed[-1]) + 1) if needed.size else (0, 0)
+            banded = all_gather_object(bool(needed.size == 0 or (nhi - nlo) <= 1.25 * needed.size))
+            ownership = "aligned" if all(banded) else "need"
+        owned = None
+        if ownership == "need":     # every cell to the lowest rank that references it: the caller-defined partition that follows the rows
+            owned = HaloSchedule.owned_by_need(needed, rank, world, all_gather_object)
         if transport == "cabi":
-            self.sched = CabiSchedule(self.rh, mpas_mesh.nCells, rank, world, id_file, ownership)
+            self.sched = CabiSchedule(self.rh, mpas_mesh.nCells, rank, world, id_file, ownership, owned_ids=owned)
+            return
+        if owned is not None:
+            self.sched = HaloSchedule.build_owned(needed, owned, rank, world, all_gather_object)
+            self.rh.localize()
             return
         self.sched = HaloSchedule.build(needed, mpas_mesh.nCells, rank, world, all_gather_object, ownership=ownership)
         if self.sched.mode == "range":
@@ -302,12 +357,13 @@ class CabiSchedule:
     class _Bytes:
         bytes_sent = bytes_received = 0
 
-    def __init__(self, rh, n_cells, rank, world, id_file, ownership):
+    def __init__(self, rh, n_cells, rank, world, id_file, ownership, owned_ids=None):
         from . import comm as MC
         self.comm = MC.Comm(rank, world, id_file)
-        self.halo = MC.Halo(self.comm, rh, n_cells, ownership)
+        self.halo = MC.Halo(self.comm, rh, n_cells, ownership, owned_ids=owned_ids)
         self.rank, self.world, self.mode = rank, world, self.halo.mode
         self.n_local, self.own, self.base, self.own_pos = self.halo.n_local, self.halo.own, self.halo.base, self.halo.own_pos
+        self.owned_ids = owned_ids
 
     def exchange(self, own_rows, local_rows, pack_fn=None):
         return self.halo.exchange(own_rows, local_rows)

@@ -70,6 +70,70 @@ def test_c_schedule_equals_the_torch_distributed_one(ownership):
                     assert np.array_equal(got["send_ids"][q], s.send_ids[q]), what + (q,)
 
 
+def _lockstep(world, fn):
+    """fn(rank, all_gather_object) for every rank in lock-step threads."""
+    barrier = threading.Barrier(world)
+    slots, out = [None] * world, [None] * world
+
+    def run(rank):
+        def gather(obj):
+            slots[rank] = obj
+            barrier.wait()
+            res = list(slots)
+            barrier.wait()
+            return res
+        try:
+            out[rank] = fn(rank, gather)
+        except Exception as e:      # noqa: BLE001 -- handed to the caller (a rank that fails AFTER its collectives must not strand the others)
+            out[rank] = e
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return out
+
+
+@pytest.mark.parametrize("partition", ["need", "random"])
+def test_owned_form_c_schedule_equals_the_torch_distributed_one(partition):
+    """Round 5: the caller's own partition of the cells (mpg_halo_build_owned).  `need`: every cell to the lowest rank that references it
+    (dist.HaloSchedule.owned_by_need); `random`: an arbitrary assignment, as a coupled model's graph partition would look to this
+    library.  C plan == Python plan, world 2 / 3 / 5; the schedules of two ranks agree (what r sends q is what q expects from r, in
+    the same order); a cell nobody owns is refused by both."""
+    from mpassit_amd import _lib, comm, dist
+    rng = np.random.default_rng(11)
+    n = 5000
+    for world in (2, 3, 5):
+        needed = [np.sort(rng.choice(n, 900, replace=False)).astype(np.int32) for _ in range(world)]
+        if partition == "need":
+            owned = _lockstep(world, lambda r, ag: dist.HaloSchedule.owned_by_need(needed[r], r, world, ag))
+            assert sum(o.size for o in owned) == np.unique(np.concatenate(needed)).size              # every referenced cell exactly once
+        else:
+            owner = rng.integers(0, world, n)
+            owned = [np.nonzero(owner == r)[0].astype(np.int32) for r in range(world)]
+        py = _lockstep(world, lambda r, ag: dist.HaloSchedule.build_owned(needed[r], owned[r], r, world, ag))
+        cs = [comm.plan_owned_host(r, needed, owned) for r in range(world)]
+        for r in range(world):
+            assert cs[r]["n_local"] == py[r].n_local == needed[r].size
+            for q in range(world):
+                assert np.array_equal(cs[r]["send_ids"][q], py[r].send_ids[q]) and np.array_equal(cs[r]["recv_ids"][q], py[r].recv_pos[q]), (world, r, q)
+                # the two sides of one transfer name the same cells in the same order
+                assert np.array_equal(owned[r][cs[r]["send_ids"][q]], needed[q][cs[q]["recv_ids"][r]]), (world, r, q)
+            got = np.sort(np.concatenate(cs[r]["recv_ids"]))
+            assert np.array_equal(got, np.arange(needed[r].size))                                       # every needed cell arrives exactly once
+        if partition == "need":                                                                        # traffic: only what row blocks share
+            sent = sum(cs[r]["send_ids"][q].size for r in range(world) for q in range(world) if q != r)
+            assert sent == sum(x.size for x in needed) - np.unique(np.concatenate(needed)).size
+    # a referenced cell that nobody owns
+    needed = [np.array([1, 5, 9], np.int32), np.array([2, 5], np.int32)]
+    owned = [np.array([1, 5], np.int32), np.array([2], np.int32)]
+    with pytest.raises(_lib.MpgError, match="no rank owns"):
+        comm.plan_owned_host(0, needed, owned)
+    res = _lockstep(2, lambda r, ag: dist.HaloSchedule.build_owned(needed[r], owned[r], r, 2, ag))
+    assert isinstance(res[0], ValueError) and "no rank owns" in str(res[0]) and res[1].n_local == 2
+    assert comm.plan_owned_host(1, needed, owned)["n_local"] == 2
+
+
 # ---- the id-file acceptance rule of mpg_comm_init (pure host logic, no GPU, no RCCL) --------------------------------------
 def _idfile(magic=b"MPGRCCL2", tag=0, written_ns=0, nranks=2, size=None):
     import struct

@@ -161,6 +161,72 @@ def test_file_order_float32_halo(world, shuffle):
     assert all(r[2] % (5 * 4) == 0 for r in res)        # whole rows of 5 float32 levels travel
 
 
+def _worker_owned(rank, world, port, q):
+    """Round 5, the owned halo form on a mesh WITHOUT banded numbering: every cell belongs to the lowest rank whose rows reference it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=90))
+    try:
+        from mpassit_amd import dist as mdist, synth, target_grid as tg
+        from oracle import oracle as o
+        g = tg.define_target_grid_params("lambert", 61, 41, dx=60000.0, dy=60000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5,
+                                         truelat2=38.5, stand_lon=-97.5)
+        m = synth.regional_mesh_for_lambert(g.proj, 61, 41, 4000)
+        perm = np.random.default_rng(7).permutation(m.nCells)
+        cxyz, _ = mesh_xyz(o, m)
+        tri, _ = o.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(m.nCells)
+        j0, j1 = mdist.row_block(g.ny, world, rank)
+        idx, w = o.bilinear_weights(cxyz, tri, o.lonlat_deg_to_xyz(g.lon[j0:j1], g.lat[j0:j1]))
+        idx = np.where(idx >= 0, inv[np.maximum(idx, 0)], -1).astype(np.int32)
+        needed = np.unique(idx[idx >= 0])
+
+        def ago(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        owned = mdist.HaloSchedule.owned_by_need(needed, rank, world, ago)
+        sched = mdist.HaloSchedule.build_owned(needed, owned, rank, world, ago)
+        assert sched.mode == "owned" and sched.n_local == needed.size
+        nlev = 3
+        full = synth.analytic_field(m.latCell, m.lonCell, nlev)[:, perm]
+        for dtype, shape3 in ((torch.float64, False), (torch.float32, True)):          # cell-fast float64 rows; file-order float32 rows
+            f = torch.from_numpy(full).to(dtype)
+            own = f[:, owned.astype(np.int64)].contiguous()
+            local = torch.full((nlev, sched.n_local), float("nan"), dtype=dtype)
+            if shape3:
+                own, local = own.t().contiguous()[None], torch.full((1, sched.n_local, nlev), float("nan"), dtype=dtype)
+            sched.exchange(own, local)
+            got = local[0].t() if shape3 else local
+            assert torch.equal(got, f[:, needed.astype(np.int64)])                       # every needed cell, exactly the field's bytes
+        lidx = np.where(idx >= 0, np.searchsorted(needed, np.maximum(idx, 0)), -1).astype(np.int32)
+        assert np.array_equal(o.apply_fixed(lidx, w, local.numpy() if not shape3 else got.double().numpy(), nlev).shape, (nlev, idx.shape[0]))
+        send_n, recv_n = sched.counts()
+        q.put((rank, sum(n for k, n in enumerate(send_n) if k != rank), sum(n for k, n in enumerate(recv_n) if k != rank), int(needed.size), int(owned.size)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_owned_form_on_a_shuffled_mesh(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_owned, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    sent, recv, needed = sum(r[1] for r in res), sum(r[2] for r in res), sum(r[3] for r in res)
+    assert sent == recv > 0
+    # the partition follows the rows: only what neighbouring row blocks share travels -- a small part of what the ranks need, where
+    # equal id blocks of this shuffled numbering move (world - 1) / world of it (test_row_sharded_halo_exchange, shuffle)
+    assert sent < 0.15 * needed
+    assert res[0][4] == res[0][3]                       # rank 0 owns everything it needs
+
+
 def test_row_and_cell_blocks():
     from mpassit_amd import dist as mdist
     assert [mdist.row_block(1060, 8, r) for r in range(8)][:2] == [(0, 133), (133, 266)]

@@ -85,7 +85,7 @@ def test_rank_without_sources(gpu_lib):
     assert np.array_equal(got, want)
 
 
-def _rank_file_order(rank, world, port, shuffle, q):
+def _rank_file_order(rank, world, port, shuffle, q, ownership="aligned"):
     """float32 sources in MPAS file order on every rank's GPU (what the shipped driver holds, input_data.F90:630-655)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -102,13 +102,14 @@ def _rank_file_order(rank, world, port, shuffle, q):
             out = [None] * world
             dist.all_gather_object(out, obj)
             return out
-        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, ago)
+        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, ago, ownership=ownership)
         nlev, nf = 5, 2
         full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5 + f) for f in range(nf)]).transpose(0, 2, 1).astype(np.float32)
         c0, c1 = sr.sched.own
         local = sr.local_buffer(nf, nlev, "cuda", dtype=torch.float32, layout=R.LAYOUT_LEV_FAST)
         local.fill_(float("nan"))
-        mine = torch.as_tensor(np.ascontiguousarray(full[:, c0:c1]), device="cuda")
+        sel = sr.sched.owned_ids if sr.sched.mode == "owned" else slice(c0, c1)
+        mine = torch.as_tensor(np.ascontiguousarray(full[:, sel]), device="cuda")
         if sr.sched.mode == "range":
             own = sr.own_view(local)
             own.copy_(mine)
@@ -116,7 +117,8 @@ def _rank_file_order(rank, world, port, shuffle, q):
             own = mine
         out = sr.step(own, local, nlev, nf)
         torch.cuda.synchronize()
-        q.put((rank, sr.j0, sr.j1, out.cpu().numpy(), sr.sched.mode))
+        plan = sr.sched.plan(nf, local)
+        q.put((rank, sr.j0, sr.j1, out.cpu().numpy(), sr.sched.mode, plan.bytes_received, sr.n_needed))
         sr.destroy()
         _lib.finalize()
     finally:
@@ -154,3 +156,37 @@ def test_file_order_float32_sources_sharded(gpu_lib, world, shuffle):
     assert all(r[4] == ("compact" if shuffle else "range") for r in res)
     got = np.concatenate([r[3] for r in res], axis=2)
     assert got.dtype == np.float32 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ownership", ["need", "auto"])
+def test_owned_form_follows_the_rows_on_a_shuffled_mesh(gpu_lib, ownership):
+    """Round 5: a mesh WITHOUT banded numbering sharded with the owned halo form (every cell to the lowest rank whose rows reference it;
+    `auto` picks it when the needed ids are not banded): the same bits as the single-GPU float32 file-order Regrid, and only a small
+    part of what the ranks need travels (equal id blocks moved two thirds of it: test_file_order_float32_sources_sharded[3-True])."""
+    import torch
+    import torch.multiprocessing as mp
+    from mpassit_amd import regrid as R, synth
+    m, g = _case()
+    m = synth.shuffle_cells(m, seed=3)
+    nlev, nf, world = 5, 2, 3
+    full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5 + f) for f in range(nf)]).transpose(0, 2, 1).astype(np.float32)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    want = rh.regrid_typed(torch.as_tensor(np.ascontiguousarray(full), device="cuda").view(-1), nlev=nlev, nfields=nf, layout=R.LAYOUT_LEV_FAST).cpu().numpy()
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_file_order, args=(r, world, port, True, q, ownership)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[4] == "owned" for r in res)
+    assert np.array_equal(np.concatenate([r[3] for r in res], axis=2), want)
+    received = sum(r[5] for r in res) / (nf * nlev * 4)                 # cells that arrived anywhere (the ranks' own shares included)
+    assert received == sum(r[6] for r in res)

@@ -126,6 +126,105 @@ def test_compact_form_on_a_shuffled_mesh(gpu_lib, V, dtype, lev_fast):
     _rehearse(synth.shuffle_cells(m, seed=11), g, V, "compact", getattr(torch, dtype), lev_fast=lev_fast, own_streams=True)
 
 
+@pytest.mark.parametrize("V,partition,dtype,lev_fast", [(3, "need", "float64", False), (5, "need", "float32", True), (4, "random", "float32", False),
+                                                        (3, "random", "float64", True)])
+def test_owned_form_the_callers_own_partition(gpu_lib, V, partition, dtype, lev_fast):
+    """mpg_halo_build_owned through the real RCCL group calls: the cells of a SHUFFLED mesh partitioned by the caller -- `need`: every
+    cell to the lowest rank whose rows reference it (what bench.py does for meshes without banded numbering); `random`: an arbitrary
+    assignment, as a coupled model's own decomposition looks to this library.  Every rank's slab holds the field at its needed ids,
+    its Regrid equals the single-GPU Regrid bit for bit, and with `need` only what neighbouring row blocks share has travelled."""
+    import torch
+
+    from mpassit_amd import comm as MC, dist as mdist, regrid as R, synth
+    m0, g = _case()
+    m = synth.shuffle_cells(m0, seed=11)
+    dt = getattr(torch, dtype)
+    nlev, nf = 6, 2
+    layout = R.LAYOUT_LEV_FAST if lev_fast else R.LAYOUT_CELL_FAST
+    full = torch.as_tensor(np.random.default_rng(5).standard_normal((nf, nlev, m.nCells)), device="cuda").to(dt)
+    src = full.permute(0, 2, 1).contiguous() if lev_fast else full.contiguous().view(nf * nlev, -1)
+    mesh0, grid0 = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh0 = R.regrid_store(mesh0, grid0, R.REGRIDMETHOD_BILINEAR)
+    want = rh0.regrid_typed(src.view(-1), nlev=nlev, nfields=nf, layout=layout).clone()
+    rh0.release()
+    mesh0.destroy()
+    grid0.destroy()
+    real = MC.Comm(0, 1)
+    vcs = [real.virtual(r, V) for r in range(V)]
+    blocks = [mdist.row_block(g.ny, V, r) for r in range(V)]
+    grids = [R.Grid.from_target(g, rows=b) for b in blocks]
+    meshes = [R.Mesh.from_mpas(m, window_grid=grids[r]) for r in range(V)]
+    rhs = [R.regrid_store(meshes[r], grids[r], R.REGRIDMETHOD_BILINEAR) for r in range(V)]
+    needed = [rh.unique_sources() for rh in rhs]
+    if partition == "need":
+        owned, seen = [], np.zeros(m.nCells, bool)
+        for r in range(V):
+            mine = needed[r][~seen[needed[r]]]
+            seen[mine] = True
+            owned.append(mine.astype(np.int32))
+    else:
+        owner = np.random.default_rng(3).integers(0, V, m.nCells)
+        owned = [np.nonzero(owner == r)[0].astype(np.int32) for r in range(V)]
+    torch.cuda.synchronize()
+
+    def body(r):
+        torch.cuda.set_device(0)
+        st = torch.cuda.Stream()
+        h = MC.Halo(vcs[r], rhs[r], m.nCells, owned_ids=owned[r])
+        assert h.mode == "owned" and h.n_local == needed[r].size and h.own == (0, owned[r].size)
+        with torch.cuda.stream(st):
+            ids = torch.as_tensor(owned[r].astype(np.int64), device="cuda")
+            own = src[:, ids].contiguous()
+            local = torch.full((nf, h.n_local, nlev) if lev_fast else (nf * nlev, h.n_local), float("nan"), dtype=dt, device="cuda")
+            h.exchange(own, local, stream=st.cuda_stream)
+            out = rhs[r].regrid_typed(local.view(-1), nlev=nlev, nfields=nf, layout=layout)
+        st.synchronize()
+        res = (h.sent_per_row, h.received_per_row, local, out)
+        h.destroy()
+        return res
+
+    res = MC.run_virtual_ranks(V, body)
+    for r, (sent, recv, local, out) in enumerate(res):
+        plan = MC.plan_owned_host(r, needed, owned)
+        assert recv == sum(x.size for q, x in enumerate(plan["recv_ids"]) if q != r) and sent == sum(x.size for q, x in enumerate(plan["send_ids"]) if q != r)
+        assert torch.equal(local, src[:, torch.as_tensor(needed[r].astype(np.int64), device="cuda")])
+        assert torch.equal(out, want[:, :, blocks[r][0]:blocks[r][1]])
+    total_sent, total_needed = sum(x[0] for x in res), sum(x.size for x in needed)
+    assert total_sent == sum(x[1] for x in res) > 0
+    if partition == "need":
+        assert total_sent == total_needed - np.unique(np.concatenate(needed)).size and total_sent < 0.2 * total_needed
+    groups, sends, recvs, allgathers = real.virtual_stats()
+    assert groups == 1 and sends == recvs > 0 and allgathers == 2
+    for rh, me, gr, vc in zip(rhs, meshes, grids, vcs):
+        rh.release()
+        me.destroy()
+        gr.destroy()
+        vc.destroy()
+    real.destroy()
+
+
+def test_owned_form_refuses_a_partition_that_is_none(gpu_lib, regional_case, monkeypatch):
+    """A cell owned twice, a referenced cell owned by nobody, an unsorted list: refused with the cell's number."""
+    from mpassit_amd import _lib, comm as MC, regrid as R
+    monkeypatch.setenv("MPG_COMM_TIMEOUT_S", "20")
+    m, g = regional_case
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    need = rh.unique_sources()
+    c = MC.Comm(0, 1)
+    with pytest.raises(_lib.MpgError, match="no rank owns"):
+        MC.Halo(c, rh, m.nCells, owned_ids=need[1:])
+    with pytest.raises(_lib.MpgError, match="sorted"):
+        MC.Halo(c, rh, m.nCells, owned_ids=need[::-1])
+    h = MC.Halo(c, rh, m.nCells, owned_ids=np.arange(m.nCells, dtype=np.int32))           # one rank owning everything: fine
+    assert h.mode == "owned" and h.n_local == need.size and h.sent_per_row == 0
+    h.destroy()
+    c.destroy()
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
 def test_para_range_ownership(gpu_lib):
     import torch
     m, g = _case()
