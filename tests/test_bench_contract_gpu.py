@@ -54,11 +54,11 @@ def test_bench_gpus2_launches_itself(gpu_lib):
     assert 0 < h["halo_bytes_per_step"] < 200e6 and h["exchange_ms_max"] > 0
 
 
-@pytest.mark.parametrize("workload,ranks,mode", [("tiny", 3, "range"), ("c5_small", 2, "compact")])
+@pytest.mark.parametrize("workload,ranks,mode", [("tiny", 3, "range"), ("c5_small", 2, "owned")])
 def test_bench_sharded_on_float32_file_order_sources(gpu_lib, workload, ranks, mode):
     """Round 5: `--gpus N --io f32 --layout lev_fast` -- the sources as the shipped driver holds them (float32, MPAS file order,
     input_data.F90:630-655) sharded over N ranks; the halo exchange moves whole [nlev] rows of that type.  BASELINE configs[4] is
-    runnable at N > 1 as written (here its small sibling, a Morton-numbered global mesh: the compact halo form, and a banded regional
+    runnable at N > 1 as written (here its small sibling, a Morton-numbered global mesh: the owned halo form -- every cell to the lowest rank that references it --, and a banded regional
     mesh: the range form); the ranks share the one card and the halo travels over gloo."""
     env = dict(os.environ, MPASSIT_DIST_BACKEND="gloo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
