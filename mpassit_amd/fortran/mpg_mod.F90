@@ -260,6 +260,16 @@ module mpg
       type(c_ptr), intent(out) :: halo
       integer(c_int) :: rc
     end function mpg_halo_build
+    !> the same for the CALLER's own partition of the source cells (a coupled model's decomposition): owned_ids = this image's sorted
+    !! unique global cell ids, 0-based; own_dev of mpg_halo_exchange_dev is then [nrows][own_ld >= n_owned] in that order
+    function mpg_halo_build_owned(comm, rh, n_cells_global, owned_ids, n_owned, halo) bind(C, name="mpg_halo_build_owned") result(rc)
+      import :: c_int, c_int32_t, c_int64_t, c_ptr
+      type(c_ptr), value :: comm, rh
+      integer(c_int64_t), value :: n_cells_global, n_owned
+      integer(c_int32_t), intent(in) :: owned_ids(*)
+      type(c_ptr), intent(out) :: halo
+      integer(c_int) :: rc
+    end function mpg_halo_build_owned
     function mpg_halo_info(halo, mode, n_local, own, base, own_pos, sent_per_row, received_per_row) bind(C, name="mpg_halo_info") result(rc)
       import :: c_int, c_int64_t, c_ptr
       type(c_ptr), value :: halo
@@ -286,6 +296,19 @@ module mpg
       integer(c_int), value :: nlev, elem_bytes, root
       integer(c_int) :: rc
     end function mpg_gather_rows
+    !> blocks until mpg_init's helper thread is done (call before a global-mode stream capture that follows mpg_init at once)
+    function mpg_warmup_wait() bind(C, name="mpg_warmup_wait") result(rc)
+      import :: c_int
+      integer(c_int) :: rc
+    end function mpg_warmup_wait
+    !> which data-dependent branches a Store took (layout by method: include/mpassit_amd.h); diagnostics
+    function mpg_handle_store_stats(rh, stats, n) bind(C, name="mpg_handle_store_stats") result(rc)
+      import :: c_int, c_int64_t, c_ptr
+      type(c_ptr), value :: rh
+      integer(c_int64_t), intent(out) :: stats(*)
+      integer(c_int), value :: n
+      integer(c_int) :: rc
+    end function mpg_handle_store_stats
     function mpg_bswap_dev(buf, n, elem_size, stream) bind(C, name="mpg_bswap_dev") result(rc)
       import :: c_int, c_int64_t, c_ptr
       type(c_ptr), value :: buf, stream
