@@ -213,8 +213,11 @@ class HaloSchedule:
                 p.recv_views.append((shaped(p.recvbuf, off, n), where))
                 off += R * L * n
         p.host_send = p.host_recv = None
-        p.bytes_sent = p.sendbuf.numel() * p.sendbuf.element_size()
-        p.bytes_received = p.recvbuf.numel() * p.recvbuf.element_size()
+        # what crosses the links: in the compact and owned forms the packed buffers also hold the rank's own share (a device copy)
+        own_s = send_n[self.rank] if self.mode != "range" else 0
+        own_r = recv_n[self.rank] if self.mode != "range" else 0
+        p.bytes_sent = (sum(send_n) - own_s) * R * L * p.sendbuf.element_size()
+        p.bytes_received = (sum(recv_n) - own_r) * R * L * p.recvbuf.element_size()
         self._plans[key] = p
         return p
 

@@ -188,5 +188,5 @@ def test_owned_form_follows_the_rows_on_a_shuffled_mesh(gpu_lib, ownership):
         assert p.exitcode == 0
     assert all(r[4] == "owned" for r in res)
     assert np.array_equal(np.concatenate([r[3] for r in res], axis=2), want)
-    received = sum(r[5] for r in res) / (nf * nlev * 4)                 # cells that arrived anywhere (the ranks' own shares included)
-    assert received == sum(r[6] for r in res)
+    received = sum(r[5] for r in res) / (nf * nlev * 4)                 # cells that crossed between ranks
+    assert 0 < received < 0.2 * sum(r[6] for r in res)                    # a small part of what the ranks need

@@ -107,6 +107,33 @@ def test_script_asks_for_the_reference_calls(exported):
         assert "-s dst_grid_center_scrip.nc" in by[k] and "-d dst_grid_%s_scrip.nc" % dst in by[k] and "--src_regional" in by[k] and "--src_type SCRIP" in by[k]
 
 
+def test_exported_files_open_in_an_independent_netcdf_reader(exported, tmp_path):
+    """ESMF reads its inputs through libnetcdf; the nearest thing here is scipy's own classic-NetCDF reader: every exported file (and a
+    weight file) opens there as a 64-bit-offset classic file with the same dimensions, attributes and numbers."""
+    from scipy.io import netcdf_file
+
+    from mpassit_amd import esmf_pin as E
+    d, m, g = exported
+    with netcdf_file(os.path.join(d, "src_mesh_esmf.nc"), "r", mmap=False) as f:
+        assert f.version_byte == 2 and f.dimensions["nodeCount"] == m.nVertices and f.dimensions["elementCount"] == m.nCells and f.dimensions["coordDim"] == 2
+        assert f.gridType == b"unstructured" and f.variables["nodeCoords"].units == b"degrees"
+        conn, num = f.variables["elementConn"][:], f.variables["numElementConn"][:]
+        assert conn.shape == m.verticesOnCell.shape and conn.dtype.kind == "i" and num.dtype.itemsize == 1 and int(f.variables["elementConn"]._FillValue) == -1
+        assert np.array_equal(num, (m.verticesOnCell > 0).sum(axis=1)) and conn.min() >= -1 and (conn != 0).all() and conn.max() == m.nVertices
+        lon = np.asarray(m.lonCell) * 180.0 / np.pi
+        assert np.array_equal(f.variables["centerCoords"][:, 0], np.where(lon > 180.0, lon - 360.0, lon))
+    with netcdf_file(os.path.join(d, "dst_grid_center_scrip.nc"), "r", mmap=False) as f:
+        assert tuple(f.variables["grid_dims"][:]) == (g.nx, g.ny) and f.dimensions["grid_size"] == g.nx * g.ny and f.dimensions["grid_corners"] == 4
+        assert np.array_equal(f.variables["grid_center_lat"][:], g.lat.reshape(-1)) and f.variables["grid_center_lon"].units == b"degrees"
+        assert np.array_equal(f.variables["grid_corner_lon"][:, 2], g.lon_c[1:, 1:].reshape(-1)) and (f.variables["grid_imask"][:] == 1).all()
+    w = str(tmp_path / "w.nc")
+    E.write_weight_file(w, [3, 1], [2, 7], [0.25, 1.0], 9, 4, "conserve")
+    with netcdf_file(w, "r", mmap=False) as f:
+        assert (f.dimensions["n_a"], f.dimensions["n_b"], f.dimensions["n_s"]) == (9, 4, 2)
+        assert list(f.variables["row"][:]) == [3, 1] and list(f.variables["col"][:]) == [2, 7] and list(f.variables["S"][:]) == [0.25, 1.0]
+        assert f.ESMF_regrid_method == b"First-order Conservative" and f.normalization == b"destarea"
+
+
 def _oracle_triplets(oracle, m, g, method):
     cxyz, vxyz = mesh_xyz(oracle, m)
     pxyz = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
