@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--io", default="f64", choices=["f64", "f32"])
     ap.add_argument("--layout", default="cell_fast", choices=["cell_fast", "lev_fast"])
     ap.add_argument("--workload", default="c4_3m_regional")
+    ap.add_argument("--ownership", default="aligned", choices=["aligned", "para_range", "need"],
+                    help="need: the owned halo form with every cell given to the lowest rank whose rows reference it (meshes without banded numbering)")
     args = ap.parse_args()
     import torch
     from mpassit_amd import _lib, comm as MC, dist as mdist, regrid as R, workloads
@@ -48,6 +50,15 @@ def main():
     grids = [R.Grid.from_target(g, rows=b) for b in blocks]
     meshes = [R.Mesh.from_mpas(m, window_grid=grids[r]) for r in range(V)]
     rhs = [R.regrid_store(meshes[r], grids[r], R.REGRIDMETHOD_BILINEAR) for r in range(V)]
+    owned = [None] * V
+    needed_total = 0
+    if args.ownership == "need":
+        seen = np.zeros(m.nCells, bool)
+        for r in range(V):
+            nd = rhs[r].unique_sources()
+            needed_total += nd.size
+            owned[r] = nd[~seen[nd]].astype(np.int32)
+            seen[nd] = True
     torch.cuda.synchronize()
     times = {}
 
@@ -55,12 +66,17 @@ def main():
         torch.cuda.set_device(0)
         st = torch.cuda.Stream()
         t0 = time.perf_counter()
-        h = MC.Halo(vcs[r], rhs[r], m.nCells)
+        h = MC.Halo(vcs[r], rhs[r], m.nCells, ownership=args.ownership if owned[r] is None else "aligned", owned_ids=owned[r])
         t_build = (time.perf_counter() - t0) * 1e3
         with torch.cuda.stream(st):
             local = torch.empty((F, h.n_local, nlev) if lev_fast else (F * nlev, h.n_local), dtype=dt, device="cuda")
-            own = local[:, h.own_pos[0]:h.own_pos[1]]
-            own.copy_(src[:, h.own[0]:h.own[1]])
+            if h.mode == "range":
+                own = local[:, h.own_pos[0]:h.own_pos[1]]
+                own.copy_(src[:, h.own[0]:h.own[1]])
+            elif h.mode == "owned":
+                own = src[:, torch.as_tensor(owned[r].astype(np.int64), device="cuda")].contiguous()
+            else:
+                own = src[:, h.own[0]:h.own[1]].contiguous()
             st.synchronize()
             ex = []
             for _ in range(5):
@@ -79,7 +95,7 @@ def main():
         ok = bool(torch.equal(out, want[:, :, blocks[r][0]:blocks[r][1]]))
         if r == 0:
             ok = ok and bool(torch.equal(whole, want[0]))
-        times[r] = dict(halo_build_ms=round(t_build, 2), exchange_ms=round(min(ex), 4), gather_ms_incl_waiting_for_the_other_threads=round(e0.elapsed_time(e1), 4), n_local=h.n_local,
+        times[r] = dict(mode=h.mode, halo_build_ms=round(t_build, 2), exchange_ms=round(min(ex), 4), gather_ms_incl_waiting_for_the_other_threads=round(e0.elapsed_time(e1), 4), n_local=h.n_local,
                         received_per_row=h.received_per_row, ok=ok)
         h.destroy()
         return ok
@@ -88,7 +104,7 @@ def main():
     groups, sends, recvs, allgathers = real.virtual_stats()
     esz = (4 if args.io == "f32" else 8)
     rows = F * nlev
-    res = {"workload": desc, "virtual_ranks": V, "fields": F, "io": args.io, "layout": args.layout, "all_row_blocks_and_gathered_field_bit_identical": all(oks),
+    res = {"workload": desc, "virtual_ranks": V, "fields": F, "io": args.io, "layout": args.layout, "ownership": args.ownership, "all_row_blocks_and_gathered_field_bit_identical": all(oks),
            "rccl_calls": {"groups": groups, "sends": sends, "recvs": recvs, "allgathers": allgathers},
            "halo_bytes_per_exchange_all_ranks": int(sum(t["received_per_row"] for t in times.values()) * rows * esz),
            "exchange_ms_all_ranks_traffic_on_one_card": max(t["exchange_ms"] for t in times.values()),
