@@ -211,6 +211,57 @@ int main(void) {
     CHECK(mpg_dev_free(s_dev)); CHECK(mpg_dev_free(d_dev)); CHECK(mpg_dev_free(src_dev)); CHECK(mpg_dev_free(loc_dev));
     CHECK(mpg_dev_free(dst_dev)); CHECK(mpg_dev_free(all_dev));
   }
+  /* ---- round-5 verbs: the caller's own partition of the cells (owned halo form), Store statistics, mpg_warmup_wait ---- */
+  {
+    mpg_comm comm;
+    mpg_halo halo;
+    mpg_handle rh;
+    CHECK(mpg_warmup_wait());
+    CHECK(mpg_comm_init(0, 1, NULL, &comm));
+    CHECK(mpg_regrid_store(mesh, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_BILINEAR, &rh));
+    int64_t st[8];
+    CHECK(mpg_handle_store_stats(rh, st, 8));
+    if (st[0] < 0 || st[2] <= 0) {   /* bilinear: [2] = triangles in all */
+      fprintf(stderr, "FAIL store stats %lld %lld %lld\n", (long long)st[0], (long long)st[1], (long long)st[2]);
+      return 1;
+    }
+    const int32_t twice[2] = {1, 1}, all4[4] = {0, 1, 2, 3}, three[3] = {0, 1, 2};
+    if (mpg_halo_build_owned(comm, rh, 4, twice, 2, &halo) != MPG_ERR_INVALID_ARG ||      /* not sorted / unique */
+        mpg_halo_build_owned(comm, rh, 4, three, 3, &halo) != MPG_ERR_INVALID_ARG) {      /* cell 3 is referenced and nobody owns it */
+      fprintf(stderr, "FAIL: a partition that is none must be refused\n");
+      return 1;
+    }
+    CHECK(mpg_halo_build_owned(comm, rh, 4, all4, 4, &halo));
+    int mode;
+    int64_t n_local, own[2], base, own_pos[2], sent, received;
+    CHECK(mpg_halo_info(halo, &mode, &n_local, own, &base, own_pos, &sent, &received));
+    if (mode != 2 || n_local != 4 || own[0] != 0 || own[1] != 4 || sent != 0 || received != 0) {
+      fprintf(stderr, "FAIL owned halo of one rank: mode %d n_local %lld own [%lld, %lld)\n", mode, (long long)n_local, (long long)own[0], (long long)own[1]);
+      return 1;
+    }
+    /* float32 sources in file order: ONE whole row of 2 levels is the exchanged element (nrows = 1 field, elem_bytes = 2 * 4) */
+    const float rows32[4][2] = {{1.f, 10.f}, {2.f, 20.f}, {3.f, 30.f}, {4.f, 40.f}};
+    float out32[2][NY][NX];
+    void *own_dev, *loc_dev, *dst_dev;
+    CHECK(mpg_dev_alloc(sizeof rows32, &own_dev));
+    CHECK(mpg_dev_alloc(sizeof rows32, &loc_dev));
+    CHECK(mpg_dev_alloc(sizeof out32, &dst_dev));
+    CHECK(mpg_dev_upload(own_dev, rows32, sizeof rows32));
+    CHECK(mpg_halo_exchange_dev(halo, own_dev, 4, loc_dev, 1, 2 * 4, NULL));
+    CHECK(mpg_regrid_typed_dev(rh, loc_dev, MPG_TYPE_F32, MPG_LAYOUT_LEV_FAST, 2, 1, dst_dev, MPG_TYPE_F32, 1.0, 0.0, NULL));
+    CHECK(mpg_dev_download(out32, dst_dev, sizeof out32));
+    for (int j = 0; j < NY; ++j)
+      for (int i = 0; i < NX; ++i)
+        if (!(out32[0][j][i] >= 1.f && out32[0][j][i] <= 4.f) || !(out32[1][j][i] >= 10.f && out32[1][j][i] <= 40.f) ||
+            fabs((double)out32[1][j][i] - 10.0 * (double)out32[0][j][i]) > 1e-4) {      /* level 2 = 10 x level 1 on every source: so on every point */
+          fprintf(stderr, "FAIL owned halo + file-order Regrid at (%d,%d): %g %g\n", i, j, out32[0][j][i], out32[1][j][i]);
+          return 1;
+        }
+    CHECK(mpg_halo_destroy(halo));
+    CHECK(mpg_comm_destroy(comm));
+    CHECK(mpg_handle_release(rh));
+    CHECK(mpg_dev_free(own_dev)); CHECK(mpg_dev_free(loc_dev)); CHECK(mpg_dev_free(dst_dev));
+  }
   /* ---- round-4 verbs: a mesh cut to a grid gives the whole mesh's weights; a projection that does not fit a grid is refused ---- */
   {
     mpg_mesh cut;
