@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--ownership", default="auto", choices=["auto", "aligned", "para_range", "need"],
                     help="N > 1: who owns which source cells -- aligned / para_range: the library's id blocks; need: every cell to the lowest rank whose "
                          "rows reference it (meshes without banded numbering); auto: aligned when the numbering is banded, else need")
+    ap.add_argument("--block-decomp-file", default=None, help="N > 1: an MPAS graph partition file (the namelist's block_decomp_file, one owner per "
+                                                              "cell): the source cells are partitioned as the model partitions them")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="kernel knob for experiments (mpg_tune), e.g. a3_staged=0; the default run sets none")
     return ap.parse_args()
@@ -195,7 +197,7 @@ def main():
     id_file = "/dev/shm/mpassit_bench_%s.rcclid" % run_id   # fresh per run
     os.environ.setdefault("MPASSIT_RUN_ID", run_id)          # tags the id file of the C-ABI transport: several ranks without one are refused
     sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file,
-                             ownership=args.ownership if world > 1 else "aligned")
+                             ownership=args.ownership if world > 1 else "aligned", decomp_file=args.block_decomp_file if world > 1 else None)
     P_local = sr.rh.n_dst
     io32 = args.io == "f32"
     c0, c1 = sr.sched.own

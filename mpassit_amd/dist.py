@@ -42,6 +42,24 @@ def cell_block(n_cells, world, rank):
     return a - 1, b
 
 
+def read_block_decomp_file(path, n_cells, nranks, rank):
+    """`block_decomp_file` of the namelist (program_setup.F90:38,148-152; read_block_decomp_file, model_grid.F90:2367-2426): an MPAS graph
+    partition file (`x1.655362.graph.info.part.8`) -- one line per cell with the number of the PET that owns it, blank lines skipped.
+    The reference checks that the file lists exactly nCells cells and was made for exactly npets processes, and takes the cells whose
+    number is its own rank (`elemIDs`, model_grid.F90:437).  -> this rank's sorted 0-based cell ids: the `owned_ids` of
+    mpg_halo_build_owned / HaloSchedule.build_owned."""
+    import os
+    if not os.path.exists(path):
+        raise FileNotFoundError("BLOCK DECOMP FILE DOES NOT EXIST: %s" % path)
+    with open(path) as f:
+        proc = np.array([int(ln.split()[0]) for ln in f if ln.strip()], dtype=np.int64)
+    if proc.size != n_cells:
+        raise ValueError("BLOCK DECOMPOSITION FILE CONTAINS MORE CELLS THAN INPUT GRID (%d lines, %d cells)" % (proc.size, n_cells))
+    if proc.size and int(proc.max()) + 1 != nranks:
+        raise ValueError("BLOCK DECOMPOSITION FILE GENERATED FOR %d PROCESSES BUT %d PROCESSORS USED." % (int(proc.max()) + 1, nranks))
+    return np.nonzero(proc == rank)[0].astype(np.int32)
+
+
 @dataclass
 class HaloSchedule:
     """Who sends which source cells to whom.  Pure host logic + one torch.distributed exchange;
@@ -266,9 +284,11 @@ class _HaloPlan:
 class ShardedRegrid:
     """Rank-local piece of a row-sharded Mesh -> Grid regrid on this rank's GPU."""
 
-    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object, ownership="aligned", transport="torch", id_file=None):
+    def __init__(self, mpas_mesh, target, regridmethod, rank, world, all_gather_object, ownership="aligned", transport="torch", id_file=None,
+                 decomp_file=None):
         """ownership: "aligned" / "para_range" (the library's id-block partitions), "need" (every cell to the lowest rank whose rows reference it:
-        a caller-defined partition, the owned halo form), "auto" (aligned when every rank's needed ids are banded, else need).
+        a caller-defined partition, the owned halo form), "auto" (aligned when every rank's needed ids are banded, else need); decomp_file:
+        an MPAS graph partition file (the namelist's block_decomp_file) -- the model's own decomposition, the owned form.
         transport "torch": schedule and exchange through torch.distributed (RCCL under the nccl backend, gloo in the CPU
         tests).  transport "cabi": the C-ABI's own verbs (mpg_comm_init / mpg_halo_build / mpg_halo_exchange_dev: librccl
         directly, what a C or Fortran host uses); the ranks meet through `id_file`."""
@@ -289,6 +309,9 @@ class ShardedRegrid:
             banded = all_gather_object(bool(needed.size == 0 or (nhi - nlo) <= 1.25 * needed.size))
             ownership = "aligned" if all(banded) else "need"
         owned = None
+        if decomp_file is not None:     # the namelist's block_decomp_file: the model's own decomposition (model_grid.F90:423-438)
+            ownership = "file"
+            owned = read_block_decomp_file(decomp_file, mpas_mesh.nCells, world, rank)
         if ownership == "need":     # every cell to the lowest rank that references it: the caller-defined partition that follows the rows
             owned = HaloSchedule.owned_by_need(needed, rank, world, all_gather_object)
         if transport == "cabi":

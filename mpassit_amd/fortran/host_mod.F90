@@ -50,6 +50,58 @@ contains
     if (iwork2 > irank) iend = iend + 1
   end subroutine para_range
 
+  !> read_block_decomp_file (model_grid.F90:2367-2426): the namelist's block_decomp_file is an MPAS graph partition file, one line per
+  !! cell with the PET that owns it (blank lines skipped).  Checks as the reference: the file exists, lists exactly ncells cells and was
+  !! made for exactly npets processes.  my_cells: this image's cells, sorted, 0-BASED -- the owned_ids of mpg_halo_build_owned.
+  subroutine read_block_decomp_file(localpet, npets, file, ncells, my_cells, my_cells_num)
+    integer, intent(in) :: localpet, npets, ncells
+    character(len=*), intent(in) :: file
+    integer, allocatable, intent(out) :: my_cells(:)      ! (default integers: 32 bits, what the C side takes as int32_t)
+    integer, intent(out) :: my_cells_num
+    logical :: ex
+    integer :: u, k, istat, nlines, proc, proc_max
+    integer, allocatable :: tmp(:)
+    character(len=200) :: line
+    character(len=200) :: msg
+    inquire (file=trim(file), exist=ex)
+    if (.not. ex) call fatal("BLOCK DECOMP FILE DOES NOT EXIST", -1)
+    open (newunit=u, file=trim(file), form='formatted', status='old', iostat=istat)
+    if (istat /= 0) call fatal("OPENING BLOCK DECOMP FILE", istat)
+    nlines = 0
+    do
+      read (u, '(A)', iostat=istat) line
+      if (istat /= 0) exit
+      if (trim(line) == '') cycle
+      nlines = nlines + 1
+    end do
+    if (nlines /= ncells) call fatal("BLOCK DECOMPOSITION FILE CONTAINS MORE CELLS THAN INPUT GRID", -1)
+    allocate (tmp(ncells))
+    my_cells_num = 0
+    proc_max = 0
+    rewind (u)
+    k = 0
+    do while (k < nlines)
+      read (u, '(A)', iostat=istat) line
+      if (istat /= 0) call fatal("READING BLOCK DECOMPOSITION FILE", istat)
+      if (trim(line) == '') cycle
+      read (line, *, iostat=istat) proc
+      if (istat /= 0) call fatal("READING BLOCK DECOMPOSITION FILE", istat)
+      k = k + 1
+      proc_max = max(proc, proc_max)
+      if (localpet == proc) then
+        my_cells_num = my_cells_num + 1
+        tmp(my_cells_num) = k - 1
+      end if
+    end do
+    close (u)
+    if (proc_max + 1 /= npets) then
+      write (msg, '(A,I10,A,I10,A)') "BLOCK DECOMPOSITION FILE GENERATED FOR ", proc_max + 1, " PROCESSES BUT ", npets, " PROCESSORS USED."
+      call fatal(trim(msg), -1)
+    end if
+    allocate (my_cells(my_cells_num))
+    my_cells(1:my_cells_num) = tmp(1:my_cells_num)
+  end subroutine read_block_decomp_file
+
   subroutine setup_ranks()
     character(len=64) :: buf
     integer :: ios

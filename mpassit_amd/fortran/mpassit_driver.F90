@@ -269,6 +269,17 @@ contains
     character(len=16) :: buf
     integer(c_int64_t) :: c0, cn, v0, vn
     real(c_double) :: margin
+    integer, allocatable :: my_cells(:)
+    integer :: my_cells_num
+    ! block_decomp_file (program_setup.F90:38; model_grid.F90:423-438): the reference gives every PET the cells the MPAS graph
+    ! partition assigns to it.  The images of this driver hold what their target ROWS reference instead (source windows, no exchange),
+    ! so the file decides nothing here -- but it is read and checked as the reference checks it (exists, lists exactly nCells cells,
+    ! was made for exactly this many processes), and the cells it gives this image are what a host that exchanges its sources hands
+    ! to mpg_halo_build_owned.
+    if (trim(block_decomp_file) /= "NULL") then
+      call read_block_decomp_file(myrank, nranks, block_decomp_file, nCells_input, my_cells, my_cells_num)
+      print '(a,i0,a,i0,a)', " - BLOCK DECOMPOSITION FILE: ", my_cells_num, " OF ", nCells_input, " CELLS BELONG TO THIS IMAGE (not used: images read by target rows)"
+    end if
     call get_environment_variable("MPASSIT_WHOLE_MESH", buf)
     if (nranks > 1 .and. len_trim(buf) == 0) then
       call mpg_check(mpg_mesh_create_window(int(nCells_input, c_int64_t), int(nVert_input, c_int64_t), int(maxEdges_input, c_int), &

@@ -227,6 +227,25 @@ def test_owned_form_on_a_shuffled_mesh(world):
     assert res[0][4] == res[0][3]                       # rank 0 owns everything it needs
 
 
+def test_block_decomp_file_is_read_as_the_reference_reads_it(tmp_path):
+    """read_block_decomp_file (model_grid.F90:2367-2426): one owner per line, blank lines skipped; exactly nCells lines and exactly npets
+    processes, else the reference's errors."""
+    from mpassit_amd import dist as mdist
+    owner = np.random.default_rng(2).integers(0, 3, 50)
+    owner[:3] = [0, 1, 2]
+    f = tmp_path / "x.graph.info.part.3"
+    f.write_text("\n".join("%d" % p for p in owner) + "\n\n")
+    got = [mdist.read_block_decomp_file(str(f), 50, 3, r) for r in range(3)]
+    assert all(np.array_equal(got[r], np.nonzero(owner == r)[0]) and got[r].dtype == np.int32 for r in range(3))
+    assert sum(g.size for g in got) == 50
+    with pytest.raises(ValueError, match="CONTAINS MORE CELLS THAN INPUT GRID"):
+        mdist.read_block_decomp_file(str(f), 49, 3, 0)
+    with pytest.raises(ValueError, match="GENERATED FOR 3 PROCESSES BUT 4 PROCESSORS USED"):
+        mdist.read_block_decomp_file(str(f), 50, 4, 0)
+    with pytest.raises(FileNotFoundError, match="BLOCK DECOMP FILE DOES NOT EXIST"):
+        mdist.read_block_decomp_file(str(tmp_path / "none"), 50, 3, 0)
+
+
 def test_row_and_cell_blocks():
     from mpassit_amd import dist as mdist
     assert [mdist.row_block(1060, 8, r) for r in range(8)][:2] == [(0, 133), (133, 266)]

@@ -85,7 +85,7 @@ def test_rank_without_sources(gpu_lib):
     assert np.array_equal(got, want)
 
 
-def _rank_file_order(rank, world, port, shuffle, q, ownership="aligned"):
+def _rank_file_order(rank, world, port, shuffle, q, ownership="aligned", decomp_file=None):
     """float32 sources in MPAS file order on every rank's GPU (what the shipped driver holds, input_data.F90:630-655)."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -102,7 +102,7 @@ def _rank_file_order(rank, world, port, shuffle, q, ownership="aligned"):
             out = [None] * world
             dist.all_gather_object(out, obj)
             return out
-        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, ago, ownership=ownership)
+        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, ago, ownership=ownership, decomp_file=decomp_file)
         nlev, nf = 5, 2
         full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5 + f) for f in range(nf)]).transpose(0, 2, 1).astype(np.float32)
         c0, c1 = sr.sched.own
@@ -190,3 +190,36 @@ def test_owned_form_follows_the_rows_on_a_shuffled_mesh(gpu_lib, ownership):
     assert np.array_equal(np.concatenate([r[3] for r in res], axis=2), want)
     received = sum(r[5] for r in res) / (nf * nlev * 4)                 # cells that crossed between ranks
     assert 0 < received < 0.2 * sum(r[6] for r in res)                    # a small part of what the ranks need
+
+
+def test_block_decomp_file_partitions_the_sources(gpu_lib, tmp_path):
+    """The namelist's block_decomp_file (an MPAS graph partition file; model_grid.F90:423-438, 2367-2426) as the partition of the source
+    cells of a sharded run: the model's decomposition -- here a random one, the hardest case -- through the owned halo form; the
+    row blocks of three ranks equal the single-GPU float32 file-order Regrid bit for bit."""
+    import torch
+    import torch.multiprocessing as mp
+    from mpassit_amd import regrid as R, synth
+    m, g = _case()
+    nlev, nf, world = 5, 2, 3
+    owner = np.random.default_rng(9).integers(0, world, m.nCells)
+    f = tmp_path / "mesh.graph.info.part.3"
+    f.write_text("\n".join("%d" % p for p in owner) + "\n")
+    full = np.stack([synth.analytic_field(m.latCell, m.lonCell, nlev, seed=5 + k) for k in range(nf)]).transpose(0, 2, 1).astype(np.float32)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    want = rh.regrid_typed(torch.as_tensor(np.ascontiguousarray(full), device="cuda").view(-1), nlev=nlev, nfields=nf, layout=R.LAYOUT_LEV_FAST).cpu().numpy()
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_file_order, args=(r, world, port, False, q, "aligned", str(f))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[4] == "owned" for r in res)
+    assert np.array_equal(np.concatenate([r[3] for r in res], axis=2), want)

@@ -335,6 +335,33 @@ def test_three_driver_images_write_the_same_file(tmp_path, gpu_lib, regional_cas
     assert not [f for f in os.listdir(d) if ".ready" in f or ".done." in f]      # the marker files are gone
 
 
+def test_block_decomp_file_is_checked_like_the_reference(tmp_path, gpu_lib, regional_case):
+    """`block_decomp_file` of the namelist (program_setup.F90:38,148-152; read_block_decomp_file, model_grid.F90:2367-2426): the images
+    of this driver take their cells by target rows, so the MPAS partition decides nothing here -- but the file is read and checked as
+    the reference checks it (exactly nCells lines, made for exactly this many processes), every image reports the cells it would own,
+    and the output stays the single image's file byte for byte."""
+    m, g = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    owner = np.random.default_rng(4).integers(0, 2, m.nCells)
+    owner[:2] = [0, 1]
+    open(os.path.join(d, "mesh.graph.info.part.2"), "w").write("\n".join("%d" % p for p in owner) + "\n")
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc")
+    open(os.path.join(d, "namelist.one"), "w").write(nml)
+    with_file = nml.replace("out.nc", "out2.nc").replace("/\n", '  block_decomp_file = "%s/mesh.graph.info.part.2"\n/\n' % d)
+    assert "block_decomp_file" in with_file
+    open(os.path.join(d, "namelist.two"), "w").write(with_file)
+    r = subprocess.run([_driver(), "namelist.one"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = _run_images(d, "namelist.two", 2)
+    for rank in range(2):
+        assert "BLOCK DECOMPOSITION FILE: %d OF %d CELLS BELONG TO THIS IMAGE" % (int((owner == rank).sum()), m.nCells) in res[rank][1]
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out2.nc"), "rb").read()
+    # made for two processes, run as one: the reference's error, its exit code
+    r = subprocess.run([_driver(), "namelist.two"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GENERATED FOR" in r.stdout and "PROCESSORS USED" in r.stdout
+
+
 def test_two_driver_images_on_a_global_grid(tmp_path, gpu_lib):
     """Row blocks of a periodic grid with pole caps (is_regional=.false.): each image keeps the cap it touches."""
     from mpassit_amd import workloads
