@@ -428,10 +428,6 @@ int mpg_halo_plan_owned_host(int rank, int nranks, const int64_t *n_needed, cons
  *   "bilinear_linetype"   Mesh -> Grid bilinear Store: 0 (default) the target point meets the plane of its source triangle
  *                 along the ray from the sphere's centre; 1 along the plane's normal (ESMF_LINETYPE_CART read literally).
  *                 In force at mpg_regrid_store time; the two differ by O(h^2) of the triangle size
- *   "cons_clip"   conservative Store, how a (cell, destination cell) pair's overlap area is computed: 0 Sutherland-Hodgman clip of the
- *                 cell against the quad's four half-spaces, the polygon in LDS; 1 the boundary integral over the parts of either
- *                 polygon's edges inside the other (no clipped polygon, higher occupancy).  Two routes to the same area: the weights
- *                 agree to ~1e-13 and differ in their last digits.  In force at mpg_regrid_store time (part of the handle cache key)
  *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice (default 35)
  * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */
 int mpg_tune(const char *key, int value);

@@ -260,17 +260,6 @@ __global__ __launch_bounds__(256) void k_pack(const double *__restrict__ src, in
 
 static int g_store_boxes = 1;
 int mpg_store_boxes() { return g_store_boxes; }
-static int g_cons_clip = -1;   // -1: not set yet (the environment's MPG_CONS_CLIP, else the default below)
-#ifndef MPG_CONS_CLIP_DEFAULT
-#define MPG_CONS_CLIP_DEFAULT 0
-#endif
-int mpg_cons_clip() {
-  if (g_cons_clip < 0) {
-    const char *e = getenv("MPG_CONS_CLIP");
-    g_cons_clip = e && (*e == '0' || *e == '1') ? *e - '0' : MPG_CONS_CLIP_DEFAULT;
-  }
-  return g_cons_clip;
-}
 static int g_bilinear_linetype = 0;
 int mpg_bilinear_linetype() { return g_bilinear_linetype; }
 int mpg_a3_staged() { return g_a3_staged; }
@@ -290,11 +279,6 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "bilinear_linetype")) {   // Mesh -> Grid bilinear Store: where the target point meets the triangle's plane
     if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
     g_bilinear_linetype = value;
-    return MPG_SUCCESS;
-  }
-  if (!strcmp(key, "cons_clip")) {   // conservative Store: 0 = Sutherland-Hodgman clip in LDS, 1 = boundary integral without a clipped polygon
-    if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
-    g_cons_clip = value;
     return MPG_SUCCESS;
   }
   if (!strcmp(key, "store_boxes")) {   // Stores on projection-built grids: candidates from the inverse projection (1) or the pyramid walk (0)

@@ -585,175 +585,6 @@ __global__ __launch_bounds__(CLIP_NT) void k_conserve_clip_pairs(int64_t npairs,
   pair_val[t] = ratio;
   if (trunc) atomicOr(truncated, 1);
 }
-// ---- the overlap area WITHOUT a clipped polygon ("cons_clip" 1, round 5) ------------------------------------------------------------
-// k_conserve_clip_pairs is held by its occupancy: the polygon being clipped needs largest-valence + 4 vertex slots of 24 bytes per lane
-// in LDS (ten wavefronts per CU on a hexagonal mesh), and Sutherland-Hodgman's inner loop is branches a wavefront always takes.  The
-// area of the intersection of two CONVEX spherical polygons P (the source cell) and Q (the destination quad) can be had without ever
-// forming the intersection: its boundary consists of the parts of P's edges that lie inside Q and the parts of Q's edges that lie
-// inside P, and the area is the sum over those arcs of the signed spherical triangle (apex, start, end) for any fixed apex -- here
-// q0, so that the two edges of Q that meet in q0 contribute nothing.  The part of a great-circle edge A -> B inside a convex polygon
-// is ONE parameter interval of the chord A + t (B - A): every bounding plane cuts it at t = dA / (dA - dB) (linear in t), so an edge
-// is a handful of dot products and at most two unit vectors; nothing is indexed at run time but P's own vertices, which sit in LDS
-// read-only ([vertex][component][lane]: valence slots instead of valence + 4).
-// Coincident edges (a cell edge on a grid line) must be counted ONCE: P's edges are tested against Q's closed half-spaces (d >= -eps,
-// the clip's own tolerance), Q's edges against P's OPEN ones (d > +eps).
-// The arithmetic differs from the clip's (every crossing point comes from original vertices, none from an earlier clip), so the
-// weights differ from "cons_clip" 0 in their last digits; both are compared with the oracle and the 50-digit goldens.
-__device__ __forceinline__ dv3 chord_point(dv3 A, dv3 B, double dA, double dB) {
-  // the point of the great circle through A and B where the plane's d vanishes: A dB - B dA, pointing to the side of the arc
-  dv3 X = A * dB - B * dA;
-  const double sgn = (dB - dA) > 0.0 ? 1.0 : -1.0;
-  const double nn = sqrt(dot3(X, X));
-  return nn > 0.0 ? X * (sgn / nn) : A;
-}
-#define AREA_NT 64
-__global__ __launch_bounds__(AREA_NT) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_conserve_area_pairs(int64_t npairs, const int32_t *__restrict__ pair_c, const int32_t *__restrict__ pair_p,
-                                                                 int maxEdges, const int32_t *__restrict__ voc, const double *__restrict__ vx,
-                                                                 const double *__restrict__ vy, const double *__restrict__ vz,
-                                                                 const uint8_t *__restrict__ flip, int nx, const double *__restrict__ qx,
-                                                                 const double *__restrict__ qy, const double *__restrict__ qz,
-                                                                 const double *__restrict__ qarea, int cb, double *__restrict__ pair_val,
-                                                                 int32_t *__restrict__ count) {
-  extern __shared__ double area_lds[];   // [cb][3][AREA_NT]: the source polygon, read-only once staged
-  const int64_t t = blockIdx.x * (int64_t)AREA_NT + threadIdx.x;
-  if (t >= npairs) return;
-  const LdsPoly L{area_lds + threadIdx.x, cb};
-  const int64_t c = pair_c[t], p = pair_p[t];
-  int32_t vid[CONS_MAXV];
-#pragma unroll
-  for (int k = 0; k < CONS_MAXV; ++k) vid[k] = k < maxEdges ? voc[c * maxEdges + k] : 0;
-  const bool rev = flip[c] != 0;
-  int ntot = 0, vsafe = 0;
-#pragma unroll
-  for (int k = 0; k < CONS_MAXV; ++k) {
-    if (vid[k] > 0) {
-      ++ntot;
-      if (vsafe == 0) vsafe = vid[k];
-    }
-  }
-  int n = 0;
-  if (vsafe > 0 && ntot <= cb) {
-    // four vertices' coordinates in flight at a time (all twelve at once, as the clip kernel has them, would cost this kernel a
-    // wavefront per SIMD in registers)
-#pragma unroll
-    for (int k0 = 0; k0 < CONS_MAXV; k0 += 4) {
-      if (k0 >= maxEdges) break;
-      dv3 vc[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t v = (vid[k0 + k] > 0 ? vid[k0 + k] : vsafe) - 1;
-        vc[k] = dv3{vx[v], vy[v], vz[v]};
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (vid[k0 + k] > 0) {
-          L.set(0, rev ? ntot - 1 - n : n, vc[k]);
-          ++n;
-        }
-    }
-  }
-  const int i = (int)(p % nx), j = (int)(p / nx), nxc = nx + 1;
-  const int64_t k00 = (int64_t)j * nxc + i;
-  double aq = qarea[p];
-  // the quad counter-clockwise: corner k of the oriented quad (registers are dear here: corners are re-read where they are needed)
-  const bool swp = aq < 0.0;
-  aq = fabs(aq);
-  auto corner = [&](int k) -> dv3 {
-    const int kk = swp ? (4 - k) & 3 : k;   // 0, 3, 2, 1 when the stored order is clockwise
-    const int64_t q = k00 + (kk == 1 || kk == 2 ? 1 : 0) + (kk >= 2 ? nxc : 0);
-    return dv3{qx[q], qy[q], qz[q]};
-  };
-  double ar = 0.0;
-  if (aq > 0.0 && n >= 3) {
-    const dv3 q0 = corner(0);
-    double sa = 0.0;
-    const dv3 first = L.get(0, 0);
-    {
-      // (1) the parts of P's edges inside Q.  Q's four closed half-spaces: normals in difference form qa x (qb - qa), as the clip takes
-      // them; a collapsed side bounds nothing (its normal is set to zero: every d is 0 >= -0)
-      dv3 N0, N1, N2, N3;
-      double e0, e1, e2, e3;
-      {
-        const dv3 q1 = corner(1), q2 = corner(2), q3 = corner(3);
-        const dv3 s0 = q1 - q0, s1 = q2 - q1, s2 = q3 - q2, s3 = q0 - q3;
-        const dv3 z = dv3{0.0, 0.0, 0.0};
-        N0 = dot3(s0, s0) < 1e-24 ? z : cross3(q0, s0);
-        N1 = dot3(s1, s1) < 1e-24 ? z : cross3(q1, s1);
-        N2 = dot3(s2, s2) < 1e-24 ? z : cross3(q2, s2);
-        N3 = dot3(s3, s3) < 1e-24 ? z : cross3(q3, s3);
-        e0 = 1e-15 * sqrt(dot3(N0, N0)); e1 = 1e-15 * sqrt(dot3(N1, N1)); e2 = 1e-15 * sqrt(dot3(N2, N2)); e3 = 1e-15 * sqrt(dot3(N3, N3));
-      }
-      dv3 A = first;
-      double a0 = dot3(N0, A), a1 = dot3(N1, A), a2 = dot3(N2, A), a3 = dot3(N3, A);
-      for (int k = 0; k < n; ++k) {
-        const dv3 B = (k + 1 == n) ? first : L.get(0, k + 1);
-        const double b0 = dot3(N0, B), b1 = dot3(N1, B), b2 = dot3(N2, B), b3 = dot3(N3, B);
-        // entry / exit of the chord: the latest plane it comes in through, the earliest it leaves through; the crossing points are
-        // formed once, from the (dA, dB) of those two planes
-        double t0 = 0.0, t1 = 1.0, ia0 = 0.0, ib0 = 0.0, ia1 = 0.0, ib1 = 0.0;
-        bool none = false;
-#define MPG_EDGE_VS_PLANE(da, db, eps)                                          \
-        {                                                                       \
-          const bool ia = (da) >= -(eps), ib = (db) >= -(eps);                  \
-          none = none || (!ia && !ib);                                          \
-          if (ia != ib) {                                                       \
-            const double tt = (da) / ((da) - (db));                             \
-            if (!ia && tt > t0) { t0 = tt; ia0 = (da); ib0 = (db); }            \
-            if (ia && tt < t1) { t1 = tt; ia1 = (da); ib1 = (db); }             \
-          }                                                                     \
-        }
-        MPG_EDGE_VS_PLANE(a0, b0, e0)
-        MPG_EDGE_VS_PLANE(a1, b1, e1)
-        MPG_EDGE_VS_PLANE(a2, b2, e2)
-        MPG_EDGE_VS_PLANE(a3, b3, e3)
-#undef MPG_EDGE_VS_PLANE
-        if (!none && t0 < t1) {
-          const dv3 X0 = t0 > 0.0 ? chord_point(A, B, ia0, ib0) : A, X1 = t1 < 1.0 ? chord_point(A, B, ia1, ib1) : B;
-          sa += sph_tri_area(q0, X0, X1);
-        }
-        A = B;
-        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-      }
-    }
-    // (2) the parts of Q's edges q1 -> q2 and q2 -> q3 inside P (open half-spaces); the two edges through the apex q0 contribute nothing
-    for (int e = 1; e <= 2; ++e) {
-      const dv3 C = corner(e), D = corner(e + 1);
-      const dv3 cd = D - C;
-      if (dot3(cd, cd) < 1e-24) continue;     // a collapsed side
-      double t0 = 0.0, t1 = 1.0, ia0 = 0.0, ib0 = 0.0, ia1 = 0.0, ib1 = 0.0;
-      bool none = false;
-      dv3 Pa = first;
-      for (int k = 0; k < n; ++k) {
-        const dv3 Pb = (k + 1 == n) ? first : L.get(0, k + 1);
-        const dv3 M = cross3(Pa, Pb - Pa);
-        const double mm = dot3(M, M);
-        if (mm > 0.0) {
-          const double eps = 1e-15 * sqrt(mm), dc = dot3(M, C), dd = dot3(M, D);
-          const bool ic = dc > eps, id = dd > eps;
-          none = none || (!ic && !id);
-          if (ic != id) {
-            const double tt = dc / (dc - dd);
-            if (!ic && tt > t0) { t0 = tt; ia0 = dc; ib0 = dd; }
-            if (ic && tt < t1) { t1 = tt; ia1 = dc; ib1 = dd; }
-          }
-        }
-        Pa = Pb;
-      }
-      if (!none && t0 < t1) {
-        const dv3 Y0 = t0 > 0.0 ? chord_point(C, D, ia0, ib0) : C, Y1 = t1 < 1.0 ? chord_point(C, D, ia1, ib1) : D;
-        sa += sph_tri_area(q0, Y0, Y1);
-      }
-    }
-    ar = sa > 0.0 ? sa : 0.0;
-  }
-  double ratio = 0.0;
-  if (ar > 1e-14 * aq) {
-    ratio = ar / aq;
-    atomicAdd(&count[p], 1);
-  }
-  pair_val[t] = ratio;
-}
-
 __global__ __launch_bounds__(256) void k_conserve_scatter_pairs(int64_t npairs, const int32_t *__restrict__ pair_c, const int32_t *__restrict__ pair_p,
                                                                 const double *__restrict__ pair_val, const int32_t *__restrict__ rowptr,
                                                                 int32_t *__restrict__ cursor, int32_t *__restrict__ col, double *__restrict__ val,
@@ -891,11 +722,7 @@ int mpg_k_store_conserve(mpg_mesh_s *m, mpg_grid_s *g, mpg_handle_s *h, hipStrea
   TmpBuf<int32_t> truncated;
   if ((rc = truncated.alloc(1, s))) return rc;
   MPG_HIP(hipMemsetAsync(truncated.p, 0, sizeof(int32_t), s));
-  if (npairs > 0 && mpg_cons_clip() == 1) {   // the boundary-integral form: the source polygon only, read-only
-    const size_t area_lds_bytes = sizeof(double) * nv * 3 * AREA_NT;
-    k_conserve_area_pairs<<<(unsigned)(((int64_t)npairs + AREA_NT - 1) / AREA_NT), AREA_NT, area_lds_bytes, s>>>(
-        npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, vx, vy, vz, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, nv, pair_val.p, count.p);
-  } else if (npairs > 0)
+  if (npairs > 0)
     k_conserve_clip_pairs<<<(unsigned)(((int64_t)npairs + CLIP_NT - 1) / CLIP_NT), CLIP_NT, clip_lds_bytes, s>>>(
         npairs, pair_c.p, pair_p.p, m->maxEdges, m->voc.p, vx, vy, vz, flip.p, nx, cor.x.p, cor.y.p, cor.z.p, qarea.p, cb,
         pair_val.p, count.p, truncated.p);

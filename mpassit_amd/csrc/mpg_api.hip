@@ -609,8 +609,7 @@ int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_stagge
   }
   StoreCtx ctx{src, dst, dst_staggerloc, regridmethod, src_meshloc};
   // the line type in force is part of what a bilinear handle IS: the two never share a cache entry
-  HandleKey key(src, src_meshloc, dst, dst_staggerloc, regridmethod + (regridmethod == MPG_REGRIDMETHOD_BILINEAR ? 16 * mpg_bilinear_linetype() : 0) +
-                                                        (regridmethod == MPG_REGRIDMETHOD_CONSERVE ? 32 * mpg_cons_clip() : 0));
+  HandleKey key(src, src_meshloc, dst, dst_staggerloc, regridmethod + (regridmethod == MPG_REGRIDMETHOD_BILINEAR ? 16 * mpg_bilinear_linetype() : 0));
   return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
     StoreCtx *x = (StoreCtx *)c;
     h->method = x->method;

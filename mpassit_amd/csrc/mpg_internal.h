@@ -413,7 +413,6 @@ int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina,
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);
 int mpg_store_boxes();         // "store_boxes" knob: 1 (default) index-space candidate boxes on projection-built grids, 0 pyramid walk only
-int mpg_cons_clip();           // "cons_clip" knob: 0 Sutherland-Hodgman clip in LDS, 1 boundary integral (k_conserve_area_pairs)
 int mpg_bilinear_linetype();   // "bilinear_linetype" knob: 0 ray from the centre (default), 1 along the triangle's normal
 int mpg_nearest_variant();
 void mpg_set_nearest_variant(int v);
