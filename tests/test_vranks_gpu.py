@@ -71,11 +71,12 @@ def _rehearse(m, g, V, expect_mode, dtype, lev_fast, own_streams, ownership="ali
     res = MC.run_virtual_ranks(V, body)
     groups, sends, recvs, allgathers = real.virtual_stats()
     for r, (info, local, out, gathered) in enumerate(res):
-        assert info["mode"] == expect_mode
+        assert expect_mode is None or info["mode"] == expect_mode
+        expect = info["mode"]
         plan = MC.plan_host(r, needed, m.nCells, ownership)          # the pure schedule (== dist.HaloSchedule, tests/test_comm_plan.py)
         assert (plan["mode"], plan["n_local"], tuple(plan["own"]), plan["base"], tuple(plan["own_pos"])) == (
             info["mode"], info["n_local"], tuple(info["own"]), info["base"], tuple(info["own_pos"]))
-        ids_local = np.arange(info["base"], info["base"] + info["n_local"]) if expect_mode == "range" else needed[r]
+        ids_local = np.arange(info["base"], info["base"] + info["n_local"]) if expect == "range" else needed[r]
         pos = torch.as_tensor(np.searchsorted(ids_local, needed[r]), device="cuda")
         ids = torch.as_tensor(needed[r].astype(np.int64), device="cuda")
         if lev_fast:
@@ -90,9 +91,9 @@ def _rehearse(m, g, V, expect_mode, dtype, lev_fast, own_streams, ownership="ali
         else:
             assert all(x is None for x in gathered)
     sent_total = sum(i["sent"] for i, *_ in res)
-    assert sent_total == sum(i["received"] for i, *_ in res) > 0
+    assert sent_total == sum(i["received"] for i, *_ in res) and (sent_total > 0 or expect_mode is None)
     # what really went through RCCL: the all-gathers of the V halo builds and nf gathers, one group per exchange and per gather
-    assert allgathers >= 2 + nf and groups == 1 + nf and sends == recvs and sends >= (V - 1) + nf * (V - 1) * nlev
+    assert allgathers >= 2 + nf and groups in (nf, 1 + nf) and sends == recvs and (expect_mode is None or sends >= (V - 1) + nf * (V - 1) * nlev)
     for rh, me, gr, vc in zip(rhs, meshes, grids, vcs):
         rh.release()
         me.destroy()
@@ -135,11 +136,15 @@ def test_owned_form_the_callers_own_partition(gpu_lib, V, partition, dtype, lev_
     its Regrid equals the single-GPU Regrid bit for bit, and with `need` only what neighbouring row blocks share has travelled."""
     import torch
 
-    from mpassit_amd import comm as MC, dist as mdist, regrid as R, synth
+    from mpassit_amd import synth
     m0, g = _case()
-    m = synth.shuffle_cells(m0, seed=11)
-    dt = getattr(torch, dtype)
-    nlev, nf = 6, 2
+    _rehearse_owned(synth.shuffle_cells(m0, seed=11), g, V, partition, getattr(torch, dtype), lev_fast)
+
+
+def _rehearse_owned(m, g, V, partition, dt, lev_fast, nlev=6, nf=2, strict=True):
+    import torch
+
+    from mpassit_amd import comm as MC, dist as mdist, regrid as R
     layout = R.LAYOUT_LEV_FAST if lev_fast else R.LAYOUT_CELL_FAST
     full = torch.as_tensor(np.random.default_rng(5).standard_normal((nf, nlev, m.nCells)), device="cuda").to(dt)
     src = full.permute(0, 2, 1).contiguous() if lev_fast else full.contiguous().view(nf * nlev, -1)
@@ -190,11 +195,11 @@ def test_owned_form_the_callers_own_partition(gpu_lib, V, partition, dtype, lev_
         assert torch.equal(local, src[:, torch.as_tensor(needed[r].astype(np.int64), device="cuda")])
         assert torch.equal(out, want[:, :, blocks[r][0]:blocks[r][1]])
     total_sent, total_needed = sum(x[0] for x in res), sum(x.size for x in needed)
-    assert total_sent == sum(x[1] for x in res) > 0
+    assert total_sent == sum(x[1] for x in res) and (total_sent > 0 or not strict)
     if partition == "need":
-        assert total_sent == total_needed - np.unique(np.concatenate(needed)).size and total_sent < 0.2 * total_needed
+        assert total_sent == total_needed - np.unique(np.concatenate(needed)).size and (total_sent < 0.2 * total_needed or not strict)
     groups, sends, recvs, allgathers = real.virtual_stats()
-    assert groups == 1 and sends == recvs > 0 and allgathers == 2
+    assert groups in (0, 1) and sends == recvs and (sends > 0 or not strict) and allgathers == 2
     for rh, me, gr, vc in zip(rhs, meshes, grids, vcs):
         rh.release()
         me.destroy()
