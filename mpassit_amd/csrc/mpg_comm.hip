@@ -1060,8 +1060,10 @@ int mpg_halo_destroy(mpg_halo H) {
 // Enqueued on hip_stream.
 int mpg_halo_exchange_dev(mpg_halo H, const void *own_dev, int64_t own_ld, void *local_dev, int nrows, int elem_bytes, void *hip_stream) {
   MPG_CHECK_INIT();
-  MPG_ARG(H && local_dev && nrows >= 1 && elem_bytes >= 4 && elem_bytes % 4 == 0 && elem_bytes <= (1 << 20), "mpg_halo_exchange_dev: bad argument");
+  MPG_ARG(H && nrows >= 1 && elem_bytes >= 4 && elem_bytes % 4 == 0 && elem_bytes <= (1 << 20), "mpg_halo_exchange_dev: bad argument");
   const HaloPlan &p = H->plan;
+  // (a rank whose rows reference nothing has an EMPTY local space and may pass NULL for it -- it still takes part: the others need its cells)
+  MPG_ARG(local_dev || p.n_local == 0, "mpg_halo_exchange_dev: local_dev is NULL");
   MPG_ARG(own_dev || p.own1 == p.own0, "mpg_halo_exchange_dev: own_dev is NULL");
   hipStream_t s = (hipStream_t)hip_stream;
   const int world = p.nranks, rank = p.rank;

@@ -230,6 +230,19 @@ def test_owned_form_refuses_a_partition_that_is_none(gpu_lib, regional_case, mon
     grid.destroy()
 
 
+@pytest.mark.parametrize("lev_fast", [False, True])
+def test_a_rank_that_needs_nothing_still_serves_its_cells(gpu_lib, lev_fast):
+    """The mesh covers the lower half of the grid only and its cells are numbered at random: with equal id blocks (para_range) the rank
+    of the top rows references no cell at all -- an EMPTY local space (NULL) -- yet owns a third of the cells the others need and takes
+    part in the exchange.  (Found by tools/vranks_soak.py: mpg_halo_exchange_dev refused the NULL.)"""
+    import torch
+
+    from mpassit_amd import synth, target_grid as tg
+    g = tg.define_target_grid_params("lambert", 121, 91, dx=30000.0, dy=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+    m = synth.shuffle_cells(synth.regional_mesh_for_lambert(g.proj, 121, 50, 12000, margin=0.0), seed=2)
+    _rehearse(m, g, 3, "compact", torch.float32, lev_fast=lev_fast, own_streams=True, ownership="para_range")
+
+
 def test_para_range_ownership(gpu_lib):
     import torch
     m, g = _case()
