@@ -82,3 +82,62 @@ def test_regrid_onto_a_file_defined_grid(oracle, gpu_lib, geo_file):
     rc.release()
     mesh.destroy()
     grid.destroy()
+
+
+def _write_geo(path, g, map_proj, nml):
+    from mpassit_amd import ncio
+    with ncio.Writer(path, format=2) as w:
+        for name, n in (("Time", None), ("west_east", g.nx), ("south_north", g.ny), ("west_east_stag", g.nx + 1), ("south_north_stag", g.ny + 1)):
+            w.def_dim(name, n)
+        for k, v in (("DX", np.float32(nml.get("dx", 0.0))), ("DY", np.float32(nml.get("dy", 0.0))), ("CEN_LAT", np.float32(nml["ref_lat"])),
+                     ("CEN_LON", np.float32(nml["ref_lon"])), ("TRUELAT1", np.float32(nml.get("truelat1", 0.0))), ("TRUELAT2", np.float32(nml.get("truelat2", nml.get("truelat1", 0.0)))),
+                     ("MOAD_CEN_LAT", np.float32(nml["ref_lat"])), ("STAND_LON", np.float32(nml.get("stand_lon", 0.0))), ("POLE_LAT", np.float32(90.0)),
+                     ("POLE_LON", np.float32(0.0)), ("MAP_PROJ", map_proj)):
+            w.put_att(k, v)
+        dims = {"M": ("Time", "south_north", "west_east"), "U": ("Time", "south_north", "west_east_stag"), "V": ("Time", "south_north_stag", "west_east")}
+        data = {"XLAT_M": (g.lat, "M"), "XLONG_M": (g.lon, "M"), "XLAT_U": (g.lat_u, "U"), "XLONG_U": (g.lon_u, "U"), "XLAT_V": (g.lat_v, "V"),
+                "XLONG_V": (g.lon_v, "V"), "MAPFAC_M": (np.ones_like(g.lat), "M"), "MAPFAC_U": (np.ones_like(g.lat_u), "U"),
+                "MAPFAC_V": (np.ones_like(g.lat_v), "V"), "HGT_M": (np.zeros_like(g.lat), "M")}
+        for name, (_, st) in data.items():
+            w.def_var(name, ncio.DOUBLE, dims[st])
+        for name, (a, _) in data.items():
+            w.put(name, a, rec=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,map_proj", [("polar", 2), ("mercator", 3), ("lat-lon", 6)])
+def test_file_grids_of_the_other_projections_claim_their_inverse(oracle, gpu_lib, tmp_path, kind, map_proj):
+    """Round 5: a WRF-style file of a polar stereographic (MAP_PROJ 2), Mercator (3) or lat-lon (6) grid: the file's projection attributes
+    with the grid's own first mass point as the known point are a claim the library checks; the bilinear and nearest Stores then search
+    through the inverse projection (same weights as the oracle's), the conservative Store keeps the pyramid (the CORNER stagger is
+    get_cell_corners', not the projection's)."""
+    from conftest import mesh_xyz
+    from _parity_helpers import assert_fixed_weights_equal, assert_nearest_equal
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    nml = {"polar": dict(dx=40000.0, dy=40000.0, ref_lat=80.0, ref_lon=-30.0, truelat1=70.0, stand_lon=-45.0),
+           "mercator": dict(dx=50000.0, dy=50000.0, ref_lat=10.0, ref_lon=120.0, truelat1=20.0, stand_lon=120.0),
+           "lat-lon": dict(dx=0.5, dy=0.5, ref_lat=-20.0, ref_lon=100.0, ref_x=1.0, ref_y=1.0, stand_lon=0.0)}[kind]
+    g = T.define_target_grid_params(kind, 81, 61, **nml)
+    path = tmp_path / ("geo_%d.nc" % map_proj)
+    _write_geo(path, g, map_proj, dict(nml, dx=nml["dx"] if kind != "lat-lon" else 55000.0))
+    t = T.define_target_grid_file(path)
+    assert t.proj.code == {2: T.PROJ_PS, 3: T.PROJ_MERC, 6: T.PROJ_LATLON}[map_proj] and t.proj.knowni == 1.0
+    m = synth.icosahedral_mesh(6)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(t)
+    cxyz, _ = mesh_xyz(oracle, m)
+    pxyz = oracle.lonlat_deg_to_xyz(t.lon, t.lat)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    assert rh.store_path == 1, kind
+    tri, _ = oracle.dual_triangles(m.verticesOnCell, m.nVertices, cxyz)
+    idx_o, w_o = oracle.bilinear_weights(cxyz, tri, pxyz)
+    assert_fixed_weights_equal(idx_o, w_o, *rh.weights(), tol=1e-11)
+    rh.release()
+    rn = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+    assert rn.store_path >= 1, kind
+    assert_nearest_equal(oracle.nearest(cxyz, pxyz), rn.weights()[0][:, 0], pxyz, cxyz, max_ties=2)
+    rn.release()
+    rc = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    assert rc.store_path == 0
+    rc.release()
+    mesh.destroy()
+    grid.destroy()
