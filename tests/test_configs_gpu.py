@@ -306,6 +306,41 @@ def test_stores_on_polar_stereographic_and_mercator_grids(gpu_lib, oracle, kind)
     grid.destroy()
 
 
+@pytest.mark.parametrize("kind", ["polar", "mercator"])
+def test_destaggering_on_polar_stereographic_and_mercator_grids(gpu_lib, oracle, kind):
+    """Grid -> Grid CENTER -> EDGE1 / EDGE2 (interp.F90:298,316) on the two other projections of the namelist: a polar stereographic grid
+    with the NORTH POLE inside a cell (the quads around it: longitudes of neighbouring centres jump by up to 180 degrees, the Newton
+    solve works on unit vectors and must not care) and a Mercator grid across the date line; weights against the oracle's, mapped masks
+    may differ on the hull-edge rim only."""
+    from mpassit_amd import regrid as R, target_grid as T
+    if kind == "polar":
+        g = T.define_target_grid_params("polar", 141, 121, dx=50000.0, dy=50000.0, ref_lat=89.0, ref_lon=25.0, truelat1=75.0, stand_lon=-100.0)
+    else:
+        g = T.define_target_grid_params("mercator", 161, 91, dx=70000.0, dy=70000.0, ref_lat=-8.0, ref_lon=179.0, truelat1=-15.0, stand_lon=179.0)
+    grid = R.Grid.from_target(g)
+    cxyz = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
+    rng = np.random.default_rng(8)
+    mass = rng.standard_normal((2, g.ny, g.nx))
+    for st_o, st_g, lon, lat in ((1, R.STAGGERLOC_EDGE1, g.lon_u, g.lat_u), (2, R.STAGGERLOC_EDGE2, g.lon_v, g.lat_v)):
+        idx_o, w_o = oracle.grid_bilinear(g.nx, g.ny, cxyz, st_o, oracle.lonlat_deg_to_xyz(lon, lat))
+        rh = R.regrid_store_grid(grid, st_g)
+        idx_g, w_g = rh.weights()
+        mo, mg = idx_o[:, 0] >= 0, idx_g[:, 0] >= 0
+        dis = (mo != mg).reshape(lon.shape)
+        rim = np.zeros(lon.shape, bool)
+        rim[0, :] = rim[-1, :] = rim[:, 0] = rim[:, -1] = True
+        assert not (dis & ~rim).any(), np.argwhere(dis & ~rim)[:5]
+        both = mo & mg
+        assert both.mean() > 0.95
+        same = (idx_o == idx_g).all(axis=1) & both
+        assert same.sum() > 0.99 * both.sum() and np.abs(w_o[same] - w_g[same]).max() < 1e-10
+        want = oracle.apply_fixed(idx_o, w_o, mass.reshape(2, -1), 2)
+        got = rh.regrid(mass.reshape(2, -1), nlev=2).reshape(2, -1)
+        assert np.abs(got[:, both] - want[:, both]).max() < 1e-9
+        rh.release()
+    grid.destroy()
+
+
 def test_coarse_mesh_under_a_fine_global_grid(gpu_lib, oracle):
     """642 cells (about 900 km apart) under a 0.5-degree global lat-lon grid: every dual triangle covers thousands of
     target points and spreads over hundreds of pyramid leaves, so the whole bilinear Store runs through the
