@@ -79,6 +79,29 @@ int rccl_load() {
       return MPG_ERR_HIP;                                                                          \
     }                                                                                              \
   } while (0)
+
+// an open ncclGroupStart is closed on every path out of the scope (a send that fails must not leave the communicator inside a group)
+struct GroupScope {
+  bool open = false;
+  ncclResult_t start() {
+    ncclResult_t r = R.GroupStart();
+    open = r == ncclSuccess;
+    return r;
+  }
+  ncclResult_t end() {
+    open = false;
+    return R.GroupEnd();
+  }
+  ~GroupScope() {
+    if (open) (void)R.GroupEnd();
+  }
+};
+struct EventScope {
+  hipEvent_t e = nullptr;
+  ~EventScope() {
+    if (e) (void)hipEventDestroy(e);
+  }
+};
 }  // namespace
 
 // One transfer of a grouped exchange as a rank states it: `ns` bytes from sbuf to `peer`, `nr` bytes from `peer` into rbuf
@@ -670,12 +693,13 @@ static int vg_allgather(mpg_comm_s *c, const void *send_host, int64_t nbytes, vo
 static int comm_exchange(mpg_comm_s *c, const std::vector<P2P> &ops, hipStream_t s) {
   if (!c->is_virtual) {
     if (c->nranks == 1) return MPG_SUCCESS;
-    MPG_NCCL(R.GroupStart());
+    GroupScope grp;
+    MPG_NCCL(grp.start());
     for (const P2P &o : ops) {
       if (o.ns) MPG_NCCL(R.Send(o.sbuf, o.ns, ncclChar, o.peer, c->comm, s));
       if (o.nr) MPG_NCCL(R.Recv(o.rbuf, o.nr, ncclChar, o.peer, c->comm, s));
     }
-    MPG_NCCL(R.GroupEnd());
+    MPG_NCCL(grp.end());
     return MPG_SUCCESS;
   }
   VGroup *g = c->vg;
@@ -723,26 +747,27 @@ static int comm_exchange(mpg_comm_s *c, const std::vector<P2P> &ops, hipStream_t
         // (Measured, round 5: handing RCCL each transfer on its own rank's stream inside one group left the receiving ranks'
         // streams unordered against the copy -- their unpack read the receive buffer before the data had landed.)
         hipStream_t lead = g->streams[0];
-        hipEvent_t ev = nullptr;
-        MPG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        EventScope evs;
+        MPG_HIP(hipEventCreateWithFlags(&evs.e, hipEventDisableTiming));
+        hipEvent_t ev = evs.e;
         for (int q = 1; q < V; ++q)
           if (g->streams[q] != lead) {
             MPG_HIP(hipEventRecord(ev, g->streams[q]));
             MPG_HIP(hipStreamWaitEvent(lead, ev, 0));
           }
-        MPG_NCCL(R.GroupStart());
+        GroupScope grp;
+        MPG_NCCL(grp.start());
         for (const Pair &p : pairs) {
           MPG_NCCL(R.Send(p.snd->sbuf, p.snd->ns, ncclChar, 0, g->comm, lead));
           MPG_NCCL(R.Recv(p.rcv->rbuf, p.rcv->nr, ncclChar, 0, g->comm, lead));
         }
-        MPG_NCCL(R.GroupEnd());
+        MPG_NCCL(grp.end());
         ++g->n_groups;
         g->n_send_calls += (int64_t)pairs.size();
         g->n_recv_calls += (int64_t)pairs.size();
         MPG_HIP(hipEventRecord(ev, lead));
         for (int q = 1; q < V; ++q)
           if (g->streams[q] != lead) MPG_HIP(hipStreamWaitEvent(g->streams[q], ev, 0));
-        MPG_HIP(hipEventDestroy(ev));
         return MPG_SUCCESS;
       });
 }
@@ -1008,13 +1033,25 @@ int mpg_halo_build_owned(mpg_comm c, mpg_handle h, int64_t n_cells, const int32_
       last = v;
     }
   }
+  {   // ... and cover what the rows reference: EVERY rank checks every rank's needs (all lists are here), so that all of them refuse
+      // together -- a rank that went on alone would wait in its first exchange for a peer that has already given up
+    std::vector<uint8_t> has((size_t)n_cells, 0);
+    for (int q = 0; q < world; ++q)
+      for (int64_t i = 0; i < n_own[q]; ++i) has[(size_t)ol[q][i]] = 1;
+    for (int q = 0; q < world; ++q)
+      for (int64_t i = 0; i < n_needed[q]; ++i)
+        if (nl[q][i] < 0 || nl[q][i] >= n_cells || !has[(size_t)nl[q][i]]) {
+          mpg_set_error("mpg_halo_build_owned: rank %d's rows reference cell %d, which no rank owns", q, nl[q][i]);
+          return MPG_ERR_INVALID_ARG;
+        }
+  }
   mpg_halo_s *H = new mpg_halo_s();
   H->comm = c;
   HaloPlan &p = H->plan;
   p.rank = rank;
   p.nranks = world;
   const int64_t orphan = plan_owned(p, n_needed.data(), nl.data(), n_own.data(), ol.data());
-  if (orphan >= 0) {
+  if (orphan >= 0) {   // (unreachable after the check above; kept as the plan's own guard)
     mpg_set_error("mpg_halo_build_owned: rank %d's rows reference cell %lld, which no rank owns", rank, (long long)orphan);
     delete H;
     return MPG_ERR_INVALID_ARG;

@@ -230,6 +230,46 @@ def test_owned_form_refuses_a_partition_that_is_none(gpu_lib, regional_case, mon
     grid.destroy()
 
 
+def test_every_rank_refuses_together_when_one_ranks_cell_has_no_owner(gpu_lib, monkeypatch):
+    """Two virtual ranks; a cell only rank 1's rows reference is left out of both owned lists.  BOTH ranks come back with the same error at
+    once (every rank checks every rank's needs): none goes on alone to wait in an exchange for a peer that has given up."""
+    import time
+
+    from mpassit_amd import _lib, comm as MC, dist as mdist, regrid as R
+    monkeypatch.setenv("MPG_COMM_TIMEOUT_S", "60")
+    m, g = _case(rows=41)
+    V = 2
+    real = MC.Comm(0, 1)
+    vcs = [real.virtual(r, V) for r in range(V)]
+    blocks = [mdist.row_block(g.ny, V, r) for r in range(V)]
+    grids = [R.Grid.from_target(g, rows=b) for b in blocks]
+    meshes = [R.Mesh.from_mpas(m, window_grid=grids[r]) for r in range(V)]
+    rhs = [R.regrid_store(meshes[r], grids[r], R.REGRIDMETHOD_BILINEAR) for r in range(V)]
+    needed = [rh.unique_sources() for rh in rhs]
+    only1 = np.setdiff1d(needed[1], needed[0])
+    lost = int(only1[only1.size // 2])
+    owned = [needed[0].astype(np.int32), np.setdiff1d(only1, [lost]).astype(np.int32)]
+    errs = [None] * V
+
+    def body(r):
+        try:
+            MC.Halo(vcs[r], rhs[r], m.nCells, owned_ids=owned[r])
+        except _lib.MpgError as e:
+            errs[r] = str(e)
+        return True
+
+    t0 = time.perf_counter()
+    MC.run_virtual_ranks(V, body, timeout=120.0)
+    assert time.perf_counter() - t0 < 20.0
+    assert all(e is not None and "rank 1's rows reference cell %d, which no rank owns" % lost in e for e in errs), errs
+    for rh, me, gr, vc in zip(rhs, meshes, grids, vcs):
+        rh.release()
+        me.destroy()
+        gr.destroy()
+        vc.destroy()
+    real.destroy()
+
+
 @pytest.mark.parametrize("lev_fast", [False, True])
 def test_a_rank_that_needs_nothing_still_serves_its_cells(gpu_lib, lev_fast):
     """The mesh covers the lower half of the grid only and its cells are numbered at random: with equal id blocks (para_range) the rank
