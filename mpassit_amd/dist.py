@@ -151,6 +151,14 @@ class HaloSchedule:
         peer's cells arrive in id order and are scattered to their positions among them."""
         needed_ids, owned_ids = np.asarray(needed_ids, np.int32), np.asarray(owned_ids, np.int32)
         lists = all_gather_object((needed_ids, owned_ids))
+        # every rank checks EVERY rank's needs (all lists are here), so that all refuse together -- a rank that went on alone would wait in
+        # its first exchange for a peer that has given up (mpg_halo_build_owned does the same)
+        everyones = np.unique(np.concatenate([np.asarray(o, np.int32) for _, o in lists]))
+        for q in range(world):
+            theirs = np.asarray(lists[q][0], np.int32)
+            orphan = np.setdiff1d(theirs, everyones, assume_unique=True)
+            if orphan.size:
+                raise ValueError("rank %d's rows reference cell %d, which no rank owns" % (q, int(orphan[0])))
         s = HaloSchedule(rank, world, "owned", int(needed_ids.size), (0, int(owned_ids.size)))
         s.owned_ids = owned_ids
         seen = np.zeros(needed_ids.size, bool)
