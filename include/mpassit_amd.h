@@ -69,7 +69,9 @@ int mpg_device_info(char *arch_buf, int buf_len, int *n_cu, int64_t *hbm_bytes);
 /* ---- ESMF_MeshCreate (model_grid.F90:488-497) ---------------------------------------------------
  * Arrays exactly as read from the MPAS file (model_grid.F90:354-417): lat/lon in RADIANS, the
  * deg conversion + (-180,180] wrap of :450-454,464-468 happens inside; verticesOnCell is
- * [nCells][maxEdges], 1-based, 0-padded (:448,479).  Elements = cells, nodes = vertices. */
+ * [nCells][maxEdges], 1-based, 0-padded (:448,479).  Elements = cells, nodes = vertices.
+ * Refused with MPG_ERR_INVALID_ARG (and the offending index in mpg_last_error) before any geometry kernel runs: a vertex number
+ * beyond nVertices, a coordinate that is NaN / Inf, a latitude beyond +-pi/2 (degrees handed over as radians). */
 int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const double *latCell,
                     const double *lonCell, const double *latVertex, const double *lonVertex,
                     const int32_t *verticesOnCell, mpg_mesh *out);
@@ -101,7 +103,9 @@ int mpg_mesh_window_info(mpg_mesh mesh, int64_t *cell_first, int64_t *cell_count
  *   in the regional case; the extra EDGE1 / CORNER column (index nx) duplicates column 0 one period later
  *   (ESMF's periodic staggers hold only the first nx columns).  Only Grid -> Grid RegridStore reads the flag.
  * OR in MPG_GRID_NO_SOUTH_POLE / MPG_GRID_NO_NORTH_POLE for a row block of a periodic grid that does not
- *   touch that pole (multi-GPU row sharding). */
+ *   touch that pole (multi-GPU row sharding).
+ * A coordinate that is NaN / Inf (or |lat| > 180) is refused with MPG_ERR_INVALID_ARG and the point's index; latitudes a little beyond
+ * the pole (the corner row of a global lat-lon grid) are angles and pass. */
 enum { MPG_GRID_PERIODIC_I = 1, MPG_GRID_NO_SOUTH_POLE = 2, MPG_GRID_NO_NORTH_POLE = 4 };
 int mpg_grid_create(int nx, int ny, int periodic_i, const double *lon_center, const double *lat_center,
                     const double *lon_corner, const double *lat_corner, const double *lon_edge1,

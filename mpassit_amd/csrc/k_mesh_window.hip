@@ -314,22 +314,25 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
     if ((rc = m->voc.alloc((size_t)m->cwn * m->maxEdges))) return rc;
     MPG_HIP(hipMemcpyAsync(m->voc.p, verticesOnCell + c0 * m->maxEdges, sizeof(int32_t) * (size_t)m->cwn * m->maxEdges, hipMemcpyHostToDevice, s));
     int64_t v0 = 0, v1 = nV;
-    if (!whole) {
+    {   // the vertex numbers the rows reference: the window's vertex range, and a check of the table itself (a number beyond nVertices
+        // would be read as a coordinate index by every geometry kernel)
       MPG_HIP(hipMemsetAsync(stats.p, 0xff, sizeof(unsigned long long), s));
       MPG_HIP(hipMemsetAsync(stats.p + 1, 0, sizeof(unsigned long long), s));
       k_vertex_range<<<(unsigned)std::min<int64_t>((m->cwn * m->maxEdges + 255) / 256, 4096), 256, 0, s>>>(m->cwn * m->maxEdges, m->voc.p, stats.p);
       MPG_HIP(hipGetLastError());
       MPG_HIP(hipMemcpyAsync(hs, stats.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
       MPG_HIP(hipStreamSynchronize(s));
-      if (hs[1] == 0) {
-        v0 = v1 = 0;
-      } else {
-        v0 = (int64_t)hs[0];
-        v1 = (int64_t)hs[1];
-      }
-      if (v1 > nV) {
-        mpg_set_error("mpg_mesh_create_window: verticesOnCell refers to vertex %lld of %lld", (long long)v1, (long long)nV);
+      if ((int64_t)hs[1] > nV) {
+        mpg_set_error("mpg_mesh_create_window: verticesOnCell refers to vertex %lld of %lld", (long long)hs[1], (long long)nV);
         return MPG_ERR_INVALID_ARG;
+      }
+      if (!whole) {
+        if (hs[1] == 0) {
+          v0 = v1 = 0;
+        } else {
+          v0 = (int64_t)hs[0];
+          v1 = (int64_t)hs[1];
+        }
       }
     }
     if (!whole && (v1 - v0) > (nV * 7) / 10) {   // numbering without bands (e.g. a Morton-ordered global mesh): the covering ranges are
@@ -349,7 +352,18 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
       if ((rc = tmp.alloc(2 * (size_t)m->vwn, s))) return rc;
       MPG_HIP(hipMemcpyAsync(tmp.p, lonVertex + v0, sizeof(double) * m->vwn, hipMemcpyHostToDevice, s));
       MPG_HIP(hipMemcpyAsync(tmp.p + m->vwn, latVertex + v0, sizeof(double) * m->vwn, hipMemcpyHostToDevice, s));
-      if ((rc = mpg_k_mesh_coords_dev(m->vwn, tmp.p, tmp.p + m->vwn, m->vert.x.p, m->vert.y.p, m->vert.z.p, s))) return rc;
+      TmpBuf<unsigned long long> cbad;
+      if ((rc = cbad.alloc(1, s))) return rc;
+      MPG_HIP(hipMemsetAsync(cbad.p, 0xff, sizeof(unsigned long long), s));
+      if ((rc = mpg_k_mesh_coords_dev(m->vwn, tmp.p, tmp.p + m->vwn, m->vert.x.p, m->vert.y.p, m->vert.z.p, cbad.p, s))) return rc;
+      unsigned long long hb = ~0ull;
+      MPG_HIP(hipMemcpyAsync(&hb, cbad.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+      MPG_HIP(hipStreamSynchronize(s));
+      if (hb != ~0ull) {
+        mpg_set_error("mpg_mesh_create_window: vertex %lld has latitude %.17g, longitude %.17g -- not angles in RADIANS (|lat| <= pi/2, finite)",
+                      (long long)(v0 + (int64_t)hb), latVertex[v0 + (int64_t)hb], lonVertex[v0 + (int64_t)hb]);
+        return MPG_ERR_INVALID_ARG;
+      }
     }   // tmp goes back to the pool in stream order; the host arrays are in use until the synchronisation that ends every path below
     if ((rc = m->tri.alloc(3 * (size_t)m->vwn))) return rc;
     TmpBuf<int32_t> cnt;
@@ -376,6 +390,27 @@ int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, con
     }
     return mpg_k_tri_canon(m, cnt.p, s);
   }
+}
+
+// mpg_mesh_create's check of the table it was handed: a vertex number beyond nVertices would be read as a coordinate index by every
+// geometry kernel (numbers <= 0 are padding, model_grid.F90:448)
+int mpg_k_voc_check(const int32_t *voc_dev, int64_t nent, int64_t nV, const char *who, hipStream_t s) {
+  if (nent <= 0) return MPG_SUCCESS;
+  int rc;
+  TmpBuf<unsigned long long> st;
+  if ((rc = st.alloc(2, s))) return rc;
+  MPG_HIP(hipMemsetAsync(st.p, 0xff, sizeof(unsigned long long), s));
+  MPG_HIP(hipMemsetAsync(st.p + 1, 0, sizeof(unsigned long long), s));
+  k_vertex_range<<<(unsigned)std::min<int64_t>((nent + 255) / 256, 4096), 256, 0, s>>>(nent, voc_dev, st.p);
+  MPG_HIP(hipGetLastError());
+  unsigned long long hs[2] = {0, 0};
+  MPG_HIP(hipMemcpyAsync(hs, st.p, sizeof(hs), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  if ((int64_t)hs[1] > nV) {
+    mpg_set_error("%s: verticesOnCell refers to vertex %lld of %lld", who, (long long)hs[1], (long long)nV);
+    return MPG_ERR_INVALID_ARG;
+  }
+  return MPG_SUCCESS;
 }
 
 // mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)

@@ -16,10 +16,12 @@
 // then degrees -> unit sphere (ESMF_COORDSYS_SPH_DEG).
 __global__ __launch_bounds__(256) void k_mesh_coords(int64_t n, const double *__restrict__ lon_rad,
                                                      const double *__restrict__ lat_rad, double *__restrict__ x,
-                                                     double *__restrict__ y, double *__restrict__ z) {
+                                                     double *__restrict__ y, double *__restrict__ z, unsigned long long *__restrict__ bad) {
   const double PI = 3.14159265358979323846;  // == 4*atan(1) in float64
   const double d2r = 3.141592653589793 / 180.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // a coordinate that is no angle (NaN / Inf, or a latitude beyond the poles: degrees handed over as radians) is reported, first index
+    if (bad && (!(fabs(lat_rad[i]) <= 1.5707963267948966 + 1e-6) || !(fabs(lon_rad[i]) <= 1e3))) atomicMin(bad, (unsigned long long)i);
     double lo = lon_rad[i] * 180.0 / PI;
     if (lo > 180.0) lo -= 360.0;
     double la = lat_rad[i] * 180.0 / PI;
@@ -35,9 +37,11 @@ __global__ __launch_bounds__(256) void k_mesh_coords(int64_t n, const double *__
 }
 __global__ __launch_bounds__(256) void k_grid_coords(int64_t n, const double *__restrict__ lon_deg,
                                                      const double *__restrict__ lat_deg, double *__restrict__ x,
-                                                     double *__restrict__ y, double *__restrict__ z) {
+                                                     double *__restrict__ y, double *__restrict__ z, unsigned long long *__restrict__ bad) {
   const double d2r = 3.141592653589793 / 180.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // (a corner row of a global lat-lon grid lies half a cell BEYOND the pole, e.g. 90.5: such values are angles and pass)
+    if (bad && (!(fabs(lat_deg[i]) <= 180.0) || !(fabs(lon_deg[i]) <= 1e5))) atomicMin(bad, (unsigned long long)i);
     double lo = lon_deg[i] * d2r, la = lat_deg[i] * d2r;
     double sl, cl, so, co;
     sincos(la, &sl, &cl);
@@ -62,21 +66,34 @@ static int coords_common(bool mesh, int64_t n, const double *lon, const double *
   if (n == 0) return MPG_SUCCESS;
   TmpBuf<double> tmp;
   if ((rc = tmp.alloc(2 * (size_t)n, s))) return rc;
+  TmpBuf<unsigned long long> bad;
+  if ((rc = bad.alloc(1, s))) return rc;
+  MPG_HIP(hipMemsetAsync(bad.p, 0xff, sizeof(unsigned long long), s));
   // pageable host arrays through the runtime's own staging: 45-50 GB/s once it is warm (a threaded pinned-buffer pipeline of
   // ours measured SLOWER: mpg_mesh_create of configuration 4 7.9-8.8 ms against 4.5, profiles/r04_first_call.txt)
   MPG_HIP(hipMemcpyAsync(tmp.p, lon, sizeof(double) * n, hipMemcpyHostToDevice, s));
   MPG_HIP(hipMemcpyAsync(tmp.p + n, lat, sizeof(double) * n, hipMemcpyHostToDevice, s));
   if (mesh)
-    k_mesh_coords<<<grid_for(n), 256, 0, s>>>(n, tmp.p, tmp.p + n, out.x.p, out.y.p, out.z.p);
+    k_mesh_coords<<<grid_for(n), 256, 0, s>>>(n, tmp.p, tmp.p + n, out.x.p, out.y.p, out.z.p, bad.p);
   else
-    k_grid_coords<<<grid_for(n), 256, 0, s>>>(n, tmp.p, tmp.p + n, out.x.p, out.y.p, out.z.p);
+    k_grid_coords<<<grid_for(n), 256, 0, s>>>(n, tmp.p, tmp.p + n, out.x.p, out.y.p, out.z.p, bad.p);
   MPG_HIP(hipGetLastError());
+  unsigned long long hb = ~0ull;
+  MPG_HIP(hipMemcpyAsync(&hb, bad.p, sizeof(hb), hipMemcpyDeviceToHost, s));
   MPG_HIP(hipStreamSynchronize(s));
   tmp.free();
+  if (hb != ~0ull) {
+    mpg_set_error(mesh ? "mesh coordinates: point %lld has latitude %.17g, longitude %.17g -- not angles in RADIANS (|lat| <= pi/2, finite)"
+                       : "grid coordinates: point %lld has latitude %.17g, longitude %.17g -- not angles in DEGREES (finite, |lat| <= 180)",
+                  (long long)hb, lat[hb], lon[hb]);
+    return MPG_ERR_INVALID_ARG;
+  }
   return MPG_SUCCESS;
 }
-int mpg_k_mesh_coords_dev(int64_t n, const double *lon_rad_dev, const double *lat_rad_dev, double *x, double *y, double *z, hipStream_t s) {
-  if (n > 0) k_mesh_coords<<<grid_for(n), 256, 0, s>>>(n, lon_rad_dev, lat_rad_dev, x, y, z);
+// bad_dev (may be NULL): one word preset to ~0, receives the first index whose coordinates are no angles
+int mpg_k_mesh_coords_dev(int64_t n, const double *lon_rad_dev, const double *lat_rad_dev, double *x, double *y, double *z, unsigned long long *bad_dev,
+                          hipStream_t s) {
+  if (n > 0) k_mesh_coords<<<grid_for(n), 256, 0, s>>>(n, lon_rad_dev, lat_rad_dev, x, y, z, bad_dev);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

@@ -346,7 +346,7 @@ int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const doubl
     mpg_mesh_destroy(m);
     return MPG_ERR_HIP;
   }
-  if ((rc = mpg_k_dual_triangles(m, s))) {
+  if ((rc = mpg_k_voc_check(m->voc.p, nCells * maxEdges, nVertices, "mpg_mesh_create", s)) || (rc = mpg_k_dual_triangles(m, s))) {
     mpg_mesh_destroy(m);
     return rc;
   }

@@ -344,7 +344,9 @@ int mpg_k_tri_scatter(mpg_mesh_s *m, int32_t *cnt, hipStream_t s);
 int mpg_k_tri_canon(mpg_mesh_s *m, const int32_t *cnt, hipStream_t s);
 // k_mesh_window.hip: cuts the mesh to what grid `g` can see (fills cw0 .. geo_margin, voc, vert, tri of `m`, whose `cell` holds all centres)
 int mpg_k_mesh_window(mpg_mesh_s *m, mpg_grid_s *g, const double *latVertex, const double *lonVertex, const int32_t *verticesOnCell, hipStream_t s);
-int mpg_k_mesh_coords_dev(int64_t n, const double *lon_rad_dev, const double *lat_rad_dev, double *x, double *y, double *z, hipStream_t s);
+int mpg_k_voc_check(const int32_t *voc_dev, int64_t nent, int64_t nV, const char *who, hipStream_t s);
+int mpg_k_mesh_coords_dev(int64_t n, const double *lon_rad_dev, const double *lat_rad_dev, double *x, double *y, double *z, unsigned long long *bad_dev,
+                          hipStream_t s);
 int mpg_k_build_pyramid(const PointSet &pts, int nx, int ny, Pyramid &pyr, hipStream_t s);
 int mpg_k_build_cell_pyramid(const PointSet &corner, int nx, int ny, Pyramid &pyr, hipStream_t s);
 PyramidView mpg_pyr_view(const Pyramid &p);

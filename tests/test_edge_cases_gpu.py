@@ -230,3 +230,57 @@ def test_vertices_on_cell_as_wide_as_mpas_writes_it(gpu_lib, regional_case):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert res[0][0][1].size > 0
+
+
+@pytest.mark.parametrize("windowed", [False, True])
+def test_a_corrupt_mesh_is_refused_at_creation(gpu_lib, regional_case, windowed):
+    """What a damaged file hands over must be caught before any geometry kernel uses it as an index or an angle: a vertex number beyond
+    nVertices (would be read as a coordinate index), a NaN coordinate, latitudes in degrees where radians are expected.  With and
+    without a geometry window; the mesh as it is still builds afterwards."""
+    from mpassit_amd import regrid as R
+    from mpassit_amd._lib import MpgError
+    m, g = regional_case
+    grid = R.Grid.from_target(g)
+    wg = grid if windowed else None
+
+    def make(**over):
+        a = dict(latCell=m.latCell, lonCell=m.lonCell, latVertex=m.latVertex, lonVertex=m.lonVertex, verticesOnCell=m.verticesOnCell)
+        a.update(over)
+        return R.Mesh(a["latCell"], a["lonCell"], a["latVertex"], a["lonVertex"], a["verticesOnCell"], window_grid=wg)
+
+    mid = m.nCells // 2
+    voc = m.verticesOnCell.copy()
+    voc[mid, 1] = m.nVertices + 5
+    with pytest.raises(MpgError, match="verticesOnCell refers to vertex %d of %d" % (m.nVertices + 5, m.nVertices)):
+        make(verticesOnCell=voc)
+    lat = m.latCell.copy()
+    lat[mid] = np.nan
+    with pytest.raises(MpgError, match="point %d has latitude nan.*RADIANS" % mid):
+        make(latCell=lat)
+    lon = m.lonVertex.copy()
+    vmid = int(m.verticesOnCell[mid, 0]) - 1
+    lon[vmid] = np.inf
+    with pytest.raises(MpgError, match="%d has latitude .* longitude inf.*RADIANS" % vmid):
+        make(lonVertex=lon)
+    with pytest.raises(MpgError, match="RADIANS"):
+        make(latCell=np.degrees(m.latCell), lonCell=np.degrees(m.lonCell))
+    mesh = make()
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    assert rh.nnz > 0
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
+
+
+def test_a_grid_with_coordinates_that_are_no_angles_is_refused(gpu_lib, regional_case):
+    from mpassit_amd import regrid as R
+    from mpassit_amd._lib import MpgError
+    _, g = regional_case
+    lat = g.lat.copy()
+    lat[3, 4] = np.nan
+    with pytest.raises(MpgError, match="point %d has latitude nan.*DEGREES" % (3 * g.nx + 4)):
+        R.Grid(g.lon, lat, g.lon_c, g.lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v)
+    lat_c = g.lat_c.copy()
+    lat_c[0, 0] = 1e30
+    with pytest.raises(MpgError, match="DEGREES"):
+        R.Grid(g.lon, g.lat, g.lon_c, lat_c, g.lon_u, g.lat_u, g.lon_v, g.lat_v)
