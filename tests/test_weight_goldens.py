@@ -179,7 +179,8 @@ def test_quad_goldens_through_the_c_abi(gpu_lib):
     assert worst < 5e-12
 
 
-@pytest.mark.parametrize("script,fixture", [("make_projection_goldens.py", "projection_wide.json"), ("make_weight_goldens.py", "weights_hp.json")])
+@pytest.mark.parametrize("script,fixture", [("make_projection_goldens.py", "projection_wide.json"), ("make_weight_goldens.py", "weights_hp.json"),
+                                            ("make_store_goldens.py", "store_hp.json")])
 def test_golden_generators_reproduce_the_committed_fixtures(tmp_path, script, fixture):
     """The fixtures are what their committed generators write, byte for byte (mpmath, fixed seeds)."""
     import subprocess
