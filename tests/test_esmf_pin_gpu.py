@@ -71,3 +71,38 @@ def test_a_foreign_weight_file_is_compared_within_the_north_star_tolerances(gpu_
         T._compare_case(cs, "conserve_center", os.path.join(d, "weights_conserve_center.nc"), verbose=False)
     cs.mesh.destroy()
     cs.grid.destroy()
+
+
+def test_weight_files_made_from_the_50_digit_goldens_compare_clean(gpu_lib, tmp_path):
+    """A stand-in for ESMF's files that shares no code with the library OR the oracle: the brute-force 50-digit Stores of
+    tests/golden/store_hp.json (case 1: regional mesh, rim, unmapped points) written in ESMF_RegridWeightGen's layout and put through
+    `compare` -- the whole kit, files to verdict, against an independent answer."""
+    from mpassit_amd import esmf_pin as E, target_grid as tg
+    from test_store_goldens import cases
+    T = _tool()
+    case = cases()[0]
+    g = tg.define_target_grid_params("lambert", 18, 14, dx=120000.0, dy=120000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5,
+                                     stand_lon=-97.5)
+    assert np.array_equal(g.lon, case.lon) and np.array_equal(g.lat_c, case.lat_c)
+    d = str(tmp_path)
+    E.export_case(d, case.mesh, g, name="golden")
+    n_a, n_b = case.mesh.nCells, case.nx * case.ny
+    row, col, S = [], [], []
+    for p, e in enumerate(case.expect["bilinear"]):
+        if e is not None:
+            assert "tie" not in e
+            row += [p + 1] * 3
+            col += [c + 1 for c in e["col"]]
+            S += e["w"]
+    E.write_weight_file(os.path.join(d, "weights_bilinear_center.nc"), row, col, S, n_a, n_b, "bilinear")
+    E.write_weight_file(os.path.join(d, "weights_neareststod_center.nc"), np.arange(1, n_b + 1), [e["col"] + 1 for e in case.expect["nearest"]], np.ones(n_b),
+                        n_a, n_b, "neareststod")
+    cons = case.expect["conserve"]
+    E.write_weight_file(os.path.join(d, "weights_conserve_center.nc"), [r + 1 for r, _, _ in cons], [c + 1 for _, c, _ in cons], [v for _, _, v in cons],
+                        n_a, n_b, "conserve")
+    cs = T._Case(d)
+    for name in ("bilinear_center", "neareststod_center", "conserve_center"):
+        rep = T._compare_case(cs, name, os.path.join(d, cs.info["cases"][name]["weights"]), verbose=True)
+        assert rep["ok"] and rep["max_abs_diff_any"] <= 2e-13 and rep["mapped_only_ours"] == rep["mapped_only_theirs"] == 0, rep
+    cs.mesh.destroy()
+    cs.grid.destroy()
