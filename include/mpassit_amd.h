@@ -456,6 +456,11 @@ int mpg_handle_store_path(mpg_handle rh, int *candidates);
  * Diagnostics (the tests use them to assert that a case built to force a branch did take it); the weights do not depend on them. */
 int mpg_handle_store_stats(mpg_handle rh, int64_t *stats_host, int n);
 
+/* Test hook: the library's own device-wide primitives (csrc/k_prims.hip; they took rocPRIM's place in round 5) on host arrays --
+ * out_host[i] = in_host[0] + ... + in_host[i - 1] (int32, exclusive; out_host may be NULL) and *sum_host = the 64-bit sum (may be NULL).
+ * The Stores use them on device counts; this entry exists so that a test can ask them directly at awkward sizes. */
+int mpg_debug_scan_i32(const int32_t *in_host, int64_t n, int32_t *out_host, long long *sum_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1143,4 +1143,34 @@ int mpg_post_ptop_parts_dev(const double *p_hyd_dev, int nlev, int64_t n_pts, do
   return mpg_k_post_ptop_parts(p_hyd_dev, nlev, n_pts, vmax_host, candmin_host, has_cand_host, (hipStream_t)hip_stream);
 }
 
+// Test hook (include/mpassit_amd.h): the device-wide primitives of k_prims.hip on host arrays
+int mpg_debug_scan_i32(const int32_t *in_host, int64_t n, int32_t *out_host, long long *sum_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(n >= 0 && (in_host || n == 0), "mpg_debug_scan_i32: bad argument");
+  if (sum_host) *sum_host = 0;
+  if (n == 0) return MPG_SUCCESS;
+  hipStream_t s = g_stream;
+  TmpBuf<int32_t> in, out;
+  TmpBuf<long long> sum;
+  int rc;
+  if ((rc = in.alloc((size_t)n, s)) || (rc = out.alloc((size_t)n, s)) || (rc = sum.alloc(1, s))) return rc;
+  MPG_HIP(hipMemcpyAsync(in.p, in_host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+  if ((rc = mpg_sum_i32_i64(in.p, n, sum.p, s)) || (rc = mpg_scan_excl_i32(in.p, out.p, n, s))) return rc;
+  if (out_host) MPG_HIP(hipMemcpyAsync(out_host, out.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+  if (sum_host) MPG_HIP(hipMemcpyAsync(sum_host, sum.p, sizeof(long long), hipMemcpyDeviceToHost, s));
+  MPG_HIP(hipStreamSynchronize(s));
+  // in place (in == out) is what the Stores do: the same answer
+  if (out_host) {
+    if ((rc = mpg_scan_excl_i32(in.p, in.p, n, s))) return rc;
+    std::vector<int32_t> again((size_t)n);
+    MPG_HIP(hipMemcpyAsync(again.data(), in.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    if (memcmp(again.data(), out_host, sizeof(int32_t) * (size_t)n) != 0) {
+      mpg_set_error("mpg_debug_scan_i32: the in-place scan differs from the out-of-place one");
+      return MPG_ERR_HIP;
+    }
+  }
+  return MPG_SUCCESS;
+}
+
 }  // extern "C"

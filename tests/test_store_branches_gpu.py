@@ -170,3 +170,25 @@ def test_nearest_tree_finishes_what_the_bins_leave(gpu_lib, oracle, regional_cas
     m, g = regional_case
     st = _nearest_vs_oracle(oracle, m, g, brute=True)
     assert st[0] == 2 and 0 < st[3] < g.nx * g.ny, st
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 8191, 8192, 12288, 1 << 20, (1 << 20) + 1, 256 * 4096, 256 * 4096 + 1,
+                               3 * 256 * 4096 - 1, 5_000_003])
+def test_the_scan_and_sum_primitives_at_awkward_sizes(gpu_lib, n):
+    """csrc/k_prims.hip (the library's own exclusive scan and 64-bit sum, in rocPRIM's place since round 5) asked directly: sizes around
+    the wavefront, the workgroup, the 4096-entry block and the 256-block walk of the block sums; out of place and in place; sums beyond
+    32 bits."""
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 400, n).astype(np.int32)
+    out = np.empty(n, np.int32)
+    tot = C.c_longlong()
+    gpu_lib.check(gpu_lib.load().mpg_debug_scan_i32(a.ctypes.data_as(C.c_void_p), C.c_int64(n), out.ctypes.data_as(C.c_void_p), C.byref(tot)))
+    want = np.concatenate([[0], np.cumsum(a[:-1], dtype=np.int64)])
+    assert want[-1] < 2 ** 31 and np.array_equal(out, want.astype(np.int32)) and tot.value == int(a.sum(dtype=np.int64))
+    big = np.full(min(n, 70000), 2 ** 31 - 1, np.int32)                 # the 64-bit sum does not wrap where the int32 scan would
+    gpu_lib.check(gpu_lib.load().mpg_debug_scan_i32(big.ctypes.data_as(C.c_void_p), C.c_int64(big.size), None, C.byref(tot)))
+    assert tot.value == int(big.size) * (2 ** 31 - 1)
+    neg = -a                                                              # negative entries subtract (two's complement)
+    gpu_lib.check(gpu_lib.load().mpg_debug_scan_i32(neg.ctypes.data_as(C.c_void_p), C.c_int64(n), out.ctypes.data_as(C.c_void_p), C.byref(tot)))
+    assert np.array_equal(out, (-want).astype(np.int32)) and tot.value == -int(a.sum(dtype=np.int64))
