@@ -74,7 +74,8 @@ int ncio_close(ncio_file *f);                   /* writer: fills numrecs, flushe
 /* Start allocating `nbytes` (an upper bound of the output size) for a file that ncio_create will open shortly: the file is
  * created / truncated and its pages are allocated on a helper thread while the caller goes on (e.g. reads its inputs);
  * ncio_create of the same path waits for the helper and keeps the file, ncio_close trims it.  Unwritten ranges read as
- * zeros either way.  One reservation at a time. */
+ * zeros either way.  One reservation at a time.  A process that exits without having claimed its reservation (it stopped on an error
+ * in between) takes the file away again: no file of zeros is left under the output's name. */
 int ncio_reserve_start(const char *path, int64_t nbytes);
 
 /* two POSIX helpers for hosts that coordinate several driver images through marker files (sleep; atomic rename) */

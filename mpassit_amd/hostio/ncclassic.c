@@ -485,9 +485,22 @@ static void *reserve_main(void *arg) {
   close(fd);
   return NULL;
 }
+/* A process that ends before its writer has claimed the reservation (a host that stops on an error in between: the Fortran driver's
+ * `error stop` runs the exit handlers) must not leave a file of zeros under the output's name. */
+static void reserve_abandon(void) {
+  if (!g_res.active) return;
+  pthread_join(g_res.th, NULL);
+  g_res.active = 0;
+  unlink(g_res.path);
+}
 int ncio_reserve_start(const char *path, int64_t nbytes) {
+  static int at_exit_set = 0;
   if (!path || nbytes <= 0 || strlen(path) >= sizeof(g_res.path)) return fail(NCIO_EINVAL, "ncio_reserve_start: bad argument");
   if (g_res.active) return fail(NCIO_EMODE, "ncio_reserve_start: a reservation is already running");
+  if (!at_exit_set) {
+    at_exit_set = 1;
+    atexit(reserve_abandon);
+  }
   strcpy(g_res.path, path);
   g_res.nbytes = nbytes;
   g_res.rc = 0;

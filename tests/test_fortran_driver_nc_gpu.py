@@ -405,3 +405,24 @@ def test_a_failing_image_takes_the_others_down(tmp_path, gpu_lib):
     assert time.monotonic() - t0 < 60
     assert all(code != 0 for code, _, _ in res)
     assert not [f for f in os.listdir(d) if ".ready" in f or ".done." in f or f.endswith("out.nc")]
+
+
+def test_a_damaged_grid_file_stops_the_driver_with_the_librarys_message(tmp_path, gpu_lib, regional_case):
+    """verticesOnCell holding a vertex number beyond nVertices (a truncated or damaged init file): the driver stops with the library's
+    message and a non-zero code before any geometry kernel has used the number as an index; nothing is written.  The Python host
+    raises the same error."""
+    from mpassit_amd import _lib, io_nc, synth
+    m, _ = regional_case
+    voc = m.verticesOnCell.copy()
+    voc[m.nCells // 3, 2] = m.nVertices + 1
+    bad = synth.MpasMesh(m.latCell, m.lonCell, m.latVertex, m.lonVertex, voc)
+    d = str(tmp_path)
+    _write_inputs(d, bad)
+    open(os.path.join(d, "namelist.input"), "w").write(NAMELIST.format(d=d).replace(".raw", ".nc"))
+    r = subprocess.run([_driver(), "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "verticesOnCell refers to vertex %d of %d" % (m.nVertices + 1, m.nVertices) in r.stdout + r.stderr, r.stdout + r.stderr
+    assert not os.path.exists(os.path.join(d, "out.nc"))
+    from mpassit_amd import regrid as R
+    got = io_nc.read_grid(os.path.join(d, "init.nc"))[0]
+    with pytest.raises(_lib.MpgError, match="verticesOnCell refers to vertex"):
+        R.Mesh.from_mpas(got)

@@ -212,3 +212,27 @@ def test_reserved_output_space_gives_the_same_file(tmp_path):
         ncio.reserve_start(tmp_path / "second.nc", 10)     # one reservation at a time (the unused one is still pending)
     write(tmp_path / "unused.nc", False)                   # claims it
     assert (tmp_path / "unused.nc").read_bytes() == plain.read_bytes()
+
+
+def test_a_process_that_exits_without_claiming_its_reservation_leaves_no_file(tmp_path, ncio):
+    """The driver reserves the output's space while it reads its inputs; when it stops on an error before the writer has opened the file
+    (a damaged input), no file of zeros stays behind under the output's name.  A claimed reservation is the finished file and stays."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mpassit_amd import ncio\n"
+            "ncio.reserve_start(sys.argv[1], 5_000_000)\n"
+            "if sys.argv[2] == 'claim':\n"
+            "    import numpy as np\n"
+            "    w = ncio.Writer(sys.argv[1], 5)\n"
+            "    w.def_dim('n', 10); w.def_var('a', ncio.DOUBLE, ('n',)); w.put('a', np.arange(10.0)); w.close()\n"
+            "sys.exit(3 if sys.argv[2] == 'fail' else 0)\n") % root
+    lost, kept = tmp_path / "lost.nc", tmp_path / "kept.nc"
+    r = subprocess.run([sys.executable, "-c", code, str(lost), "fail"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and not lost.exists(), r.stderr
+    r = subprocess.run([sys.executable, "-c", code, str(kept), "claim"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and kept.exists() and kept.stat().st_size < 1000, r.stderr
+    with ncio.Reader(kept) as f:
+        assert f.get("a")[9] == 9.0
