@@ -16,4 +16,4 @@ make -C oracle clean >/dev/null
 make -C oracle CFLAGS="$SAN -fPIC -fopenmp -ffp-contract=off" >/dev/null
 LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   python -m pytest tests/test_ncio.py tests/test_ncio_property.py tests/test_target_grid_file.py tests/test_oracle.py \
-    tests/test_projection_properties.py tests/test_projection_goldens.py tests/test_weight_goldens.py tests/test_esmf_pin.py -x -q -m "not gpu"
+    tests/test_projection_properties.py tests/test_projection_goldens.py tests/test_weight_goldens.py tests/test_store_goldens.py tests/test_esmf_pin.py -x -q -m "not gpu"
