@@ -7,9 +7,12 @@
  *           (write_data.F90:173-1498)
  * Formats: CDF-1 (classic), CDF-2 (64-bit offset), CDF-5 (64-bit data) -- the on-disk layout published in the
  * NetCDF User's Guide ("File Format Specification") and the PnetCDF CDF-5 note; big-endian data, 4-byte padding,
- * record variables interleaved per record.  NetCDF-4 files are HDF5 containers (the reference creates its output
- * with NF90_NETCDF4, write_data.F90:173) and are NOT handled: ncio_open reports them as such, and the writer emits
- * CDF-5 / CDF-2, which every NetCDF tool reads and `nccopy -k nc4` converts.  Host code, no GPU involved.
+ * record variables interleaved per record.  These are read and written by code of this repository alone.
+ * NetCDF-4 files are HDF5 containers (the reference creates its output with NF90_NETCDF4, write_data.F90:173): where the build finds
+ * the HDF5 C library (hdf5.h, libhdf5, libhdf5_hl: the reference's own dependency under libnetcdf; mpassit_amd/build.py find_hdf5) the
+ * same calls read them (ncio_open recognises the magic) and write them (ncio_create with format 4) following the "NetCDF-4 File
+ * Format" appendix of the User's Guide -- hostio/nc4hdf5.h; such files offer no raw byte range (ncio_var_extent).  A build without
+ * HDF5 reports NCIO_EHDF5 for them and says how to convert.  Host code, no GPU involved.
  * All functions return 0 on success or a negative NCIO_E* code; ncio_strerror() explains the last failure. */
 #ifndef MPASSIT_NCIO_H
 #define MPASSIT_NCIO_H
@@ -31,7 +34,8 @@ const char *ncio_strerror(void);
 
 /* ---- reading ------------------------------------------------------------------------------------------------ */
 int ncio_open(const char *path, ncio_file **out);
-int ncio_format(ncio_file *f);                  /* 1, 2 or 5 */
+int ncio_format(ncio_file *f);                  /* 1, 2, 5 -- or 4: a NetCDF-4 file (HDF5 container) */
+int ncio_has_netcdf4(void);                     /* 1 when this build has the HDF5 backend (see the head of this file), 0 otherwise */
 int64_t ncio_numrecs(ncio_file *f);
 int ncio_ndims(ncio_file *f);
 int ncio_nvars(ncio_file *f);
@@ -51,7 +55,7 @@ int ncio_get_att_text(ncio_file *f, int varid, const char *name, char *buf, int 
 int ncio_get_att_double(ncio_file *f, int varid, const char *name, double *vals, int max_n, int *n);
 
 /* ---- writing ------------------------------------------------------------------------------------------------ */
-int ncio_create(const char *path, int format /* 1, 2 or 5 */, ncio_file **out);
+int ncio_create(const char *path, int format /* 1, 2, 5; 4 = NetCDF-4 (needs the HDF5 backend) */, ncio_file **out);
 int ncio_def_dim(ncio_file *f, const char *name, int64_t len /* 0 = unlimited (one per file) */, int *dimid);
 int ncio_def_var(ncio_file *f, const char *name, int type, int ndims, const int *dimids, int *varid);
 int ncio_put_att_text(ncio_file *f, int varid, const char *name, const char *text);

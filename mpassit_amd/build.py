@@ -92,13 +92,42 @@ NCIO_SRC = os.path.join(HERE, "hostio", "ncclassic.c")
 NCIO_SO = os.path.join(HERE, "hostio", "libmpassit_ncio.so")
 
 
+def find_hdf5():
+    """(include_dir, lib_dir) of an HDF5 C library with its high-level library (hdf5.h, libhdf5.so, libhdf5_hl.so), or None.
+    MPASSIT_HDF5_ROOT names a prefix (empty string / "none" = build without); otherwise the usual prefixes -- the image has 1.10.6 under
+    /opt/conda.  NetCDF-4 is an HDF5 container: with the library the ncio interface reads and writes it too."""
+    root = os.environ.get("MPASSIT_HDF5_ROOT")
+    if root is not None and root.strip().lower() in ("", "none", "0"):
+        return None
+    cands = [root] if root else ["/usr", "/usr/local", "/opt/conda"]
+    for c in cands:
+        for inc, lib in ((os.path.join(c, "include"), os.path.join(c, "lib")),
+                         (os.path.join(c, "include", "hdf5", "serial"), os.path.join(c, "lib", "x86_64-linux-gnu", "hdf5", "serial"))):
+            if all(os.path.exists(x) for x in (os.path.join(inc, "hdf5.h"), os.path.join(inc, "hdf5_hl.h"), os.path.join(lib, "libhdf5.so"),
+                                               os.path.join(lib, "libhdf5_hl.so"))):
+                return inc, lib
+    return None
+
+
 def build_ncio(force=False):
-    """Host-side NetCDF classic I/O (plain C, gcc): mpassit_amd/hostio/libmpassit_ncio.so."""
+    """Host-side NetCDF I/O (plain C, gcc): mpassit_amd/hostio/libmpassit_ncio.so -- the classic formats always, NetCDF-4 through libhdf5
+    where find_hdf5() finds one."""
     hdr = os.path.join(HERE, "..", "include", "mpassit_ncio.h")
-    if force or not _newer(NCIO_SO, [NCIO_SRC, hdr]):
-        r = subprocess.run(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-pthread", "-o", NCIO_SO, NCIO_SRC], capture_output=True, text=True)
+    h5 = find_hdf5()
+    stamp = NCIO_SO + ".cfg"
+    cfg = "hdf5=%s" % (h5,)
+    same = os.path.exists(stamp) and open(stamp).read() == cfg
+    if force or not same or not _newer(NCIO_SO, [NCIO_SRC, hdr, os.path.join(os.path.dirname(NCIO_SRC), "nc4hdf5.h")]):
+        cmd = ["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-pthread", "-o", NCIO_SO, NCIO_SRC]
+        if h5:
+            # the two libraries by full path, run path = their directory only for THEIR lookup (DT_RUNPATH is not inherited by dependencies)
+            cmd += ["-DMPASSIT_HAVE_HDF5", "-I" + h5[0], os.path.join(h5[1], "libhdf5_hl.so"), os.path.join(h5[1], "libhdf5.so"),
+                    "-Wl,--enable-new-dtags,-rpath," + h5[1]]
+        r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("gcc failed:\n%s" % r.stderr[-4000:])
+        with open(stamp, "w") as f:
+            f.write(cfg)
     return NCIO_SO
 
 

@@ -47,6 +47,7 @@ struct ncio_file {
   att_t *gatts;
   int64_t data_end; /* writer: end of the non-record section / start of records */
   int64_t rec_start;
+  void *h5; /* NetCDF-4: the HDF5 backend's state (nc4hdf5.h); the header above is shared, fp is NULL */
 };
 
 static __thread char g_err[512] = "";
@@ -125,12 +126,14 @@ static int rd_atts(rd_t *r, int *natts, att_t **atts) {
   return r->bad ? -1 : 0;
 }
 
+static void h5_free(ncio_file *f); /* nc4hdf5.h */
 static void free_atts(int n, att_t *a) {
   for (int i = 0; i < n; ++i) { free(a[i].name); free(a[i].data); }
   free(a);
 }
 static void free_file(ncio_file *f) {
   if (!f) return;
+  if (f->h5) h5_free(f);
   for (int i = 0; i < f->ndims; ++i) free(f->dims[i].name);
   free(f->dims);
   free_atts(f->ngatts, f->gatts);
@@ -155,6 +158,8 @@ static void finish_layout_info(ncio_file *f) { /* per-variable element counts, r
       if (f->vars[v].is_rec) f->recsize = f->vars[v].count * tsize(f->vars[v].type);
 }
 
+#include "nc4hdf5.h"
+
 int ncio_open(const char *path, ncio_file **out) {
   if (!path || !out) return fail(NCIO_EINVAL, "ncio_open: NULL argument");
   FILE *fp = fopen(path, "rb");
@@ -163,8 +168,7 @@ int ncio_open(const char *path, ncio_file **out) {
   if (fread(m, 1, 4, fp) != 4) { fclose(fp); return fail(NCIO_EFORMAT, "ncio_open: %s is too short to be a NetCDF file", path); }
   if (m[0] == 0x89 && m[1] == 'H' && m[2] == 'D' && m[3] == 'F') {
     fclose(fp);
-    return fail(NCIO_EHDF5, "ncio_open: %s is a NetCDF-4/HDF5 file; this build reads the classic formats only "
-                            "(convert with `nccopy -k cdf5 in.nc out.nc`)", path);
+    return nc4_open(path, out); /* NetCDF-4 = an HDF5 container: through libhdf5 where this build has it */
   }
   if (m[0] != 'C' || m[1] != 'D' || m[2] != 'F' || (m[3] != 1 && m[3] != 2 && m[3] != 5)) {
     fclose(fp);
@@ -250,6 +254,7 @@ int ncio_open(const char *path, ncio_file **out) {
 }
 
 int ncio_format(ncio_file *f) { return f ? f->format : NCIO_EINVAL; }
+int ncio_has_netcdf4(void) { return NC4_AVAILABLE; }
 int64_t ncio_numrecs(ncio_file *f) { return f ? f->numrecs : NCIO_EINVAL; }
 int ncio_ndims(ncio_file *f) { return f ? f->ndims : NCIO_EINVAL; }
 int ncio_nvars(ncio_file *f) { return f ? f->nvars : NCIO_EINVAL; }
@@ -407,6 +412,7 @@ static int par_xfer(par_job *j, int nthr) {
 int ncio_get_var(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf) {
   if (!f || f->writing) return fail(NCIO_EMODE, "ncio_get_var: file not open for reading");
   if (varid < 0 || varid >= f->nvars || !buf || !tsize(mem_type)) return fail(NCIO_EINVAL, "ncio_get_var: bad argument");
+  if (f->h5) return nc4_xfer(f, varid, rec, mem_type, buf, 0, "ncio_get_var");
   var_t *x = &f->vars[varid];
   int64_t off;
   int rc = var_offset(f, x, rec, &off, "ncio_get_var");
@@ -517,7 +523,19 @@ static int reserved_for(const char *path) {
 }
 
 int ncio_create(const char *path, int format, ncio_file **out) {
-  if (!path || !out || (format != 1 && format != 2 && format != 5)) return fail(NCIO_EINVAL, "ncio_create: format must be 1, 2 or 5");
+  if (!path || !out || (format != 1 && format != 2 && format != 5 && format != 4)) return fail(NCIO_EINVAL, "ncio_create: format must be 1, 2, 5 or 4");
+  if (format == 4) { /* NetCDF-4: libhdf5 creates the file (a pending reservation of the path is waited for, then overwritten) */
+    (void)reserved_for(path);
+    ncio_file *f4 = (ncio_file *)calloc(1, sizeof(*f4));
+    if (!f4) return fail(NCIO_ENOMEM, "out of memory");
+    f4->writing = f4->defmode = 1;
+    f4->format = 4;
+    f4->recdim = -1;
+    int rc4 = nc4_create(path, f4);
+    if (rc4) { free(f4); return rc4; }
+    *out = f4;
+    return 0;
+  }
   /* a file this process reserved a moment ago (truncated, then allocated: all zeros) is kept; anything else is truncated */
   FILE *fp = fopen(path, reserved_for(path) ? "rb+" : "wb+");
   if (!fp) return fail(NCIO_EIO, "ncio_create: cannot create %s", path);
@@ -539,7 +557,7 @@ int ncio_def_dim(ncio_file *f, const char *name, int64_t len, int *dimid) {
   if (rc) return rc;
   if (!name || len < 0) return fail(NCIO_EINVAL, "ncio_def_dim: bad argument");
   if (len == 0 && f->recdim >= 0) return fail(NCIO_EINVAL, "ncio_def_dim: only one unlimited dimension per file");
-  if (f->format != 5 && len > 0xFFFFFFFFll) return fail(NCIO_ERANGE, "ncio_def_dim: %s too long for CDF-%d", name, f->format);
+  if (f->format != 5 && f->format != 4 && len > 0xFFFFFFFFll) return fail(NCIO_ERANGE, "ncio_def_dim: %s too long for CDF-%d", name, f->format);
   f->dims = (dim_t *)realloc(f->dims, sizeof(dim_t) * (size_t)(f->ndims + 1));
   f->dims[f->ndims].name = strdup(name);
   f->dims[f->ndims].len = len;
@@ -552,7 +570,7 @@ int ncio_def_var(ncio_file *f, const char *name, int type, int ndims, const int 
   int rc = need_def(f, "ncio_def_var");
   if (rc) return rc;
   if (!name || !tsize(type) || ndims < 0 || ndims > NCIO_MAX_DIMS || (ndims && !dimids)) return fail(NCIO_EINVAL, "ncio_def_var: bad argument");
-  if (f->format != 5 && type > NCIO_DOUBLE) return fail(NCIO_EINVAL, "ncio_def_var: type %d needs CDF-5", type);
+  if (f->format != 5 && f->format != 4 && type > NCIO_DOUBLE) return fail(NCIO_EINVAL, "ncio_def_var: type %d needs CDF-5 or NetCDF-4", type);
   f->vars = (var_t *)realloc(f->vars, sizeof(var_t) * (size_t)(f->nvars + 1));
   var_t *x = &f->vars[f->nvars];
   memset(x, 0, sizeof(*x));
@@ -664,6 +682,7 @@ static void serialise(ncio_file *f, wb_t *w) {
 int ncio_enddef(ncio_file *f) {
   int rc = need_def(f, "ncio_enddef");
   if (rc) return rc;
+  if (f->format == 4) return nc4_enddef(f);
   int nrec = 0;
   for (int v = 0; v < f->nvars; ++v) {
     var_t *x = &f->vars[v];
@@ -706,6 +725,7 @@ int ncio_enddef(ncio_file *f) {
 int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void *buf) {
   if (!f || !f->writing || f->defmode) return fail(NCIO_EMODE, "ncio_put_var: call ncio_enddef first");
   if (varid < 0 || varid >= f->nvars || !buf || !tsize(mem_type)) return fail(NCIO_EINVAL, "ncio_put_var: bad argument");
+  if (f->h5) return nc4_xfer(f, varid, rec, mem_type, (void *)(uintptr_t)buf, 1, "ncio_put_var");
   var_t *x = &f->vars[varid];
   int64_t off;
   int rc = var_offset(f, x, rec, &off, "ncio_put_var");
@@ -736,6 +756,8 @@ int ncio_put_var(ncio_file *f, int varid, int64_t rec, int mem_type, const void 
 
 int ncio_var_extent(ncio_file *f, int varid, int64_t rec, int64_t *offset, int64_t *nbytes) {
   if (!f || varid < 0 || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_var_extent: bad argument");
+  if (f->h5) return fail(NCIO_EMODE, "ncio_var_extent: a NetCDF-4 file has no raw byte range to offer (chunked / compressed / little-endian container): "
+                                    "use ncio_get_var / ncio_put_var");
   if (f->writing && f->defmode) return fail(NCIO_EMODE, "ncio_var_extent: call ncio_enddef first");
   var_t *x = &f->vars[varid];
   int64_t off;
@@ -758,6 +780,12 @@ int ncio_var_extent(ncio_file *f, int varid, int64_t rec, int64_t *offset, int64
 int ncio_close(ncio_file *f) {
   if (!f) return 0;
   int rc = 0;
+  if (f->format == 4) {
+    if (f->writing && f->defmode) rc = nc4_enddef(f);
+    int rc2 = nc4_close(f);
+    free_file(f);
+    return rc ? rc : rc2;
+  }
   if (f->writing) {
     if (f->defmode) rc = ncio_enddef(f);
     if (!rc) {

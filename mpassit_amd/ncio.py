@@ -1,4 +1,5 @@
-"""ctypes front-end of the host-side NetCDF classic I/O (include/mpassit_ncio.h, hostio/ncclassic.c).
+"""ctypes front-end of the host-side NetCDF I/O (include/mpassit_ncio.h: hostio/ncclassic.c for the classic formats, hostio/nc4hdf5.h for
+NetCDF-4 through libhdf5 where the build found it).
 
 Numpy in, numpy out; shapes follow the file (slowest dimension first, i.e. a Fortran `var(nVertLevels, nCells, Time)`
 is `[Time][nCells][nVertLevels]` here).  Used by io_nc.py for the MPAS grid / diag / history files the reference reads
@@ -35,6 +36,11 @@ def lib():
         L.ncio_numrecs.restype = C.c_int64
         _lib = L
     return _lib
+
+
+def has_netcdf4():
+    """True when this build of the library has the HDF5 backend: NetCDF-4 files are read (Reader) and written (Writer(path, format=4))."""
+    return bool(lib().ncio_has_netcdf4())
 
 
 def _check(rc):

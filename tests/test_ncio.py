@@ -122,7 +122,8 @@ def test_cdf5_round_trip_and_header(ncio, tmp_path):
 def test_errors_are_explicit(ncio, tmp_path):
     h5 = tmp_path / "h5.nc"
     h5.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
-    with pytest.raises(ncio.NcioError, match="NetCDF-4/HDF5"):
+    # an HDF5 signature with nothing behind it: a build with the HDF5 backend lets libhdf5 refuse it, one without says how to convert
+    with pytest.raises(ncio.NcioError, match="libhdf5 cannot open" if ncio.has_netcdf4() else "NetCDF-4/HDF5"):
         ncio.Reader(h5)
     junk = tmp_path / "junk.nc"
     junk.write_bytes(b"not a netcdf file")
