@@ -51,6 +51,8 @@ int ncio_inq_var(ncio_file *f, int varid, char *name_buf, int buf_len, int *type
 int ncio_get_var(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf);
 /* attributes: varid = NCIO_GLOBAL for global ones.  Text: copied NUL-terminated (truncated to buf_len-1).
  * Numeric: converted to double, up to max_n values; *n receives the stored count. */
+int ncio_natts(ncio_file *f, int varid);        /* number of attributes of a variable (NCIO_GLOBAL: of the file) */
+int ncio_inq_att(ncio_file *f, int varid, int index, char *name_buf, int buf_len, int *type, int64_t *n);   /* nf90_inq_attname + nf90_inquire_attribute */
 int ncio_get_att_text(ncio_file *f, int varid, const char *name, char *buf, int buf_len);
 int ncio_get_att_double(ncio_file *f, int varid, const char *name, double *vals, int max_n, int *n);
 

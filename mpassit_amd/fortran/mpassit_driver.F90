@@ -2,9 +2,10 @@
 !! (default fort.41), &config namelist, diaglist / histlist_2d / histlist_3d / histlist_soil in the CWD.
 !! Phases in the reference's order (mpassit.F90:105-137): namelist -> target grid -> input grid ->
 !! input data -> interp_data (HIP, through the C-ABI) -> write.  No MPI/ESMF: one process drives one GPU.
-!! File I/O: NetCDF classic files (CDF-1/2/5, through ncio: the image has no libnetcdf, so NetCDF-4 is not read) are
-!! recognised by their magic; anything else is taken as the MPGRAW1 raw container.  An output_file ending in ".nc" is
-!! written as CDF-5 with the reference's dimension / variable names and post-ops (ncfiles_mod.F90).
+!! File I/O: NetCDF files -- the classic formats CDF-1/2/5 by this repository's own reader / writer, NetCDF-4 through libhdf5 where
+!! libmpassit_ncio was built with it -- are recognised by their magic; anything else is taken as the MPGRAW1 raw container.  An
+!! output_file ending in ".nc" is written as CDF-5 (MPASSIT_OUTPUT_FORMAT=netcdf4: as NetCDF-4, what the reference creates) with the
+!! reference's dimension / variable names and post-ops (ncfiles_mod.F90).
 !! Two data flows: with NetCDF at both ends every listed variable goes file -> GPU as raw bytes, stays in device buffers
 !! through Regrid / rotation / destaggering / post-ops and goes GPU -> file the same way (dev_flow; no host array, no
 !! host conversion); otherwise (raw container, or MPASSIT_HOST_ARRAYS set) fields live in host arrays like the
@@ -45,8 +46,10 @@ program mpassit
   if (nranks > 1) print '(a,i0,a,i0)', " - DRIVER IMAGE ", myrank, " OF ", nranks
   f32_out = is_nc_name(output_file)
   call get_environment_variable("MPASSIT_HOST_ARRAYS", envbuf)
-  dev_flow = f32_out .and. len_trim(envbuf) == 0 .and. nc_is_netcdf(grid_file_input_grid) .and. &
-             (.not. interp_hist .or. nc_is_netcdf(hist_file_input_grid)) .and. (.not. interp_diag .or. nc_is_netcdf(diag_file_input_grid))
+  ! (variables of classic files are byte ranges; a NetCDF-4 file at either end -- chunked, deflated, little-endian -- goes through libhdf5 and host arrays)
+  dev_flow = f32_out .and. len_trim(envbuf) == 0 .and. nc_is_classic(grid_file_input_grid) .and. &
+             (.not. interp_hist .or. nc_is_classic(hist_file_input_grid)) .and. (.not. interp_diag .or. nc_is_classic(diag_file_input_grid))
+  if (f32_out) dev_flow = dev_flow .and. nc_output_format() /= 4
   if (dev_flow) print *, "- NETCDF IN AND OUT: FIELDS STAY ON THE DEVICE BETWEEN THE FILES"
   ! one image per GPU: MPASSIT_DEVICE (set by the launcher: rank modulo the GPUs of the node), else device 0
   call get_environment_variable("MPASSIT_DEVICE", envbuf)

@@ -1,4 +1,4 @@
-!> NetCDF (classic formats) file surface of the Fortran driver, through ncio (ncio_mod.F90):
+!> NetCDF file surface of the Fortran driver, through ncio (ncio_mod.F90: the classic formats, and NetCDF-4 where the library has HDF5):
 !!   nc_read_grid     model_grid.F90:287-417   dimensions, lat/lon of cells and vertices, verticesOnCell, ter
 !!   nc_load_field    input_data.F90:316-812   one listed variable, first Time record, file order (level fastest)
 !!   nc_write_target  write_data.F90:173-1498  dimensions, global attributes, grid variables, every target field with
@@ -15,7 +15,7 @@ module ncfiles
   use model_data
   implicit none
   private
-  public :: nc_is_netcdf, nc_read_grid, nc_load_field, nc_write_target, nc_read_meta, nc_upload_hgt
+  public :: nc_is_netcdf, nc_is_classic, nc_output_format, nc_read_grid, nc_load_field, nc_write_target, nc_read_meta, nc_upload_hgt
   ! what the output header takes from the input files (model_grid.F90:34-46,182; read by input_data.F90:219-245,347-389)
   character(len=50), public :: start_time = ""
   real(dp), public :: config_dt = 0.0_dp
@@ -109,17 +109,51 @@ contains
     ok = .true.
   end function stamp_seconds
 
-  logical function nc_is_netcdf(file)
+  !> 'C' = a NetCDF classic file (CDF-1/2/5), 'H' = an HDF5 container (NetCDF-4), ' ' = neither (or unreadable)
+  character function nc_magic(file)
     character(len=*), intent(in) :: file
-    character(len=3) :: magic
+    character(len=4) :: magic
     integer :: u, ios
-    nc_is_netcdf = .false.
+    nc_magic = ' '
     open (newunit=u, file=trim(file), access='stream', form='unformatted', status='old', iostat=ios)
     if (ios /= 0) return
     read (u, iostat=ios) magic
     close (u)
-    nc_is_netcdf = ios == 0 .and. magic == 'CDF'
+    if (ios /= 0) return
+    if (magic(1:3) == 'CDF') nc_magic = 'C'
+    if (magic == achar(137)//'HDF') nc_magic = 'H'
+  end function nc_magic
+
+  !> a file ncio reads: the classic formats always, NetCDF-4 where libmpassit_ncio was built with the HDF5 backend (otherwise ncio_open
+  !! stops with the way out -- rebuild, or nccopy -k cdf5)
+  logical function nc_is_netcdf(file)
+    character(len=*), intent(in) :: file
+    nc_is_netcdf = nc_magic(file) /= ' '
   end function nc_is_netcdf
+
+  !> a classic file: its variables are byte ranges, which the device-resident flow moves file <-> GPU as they are
+  logical function nc_is_classic(file)
+    character(len=*), intent(in) :: file
+    nc_is_classic = nc_magic(file) == 'C'
+  end function nc_is_classic
+
+  !> Format of a ".nc" output: MPASSIT_OUTPUT_FORMAT = cdf5 (default; 64-bit data, device-resident flow), cdf2, or netcdf4 (what the
+  !! reference creates, write_data.F90:173 NF90_NETCDF4; through libhdf5 and host arrays).  The namelist has no such switch.
+  integer function nc_output_format()
+    character(len=32) :: e
+    call get_environment_variable("MPASSIT_OUTPUT_FORMAT", e)
+    nc_output_format = 5
+    select case (trim(e))
+    case ("", "cdf5", "CDF5", "5")
+      nc_output_format = 5
+    case ("cdf2", "CDF2", "2")
+      nc_output_format = 2
+    case ("netcdf4", "NETCDF4", "nc4", "4")
+      nc_output_format = 4
+    case default
+      call fatal("MPASSIT_OUTPUT_FORMAT must be cdf5, cdf2 or netcdf4 - "//trim(e), 1)
+    end select
+  end function nc_output_format
 
   subroutine get_f64(nf, name, arr, n)
     type(c_ptr), intent(in) :: nf
@@ -284,6 +318,7 @@ contains
     integer(c_int), intent(in) :: id
     integer(c_int64_t) :: off, nb
     if (myrank > 0) return
+    if (ncio_format(nf_out) == 4) return      ! NetCDF-4: a record nobody wrote reads as zeros (the fill value) once the file is closed at its record count
     call ncio_check(ncio_var_extent(nf_out, id, 0_c_int64_t, off, nb), "WRITING RECORD")
   end subroutine put_zero
 
@@ -537,7 +572,7 @@ contains
     if (hist_soil%n > 0) nsoil_input = hist_soil%f(1)%nlev
     nsoil_input = max(nsoil_input, 1)
     out_path = file
-    if (nranks > 1 .and. .not. dev_flow) call fatal("several driver images need NetCDF in and out (the device-resident flow)", nranks)
+    if (nranks > 1 .and. .not. dev_flow) call fatal("several driver images need NetCDF CLASSIC files in and out (the device-resident flow; NetCDF-4 goes through one image)", nranks)
     if (myrank > 0) then
       ! image 0 has created the file, written header, grid and time variables and its own rows, and closed it
       call wait_for(marker_name("ready", -1))
@@ -545,7 +580,7 @@ contains
       call ncio_check(ncio_open(trim(file), nf_out), "opening "//trim(file))
     else
       call remove_file(marker_name("ready", -1))
-    call ncio_check(ncio_create(file, 5, nf_out), "CREATING FILE "//trim(file))
+    call ncio_check(ncio_create(file, nc_output_format(), nf_out), "CREATING FILE "//trim(file))
     call ncio_check(ncio_def_dim(nf_out, "Time", 0, d_time), "DEFINING Time")                    ! write_data.F90:177-194
     call ncio_check(ncio_def_dim(nf_out, "west_east", i_target, d_we), "DEFINING west_east")
     call ncio_check(ncio_def_dim(nf_out, "west_east_stag", i_target + 1, d_wes), "DEFINING west_east_stag")

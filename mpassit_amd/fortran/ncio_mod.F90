@@ -70,6 +70,12 @@ module ncio
       integer(c_int64_t), intent(out) :: offset, nbytes
       integer(c_int) :: rc
     end function ncio_var_extent
+    !> 1, 2, 5: a classic file; 4: NetCDF-4 (an HDF5 container: no byte ranges, ncio_var_extent refuses)
+    function ncio_format(f) bind(C, name="ncio_format") result(fmt)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: f
+      integer(c_int) :: fmt
+    end function ncio_format
     function ncio_create_c(path, fmt, f) bind(C, name="ncio_create") result(rc)
       import :: c_char, c_ptr, c_int
       character(kind=c_char), intent(in) :: path(*)

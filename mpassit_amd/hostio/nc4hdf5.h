@@ -178,7 +178,14 @@ static herr_t h5_att_cb(hid_t obj, const char *name, const H5A_info_t *info, voi
 static int h5_read_atts(hid_t obj, int *natts, att_t **atts) {
   h5_attlist L = {0, NULL, 0};
   hsize_t idx = 0;
-  H5Aiterate2(obj, H5_INDEX_NAME, H5_ITER_INC, &idx, h5_att_cb, &L);
+  /* in creation order where the object tracks it (libnetcdf's files and this writer's do: the definition order), by name otherwise */
+  if (H5Aiterate2(obj, H5_INDEX_CRT_ORDER, H5_ITER_INC, &idx, h5_att_cb, &L) < 0 && !L.bad) {
+    free_atts(L.n, L.a);
+    L.n = 0;
+    L.a = NULL;
+    idx = 0;
+    H5Aiterate2(obj, H5_INDEX_NAME, H5_ITER_INC, &idx, h5_att_cb, &L);
+  }
   *natts = L.n;
   *atts = L.a;
   return L.bad ? -1 : 0;

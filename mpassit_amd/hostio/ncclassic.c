@@ -445,6 +445,20 @@ static att_t *find_att(ncio_file *f, int varid, const char *name) {
     if (!strcmp(a[i].name, name)) return &a[i];
   return NULL;
 }
+int ncio_natts(ncio_file *f, int varid) {
+  if (!f || varid < NCIO_GLOBAL || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_natts: bad argument");
+  return varid == NCIO_GLOBAL ? f->ngatts : f->vars[varid].natts;
+}
+int ncio_inq_att(ncio_file *f, int varid, int index, char *name_buf, int buf_len, int *type, int64_t *n) {
+  if (!f || varid < NCIO_GLOBAL || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_inq_att: bad argument");
+  const int na = varid == NCIO_GLOBAL ? f->ngatts : f->vars[varid].natts;
+  att_t *a = varid == NCIO_GLOBAL ? f->gatts : f->vars[varid].atts;
+  if (index < 0 || index >= na) return fail(NCIO_ENOTFOUND, "ncio_inq_att: attribute %d of %d", index, na);
+  copy_name(name_buf, buf_len, a[index].name);
+  if (type) *type = a[index].type;
+  if (n) *n = a[index].n;
+  return 0;
+}
 int ncio_get_att_text(ncio_file *f, int varid, const char *name, char *buf, int buf_len) {
   if (!f || !name || !buf || buf_len < 1 || varid < NCIO_GLOBAL || varid >= f->nvars) return fail(NCIO_EINVAL, "ncio_get_att_text: bad argument");
   att_t *a = find_att(f, varid, name);

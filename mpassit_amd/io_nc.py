@@ -140,7 +140,7 @@ def _read_field_dev(r, name, device):
     (MPG_TYPE_BE) -- no byte-swap pass over the data."""
     import torch
     v = r.vars[name]
-    if v["type"] not in _RAW_TYPES:
+    if v["type"] not in _RAW_TYPES or r.format == 4:   # (a NetCDF-4 file has no raw byte range: chunked / deflated / little-endian -- through libhdf5 and the host)
         return torch.as_tensor(_read_field(r, name), device=device)
     off, nb = r.extent(name, rec=0)
     t = torch.empty(nb, dtype=torch.uint8, device=device)
@@ -282,6 +282,13 @@ def _put_dev(w, name, a):
     import torch
     is_be = bool(getattr(a, "mpg_be", False))
     a = a.contiguous()
+    if w.format == 4:                                     # NetCDF-4: no byte range to fill; host order through libhdf5 (unwritten levels read as zeros)
+        host = (bswap_(a.clone()) if is_be else a).reshape(-1).cpu().numpy()
+        count = w._vars[name][2]
+        if host.size < count:
+            host = np.concatenate([host, np.zeros(count - host.size, host.dtype)])
+        w.put(name, host, rec=0)
+        return
     off, _ = w.extent(name, rec=0)                        # makes the record exist: a file being created reads as zeros
     if a.numel() and not bool(a.view(torch.int32).any()):
         return                                            # all-zero bit patterns (MU, PH, P of wrf_mod_vars): nothing to store

@@ -115,6 +115,16 @@ class Reader:
         _check(lib().ncio_get_att_double(self._h, vid, name.encode(), vals, 64, C.byref(n)))
         return np.array(vals[:min(n.value, 64)])
 
+    def atts(self, var=None):
+        """{name: value} of every attribute of a variable (None: of the file), in the file's order."""
+        vid = GLOBAL if var is None else self.vars[var]["id"]
+        out = {}
+        for i in range(_check(lib().ncio_natts(self._h, vid))):
+            name = C.create_string_buffer(256)
+            _check(lib().ncio_inq_att(self._h, vid, i, name, 256, None, None))
+            out[name.value.decode("utf-8", "replace")] = self.att(name.value.decode("utf-8", "replace"), var)
+        return out
+
     def close(self):
         if self._h:
             lib().ncio_close(self._h)
@@ -139,6 +149,7 @@ class Writer:
     def __init__(self, path, format=5):
         self._h = C.c_void_p()
         self.path = str(path)
+        self.format = int(format)              # 1, 2, 5: classic; 4: NetCDF-4 (needs the HDF5 backend, has_netcdf4())
         _check(lib().ncio_create(str(path).encode(), format, C.byref(self._h)))
         self._dims, self._dimlen, self._vars, self._defining = {}, {}, {}, True
 

@@ -4,14 +4,16 @@ import numpy as np
 import pytest
 
 
-@pytest.fixture(scope="module")
-def geo_file(tmp_path_factory):
+@pytest.fixture(scope="module", params=[2, 4], ids=["cdf2", "netcdf4"])
+def geo_file(tmp_path_factory, request):
     from mpassit_amd import build, ncio, target_grid as T
     build.build_ncio()
+    if request.param == 4 and not ncio.has_netcdf4():
+        pytest.skip("libmpassit_ncio was built without HDF5")
     nml = dict(dx=30000.0, dy=30000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
     g = T.define_target_grid_params("lambert", 41, 31, **nml)
     path = tmp_path_factory.mktemp("geo") / "geo_em.d01.nc"
-    with ncio.Writer(path, format=2) as w:
+    with ncio.Writer(path, format=request.param) as w:                 # geo_em / wrfinput files come as classic or as NetCDF-4 files
         for name, n in (("Time", None), ("west_east", g.nx), ("south_north", g.ny), ("west_east_stag", g.nx + 1), ("south_north_stag", g.ny + 1)):
             w.def_dim(name, n)
         for k, v in (("DX", np.float32(30000.0)), ("DY", np.float32(30000.0)), ("CEN_LAT", np.float32(38.5)), ("CEN_LON", np.float32(-97.5)),
