@@ -227,7 +227,7 @@ static int h5_add_dim(ncio_file *f, const char *name, int64_t len) {
   return f->ndims++;
 }
 
-static int nc4_open(const char *path, ncio_file **out) {
+static int nc4_open_(const char *path, ncio_file **out) {
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL); /* failures are reported through ncio_strerror, not printed by the library */
   ncio_file *f = (ncio_file *)calloc(1, sizeof(*f));
   h5_t *h = (h5_t *)calloc(1, sizeof(*h));
@@ -365,7 +365,7 @@ static int nc4_open(const char *path, ncio_file **out) {
   return 0;
 }
 
-static int nc4_xfer(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf, int writing, const char *who) {
+static int nc4_xfer_(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf, int writing, const char *who) {
   h5_t *h = (h5_t *)f->h5;
   var_t *x = &f->vars[varid];
   hid_t d = h->dset[varid];
@@ -411,7 +411,7 @@ static int nc4_xfer(ncio_file *f, int varid, int64_t rec, int mem_type, void *bu
 }
 
 /* ---- writing ---------------------------------------------------------------------------------------------------------- */
-static int nc4_create(const char *path, ncio_file *f) {
+static int nc4_create_(const char *path, ncio_file *f) {
   H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
   h5_t *h = (h5_t *)calloc(1, sizeof(*h));
   if (!h) return fail(NCIO_ENOMEM, "out of memory");
@@ -446,7 +446,7 @@ static int h5_put_atts(hid_t obj, int n, att_t *a, const char *owner) {
   }
   return 0;
 }
-static int nc4_enddef(ncio_file *f) {
+static int nc4_enddef_(ncio_file *f) {
   h5_t *h = (h5_t *)f->h5;
   for (int v = 0; v < f->nvars; ++v) { /* the shared per-variable counts (ncio_enddef's first loop) */
     var_t *x = &f->vars[v];
@@ -547,7 +547,7 @@ static int nc4_enddef(ncio_file *f) {
   if (!rc) f->defmode = 0;
   return rc;
 }
-static int nc4_close(ncio_file *f) {
+static int nc4_close_(ncio_file *f) {
   h5_t *h = (h5_t *)f->h5;
   int rc = 0;
   if (f->writing && !f->defmode && f->recdim >= 0 && h && h->dset) {
@@ -573,6 +573,23 @@ static int nc4_close(ncio_file *f) {
   h5_free(f);
   return rc;
 }
+/* libhdf5 is not thread-safe in its usual build, and hosts do use two threads (io_nc.run_series reads the next file while the current one is
+ * written): every entry into the library goes through one lock. */
+static pthread_mutex_t g_h5_lock = PTHREAD_MUTEX_INITIALIZER;
+#define NC4_LOCKED(call)                \
+  do {                                  \
+    pthread_mutex_lock(&g_h5_lock);     \
+    int rc_ = (call);                   \
+    pthread_mutex_unlock(&g_h5_lock);   \
+    return rc_;                         \
+  } while (0)
+static int nc4_open(const char *path, ncio_file **out) { NC4_LOCKED(nc4_open_(path, out)); }
+static int nc4_xfer(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf, int writing, const char *who) {
+  NC4_LOCKED(nc4_xfer_(f, varid, rec, mem_type, buf, writing, who));
+}
+static int nc4_create(const char *path, ncio_file *f) { NC4_LOCKED(nc4_create_(path, f)); }
+static int nc4_enddef(ncio_file *f) { NC4_LOCKED(nc4_enddef_(f)); }
+static int nc4_close(ncio_file *f) { NC4_LOCKED(nc4_close_(f)); }
 #define NC4_AVAILABLE 1
 #else /* ---- built without HDF5: every entry says so ------------------------------------------------------------------------ */
 #define NC4_AVAILABLE 0

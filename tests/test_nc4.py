@@ -286,3 +286,37 @@ def test_a_build_without_hdf5_says_so(tmp_path):
     assert L.ncio_open(str(p).encode(), C.byref(h)) == -3 and b"nccopy -k cdf5" in L.ncio_strerror() and b"MPASSIT_HDF5_ROOT" in L.ncio_strerror()
     assert L.ncio_create(str(tmp_path / "y.nc").encode(), 4, C.byref(h)) == -3
     assert L.ncio_create(str(tmp_path / "y.nc").encode(), 5, C.byref(h)) == 0 and L.ncio_close(h) == 0
+
+
+def test_two_threads_inside_the_hdf5_backend(ncio, tmp_path):
+    """Hosts use two threads on files (io_nc.run_series reads the next file while the current one is written) and libhdf5's usual build
+    is not thread-safe: every entry of the backend takes one lock.  Three threads write and read their own NetCDF-4 files over and over
+    (ctypes drops the GIL inside the calls): every value comes back."""
+    import threading
+    errs = []
+
+    def work(k):
+        try:
+            rng = np.random.default_rng(k)
+            for it in range(12):
+                a = rng.normal(size=(3, 40, 50)).astype(np.float32)
+                p = tmp_path / ("t%d_%d.nc" % (k, it))
+                w = ncio.Writer(p, format=4)
+                w.def_dim("Time", None)
+                w.def_dim("y", 40)
+                w.def_dim("x", 50)
+                w.def_var("v", ncio.FLOAT, ("Time", "y", "x"), units="K")
+                for r in range(3):
+                    w.put("v", a[r], rec=r)
+                w.close()
+                with ncio.Reader(p) as rd:
+                    assert rd.numrecs == 3 and np.array_equal(rd.get("v"), a) and rd.att("units", "v") == "K"
+        except Exception as e:      # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
