@@ -169,12 +169,12 @@ def corners_from_scrip(sg):
     return out
 
 
-def write_weight_file(path, row, col, S, n_a, n_b, method="bilinear", title="weights of mpassit_amd in ESMF_RegridWeightGen's layout"):
+def write_weight_file(path, row, col, S, n_a, n_b, method="bilinear", title="weights of mpassit_amd in ESMF_RegridWeightGen's layout", fmt=2):
     """(row, col, S) in ESMF's convention -- 1-based, row = destination, col = source sequence index -- as the weight file
     ESMF_RegridWeightGen writes (the `--weight_only` subset: col, row, S and the three dimensions; the attributes it sets)."""
     row, col, S = np.asarray(row, np.int32), np.asarray(col, np.int32), np.asarray(S, np.float64)
     assert row.shape == col.shape == S.shape and row.ndim == 1
-    with ncio.Writer(path, format=2) as w:
+    with ncio.Writer(path, format=fmt) as w:       # fmt 2 = --64bit_offset; 4 = --netcdf4 (needs the HDF5 backend of ncio)
         w.def_dim("n_a", int(n_a))
         w.def_dim("n_b", int(n_b))
         w.def_dim("n_s", max(int(S.size), 1))
@@ -199,7 +199,8 @@ def write_weight_file(path, row, col, S, n_a, n_b, method="bilinear", title="wei
 
 def read_weight_file(path):
     """-> dict(row, col, S, n_a, n_b, method): an ESMF_RegridWeightGen file (full or --weight_only) in classic / 64-bit-offset /
-    CDF-5 form (a NetCDF-4 file: `nccopy -k cdf5 in.nc out.nc` first, or run the generator with --64bit_offset)."""
+    CDF-5 form, or NetCDF-4 (the generator's --netcdf4) where libmpassit_ncio has its HDF5 backend (otherwise: `nccopy -k cdf5 in.nc
+    out.nc` first, or run the generator with --64bit_offset, as the exported script does)."""
     with ncio.Reader(path) as r:
         for v in ("S", "row", "col"):
             if v not in r.vars:

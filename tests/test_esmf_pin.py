@@ -219,3 +219,21 @@ def test_global_grid_drops_the_duplicate_edge1_column(tmp_path):
     assert info["grid_edge1"]["grid_dims"] == (g.nx, g.ny) and info["grid_edge2"]["grid_dims"] == (g.nx, g.ny + 1) and not info["regional"]
     sh = open(os.path.join(str(tmp_path), "run_esmf_regridweightgen.sh")).read()
     assert "_regional" not in sh and sh.count("-p all") == 2
+
+
+def test_a_netcdf4_weight_file_is_read_too(tmp_path):
+    """ESMF_RegridWeightGen --netcdf4 writes its weights into an HDF5 container: read like the classic ones where ncio has HDF5."""
+    from mpassit_amd import esmf_pin as E, ncio
+    if not ncio.has_netcdf4():
+        pytest.skip("libmpassit_ncio was built without HDF5")
+    rng = np.random.default_rng(2)
+    key = rng.choice(50 * 80, 200, replace=False)                       # distinct (row, col) entries
+    row, col, S = key // 80 + 1, key % 80 + 1, rng.uniform(0, 1, 200)
+    for fmt in (2, 4):
+        E.write_weight_file(tmp_path / ("w%d.nc" % fmt), row, col, S, 80, 50, "conserve", fmt=fmt)
+    a, b = E.read_weight_file(tmp_path / "w2.nc"), E.read_weight_file(tmp_path / "w4.nc")
+    assert open(tmp_path / "w4.nc", "rb").read(4) == b"\x89HDF" and a["method"] == b["method"] and (a["n_a"], a["n_b"]) == (b["n_a"], b["n_b"]) == (80, 50)
+    for k in ("row", "col", "S"):
+        assert np.array_equal(a[k], b[k])
+    rep = E.compare_weights((a["row"], a["col"], a["S"]), (b["row"], b["col"], b["S"]), 80, 50, "conserve")
+    assert rep["ok"] and rep["max_abs_diff_any"] == 0.0
