@@ -377,6 +377,21 @@ static int nc4_xfer_(ncio_file *f, int varid, int64_t rec, int mem_type, void *b
     mt = h5_memtype(mem_type);
     if (mt < 0) return fail(NCIO_EINVAL, "%s: unsupported memory type %d", who, mem_type);
   }
+  /* A value conversion (the host-array flow hands float64 to NF90_FLOAT variables) is done HERE, in one pass over a buffer of the
+   * variable's own type, and the library moves that buffer as it is: libhdf5's own conversion works through a 1 MB scratch buffer and
+   * is several times slower than the threaded pass here. */
+  void *staged = NULL;
+  void *user = buf;
+  if (x->type != NCIO_CHAR && mem_type != x->type && x->count > 0) {
+    staged = malloc((size_t)x->count * (size_t)tsize(x->type));
+    if (!staged) return fail(NCIO_ENOMEM, "%s: out of memory", who);
+    if (writing && convert_mt(mem_type, user, x->type, staged, x->count)) {
+      free(staged);
+      return fail(NCIO_EINVAL, "%s: unsupported conversion", who);
+    }
+    buf = staged;
+    mt = h5_memtype(x->type);
+  }
   hid_t fs = H5S_ALL, ms = H5S_ALL;
   herr_t e = 0;
   if (x->is_rec) {
@@ -386,25 +401,32 @@ static int nc4_xfer_(ncio_file *f, int varid, int64_t rec, int mem_type, void *b
     if (rec < 0 || (!writing && rec >= (int64_t)cur[0])) {
       H5Sclose(fs);
       if (own >= 0) H5Tclose(own);
+      free(staged);
       return fail(NCIO_ERANGE, "%s: record %lld of %s out of range (%lld records)", who, (long long)rec, x->name, (long long)cur[0]);
     }
     if (writing && rec >= (int64_t)cur[0]) {
       cur[0] = (hsize_t)rec + 1;
       H5Sclose(fs);
-      if (H5Dset_extent(d, cur) < 0) { if (own >= 0) H5Tclose(own); return fail(NCIO_EIO, "%s: cannot extend %s", who, x->name); }
+      if (H5Dset_extent(d, cur) < 0) { if (own >= 0) H5Tclose(own); free(staged); return fail(NCIO_EIO, "%s: cannot extend %s", who, x->name); }
       fs = H5Dget_space(d);
     }
     start[0] = (hsize_t)rec;
     cnt[0] = 1;
     for (int k = 1; k < x->ndims; ++k) cnt[k] = cur[k];
     e = H5Sselect_hyperslab(fs, H5S_SELECT_SET, start, NULL, cnt, NULL);
-    hsize_t n1 = (hsize_t)x->count;
-    ms = H5Screate_simple(1, &n1, NULL);
+    /* the memory side has the record's own shape: with a memory space of another rank (a flat list of the record's elements) the library
+     * maps chunks to memory element by element -- 85 MB/s on a 420 MB record, against 1.5 GB/s this way */
+    ms = H5Screate_simple(x->ndims, cnt, NULL);
   }
   if (e >= 0 && x->count > 0) e = writing ? H5Dwrite(d, mt, ms, fs, H5P_DEFAULT, buf) : H5Dread(d, mt, ms, fs, H5P_DEFAULT, buf);
   if (fs != H5S_ALL) H5Sclose(fs);
   if (ms != H5S_ALL) H5Sclose(ms);
   if (own >= 0) H5Tclose(own);
+  if (e >= 0 && staged && !writing && convert_mt(x->type, staged, mem_type, user, x->count)) {
+    free(staged);
+    return fail(NCIO_EINVAL, "%s: unsupported conversion", who);
+  }
+  free(staged);
   if (e < 0) return fail(NCIO_EIO, "%s: libhdf5 could not %s %s", who, writing ? "write" : "read", x->name);
   if (writing && x->is_rec && rec + 1 > f->numrecs) f->numrecs = rec + 1;
   return 0;

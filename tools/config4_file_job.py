@@ -136,6 +136,34 @@ def main():
     print("fortran, device flow:  %.2f s wall (process start to exit; %.2f GB out)" % (t_f, gb_out), flush=True)
     print("    " + "  ".join(ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("[")), flush=True)
 
+    if os.environ.get("C4JOB_NC4"):                   # C4JOB_NC4=1: the same job with a NetCDF-4 output (what the reference creates): host arrays, libhdf5
+        from mpassit_amd import ncio
+        if not ncio.has_netcdf4():
+            print("NetCDF-4 leg skipped: libmpassit_ncio was built without HDF5")
+        else:
+            nml4 = open(os.path.join(d, "namelist.input")).read().replace("out_fortran.nc", "out_fortran_nc4.nc")
+            open(os.path.join(d, "namelist.nc4"), "w").write(nml4)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "namelist.nc4"], cwd=d, capture_output=True, text=True, timeout=900, env=dict(os.environ, MPASSIT_OUTPUT_FORMAT="netcdf4"))
+            t4 = time.perf_counter() - t0
+            if r.returncode != 0:
+                print(r.stdout[-3000:], r.stderr[-3000:])
+                return 1
+            p4 = os.path.join(d, "out_fortran_nc4.nc")
+            print("fortran, NetCDF-4 out: %.2f s wall (%.2f GB)   %s" % (t4, os.path.getsize(p4) / 1e9, "  ".join(
+                ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("["))), flush=True)
+            worst, nvar = 0, 0
+            with ncio.Reader(p4) as a, ncio.Reader(os.path.join(d, "out_fortran.nc")) as b:
+                same_hdr = list(a.vars) == list(b.vars) and a.dims == b.dims and list(a.atts()) == list(b.atts())
+                for name in a.vars:
+                    nvar += 1
+                    worst += int(a.get(name).tobytes() != b.get(name).tobytes())
+            print("    NetCDF-4 output vs CDF-5 output: same dimensions / variables / attributes: %s; %d variables compared, %d differ in any bit" % (
+                same_hdr, nvar, worst), flush=True)
+            os.remove(p4)
+            if worst or not same_hdr:
+                return 1
+
     nr = int(os.environ.get("C4JOB_RANKS", "0"))      # C4JOB_RANKS=N: the same job as N driver images (row blocks of the target grid)
     if nr > 1:
         import mpassit_ranks
