@@ -264,8 +264,16 @@ def test_every_type_round_trips_and_misuse_is_refused(ncio, tmp_path):
     plane = rng.normal(size=(40, 700, 900)).astype(np.float32)
     w.put("P", plane, rec=0)
     w.close()
+    w = ncio.Writer(tmp_path / "big64.nc", format=4)                      # float64 handed to a float32 variable: the threaded conversion pass
+    w.def_dim("Time", None)
+    w.def_dim("n", plane.size)
+    w.def_var("P", ncio.FLOAT, ("Time", "n"))
+    w.put("P", plane.astype(np.float64).ravel(), rec=0)
+    w.close()
+    with ncio.Reader(tmp_path / "big64.nc") as r:
+        assert np.array_equal(r.get("P", rec=0).reshape(plane.shape), plane)
     with ncio.Reader(big) as r:
-        assert r.numrecs == 1 and np.array_equal(r.get("P", rec=0), plane)
+        assert r.numrecs == 1 and np.array_equal(r.get("P", rec=0), plane) and np.array_equal(r.get("P", rec=0, dtype=np.float64), plane.astype(np.float64))
     d = json.loads(_h5py(DUMP, big))["datasets"]["P"]
     assert d["chunks"] == [1, 1, 700, 900] and abs(d["sum"] - float(plane.astype(float).sum())) < 1e-3
 
