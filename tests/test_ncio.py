@@ -237,3 +237,21 @@ def test_a_process_that_exits_without_claiming_its_reservation_leaves_no_file(tm
     assert r.returncode == 0 and kept.exists() and kept.stat().st_size < 1000, r.stderr
     with ncio.Reader(kept) as f:
         assert f.get("a")[9] == 9.0
+
+
+def test_every_entry_point_survives_null_arguments(ncio):
+    """Each function of include/mpassit_ncio.h with NULL / zero for every argument: an error code (ncio_close(NULL): a no-op), never a crash."""
+    import ctypes as C
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mpassit_ncio.h")).read()
+    names = sorted(set(re.findall(r"\b(ncio_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 28
+    zeros = [C.c_void_p(0)] * 12
+    for n in names:
+        if n in ("ncio_strerror", "ncio_msleep", "ncio_has_netcdf4"):
+            continue
+        fn = getattr(ncio.lib(), n)
+        fn.restype = C.c_int
+        rc = fn(*zeros)
+        assert (rc == 0) if n == "ncio_close" else (rc < 0), (n, rc)
