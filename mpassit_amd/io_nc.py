@@ -7,11 +7,10 @@ Mirrors the nf90 calls of the reference with the classic-format library of this 
                                                  transpose of :653-655 is not done
   write_target_data  write_data.F90:173-1498    dimensions, global attributes, grid variables, fields after the
                                                  post-ops of post.output_fields; NF90_FLOAT everywhere
-Differences, all forced by the build image (no libnetcdf): files are NetCDF CLASSIC (CDF-5 by default, CDF-2 on
-request), not NetCDF-4; input files in NetCDF-4 have to be converted (`nccopy -k cdf5`) -- ncio says so when it meets
-one.  `write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
-import os
-
+Differences, all forced by the build image (no libnetcdf): files are NetCDF CLASSIC by default (CDF-5, CDF-2 on request:
+their variables are byte ranges, which the device-resident flow moves file <-> GPU as they are); NetCDF-4 files (fmt=4 for the output; inputs
+recognised by their magic) go through libhdf5 and host arrays where ncio was built with it -- a build without says how to convert.
+`write_mpas_files` produces synthetic input files in the MPAS layout for tests and demos."""
 import numpy as np
 
 from . import _lib as L

@@ -214,7 +214,6 @@ def regional_hex_mesh(proj, x0, y0, q_cells, r_cells, spacing, seed=SEED, jitter
     # triangles between lattice rows g and g+1 (ghost indices); parity refers to the KEPT row index
     # r = g-1, whose odd rows are shifted by +0.5 -> ghost row g is shifted iff (g-1)%2==1.
     g = np.arange(R - 1)[:, None]
-    q = np.arange(Q - 1)[None, :]
     shifted = ((g - 1) % 2 == 1)  # row g shifted
     p00, p01 = gid[:-1, :-1], gid[:-1, 1:]  # (g,q), (g,q+1)
     p10, p11 = gid[1:, :-1], gid[1:, 1:]    # (g+1,q), (g+1,q+1)
