@@ -63,6 +63,8 @@ int mpg_init(int device);
 int mpg_warmup_wait(void);
 int mpg_finalize(void);
 const char *mpg_last_error(void);
+/* number of GPUs the process sees (0 when there is none); needs no mpg_init: a launcher's ranks choose their device with it */
+int mpg_device_count(int *n);
 /* "gfx950" etc.; buf may be NULL */
 int mpg_device_info(char *arch_buf, int buf_len, int *n_cu, int64_t *hbm_bytes);
 

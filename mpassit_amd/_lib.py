@@ -20,7 +20,7 @@ SYMBOLS = [
     "mpg_grid_get_rotang", "mpg_grid_get_mapfac", "mpg_grid_rotang_dev", "mpg_handle_source_range", "mpg_mesh_set_source_window",
     "mpg_comm_init", "mpg_comm_destroy", "mpg_comm_info", "mpg_comm_allgather", "mpg_halo_build", "mpg_halo_info", "mpg_halo_exchange_dev",
     "mpg_halo_destroy", "mpg_gather_rows", "mpg_halo_plan_host", "mpg_comm_idfile_verdict", "mpg_pack_rows_dev", "mpg_comm_virtual",
-    "mpg_comm_virtual_stats", "mpg_handle_store_stats", "mpg_debug_scan_i32", "mpg_warmup_wait", "mpg_halo_build_owned", "mpg_halo_plan_owned_host",
+    "mpg_comm_virtual_stats", "mpg_handle_store_stats", "mpg_debug_scan_i32", "mpg_device_count", "mpg_warmup_wait", "mpg_halo_build_owned", "mpg_halo_plan_owned_host",
 ]
 
 MPG_SUCCESS = 0

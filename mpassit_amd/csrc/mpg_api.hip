@@ -260,6 +260,15 @@ int mpg_finalize(void) {
   return MPG_SUCCESS;
 }
 
+// GPUs this process can see; may be called before mpg_init (a launcher's ranks pick their device with it)
+int mpg_device_count(int *n) {
+  MPG_ARG(n, "mpg_device_count: NULL argument");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *n = c;
+  return MPG_SUCCESS;
+}
+
 int mpg_device_info(char *arch_buf, int buf_len, int *n_cu, int64_t *hbm_bytes) {
   MPG_CHECK_INIT();
   hipDeviceProp_t p;

@@ -32,8 +32,9 @@ module program_setup
   ! j_lo..j_hi (the split of regDecomp=(/1,npets/), model_grid.F90:693, by para_range :2428-2441) and regrids rows
   ! je_lo..je_hi -- its own plus one halo row each side, which the CENTER -> EDGE destaggering of its first / last row needs.
   ! Every image reads the input files whole, like every rank of the reference (input_data.F90:645); no data moves between
-  ! the images.  Set by the launcher through MPASSIT_NRANKS / MPASSIT_RANK / MPASSIT_RUN_ID (tools/mpassit_ranks.py).
-  integer :: nranks = 1, myrank = 0, j_lo = 1, j_hi = 0, je_lo = 1, je_hi = 0, ny_ext = 0
+  ! the images.  Set by the launcher: MPASSIT_NRANKS / MPASSIT_RANK / MPASSIT_RUN_ID (tools/mpassit_ranks.py), or the variables of mpiexec / srun
+  ! (setup_ranks below).
+  integer :: nranks = 1, myrank = 0, local_rank = 0, j_lo = 1, j_hi = 0, je_lo = 1, je_hi = 0, ny_ext = 0
   character(len=64) :: run_id = "0"
 
 contains
@@ -102,24 +103,102 @@ contains
     my_cells(1:my_cells_num) = tmp(1:my_cells_num)
   end subroutine read_block_decomp_file
 
+  !> Who am I among how many driver images?  In this order:
+  !!   1. MPASSIT_NRANKS / MPASSIT_RANK / MPASSIT_RUN_ID        -- tools/mpassit_ranks.py (no MPI anywhere)
+  !!   2. the variables an MPI or Slurm launcher gives its ranks   -- `mpiexec -n 8 mpassit namelist.input`, `srun -n 8 ...`, the
+  !!      reference's own launch lines (mpassit.F90:84-96 asks MPI; this driver links no MPI and only reads the launcher's environment):
+  !!        MPICH / hydra   PMI_SIZE, PMI_RANK, MPI_LOCALRANKID;        run tag: the launcher's proxy (parent process id)
+  !!        Open MPI        OMPI_COMM_WORLD_SIZE, _RANK, _LOCAL_RANK;   run tag: PMIX_NAMESPACE (or the parent process id)
+  !!        Slurm srun      SLURM_NTASKS, SLURM_PROCID, SLURM_LOCALID;  run tag: SLURM_JOB_ID.SLURM_STEP_ID -- only inside a job STEP
+  !!                        (SLURM_STEP_ID set): a plain `./mpassit` in a batch script also sees SLURM_NTASKS and must stay one image
+  !!   3. one image.
+  !! local_rank is the rank's number on its node: the GPU it takes when MPASSIT_DEVICE says nothing (modulo the node's GPUs).
   subroutine setup_ranks()
     character(len=64) :: buf
     integer :: ios
+    interface
+      function c_getppid() bind(C, name="getppid") result(p)
+        use, intrinsic :: iso_c_binding, only: c_int
+        integer(c_int) :: p
+      end function c_getppid
+    end interface
+    local_rank = 0
     call get_environment_variable("MPASSIT_NRANKS", buf)
     if (len_trim(buf) > 0) then
       read (buf, *, iostat=ios) nranks
       if (ios /= 0 .or. nranks < 1) call fatal("MPASSIT_NRANKS must be a positive integer", ios)
+      call get_environment_variable("MPASSIT_RANK", buf)
+      if (len_trim(buf) > 0) then
+        read (buf, *, iostat=ios) myrank
+        if (ios /= 0 .or. myrank < 0 .or. myrank >= nranks) call fatal("MPASSIT_RANK must lie in 0 .. MPASSIT_NRANKS-1", ios)
+      end if
+      local_rank = myrank
+      call get_environment_variable("MPASSIT_RUN_ID", buf)
+      if (len_trim(buf) > 0) run_id = buf
+      ! the images find each other through marker files named after the run id: a constant default would let the markers of
+      ! a killed earlier run release this one's images early (tools/mpassit_ranks.py draws a fresh id per launch)
+      if (nranks > 1 .and. len_trim(buf) == 0) call fatal("MPASSIT_NRANKS > 1 needs MPASSIT_RUN_ID, unique per launch", nranks)
+      return
     end if
-    call get_environment_variable("MPASSIT_RANK", buf)
-    if (len_trim(buf) > 0) then
-      read (buf, *, iostat=ios) myrank
-      if (ios /= 0 .or. myrank < 0 .or. myrank >= nranks) call fatal("MPASSIT_RANK must lie in 0 .. MPASSIT_NRANKS-1", ios)
+    if (from_launcher("PMI_SIZE", "PMI_RANK", "MPI_LOCALRANKID")) then
+      write (run_id, '(a,i0)') "hydra", c_getppid()
+    else if (from_launcher("OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_LOCAL_RANK")) then
+      call get_environment_variable("PMIX_NAMESPACE", buf)
+      if (len_trim(buf) > 0) then
+        run_id = "ompi"//tag_of(buf)
+      else
+        write (run_id, '(a,i0)') "ompi", c_getppid()
+      end if
+    else
+      call get_environment_variable("SLURM_STEP_ID", buf)
+      if (len_trim(buf) > 0) then
+        if (from_launcher("SLURM_NTASKS", "SLURM_PROCID", "SLURM_LOCALID")) then
+          run_id = "slurm"//trim(buf)
+          call get_environment_variable("SLURM_JOB_ID", buf)
+          run_id = trim(run_id)//"j"//trim(buf)
+        end if
+      end if
     end if
-    call get_environment_variable("MPASSIT_RUN_ID", buf)
-    if (len_trim(buf) > 0) run_id = buf
-    ! the images find each other through marker files named after the run id: a constant default would let the markers of
-    ! a killed earlier run release this one's images early (tools/mpassit_ranks.py draws a fresh id per launch)
-    if (nranks > 1 .and. len_trim(buf) == 0) call fatal("MPASSIT_NRANKS > 1 needs MPASSIT_RUN_ID, unique per launch", nranks)
+    if (nranks > 1) print '(a,i0,a,i0,a,a)', " - LAUNCHED AS RANK ", myrank, " OF ", nranks, " BY AN MPI / SLURM LAUNCHER; RUN TAG ", trim(run_id)
+  contains
+    !> nranks / myrank / local_rank from a launcher's three variables; .false. (and nothing changed) unless the first two are there and sane
+    logical function from_launcher(v_size, v_rank, v_local)
+      character(len=*), intent(in) :: v_size, v_rank, v_local
+      character(len=64) :: b
+      integer :: n, r, l, e1, e2
+      from_launcher = .false.
+      call get_environment_variable(v_size, b)
+      if (len_trim(b) == 0) return
+      read (b, *, iostat=e1) n
+      call get_environment_variable(v_rank, b)
+      if (len_trim(b) == 0) return
+      read (b, *, iostat=e2) r
+      if (e1 /= 0 .or. e2 /= 0 .or. n < 1 .or. r < 0 .or. r >= n) return
+      nranks = n
+      myrank = r
+      local_rank = r
+      call get_environment_variable(v_local, b)
+      if (len_trim(b) > 0) then
+        read (b, *, iostat=e1) l
+        if (e1 == 0 .and. l >= 0) local_rank = l
+      end if
+      from_launcher = .true.
+    end function from_launcher
+    !> letters and digits of a launcher's job name (it goes into file names)
+    function tag_of(txt) result(t)
+      character(len=*), intent(in) :: txt
+      character(len=40) :: t
+      integer :: i, k
+      t = ""
+      k = 0
+      do i = 1, len_trim(txt)
+        if (k >= 40) exit
+        if (verify(txt(i:i), "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789") == 0) then
+          k = k + 1
+          t(k:k) = txt(i:i)
+        end if
+      end do
+    end function tag_of
   end subroutine setup_ranks
 
   !> row blocks once the target grid's size is known

@@ -28,6 +28,7 @@ program mpassit
   logical :: nc_in = .false.
   type(c_ptr) :: nf_in = c_null_ptr
   integer :: nargs, gpu
+  integer(c_int) :: ngpu
   character(len=16) :: envbuf
   logical :: no_reserve, no_window
   integer(int64) :: clk0, clk_prev, clk_now, clk_rate
@@ -51,10 +52,16 @@ program mpassit
              (.not. interp_hist .or. nc_is_classic(hist_file_input_grid)) .and. (.not. interp_diag .or. nc_is_classic(diag_file_input_grid))
   if (f32_out) dev_flow = dev_flow .and. nc_output_format() /= 4
   if (dev_flow) print *, "- NETCDF IN AND OUT: FIELDS STAY ON THE DEVICE BETWEEN THE FILES"
-  ! one image per GPU: MPASSIT_DEVICE (set by the launcher: rank modulo the GPUs of the node), else device 0
+  ! one image per GPU: MPASSIT_DEVICE (tools/mpassit_ranks.py sets it), else the rank's number on its node modulo the node's GPUs
+  ! (a rank started by mpiexec / srun), else device 0
   call get_environment_variable("MPASSIT_DEVICE", envbuf)
   gpu = 0
-  if (len_trim(envbuf) > 0) read (envbuf, *) gpu
+  if (len_trim(envbuf) > 0) then
+    read (envbuf, *) gpu
+  else if (local_rank > 0) then
+    call mpg_check(mpg_device_count(ngpu), "COUNTING GPUS")
+    if (ngpu > 0) gpu = mod(local_rank, int(ngpu))
+  end if
   call get_environment_variable("MPASSIT_NO_RESERVE", envbuf)   ! A/B switches for measurements (tools/config4_file_job.py)
   no_reserve = len_trim(envbuf) > 0
   call get_environment_variable("MPASSIT_NO_WINDOW", envbuf)

@@ -42,6 +42,12 @@ module mpg
       integer(c_int) :: rc
     end function mpg_init
 
+    function mpg_device_count(n) bind(C, name="mpg_device_count") result(rc)
+      import :: c_int
+      integer(c_int), intent(out) :: n
+      integer(c_int) :: rc
+    end function mpg_device_count
+
     function mpg_finalize() bind(C, name="mpg_finalize") result(rc)
       import :: c_int
       integer(c_int) :: rc

@@ -426,3 +426,36 @@ def test_a_damaged_grid_file_stops_the_driver_with_the_librarys_message(tmp_path
     got = io_nc.read_grid(os.path.join(d, "init.nc"))[0]
     with pytest.raises(_lib.MpgError, match="verticesOnCell refers to vertex"):
         R.Mesh.from_mpas(got)
+
+
+def test_the_references_launch_line_works_mpiexec_starts_the_images(tmp_path, gpu_lib, regional_case):
+    """`mpiexec -n 3 mpassit namelist.input` -- the reference's own launch line (mpassit.F90:84-96 asks MPI for rank and size).  This driver
+    links no MPI; it reads the launcher's environment (hydra: PMI_SIZE / PMI_RANK / MPI_LOCALRANKID; Open MPI's and srun's variables the
+    same way) and its images find each other through the marker files, tagged with the launcher's process id.  The file is the single
+    image's, byte for byte; a batch script's SLURM_NTASKS alone (no job step) must NOT turn a plain run into rank 0 of many."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec in this image")
+    m, _ = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc")
+    open(os.path.join(d, "namelist.one"), "w").write(nml)
+    open(os.path.join(d, "namelist.mpi"), "w").write(nml.replace("out.nc", "out_mpi.nc"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("MPASSIT_", "PMI_", "OMPI_", "SLURM_"))}
+    r = subprocess.run([_driver(), "namelist.one"], cwd=d, capture_output=True, text=True, timeout=300, env=dict(env, SLURM_NTASKS="8", SLURM_PROCID="0"))
+    assert r.returncode == 0 and "LAUNCHED AS RANK" not in r.stdout, r.stdout + r.stderr          # no job step: one image
+    r = subprocess.run([mpiexec, "-n", "3", _driver(), "namelist.mpi"], cwd=d, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in range(3):
+        assert "LAUNCHED AS RANK %d OF 3 BY AN MPI / SLURM LAUNCHER; RUN TAG hydra" % k in r.stdout, r.stdout[-3000:]
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_mpi.nc"), "rb").read()
+    assert not [f for f in os.listdir(d) if ".ready" in f or ".done." in f]
+    # srun's variables, set by hand for two processes started side by side (a job step: SLURM_STEP_ID is there)
+    open(os.path.join(d, "namelist.srun"), "w").write(nml.replace("out.nc", "out_srun.nc"))
+    ps = [subprocess.Popen([_driver(), "namelist.srun"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(env, SLURM_NTASKS="2", SLURM_PROCID=str(k), SLURM_LOCALID=str(k), SLURM_STEP_ID="0", SLURM_JOB_ID="4711")) for k in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in ps]
+    assert all(p.returncode == 0 for p in ps), outs
+    assert "RUN TAG slurm0j4711" in outs[0] and "LAUNCHED AS RANK 1 OF 2" in outs[1]
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_srun.nc"), "rb").read()
