@@ -9,6 +9,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The Fortran driver reads an MPI / Slurm launcher's variables to find its rank (host_mod.F90 setup_ranks).  Should the test box itself have
+# been started by such a launcher, the single-image runs of these tests must not take themselves for one rank of its job.
+for _k in [k for k in os.environ if k in ("PMI_RANK", "PMI_SIZE", "MPI_LOCALRANKID", "SLURM_STEP_ID", "SLURM_NTASKS", "SLURM_PROCID", "SLURM_LOCALID") or
+           k.startswith("OMPI_COMM_WORLD_")]:
+    del os.environ[_k]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
