@@ -424,12 +424,26 @@ contains
     character(len=*), intent(in) :: file
     logical :: there
     integer(int64) :: c0, c1, cr
+    real(dp) :: limit
+    character(len=32) :: e
+    character(len=200) :: msg
+    integer :: ios
+    limit = 1800.0_dp                              ! MPASSIT_WAIT_S: how long an image waits for another's marker
+    call get_environment_variable("MPASSIT_WAIT_S", e)
+    if (len_trim(e) > 0) then
+      read (e, *, iostat=ios) limit
+      if (ios /= 0 .or. limit <= 0.0_dp) limit = 1800.0_dp
+    end if
     call system_clock(c0, cr)
     do
       inquire (file=trim(file), exist=there)
       if (there) exit
       call system_clock(c1)
-      if (real(c1 - c0, dp)/real(cr, dp) > 1800.0_dp) call fatal("timed out waiting for "//trim(file), -1)
+      if (real(c1 - c0, dp)/real(cr, dp) > limit) then
+        write (msg, '(a,i0,a,i0,a,i0,a)') "image ", myrank, " of ", nranks, " waited ", int(limit), &
+          " s for another image's marker (are all images running? MPASSIT_NRANKS, or mpiexec's / srun's rank variables, say how many there are) - "
+        call fatal(trim(msg)//trim(file), -1)
+      end if
       if (ncio_msleep(2_c_int) /= 0) exit
     end do
   end subroutine wait_for

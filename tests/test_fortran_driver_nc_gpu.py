@@ -459,3 +459,20 @@ def test_the_references_launch_line_works_mpiexec_starts_the_images(tmp_path, gp
     assert all(p.returncode == 0 for p in ps), outs
     assert "RUN TAG slurm0j4711" in outs[0] and "LAUNCHED AS RANK 1 OF 2" in outs[1]
     assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_srun.nc"), "rb").read()
+
+
+def test_an_image_whose_peers_never_come_stops_with_a_message(tmp_path, gpu_lib, regional_case):
+    """Rank 1 of 2 by srun's variables, but nobody is rank 0 (a stray environment, a rank that died before its marker): the image waits
+    MPASSIT_WAIT_S and stops saying how many images it expected -- it does not hang, and it writes nothing."""
+    import time
+    m, _ = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    open(os.path.join(d, "namelist.input"), "w").write(NAMELIST.format(d=d).replace(".raw", ".nc"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("MPASSIT_", "PMI_", "OMPI_", "SLURM_"))}
+    t0 = time.monotonic()
+    r = subprocess.run([_driver(), "namelist.input"], cwd=d, capture_output=True, text=True, timeout=300,
+                       env=dict(env, SLURM_NTASKS="2", SLURM_PROCID="1", SLURM_LOCALID="1", SLURM_STEP_ID="3", SLURM_JOB_ID="9", MPASSIT_WAIT_S="3"))
+    assert r.returncode != 0 and time.monotonic() - t0 < 120
+    assert "image 1 of 2 waited 3 s for another image's marker" in r.stdout + r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
+    assert not os.path.exists(os.path.join(d, "out.nc"))
