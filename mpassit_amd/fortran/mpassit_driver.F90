@@ -51,6 +51,10 @@ program mpassit
   dev_flow = f32_out .and. len_trim(envbuf) == 0 .and. nc_is_classic(grid_file_input_grid) .and. &
              (.not. interp_hist .or. nc_is_classic(hist_file_input_grid)) .and. (.not. interp_diag .or. nc_is_classic(diag_file_input_grid))
   if (f32_out) dev_flow = dev_flow .and. nc_output_format() /= 4
+  ! several images share one output file through its variables' byte ranges and regrid row blocks of device-resident fields: that is the
+  ! device flow only -- said here, before any image has sized an array for a flow that does not exist
+  if (nranks > 1 .and. .not. dev_flow) call fatal("several driver images need NetCDF CLASSIC files in and out (the device-resident flow; "// &
+                                                  "NetCDF-4, the raw container and MPASSIT_HOST_ARRAYS go through one image)", nranks)
   if (dev_flow) print *, "- NETCDF IN AND OUT: FIELDS STAY ON THE DEVICE BETWEEN THE FILES"
   ! one image per GPU: MPASSIT_DEVICE (tools/mpassit_ranks.py sets it), else the rank's number on its node modulo the node's GPUs
   ! (a rank started by mpiexec / srun), else device 0
