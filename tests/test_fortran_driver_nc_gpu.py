@@ -178,6 +178,10 @@ def test_driver_with_a_file_defined_target_grid(tmp_path, gpu_lib, regional_case
     with ncio.Reader(os.path.join(d, "out.nc")) as f, ncio.Reader(os.path.join(d, "out_py.nc")) as fp:
         for k in ("XLAT", "XLONG_U", "MAPFAC_M", "MAPFAC_V", "SINALPHA", "COSALPHA", "T", "U", "V", "XLAND", "TSLB", "P_TOP"):
             assert np.array_equal(f.get(k, rec=0), fp.get(k, rec=0)), k
+    # ... and so do two driver images (row blocks of a grid that came from a file): the single image's file, byte for byte
+    open(os.path.join(d, "namelist.two"), "w").write(nml.replace("out.nc", "out2.nc"))
+    _run_images(d, "namelist.two", 2)
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out2.nc"), "rb").read()
 
 
 def test_driver_on_a_global_latlon_grid(tmp_path, gpu_lib):
