@@ -483,3 +483,31 @@ def test_an_image_whose_peers_never_come_stops_with_a_message(tmp_path, gpu_lib,
     assert r.returncode != 0 and time.monotonic() - t0 < 120
     assert "image 1 of 2 waited 3 s for another image's marker" in r.stdout + r.stderr, r.stdout[-2000:] + r.stderr[-2000:]
     assert not os.path.exists(os.path.join(d, "out.nc"))
+
+
+@pytest.mark.parametrize("flags", [dict(interp_diag=".false."), dict(interp_hist=".false."), dict(wrf_mod_vars=".false."),
+                                   dict(interp_diag=".false.", wrf_mod_vars=".false.")], ids=lambda f: "+".join("%s=%s" % kv for kv in f.items()))
+def test_flag_combinations_one_image_two_images_host_arrays(tmp_path, gpu_lib, regional_case, flags):
+    """The namelist's switches (program_setup.F90:103-106: only the diag file, only the history file, no WRF post-ops) through the three
+    flows of the driver -- device resident, host arrays, two images: each runs, and all three write the same bytes."""
+    m, _ = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc")
+    for k, v in flags.items():
+        assert "%s=.true." % k in nml
+        nml = nml.replace("%s=.true." % k, "%s=%s" % (k, v))
+    open(os.path.join(d, "namelist.dev"), "w").write(nml)
+    open(os.path.join(d, "namelist.host"), "w").write(nml.replace("out.nc", "out_host.nc"))
+    open(os.path.join(d, "namelist.two"), "w").write(nml.replace("out.nc", "out_two.nc"))
+    r = subprocess.run([_driver(), "namelist.dev"], cwd=d, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "FIELDS STAY ON THE DEVICE" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([_driver(), "namelist.host"], cwd=d, capture_output=True, text=True, timeout=300, env=dict(os.environ, MPASSIT_HOST_ARRAYS="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    _run_images(d, "namelist.two", 2)
+    one = open(os.path.join(d, "out.nc"), "rb").read()
+    assert one == open(os.path.join(d, "out_host.nc"), "rb").read() and one == open(os.path.join(d, "out_two.nc"), "rb").read()
+    from mpassit_amd import ncio
+    with ncio.Reader(os.path.join(d, "out.nc")) as f:
+        assert ("T2" in f.vars) == (flags.get("interp_diag") != ".false.") and ("TSK" in f.vars) == (flags.get("interp_hist") != ".false.")
+        assert ("P_TOP" in f.vars) == (flags.get("wrf_mod_vars") != ".false." and flags.get("interp_hist") != ".false.")
