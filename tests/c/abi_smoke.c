@@ -41,6 +41,12 @@ int main(void) {
     fprintf(stderr, "FAIL: calls before mpg_init must return MPG_ERR_NOT_INITIALIZED\n");
     return 1;
   }
+  int ngpu = -1;
+  CHECK(mpg_device_count(&ngpu));   /* before mpg_init: a launcher's ranks choose their device with it */
+  if (ngpu < 1) {
+    fprintf(stderr, "FAIL: mpg_device_count sees %d GPUs\n", ngpu);
+    return 1;
+  }
   CHECK(mpg_init(0));
   mpg_mesh mesh;
   CHECK(mpg_mesh_create(4, 4, 3, latC, lonC, latV, lonV, &voc[0][0], &mesh));
