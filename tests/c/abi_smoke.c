@@ -43,11 +43,15 @@ int main(void) {
   }
   int ngpu = -1;
   CHECK(mpg_device_count(&ngpu));   /* before mpg_init: a launcher's ranks choose their device with it */
-  if (ngpu < 1) {
-    fprintf(stderr, "FAIL: mpg_device_count sees %d GPUs\n", ngpu);
+  if (ngpu < 0) {
+    fprintf(stderr, "FAIL: mpg_device_count left %d\n", ngpu);
     return 1;
   }
-  CHECK(mpg_init(0));
+  CHECK(mpg_init(0));               /* (no GPU: fails here, saying that there is no CPU fallback) */
+  if (ngpu < 1) {
+    fprintf(stderr, "FAIL: mpg_init succeeded although mpg_device_count saw no GPU\n");
+    return 1;
+  }
   mpg_mesh mesh;
   CHECK(mpg_mesh_create(4, 4, 3, latC, lonC, latV, lonV, &voc[0][0], &mesh));
   enum { NX = 12, NY = 6 };
