@@ -7,7 +7,7 @@ fields in file order with its fraction of the HBM roofline, and parity where the
   * bilinear and nearest on a SAMPLE of target points (a 256 x 256 patch + random points) against the oracle (its own search structures);
   * conservative on a 96 x 96 patch of destination cells against the oracle; every row of the global grid sums to 1;
   * a constant field comes back constant on every mapped point.
-usage (GPU box): python tools/scale_probe.py [--level 10] [--fields 4] [--targets conus,global]"""
+usage (GPU box): python tests/scale_probe.py [--level 10] [--fields 4] [--targets conus,global]"""
 import argparse
 import json
 import os
@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))   # (this script lives in tests/: it calls the oracle, which only tests may)
 
 
 def lap(t0):
