@@ -68,6 +68,11 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 bad = re.search(r"import oracle|from oracle|libmpassit_oracle|#include\s*[\"<][^\"\n>]*oracle|orc_[a-z_]+\s*\(", txt)
                 assert bad is None, (os.path.join(dirpath, f), bad.group(0))
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):          # the tools are no tests either: none of them may call the oracle
+        if f.endswith((".py", ".sh", ".c", ".hip")) and f != "sanitize_cpu.sh":   # (sanitize_cpu.sh BUILDS the oracle with sanitizers for the tests it then runs)
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            bad = re.search(r"import oracle|from oracle|libmpassit_oracle|orc_[a-z_]+\s*\(", txt)
+            assert bad is None, (f, bad.group(0))
     code = ("import sys; sys.path.insert(0, %r); import mpassit_amd, mpassit_amd.regrid, mpassit_amd.interp, mpassit_amd.dist, "
             "mpassit_amd.fields, mpassit_amd.target_grid, mpassit_amd.workloads; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
