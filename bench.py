@@ -377,6 +377,17 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     copy_gbs = 5 * 2 * cp_a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    # ... and what the same memory system gives a 2 reads : 1 write mix (the headline kernel's traffic is 61 : 39) and pure writes
+    # (profiles/r05_hbm_mix.md: no mix reaches the data sheet's 8 TB/s; a copy's 1 : 1 is the slowest)
+    mix = {}
+    for key, fn, nbytes in (("device_add_2r1w_GBs", lambda: torch.add(cp_a, cp_b, out=cp_b), 3), ("device_fill_GBs", lambda: cp_b.fill_(1.5), 1)):
+        fn()
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        mix[key] = 5 * nbytes * cp_a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del cp_a, cp_b
 
     U = sr.n_needed
@@ -460,7 +471,7 @@ def main():
             "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
                               "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
-                              "device_copy_GBs": copy_gbs}, **flat),
+                              "device_copy_GBs": copy_gbs, **mix}, **flat),
             "cpu_baseline": cpu,
             "end_to_end_pcie": e2e,
             "production_path": production,
