@@ -435,6 +435,8 @@ int mpg_halo_plan_owned_host(int rank, int nranks, const int64_t *n_needed, cons
  *                 along the ray from the sphere's centre; 1 along the plane's normal (ESMF_LINETYPE_CART read literally).
  *                 In force at mpg_regrid_store time; the two differ by O(h^2) of the triangle size
  *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice (default 35)
+ *   "lfu_npf"     row slots per thread of the staged level-fast kernel: 0 (default) = by the handle's longest tile list (2 / 4 / 8 / 16),
+ *                 16 = the fixed shape of rounds 1-4 (A/B measurements; the results are the same bits)
  * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */
 int mpg_tune(const char *key, int value);
 

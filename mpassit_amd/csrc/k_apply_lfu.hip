@@ -522,12 +522,17 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32,
 // and stores is not what holds this kernel back, and the form was not kept.  Nor is occupancy: the float32 form holds 94 VGPRs
 // (two workgroups = 16 waves per CU); asked to fit 80 / 64 registers (three / four workgroups, no scratch) it ran 6.39 / 6.59
 // ms against 6.40-6.45.
-template <typename TS, typename TD, int NT, bool EPI, bool SWZ>
+// Round 5: NPF, the row slots a thread loads and parks per chunk (NT / 16 * NPF rows in the slab), follows the handle's longest tile list
+// instead of being 16 for everyone: a tile of a coarse mesh under a fine grid lists 30-60 cells, and the branch-free form above spent as many
+// instructions re-loading and re-parking the list's last row 450 times as it spent on the 512 points (a write-dominated global 0.05-degree
+// target on the 655 k mesh: 7.3 ms = 0.42 of 8 TB/s, where the bare store pattern of the same tiles runs at 5.3 TB/s,
+// tools/store_pattern_probe.hip).  Same arithmetic, same bits.
+template <typename TS, typename TD, int NT, bool EPI, bool SWZ, int NPF>
 __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w, const TS *__restrict__ src,
                                                    TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc, int nlev, int ntx, int nty,
                                                    double scale, double offset, int sbe, int dbe, int band, FieldTab tab) {
-  constexpr int LC = 16, NPF = 16, LS = LC + 1, RPP = NT / LC, TY = NT / 64, ZROW = NPF * RPP;
+  constexpr int LC = 16, LS = LC + 1, RPP = NT / LC, TY = NT / 64, ZROW = NPF * RPP;
   extern __shared__ double lds_raw[];
   TS *slab = (TS *)lds_raw;                                  // [ZROW + 1][LS]; row ZROW stays zero
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
@@ -608,20 +613,38 @@ __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ u
   }
 }
 
-template <typename TS, typename TD, int NT, bool EPI>
-static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
-                      hipStream_t s, const FieldTab &tab) {
+static int g_lfu_npf = 0;   // "lfu_npf" knob: 0 = by the handle's longest tile list, 2 / 4 / 8 / 16 = that many row slots per thread (A/B)
+void mpg_lfu_set_npf(int v) { g_lfu_npf = v; }
+
+template <typename TS, typename TD, int NT, bool EPI, int NPF>
+static int launch_lfu_n(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
+                        hipStream_t s, const FieldTab &tab) {
   const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + NT / 64 - 1) / (NT / 64);
-  const size_t lds = sizeof(TS) * (NT + 1) * 17;
-  if (h->ut_max > NT || h->ut_stride < NT || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
+  constexpr int ROWS = NT / 16 * NPF;   // rows of the slab
+  const size_t lds = sizeof(TS) * (ROWS + 1) * 17;
+  if (h->ut_max > ROWS || h->ut_stride < ROWS || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
     return MPG_ERR_UNSUPPORTED;
-  static_assert(NT <= LFU_LIST_PAD, "the kernel reads NT list entries of every tile");
-  auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true> : k_apply3_lfu<TS, TD, NT, EPI, false>;
+  static_assert(ROWS <= LFU_LIST_PAD, "the kernel reads ROWS list entries of every tile");
+  auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true, NPF> : k_apply3_lfu<TS, TD, NT, EPI, false, NPF>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
                                                    h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe, mpg_field_band(0), tab);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
+}
+template <typename TS, typename TD, int NT, bool EPI>
+static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
+                      hipStream_t s, const FieldTab &tab) {
+  constexpr int RPP = NT / 16;
+  int npf = g_lfu_npf;
+  if (npf == 0) npf = h->ut_max <= 2 * RPP ? 2 : h->ut_max <= 4 * RPP ? 4 : h->ut_max <= 8 * RPP ? 8 : 16;
+  if (npf * RPP < h->ut_max) npf = 16;   // (a forced value too small for this handle)
+  switch (npf) {
+    case 2: return launch_lfu_n<TS, TD, NT, EPI, 2>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+    case 4: return launch_lfu_n<TS, TD, NT, EPI, 4>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+    case 8: return launch_lfu_n<TS, TD, NT, EPI, 8>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+    default: return launch_lfu_n<TS, TD, NT, EPI, 16>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  }
 }
 
 #define LFU_NT 512   // 64 x 8-point tiles; float32 rows: 35 KB of LDS, four workgroups of eight waves per CU; float64: 70 KB, two

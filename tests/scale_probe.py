@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--fields", type=int, default=4)
     ap.add_argument("--targets", default="conus,global")
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for mpg_tune (A/B of a knob)")
     args = ap.parse_args()
     import torch
 
@@ -43,6 +44,8 @@ def main():
     out["mesh"] = {"nCells": int(m.nCells), "nVertices": int(m.nVertices), "generated_s": lap(t0)}
     print("mesh: %d cells, %d vertices, generated in %.0f s" % (m.nCells, m.nVertices, out["mesh"]["generated_s"]), flush=True)
     _lib.init(0)
+    for kv in args.tune:
+        _lib.tune(kv.split("=")[0], int(kv.split("=")[1]))
     t0 = time.perf_counter()
     mesh = R.Mesh.from_mpas(m)
     torch.cuda.synchronize()
