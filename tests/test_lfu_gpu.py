@@ -144,3 +144,38 @@ def test_staged_level_fast_kernel_at_every_chunk_boundary(gpu_lib, nlev):
     rh.release()
     mesh.destroy()
     grid.destroy()
+
+
+@pytest.mark.parametrize("n_cells,band", [(1500, (1, 64)), (4000, (65, 128)), (9000, (129, 256)), (20000, (257, 512))])
+def test_every_row_slot_variant_of_the_staged_level_fast_kernel(gpu_lib, n_cells, band):
+    """Round 5: the staged level-fast kernel's row slots per thread follow the handle's longest tile list (2 / 4 / 8 / 16: slabs of 64 / 128 /
+    256 / 512 rows).  Meshes of four densities under one 241 x 161 grid put that list into each band; the staged result equals the row
+    gather's and the cell-fast kernel's bit for bit -- with the automatic choice, with every larger forced value, and with a forced value too
+    small for the handle (which the launcher must not take)."""
+    from mpassit_amd import regrid as R, synth, target_grid as T
+    g = T.define_target_grid_params("lambert", 242, 162, dx=12000.0, dy=12000.0, ref_lat=38.5, ref_lon=-97.5, truelat1=38.5, truelat2=38.5, stand_lon=-97.5)
+    m = synth.regional_mesh_for_lambert(g.proj, 242, 162, n_cells, margin=0.02)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
+    rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    nlev, nf = 21, 2
+    rng = np.random.default_rng(n_cells)
+    src = rng.normal(size=(nf, nlev, m.nCells)).astype(np.float32)
+    src_lf = np.ascontiguousarray(src.transpose(0, 2, 1))
+    want = rh.regrid_typed_host(src.reshape(-1), nlev=nlev, nfields=nf)                       # cell-fast kernels
+    try:
+        gpu_lib.tune("lf_variant", 0)
+        rows = rh.regrid_typed_host(src_lf.reshape(-1), nlev=nlev, nfields=nf, layout=R.LAYOUT_LEV_FAST)
+        assert np.array_equal(rows, want)
+        gpu_lib.tune("lf_variant", 1)                                                        # staged, whatever the reuse statistic says
+        for npf in (0, 2, 4, 8, 16):
+            gpu_lib.tune("lfu_npf", npf)
+            got = rh.regrid_typed_host(src_lf.reshape(-1), nlev=nlev, nfields=nf, layout=R.LAYOUT_LEV_FAST)
+            assert np.array_equal(got, want), "lfu_npf %d" % npf
+        ut_max = rh.kernel_choice()[2]
+        assert band[0] <= ut_max <= band[1], (ut_max, band)                                   # the case is in the band it was built for
+    finally:
+        gpu_lib.tune("lf_variant", -1)
+        gpu_lib.tune("lfu_npf", 0)
+    rh.release()
+    mesh.destroy()
+    grid.destroy()
