@@ -90,6 +90,13 @@ def workload(name, arrays=True):
         m = synth.icosahedral_mesh(level)
         return m, g, 55, "%d-cell global icosahedral mesh x 55 levels -> %dx%d global lat-lon (%dx%d mass points)" % (
             m.nCells, nx, ny, nx - 1, ny - 1)
+    if name == "x_655k_global005":
+        # extra workload (not a BASELINE config): a COARSE mesh under a FINE global grid -- 655 362 cells (30 km) -> 7200 x 3600 points (0.05 degrees):
+        # 40 target points per cell, 94 % of the algorithmic bytes are stores.  The shape that showed the staged level-fast kernel's fixed row
+        # slots (profiles/r05_lfu_npf.md); use --fields 4 (thirteen 55-level float64 fields of 25.9 M points are 148 GB)
+        g = tg.define_target_grid_params("lat-lon", 7201, 3601, stand_lon=0.0, is_regional=False)
+        m = synth.icosahedral_mesh(8)
+        return m, g, 55, "655 362-cell global icosahedral mesh x 55 levels -> 7201x3601 global lat-lon (7200x3600 mass points)"
     if name == "c4_3m_morton":
         # configuration 4 with a REALISTIC cell numbering: the same 3.0 M cells, renumbered along a Morton curve
         # (locality-preserving, not row-banded -- what a production mesh reordered by a space-filling curve or a graph

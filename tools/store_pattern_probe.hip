@@ -15,7 +15,7 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned lin, unsigned n) {   // g
 }
 
 // TW x TH points per workgroup of NT threads; thread t owns points t, t + NT, ... of the tile (x fastest); LC levels per chunk
-template <int TW, int TH, int NT, int LC, bool REMAP>
+template <int TW, int TH, int NT, int LC, bool REMAP, bool ALIGN>
 __global__ __launch_bounds__(NT) void k_tiles(float *__restrict__ dst, int nx, int ny, int nlev, int ntx) {
   const unsigned tile = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
   const int tx = tile % ntx, ty = tile / ntx;
@@ -26,11 +26,33 @@ __global__ __launch_bounds__(NT) void k_tiles(float *__restrict__ dst, int nx, i
     for (int kk = 0; kk < kn; ++kk) {
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
-        const int pt = threadIdx.x + NT * r, i = tx * TW + pt % TW, j = ty * TH + pt / TW;
-        if (i < nx && j < ny) __builtin_nontemporal_store((float)(k0 + kk) + 0.5f, dst + (int64_t)(k0 + kk) * P + (int64_t)j * nx + i);
+        const int pt = threadIdx.x + NT * r, j = ty * TH + pt / TW, i = tx * TW + pt % TW - (ALIGN ? (int)(((long long)j * nx) % 32) : 0);
+        if (i >= 0 && i < nx && j < ny) __builtin_nontemporal_store((float)(k0 + kk) + 0.5f, dst + (int64_t)(k0 + kk) * P + (int64_t)j * nx + i);
       }
     }
     __syncthreads();   // the kernel's chunk barrier
+  }
+}
+
+// the same with TWO adjacent points per lane (one 8-byte store: 512 bytes per wave-instruction, what a float64 result gets for free)
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int TW, int TH, int NT, int LC>
+__global__ __launch_bounds__(NT) void k_tiles2(float *__restrict__ dst, int nx, int ny, int nlev, int ntx) {
+  const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % ntx, ty = tile / ntx;
+  constexpr int RPT = TW * TH / NT / 2;
+  const int64_t P = (int64_t)nx * ny;
+  for (int k0 = 0; k0 < nlev; k0 += LC) {
+    const int kn = min(LC, nlev - k0);
+    for (int kk = 0; kk < kn; ++kk) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int pt = 2 * (threadIdx.x + NT * r), j = ty * TH + pt / TW, i = tx * TW + pt % TW - (int)(((long long)j * nx) % 32 & ~1);   // (even shift: pairs stay 8-byte aligned)
+        const f2 v = {(float)(k0 + kk) + 0.5f, (float)(k0 + kk) + 0.25f};
+        if (i >= 0 && i + 1 < nx && j < ny) __builtin_nontemporal_store(v, (f2 *)(dst + (int64_t)(k0 + kk) * P + (int64_t)j * nx + i));
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -58,11 +80,11 @@ static double timed(F launch, int n = 5) {
   return ms / n * 1e-3;
 }
 
-template <int TW, int TH, int NT, bool REMAP>
+template <int TW, int TH, int NT, bool REMAP, bool ALIGN = false>
 static void run(const char *name, float *d, int nx, int ny, int nlev) {
-  const int ntx = (nx + TW - 1) / TW, nty = (ny + TH - 1) / TH;
+  const int ntx = (nx + 31 + TW - 1) / TW, nty = (ny + TH - 1) / TH;
   const double gb = (double)nx * ny * nlev * 4 / 1e9;
-  double t = timed([&] { k_tiles<TW, TH, NT, 16, REMAP><<<ntx * nty, NT>>>(d, nx, ny, nlev, ntx); });
+  double t = timed([&] { k_tiles<TW, TH, NT, 16, REMAP, ALIGN><<<ntx * nty, NT>>>(d, nx, ny, nlev, ntx); });
   printf("  %-28s %7.0f GB/s\n", name, gb / t);
 }
 
@@ -77,12 +99,22 @@ int main() {
     double t = timed([&] { k_fill<<<8192, 256>>>((f4 *)d, n / 4); });
     printf("  %-28s %7.0f GB/s\n", "linear fill (float4)", n * 4 / 1e9 / t);
     run<64, 8, 512, true>("64 x 8 tiles (the kernel's)", d, nx, ny, nlev);
+    run<64, 8, 512, true, true>("64 x 8, rows shifted to 128 B", d, nx, ny, nlev);
     run<64, 8, 512, false>("64 x 8, no XCD remap", d, nx, ny, nlev);
     run<64, 4, 256, true>("64 x 4 tiles, 256 threads", d, nx, ny, nlev);
     run<64, 16, 512, true>("64 x 16 tiles", d, nx, ny, nlev);
     run<128, 4, 512, true>("128 x 4 tiles", d, nx, ny, nlev);
     run<256, 2, 512, true>("256 x 2 tiles", d, nx, ny, nlev);
     run<512, 1, 512, true>("512 x 1 tiles", d, nx, ny, nlev);
+    {
+      const double gb = (double)nx * ny * nlev * 4 / 1e9;
+      int ntx = (nx + 31 + 127) / 128, nty = (ny + 7) / 8;
+      double t2 = timed([&] { k_tiles2<128, 8, 512, 16><<<ntx * nty, 512>>>(d, nx, ny, nlev, ntx); });
+      printf("  %-28s %7.0f GB/s\n", "128 x 8, 2 per lane, shifted", gb / t2);
+      ntx = (nx + 31 + 127) / 128, nty = (ny + 3) / 4;
+      t2 = timed([&] { k_tiles2<128, 4, 256, 16><<<ntx * nty, 256>>>(d, nx, ny, nlev, ntx); });
+      printf("  %-28s %7.0f GB/s\n", "128 x 4, 2/lane, 256, shifted", gb / t2);
+    }
     CK(hipFree(d));
   }
   return 0;
