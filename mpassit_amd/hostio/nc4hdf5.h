@@ -26,7 +26,7 @@
 #include <hdf5_hl.h>
 
 #define NC4_DIM_WITHOUT_VAR "This is a netCDF dimension but not a netCDF variable."
-#define NC4_MAX_CHUNK ((int64_t)64 << 20)
+#define NC4_CHUNK_TARGET ((int64_t)8 << 20)
 
 typedef struct {
   hid_t file;
@@ -529,10 +529,18 @@ static int nc4_enddef_(ncio_file *f) {
     hid_t s = x->ndims ? H5Screate_simple(x->ndims, cur, mx) : H5Screate(H5S_SCALAR);
     hid_t dcpl = H5Pcreate(H5P_DATASET_CREATE);
     H5Pset_attr_creation_order(dcpl, H5P_CRT_ORDER_TRACKED | H5P_CRT_ORDER_INDEXED);
-    if (x->is_rec) { /* one record per chunk, split along the leading axes until a chunk is at most NC4_MAX_CHUNK */
-      int64_t bytes = tsize(x->type);
-      for (int d = 1; d < x->ndims; ++d) bytes *= (int64_t)ch[d];
-      for (int d = 1; d < x->ndims - 1 && bytes > NC4_MAX_CHUNK; ++d) { bytes /= (int64_t)ch[d]; ch[d] = 1; }
+    if (x->is_rec) {
+      /* One record per chunk while a record is at most NC4_CHUNK_TARGET; a larger one is cut along its slowest axes into pieces of about
+       * that size: whole planes of a [level][y][x] field (a reader that takes one level finds it in one chunk of a few MB), runs of whole
+       * rows of an MPAS-shaped [cell][level] field.  (Never one row per chunk: three million 220-byte chunks are a B-tree, not a file.) */
+      for (int d = 1; d < x->ndims; ++d) {
+        int64_t inner = tsize(x->type);
+        for (int q = d + 1; q < x->ndims; ++q) inner *= (int64_t)ch[q];
+        if (inner * (int64_t)ch[d] <= NC4_CHUNK_TARGET) break;          /* what is left fits: this axis and the faster ones stay whole */
+        if (inner >= NC4_CHUNK_TARGET) { ch[d] = 1; continue; }           /* a single index of this axis is already a chunk's worth: cut the next one too */
+        ch[d] = (hsize_t)(NC4_CHUNK_TARGET / inner);                       /* >= 1: as many indices of this axis as fit */
+        break;
+      }
       H5Pset_chunk(dcpl, x->ndims, ch);
     }
     hid_t own = -1, ft = x->type == NCIO_CHAR ? (own = h5_chartype(1)) : h5_filetype(x->type);

@@ -253,7 +253,7 @@ def test_every_type_round_trips_and_misuse_is_refused(ncio, tmp_path):
             got = r.get("v%d" % t)
             assert got.dtype == a.dtype and np.array_equal(got, a), t
         assert np.allclose(r.get("v%d" % ncio.INT, dtype=np.float64), data[ncio.INT].astype(np.float64))
-    # a large record variable is split into chunks of at most 64 MiB along its leading axes
+    # a large record variable is cut along its slowest axes into chunks of about 8 MiB: levels of a [z][y][x] field, runs of rows of a [cell][level] one
     big = tmp_path / "big.nc"
     w = ncio.Writer(big, format=4)
     w.def_dim("Time", None)
@@ -272,10 +272,25 @@ def test_every_type_round_trips_and_misuse_is_refused(ncio, tmp_path):
     w.close()
     with ncio.Reader(tmp_path / "big64.nc") as r:
         assert np.array_equal(r.get("P", rec=0).reshape(plane.shape), plane)
+    d64 = json.loads(_h5py(DUMP, tmp_path / "big64.nc"))["datasets"]["P"]          # an MPAS-shaped variable: 25.2 M x 1 x 4 B in chunks of 2 M elements
+    assert d64["chunks"] == [1, 2097152]
+    cells = tmp_path / "cells.nc"
+    w = ncio.Writer(cells, format=4)
+    w.def_dim("Time", None)
+    w.def_dim("nCells", 300000)
+    w.def_dim("nVertLevels", 55)
+    w.def_var("theta", ncio.FLOAT, ("Time", "nCells", "nVertLevels"))
+    th = rng.normal(size=(300000, 55)).astype(np.float32)
+    w.put("theta", th, rec=0)
+    w.close()
+    dth = json.loads(_h5py(DUMP, cells))["datasets"]["theta"]
+    assert dth["chunks"] == [1, 38130, 55]                                             # runs of whole rows, 8 MiB each: never one row per chunk
+    with ncio.Reader(cells) as r:
+        assert np.array_equal(r.get("theta", rec=0), th)
     with ncio.Reader(big) as r:
         assert r.numrecs == 1 and np.array_equal(r.get("P", rec=0), plane) and np.array_equal(r.get("P", rec=0, dtype=np.float64), plane.astype(np.float64))
     d = json.loads(_h5py(DUMP, big))["datasets"]["P"]
-    assert d["chunks"] == [1, 1, 700, 900] and abs(d["sum"] - float(plane.astype(float).sum())) < 1e-3
+    assert d["chunks"] == [1, 3, 700, 900] and abs(d["sum"] - float(plane.astype(float).sum())) < 1e-3
 
 
 def test_a_build_without_hdf5_says_so(tmp_path):
