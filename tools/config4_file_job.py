@@ -100,6 +100,12 @@ def main():
     ter = rng.uniform(0, 3000, m.nCells)
     io_nc.write_mpas_files(os.path.join(d, "init.nc"), os.path.join(d, "hist.nc"), m, ter, [0.05, 0.25, 0.7, 1.5], hist, nz, nsoil,
                            diag_path=os.path.join(d, "diag.nc"), diag=diag, xtime="2024-08-07_12:00:00", fmt=5)
+    if os.environ.get("C4JOB_NC4") and ncio.has_netcdf4():   # the same inputs once more as NetCDF-4 files (HDF5 containers; MPAS's io_type "netcdf4")
+        t4 = time.perf_counter()
+        os.makedirs(os.path.join(d, "nc4"), exist_ok=True)
+        io_nc.write_mpas_files(os.path.join(d, "nc4", "init.nc"), os.path.join(d, "nc4", "hist.nc"), m, ter, [0.05, 0.25, 0.7, 1.5], hist, nz, nsoil,
+                               diag_path=os.path.join(d, "nc4", "diag.nc"), diag=diag, xtime="2024-08-07_12:00:00", fmt=4)
+        print("the same inputs as NetCDF-4 files: written in %.0f s" % (time.perf_counter() - t4), flush=True)
     del hist, diag, base
     gb_in = sum(os.path.getsize(os.path.join(d, f)) for f in ("init.nc", "hist.nc", "diag.nc")) / 1e9
     print("inputs: %.2f GB (grid + history + diag) generated and written in %.0f s" % (gb_in, time.perf_counter() - t0), flush=True)
@@ -162,6 +168,24 @@ def main():
                 same_hdr, nvar, worst), flush=True)
             os.remove(p4)
             if worst or not same_hdr:
+                return 1
+            # NetCDF-4 INPUTS (through libhdf5, host arrays), classic output: the device flow's file, byte for byte
+            nml_in = open(os.path.join(d, "namelist.input")).read().replace("%s/init.nc" % d, "%s/nc4/init.nc" % d).replace(
+                "%s/hist.nc" % d, "%s/nc4/hist.nc" % d).replace("%s/diag.nc" % d, "%s/nc4/diag.nc" % d).replace("out_fortran.nc", "out_fortran_nc4in.nc")
+            open(os.path.join(d, "namelist.nc4in"), "w").write(nml_in)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "namelist.nc4in"], cwd=d, capture_output=True, text=True, timeout=900)
+            t4 = time.perf_counter() - t0
+            if r.returncode != 0:
+                print(r.stdout[-3000:], r.stderr[-3000:])
+                return 1
+            same_in = open(os.path.join(d, "out_fortran_nc4in.nc"), "rb").read() == open(os.path.join(d, "out_fortran.nc"), "rb").read()
+            print("fortran, NetCDF-4 in:  %.2f s wall   %s" % (t4, "  ".join(ln.strip() for ln in r.stdout.splitlines() if ln.lstrip().startswith("["))), flush=True)
+            print("    output identical to the classic inputs' byte for byte: %s" % same_in, flush=True)
+            os.remove(os.path.join(d, "out_fortran_nc4in.nc"))
+            import shutil
+            shutil.rmtree(os.path.join(d, "nc4"))
+            if not same_in:
                 return 1
 
     nr = int(os.environ.get("C4JOB_RANKS", "0"))      # C4JOB_RANKS=N: the same job as N driver images (row blocks of the target grid)
