@@ -10,6 +10,7 @@ under test except the definitions SURVEY App. A states:
   holds target point P is the one for which  A + u (B - A) + v (C - A) = t P  has u, v, 1 - u - v >= 0 and t > 0 (3 x 3 solve at 50 digits
   for EVERY candidate triangle, no search structure); weights (1 - u - v, u, v); a point in no triangle is unmapped (IGNORE);
 * nearest source to destination (A3): argmin over ALL cell centres of the chord distance;
+* Grid -> Grid destaggering (A4): see grid_to_grid below;
 * first-order conservative (A5): for every destination cell (quad of four CORNER points) and every source cell (polygon of its vertices)
   the great-circle intersection polygon by Sutherland-Hodgman at 50 digits, areas by Girard's theorem, w = area(src ^ dst) / area(dst).
 
@@ -138,9 +139,64 @@ def store(mesh, lon_c, lat_c, lon_k, lat_k):
     return {"bilinear": bil, "nearest": nst, "conserve": cons}
 
 
+def grid_to_grid(lon_c, lat_c, lon_e, lat_e):
+    """Destaggering (A4): every EDGE point in the bilinear quad of four CENTER points that holds it -- X(s, t) = A + s (B - A) + t (D - A) +
+    s t (A - B + C - D) = lam P solved by findroot at 40 digits for every quad near the point; a point held by no quad is unmapped.  A C-grid's
+    edge points lie (to the grid's curvature) ON the line between two centres, i.e. on the border of two quads: both give the same sparse
+    weight vector, which is what is recorded ({centre: weight}, weights below 1e-13 dropped)."""
+    ny, nx = lat_c.shape
+    Cm = [[xyz_from_deg(lon_c[j, i], lat_c[j, i]) for i in range(nx)] for j in range(ny)]
+    Cf = np.array([[f3(Cm[j][i]) for i in range(nx)] for j in range(ny)])
+    qc = 0.25 * (Cf[:-1, :-1] + Cf[:-1, 1:] + Cf[1:, :-1] + Cf[1:, 1:])                      # quad centres (float64: the pre-filter only)
+    qr = np.linalg.norm(Cf[:-1, :-1] - Cf[1:, 1:], axis=2)
+    out = []
+    for p in range(lat_e.size):
+        P = xyz_from_deg(lon_e.flat[p], lat_e.flat[p])
+        Pf = f3(P)
+        cand = np.argwhere(np.linalg.norm(qc - Pf, axis=2) <= 1.2 * qr)
+        vec, tie, near, strict = None, False, False, False
+        for j, i in cand:
+            A, B, D, Cq = Cm[j][i], Cm[j][i + 1], Cm[j + 1][i], Cm[j + 1][i + 1]
+            f = lambda s_, t_, l_: [A[k] + s_ * (B[k] - A[k]) + t_ * (D[k] - A[k]) + s_ * t_ * (A[k] - B[k] + Cq[k] - D[k]) - l_ * P[k] for k in range(3)]   # noqa: E731
+            try:
+                sol = mp.findroot(f, (mp.mpf("0.5"), mp.mpf("0.5"), mp.mpf(1)), tol=mp.mpf(10) ** -40, maxsteps=60)
+            except (ValueError, ZeroDivisionError):
+                continue
+            s1, t1, lam = sol[0], sol[1], sol[2]
+            eps = mp.mpf(10) ** -9
+            if lam <= 0:
+                continue
+            out_by = max(-s1, s1 - 1, -t1, t1 - 1)                   # > 0: that far outside this quad (in its own s, t)
+            if out_by > eps:
+                if out_by < mp.mpf(10) ** -6:
+                    near = True                                       # a hair outside: on the hull, or over the border into a neighbour
+                continue
+            w = {int(j * nx + i): (1 - s1) * (1 - t1), int(j * nx + i + 1): s1 * (1 - t1), int((j + 1) * nx + i): (1 - s1) * t1,
+                 int((j + 1) * nx + i + 1): s1 * t1}
+            w = {k: float(v) for k, v in w.items() if abs(v) > mp.mpf(10) ** -13}
+            strict = strict or out_by < -eps
+            if vec is None:
+                vec = w
+            else:                                                     # a second quad holds the point (within 1e-9 of their shared border): the two
+                keys = set(vec) | set(w)                              # vectors differ by the distance from the border at most -- marked, either is right
+                assert all(abs(vec.get(k, 0.0) - w.get(k, 0.0)) < 1e-8 for k in keys), (p, vec, w)
+                tie = True
+        if vec is None:                                               # in no quad; `hull`: within 1e-6 of one (on the hull of the CENTER points to rounding:
+            out.append({"hull": True} if near else None)              # whether such a point is mapped is a tolerance's business, not the geometry's)
+        elif not strict and not tie:                                  # held by ONE quad and only within 1e-9 of its border: the hull again
+            out.append({"hull": True})
+        else:
+            out.append(dict({"col": sorted(vec), "w": [vec[k] for k in sorted(vec)]}, **({"tie": True} if tie else {})))
+    return out
+
+
 def case(name, mesh, g):
     print("case %s: %d cells, %d vertices, grid %d x %d" % (name, mesh.nCells, mesh.nVertices, g.nx, g.ny), flush=True)
     res = store(mesh, g.lon, g.lat, g.lon_c, g.lat_c)
+    res["edge1"] = grid_to_grid(g.lon, g.lat, g.lon_u, g.lat_u)
+    res["edge2"] = grid_to_grid(g.lon, g.lat, g.lon_v, g.lat_v)
+    cnt = lambda k: (sum(1 for e in res[k] if e and "col" in e), sum(e is None for e in res[k]), sum(1 for e in res[k] if e and "hull" in e))   # noqa: E731
+    print("  grid -> grid: EDGE1 %d mapped / %d unmapped / %d on the hull, EDGE2 %d / %d / %d" % (cnt("edge1") + cnt("edge2")), flush=True)
     nb = sum(1 for b in res["bilinear"] if b and "col" in b)
     print("  bilinear: %d mapped, %d unmapped, %d ties; nearest ties %d; conservative entries %d" % (
         nb, sum(1 for b in res["bilinear"] if b is None), sum(1 for b in res["bilinear"] if b and "tie" in b),
@@ -149,6 +205,7 @@ def case(name, mesh, g):
             "latCell": mesh.latCell.tolist(), "lonCell": mesh.lonCell.tolist(), "latVertex": mesh.latVertex.tolist(), "lonVertex": mesh.lonVertex.tolist(),
             "verticesOnCell": mesh.verticesOnCell.tolist(),
             "lon": g.lon.ravel().tolist(), "lat": g.lat.ravel().tolist(), "lon_c": g.lon_c.ravel().tolist(), "lat_c": g.lat_c.ravel().tolist(),
+            "lon_u": g.lon_u.ravel().tolist(), "lat_u": g.lat_u.ravel().tolist(), "lon_v": g.lon_v.ravel().tolist(), "lat_v": g.lat_v.ravel().tolist(),
             "expect": res}
 
 

@@ -31,6 +31,8 @@ class Case:
         sh, shc = (self.ny, self.nx), (self.ny + 1, self.nx + 1)
         self.lon, self.lat = np.array(c["lon"]).reshape(sh), np.array(c["lat"]).reshape(sh)
         self.lon_c, self.lat_c = np.array(c["lon_c"]).reshape(shc), np.array(c["lat_c"]).reshape(shc)
+        self.lon_u, self.lat_u = np.array(c["lon_u"]).reshape(self.ny, self.nx + 1), np.array(c["lat_u"]).reshape(self.ny, self.nx + 1)
+        self.lon_v, self.lat_v = np.array(c["lon_v"]).reshape(self.ny + 1, self.nx), np.array(c["lat_v"]).reshape(self.ny + 1, self.nx)
         self.expect = c["expect"]
         a, b = np.radians([self.lon[0, 0], self.lat[0, 0]]), np.radians([self.lon[0, 1], self.lat[0, 1]])
         xyz = lambda q: np.array([np.cos(q[1]) * np.cos(q[0]), np.cos(q[1]) * np.sin(q[0]), np.sin(q[1])])   # noqa: E731
@@ -111,3 +113,40 @@ def test_the_goldens_cover_what_they_claim():
     assert lon.min() < 180.0 < lon.max()
     assert c3.lat.max() > 85.0 and np.ptp(c3.lon) > 300.0
     assert {4, 5, 6, 7} <= set(((np.array(c2.mesh.verticesOnCell) > 0).sum(1)).tolist())
+
+
+def check_grid_to_grid(case, stagger_key, idx, w):
+    """idx / w [P][4] (-1 = unmapped) against the golden's sparse weight vectors; returns (worst difference, points that are mapped on one
+    side only, with their distance-from-the-hull diagnostics left to the caller)."""
+    exp = case.expect[stagger_key]
+    worst, one_sided = 0.0, []
+    for p, e in enumerate(exp):
+        got = {}
+        for c, v in zip(idx[p], w[p]):
+            if c >= 0 and abs(v) > 1e-13:
+                got[int(c)] = got.get(int(c), 0.0) + float(v)
+        if e is not None and "hull" in e:          # on the hull of the CENTER points to rounding: mapped or not is a tolerance's business
+            continue
+        if e is None or not got:
+            if (e is None) != (not got):
+                one_sided.append(p)
+            continue
+        want = dict(zip(e["col"], e["w"]))
+        d = max(abs(want.get(k, 0.0) - got.get(k, 0.0)) for k in set(want) | set(got))
+        if e.get("tie"):       # within 1e-9 of the border of two quads: their vectors differ by that distance at most, and either quad is right
+            assert d < 3e-9, (case.name, stagger_key, p, d)
+        else:
+            worst = max(worst, d)
+    return worst, one_sided
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c.name)
+def test_oracle_destaggering_stores_equal_the_brute_force_goldens(oracle, case):
+    o = oracle
+    cxyz = o.lonlat_deg_to_xyz(case.lon, case.lat)
+    for key, stag, lon_e, lat_e in (("edge1", 1, case.lon_u, case.lat_u), ("edge2", 2, case.lon_v, case.lat_v)):
+        idx, w = o.grid_bilinear(case.nx, case.ny, cxyz, stag, o.lonlat_deg_to_xyz(lon_e, lat_e))
+        worst, one_sided = check_grid_to_grid(case, key, idx, w)
+        print("%s %s: oracle vs 50-digit brute force %.1e, mapped on one side only: %d" % (case.name, key, worst, len(one_sided)))
+        assert worst < 10 * tol_for(case), (case.name, key, worst)
+        assert not one_sided, (case.name, key, one_sided[:10])

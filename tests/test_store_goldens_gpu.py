@@ -50,3 +50,19 @@ def test_index_space_search_gives_the_golden_too(gpu_lib):
         h.release()
     mesh.destroy()
     grid.destroy()
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c.name)
+def test_library_destaggering_stores_equal_the_brute_force_goldens(gpu_lib, case):
+    """CENTER -> EDGE1 / EDGE2 (the U / V destaggering, interp.F90:298,316) through the C-ABI against the 40-digit findroot goldens: the same
+    points mapped, the same weights; points on a border of two quads (every V point of a lat-lon grid) or on the hull are judged as such."""
+    from mpassit_amd import regrid as R
+    from test_store_goldens import check_grid_to_grid, tol_for
+    grid = R.Grid(case.lon, case.lat, case.lon_c, case.lat_c, case.lon_u, case.lat_u, case.lon_v, case.lat_v)
+    for key, stag in (("edge1", R.STAGGERLOC_EDGE1), ("edge2", R.STAGGERLOC_EDGE2)):
+        rh = R.regrid_store_grid(grid, stag)
+        idx, w = rh.weights()
+        worst, one_sided = check_grid_to_grid(case, key, idx, w)
+        assert worst < 10 * tol_for(case) and not one_sided, (case.name, key, worst, one_sided[:10])
+        rh.release()
+    grid.destroy()
