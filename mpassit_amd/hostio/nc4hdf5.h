@@ -198,9 +198,16 @@ static herr_t h5_link_cb(hid_t g, const char *name, const H5L_info_t *info, void
   hid_t d = H5Dopen2(g, name, H5P_DEFAULT); /* succeeds for datasets only: groups and named types are not part of the classic model */
   if (d < 0) return 0;
   if (N->n == N->cap) {
-    N->cap = N->cap ? 2 * N->cap : 64;
-    N->name = (char **)realloc(N->name, sizeof(char *) * (size_t)N->cap);
-    N->id = (hid_t *)realloc(N->id, sizeof(hid_t) * (size_t)N->cap);
+    const int cap = N->cap ? 2 * N->cap : 64;
+    char **nn = (char **)realloc(N->name, sizeof(char *) * (size_t)cap);
+    if (nn) N->name = nn;
+    hid_t *ni = nn ? (hid_t *)realloc(N->id, sizeof(hid_t) * (size_t)cap) : NULL;
+    if (ni) N->id = ni;
+    if (!nn || !ni) {   /* out of memory: this dataset is left out (the caller sees a file without it rather than a crash) */
+      H5Dclose(d);
+      return 0;
+    }
+    N->cap = cap;
   }
   N->name[N->n] = strdup(name);
   N->id[N->n++] = d;
