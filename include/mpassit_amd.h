@@ -218,6 +218,23 @@ int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const doub
                      double *u_host, double *v_host);
 int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const double *sina_dev,
                          double *u_dev, double *v_dev, void *hip_stream);
+/* The whole wind chain of interp_hist_data in ONE pass over the mass-point winds (interp.F90:291-328): rotate_winds_cgrid on
+ * (UMASS, VMASS) -- :291-293, 737-748 -- followed by the two Grid -> Grid Regrids UMASS(CENTER) -> U(EDGE1) -- :295-311 -- and
+ * VMASS(CENTER) -> V(EDGE2) -- :313-328.  u/v_target_grid_nostag are intermediates the reference never writes, so the earth-relative
+ * mass winds are read once and only U and V are stored; the results are bit-identical to mpg_rotate_winds_dev followed by
+ * mpg_regrid_dev (dst_type MPG_TYPE_F64) or mpg_regrid_typed_dev(..., dst_type, 1.0, 0.0) (any other dst_type) on the two handles.
+ *   rh_edge1, rh_edge2   handles of mpg_regrid_store_grid(grid, CENTER, EDGE1 / EDGE2) on ONE grid; either may be NULL (that
+ *                        component is not produced: do_u_interp / do_v_interp, interp.F90:295,313)
+ *   cosa_dev, sina_dev   [ny][nx] as for mpg_rotate_winds_dev, or both NULL: no rotation (proj_code /= PROJ_LC, or one component)
+ *   umass_dev, vmass_dev [nlev][ny][nx] float64, NOT modified
+ *   u_dev, v_dev         [nlev][ny][nx+1], [nlev][ny+1][nx] of dst_type
+ *   umass_rot_dev, vmass_rot_dev   optional (NULL): the rotated mass winds [nlev][ny][nx] as mpg_rotate_winds_dev would have left
+ *                        them in place; must not be the input arrays
+ * MPG_ERR_UNSUPPORTED: the handles are not such a pair (re-indexed by mpg_handle_localize / rebase, different grids): use the
+ * three separate calls. */
+int mpg_wind_destagger_dev(mpg_handle rh_edge1, mpg_handle rh_edge2, const double *cosa_dev, const double *sina_dev,
+                           const double *umass_dev, const double *vmass_dev, int nlev, void *u_dev, void *v_dev, int dst_type,
+                           double *umass_rot_dev, double *vmass_rot_dev, void *hip_stream);
 
 /* ---- output epilogues: what write_data.F90 computes on rank 0 between ESMF_FieldGather and nf90_put_var, done on
  * the device-resident regridded fields so that only final float32 arrays leave the GPU.

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(HERE, "_build")
 SO = os.path.join(HERE, "libmpassit_amd.so")
 SOURCES = ["mpg_api.hip", "mpg_comm.hip", "mpg_hostpipe.hip", "mpg_fileio.hip", "k_setup.hip", "k_mesh_window.hip", "k_target_grid.hip", "k_store_bilinear.hip", "k_store_nearest.hip", "k_store_conserve.hip",
-           "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_pole.hip", "k_post.hip", "k_halo.hip", "k_prims.hip", "k_sort.hip"]
+           "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_wind.hip", "k_pole.hip", "k_post.hip", "k_halo.hip", "k_prims.hip", "k_sort.hip"]
 HEADERS = ["mpg_internal.h", "geom.h", os.path.join("..", "..", "include", "mpassit_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 STRIP = os.environ.get("MPASSIT_STRIP_DEVICE", "").split()   # e.g. "-Xoffload-linker --strip-all" (measured in round 5: see below)

@@ -121,7 +121,7 @@ void mpg_pool_release() {
 // creates the pinned staging of the host-array upload path, while the caller goes on (reading its namelist, opening its
 // files); a call that needs a module before the helper got to it simply loads it itself (the runtime serialises that).
 #define MPG_ANCHORS(X) X(k_setup) X(k_target_grid) X(k_store_bilinear) X(k_store_nearest) X(k_store_conserve) X(k_store_gridbil) \
-  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_pole) X(k_post) X(k_halo) X(mpg_comm) X(k_mesh_window) X(k_prims) X(k_sort)
+  X(k_apply) X(k_apply_lfu) X(k_apply_typed) X(k_wind) X(k_pole) X(k_post) X(k_halo) X(mpg_comm) X(k_mesh_window) X(k_prims) X(k_sort)
 #define X(n) const void *mpg_anchor_##n();
 MPG_ANCHORS(X)
 #undef X
@@ -787,6 +787,27 @@ int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const d
   MPG_ARG(cosa_dev && sina_dev && u_dev && v_dev, "mpg_rotate_winds: NULL argument");
   MPG_ARG(npts >= 0 && nlev >= 1, "mpg_rotate_winds: bad sizes");
   return mpg_k_rotate(npts, nlev, cosa_dev, sina_dev, u_dev, v_dev, (hipStream_t)hip_stream);
+}
+
+int mpg_wind_destagger_dev(mpg_handle h1, mpg_handle h2, const double *cosa_dev, const double *sina_dev, const double *umass_dev,
+                           const double *vmass_dev, int nlev, void *u_dev, void *v_dev, int dst_type, double *umass_rot_dev, double *vmass_rot_dev,
+                           void *hip_stream) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h1 || h2, "mpg_wind_destagger: no handle");
+  MPG_ARG((cosa_dev == nullptr) == (sina_dev == nullptr), "mpg_wind_destagger: cosa and sina come together");
+  const bool rot = cosa_dev != nullptr;
+  MPG_ARG(!rot || (h1 && h2), "mpg_wind_destagger: the rotation needs both components (interp.F90:291)");
+  MPG_ARG((!h1 || u_dev) && (!h2 || v_dev), "mpg_wind_destagger: NULL destination");
+  MPG_ARG((!(h1 || rot) || umass_dev) && (!(h2 || rot) || vmass_dev), "mpg_wind_destagger: NULL mass field");
+  MPG_ARG(nlev >= 1, "mpg_wind_destagger: nlev must be >= 1");
+  MPG_ARG(dst_type >= 0 && dst_type <= 3, "mpg_wind_destagger: dst_type must be MPG_TYPE_F64 or MPG_TYPE_F32, optionally | MPG_TYPE_BE");
+  MPG_ARG((!umass_rot_dev || umass_rot_dev != umass_dev) && (!vmass_rot_dev || vmass_rot_dev != vmass_dev),
+          "mpg_wind_destagger: the rotated mass winds cannot replace the inputs (neighbouring tiles read them)");
+  MPG_ARG(rot || (!umass_rot_dev && !vmass_rot_dev), "mpg_wind_destagger: rotated mass winds asked for without a rotation");
+  int rc = mpg_k_wind_destagger(h1, h2, cosa_dev, sina_dev, umass_dev, vmass_dev, nlev, u_dev, v_dev, dst_type, umass_rot_dev, vmass_rot_dev,
+                                (hipStream_t)hip_stream);
+  if (rc == MPG_ERR_UNSUPPORTED) mpg_set_error("mpg_wind_destagger: the handles are not the CENTER -> EDGE1 / EDGE2 pair of one grid");
+  return rc;
 }
 
 int mpg_rotate_winds(int64_t npts, int nlev, const double *cosa_host, const double *sina_host, double *u_host, double *v_host) {

@@ -413,6 +413,8 @@ int mpg_k_post_layer_mean(const double *src, int nlevp1, int64_t P, float *dst, 
 int mpg_k_post_ptop(const double *src, int nlev, int64_t P, double *ptop_host, hipStream_t s);
 int mpg_k_post_ptop_parts(const double *src, int nlev, int64_t P, double *vmax_host, double *candmin_host, int *has_cand_host, hipStream_t s);
 int mpg_k_rotate(int64_t npts, int nlev, const double *cosa, const double *sina, double *u, double *v, hipStream_t s);
+int mpg_k_wind_destagger(mpg_handle_s *h1, mpg_handle_s *h2, const double *cosa, const double *sina, const double *um, const double *vm, int nlev,
+                         void *u, void *v, int dst_type, double *um_rot, double *vm_rot, hipStream_t s);   // k_wind.hip
 int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, int64_t n_ids, double *dst, hipStream_t s);
 int mpg_k_tune(const char *key, int value);
 int mpg_store_boxes();         // "store_boxes" knob: 1 (default) index-space candidate boxes on projection-built grids, 0 pyramid walk only

@@ -44,6 +44,8 @@ class InterpConfig:
     hist_2d: list = field(default_factory=list)
     hist_3d: list = field(default_factory=list)
     hist_soil: list = field(default_factory=list)
+    keep_mass_winds: bool = False     # also return UMASS / VMASS (u/v_target_grid_nostag): intermediates the reference never writes
+    fused_winds: bool = True          # device-resident fields: rotation + both destaggerings in one pass (mpg_wind_destagger_dev)
 
 
 def _is_torch(x):
@@ -89,16 +91,22 @@ def _bundle_regrid(rh, arrs, nlev, layout):
     return [out[i] for i in range(len(arrs))]
 
 
+def _rot_angles_dev(target, device):
+    """cosalpha / sinalpha of the CENTER stagger as device tensors, uploaded once per target grid, not once per call."""
+    import torch
+    cosa = target.cosa
+    dev = getattr(target, "_rot_dev", None)
+    if dev is None or dev[0].device != device or dev[2] is not cosa:
+        dev = (torch.as_tensor(np.ascontiguousarray(cosa), device=device), torch.as_tensor(np.ascontiguousarray(target.sina), device=device), cosa)
+        target._rot_dev = dev
+    return dev[0], dev[1]
+
+
 def rotate_winds_cgrid(target, u, v):
     """In place earth -> grid-relative rotation with cosalpha/sinalpha of the CENTER stagger."""
     cosa, sina = target.cosa, target.sina
     if _is_torch(u):
-        import torch
-        dev = getattr(target, "_rot_dev", None)            # uploaded once per target grid, not once per call
-        if dev is None or dev[0].device != u.device or dev[2] is not cosa:
-            dev = (torch.as_tensor(np.ascontiguousarray(cosa), device=u.device), torch.as_tensor(np.ascontiguousarray(sina), device=u.device), cosa)
-            target._rot_dev = dev
-        cosa, sina = dev[0], dev[1]
+        cosa, sina = _rot_angles_dev(target, u.device)
     return R.rotate_winds_cgrid(cosa, sina, u, v)
 
 
@@ -128,6 +136,42 @@ def _destagger_local(grid, staggerloc, mass, nz):
     return res
 
 
+def _wind_chain_fused(grid, target, cfg, um, vm, rot, nz, out, destagger):
+    """interp.F90:291-328 through mpg_wind_destagger_dev when the mass winds are device-resident and the destaggering is this
+    grid's own (no row halo supplied by a sharded driver): one pass instead of three, the same bits.  -> False: the caller
+    takes the three-call chain."""
+    ref = um if um is not None else vm
+    if destagger is not None or not cfg.fused_winds or not _is_torch(ref) or not ref.is_cuda:
+        return False
+    import torch
+    if any(t is not None and t.dtype != torch.float64 for t in (um, vm)):
+        return False
+    rh_u = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1) if um is not None else None      # :298
+    rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2) if vm is not None else None      # :316
+    try:
+        cosa, sina = _rot_angles_dev(target, ref.device) if rot else (None, None)
+        try:
+            u, v, ur, vr = R.wind_destagger(rh_u, rh_v, cosa, sina, um, vm, nz, keep_mass=cfg.keep_mass_winds)
+        except R.L.MpgError as e:
+            if e.rc != R.L.MPG_ERR_UNSUPPORTED:
+                raise
+            return False
+    finally:
+        for rh in (rh_u, rh_v):
+            if rh is not None:
+                rh.release()
+    if u is not None:
+        out["U"] = u
+    if v is not None:
+        out["V"] = v
+    if cfg.keep_mass_winds:
+        if um is not None:
+            out["UMASS"] = ur if ur is not None else um
+        if vm is not None:
+            out["VMASS"] = vr if vr is not None else vm
+    return True
+
+
 def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
     h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars)
     # `method` is only assigned inside `if (n_hist_fields_2d_patch>0)` in the reference (interp.F90:203-204) and
@@ -138,19 +182,26 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
     out["HGT"] = rh_patch.regrid(inp.hgt, nlev=1, **_be_kw(inp.hgt))[0, 0]   # interp.F90:226-238
     for (n, t), o in zip(h.nz_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nz_3d], inp.nz, inp.layout)):
         out[t] = o                                                    # interp.F90:240-254
+    um = vm = None
     if h.do_u_interp:
-        out["UMASS"] = rh_patch.regrid(inp.hist["uReconstructZonal"], nlev=inp.nz, layout=inp.layout,
-                                       **_be_kw(inp.hist["uReconstructZonal"]))[0]                          # :256-272
+        um = rh_patch.regrid(inp.hist["uReconstructZonal"], nlev=inp.nz, layout=inp.layout, **_be_kw(inp.hist["uReconstructZonal"]))[0]            # :256-272
     if h.do_v_interp:
-        out["VMASS"] = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout,
-                                       **_be_kw(inp.hist["uReconstructMeridional"]))[0]                     # :274-289
-    if h.do_u_interp and h.do_v_interp and cfg.proj_is_lambert:
-        rotate_winds_cgrid(target, out["UMASS"], out["VMASS"])        # :291-293
-    destagger = destagger or _destagger_local
-    if h.do_u_interp:
-        out["U"] = destagger(grid, R.STAGGERLOC_EDGE1, out["UMASS"], inp.nz)   # :295-311  UMASS(CENTER) -> U(EDGE1)
-    if h.do_v_interp:
-        out["V"] = destagger(grid, R.STAGGERLOC_EDGE2, out["VMASS"], inp.nz)   # :313-328  VMASS(CENTER) -> V(EDGE2)
+        vm = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout, **_be_kw(inp.hist["uReconstructMeridional"]))[0]  # :274-289
+    rot = h.do_u_interp and h.do_v_interp and cfg.proj_is_lambert                                                                         # :291
+    if um is not None or vm is not None:
+        if not _wind_chain_fused(grid, target, cfg, um, vm, rot, inp.nz, out, destagger):
+            if rot:
+                rotate_winds_cgrid(target, um, vm)                    # :291-293
+            ds = destagger or _destagger_local
+            if um is not None:
+                out["U"] = ds(grid, R.STAGGERLOC_EDGE1, um, inp.nz)   # :295-311  UMASS(CENTER) -> U(EDGE1)
+            if vm is not None:
+                out["V"] = ds(grid, R.STAGGERLOC_EDGE2, vm, inp.nz)   # :313-328  VMASS(CENTER) -> V(EDGE2)
+            if cfg.keep_mass_winds:
+                if um is not None:
+                    out["UMASS"] = um
+                if vm is not None:
+                    out["VMASS"] = vm
     for (n, t), o in zip(h.nzp1_3d, _bundle_regrid(rh_patch, [inp.hist[n] for n, _ in h.nzp1_3d], inp.nzp1, inp.layout)):
         out[t] = o                                                    # :331-347
     if h.vert_3d:                                                     # :350-366 node-located sources (vorticity)

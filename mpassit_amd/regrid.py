@@ -18,7 +18,7 @@ from ._lib import (LAYOUT_CELL_FAST, LAYOUT_LEV_FAST, MESHLOC_ELEMENT, MESHLOC_N
                    REGRIDMETHOD_NEAREST_STOD, STAGGERLOC_CENTER, STAGGERLOC_CORNER, STAGGERLOC_EDGE1, STAGGERLOC_EDGE2,
                    check)
 
-__all__ = ["MESHLOC_ELEMENT", "MESHLOC_NODE", "Mesh", "Grid", "RouteHandle", "regrid_store", "regrid_store_grid", "rotate_winds_cgrid",
+__all__ = ["MESHLOC_ELEMENT", "MESHLOC_NODE", "Mesh", "Grid", "RouteHandle", "regrid_store", "regrid_store_grid", "rotate_winds_cgrid", "wind_destagger",
            "REGRIDMETHOD_BILINEAR", "REGRIDMETHOD_CONSERVE", "REGRIDMETHOD_NEAREST_STOD", "STAGGERLOC_CENTER",
            "STAGGERLOC_EDGE1", "STAGGERLOC_EDGE2", "STAGGERLOC_CORNER", "LAYOUT_CELL_FAST", "LAYOUT_LEV_FAST"]
 
@@ -492,3 +492,39 @@ def rotate_winds_cgrid(cosa, sina, u, v):
     nlev = u.size // npts
     check(L.load().mpg_rotate_winds(C.c_int64(npts), C.c_int(nlev), _ptr(cosa), _ptr(sina), _ptr(u), _ptr(v)))
     return u, v
+
+
+def wind_destagger(rh_u, rh_v, cosa, sina, umass, vmass, nlev, out_dtype=None, dst_be=False, keep_mass=False):
+    """interp.F90:291-328 in one pass (mpg_wind_destagger_dev): rotate_winds_cgrid on the CENTER-stagger winds (cosa / sina
+    None: no rotation) + UMASS -> U(EDGE1) + VMASS -> V(EDGE2).  rh_u / rh_v: the regrid_store_grid handles of ONE grid (either
+    may be None); umass / vmass: float64 CUDA tensors [nlev][ny][nx], not modified.  Returns (U, V, UMASS', VMASS'): U
+    [nlev][ny][nx+1], V [nlev][ny+1][nx] of out_dtype (float64), the rotated mass winds only with keep_mass (else None).
+    Bit-identical to rotate_winds_cgrid followed by the two handles' regrid().  Raises MpgError(rc = MPG_ERR_UNSUPPORTED) for
+    handles that are not such a pair (re-indexed ones)."""
+    import torch
+    ref = umass if umass is not None else vmass
+    rot = cosa is not None
+    out_dtype = out_dtype or torch.float64
+    for t in (umass, vmass):
+        if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float64):
+            raise ValueError("wind_destagger needs contiguous float64 CUDA tensors")
+    u = torch.empty((nlev, rh_u.ny_dst, rh_u.nx_dst), dtype=out_dtype, device=ref.device) if rh_u is not None else None
+    v = torch.empty((nlev, rh_v.ny_dst, rh_v.nx_dst), dtype=out_dtype, device=ref.device) if rh_v is not None else None
+    ur = torch.empty_like(umass) if (keep_mass and rot) else None
+    vr = torch.empty_like(vmass) if (keep_mass and rot) else None
+    if ACCOUNT is not None:     # both mass fields read once, U and V written once, indices + weights of both handles and the angles once
+        npts = ref.numel() // nlev
+        es = 4 if out_dtype == torch.float32 else 8
+        by = 0
+        if rh_u is not None:
+            by += nlev * (npts * 8 + rh_u.n_dst * es) + rh_u.n_dst * 48
+        if rh_v is not None:
+            by += nlev * (npts * 8 + rh_v.n_dst * es) + rh_v.n_dst * 48
+        ACCOUNT.append(("wind_destagger L%d" % nlev, by + (npts * 16 if rot else 0)))
+
+    def p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+    check(L.load().mpg_wind_destagger_dev(rh_u._h if rh_u is not None else None, rh_v._h if rh_v is not None else None, p(cosa), p(sina),
+                                          p(umass), p(vmass), C.c_int(nlev), p(u), p(v),
+                                          C.c_int(int(out_dtype == torch.float32) | (2 if dst_be else 0)), p(ur), p(vr), _stream_ptr()))
+    return u, v, ur, vr

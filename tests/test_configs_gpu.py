@@ -236,7 +236,7 @@ def test_config2_655k_global_bilinear_nearest(c23, oracle):
     assert 0.015 * m.nCells < st["unique_sources"] < 0.04 * m.nCells      # 2-3 % of the global mesh is touched
     lists2d = [p for p in HIST_2D if p[0] not in ("snow", "snowh")]
     inp, host = make_inputs(torch, synth, m, lists2d, HIST_3D, [], nz, 4)
-    cfg = I.InterpConfig(interp_diag=False, wrf_mod_vars=True, hist_2d=lists2d, hist_3d=HIST_3D)
+    cfg = I.InterpConfig(interp_diag=False, wrf_mod_vars=True, keep_mass_winds=True, hist_2d=lists2d, hist_3d=HIST_3D)
     out = I.interp_data(mesh, grid, g, inp, cfg)
     torch.cuda.synchronize()
     del inp

@@ -42,7 +42,7 @@ def test_interp_data_default_lists(gpu_lib, oracle, regional_case):
         inp.diag[n] = synth.analytic_field(m.latCell, m.lonCell, nz if n == "refl10cm" else 1, seed=70 + k)
         if n != "refl10cm":
             inp.diag[n] = inp.diag[n][0]
-    cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=diag, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
+    cfg = I.InterpConfig(wrf_mod_vars=True, keep_mass_winds=True, diag_list=diag, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
     mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
     out = I.interp_data(mesh, grid, g, inp, cfg)
     mesh.destroy()
