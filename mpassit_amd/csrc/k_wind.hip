@@ -28,9 +28,13 @@
 #include "mpg_internal.h"
 
 #define WD_TX 64
+#ifndef WD_TY
 #define WD_TY 16
+#endif
 #define WD_NT 512
-#define WD_A 16                         // store segments start on multiples of 16 elements
+#ifndef WD_A
+#define WD_A 8                          // store segments start on multiples of 8 elements (A/B r06: 1, 8, 16, 32 within 4 %, 8 ahead)
+#endif
 #define WD_WW (WD_TX + 2 + WD_A - 1)    // 81 window columns: i0 - 16 .. i0 + 64
 #define WD_WH (WD_TY + 2)               // 18 window rows:    j0 - 1  .. j0 + 16
 #define WD_NW (WD_WW * WD_WH)
@@ -58,7 +62,7 @@ __device__ __forceinline__ void wd_rotate(double uo, double vo, double ca, doubl
 }
 
 template <typename TD, bool ROT, bool TYPED>
-__global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
+__global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wind_destagger(const WindArgs a) {
   __shared__ double lds[2 * 2 * WD_NW];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -70,9 +74,9 @@ __global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
   const bool src_u = ROT || do_u, src_v = ROT || do_v;
   const Swz zd = make_swz(a.dbe);
 
-  // ---- this thread's window points ---------------------------------------------------------------------------
-  int32_t goff[WD_WPT];
-  bool wval[WD_WPT], wown[WD_WPT];
+  // ---- this thread's window points: byte offset inside a level plane (MPG_BUF_NONE: outside the grid -> loads 0) ----
+  uint32_t gb[WD_WPT];
+  bool wown[WD_WPT];
   double rca[WD_WPT], rsa[WD_WPT], rtn[WD_WPT], rdn[WD_WPT];
 #pragma unroll
   for (int r = 0; r < WD_WPT; ++r) {
@@ -81,25 +85,28 @@ __global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
     int ci = wi0 + lx;
     const bool raw_in = ci >= 0 && ci < nx;
     if (per) ci = ((ci % nx) + nx) % nx;
-    wval[r] = e < WD_NW && cj >= 0 && cj < ny && ci >= 0 && ci < nx;
-    wown[r] = wval[r] && raw_in && lx >= WD_A && lx < WD_A + WD_TX && ly >= 1 && ly <= WD_TY;
-    goff[r] = wval[r] ? cj * nx + ci : 0;
+    const bool val = e < WD_NW && cj >= 0 && cj < ny && ci >= 0 && ci < nx;
+    wown[r] = val && raw_in && lx >= WD_A && lx < WD_A + WD_TX && ly >= 1 && ly <= WD_TY;
+    const int32_t g = val ? cj * nx + ci : 0;
+    gb[r] = val ? (uint32_t)g * 8u : MPG_BUF_NONE;
     rca[r] = 1.0; rsa[r] = 0.0; rtn[r] = 0.0; rdn[r] = 1.0;
     if constexpr (ROT) {
-      if (wval[r]) {
-        rca[r] = a.cosa[goff[r]];
-        rsa[r] = a.sina[goff[r]];
+      if (val) {
+        rca[r] = a.cosa[g];
+        rsa[r] = a.sina[g];
         rtn[r] = rsa[r] / rca[r];
         rdn[r] = rca[r] + rsa[r] * rtn[r];
       }
     }
   }
 
-  // ---- this thread's output points: WD_RPT rows of U and of V ---------------------------------------------------
-  int lu[WD_RPT][4], lv[WD_RPT][4];
+  // ---- this thread's output points: WD_RPT rows of U and of V.  A point's four sources are the corners of one quad of
+  // CENTER points (k_store_gridbil.hip: A, B = A + 1, C = B + nx, D = A + nx, columns wrapping on a periodic grid): the slot of A
+  // in the window stands for all four; anything else (pole-cap fillers, handles of other origin) is a `far` point ----
+  int lu[WD_RPT], lv[WD_RPT];
   double wu[WD_RPT][4], wv[WD_RPT][4];
-  bool actu[WD_RPT], actv[WD_RPT], mapu[WD_RPT], mapv[WD_RPT], faru[WD_RPT], farv[WD_RPT];
-  int64_t pu[WD_RPT], pv[WD_RPT];
+  bool mapu[WD_RPT], mapv[WD_RPT], faru[WD_RPT], farv[WD_RPT];
+  uint32_t pu[WD_RPT], pv[WD_RPT];     // byte offset inside a level plane of U / V; MPG_BUF_NONE: nothing to store in the level loop
   const int nxu = nx + 1;
   const int64_t P1 = (int64_t)nxu * ny, P2 = (int64_t)nx * (ny + 1);
   auto locate = [&](int32_t c, bool &far) -> int {   // global CENTER index -> slot of the window
@@ -114,73 +121,65 @@ __global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
     far = far || !in;
     return in ? ly * WD_WW + lx : 0;
   };
+  auto point = [&](const int32_t *idx, const double *w, int64_t P, int64_t p, int &slot, double *w4, bool &mapped, bool &far) {
+    int32_t c[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      c[q] = idx[q * P + p];
+      w4[q] = w[q * P + p];
+    }
+    mapped = c[0] >= 0;
+    far = false;
+    slot = 0;
+    if (mapped) {
+      slot = locate(c[0], far);
+      const int l1 = locate(c[1], far), l2 = locate(c[2], far), l3 = locate(c[3], far);
+      far = far || l1 != slot + 1 || l2 != slot + WD_WW + 1 || l3 != slot + WD_WW;
+      if (far) slot = 0;
+    }
+  };
 #pragma unroll
   for (int r = 0; r < WD_RPT; ++r) {
     const int j = j0 + wave + (WD_NT / 64) * r;
     {
       const int i = i0 + lane - (int)(((long long)j * nxu) % WD_A);
-      actu[r] = do_u && j < ny && i >= 0 && i < nxu;
-      pu[r] = actu[r] ? (int64_t)j * nxu + i : 0;
-      mapu[r] = false;
-      faru[r] = false;
+      const bool act = do_u && j < ny && i >= 0 && i < nxu;
+      const int64_t p = act ? (int64_t)j * nxu + i : 0;
+      lu[r] = 0; mapu[r] = false; faru[r] = false;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { lu[r][q] = 0; wu[r][q] = 0.0; }
-      if (actu[r]) {
-        int32_t c[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          c[q] = a.idx1[q * P1 + pu[r]];
-          wu[r][q] = a.w1[q * P1 + pu[r]];
-        }
-        mapu[r] = c[0] >= 0;
-        if (mapu[r]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) lu[r][q] = locate(c[q], faru[r]);
-        }
-      }
+      for (int q = 0; q < 4; ++q) wu[r][q] = 0.0;
+      if (act) point(a.idx1, a.w1, P1, p, lu[r], wu[r], mapu[r], faru[r]);
+      pu[r] = (act && !faru[r]) ? (uint32_t)p * (uint32_t)sizeof(TD) : MPG_BUF_NONE;
     }
     {
       const int i = i0 + lane - (int)(((long long)j * nx) % WD_A);
-      actv[r] = do_v && j <= ny && i >= 0 && i < nx;
-      pv[r] = actv[r] ? (int64_t)j * nx + i : 0;
-      mapv[r] = false;
-      farv[r] = false;
+      const bool act = do_v && j <= ny && i >= 0 && i < nx;
+      const int64_t p = act ? (int64_t)j * nx + i : 0;
+      lv[r] = 0; mapv[r] = false; farv[r] = false;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { lv[r][q] = 0; wv[r][q] = 0.0; }
-      if (actv[r]) {
-        int32_t c[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          c[q] = a.idx2[q * P2 + pv[r]];
-          wv[r][q] = a.w2[q * P2 + pv[r]];
-        }
-        mapv[r] = c[0] >= 0;
-        if (mapv[r]) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) lv[r][q] = locate(c[q], farv[r]);
-        }
-      }
+      for (int q = 0; q < 4; ++q) wv[r][q] = 0.0;
+      if (act) point(a.idx2, a.w2, P2, p, lv[r], wv[r], mapv[r], farv[r]);
+      pv[r] = (act && !farv[r]) ? (uint32_t)p * (uint32_t)sizeof(TD) : MPG_BUF_NONE;
     }
   }
 
-  auto emit = [&](double val, bool mapped, TD *plane, int64_t p) {
+  auto finish = [&](double val, bool mapped) -> TD {
     val = mapped ? val : 0.0;
-    if constexpr (TYPED) {
-      val = fma(val, a.scale, a.offset);
-      __builtin_nontemporal_store(swz<true>((TD)val, zd), plane + p);
-    } else {
-      __builtin_nontemporal_store((TD)val, plane + p);
-    }
+    if constexpr (TYPED) return swz<true>((TD)fma(val, a.scale, a.offset), zd);
+    else return (TD)val;
   };
 
-  // ---- level loop -------------------------------------------------------------------------------------------
+  // ---- level loop: branch-free (buffer addressing: lanes without a point load 0 / have their store dropped), so that the
+  // wait for level k + 1's loads does not also wait for level k's stores (one in-order counter on gfx950) -------------
+  const uint32_t src_bytes = (uint32_t)(NP * 8), u_bytes = (uint32_t)(P1 * sizeof(TD)), v_bytes = (uint32_t)(P2 * sizeof(TD));
   double fu[WD_WPT], fv[WD_WPT];
   auto fetch = [&](int k) {
-    const double *uk = a.um + (int64_t)k * NP, *vk = a.vm + (int64_t)k * NP;
+    const BufRsrc ru = buf_rsrc(a.um + (src_u ? (int64_t)k * NP : 0), src_u ? src_bytes : 0u);
+    const BufRsrc rv = buf_rsrc(a.vm + (src_v ? (int64_t)k * NP : 0), src_v ? src_bytes : 0u);
 #pragma unroll
     for (int r = 0; r < WD_WPT; ++r) {
-      fu[r] = (src_u && wval[r]) ? uk[goff[r]] : 0.0;
-      fv[r] = (src_v && wval[r]) ? vk[goff[r]] : 0.0;
+      buf_load(fu[r], ru, gb[r], 0u);
+      buf_load(fv[r], rv, gb[r], 0u);
     }
   };
   fetch(0);
@@ -196,26 +195,31 @@ __global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
         bu[e] = un;
         bv[e] = vn;
       }
-      if (wown[r]) {
-        if (a.um_rot) __builtin_nontemporal_store(un, a.um_rot + (int64_t)k * NP + goff[r]);
-        if (a.vm_rot) __builtin_nontemporal_store(vn, a.vm_rot + (int64_t)k * NP + goff[r]);
+      if constexpr (ROT) {
+        if (a.um_rot && wown[r]) __builtin_nontemporal_store(un, a.um_rot + (int64_t)k * NP + (gb[r] >> 3));
+        if (a.vm_rot && wown[r]) __builtin_nontemporal_store(vn, a.vm_rot + (int64_t)k * NP + (gb[r] >> 3));
       }
     }
     __syncthreads();
     if (k + 1 < nlev) fetch(k + 1);
+    const BufRsrc ou = buf_rsrc(do_u ? uplane : nullptr, do_u ? u_bytes : 0u), ov = buf_rsrc(do_v ? vplane : nullptr, do_v ? v_bytes : 0u);
 #pragma unroll
     for (int r = 0; r < WD_RPT; ++r) {
-      if (actu[r] && !faru[r]) {
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = fma(wu[r][q], bu[lu[r][q]], acc);
-        emit(acc, mapu[r], uplane, pu[r]);
+      {
+        const double *q = bu + lu[r];
+        double acc = fma(wu[r][0], q[0], 0.0);
+        acc = fma(wu[r][1], q[1], acc);
+        acc = fma(wu[r][2], q[WD_WW + 1], acc);
+        acc = fma(wu[r][3], q[WD_WW], acc);
+        buf_store_nt(finish(acc, mapu[r]), ou, pu[r]);
       }
-      if (actv[r] && !farv[r]) {
-        double acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc = fma(wv[r][q], bv[lv[r][q]], acc);
-        emit(acc, mapv[r], vplane, pv[r]);
+      {
+        const double *q = bv + lv[r];
+        double acc = fma(wv[r][0], q[0], 0.0);
+        acc = fma(wv[r][1], q[1], acc);
+        acc = fma(wv[r][2], q[WD_WW + 1], acc);
+        acc = fma(wv[r][3], q[WD_WW], acc);
+        buf_store_nt(finish(acc, mapv[r]), ov, pv[r]);
       }
     }
     uplane += P1;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
 #pragma unroll
   for (int r = 0; r < WD_RPT; ++r) any_far = any_far || faru[r] || farv[r];
   if (!any_far) return;
-  auto far_point = [&](const int32_t *idx, int64_t P, int64_t p, const double *w4, bool want_v, TD *out, int64_t plane) {
+  auto far_point = [&](const int32_t *idx, int64_t P, int64_t p, const double *w4, bool want_v, TD *out) {
     int32_t c[4];
     double ca[4], sa[4], tn[4], dn[4];
 #pragma unroll
@@ -251,13 +255,14 @@ __global__ __launch_bounds__(WD_NT) void k_wind_destagger(const WindArgs a) {
         if constexpr (ROT) wd_rotate(uo, vo, ca[q], sa[q], tn[q], dn[q], un, vn);
         acc = fma(w4[q], want_v ? vn : un, acc);
       }
-      emit(acc, true, out + (int64_t)k * plane, p);
+      out[(int64_t)k * P + p] = finish(acc, true);
     }
   };
 #pragma unroll
   for (int r = 0; r < WD_RPT; ++r) {
-    if (faru[r]) far_point(a.idx1, P1, pu[r], wu[r], false, (TD *)a.u, P1);
-    if (farv[r]) far_point(a.idx2, P2, pv[r], wv[r], true, (TD *)a.v, P2);
+    const int j = j0 + wave + (WD_NT / 64) * r;
+    if (faru[r]) far_point(a.idx1, P1, (int64_t)j * nxu + (i0 + lane - (int)(((long long)j * nxu) % WD_A)), wu[r], false, (TD *)a.u);
+    if (farv[r]) far_point(a.idx2, P2, (int64_t)j * nx + (i0 + lane - (int)(((long long)j * nx) % WD_A)), wv[r], true, (TD *)a.v);
   }
 }
 
@@ -290,7 +295,7 @@ int mpg_k_wind_destagger(mpg_handle_s *h1, mpg_handle_s *h2, const double *cosa,
         h->ny_dst != ny + (e1 ? 0 : 1))
       return MPG_ERR_UNSUPPORTED;
   }
-  if ((int64_t)(nx + 1) * (ny + 1) >= 0x7fffffffLL) return MPG_ERR_UNSUPPORTED;
+  if ((int64_t)(nx + 1) * (ny + 1) * 8 >= 0xFFFFFFFFLL) return MPG_ERR_UNSUPPORTED;   // 32-bit byte offsets inside a level plane
   const bool rot = cosa != nullptr;
   const int64_t n_pole = (h1 ? h1->n_pole : 0) + (h2 ? h2->n_pole : 0);
   if (rot && n_pole) return MPG_ERR_UNSUPPORTED;   // (a rotated field under pole caps: no projection of the reference asks for it)

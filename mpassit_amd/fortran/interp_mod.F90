@@ -299,6 +299,11 @@ contains
     if (hist_3d_nz%n > 0) call regrid_bundle(rh_patch, hist_3d_nz)
     if (do_u_interp == 1) call regrid_to(rh_patch, u_field, umass)
     if (do_v_interp == 1) call regrid_to(rh_patch, v_field, vmass)
+    if (dev_flow .and. (do_u_interp == 1 .or. do_v_interp == 1)) then
+      ! device-resident fields: rotation and both destaggerings in ONE pass over the mass winds (mpg_wind_destagger_dev); a pair of
+      ! handles it does not take (MPG_ERR_UNSUPPORTED) leaves the three calls below to do the work
+      if (wind_chain_fused()) go to 100
+    end if
     if (do_u_interp == 1 .and. do_v_interp == 1 .and. proj_code == PROJ_LC) call rotate_winds_cgrid(umass, vmass)
     if (do_u_interp == 1) then          ! UMASS(CENTER) -> U(EDGE1), interp.F90:295-311
       call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, method, rh_stag), &
@@ -312,6 +317,7 @@ contains
       call destagger(rh_stag, vmass, v_field)
       call mpg_check(mpg_handle_release(rh_stag), "IN FieldRegridRelease")
     end if
+100 continue
     if (dev_flow) then                  ! UMASS / VMASS are not output variables of the NetCDF file
       if (c_associated(umass%dst_dev)) call mpg_check(mpg_dev_free(umass%dst_dev), "IN dev_free")
       if (c_associated(vmass%dst_dev)) call mpg_check(mpg_dev_free(vmass%dst_dev), "IN dev_free")
@@ -351,6 +357,63 @@ contains
     if (have_cons) call mpg_check(mpg_handle_release(rh_cons), "IN FieldRegridRelease")
     if (have_nstd) call mpg_check(mpg_handle_release(rh_nstd), "IN FieldRegridRelease")
   end subroutine interp_hist_data
+
+  !> interp.F90:291-328 on device-resident mass winds: rotate_winds_cgrid (PROJ_LC, both components) and the two Grid -> Grid
+  !! Store / Regrid pairs as one kernel pass; U / V come out as the file stores them (NF90_FLOAT, big-endian), bit-identical to
+  !! the three calls.  .false.: the library does not take this pair of handles -- nothing has been done.
+  logical function wind_chain_fused()
+    type(c_ptr) :: rh_u, rh_v, ca, sa
+    integer(c_int64_t) :: n_src, n_dst, nnz, npts
+    integer(c_int) :: nxd, nyd, npr, rc, nlev
+    logical :: rot
+    wind_chain_fused = .false.
+    rh_u = c_null_ptr; rh_v = c_null_ptr; ca = c_null_ptr; sa = c_null_ptr
+    rot = do_u_interp == 1 .and. do_v_interp == 1 .and. proj_code == PROJ_LC
+    nlev = int(merge(umass%nlev, vmass%nlev, do_u_interp == 1), c_int)
+    if (do_u_interp == 1) then          ! the mass winds must be the float64 fields regrid_to left (keeps_r8)
+      if (umass%dst_is_f32 .or. umass%dst_is_be) return
+    end if
+    if (do_v_interp == 1) then
+      if (vmass%dst_is_f32 .or. vmass%dst_is_be) return
+    end if
+    if (do_u_interp == 1) then
+      call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, MPG_REGRIDMETHOD_BILINEAR, rh_u), &
+                     "IN FieldRegridStore")
+    end if
+    if (do_v_interp == 1) then
+      call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE2, MPG_REGRIDMETHOD_BILINEAR, rh_v), &
+                     "IN FieldRegridStore")
+    end if
+    if (rot) then
+      npts = int(i_target, c_int64_t)*int(ny_ext, c_int64_t)
+      if (.not. c_associated(cosa_dev)) then                    ! the rotation angles go up once
+        call mpg_check(mpg_dev_alloc(npts*8, cosa_dev), "IN dev_alloc")
+        call mpg_check(mpg_dev_alloc(npts*8, sina_dev), "IN dev_alloc")
+        call mpg_check(mpg_dev_upload(cosa_dev, cosa(:, je_lo:je_hi), npts*8), "IN dev_upload")
+        call mpg_check(mpg_dev_upload(sina_dev, sina(:, je_lo:je_hi), npts*8), "IN dev_upload")
+      end if
+      ca = cosa_dev; sa = sina_dev
+    end if
+    if (do_u_interp == 1) then
+      call mpg_check(mpg_handle_info(rh_u, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+      if (c_associated(u_field%dst_dev)) call mpg_check(mpg_dev_free(u_field%dst_dev), "IN dev_free")
+      u_field%dst_is_f32 = .true.; u_field%dst_is_be = .true.; u_field%n_dst_elems = n_dst*nlev
+      call mpg_check(mpg_dev_alloc(u_field%n_dst_elems*4, u_field%dst_dev), "IN dev_alloc")
+    end if
+    if (do_v_interp == 1) then
+      call mpg_check(mpg_handle_info(rh_v, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+      if (c_associated(v_field%dst_dev)) call mpg_check(mpg_dev_free(v_field%dst_dev), "IN dev_free")
+      v_field%dst_is_f32 = .true.; v_field%dst_is_be = .true.; v_field%n_dst_elems = n_dst*nlev
+      call mpg_check(mpg_dev_alloc(v_field%n_dst_elems*4, v_field%dst_dev), "IN dev_alloc")
+    end if
+    rc = mpg_wind_destagger_dev(rh_u, rh_v, ca, sa, umass%dst_dev, vmass%dst_dev, nlev, u_field%dst_dev, v_field%dst_dev, &
+                                MPG_TYPE_F32 + MPG_TYPE_BE, c_null_ptr, c_null_ptr, c_null_ptr)
+    if (c_associated(rh_u)) call mpg_check(mpg_handle_release(rh_u), "IN FieldRegridRelease")
+    if (c_associated(rh_v)) call mpg_check(mpg_handle_release(rh_v), "IN FieldRegridRelease")
+    if (rc == MPG_ERR_UNSUPPORTED) return
+    call mpg_check(rc, "IN wind_destagger")
+    wind_chain_fused = .true.
+  end function wind_chain_fused
 
   !> mesh field `src` -> CENTER-stagger field `dst` (uReconstructZonal -> UMASS, interp.F90:256-289)
   subroutine regrid_to(rh, src, dst)

@@ -15,7 +15,7 @@ module mpg
   implicit none
   public
 
-  integer(c_int), parameter :: MPG_SUCCESS = 0
+  integer(c_int), parameter :: MPG_SUCCESS = 0, MPG_ERR_UNSUPPORTED = 4
   integer(c_int), parameter :: MPG_REGRIDMETHOD_BILINEAR = 0, MPG_REGRIDMETHOD_CONSERVE = 1, MPG_REGRIDMETHOD_NEAREST_STOD = 2
   integer(c_int), parameter :: MPG_MESHLOC_ELEMENT = 0, MPG_MESHLOC_NODE = 1
   integer(c_int), parameter :: MPG_STAGGERLOC_CENTER = 0, MPG_STAGGERLOC_EDGE1 = 1, MPG_STAGGERLOC_EDGE2 = 2, &
@@ -194,6 +194,15 @@ module mpg
       type(c_ptr), value :: cosa, sina, u, v, stream
       integer(c_int) :: rc
     end function mpg_rotate_winds_dev
+
+    !> interp.F90:291-328 in one pass: rotate_winds_cgrid + UMASS -> U(EDGE1) + VMASS -> V(EDGE2) (include/mpassit_amd.h)
+    function mpg_wind_destagger_dev(rh_edge1, rh_edge2, cosa, sina, umass, vmass, nlev, u, v, dst_type, umass_rot, vmass_rot, stream) &
+      bind(C, name="mpg_wind_destagger_dev") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: rh_edge1, rh_edge2, cosa, sina, umass, vmass, u, v, umass_rot, vmass_rot, stream
+      integer(c_int), value :: nlev, dst_type
+      integer(c_int) :: rc
+    end function mpg_wind_destagger_dev
 
     !> device buffers for fields that stay in HBM between the input and the output file
     function mpg_dev_alloc(nbytes, dev) bind(C, name="mpg_dev_alloc") result(rc)

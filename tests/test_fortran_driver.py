@@ -103,7 +103,7 @@ def test_driver_matches_python_mirror(tmp_path, gpu_lib, regional_case):
     assert r.returncode == 0, r.stdout + r.stderr
     got = rawio.read(os.path.join(d, "out.raw"))
     inp = I.InputData(nz=6, nzp1=7, nsoil=4, hgt=ter, layout=R.LAYOUT_LEV_FAST, hist=hist, diag=diag)
-    cfg = I.InterpConfig(wrf_mod_vars=True, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
+    cfg = I.InterpConfig(wrf_mod_vars=True, keep_mass_winds=True, diag_list=DIAG, hist_2d=HIST_2D, hist_3d=HIST_3D, hist_soil=SOIL)
     import copy
     gd = copy.copy(g)            # both hosts evaluate the projection on the device (mpg_grid_create_proj)
     mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(gd)
