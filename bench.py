@@ -189,182 +189,257 @@ def main():
     F = args.fields
     layout = R.LAYOUT_CELL_FAST if args.layout == "cell_fast" else R.LAYOUT_LEV_FAST
 
-    # MPASSIT_BENCH_TRANSPORT=cabi: the halo schedule and exchange through the C-ABI's own RCCL verbs (mpg_comm_init,
-    # mpg_halo_build, mpg_halo_exchange_dev) instead of torch.distributed; the default stays torch.distributed
-    transport = os.environ.get("MPASSIT_BENCH_TRANSPORT", "torch")
-    import uuid
-    run_id = all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]
-    id_file = "/dev/shm/mpassit_bench_%s.rcclid" % run_id   # fresh per run
-    os.environ.setdefault("MPASSIT_RUN_ID", run_id)          # tags the id file of the C-ABI transport: several ranks without one are refused
-    sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file,
-                             ownership=args.ownership if world > 1 else "aligned", decomp_file=args.block_decomp_file if world > 1 else None)
-    P_local = sr.rh.n_dst
-    io32 = args.io == "f32"
-    c0, c1 = sr.sched.own
-    own_sel = sr.sched.owned_ids if sr.sched.mode == "owned" else slice(c0, c1)     # the cells this rank provides (an id list in the owned form)
-    big_bundle = io32 and world == 1 and F * nlev * 8.0 * sr.sched.n_local > 40e9
-    if big_bundle:
-        # BASELINE configs[4] as written ("100+ 3-D fields" in ONE bundle, interp.F90:240-254): the float64 staging copies of the
-        # generic path below would not fit beside 58 GB of sources + 143 GB of results; the source goes straight into its final
-        # form, field by field: float32, file order or cell-fast
-        own = local = None
-        src_for_kernel = torch.empty((F, sr.sched.n_local, nlev) if layout == R.LAYOUT_LEV_FAST else (F, nlev, sr.sched.n_local),
-                                     dtype=torch.float32, device=dev)
-        one = torch.empty((nlev, sr.sched.n_local), dtype=torch.float64, device=dev)
-        for f in range(F):
-            synth_fields_device(torch, m.latCell, m.lonCell, nlev, 1, one, seed=20240807 + f)
-            src_for_kernel[f].copy_(one.t() if layout == R.LAYOUT_LEV_FAST else one)
-        del one
-    elif world > 1 and (io32 or layout == R.LAYOUT_LEV_FAST):
-        # sharded run on the sources as the driver holds them (float32 and / or MPAS file order, input_data.F90:630-655): the local
-        # slab exists in its final form only -- [F][n_local][L] in file order, where a neighbour's strip is one byte range per field --
-        # and the halo exchange moves that element type
-        local = sr.local_buffer(F, nlev, dev, dtype=torch.float32 if io32 else torch.float64, layout=layout)
-        lev_fast = layout == R.LAYOUT_LEV_FAST
-        if sr.sched.mode == "range":
-            own = sr.own_view(local)
-        else:
-            own = torch.empty((F, c1 - c0, nlev) if lev_fast else (F * nlev, c1 - c0), dtype=local.dtype, device=dev)
-        gen = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
-        synth_fields_device(torch, m.latCell[own_sel], m.lonCell[own_sel], nlev, F, gen)
-        own.copy_(gen.view(F, nlev, -1).permute(0, 2, 1) if lev_fast else gen)
-        del gen
-        src_for_kernel = local
-    else:
-        local = sr.local_buffer(F, nlev, dev)
-        if sr.sched.mode == "range":
-            own = sr.own_view(local)
-        else:
-            own = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
-        synth_fields_device(torch, m.latCell[own_sel], m.lonCell[own_sel], nlev, F, own)
-        src_for_kernel = local
-        if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
-            src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()
-        if io32:  # fused ingest/egress variant: float32 in HBM on both sides, float64 arithmetic (not the headline)
-            src_for_kernel = src_for_kernel.float()
-            del local
-    out = torch.empty((F, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dtype=torch.float32 if io32 else torch.float64, device=dev)
-    torch.cuda.synchronize()
-
-    ev = []
-    # N > 1: the halo exchange of batch s+1 runs on its own stream while batch s is regridded (two source buffers);
-    # every step still performs exactly one exchange and one Regrid.
-    pipe = None
-    if world > 1:
-        local2 = local.clone()
-        bufs = [local, local2]
-        owns = [own, sr.own_view(local2)] if sr.sched.mode == "range" else [own, own]
-        halo_stream = torch.cuda.Stream(device=dev)
-        pipe = {"n": 0, "halo_done": [torch.cuda.Event(), torch.cuda.Event()], "comp_done": [None, None], "ev": []}
-
-        def exchange_into(b, record=False):
-            with torch.cuda.stream(halo_stream):
-                if pipe["comp_done"][b] is not None:
-                    halo_stream.wait_event(pipe["comp_done"][b])   # the Regrid that last read this buffer
-                if record:
-                    x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    x0.record(halo_stream)
-                sr.sched.exchange(owns[b], bufs[b], pack_fn=sr._pack)
-                if record:
-                    x1.record(halo_stream)
-                    pipe["ev"].append((x0, x1))
-                pipe["halo_done"][b].record(halo_stream)
-        halo_stream.wait_stream(torch.cuda.current_stream())
-        exchange_into(0)
-
-    def one_step(record):
-        if world > 1:
-            b = pipe["n"] % 2
-            exchange_into(1 - b, record)                           # next batch's halo, overlapped
-            torch.cuda.current_stream().wait_event(pipe["halo_done"][b])
-            src_t = bufs[b]
-        else:
-            src_t = src_for_kernel
-        if record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        if io32:
-            sr.rh.regrid_typed(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
-        else:
-            sr.rh.regrid(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
-        if record:
-            e1.record()
-            ev.append((e0, e1))
-        if world > 1:
-            if pipe["comp_done"][b] is None:
-                pipe["comp_done"][b] = torch.cuda.Event()
-            pipe["comp_done"][b].record()
-            pipe["n"] += 1
-
-    if args.calib:  # 1 GiB read / 1 GiB write, 8 B per lane fully coalesced: calibrates FETCH_SIZE / WRITE_SIZE
-        n_cal = 1 << 27
-        cal_src = torch.zeros(n_cal, dtype=torch.float64, device=dev)
-        cal_dst = torch.empty(n_cal, dtype=torch.float64, device=dev)
-        cal_ids = torch.arange(n_cal, dtype=torch.int32, device=dev)
-        for _ in range(3):
-            _lib.check(_lib.load().mpg_pack_dev(ctypes.c_void_p(cal_src.data_ptr()), ctypes.c_int64(n_cal), ctypes.c_int(1),
-                                                ctypes.c_void_p(cal_ids.data_ptr()), ctypes.c_int64(n_cal),
-                                                ctypes.c_void_p(cal_dst.data_ptr()),
-                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-        torch.cuda.synchronize()
-        del cal_src, cal_dst, cal_ids
-
-    for _ in range(args.warmup):
-        one_step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-    halo = None
-    if world > 1:   # the exchange as the halo stream saw it (it overlaps the Regrid of the previous batch), and what it moved
-        plan = sr.sched.plan(local.shape[0], local)
-        per_rank = all_gather_object({"exchange_ms": float(np.mean([a.elapsed_time(b) for a, b in pipe["ev"]])) if pipe["ev"] else None,
-                                      "kernel_ms": kern_ms, "sent": int(plan.bytes_sent), "received": int(plan.bytes_received),
-                                      "n_local": int(sr.sched.n_local), "needed": int(sr.n_needed), "rows": int(sr.j1 - sr.j0)})
-        halo = {"mode": sr.sched.mode,
-                "transport": "%s all_to_all_single (grouped send/recv, zero-size peers skipped)" % backend if transport == "torch" else
-                             "C-ABI mpg_halo_exchange_dev (librccl: grouped ncclSend / ncclRecv)",
-                "ranks_in_group": dist.get_world_size(),
-                "exchange_ms_max": max(r["exchange_ms"] or 0.0 for r in per_rank),
-                "kernel_ms_max": max(r["kernel_ms"] for r in per_rank),
-                "halo_bytes_per_step": sum(r["received"] for r in per_rank),
-                "halo_bytes_per_step_max_rank": max(r["received"] for r in per_rank),
-                "per_rank": per_rank}
-
-    # correctness guard inside the bench: constant field -> constant on mapped points (sum of weights = 1)
-    chk = torch.full((nlev, sr.sched.n_local), 2.5, dtype=torch.float64, device=dev)
-    if layout == R.LAYOUT_LEV_FAST:
-        chk = chk.t().contiguous()
-    o1 = sr.rh.regrid(chk.view(-1), nlev=nlev, nfields=1, layout=layout)
-    torch.cuda.synchronize()
-    bad = int(((o1 != 0.0) & ((o1 - 2.5).abs() > 1e-12)).sum().item())
-    n_unmapped = int((o1[0, 0] == 0.0).sum().item())
-    if bad:
-        raise SystemExit("bench self-check failed: %d points off" % bad)
-
-    # a bundle's first and last field against the same fields regridded alone (any 32-bit overflow in field * level * point
-    # offsets would show in the last one): bit for bit
-    bundle_check = None
+    # N > 1: the product's own transport is the C-ABI's (mpg_comm_init -> mpg_halo_build -> mpg_halo_exchange_dev: librccl directly, what the
+    # Fortran / C hosts call); `value` is timed on it.  The same schedule on torch.distributed (all_to_all_single over the nccl backend =
+    # RCCL) is timed FIRST in the same run as the comparison leg.  MPASSIT_BENCH_TRANSPORT=torch | cabi runs one leg only.  Under the gloo
+    # rehearsal backend (ranks sharing a card, where RCCL refuses a second rank per device) the default is the torch leg alone.
+    want = os.environ.get("MPASSIT_BENCH_TRANSPORT", "both")
+    if want not in ("both", "torch", "cabi"):
+        raise SystemExit("MPASSIT_BENCH_TRANSPORT must be both, torch or cabi")
     if world == 1:
-        bundle_check = True
-        for f in sorted({0, F - 1}):
-            sf = src_for_kernel.view(F, -1)[f]
-            alone = sr.rh.regrid_typed(sf, nlev=nlev, nfields=1, layout=layout) if io32 else sr.rh.regrid(sf, nlev=nlev, nfields=1, layout=layout)
-            if not torch.equal(alone[0], out[f]):
-                raise SystemExit("bench self-check failed: field %d of the %d-field bundle differs from the same field regridded alone" % (f, F))
-            del alone
-    torch.cuda.synchronize()
+        legs = ["torch"]
+    elif want == "both":
+        legs = ["torch", "cabi"] if backend == "nccl" or os.environ.get("MPASSIT_BENCH_FORCE_CABI_LEG") == "1" else ["torch"]
+    else:
+        legs = [want]
+    import uuid
+    io32 = args.io == "f32"
+
+    class Leg:
+        pass
+
+    def run_transport_leg(transport):
+        """One whole measurement on one transport: Store, schedule, sources, W warm-up and K timed steps (barrier + synchronise on
+        both sides, max over ranks), the halo object of that transport."""
+        L_ = Leg()
+        run_id = all_gather_object(uuid.uuid4().hex if rank == 0 else None)[0]
+        id_file = "/dev/shm/mpassit_bench_%s.rcclid" % run_id   # fresh per leg
+        os.environ["MPASSIT_RUN_ID"] = run_id                   # tags the id file of the C-ABI transport: several ranks without one are refused
+        sr = mdist.ShardedRegrid(m, g, R.REGRIDMETHOD_BILINEAR, rank, world, all_gather_object, transport=transport, id_file=id_file,
+                                 ownership=args.ownership if world > 1 else "aligned", decomp_file=args.block_decomp_file if world > 1 else None)
+        L_.sr = sr
+        c0, c1 = sr.sched.own
+        own_sel = sr.sched.owned_ids if sr.sched.mode == "owned" else slice(c0, c1)     # the cells this rank provides (an id list in the owned form)
+        big_bundle = io32 and world == 1 and F * nlev * 8.0 * sr.sched.n_local > 40e9
+        if big_bundle:
+            # BASELINE configs[4] as written ("100+ 3-D fields" in ONE bundle, interp.F90:240-254): the float64 staging copies of the
+            # generic path below would not fit beside 58 GB of sources + 143 GB of results; the source goes straight into its final
+            # form, field by field: float32, file order or cell-fast
+            own = local = None
+            src_for_kernel = torch.empty((F, sr.sched.n_local, nlev) if layout == R.LAYOUT_LEV_FAST else (F, nlev, sr.sched.n_local),
+                                         dtype=torch.float32, device=dev)
+            one = torch.empty((nlev, sr.sched.n_local), dtype=torch.float64, device=dev)
+            for f in range(F):
+                synth_fields_device(torch, m.latCell, m.lonCell, nlev, 1, one, seed=20240807 + f)
+                src_for_kernel[f].copy_(one.t() if layout == R.LAYOUT_LEV_FAST else one)
+            del one
+        elif world > 1 and (io32 or layout == R.LAYOUT_LEV_FAST):
+            # sharded run on the sources as the driver holds them (float32 and / or MPAS file order, input_data.F90:630-655): the local
+            # slab exists in its final form only -- [F][n_local][L] in file order, where a neighbour's strip is one byte range per field --
+            # and the halo exchange moves that element type
+            local = sr.local_buffer(F, nlev, dev, dtype=torch.float32 if io32 else torch.float64, layout=layout)
+            lev_fast = layout == R.LAYOUT_LEV_FAST
+            if sr.sched.mode == "range":
+                own = sr.own_view(local)
+            else:
+                own = torch.empty((F, c1 - c0, nlev) if lev_fast else (F * nlev, c1 - c0), dtype=local.dtype, device=dev)
+            gen = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
+            synth_fields_device(torch, m.latCell[own_sel], m.lonCell[own_sel], nlev, F, gen)
+            own.copy_(gen.view(F, nlev, -1).permute(0, 2, 1) if lev_fast else gen)
+            del gen
+            src_for_kernel = local
+        else:
+            local = sr.local_buffer(F, nlev, dev)
+            if sr.sched.mode == "range":
+                own = sr.own_view(local)
+            else:
+                own = torch.empty((F * nlev, c1 - c0), dtype=torch.float64, device=dev)
+            synth_fields_device(torch, m.latCell[own_sel], m.lonCell[own_sel], nlev, F, own)
+            src_for_kernel = local
+            if layout == R.LAYOUT_LEV_FAST:  # [F][n][L]
+                src_for_kernel = local.view(F, nlev, -1).permute(0, 2, 1).contiguous()
+            if io32:  # fused ingest/egress variant: float32 in HBM on both sides, float64 arithmetic (not the headline)
+                src_for_kernel = src_for_kernel.float()
+                del local
+                local = None
+        out = torch.empty((F, nlev, sr.rh.ny_dst, sr.rh.nx_dst), dtype=torch.float32 if io32 else torch.float64, device=dev)
+        torch.cuda.synchronize()
+        L_.local, L_.own, L_.src_for_kernel, L_.out = local, own, src_for_kernel, out
+
+        ev = []
+        # N > 1: the halo exchange of batch s+1 runs on its own stream while batch s is regridded (two source buffers);
+        # every step still performs exactly one exchange and one Regrid.
+        pipe = None
+        if world > 1:
+            local2 = local.clone()
+            bufs = [local, local2]
+            owns = [own, sr.own_view(local2)] if sr.sched.mode == "range" else [own, own]
+            halo_stream = torch.cuda.Stream(device=dev)
+            pipe = {"n": 0, "halo_done": [torch.cuda.Event(), torch.cuda.Event()], "comp_done": [None, None], "ev": []}
+
+            def exchange_into(b, record=False):
+                with torch.cuda.stream(halo_stream):
+                    if pipe["comp_done"][b] is not None:
+                        halo_stream.wait_event(pipe["comp_done"][b])   # the Regrid that last read this buffer
+                    if record:
+                        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        x0.record(halo_stream)
+                    sr.sched.exchange(owns[b], bufs[b], pack_fn=sr._pack)
+                    if record:
+                        x1.record(halo_stream)
+                        pipe["ev"].append((x0, x1))
+                    pipe["halo_done"][b].record(halo_stream)
+            halo_stream.wait_stream(torch.cuda.current_stream())
+            exchange_into(0)
+
+        def one_step(record):
+            if world > 1:
+                b = pipe["n"] % 2
+                exchange_into(1 - b, record)                           # next batch's halo, overlapped
+                torch.cuda.current_stream().wait_event(pipe["halo_done"][b])
+                src_t = bufs[b]
+            else:
+                src_t = src_for_kernel
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if io32:
+                sr.rh.regrid_typed(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+            else:
+                sr.rh.regrid(src_t.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+            if record:
+                e1.record()
+                ev.append((e0, e1))
+            if world > 1:
+                if pipe["comp_done"][b] is None:
+                    pipe["comp_done"][b] = torch.cuda.Event()
+                pipe["comp_done"][b].record()
+                pipe["n"] += 1
+
+        if args.calib:  # 1 GiB read / 1 GiB write, 8 B per lane fully coalesced: calibrates FETCH_SIZE / WRITE_SIZE
+            n_cal = 1 << 27
+            cal_src = torch.zeros(n_cal, dtype=torch.float64, device=dev)
+            cal_dst = torch.empty(n_cal, dtype=torch.float64, device=dev)
+            cal_ids = torch.arange(n_cal, dtype=torch.int32, device=dev)
+            for _ in range(3):
+                _lib.check(_lib.load().mpg_pack_dev(ctypes.c_void_p(cal_src.data_ptr()), ctypes.c_int64(n_cal), ctypes.c_int(1),
+                                                    ctypes.c_void_p(cal_ids.data_ptr()), ctypes.c_int64(n_cal),
+                                                    ctypes.c_void_p(cal_dst.data_ptr()),
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            del cal_src, cal_dst, cal_ids
+
+        for _ in range(args.warmup):
+            one_step(False)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        L_.dt = dt
+        L_.kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+        L_.halo = None
+        if world > 1:   # the exchange as the halo stream saw it (it overlaps the Regrid of the previous batch), and what it moved
+            plan = sr.sched.plan(local.shape[0], local)
+            per_rank = all_gather_object({"exchange_ms": float(np.mean([a.elapsed_time(b) for a, b in pipe["ev"]])) if pipe["ev"] else None,
+                                          "kernel_ms": L_.kern_ms, "sent": int(plan.bytes_sent), "received": int(plan.bytes_received),
+                                          "n_local": int(sr.sched.n_local), "needed": int(sr.n_needed), "rows": int(sr.j1 - sr.j0)})
+            if transport == "cabi":
+                ranks_in_group = sr.sched.comm.info()[1]      # mpg_comm_info: what the C-ABI communicator itself says
+            else:
+                ranks_in_group = dist.get_world_size()
+            L_.halo = {"mode": sr.sched.mode,
+                       "transport": "%s all_to_all_single (grouped send/recv, zero-size peers skipped)" % backend if transport == "torch" else
+                                    "C-ABI mpg_halo_exchange_dev (librccl: grouped ncclSend / ncclRecv)",
+                       "ranks_in_group": int(ranks_in_group),
+                       "ms_per_step": dt / args.steps * 1e3, "fields_per_s": F * args.steps / dt,
+                       "exchange_ms_max": max(r["exchange_ms"] or 0.0 for r in per_rank),
+                       "kernel_ms_max": max(r["kernel_ms"] for r in per_rank),
+                       "halo_bytes_per_step": sum(r["received"] for r in per_rank),
+                       "halo_bytes_per_step_max_rank": max(r["received"] for r in per_rank),
+                       "per_rank": per_rank}
+        # correctness guard inside the bench, on every transport's own handle: constant field -> constant on mapped points (sum of weights = 1)
+        chk = torch.full((nlev, sr.sched.n_local), 2.5, dtype=torch.float64, device=dev)
+        if layout == R.LAYOUT_LEV_FAST:
+            chk = chk.t().contiguous()
+        o1 = sr.rh.regrid(chk.view(-1), nlev=nlev, nfields=1, layout=layout)
+        torch.cuda.synchronize()
+        bad = int(((o1 != 0.0) & ((o1 - 2.5).abs() > 1e-12)).sum().item())
+        L_.n_unmapped = int((o1[0, 0] == 0.0).sum().item())
+        del chk, o1
+        if bad:
+            raise SystemExit("bench self-check failed: %d points off" % bad)
+        # a bundle's first and last field against the same fields regridded alone (any 32-bit overflow in field * level * point
+        # offsets would show in the last one): bit for bit
+        L_.bundle_check = None
+        if world == 1:
+            L_.bundle_check = True
+            for f in sorted({0, F - 1}):
+                sf = src_for_kernel.view(F, -1)[f]
+                alone = sr.rh.regrid_typed(sf, nlev=nlev, nfields=1, layout=layout) if io32 else sr.rh.regrid(sf, nlev=nlev, nfields=1, layout=layout)
+                if not torch.equal(alone[0], out[f]):
+                    raise SystemExit("bench self-check failed: field %d of the %d-field bundle differs from the same field regridded alone" % (f, F))
+                del alone
+        torch.cuda.synchronize()
+        L_.P_local, L_.U, L_.mode, L_.store_ms, L_.kernel = sr.rh.n_dst, sr.n_needed, sr.sched.mode, sr.store_ms, kernel_label(sr.rh, layout, R)
+        return L_
+
+    def teardown(L_):
+        """A finished leg keeps its numbers; its handle, communicator and buffers go."""
+        if L_.sr is not None:
+            L_.sr.destroy()
+        L_.sr = L_.local = L_.own = L_.src_for_kernel = L_.out = None
+        torch.cuda.empty_cache()
+
+    done, leg_error = {}, {}
+    primary = None
+    for transport in legs:
+        if primary is not None:        # the comparison leg's buffers go before the product's leg allocates its own; its numbers stay
+            teardown(primary)
+        err = res_leg = None
+        try:
+            res_leg = run_transport_leg(transport)
+        except Exception as e:         # noqa: BLE001 -- a failing C-ABI leg is reported IN the line (halo.transports.cabi.error); the torch leg,
+            if world == 1 or transport != "cabi":   # already measured, supplies the line's numbers, and the run ends non-zero below.  Nothing is
+                raise                                # re-executed and no communicator is built again in a process whose RCCL call failed.
+            err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            res_leg = None
+        errs = all_gather_object(err)
+        if any(errs):                  # one rank's failure is every rank's: nobody goes on with a communicator a peer has left
+            leg_error[transport] = next(e for e in errs if e)
+            continue
+        done[transport] = res_leg.halo
+        primary = res_leg
+    if primary is None:                # MPASSIT_BENCH_TRANSPORT=cabi alone, and it failed: a line without a measurement
+        if rank == 0:
+            print(json.dumps({"metric": "interpolated 3-D fields/sec (nCells x nLev -> nx x ny)", "value": None, "unit": "fields/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "halo": {"transports": {k: {"error": e} for k, e in leg_error.items()}}}), flush=True)
+        sys.stderr.write("bench.py: transport leg failed: %s\n" % leg_error)
+        sys.exit(3)
+    transport = "cabi" if "cabi" in done else "torch"
+    sr, local, own, src_for_kernel, out, dt, kern_ms, halo = (primary.sr, primary.local, primary.own, primary.src_for_kernel, primary.out, primary.dt,
+                                                               primary.kern_ms, primary.halo)
+    P_local, n_unmapped, bundle_check = primary.P_local, primary.n_unmapped, primary.bundle_check
+    if halo is not None:
+        # both transports of the run, flat: ms per step, exchange time as the halo stream saw it, bytes
+        halo = dict(halo)
+        halo["value_transport"] = transport
+        halo["transports"] = {k: {kk: v[kk] for kk in ("transport", "ranks_in_group", "ms_per_step", "fields_per_s", "exchange_ms_max", "kernel_ms_max",
+                                                       "halo_bytes_per_step", "halo_bytes_per_step_max_rank")} for k, v in done.items() if v}
+        for k, e in leg_error.items():
+            halo["transports"][k] = {"error": e}
+        if world > 1 and "cabi" not in legs:
+            halo["transports"]["cabi"] = {"skipped": "MPASSIT_BENCH_TRANSPORT=torch" if want == "torch" else
+                                                     "backend %s: ranks may share a card, RCCL refuses a second rank per device" % backend}
 
     # live streaming reference of THIS device (boxes differ by >10 %): plain 2 GiB -> 2 GiB device copy
     cp_a = torch.empty(1 << 28, dtype=torch.float64, device=dev)
@@ -390,7 +465,7 @@ def main():
         mix[key] = 5 * nbytes * cp_a.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del cp_a, cp_b
 
-    U = sr.n_needed
+    U = primary.U
     esz = 4.0 if io32 else 8.0  # element size of the field values in HBM (float64 = reference-faithful headline)
     alg_bytes = F * nlev * esz * (U + P_local) + P_local * 36.0  # U*L*e + P*L*e per field + P*36 once per launch
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -431,6 +506,7 @@ def main():
     if extras and not io32 and layout == R.LAYOUT_CELL_FAST:
         production = production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint=sr.n_needed)
         del out, local, src_for_kernel, own
+        primary.local = primary.own = primary.src_for_kernel = primary.out = None
         torch.cuda.empty_cache()
         store = fresh_process_leg("store", args)      # one fresh child process per leg: first-in-process numbers
         job = fresh_process_leg("job", args) if args.workload == "c4_3m_regional" else None
@@ -466,10 +542,10 @@ def main():
             "config": {"workload": "%s: %s" % (args.workload, desc), "fields_per_step": F, "nlev": nlev, "nCells": int(m.nCells),
                        "target_points": int(g.nx * g.ny), "method": "bilinear", "src_layout": args.layout,
                        "io_dtype": "f32 (fused ingest/egress, f64 arithmetic)" if io32 else "f64",
-                       "parallelism": "rows%d+halo(%s)" % (world, sr.sched.mode) if world > 1 else "single-gpu",
+                       "parallelism": "rows%d+halo(%s,%s)" % (world, primary.mode, "c-abi rccl" if transport == "cabi" else "torch " + backend) if world > 1 else "single-gpu",
                        "unmapped_points_rank0": n_unmapped, "bundle_ends_equal_single": bundle_check},
             "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": traffic, "traffic_source": traffic_source, "kernel": kernel_label(sr.rh, layout, R),
+                              "traffic": traffic, "traffic_source": traffic_source, "kernel": primary.kernel,
                               "kernel_ms": kern_ms, "alg_bytes_per_launch": alg_bytes, "unique_src_cells": int(U),
                               "device_copy_GBs": copy_gbs, **mix}, **flat),
             "cpu_baseline": cpu,
@@ -479,15 +555,19 @@ def main():
             "job": job,
             "cell_numbering": numbering,
             "halo": halo,
-            "store_ms": sr.store_ms,
+            "store_ms": primary.store_ms,
             "device": {"arch": arch, "cus": n_cu, "hbm_gib": round(hbm / 2 ** 30, 1), "name": torch.cuda.get_device_name(dev),
                        "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))},
             "setup_s": {"synthetic_mesh_and_grid": round(t_gen, 2)},
         }
         print(json.dumps(rec), flush=True)
-    sr.destroy()
+    if primary.sr is not None:
+        teardown(primary)
     if world > 1:
         dist.destroy_process_group()
+    if leg_error:      # the line above carries the error (halo.transports) and the comparison leg's numbers; the run itself has failed
+        sys.stderr.write("bench.py: transport leg failed: %s\n" % leg_error)
+        sys.exit(3)
 
 
 def realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, rh_rows):

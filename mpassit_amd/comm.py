@@ -63,6 +63,12 @@ class Comm:
             check(L.load().mpg_comm_init(C.c_int(rank), C.c_int(nranks), id_file.encode() if id_file else None, C.byref(self._h)))
         self.rank, self.nranks = rank, nranks
 
+    def info(self):
+        """mpg_comm_info -> (rank, nranks) as the communicator itself reports them."""
+        r, n = C.c_int(), C.c_int()
+        check(L.load().mpg_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
     def virtual(self, v_rank, v_nranks):
         """REHEARSAL on one GPU (mpg_comm_virtual): virtual rank v_rank of v_nranks on top of this one-rank communicator.  Drive every
         virtual rank from its own thread (`run_virtual_ranks`)."""

@@ -153,7 +153,12 @@ class HaloSchedule:
         lists = all_gather_object((needed_ids, owned_ids))
         # every rank checks EVERY rank's needs (all lists are here), so that all refuse together -- a rank that went on alone would wait in
         # its first exchange for a peer that has given up (mpg_halo_build_owned does the same)
-        everyones = np.unique(np.concatenate([np.asarray(o, np.int32) for _, o in lists]))
+        all_owned = np.sort(np.concatenate([np.asarray(o, np.int32) for _, o in lists]), kind="stable")
+        dup = np.nonzero(all_owned[1:] == all_owned[:-1])[0]
+        if dup.size:      # mpg_halo_build_owned refuses a cell with two owners too: both transports accept the same partitions
+            c = int(all_owned[dup[0]])
+            raise ValueError("cell %d is owned by ranks %s: a partition gives every cell one owner" % (c, [q for q in range(world) if c in set(np.asarray(lists[q][1]).tolist())]))
+        everyones = np.unique(all_owned)
         for q in range(world):
             theirs = np.asarray(lists[q][0], np.int32)
             orphan = np.setdiff1d(theirs, everyones, assume_unique=True)

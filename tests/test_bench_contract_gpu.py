@@ -52,6 +52,28 @@ def test_bench_gpus2_launches_itself(gpu_lib):
     assert sum(p["rows"] for p in h["per_rank"]) == 1060
     # aligned ownership: only the strips straddling the row-block boundary travel -- a few lattice rows of 13 x 55 values
     assert 0 < h["halo_bytes_per_step"] < 200e6 and h["exchange_ms_max"] > 0
+    # round 6: the line names every transport of the run; on a multi-GPU node the C-ABI leg supplies `value` and the torch leg is the
+    # comparison; in this rehearsal (gloo, ranks sharing the card) the C-ABI leg is skipped and says why
+    tr = h["transports"]
+    assert h["value_transport"] == "torch" and tr["torch"]["ms_per_step"] > 0 and tr["torch"]["ranks_in_group"] == 2
+    assert abs(tr["torch"]["ms_per_step"] - rec["ms_per_step"]) < 1e-9 and "skipped" in tr["cabi"]
+
+
+def test_bench_failing_cabi_leg_is_reported_and_ends_nonzero(gpu_lib):
+    """MPASSIT_BENCH_TRANSPORT=both forced on the one-card rehearsal: RCCL refuses the second rank on the device, so the C-ABI leg
+    (mpg_comm_init) FAILS for real.  The line must still come -- the torch leg's numbers, the error under halo.transports.cabi --
+    and the run must end non-zero; nothing is re-executed."""
+    env = dict(os.environ, MPASSIT_DIST_BACKEND="gloo", MPASSIT_BENCH_FORCE_CABI_LEG="1", MPG_COMM_TIMEOUT_S="30")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = json.loads(lines[0])
+    tr = rec["halo"]["transports"]
+    assert r.returncode != 0, "a failed transport leg must fail the run"
+    assert "error" in tr["cabi"] and tr["torch"]["ms_per_step"] > 0 and rec["halo"]["value_transport"] == "torch" and rec["value"] > 0
 
 
 @pytest.mark.parametrize("workload,ranks,mode", [("tiny", 3, "range"), ("c5_small", 2, "owned")])

@@ -132,6 +132,11 @@ def test_owned_form_c_schedule_equals_the_torch_distributed_one(partition):
     res = _lockstep(2, lambda r, ag: dist.HaloSchedule.build_owned(needed[r], owned[r], r, 2, ag))
     assert all(isinstance(x, ValueError) and "rank 0's rows reference cell 9, which no rank owns" in str(x) for x in res)   # all ranks refuse together
     assert comm.plan_owned_host(1, needed, owned)["n_local"] == 2        # (the plan of one rank alone, without the collective check)
+    # a cell with two owners is no partition: the torch.distributed schedule refuses it on every rank together, as mpg_halo_build_owned does
+    # (round-5 advisor: the two transports must accept the same inputs)
+    owned2 = [np.array([1, 5, 9], np.int32), np.array([2, 5], np.int32)]
+    res = _lockstep(2, lambda r, ag: dist.HaloSchedule.build_owned(needed[r], owned2[r], r, 2, ag))
+    assert all(isinstance(x, ValueError) and "cell 5 is owned by ranks [0, 1]" in str(x) for x in res)
 
 
 # ---- the id-file acceptance rule of mpg_comm_init (pure host logic, no GPU, no RCCL) --------------------------------------
