@@ -164,6 +164,15 @@ int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_stagge
 /* Grid -> Grid on the same grid, CENTER -> EDGE1/EDGE2 bilinear (interp.F90:298,316). */
 int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod,
                           mpg_handle *out);
+/* The same two Stores STARTED and not waited for.  interp.F90:207-437 stores its weight sets one after the other, each in front of
+ * the Regrids that use it; they are independent of each other and of every Regrid that does not use them.  A _begin call queues
+ * the Store on the library's worker thread (own stream, one Store at a time) and returns; the matching mpg_regrid_store[_grid]
+ * -- same arguments -- later returns the finished handle, waiting only for what is left of it.  A host that begins its
+ * conservative, nearest-neighbour and destaggering Stores before it regrids its bilinear fields hides them behind those Regrids
+ * (bench.py `job` leg).  Weights, cache and reference counting are those of the plain calls; a Store that nobody collects stays
+ * a parked cache entry.  Errors of a begun Store surface in the collecting call. */
+int mpg_regrid_store_begin(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod);
+int mpg_regrid_store_grid_begin(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod);
 
 /* ---- ESMF_Field[Bundle]Regrid (interp.F90:134,219,236,251,268,286,307,325,344,363,382,404,431,443) --
  * dst is fully overwritten: [nfields][nlev][ny_dst][nx_dst], unmapped points = 0.0 (zeroregion=TOTAL).

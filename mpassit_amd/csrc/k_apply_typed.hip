@@ -72,6 +72,58 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
   }
 }
 
+// A bundle of 2-D fields held in SEPARATE arrays (interp.F90:123-134 diag bundle, :207-219 hist 2-D bundle; mpg_regrid_bundle_typed_dev
+// with nlev = 1): the fields take the place of the levels -- a workgroup keeps its 64 x 8 points' indices and weights in registers and
+// walks the bundle's fields, where one launch item per (field, tile) would load those 36 bytes per point once per FIELD to produce 8
+// (the staged kernel did, after building tile lists no 3-D Regrid of a file-order job ever uses: 0.47 + 0.95 ms of a cold
+// configuration-4 job for its 19 diag fields, round 6 timeline).  Arithmetic and epilogue of k_apply3_cf_t: the same bits.
+template <typename TS, typename TD, bool SWZ>
+__global__ __launch_bounds__(256) void k_apply3_cf_fields(const int32_t *__restrict__ idx, const double *__restrict__ w, int nx, int ny, int ntx,
+                                                          double scale, int sbe, int dbe, FieldTab tab) {
+  constexpr int RPT = 2, TY = 4 * RPT;
+  const Swz zs = make_swz(sbe), zd = make_swz(dbe);
+  const int64_t P = (int64_t)nx * ny;
+  const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % ntx, ty = tile / ntx;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = ty * TY + wave * RPT;
+  int32_t c[RPT][3];
+  double ww[RPT][3];
+  bool act[RPT], mapped[RPT];
+  int64_t po[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int j = j0 + r;
+    const int i = tx * 64 + lane - mpg_tile_shift(j, nx);
+    act[r] = (i >= 0) && (i < nx) && (j < ny);
+    const int64_t p = act[r] ? (int64_t)j * nx + i : 0;
+    po[r] = p;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      c[r][q] = idx[q * P + p];
+      ww[r][q] = w[q * P + p];
+    }
+    mapped[r] = c[r][0] >= 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) c[r][q] = max(c[r][q], 0);
+  }
+  for (int f = 0; f < tab.n; ++f) {
+    const TS *s = (const TS *)tab.src[f];
+    TD *d = (TD *)tab.dst[f];
+    const double offset = tab.off[f];
+    __syncthreads();
+    double v[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const double a = (double)swz<SWZ>(s[c[r][0]], zs), b = (double)swz<SWZ>(s[c[r][1]], zs), e = (double)swz<SWZ>(s[c[r][2]], zs);
+      v[r] = wsum3(ww[r][0], a, ww[r][1], b, ww[r][2], e);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r)
+      if (act[r]) __builtin_nontemporal_store(swz<SWZ>((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), zd), d + po[r]);
+  }
+}
+
 template <typename TS, typename TD, bool SWZ>
 __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                      const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int64_t nsrc,
@@ -407,6 +459,22 @@ int mpg_k_apply_typed(mpg_handle_s *h, const void *src, int src_type, int layout
   const bool three = h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3;
   const bool lev_fast = layout == MPG_LAYOUT_LEV_FAST && nlev > 1;
   const bool long_bundle = nlev * nfields >= MPG_STAGE_MIN_LEVELS;
+  if (three && nlev == 1 && tab.n > 1) {   // 2-D fields in separate arrays: the bundle's fields are walked like levels
+    const int ntx = mpg_tile_ntx(h->nx_dst, 64), nty = (h->ny_dst + 7) / 8;
+    const unsigned nwg = (unsigned)ntx * nty;
+#define CF_FIELDS(TS, TD)                                                                                                                                        \
+  do {                                                                                                                                                           \
+    if (sbe || dbe) k_apply3_cf_fields<TS, TD, true><<<nwg, 256, 0, s>>>(h->idx.p, h->w.p, h->nx_dst, h->ny_dst, ntx, scale, sbe, dbe, tab);                      \
+    else k_apply3_cf_fields<TS, TD, false><<<nwg, 256, 0, s>>>(h->idx.p, h->w.p, h->nx_dst, h->ny_dst, ntx, scale, 0, 0, tab);                                   \
+  } while (0)
+    if (sf32 && df32) CF_FIELDS(float, float);
+    else if (sf32) CF_FIELDS(float, double);
+    else if (df32) CF_FIELDS(double, float);
+    else CF_FIELDS(double, double);
+#undef CF_FIELDS
+    MPG_HIP(hipGetLastError());
+    return MPG_SUCCESS;
+  }
   if (three && !lev_fast && !sbe && !dbe) {   // cell-fast: LDS-staged (k_apply_lfu.hip) unless the knob or the handle says lane gather
     int staged = mpg_a3_staged(), rc;
     if (staged == -1) {

@@ -7,6 +7,10 @@
 #include <string.h>
 #include <time.h>
 
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -25,6 +29,12 @@ static std::map<HandleKey, mpg_handle_s *> g_cache;
 // mpg_regrid_store of a released 5-tuple was a second run of the rasteriser (r02j: 2 x k_tri_raster in one job).
 #define MPG_MAX_PARKED 8
 static uint64_t g_park_clock = 0;
+// The cache is shared with the Store worker below (it inserts finished handles): every walk, lookup and change holds this lock.
+static std::recursive_mutex g_cache_mu;
+#define CACHE_LOCK() std::lock_guard<std::recursive_mutex> cache_lock_(g_cache_mu)
+static void store_worker_drain();   // below: every queued / running Store has finished when this returns
+static void store_worker_stop();
+static int store_worker_start(int device);
 
 void mpg_set_error(const char *fmt, ...) {
   va_list ap;
@@ -37,6 +47,7 @@ hipStream_t mpg_setup_stream() { return g_stream; }
 int mpg_device_index() { return g_device; }
 
 void mpg_cache_detach(mpg_handle_s *h) {
+  CACHE_LOCK();
   if (h->cached) {
     g_cache.erase(h->key);
     h->cached = false;
@@ -136,6 +147,7 @@ static double now_ms() {
 }
 static void warm_modules(int device) {
   if (hipSetDevice(device) != hipSuccess) return;
+  (void)store_worker_start(device);   // the Store worker's thread and stream exist before the first RegridStore asks for them
   hipFuncAttributes a;
   double t0 = now_ms();
 #define X(n)                                                                                                          \
@@ -230,11 +242,13 @@ int mpg_init(int device) {
 // after mpg_init (hipStreamBeginCapture forbids such calls from other threads while it lasts) waits for it here first.
 int mpg_warmup_wait(void) {
   warm_join();
+  store_worker_drain();   // ... and for the Store worker (mpg_regrid_store_begin): it allocates too
   return MPG_SUCCESS;
 }
 
 static void handle_free(mpg_handle_s *h);
 static void drop_parked(void *obj) {   // obj == nullptr: all of them
+  CACHE_LOCK();
   for (auto it = g_cache.begin(); it != g_cache.end();) {
     mpg_handle_s *h = it->second;
     if (h->refcount == 0 && (!obj || std::get<0>(it->first) == obj || std::get<2>(it->first) == obj)) {
@@ -249,6 +263,7 @@ static void drop_parked(void *obj) {   // obj == nullptr: all of them
 int mpg_finalize(void) {
   if (!g_init) return MPG_SUCCESS;
   warm_join();
+  store_worker_stop();
   drop_parked(nullptr);
   mpg_fileio_release();
   mpg_hostpipe_release();
@@ -365,6 +380,8 @@ int mpg_mesh_create(int64_t nCells, int64_t nVertices, int maxEdges, const doubl
 
 // handles outlive neither their mesh nor their grid in the cache: a recycled address must never hit
 static void cache_purge(void *obj) {
+  store_worker_drain();   // a Store in flight reads the mesh and the grid it was started on
+  CACHE_LOCK();
   drop_parked(obj);
   for (auto it = g_cache.begin(); it != g_cache.end();) {
     if (std::get<0>(it->first) == obj || std::get<2>(it->first) == obj) {
@@ -560,35 +577,6 @@ static void handle_free(mpg_handle_s *h) {
   delete h;
 }
 
-static int store_common(HandleKey key, mpg_handle *out, int (*build)(mpg_handle_s *, void *), void *ctx) {
-  auto it = g_cache.find(key);
-  if (it != g_cache.end()) {   // in use elsewhere, or parked by an earlier release: the same weights, no device work
-    it->second->refcount++;
-    *out = it->second;
-    return MPG_SUCCESS;
-  }
-  mpg_handle_s *h = new mpg_handle_s();
-  hipEvent_t e0, e1;
-  MPG_HIP(hipEventCreate(&e0));
-  MPG_HIP(hipEventCreate(&e1));
-  MPG_HIP(hipEventRecord(e0, g_stream));
-  int rc = build(h, ctx);
-  if (rc) {
-    handle_free(h);
-    return rc;
-  }
-  MPG_HIP(hipEventRecord(e1, g_stream));
-  MPG_HIP(hipEventSynchronize(e1));
-  MPG_HIP(hipEventElapsedTime(&h->store_ms, e0, e1));
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  h->key = key;
-  h->cached = true;
-  g_cache[key] = h;
-  *out = h;
-  return MPG_SUCCESS;
-}
-
 struct StoreCtx {
   mpg_mesh_s *m;
   mpg_grid_s *g;
@@ -597,39 +585,229 @@ struct StoreCtx {
   int meshloc;
 };
 
-int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+// ---- the Store worker -------------------------------------------------------------------------------------------------
+// interp.F90:207-437 stores its weight sets one after the other, each in front of the Regrids that use it; they are
+// independent of each other and of every Regrid that does not use them.  All RegridStores of this library run on ONE worker
+// thread with a stream of its own: mpg_regrid_store[_grid]_begin queues a Store and returns; mpg_regrid_store[_grid] returns
+// the finished handle of its key -- from the cache, from the queue (waiting for it), or by queueing it itself and waiting.
+// While the worker builds the conservative and nearest-neighbour weights (3 of the 4.6 ms of configuration 4's Stores,
+// compute-bound kernels) the caller's thread is already issuing the bilinear Regrids (HBM-bound) on ITS stream.  One
+// Store at a time: the lazily built search structures of a mesh / grid (pyramids, BVH, fans) are only ever touched by this
+// thread.  The weights do not depend on which thread builds them.
+struct StoreJob {
+  HandleKey key;
+  int (*build)(mpg_handle_s *, void *, hipStream_t);
+  StoreCtx ctx;
+  hipEvent_t ready = nullptr;   // recorded on the set-up stream when the job was queued: the mesh / grid uploads and kernels issued there come first
+  bool done = false;
+  int rc = MPG_SUCCESS;
+  char err[1024] = "";
+  ~StoreJob() {
+    if (ready) (void)hipEventDestroy(ready);
+  }
+};
+// The worker's state lives on the heap and is never destroyed: a process that ends without mpg_finalize (a Fortran `stop`, an error exit)
+// must not run the destructor of a condition variable the worker is waiting on (that blocks for ever).
+struct StoreWorker {
+  std::mutex mu, start_mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<StoreJob>> queue;
+  std::map<HandleKey, std::shared_ptr<StoreJob>> pending;   // queued or running
+  std::thread *thread = nullptr;
+  hipStream_t stream = nullptr;
+  bool stop = false;
+};
+static StoreWorker &SW() {
+  static StoreWorker *w = new StoreWorker();
+  return *w;
+}
+static const char *mpg_last_error_cstr() { return g_err; }
+
+static int store_build_now(StoreJob &job, hipStream_t s) {
+  mpg_handle_s *h = new mpg_handle_s();
+  h->refcount = 0;   // nobody holds it yet: parked in the cache until a mpg_regrid_store collects it
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    mpg_set_error("hipEventCreate failed in a RegridStore");
+    handle_free(h);
+    return MPG_ERR_HIP;
+  }
+  (void)hipEventRecord(e0, s);
+  int rc = job.build(h, &job.ctx, s);
+  if (!rc) {
+    hipError_t e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&h->store_ms, e0, e1);
+    if (e != hipSuccess) {
+      mpg_set_error("RegridStore: %s", hipGetErrorString(e));
+      rc = MPG_ERR_HIP;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) {
+    handle_free(h);
+    return rc;
+  }
+  CACHE_LOCK();
+  h->key = job.key;
+  h->cached = true;
+  h->parked_at = ++g_park_clock;
+  g_cache[job.key] = h;
+  return MPG_SUCCESS;
+}
+
+static void store_worker_main(int device) {
+  if (hipSetDevice(device) != hipSuccess) return;
+  for (;;) {
+    std::shared_ptr<StoreJob> job;
+    {
+      std::unique_lock<std::mutex> lk(SW().mu);
+      SW().cv.wait(lk, [] { return SW().stop || !SW().queue.empty(); });
+      if (SW().queue.empty()) return;   // stop asked and nothing left
+      job = SW().queue.front();
+      SW().queue.pop_front();
+    }
+    g_err[0] = 0;
+    if (job->ready) (void)hipStreamWaitEvent(SW().stream, job->ready, 0);
+    const int rc = store_build_now(*job, SW().stream);
+    {
+      std::lock_guard<std::mutex> lk(SW().mu);
+      job->rc = rc;
+      if (rc) snprintf(job->err, sizeof(job->err), "%s", mpg_last_error_cstr());
+      job->done = true;
+      SW().pending.erase(job->key);
+    }
+    SW().cv.notify_all();
+  }
+}
+
+static int store_worker_start(int device) {   // mpg_init's helper thread starts it; a Store that comes first starts it itself
+  std::lock_guard<std::mutex> lk(SW().start_mu);
+  if (SW().thread) return MPG_SUCCESS;
+  MPG_HIP(hipStreamCreateWithFlags(&SW().stream, hipStreamNonBlocking));
+  SW().stop = false;
+  SW().thread = new std::thread(store_worker_main, device);
+  return MPG_SUCCESS;
+}
+
+static void store_worker_drain() {
+  std::unique_lock<std::mutex> lk(SW().mu);
+  SW().cv.wait(lk, [] { return SW().pending.empty(); });
+}
+
+static void store_worker_stop() {   // mpg_finalize
+  if (!SW().thread) return;
+  store_worker_drain();
+  {
+    std::lock_guard<std::mutex> lk(SW().mu);
+    SW().stop = true;
+  }
+  SW().cv.notify_all();
+  SW().thread->join();
+  delete SW().thread;
+  SW().thread = nullptr;
+  (void)hipStreamDestroy(SW().stream);
+  SW().stream = nullptr;
+}
+
+// out == nullptr: start the Store and return (mpg_regrid_store[_grid]_begin); else return the handle, waiting for its Store
+static int store_common(HandleKey key, mpg_handle *out, int (*build)(mpg_handle_s *, void *, hipStream_t), const StoreCtx &ctx) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    {
+      CACHE_LOCK();
+      auto it = g_cache.find(key);
+      if (it != g_cache.end()) {   // in use elsewhere, or parked by an earlier release / a finished _begin: the same weights, no device work
+        if (out) {
+          it->second->refcount++;
+          *out = it->second;
+        }
+        return MPG_SUCCESS;
+      }
+    }
+    int rc = store_worker_start(g_device);
+    if (rc) return rc;
+    std::shared_ptr<StoreJob> job;
+    {
+      std::unique_lock<std::mutex> lk(SW().mu);
+      auto pit = SW().pending.find(key);
+      if (pit != SW().pending.end()) {
+        job = pit->second;
+      } else {
+        job = std::make_shared<StoreJob>();
+        job->key = key;
+        job->build = build;
+        job->ctx = ctx;
+        if (hipEventCreateWithFlags(&job->ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(job->ready, g_stream);
+        SW().pending[key] = job;
+        SW().queue.push_back(job);
+      }
+      if (!out) {
+        lk.unlock();
+        SW().cv.notify_all();
+        return MPG_SUCCESS;
+      }
+      SW().cv.notify_all();
+      SW().cv.wait(lk, [&] { return job->done; });
+    }
+    if (job->rc) {
+      mpg_set_error("%s", job->err);
+      return job->rc;
+    }
+    // finished: the handle is in the cache now (unless a flood of releases has pushed it out again: then once more)
+  }
+  mpg_set_error("RegridStore: the finished handle left the cache before it was collected");
+  return MPG_ERR_HIP;
+}
+
+static int store_mesh_build(mpg_handle_s *h, void *c, hipStream_t s) {
+  StoreCtx *x = (StoreCtx *)c;
+  h->method = x->method;
+  int rc;
+  if (x->method == MPG_REGRIDMETHOD_BILINEAR) rc = mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, x->meshloc, h, s);
+  else if (x->method == MPG_REGRIDMETHOD_NEAREST_STOD) rc = mpg_k_store_nearest(x->m, x->g, x->stagger, h, s);
+  else rc = mpg_k_store_conserve(x->m, x->g, h, s);
+  if (!rc && x->m->win_count[x->meshloc] >= 0)    // the mesh's sources are windowed: index relative to the window from the start
+    rc = mpg_k_rebase(h, x->m->win_first[x->meshloc], x->m->win_count[x->meshloc], s, true);
+  return rc;
+}
+static int store_grid_build(mpg_handle_s *h, void *c, hipStream_t s) {
+  StoreCtx *x = (StoreCtx *)c;
+  h->method = x->method;
+  return mpg_k_store_grid_bilinear(x->g, x->stagger, h, s);
+}
+
+static int store_mesh_entry(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod, mpg_handle *out, const char *who) {
   MPG_CHECK_INIT();
-  MPG_ARG(src && dst && out, "mpg_regrid_store: NULL argument");
+  MPG_ARG(src && dst, "mpg_regrid_store: NULL argument");
   MPG_ARG(dst_staggerloc >= 0 && dst_staggerloc <= 2, "mpg_regrid_store: destination stagger must be CENTER, EDGE1 or EDGE2");
   MPG_ARG(src_meshloc == MPG_MESHLOC_ELEMENT || src_meshloc == MPG_MESHLOC_NODE, "mpg_regrid_store: unknown mesh location");
   if (src_meshloc == MPG_MESHLOC_NODE && regridmethod != MPG_REGRIDMETHOD_BILINEAR) {
-    mpg_set_error("mpg_regrid_store: node-located sources are only regridded bilinearly by the reference (interp.F90:350-366)");
+    mpg_set_error("%s: node-located sources are only regridded bilinearly by the reference (interp.F90:350-366)", who);
     return MPG_ERR_UNSUPPORTED;
   }
   MPG_ARG(regridmethod >= 0 && regridmethod <= 2, "mpg_regrid_store: unknown regrid method");
   if (src->geo_grid && (src->geo_grid != dst || src->geo_grid_gone)) {
-    mpg_set_error("mpg_regrid_store: the mesh was cut to another grid (mpg_mesh_create_window%s); it holds only the cells that grid can see",
+    mpg_set_error("%s: the mesh was cut to another grid (mpg_mesh_create_window%s); it holds only the cells that grid can see", who,
                   src->geo_grid_gone ? ", which has been destroyed" : "");
     return MPG_ERR_INVALID_ARG;
   }
   if (regridmethod == MPG_REGRIDMETHOD_CONSERVE && dst_staggerloc != MPG_STAGGERLOC_CENTER) {
-    mpg_set_error("mpg_regrid_store: conservative regridding is defined on the CENTER stagger only");
+    mpg_set_error("%s: conservative regridding is defined on the CENTER stagger only", who);
     return MPG_ERR_UNSUPPORTED;
   }
   StoreCtx ctx{src, dst, dst_staggerloc, regridmethod, src_meshloc};
   // the line type in force is part of what a bilinear handle IS: the two never share a cache entry
   HandleKey key(src, src_meshloc, dst, dst_staggerloc, regridmethod + (regridmethod == MPG_REGRIDMETHOD_BILINEAR ? 16 * mpg_bilinear_linetype() : 0));
-  return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
-    StoreCtx *x = (StoreCtx *)c;
-    h->method = x->method;
-    int rc;
-    if (x->method == MPG_REGRIDMETHOD_BILINEAR) rc = mpg_k_store_bilinear_mesh(x->m, x->g, x->stagger, x->meshloc, h, g_stream);
-    else if (x->method == MPG_REGRIDMETHOD_NEAREST_STOD) rc = mpg_k_store_nearest(x->m, x->g, x->stagger, h, g_stream);
-    else rc = mpg_k_store_conserve(x->m, x->g, h, g_stream);
-    if (!rc && x->m->win_count[x->meshloc] >= 0)    // the mesh's sources are windowed: index relative to the window from the start
-      rc = mpg_k_rebase(h, x->m->win_first[x->meshloc], x->m->win_count[x->meshloc], g_stream, true);
-    return rc;
-  }, &ctx);
+  return store_common(key, out, store_mesh_build, ctx);
+}
+
+int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+  MPG_ARG(out, "mpg_regrid_store: NULL argument");
+  return store_mesh_entry(src, src_meshloc, dst, dst_staggerloc, regridmethod, out, "mpg_regrid_store");
+}
+int mpg_regrid_store_begin(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod) {
+  return store_mesh_entry(src, src_meshloc, dst, dst_staggerloc, regridmethod, nullptr, "mpg_regrid_store_begin");
 }
 
 // ---- source window of a mesh (a host that holds only the cells its target rows reference) ---------------------------------
@@ -656,6 +834,8 @@ int mpg_mesh_set_source_window(mpg_mesh m, int meshloc, int64_t first, int64_t c
   const int64_t n_all = meshloc == MPG_MESHLOC_ELEMENT ? m->nCells : m->nVertices;
   MPG_ARG(first >= 0 && count >= 0 && first + count <= n_all, "mpg_mesh_set_source_window: the window must lie inside the mesh");
   const int64_t old_first = m->win_count[meshloc] >= 0 ? m->win_first[meshloc] : 0;
+  store_worker_drain();
+  CACHE_LOCK();
   struct Busy { Busy() { g_cache_busy = true; } ~Busy() { g_cache_busy = false; } } busy;
   // every handle of this mesh and location that exists already (in use or parked) moves to the new window -- after ALL of
   // them have been checked: one that references a source outside it fails the call and nothing has changed
@@ -684,9 +864,9 @@ int mpg_mesh_set_source_window(mpg_mesh m, int meshloc, int64_t first, int64_t c
   return MPG_SUCCESS;
 }
 
-int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+static int store_grid_entry(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {
   MPG_CHECK_INIT();
-  MPG_ARG(grid && out, "mpg_regrid_store_grid: NULL argument");
+  MPG_ARG(grid, "mpg_regrid_store_grid: NULL argument");
   if (src_staggerloc != MPG_STAGGERLOC_CENTER || (dst_staggerloc != MPG_STAGGERLOC_EDGE1 && dst_staggerloc != MPG_STAGGERLOC_EDGE2) ||
       regridmethod != MPG_REGRIDMETHOD_BILINEAR) {
     mpg_set_error("mpg_regrid_store_grid: only bilinear CENTER -> EDGE1/EDGE2 is used by the reference (interp.F90:298,316)");
@@ -694,15 +874,19 @@ int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc,
   }
   StoreCtx ctx{nullptr, grid, dst_staggerloc, regridmethod, 0};
   HandleKey key(grid, 100 + src_staggerloc, grid, dst_staggerloc, regridmethod);
-  return store_common(key, out, [](mpg_handle_s *h, void *c) -> int {
-    StoreCtx *x = (StoreCtx *)c;
-    h->method = x->method;
-    return mpg_k_store_grid_bilinear(x->g, x->stagger, h, g_stream);
-  }, &ctx);
+  return store_common(key, out, store_grid_build, ctx);
+}
+int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+  MPG_ARG(out, "mpg_regrid_store_grid: NULL argument");
+  return store_grid_entry(grid, src_staggerloc, dst_staggerloc, regridmethod, out);
+}
+int mpg_regrid_store_grid_begin(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod) {
+  return store_grid_entry(grid, src_staggerloc, dst_staggerloc, regridmethod, nullptr);
 }
 
 int mpg_handle_release(mpg_handle h) {
   if (!h) return MPG_SUCCESS;
+  CACHE_LOCK();
   if (--h->refcount > 0) return MPG_SUCCESS;
   if (!h->cached) {
     handle_free(h);
@@ -1067,6 +1251,7 @@ int mpg_handle_localize(mpg_handle h) {
   MPG_NOT_WINDOWED(h, "mpg_handle_localize");
   // a localized handle no longer matches its cache key: detach it
   if (h->cached) {
+    CACHE_LOCK();
     g_cache.erase(h->key);
     h->cached = false;
   }
@@ -1085,6 +1270,7 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
   MPG_ARG(base >= 0 && n_local >= 0 && n_local < 0x7fffffff, "mpg_handle_rebase: bad range");
   MPG_NOT_WINDOWED(h, "mpg_handle_rebase");
   if (h->cached) {
+    CACHE_LOCK();
     g_cache.erase(h->key);
     h->cached = false;
   }

@@ -84,13 +84,35 @@ module interp
   private
   public :: interp_data
   type(c_ptr) :: cosa_dev = c_null_ptr, sina_dev = c_null_ptr
+  logical :: rotang_owned = .false.     ! cosa_dev / sina_dev were allocated here (not the grid's own arrays)
 
 contains
 
   subroutine interp_data()
+    call begin_stores()
     if (interp_diag) call interp_diag_data()
     if (interp_hist) call interp_hist_data()
   end subroutine interp_data
+
+  !> Every RegridStore of the run (interp.F90:123, 207-437) started now, in the order of use, on the library's worker thread: the
+  !! reference stores each weight set in front of the Regrids that use it; they are independent, so the conservative, nearest and
+  !! destaggering weights build while the bilinear Regrids are running.  The Store calls further down collect them (same weights).
+  subroutine begin_stores()
+    if (.not. (interp_diag .or. interp_hist)) return
+    call mpg_check(mpg_regrid_store_begin(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_BILINEAR), &
+                   "IN FieldBundleRegridStore (begin)")
+    if (.not. interp_hist) return
+    if (do_u_interp == 1) call mpg_check(mpg_regrid_store_grid_begin(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, &
+                                                                      MPG_REGRIDMETHOD_BILINEAR), "IN FieldRegridStore (begin)")
+    if (do_v_interp == 1) call mpg_check(mpg_regrid_store_grid_begin(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE2, &
+                                                                      MPG_REGRIDMETHOD_BILINEAR), "IN FieldRegridStore (begin)")
+    if (hist_3d_vert%n > 0) call mpg_check(mpg_regrid_store_begin(input_grid, MPG_MESHLOC_NODE, target_grid_h, MPG_STAGGERLOC_CENTER, &
+                                                                   MPG_REGRIDMETHOD_BILINEAR), "IN FieldBundleRegridStore (begin)")
+    if (hist_2d_cons%n > 0) call mpg_check(mpg_regrid_store_begin(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, &
+                                                                   MPG_REGRIDMETHOD_CONSERVE), "IN FieldBundleRegridStore (begin)")
+    if (hist_2d_nstd%n > 0) call mpg_check(mpg_regrid_store_begin(input_grid, MPG_MESHLOC_ELEMENT, target_grid_h, MPG_STAGGERLOC_CENTER, &
+                                                                   MPG_REGRIDMETHOD_NEAREST_STOD), "IN FieldBundleRegridStore (begin)")
+  end subroutine begin_stores
 
   !> ESMF_FieldBundleRegrid: every field of the bundle through one route handle.
   !! 3-D sources arrive in MPAS file order (level fastest): the GPU kernel fuses the transpose the reference
@@ -358,6 +380,26 @@ contains
     if (have_nstd) call mpg_check(mpg_handle_release(rh_nstd), "IN FieldRegridRelease")
   end subroutine interp_hist_data
 
+  !> cos / sin(alpha) of this image's row block on the device: the grid's own arrays when mpg_grid_create_proj built it there (one
+  !! image, grid from the namelist's projection: no upload at all), else uploaded once from the host's copies
+  subroutine rotang_on_device()
+    integer(c_int64_t) :: npts
+    type(c_ptr) :: ca, sa
+    if (c_associated(cosa_dev)) return
+    if (ny_ext == j_target) then
+      if (mpg_grid_rotang_dev(target_grid_h, ca, sa) == MPG_SUCCESS) then
+        cosa_dev = ca; sina_dev = sa; rotang_owned = .false.
+        return
+      end if
+    end if
+    npts = int(i_target, c_int64_t)*int(ny_ext, c_int64_t)  ! this image's row block (all rows with one image)
+    call mpg_check(mpg_dev_alloc(npts*8, cosa_dev), "IN dev_alloc")
+    call mpg_check(mpg_dev_alloc(npts*8, sina_dev), "IN dev_alloc")
+    call mpg_check(mpg_dev_upload(cosa_dev, cosa(:, je_lo:je_hi), npts*8), "IN dev_upload")
+    call mpg_check(mpg_dev_upload(sina_dev, sina(:, je_lo:je_hi), npts*8), "IN dev_upload")
+    rotang_owned = .true.
+  end subroutine rotang_on_device
+
   !> interp.F90:291-328 on device-resident mass winds: rotate_winds_cgrid (PROJ_LC, both components) and the two Grid -> Grid
   !! Store / Regrid pairs as one kernel pass; U / V come out as the file stores them (NF90_FLOAT, big-endian), bit-identical to
   !! the three calls.  .false.: the library does not take this pair of handles -- nothing has been done.
@@ -385,13 +427,7 @@ contains
                      "IN FieldRegridStore")
     end if
     if (rot) then
-      npts = int(i_target, c_int64_t)*int(ny_ext, c_int64_t)
-      if (.not. c_associated(cosa_dev)) then                    ! the rotation angles go up once
-        call mpg_check(mpg_dev_alloc(npts*8, cosa_dev), "IN dev_alloc")
-        call mpg_check(mpg_dev_alloc(npts*8, sina_dev), "IN dev_alloc")
-        call mpg_check(mpg_dev_upload(cosa_dev, cosa(:, je_lo:je_hi), npts*8), "IN dev_upload")
-        call mpg_check(mpg_dev_upload(sina_dev, sina(:, je_lo:je_hi), npts*8), "IN dev_upload")
-      end if
+      call rotang_on_device()
       ca = cosa_dev; sa = sina_dev
     end if
     if (do_u_interp == 1) then
@@ -466,12 +502,7 @@ contains
     integer(c_int64_t) :: npts
     if (dev_flow) then
       npts = int(i_target, c_int64_t)*int(ny_ext, c_int64_t)  ! this image's row block (all rows with one image)
-      if (.not. c_associated(cosa_dev)) then                    ! the rotation angles go up once
-        call mpg_check(mpg_dev_alloc(npts*8, cosa_dev), "IN dev_alloc")
-        call mpg_check(mpg_dev_alloc(npts*8, sina_dev), "IN dev_alloc")
-        call mpg_check(mpg_dev_upload(cosa_dev, cosa(:, je_lo:je_hi), npts*8), "IN dev_upload")
-        call mpg_check(mpg_dev_upload(sina_dev, sina(:, je_lo:je_hi), npts*8), "IN dev_upload")
-      end if
+      call rotang_on_device()
       call mpg_check(mpg_rotate_winds_dev(npts, int(u%nlev, c_int), cosa_dev, sina_dev, u%dst_dev, v%dst_dev, c_null_ptr), &
                      "IN rotate_winds_cgrid")
       return

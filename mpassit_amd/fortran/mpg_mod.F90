@@ -131,6 +131,20 @@ module mpg
       integer(c_int) :: rc
     end function mpg_regrid_store_grid
 
+    !> the two Stores STARTED on the library's worker thread (include/mpassit_amd.h): the matching mpg_regrid_store[_grid] collects them
+    function mpg_regrid_store_begin(src, src_meshloc, dst, dst_staggerloc, regridmethod) bind(C, name="mpg_regrid_store_begin") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: src, dst
+      integer(c_int), value :: src_meshloc, dst_staggerloc, regridmethod
+      integer(c_int) :: rc
+    end function mpg_regrid_store_begin
+    function mpg_regrid_store_grid_begin(grid, src_staggerloc, dst_staggerloc, regridmethod) bind(C, name="mpg_regrid_store_grid_begin") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: grid
+      integer(c_int), value :: src_staggerloc, dst_staggerloc, regridmethod
+      integer(c_int) :: rc
+    end function mpg_regrid_store_grid_begin
+
     function mpg_regrid(rh, src, src_layout, nlev, nfields, dst) bind(C, name="mpg_regrid") result(rc)
       import :: c_int, c_double, c_ptr
       type(c_ptr), value :: rh
@@ -423,6 +437,13 @@ module mpg
       real(c_double), intent(out) :: cosa(*), sina(*)
       integer(c_int) :: rc
     end function mpg_grid_get_rotang
+    !> cos / sin(alpha) where mpg_grid_create_proj computed them: device pointers owned by the grid ([ny][nx], CENTER)
+    function mpg_grid_rotang_dev(grid, cosa_dev, sina_dev) bind(C, name="mpg_grid_rotang_dev") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: grid
+      type(c_ptr), intent(out) :: cosa_dev, sina_dev
+      integer(c_int) :: rc
+    end function mpg_grid_rotang_dev
 
     function mpg_grid_get_mapfac(grid, staggerloc, mapfac) bind(C, name="mpg_grid_get_mapfac") result(rc)
       import :: c_int, c_ptr, c_double

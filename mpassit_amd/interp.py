@@ -44,6 +44,7 @@ class InterpConfig:
     hist_2d: list = field(default_factory=list)
     hist_3d: list = field(default_factory=list)
     hist_soil: list = field(default_factory=list)
+    overlap_stores: bool = True       # start every Store of the run on the library's worker thread before the first Regrid (mpg_regrid_store_begin)
     keep_mass_winds: bool = False     # also return UMASS / VMASS (u/v_target_grid_nostag): intermediates the reference never writes
     fused_winds: bool = True          # device-resident fields: rotation + both destaggerings in one pass (mpg_wind_destagger_dev)
 
@@ -91,9 +92,15 @@ def _bundle_regrid(rh, arrs, nlev, layout):
     return [out[i] for i in range(len(arrs))]
 
 
-def _rot_angles_dev(target, device):
-    """cosalpha / sinalpha of the CENTER stagger as device tensors, uploaded once per target grid, not once per call."""
+def _rot_angles_dev(target, device, grid=None):
+    """cosalpha / sinalpha of the CENTER stagger on the device: the grid's own arrays when it was built from its projection on the device
+    (mpg_grid_create_proj computed them there), else device tensors uploaded once per target grid, not once per call."""
     import torch
+    if grid is not None and getattr(grid, "built_from_proj", False) is True and grid.ny * grid.nx == int(np.size(target.cosa)):
+        dev = getattr(grid, "_rot_dev", None)
+        if dev is None:
+            dev = grid._rot_dev = grid.rotang_dev()
+        return dev
     cosa = target.cosa
     dev = getattr(target, "_rot_dev", None)
     if dev is None or dev[0].device != device or dev[2] is not cosa:
@@ -102,11 +109,11 @@ def _rot_angles_dev(target, device):
     return dev[0], dev[1]
 
 
-def rotate_winds_cgrid(target, u, v):
+def rotate_winds_cgrid(target, u, v, grid=None):
     """In place earth -> grid-relative rotation with cosalpha/sinalpha of the CENTER stagger."""
     cosa, sina = target.cosa, target.sina
     if _is_torch(u):
-        cosa, sina = _rot_angles_dev(target, u.device)
+        cosa, sina = _rot_angles_dev(target, u.device, grid)
     return R.rotate_winds_cgrid(cosa, sina, u, v)
 
 
@@ -125,7 +132,7 @@ def interp_diag_data(mesh, grid, target, inp, cfg, out):
     iu, iv = F.diag_wind_indices(cfg.diag_list)
     if iu is not None and iv is not None and cfg.proj_is_lambert:     # interp.F90:138-140
         tu, tv = cfg.diag_list[iu][1], cfg.diag_list[iv][1]
-        rotate_winds_cgrid(target, out[tu], out[tv])
+        rotate_winds_cgrid(target, out[tu], out[tv], grid)
 
 
 def _destagger_local(grid, staggerloc, mass, nz):
@@ -149,7 +156,7 @@ def _wind_chain_fused(grid, target, cfg, um, vm, rot, nz, out, destagger):
     rh_u = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1) if um is not None else None      # :298
     rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2) if vm is not None else None      # :316
     try:
-        cosa, sina = _rot_angles_dev(target, ref.device) if rot else (None, None)
+        cosa, sina = _rot_angles_dev(target, ref.device, grid) if rot else (None, None)
         try:
             u, v, ur, vr = R.wind_destagger(rh_u, rh_v, cosa, sina, um, vm, nz, keep_mass=cfg.keep_mass_winds)
         except R.L.MpgError as e:
@@ -191,7 +198,7 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
     if um is not None or vm is not None:
         if not _wind_chain_fused(grid, target, cfg, um, vm, rot, inp.nz, out, destagger):
             if rot:
-                rotate_winds_cgrid(target, um, vm)                    # :291-293
+                rotate_winds_cgrid(target, um, vm, grid)              # :291-293
             ds = destagger or _destagger_local
             if um is not None:
                 out["U"] = ds(grid, R.STAGGERLOC_EDGE1, um, inp.nz)   # :295-311  UMASS(CENTER) -> U(EDGE1)
@@ -230,10 +237,35 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
         rh_nstd.release()
 
 
+def begin_stores(mesh, grid, cfg, local_destagger=True):
+    """Every RegridStore interp_data will ask for (interp.F90:123, 207-437), started now in the order of use on the library's worker
+    thread: the reference stores each weight set in front of the Regrids that use it, one after the other; they are independent, so
+    the conservative / nearest / destaggering / node-located Stores build while the bilinear Regrids are already running.  The
+    regrid_store calls below collect them; the weights are the same."""
+    h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars) if cfg.interp_hist else None
+    if (cfg.interp_diag and cfg.diag_list) or h is not None:
+        R.regrid_store_begin(mesh, grid, R.REGRIDMETHOD_BILINEAR)
+    if h is None:
+        return
+    if local_destagger:
+        if h.do_u_interp:
+            R.regrid_store_grid_begin(grid, R.STAGGERLOC_EDGE1)
+        if h.do_v_interp:
+            R.regrid_store_grid_begin(grid, R.STAGGERLOC_EDGE2)
+    if h.vert_3d:
+        R.regrid_store_begin(mesh, grid, R.REGRIDMETHOD_BILINEAR, meshloc=R.MESHLOC_NODE)
+    if h.cons_2d:
+        R.regrid_store_begin(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    if h.nstd_2d:
+        R.regrid_store_begin(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+
+
 def interp_data(mesh, grid, target, inp, cfg, destagger=None):
     """-> dict target_name -> array ([ny][nx], [nlev][ny][nx]; U on EDGE1, V on EDGE2).
     `destagger` lets the row-sharded driver (dist.ShardedInterp) supply the CENTER -> EDGE step with its row halo."""
     out = {}
+    if cfg.overlap_stores:
+        begin_stores(mesh, grid, cfg, local_destagger=destagger is None)
     if cfg.interp_diag:
         interp_diag_data(mesh, grid, target, inp, cfg, out)
     if cfg.interp_hist:
