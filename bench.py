@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip production_path / store / job / cell_numbering / end_to_end_pcie")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--calib", action="store_true", help="also launch a known-byte-count streaming kernel (PMC calibration)")
-    ap.add_argument("--leg", default=None, choices=["job", "store"],
+    ap.add_argument("--leg", default=None, choices=["job", "store", "c3"],
                     help="internal: run only this leg in THIS (fresh) process and print its JSON object -- the default run starts one "
                          "child process per leg so that its first-call numbers are first-in-process ones")
     ap.add_argument("--ownership", default="auto", choices=["auto", "aligned", "para_range", "need"],
@@ -134,6 +134,8 @@ def run_leg(args):
     if args.leg == "store":
         m, g, _, _ = workloads.workload(args.workload)
         res = store_leg(R, m, g)
+    elif args.leg == "c3":
+        res = c3_leg(torch, R, workloads, dev)
     else:
         res = job_leg(torch, R, workloads, args, dev)
     if res is not None:
@@ -502,7 +504,7 @@ def main():
     if extras and args.workload == "c4_3m_regional" and not io32:
         numbering = realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, sr.rh)
     # what the shipped Fortran driver runs: float32 as the MPAS / WRF files hold it, MPAS file order, either byte order
-    production = store = job = None
+    production = store = job = c3 = None
     if extras and not io32 and layout == R.LAYOUT_CELL_FAST:
         production = production_path_leg(torch, R, args, F, nlev, dev, sr, local, U_hint=sr.n_needed)
         del out, local, src_for_kernel, own
@@ -510,6 +512,7 @@ def main():
         torch.cuda.empty_cache()
         store = fresh_process_leg("store", args)      # one fresh child process per leg: first-in-process numbers
         job = fresh_process_leg("job", args) if args.workload == "c4_3m_regional" else None
+        c3 = fresh_process_leg("c3", args) if args.workload == "c4_3m_regional" else None
 
     if rank == 0:
         fields_per_s = F * args.steps / dt
@@ -532,6 +535,9 @@ def main():
                         store_mpg_init_ms=store.get("mpg_init_ms"))
             for k, v in st.items():
                 flat["store_%s_first_ms" % k] = round(v["ms_first"], 3)
+        if c3 and "error" not in c3:   # BASELINE configs[2]: conservative snow fields + nearest soil on the 655 k mesh
+            flat.update({k: c3[k] for k in ("c3_conserve_ms", "c3_conserve_frac", "c3_nearest_soil_ms", "c3_nearest_soil_frac", "c3_store_conserve_first_ms",
+                                            "c3_store_nearest_first_ms", "c3_job_cold_first_ms", "c3_job_warm_ms", "c3_job_warm_frac")})
         if traffic:
             flat["traffic_ratio"] = round(traffic / alg_bytes, 3)
         rec = {
@@ -553,6 +559,7 @@ def main():
             "production_path": production,
             "store": store,
             "job": job,
+            "c3": c3,
             "cell_numbering": numbering,
             "halo": halo,
             "store_ms": primary.store_ms,
@@ -768,6 +775,90 @@ def job_leg(torch, R, workloads, args, dev):
             "geometry_first_ms": round(geom[0], 3), "geometry_ms": round(min(geom), 3),
             "alg_bytes_warm": alg_warm, "frac_warm": round(alg_warm / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "fields_3d_per_s_cold_first": n3d / (cold[0][0] * 1e-3), "fields_3d_per_s_warm": n3d / (warm_ms * 1e-3)}
+
+
+def c3_leg(torch, R, workloads, dev):
+    """BASELINE configs[2]: the 655 362-cell global mesh under the README's Lambert grid with the snow fields regridded conservatively
+    (interp.F90:368-416), the soil bundle through the nearest-neighbour weights (the method set last, :436-447) and the
+    rest of histlist_2d / 3d bilinearly -- device-resident float32 fields in MPAS file order, as the driver holds them.
+    c3_conserve_* : one Regrid of the {snow, snowh} bundle through the CSR handle; c3_nearest_soil_*: one Regrid of the 3 x nsoil soil bundle;
+    algorithmic bytes per SURVEY s8(d): U * L * e_src + P * L * e_dst per field + the handle's indices and weights once per call
+    (CSR: nnz * 12 + (P + 1) * 4; nearest: P * 4).  c3_job_*: the whole interp_hist_data of the configuration, first-in-process cold
+    and warm, fraction from the accounted bytes of its Regrids as in the `job` leg.  Store times are first-in-process."""
+    from mpassit_amd import interp as I
+    m, g, nz, desc = workloads.workload("c2_655k_global", arrays=False)
+    nsoil = 4
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20240807)
+
+    def f2():
+        return torch.rand(m.nCells, dtype=torch.float32, device=dev, generator=gen)
+
+    def f3(L):
+        return torch.rand((m.nCells, L), dtype=torch.float32, device=dev, generator=gen)
+    inp = I.InputData(nz=nz, nzp1=nz + 1, nsoil=nsoil, hgt=torch.rand(m.nCells, dtype=torch.float64, device=dev, generator=gen), layout=R.LAYOUT_LEV_FAST)
+    for n, _ in workloads.JOB_HIST_2D:
+        inp.hist[n] = torch.floor(f2() * 3) if n == "xland" else f2()
+    for n, _ in workloads.JOB_HIST_3D:
+        inp.hist[n] = f3(nz + 1 if n in ("zgrid", "w") else nz)
+    for n, _ in workloads.JOB_SOIL:
+        inp.hist[n] = f3(nsoil)
+    cfg = I.InterpConfig(interp_diag=False, wrf_mod_vars=True, hist_2d=workloads.JOB_HIST_2D, hist_3d=workloads.JOB_HIST_3D, hist_soil=workloads.JOB_SOIL)
+    mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_proj(g)
+    torch.cuda.synchronize()
+    # the whole configuration first: its Stores and first calls are the process's first
+    times = []
+    for k in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = I.interp_data(mesh, grid, g, inp, cfg)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        n3d = sum(1 for v in out.values() if v.ndim == 3 and v.shape[0] >= nz)
+        del out
+    R.ACCOUNT = []
+    out = I.interp_data(mesh, grid, g, inp, cfg)
+    torch.cuda.synchronize()
+    alg_warm = float(sum(b for _, b in R.ACCOUNT))
+    R.ACCOUNT = None
+    del out
+    res = {"workload": "c3: " + desc + "; conservative snow / snowh, nearest soil (nsoil %d)" % nsoil, "fields_3d": n3d,
+           "c3_job_cold_first_ms": round(times[0], 3), "c3_job_warm_ms": round(min(times[1:]), 3),
+           "c3_job_warm_frac": round(alg_warm / (min(times[1:]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_warm": alg_warm}
+    rh_c = R.regrid_store(mesh, grid, R.REGRIDMETHOD_CONSERVE)
+    rh_n = R.regrid_store(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
+    res["c3_store_conserve_first_ms"], res["c3_store_nearest_first_ms"] = round(rh_c.store_ms, 3), round(rh_n.store_ms, 3)
+    P = rh_c.n_dst
+
+    def timed(fn, reps=30):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    snow = [inp.hist["snow"], inp.hist["snowh"]]
+    outs_c = [torch.empty((1, g.ny, g.nx), dtype=torch.float64, device=dev) for _ in snow]
+    ms_c = timed(lambda: rh_c.regrid_bundle(snow, nlev=1, layout=R.LAYOUT_CELL_FAST, out_dtype=torch.float64, outs=outs_c))
+    U_c = int(rh_c.unique_sources().size)
+    alg_c = len(snow) * (U_c * 4.0 + P * 8.0) + rh_c.nnz * 12.0 + (P + 1) * 4.0
+    soil = [inp.hist[n].reshape(-1) for n, _ in workloads.JOB_SOIL]
+    outs_n = [torch.empty((nsoil, g.ny, g.nx), dtype=torch.float64, device=dev) for _ in soil]
+    ms_n = timed(lambda: rh_n.regrid_bundle(soil, nlev=nsoil, layout=R.LAYOUT_LEV_FAST, out_dtype=torch.float64, outs=outs_n))
+    U_n = int(rh_n.unique_sources().size)
+    alg_n = len(soil) * nsoil * (U_n * 4.0 + P * 8.0) + P * 4.0
+    res.update(c3_conserve_ms=round(ms_c, 4), c3_conserve_frac=round(alg_c / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), c3_conserve_alg_bytes=alg_c,
+               c3_conserve_nnz=int(rh_c.nnz), c3_conserve_unique_src=U_c,
+               c3_nearest_soil_ms=round(ms_n, 4), c3_nearest_soil_frac=round(alg_n / (ms_n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), c3_nearest_soil_alg_bytes=alg_n,
+               c3_nearest_unique_src=U_n)
+    rh_c.release()
+    rh_n.release()
+    mesh.destroy()
+    grid.destroy()
+    return res
 
 
 def cpu_baseline(sr, local_rows, nlev, seconds, m, g):

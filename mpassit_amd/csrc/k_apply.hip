@@ -162,70 +162,75 @@ __global__ __launch_bounds__(512) void k_apply3_lf(const int32_t *__restrict__ i
 // k_apply3_lf_t: the capacity fallback)
 static int g_lf_variant = -1;
 
-// nearest neighbour: bit-exact copy
+// nearest neighbour (bit-exact copy), 4-point destagger and conservative CSR: one thread per target point.  LEVF (the source is in file
+// order, [cell][lev]) is a template parameter -- no per-level branch on the layout -- and the stores are non-temporal: a result is
+// written once and never read by this kernel, it must not push the gathered source lines out of L2 (round-5 review, item 6).
+template <bool LEVF>
 __global__ __launch_bounds__(256) void k_apply1(const int32_t *__restrict__ idx, const double *__restrict__ src,
-                                                double *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast,
-                                                int nblk) {
+                                                double *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int nblk) {
   unsigned blk = blockIdx.x % nblk;
   int fld = blockIdx.x / nblk;
   int64_t p = (int64_t)blk * 256 + threadIdx.x;
   if (p >= P) return;
   int32_t c = idx[p];
-  const double *sf = src + (int64_t)fld * nlev * nsrc;
-  double *df = dst + (int64_t)fld * nlev * P;
+  const double *sf = src + (int64_t)fld * nlev * nsrc + (c >= 0 ? (LEVF ? (int64_t)c * nlev : (int64_t)c) : 0);
+  const int64_t step = LEVF ? 1 : nsrc;
+  double *df = dst + (int64_t)fld * nlev * P + p;
   for (int k = 0; k < nlev; ++k) {
     double v = 0.0;
-    if (c >= 0) v = lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c];
-    df[(int64_t)k * P + p] = v;
+    if (c >= 0) v = sf[k * step];
+    __builtin_nontemporal_store(v, df + (int64_t)k * P);
   }
 }
 
-template <int NNZ>
+template <int NNZ, bool LEVF>
 __global__ __launch_bounds__(256) void k_applyN(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                 const double *__restrict__ src, double *__restrict__ dst, int64_t P,
-                                                int64_t nsrc, int nlev, int lev_fast, int nblk) {
+                                                int64_t nsrc, int nlev, int nblk) {
   unsigned blk = blockIdx.x % nblk;
   int fld = blockIdx.x / nblk;
   int64_t p = (int64_t)blk * 256 + threadIdx.x;
   if (p >= P) return;
-  int32_t c[NNZ];
+  int64_t c[NNZ];
   double ww[NNZ];
 #pragma unroll
   for (int q = 0; q < NNZ; ++q) {
-    c[q] = idx[q * P + p];
+    const int32_t ci = idx[q * P + p];
+    c[q] = ci < 0 ? -1 : (LEVF ? (int64_t)ci * nlev : (int64_t)ci);
     ww[q] = w[q * P + p];
   }
   bool mapped = c[0] >= 0;
+  const int64_t step = LEVF ? 1 : nsrc;
   const double *sf = src + (int64_t)fld * nlev * nsrc;
-  double *df = dst + (int64_t)fld * nlev * P;
+  double *df = dst + (int64_t)fld * nlev * P + p;
   for (int k = 0; k < nlev; ++k) {
     double acc = 0.0;
     if (mapped) {
 #pragma unroll
-      for (int q = 0; q < NNZ; ++q) acc = fma(ww[q], (lev_fast ? sf[(int64_t)c[q] * nlev + k] : sf[(int64_t)k * nsrc + c[q]]), acc);
+      for (int q = 0; q < NNZ; ++q) acc = fma(ww[q], sf[c[q] + k * step], acc);
     }
-    df[(int64_t)k * P + p] = acc;
+    __builtin_nontemporal_store(acc, df + (int64_t)k * P);
   }
 }
 
+template <bool LEVF>
 __global__ __launch_bounds__(256) void k_apply_csr(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                    const double *__restrict__ val, const double *__restrict__ src,
-                                                   double *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast,
-                                                   int nblk) {
+                                                   double *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int nblk) {
   unsigned blk = blockIdx.x % nblk;
   int fld = blockIdx.x / nblk;
   int64_t p = (int64_t)blk * 256 + threadIdx.x;
   if (p >= P) return;
   int b = rowptr[p], e = rowptr[p + 1];
   const double *sf = src + (int64_t)fld * nlev * nsrc;
-  double *df = dst + (int64_t)fld * nlev * P;
+  double *df = dst + (int64_t)fld * nlev * P + p;
   for (int k = 0; k < nlev; ++k) {
     double acc = 0.0;
     for (int q = b; q < e; ++q) {
       int32_t c = col[q];
-      acc = fma(val[q], (lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c]), acc);
+      acc = fma(val[q], LEVF ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], acc);
     }
-    df[(int64_t)k * P + p] = acc;
+    __builtin_nontemporal_store(acc, df + (int64_t)k * P);
   }
 }
 
@@ -318,12 +323,16 @@ int mpg_k_apply(mpg_handle_s *h, const double *src, int layout, int nlev, int nf
     return MPG_SUCCESS;
   }
   int nblk = (int)((P + 255) / 256);
+  const bool levf = lev_fast && nlev > 1;   // (a single level is the same memory in both layouts)
   if (h->kind == MPG_KIND_CSR) {
-    k_apply_csr<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->rowptr.p, h->col.p, h->val.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
+    if (levf) k_apply_csr<true><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->rowptr.p, h->col.p, h->val.p, src, dst, P, h->n_src, nlev, nblk);
+    else k_apply_csr<false><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->rowptr.p, h->col.p, h->val.p, src, dst, P, h->n_src, nlev, nblk);
   } else if (h->nnz_per_row == 1) {
-    k_apply1<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
+    if (levf) k_apply1<true><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, src, dst, P, h->n_src, nlev, nblk);
+    else k_apply1<false><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, src, dst, P, h->n_src, nlev, nblk);
   } else if (h->nnz_per_row == 4) {
-    k_applyN<4><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, lev_fast, nblk);
+    if (levf) k_applyN<4, true><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, nblk);
+    else k_applyN<4, false><<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, nblk);
   } else if (h->nnz_per_row == 3 && lev_fast && nlev > 1) {
     int lfv = g_lf_variant;
     if (lfv < 0) {  // per handle, by the (sampled) reuse statistic of its tiles (k_apply_lfu.hip); short bundles: row gather

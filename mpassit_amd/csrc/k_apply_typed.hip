@@ -285,12 +285,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // nearest (NNZ = 1, weights implicit), 4-point destagger (NNZ = 4) and CSR (NNZ = 0): one thread per target point.  The
 // fixed forms keep the point's indices and weights in registers for all levels and work on two levels at a time (2 x NNZ
 // independent loads in flight); accumulation order per level as k_applyN / k_apply1 of k_apply.hip -> the same bits.
-template <typename TS, typename TD, bool SWZ, int NNZ>
+template <typename TS, typename TD, bool SWZ, int NNZ, bool LEVF>
 __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restrict__ idx, const double *__restrict__ w,
                                                          const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                          const double *__restrict__ val, const TS *__restrict__ src,
-                                                         TD *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int lev_fast, int nblk,
+                                                         TD *__restrict__ dst, int64_t P, int64_t nsrc, int nlev, int nblk,
                                                          double scale, double offset, int sbe, int dbe, FieldTab tab) {
+  constexpr bool lev_fast = LEVF;   // the layout is part of the instantiation: no per-level branch on it (round-5 review, item 6)
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
   unsigned blk = blockIdx.x % nblk;
   int fld = blockIdx.x / nblk;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
         int32_t c = col[q];
         acc = fma(val[q], (double)swz<SWZ>(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], zs), acc);
       }
-      df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(acc, scale, offset), zd);
+      __builtin_nontemporal_store(swz<SWZ>((TD)fma(acc, scale, offset), zd), df + (int64_t)k * P + p);
     }
   } else {
     int32_t c[NNZ];
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
     // share one in-order counter on gfx950, so a load issued after a store cannot be consumed before that store has been
     // acknowledged -- with the loads in front, a step waits for its own data only (s_waitcnt vmcnt(2): the two stores stay
     // in flight).
-    auto put = [&](int k, const double *v) { df[(int64_t)k * P + p] = swz<SWZ>((TD)fma(combine(v), scale, offset), zd); };
+    auto put = [&](int k, const double *v) { __builtin_nontemporal_store(swz<SWZ>((TD)fma(combine(v), scale, offset), zd), df + (int64_t)k * P + p); };
     double a0[NNZ], a1[NNZ];
     level(0, a0);
     level(nlev > 1 ? 1 : 0, a1);
@@ -407,13 +408,14 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
   } else {
     int nblk = (int)((P + 255) / 256);
     const int nnz = h->kind == MPG_KIND_CSR ? 0 : h->nnz_per_row;
-    auto fn = nnz == 0 ? k_apply_generic_t<TS, TD, SWZ, 0> : (nnz == 1 ? k_apply_generic_t<TS, TD, SWZ, 1> : k_apply_generic_t<TS, TD, SWZ, 4>);
     if (nnz != 0 && nnz != 1 && nnz != 4) {
       mpg_set_error("Regrid: unsupported handle (%d weights per row)", nnz);
       return MPG_ERR_UNSUPPORTED;
     }
+    auto fn = lev_fast ? (nnz == 0 ? k_apply_generic_t<TS, TD, SWZ, 0, true> : (nnz == 1 ? k_apply_generic_t<TS, TD, SWZ, 1, true> : k_apply_generic_t<TS, TD, SWZ, 4, true>))
+                       : (nnz == 0 ? k_apply_generic_t<TS, TD, SWZ, 0, false> : (nnz == 1 ? k_apply_generic_t<TS, TD, SWZ, 1, false> : k_apply_generic_t<TS, TD, SWZ, 4, false>));
     fn<<<(unsigned)nblk * nfields, 256, 0, s>>>(h->idx.p, h->w.p, h->rowptr.p, h->col.p, h->val.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev,
-                                               layout == MPG_LAYOUT_LEV_FAST, nblk, scale, offset, sbe, dbe, tab);
+                                               nblk, scale, offset, sbe, dbe, tab);
   }
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
