@@ -267,6 +267,10 @@ static int g_store_boxes = 1;
 int mpg_store_boxes() { return g_store_boxes; }
 static int g_bilinear_linetype = 0;
 int mpg_bilinear_linetype() { return g_bilinear_linetype; }
+static int g_node_fan_origin = 0;
+int mpg_node_fan_origin() { return g_node_fan_origin; }
+static int g_grid_inside_tol_exp = 10;
+int mpg_grid_inside_tol_exp() { return g_grid_inside_tol_exp; }
 int mpg_a3_staged() { return g_a3_staged; }
 int mpg_lf_variant() { return g_lf_variant; }
 
@@ -284,6 +288,16 @@ int mpg_k_tune(const char *key, int value) {
   if (!strcmp(key, "bilinear_linetype")) {   // Mesh -> Grid bilinear Store: where the target point meets the triangle's plane
     if (value != 0 && value != 1) return MPG_ERR_INVALID_ARG;
     g_bilinear_linetype = value;
+    return MPG_SUCCESS;
+  }
+  if (!strcmp(key, "node_fan_origin")) {   // node-located bilinear Store: which listed vertex of a polygon is the apex of its fan (-1: the last one)
+    if (value < -8 || value > 15) return MPG_ERR_INVALID_ARG;
+    g_node_fan_origin = value;
+    return MPG_SUCCESS;
+  }
+  if (!strcmp(key, "grid_inside_tol_exp")) {   // Grid -> Grid Store: a stagger point is inside a quad of centres within 10^-value of its parametric range
+    if (value < 3 || value > 16) return MPG_ERR_INVALID_ARG;
+    g_grid_inside_tol_exp = value;
     return MPG_SUCCESS;
   }
   if (!strcmp(key, "store_boxes")) {   // Stores on projection-built grids: candidates from the inverse projection (1) or the pyramid walk (0)

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_fill_i32(int64_t n, int32_t v, int32_t 
 // corners.  ESMF triangulates polygons with > 4 sides in an undocumented order; this build uses the fan from the
 // first listed vertex (triangle k of cell c = (v0, v_{k+1}, v_{k+2}), id = c*(maxEdges-2)+k) and the same
 // rasteriser as the element-located case, with vertex coordinates as the source points.
-__global__ __launch_bounds__(256) void k_fan_triangles(int64_t nCells, int maxEdges, const int32_t *__restrict__ voc,
+__global__ __launch_bounds__(256) void k_fan_triangles(int64_t nCells, int maxEdges, int origin, const int32_t *__restrict__ voc,
                                                        const double *__restrict__ vx, const double *__restrict__ vy,
                                                        const double *__restrict__ vz, int32_t *__restrict__ ftri) {
   int nf = maxEdges - 2;
@@ -273,16 +273,22 @@ __global__ __launch_bounds__(256) void k_fan_triangles(int64_t nCells, int maxEd
   if (t >= nFan) return;
   int64_t c = t / nf;
   int k = (int)(t % nf);
-  // k-th fan triangle uses the 1st, (k+2)-th and (k+3)-th non-zero entries of the cell's row
-  int32_t a = -1, b = -1, d = -1;
+  // the polygon's n listed (non-zero) vertices; apex = number (origin mod n) of them ("node_fan_origin": 0 the first, -1 the last),
+  // the k-th fan triangle takes the (k+1)-th and (k+2)-th after the apex in listed order, cyclically
   int n = 0;
-  for (int j = 0; j < maxEdges; ++j) {
-    int32_t x = voc[c * maxEdges + j];
-    if (x <= 0) continue;
-    if (n == 0) a = x - 1;
-    if (n == k + 1) b = x - 1;
-    if (n == k + 2) d = x - 1;
-    ++n;
+  for (int j = 0; j < maxEdges; ++j) n += voc[c * maxEdges + j] > 0;
+  int32_t a = -1, b = -1, d = -1;
+  if (k + 2 < n) {
+    const int o = ((origin % n) + n) % n, ib = (o + k + 1) % n, id = (o + k + 2) % n;
+    int m = 0;
+    for (int j = 0; j < maxEdges; ++j) {
+      int32_t x = voc[c * maxEdges + j];
+      if (x <= 0) continue;
+      if (m == o) a = x - 1;
+      if (m == ib) b = x - 1;
+      if (m == id) d = x - 1;
+      ++m;
+    }
   }
   if (d >= 0) {
     double det = det3_from(dv3{vx[a], vy[a], vz[a]}, dv3{vx[b], vy[b], vz[b]}, dv3{vx[d], vy[d], vz[d]});
@@ -311,9 +317,11 @@ int mpg_k_store_bilinear_mesh(mpg_mesh_s *m, mpg_grid_s *g, int stagger, int mes
       return MPG_ERR_OVERFLOW;
     }
     sx = m->vx_g(); sy = m->vy_g(); sz = m->vz_g();
-    if (!m->fan.p && nT > 0) {
-      if ((rc = m->fan.alloc(3 * (size_t)nT))) return rc;
-      k_fan_triangles<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(m->cwn, m->maxEdges, m->voc.p, sx, sy, sz, m->fan.p);
+    const int origin = mpg_node_fan_origin();
+    if ((!m->fan.p || m->fan_origin != origin) && nT > 0) {   // built once per mesh and apex rule
+      if (!m->fan.p && (rc = m->fan.alloc(3 * (size_t)nT))) return rc;
+      k_fan_triangles<<<(unsigned)((nT + 255) / 256), 256, 0, s>>>(m->cwn, m->maxEdges, origin, m->voc.p, sx, sy, sz, m->fan.p);
+      m->fan_origin = origin;
     }
     trip = m->fan.p;
   }

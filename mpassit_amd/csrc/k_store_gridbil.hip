@@ -9,6 +9,8 @@
 // No floating-point contraction in this translation unit (see k_store_conserve.hip): what it computes -- weights, coordinates --
 // is a function of the source text, not of which product the compiler chooses to fuse; explicit fma() calls stay what they are.
 #pragma clang fp contract(off)
+#include <math.h>
+
 #include "geom.h"
 #include "mpg_internal.h"
 
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void k_grid_bilinear(int nx, int ny, int stagg
                                                        const double *__restrict__ px, const double *__restrict__ py,
                                                        const double *__restrict__ pz, int32_t *__restrict__ idx,
                                                        double *__restrict__ w, int32_t *__restrict__ pole_dst,
-                                                       int32_t *__restrict__ pole_src0, double *__restrict__ pole_w) {
+                                                       int32_t *__restrict__ pole_src0, double *__restrict__ pole_w, double tol) {
   int nxd = stagger == MPG_STAGGERLOC_EDGE1 ? nx + 1 : nx, nyd = stagger == MPG_STAGGERLOC_EDGE2 ? ny + 1 : ny;
   int64_t P = (int64_t)nxd * nyd;
   int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k_grid_bilinear(int nx, int ny, int stagg
       int64_t iA = (int64_t)b * nx + a, iB = (int64_t)b * nx + a1, iC = iB + nx, iD = iA + nx;
       double xi, eta;
       if (!quad_solve(Pt, ld3(cx, cy, cz, iA), ld3(cx, cy, cz, iB), ld3(cx, cy, cz, iC), ld3(cx, cy, cz, iD), &xi, &eta)) continue;
-      if (xi < -MPG_TOL || xi > 1.0 + MPG_TOL || eta < -MPG_TOL || eta > 1.0 + MPG_TOL) continue;
+      if (xi < -tol || xi > 1.0 + tol || eta < -tol || eta > 1.0 + tol) continue;   // tol: MPG_TOL unless "grid_inside_tol_exp" says otherwise
       id[0] = (int32_t)iA; id[1] = (int32_t)iB; id[2] = (int32_t)iC; id[3] = (int32_t)iD;
       ww[0] = (1 - xi) * (1 - eta); ww[1] = xi * (1 - eta); ww[2] = xi * eta; ww[3] = (1 - xi) * eta;
       found = true;
@@ -138,7 +140,7 @@ int mpg_k_store_grid_bilinear(mpg_grid_s *g, int dst_stagger, mpg_handle_s *h, h
   }
   k_grid_bilinear<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(g->nx, g->ny, dst_stagger, g->periodic, cen.x.p, cen.y.p, cen.z.p,
                                                              dst.x.p, dst.y.p, dst.z.p, h->idx.p, h->w.p, h->pole_dst.p,
-                                                             h->pole_src0.p, h->pole_w.p);
+                                                             h->pole_src0.p, h->pole_w.p, mpg_grid_inside_tol_exp() == 10 ? MPG_TOL : pow(10.0, -(double)mpg_grid_inside_tol_exp()));
   MPG_HIP(hipGetLastError());
   MPG_HIP(hipStreamSynchronize(s));
   return MPG_SUCCESS;

@@ -798,7 +798,10 @@ static int store_mesh_entry(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst
   }
   StoreCtx ctx{src, dst, dst_staggerloc, regridmethod, src_meshloc};
   // the line type in force is part of what a bilinear handle IS: the two never share a cache entry
-  HandleKey key(src, src_meshloc, dst, dst_staggerloc, regridmethod + (regridmethod == MPG_REGRIDMETHOD_BILINEAR ? 16 * mpg_bilinear_linetype() : 0));
+  // ... and so is the apex rule of the polygon fans for node-located sources
+  HandleKey key(src, src_meshloc, dst, dst_staggerloc,
+                regridmethod + (regridmethod == MPG_REGRIDMETHOD_BILINEAR ? 16 * mpg_bilinear_linetype() : 0) +
+                    (regridmethod == MPG_REGRIDMETHOD_BILINEAR && src_meshloc == MPG_MESHLOC_NODE ? 256 * (mpg_node_fan_origin() + 16) : 0));
   return store_common(key, out, store_mesh_build, ctx);
 }
 
@@ -873,7 +876,7 @@ static int store_grid_entry(mpg_grid grid, int src_staggerloc, int dst_staggerlo
     return MPG_ERR_UNSUPPORTED;
   }
   StoreCtx ctx{nullptr, grid, dst_staggerloc, regridmethod, 0};
-  HandleKey key(grid, 100 + src_staggerloc, grid, dst_staggerloc, regridmethod);
+  HandleKey key(grid, 100 + src_staggerloc, grid, dst_staggerloc, regridmethod + 256 * mpg_grid_inside_tol_exp());   // the inside tolerance in force is part of the handle
   return store_common(key, out, store_grid_build, ctx);
 }
 int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {
@@ -1280,6 +1283,7 @@ int mpg_handle_rebase(mpg_handle h, int64_t base, int64_t n_local) {
 
 int mpg_tune(const char *key, int value) {
   MPG_ARG(key, "mpg_tune: NULL key");
+  store_worker_drain();   // a Store that was begun under the old setting finishes under it: its cache key says so
   int rc = mpg_k_tune(key, value);
   if (rc) mpg_set_error("mpg_tune: unknown key or value out of range: %s=%d", key, value);
   return rc;

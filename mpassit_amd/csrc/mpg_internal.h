@@ -210,6 +210,7 @@ struct mpg_mesh_s {
   DevBuf<int32_t> tri;          // [3][nVertices] dual triangles (cells), -1 = none; CCW
   int64_t nTriValid = 0;
   DevBuf<int32_t> fan;          // [3][nCells*(maxEdges-2)] fan triangles of the Voronoi polygons (vertex ids), lazily
+  int fan_origin = 0;           // the "node_fan_origin" value `fan` was built for
   SiteBvh bvh;
   // source window per mesh location (ELEMENT, NODE): Regrid sources hold ids [win_first, win_first + win_count) only and
   // every handle of this mesh indexes relative to win_first (mpg_mesh_set_source_window); whole mesh by default
@@ -419,6 +420,8 @@ int mpg_k_pack(const double *src, int64_t n_src, int nlev, const int32_t *ids, i
 int mpg_k_tune(const char *key, int value);
 int mpg_store_boxes();         // "store_boxes" knob: 1 (default) index-space candidate boxes on projection-built grids, 0 pyramid walk only
 int mpg_bilinear_linetype();   // "bilinear_linetype" knob: 0 ray from the centre (default), 1 along the triangle's normal
+int mpg_node_fan_origin();     // "node_fan_origin" knob: apex of a polygon's fan = listed vertex number (value mod n); 0 (default) the first, -1 the last
+int mpg_grid_inside_tol_exp(); // "grid_inside_tol_exp" knob: Grid -> Grid inside tolerance 10^-value (default 10 = MPG_TOL)
 int mpg_nearest_variant();
 void mpg_set_nearest_variant(int v);
 int mpg_k_rebase(mpg_handle_s *h, int64_t base, int64_t n_local, hipStream_t s, bool keep_global = false);

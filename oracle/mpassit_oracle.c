@@ -116,7 +116,12 @@ int64_t orc_dual_triangles(int64_t nCells, int64_t nVertices, int maxEdges, cons
  * sides internally in an undocumented order [ESMF-doc] => IMPLEMENTATION-DEFINED; this restatement (and the
  * GPU) use the fan from the first listed vertex: triangle k of cell c = (v0, v_{k+1}, v_{k+2}),
  * id = c*(maxEdges-2)+k, lowest id wins on shared edges.  ftri[3*id+..] = 0-based vertex ids or -1.
+ * orc_set_fan_origin(o): the fan's apex is the listed vertex number o mod n instead (o = -1: the LAST listed vertex -- what an
+ * ear-clipping loop that always cuts the first ear of a convex polygon produces), the others follow in listed order from there:
+ * the kernels' "node_fan_origin" knob, so that a site's ESMF comparison can say which split its library makes.
  * ---------------------------------------------------------------------------------------- */
+static int g_orc_fan_origin = 0;
+void orc_set_fan_origin(int o) { g_orc_fan_origin = o; }
 int64_t orc_fan_triangles(int64_t nCells, int maxEdges, const int32_t *voc, const double *vert_xyz, int32_t *ftri) {
   int nf = maxEdges - 2;
   int64_t nvalid = 0;
@@ -124,9 +129,11 @@ int64_t orc_fan_triangles(int64_t nCells, int maxEdges, const int32_t *voc, cons
   for (int64_t c = 0; c < nCells; ++c) {
     int32_t v[64]; int n = 0;
     for (int j = 0; j < maxEdges && n < 64; ++j) { int32_t x = voc[c * maxEdges + j]; if (x > 0) v[n++] = x - 1; }
+    if (n == 0) continue;
+    const int o = ((g_orc_fan_origin % n) + n) % n;
     for (int k = 0; k + 2 < n; ++k) {
       int64_t t = c * nf + k;
-      int32_t a = v[0], b = v[k + 1], d = v[k + 2];
+      int32_t a = v[o], b = v[(o + k + 1) % n], d = v[(o + k + 2) % n];
       double det = det3_from(v3load(vert_xyz, a), v3load(vert_xyz, b), v3load(vert_xyz, d));
       if (det == 0) continue;
       if (det < 0) { int32_t x = b; b = d; d = x; }
@@ -213,6 +220,10 @@ static inline int tri_weights(v3 P, v3 A, v3 B, v3 C, double tol, double *w) {
  * this form for orc_bilinear_weights (Mesh -> Grid only) so that the difference can be measured. */
 static int g_orc_linetype = 0;
 void orc_set_linetype(int v) { g_orc_linetype = v; }
+/* A4: the tolerance within which a stagger point counts as inside a quad of CENTER points (parametric coordinates); the kernels'
+ * "grid_inside_tol_exp" knob: 10^-e, default e = 10 */
+static double g_orc_grid_tol = ORC_TOL;
+void orc_set_grid_tol(double t) { g_orc_grid_tol = t; }
 static inline int tri_weights_normal(v3 P, v3 A, v3 B, v3 C, double tol, double *w) {
   v3 n = v3cross(v3sub(B, A), v3sub(C, A));
   double nn = v3dot(n, n);
@@ -560,7 +571,7 @@ void orc_grid_bilinear_p(int nx, int ny, int flags, const double *centre_xyz, in
       int64_t iA = (int64_t)b * nx + a, iB = (int64_t)b * nx + a1, iC = iB + nx, iD = iA + nx;
       double xi, eta;
       if (!quad_solve(P, v3load(centre_xyz, iA), v3load(centre_xyz, iB), v3load(centre_xyz, iC), v3load(centre_xyz, iD), &xi, &eta)) continue;
-      if (xi < -ORC_TOL || xi > 1 + ORC_TOL || eta < -ORC_TOL || eta > 1 + ORC_TOL) continue;
+      if (xi < -g_orc_grid_tol || xi > 1 + g_orc_grid_tol || eta < -g_orc_grid_tol || eta > 1 + g_orc_grid_tol) continue;
       idx[4 * p] = (int32_t)iA; idx[4 * p + 1] = (int32_t)iB; idx[4 * p + 2] = (int32_t)iC; idx[4 * p + 3] = (int32_t)iD;
       w[4 * p] = (1 - xi) * (1 - eta); w[4 * p + 1] = xi * (1 - eta); w[4 * p + 2] = xi * eta; w[4 * p + 3] = (1 - xi) * eta;
       found = 1;

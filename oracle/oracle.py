@@ -70,12 +70,17 @@ def dual_triangles(voc, n_vertices, cell_xyz):
     return tri, int(n)
 
 
-def fan_triangles(voc, vert_xyz):
-    """Fan triangulation of the Voronoi polygons (node-located bilinear, App. A3): [nCells*(maxEdges-2)][3] vertex ids."""
+def fan_triangles(voc, vert_xyz, origin=0):
+    """Fan triangulation of the Voronoi polygons (node-located bilinear, App. A3): [nCells*(maxEdges-2)][3] vertex ids.
+    origin: the fan's apex is listed vertex number origin mod n (-1: the last one) -- the kernels' "node_fan_origin" knob."""
     voc, vert_xyz = _c(voc, np.int32), _c(vert_xyz, np.float64)
     n_cells, max_edges = voc.shape
     ftri = np.empty((n_cells * (max_edges - 2), 3), np.int32)
-    n = lib().orc_fan_triangles(C.c_int64(n_cells), C.c_int(max_edges), voc.ctypes, vert_xyz.ctypes, ftri.ctypes)
+    lib().orc_set_fan_origin(C.c_int(int(origin)))
+    try:
+        n = lib().orc_fan_triangles(C.c_int64(n_cells), C.c_int(max_edges), voc.ctypes, vert_xyz.ctypes, ftri.ctypes)
+    finally:
+        lib().orc_set_fan_origin(C.c_int(0))
     return ftri, int(n)
 
 
@@ -117,12 +122,17 @@ def conserve(voc, vert_xyz, nx, ny, corner_xyz):
     return rowptr, col, val
 
 
-def grid_bilinear(nx, ny, centre_xyz, stagger, dst_xyz):
+def grid_bilinear(nx, ny, centre_xyz, stagger, dst_xyz, tol=1e-10):
+    """tol: how far outside a quad's parametric range a stagger point still counts as inside (the kernels' "grid_inside_tol_exp" knob)."""
     centre_xyz, dst_xyz = _c(centre_xyz, np.float64), _c(dst_xyz, np.float64)
     P = dst_xyz.shape[0]
     idx, w = np.empty((P, 4), np.int32), np.empty((P, 4))
-    lib().orc_grid_bilinear(C.c_int(nx), C.c_int(ny), centre_xyz.ctypes, C.c_int(stagger), dst_xyz.ctypes,
-                            idx.ctypes, w.ctypes)
+    lib().orc_set_grid_tol(C.c_double(float(tol)))
+    try:
+        lib().orc_grid_bilinear(C.c_int(nx), C.c_int(ny), centre_xyz.ctypes, C.c_int(stagger), dst_xyz.ctypes,
+                                idx.ctypes, w.ctypes)
+    finally:
+        lib().orc_set_grid_tol(C.c_double(1e-10))
     return idx, w
 
 

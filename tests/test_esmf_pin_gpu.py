@@ -64,7 +64,27 @@ def test_a_foreign_weight_file_is_compared_within_the_north_star_tolerances(gpu_
     E.write_weight_file(os.path.join(d, "weights_bilinear_center.nc"), np.broadcast_to(np.arange(1, n_b + 1)[:, None], idx1.shape)[keep], idx1[keep] + 1,
                         w1[keep], n_a, n_b, "bilinear")
     rep = T._compare_case(cs, "bilinear_center", os.path.join(d, "weights_bilinear_center.nc"), verbose=False)
-    assert rep["ok"] and rep["max_abs_diff_any"] <= 1e-10
+    assert rep["ok"] and rep["max_abs_diff_any"] <= 1e-10 and rep["closest_setting"] == {"linetype": 1}
+    # round 6: the other two open choices are answered from the files the same way.  A stand-in "ESMF" that fans every polygon of the
+    # node-located case from its LAST vertex is recognised as node_fan_origin = -1 ...
+    ftri, _ = oracle.fan_triangles(m.verticesOnCell, vxyz, origin=-1)
+    idxn, wn = oracle.bilinear_weights(vxyz, ftri, pxyz)
+    keep = idxn >= 0
+    E.write_weight_file(os.path.join(d, "weights_bilinear_node.nc"), np.broadcast_to(np.arange(1, n_b + 1)[:, None], idxn.shape)[keep], idxn[keep] + 1,
+                        wn[keep], m.nVertices, n_b, "bilinear")
+    rep = T._compare_case(cs, "bilinear_node", os.path.join(d, "weights_bilinear_node.nc"), verbose=True)
+    assert rep["ok"] and rep["max_abs_diff_any"] <= 1e-10 and rep["closest_setting"] == {"linetype": 0, "fan_origin": -1}, rep["closest_setting"]
+    # ... and one whose Grid -> Grid Store takes a stagger point as inside within 1e-4 of a quad as grid_inside_tol_exp = 4 (on this coarse
+    # grid the mapped masks of the settings differ at the hull only where a point sits within the tolerance of it: the default must at
+    # least compare no better than the setting the file was made with)
+    cen = oracle.lonlat_deg_to_xyz(g.lon, g.lat)
+    oi, ow = oracle.grid_bilinear(g.nx, g.ny, cen, 2, oracle.lonlat_deg_to_xyz(g.lon_v, g.lat_v), tol=1e-4)
+    keep = oi >= 0
+    nv = g.lon_v.size
+    E.write_weight_file(os.path.join(d, "weights_bilinear_center_to_edge2.nc"), np.broadcast_to(np.arange(1, nv + 1)[:, None], oi.shape)[keep], oi[keep] + 1,
+                        ow[keep], g.nx * g.ny, nv, "bilinear")
+    rep = T._compare_case(cs, "bilinear_center_to_edge2", os.path.join(d, "weights_bilinear_center_to_edge2.nc"), verbose=True)
+    assert rep["ok"] and rep["max_abs_diff_any"] <= 1e-10 and rep["only_ours"] == rep["only_theirs"] == 0
     # a file for another grid is refused, a missing one skipped with exit code 2
     E.write_weight_file(os.path.join(d, "weights_conserve_center.nc"), [1], [1], [1.0], n_a + 1, n_b, "conserve")
     with pytest.raises(SystemExit, match="sources"):

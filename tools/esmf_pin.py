@@ -75,26 +75,32 @@ class _Case:
         self.mesh.destroy()
         self.grid.destroy()
 
-    def handle(self, case, linetype=0):
+    def handle(self, case, linetype=0, fan_origin=0, tol_exp=10):
+        """The library's handle of `case` under one setting of the three choices ESMF's documentation leaves open: the bilinear
+        line type, the apex of the polygon fans of node-located sources, the inside tolerance of the Grid -> Grid Store."""
         R = self.R
         from mpassit_amd import _lib
         c = self.info["cases"][case]
         method = {"bilinear": R.REGRIDMETHOD_BILINEAR, "conserve": R.REGRIDMETHOD_CONSERVE, "neareststod": R.REGRIDMETHOD_NEAREST_STOD}[c["method"]]
-        if c["src"] == "mesh":
-            _lib.tune("bilinear_linetype", linetype)
-            try:
+        _lib.tune("bilinear_linetype", linetype)
+        _lib.tune("node_fan_origin", fan_origin)
+        _lib.tune("grid_inside_tol_exp", tol_exp)
+        try:
+            if c["src"] == "mesh":
                 rh = R.regrid_store(self.mesh, self.grid, method, meshloc=R.MESHLOC_NODE if c["src_loc"] == "corner" else R.MESHLOC_ELEMENT)
-            finally:
-                _lib.tune("bilinear_linetype", 0)
-            n_a = self.m.nVertices if c["src_loc"] == "corner" else self.m.nCells
-        else:
-            rh = R.regrid_store_grid(self.grid, R.STAGGERLOC_EDGE1 if c["dst"] == "grid_edge1" else R.STAGGERLOC_EDGE2)
-            n_a = self.nx * self.ny
+                n_a = self.m.nVertices if c["src_loc"] == "corner" else self.m.nCells
+            else:
+                rh = R.regrid_store_grid(self.grid, R.STAGGERLOC_EDGE1 if c["dst"] == "grid_edge1" else R.STAGGERLOC_EDGE2)
+                n_a = self.nx * self.ny
+        finally:
+            _lib.tune("bilinear_linetype", 0)
+            _lib.tune("node_fan_origin", 0)
+            _lib.tune("grid_inside_tol_exp", 10)
         return rh, n_a
 
-    def ours(self, case, linetype=0):
+    def ours(self, case, **knobs):
         """(row, col, S) of the library in ESMF's numbering of the exported files, n_a, n_b, the handle."""
-        rh, n_a = self.handle(case, linetype)
+        rh, n_a = self.handle(case, **knobs)
         row, col, S = rh.to_esmf_weights()
         n_b = rh.n_dst
         if not self.regional and self.info["cases"][case]["dst"] == "grid_edge1":
@@ -123,15 +129,36 @@ def _compare_case(cs, case, wpath, verbose=True):
     if theirs["n_a"] not in (None, n_a) or theirs["n_b"] not in (None, n_b):
         raise SystemExit("%s: the weight file is for %s sources x %s destinations, the exported case has %d x %d" % (wpath, theirs["n_a"], theirs["n_b"], n_a, n_b))
     rep = E.compare_weights(ours, (theirs["row"], theirs["col"], theirs["S"]), n_a, n_b, c["method"])
-    reps = {"linetype 0 (ray from the sphere's centre)": rep}
-    if c["method"] == "bilinear" and c["src"] == "mesh":
-        # the one undocumented choice of the bilinear Store -- which reading does this ESMF follow?
-        ours1, _, _, rh1 = cs.ours(case, linetype=1)
-        rep1 = E.compare_weights(ours1, (theirs["row"], theirs["col"], theirs["S"]), n_a, n_b, c["method"])
-        rh1.release()
-        reps["linetype 1 (along the triangle's normal)"] = rep1
-        if rep1["max_abs_diff_any"] < rep["max_abs_diff_any"]:
-            rep = rep1
+    # the choices ESMF's documentation leaves open, each selectable at run time (mpg_tune) -- which setting does THIS ESMF follow?
+    # every alternative is built and compared; the report names the closest (mismatching entries first, then the largest weight difference)
+    alts = []
+    if c["method"] == "bilinear" and c["src"] == "mesh" and c["src_loc"] != "corner":
+        reps = {"linetype 0 (ray from the sphere's centre) [default]": rep}
+        alts = [("linetype 1 (along the triangle's normal)", dict(linetype=1))]
+    elif c["method"] == "bilinear" and c["src"] == "mesh":
+        reps = {"linetype 0, fan from the first listed vertex [default]": rep}
+        alts = [("linetype %d, fan from listed vertex %s" % (lt, "n-1 (the last)" if o < 0 else str(o)), dict(linetype=lt, fan_origin=o))
+                for lt in (0, 1) for o in (0, -1, 1, 2) if (lt, o) != (0, 0)]
+    elif c["src"] != "mesh":
+        reps = {"inside tolerance 1e-10 [default]": rep}
+        alts = [("inside tolerance 1e-%d" % e, dict(tol_exp=e)) for e in (14, 8, 6, 5, 4)]
+    else:
+        reps = {"default": rep}
+
+    def badness(r):
+        return (r["only_ours"] + r["only_theirs"], r["max_abs_diff_any"])
+    best_knobs = {}
+    for label, knobs in alts:
+        ours_a, _, _, rh_a = cs.ours(case, **knobs)
+        rep_a = E.compare_weights(ours_a, (theirs["row"], theirs["col"], theirs["S"]), n_a, n_b, c["method"])
+        reps[label] = rep_a
+        if badness(rep_a) < badness(rep):
+            rep, best_knobs = rep_a, knobs
+            rh.release()
+            rh = rh_a
+        else:
+            rh_a.release()
+    rep["closest_setting"] = best_knobs
     # (a) of INTEGRATION.md s5: ESMF's weights applied by this library's Regrid kernels, beside its own weights
     src = cs.source_field(case)
     nlev = src.shape[0]
@@ -148,7 +175,7 @@ def _compare_case(cs, case, wpath, verbose=True):
                 print(" -- " + label)
             print(E.report_text(r))
         if len(reps) > 1:
-            print("  -> closer to: %s" % min(reps, key=lambda k: reps[k]["max_abs_diff_any"]))
+            print("  -> closest: %s%s" % (min(reps, key=lambda k: badness(reps[k])), ("   [mpg_tune: %s]" % rep["closest_setting"]) if rep["closest_setting"] else ""))
         if "field_rel_diff" in rep:
             print("  smooth field regridded with either weight set: max difference %.3e of its maximum" % rep["field_rel_diff"])
     return rep
