@@ -315,8 +315,8 @@ int mpg_k_tune(const char *key, int value) {
     mpg_set_field_band(value);
     return MPG_SUCCESS;
   }
-  if (!strcmp(key, "lfu_npf")) {   // row slots per thread of the staged level-fast kernel: 0 = by the handle's longest tile list (A/B: 16 = rounds 1-4)
-    if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) return MPG_ERR_INVALID_ARG;
+  if (!strcmp(key, "lfu_npf")) {   // row slots per thread of the staged level-fast kernel: 0 = by each tile's own list (round 6); 2 .. 32 = at least that many for every tile (A/B: 16 = rounds 1-4)
+    if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) return MPG_ERR_INVALID_ARG;
     mpg_lfu_set_npf(value);
     return MPG_SUCCESS;
   }

@@ -28,13 +28,14 @@
 #include <string.h>
 
 #include <utility>
+#include <vector>
 
 #include "geom.h"
 #include "mpg_internal.h"
 
 int mpg_field_band(int kernel_default);
 #define LFU_THREADS 256
-#define LFU_LIST_PAD 512   // every tile's list is padded with its last cell up to min(stride, this many) entries
+#define LFU_LIST_PAD 1024  // a tile's list is padded with its last cell up to the row count of its class: 64, 128 ... this many (min stride)
 #define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two
 
 // ---- per-tile unique cell lists (set-up, runtime tile shape) --------------------------------------------------
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(LFU_THREADS) void k_lfu_build(const int32_t *__rest
   // entries per tile without looking at the count first
   {
     const int32_t last = total > 0 ? keys[total - 1] : 0;
-    const int pad_to = stride < LFU_LIST_PAD ? stride : LFU_LIST_PAD;
+    int cls_rows = 64;                       // the row count of the tile's class (launch_lfu: 64 << c)
+    while (cls_rows < total && cls_rows < LFU_LIST_PAD) cls_rows <<= 1;
+    const int pad_to = stride < cls_rows ? stride : cls_rows;
     for (int e = total + t; e < pad_to; e += LFU_THREADS) out[e] = last;
   }
   // locality statistic: distinct groups of 16 consecutive ids (= 128-byte lines of a cell-fast float64 field) in the list
@@ -293,6 +296,8 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
     std::swap(h->ut_total, h->ut2_total);
     std::swap(h->ut_lines, h->ut2_lines);
     std::swap(h->ut_stride, h->ut2_stride);
+    std::swap(h->ut_order, h->ut2_order);
+    for (int c = 0; c < 7; ++c) std::swap(h->ut_cls_off[c], h->ut2_cls_off[c]);
     return MPG_SUCCESS;
   }
   int rc;
@@ -309,12 +314,17 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
     h->ut2_total = h->ut_total;
     h->ut2_lines = h->ut_lines;
     h->ut2_stride = h->ut_stride;
+    h->ut2_order.free();
+    h->ut2_order = h->ut_order;
+    h->ut_order = DevBuf<int32_t>();
+    for (int c = 0; c < 7; ++c) h->ut2_cls_off[c] = h->ut_cls_off[c];
     h->ut_cnt = DevBuf<int32_t>();
     h->ut_cells = DevBuf<int32_t>();
     h->lidx = DevBuf<uint16_t>();
   }
   h->ut_cnt.free();
   h->ut_cells.free();
+  h->ut_order.free();
   h->ut_rpt = 0;
   const bool big = 3 * txu * tyu > LFU_SORT;   // tiles of more than 1365 points sort in an 8192-entry buffer
   if (3 * txu * tyu > 2 * LFU_SORT) {
@@ -355,6 +365,34 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
   h->ut_max = (int)hs[1];
   h->ut_total = (int64_t)hs[2];
   h->ut_lines = (int64_t)hs[0];
+  // The tiles grouped by list length (classes of at most 64, 128, ... 1024 cells), tile order kept inside a class: the staged level-fast
+  // kernel is launched once per class with the row slots that class needs (round 5 chose the slots per HANDLE from its longest list: on a
+  // global lat-lon grid the tiles at 60 degrees list half, at 80 degrees a fifth of the cells of a tile at the equator).
+  for (int c = 0; c < 7; ++c) h->ut_cls_off[c] = 0;
+  if (txu == 64 && tyu == 8) {   // the tile shape of k_apply3_lfu (LFU_NT / 64 rows)
+    const int ntx = mpg_tile_ntx(h->nx_dst, txu, h->ut_align);
+    const int64_t ntile = (int64_t)ntx * nty;
+    std::vector<int32_t> cnt((size_t)ntile), order((size_t)ntile);
+    MPG_HIP(hipMemcpyAsync(cnt.data(), h->ut_cnt.p, sizeof(int32_t) * (size_t)ntile, hipMemcpyDeviceToHost, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    auto cls_of = [](int n) {
+      int c = 0;
+      while ((64 << c) < n && c < 5) ++c;
+      return c;   // 5: more than 1024 cells (no staged level-fast kernel holds them)
+    };
+    int64_t n_in[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t t = 0; t < ntile; ++t) n_in[cls_of(cnt[(size_t)t])]++;
+    int64_t off[7];
+    off[0] = 0;
+    for (int c = 0; c < 6; ++c) off[c + 1] = off[c] + n_in[c];
+    int64_t fill[6];
+    for (int c = 0; c < 6; ++c) fill[c] = off[c];
+    for (int64_t t = 0; t < ntile; ++t) order[(size_t)fill[cls_of(cnt[(size_t)t])]++] = (int32_t)t;
+    if ((rc = h->ut_order.alloc((size_t)ntile + 1))) return rc;
+    MPG_HIP(hipMemcpyAsync(h->ut_order.p, order.data(), sizeof(int32_t) * (size_t)ntile, hipMemcpyHostToDevice, s));
+    MPG_HIP(hipStreamSynchronize(s));
+    for (int c = 0; c < 7; ++c) h->ut_cls_off[c] = (int)off[c];
+  }
   return MPG_SUCCESS;
 }
 
@@ -530,18 +568,19 @@ int mpg_k_apply3_cfu(mpg_handle_s *h, int variant, const void *src, int src_f32,
 template <typename TS, typename TD, int NT, bool EPI, bool SWZ, int NPF>
 __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w, const TS *__restrict__ src,
-                                                   TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc, int nlev, int ntx, int nty,
+                                                   TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc, int nlev, int ntx,
+                                                   const int32_t *__restrict__ order, unsigned n_cls,
                                                    double scale, double offset, int sbe, int dbe, int band, FieldTab tab) {
   constexpr int LC = 16, LS = LC + 1, RPP = NT / LC, TY = NT / 64, ZROW = NPF * RPP;
   extern __shared__ double lds_raw[];
   TS *slab = (TS *)lds_raw;                                  // [ZROW + 1][LS]; row ZROW stays zero
   const Swz zs = make_swz(sbe), zd = make_swz(dbe);
   const int64_t P = (int64_t)nx * ny;
-  const unsigned ntile = (unsigned)ntx * nty;
   const unsigned lin = xcd_remap(blockIdx.x, gridDim.x);
   unsigned tile;
   int f;
-  band_map(lin, ntile, gridDim.x / ntile, (unsigned)band, tile, f);
+  band_map(lin, n_cls, gridDim.x / n_cls, (unsigned)band, tile, f);   // the tiles of this launch's class, in tile order ...
+  tile = (unsigned)order[tile];                                        // ... and which tile of the grid that is
   const int t = threadIdx.x, lrow = t / LC, llev = t % LC;
   const int32_t *list = ut_cells + (int64_t)tile * stride;   // padded with its last cell up to LFU_LIST_PAD entries
   // this thread's 16 rows: byte offsets of (cell, level llev) inside the field
@@ -618,33 +657,48 @@ void mpg_lfu_set_npf(int v) { g_lfu_npf = v; }
 
 template <typename TS, typename TD, int NT, bool EPI, int NPF>
 static int launch_lfu_n(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
-                        hipStream_t s, const FieldTab &tab) {
-  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + NT / 64 - 1) / (NT / 64);
+                        hipStream_t s, const FieldTab &tab, const int32_t *order, unsigned n_cls) {
+  if (n_cls == 0) return MPG_SUCCESS;
+  const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align);
   constexpr int ROWS = NT / 16 * NPF;   // rows of the slab
   const size_t lds = sizeof(TS) * (ROWS + 1) * 17;
-  if (h->ut_max > ROWS || h->ut_stride < ROWS || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull || (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
-    return MPG_ERR_UNSUPPORTED;
   static_assert(ROWS <= LFU_LIST_PAD, "the kernel reads ROWS list entries of every tile");
   auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true, NPF> : k_apply3_lfu<TS, TD, NT, EPI, false, NPF>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
-                                                   h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, scale, offset, sbe, dbe, mpg_field_band(0), tab);
+  fn<<<n_cls * (unsigned)nfields, NT, lds, s>>>(h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst,
+                                               h->nx_dst, h->ny_dst, h->ut_align, h->n_src, nlev, ntx, order, n_cls, scale, offset, sbe, dbe, mpg_field_band(0), tab);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
+// One launch per class of tiles (lists of at most 64, 128, 256, 512, 1024 cells: NPF = 2, 4, 8, 16, 32 row slots per thread on 512
+// threads).  "lfu_npf" (A/B): a forced value serves every class it can hold, as rounds 1-5 did with 16.
 template <typename TS, typename TD, int NT, bool EPI>
 static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
                       hipStream_t s, const FieldTab &tab) {
   constexpr int RPP = NT / 16;
-  int npf = g_lfu_npf;
-  if (npf == 0) npf = h->ut_max <= 2 * RPP ? 2 : h->ut_max <= 4 * RPP ? 4 : h->ut_max <= 8 * RPP ? 8 : 16;
-  if (npf * RPP < h->ut_max) npf = 16;   // (a forced value too small for this handle)
-  switch (npf) {
-    case 2: return launch_lfu_n<TS, TD, NT, EPI, 2>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
-    case 4: return launch_lfu_n<TS, TD, NT, EPI, 4>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
-    case 8: return launch_lfu_n<TS, TD, NT, EPI, 8>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
-    default: return launch_lfu_n<TS, TD, NT, EPI, 16>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
+  static_assert(RPP * 2 == 64, "class c holds 64 << c rows");
+  if (h->ut_cls_off[6] > h->ut_cls_off[5] || !h->ut_order.p || h->ut_stride < 64 || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull ||
+      (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
+    return MPG_ERR_UNSUPPORTED;   // a tile lists more than 1024 cells, or the 32-bit offsets do not reach
+  for (int c = 0; c < 5; ++c) {
+    const unsigned n_cls = (unsigned)(h->ut_cls_off[c + 1] - h->ut_cls_off[c]);
+    if (n_cls == 0) continue;
+    if (h->ut_stride < (64 << c)) return MPG_ERR_UNSUPPORTED;
+    const int32_t *order = h->ut_order.p + h->ut_cls_off[c];
+    int npf = 2 << c;
+    if (g_lfu_npf > npf) npf = g_lfu_npf;
+    if (h->ut_stride < RPP * npf) npf = 2 << c;   // (a forced value whose slab would read past the list's stride)
+    int rc;
+    switch (npf) {
+      case 2: rc = launch_lfu_n<TS, TD, NT, EPI, 2>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      case 4: rc = launch_lfu_n<TS, TD, NT, EPI, 4>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      case 8: rc = launch_lfu_n<TS, TD, NT, EPI, 8>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      case 16: rc = launch_lfu_n<TS, TD, NT, EPI, 16>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      default: rc = launch_lfu_n<TS, TD, NT, EPI, 32>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+    }
+    if (rc) return rc;
   }
+  return MPG_SUCCESS;
 }
 
 #define LFU_NT 512   // 64 x 8-point tiles; float32 rows: 35 KB of LDS, four workgroups of eight waves per CU; float64: 70 KB, two
@@ -653,7 +707,7 @@ static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
                            double offset, hipStream_t s, const FieldTab &tab) {
   const int sbe = (src_type & MPG_TYPE_BE) != 0, dbe = (dst_type & MPG_TYPE_BE) != 0, sf32 = src_type & MPG_TYPE_F32, df32 = dst_type & MPG_TYPE_F32;
-  int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_NT);
+  int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_LIST_PAD);
   if (rc) return rc;
   if (sf32 && df32) return launch_lfu<float, float, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
   if (sf32) return launch_lfu<float, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
@@ -661,7 +715,7 @@ int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int n
   return launch_lfu<double, double, LFU_NT, true>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab);
 }
 int mpg_k_apply3_lfu(mpg_handle_s *h, const double *src, int nlev, int nfields, double *dst, hipStream_t s) {
-  int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_NT);
+  int rc = lfu_build_shape(h, 64, LFU_NT / 64, s, LFU_LIST_PAD);
   if (rc) return rc;
   return launch_lfu<double, double, LFU_NT, false>(h, src, nlev, nfields, dst, 1.0, 0.0, 0, 0, s, FieldTab());
 }

@@ -302,6 +302,10 @@ struct mpg_handle_s {
   DevBuf<int32_t> ut_cnt, ut_cells;   // list of tile t: ut_cells[t * ut_stride .. + ut_cnt[t])
   int ut_stride = 0, ut2_stride = 0;
   DevBuf<uint16_t> lidx;  // [3][n_dst] positions in the tile's list, 0xFFFF = unmapped
+  // the tiles of the staged level-fast kernel grouped by the length of their lists (k_apply_lfu.hip, round 6): ut_order = tile numbers,
+  // class c (lists of at most 64 << c cells) at [ut_cls_off[c], ut_cls_off[c + 1]); one launch per class, each with the row slots it needs
+  DevBuf<int32_t> ut_order, ut2_order;
+  int ut_cls_off[7] = {0, 0, 0, 0, 0, 0, 0}, ut2_cls_off[7] = {0, 0, 0, 0, 0, 0, 0};
   // a second, parked set of tile lists: a job that alternates layouts on one handle (2-D fields cell-fast, 3-D fields
   // in file order) needs two tile shapes in turn; the lists of the shape not in use wait here and are swapped back in
   // instead of being rebuilt (a rebuild allocates and synchronises, which would also break hipGraph capture)
@@ -310,7 +314,7 @@ struct mpg_handle_s {
   DevBuf<int32_t> ut2_cnt, ut2_cells;
   DevBuf<uint16_t> lidx2;
   void free_tile_lists() {
-    ut_cnt.free(); ut_cells.free(); lidx.free(); ut2_cnt.free(); ut2_cells.free(); lidx2.free();
+    ut_cnt.free(); ut_cells.free(); lidx.free(); ut2_cnt.free(); ut2_cells.free(); lidx2.free(); ut_order.free(); ut2_order.free();
     ut_rpt = ut2_rpt = 0;
   }
 };

@@ -94,13 +94,7 @@ def icosahedral_mesh(level, order="morton"):
     vertices are the circumcentres of the bisection triangles.  O(N log N) numpy, no scipy.
     order="morton": cells and vertices renumbered along a space-filling curve (production meshes are reordered for
     locality too); order="native": bisection order (each level's midpoints appended), which is close to random."""
-    t = (1.0 + 5.0 ** 0.5) / 2.0
-    verts = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
-                      [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
-    verts /= np.linalg.norm(verts, axis=1, keepdims=True)
-    faces = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
-                      [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
-                      [8, 6, 7], [9, 8, 1]], np.int64)
+    verts, faces = _icosahedron()
     for _ in range(level):
         nv, nf = verts.shape[0], faces.shape[0]
         e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
@@ -114,6 +108,63 @@ def icosahedral_mesh(level, order="morton"):
         faces = np.concatenate([np.stack([v0, m01, m20], 1), np.stack([v1, m12, m01], 1), np.stack([v2, m20, m12], 1),
                                 np.stack([m01, m12, m20], 1)])
         verts = np.concatenate([verts, mid])
+    return _mesh_from_sphere_triangulation(verts, faces, order)
+
+
+def _icosahedron():
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    verts = np.array([[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t],
+                      [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]], np.float64)
+    verts /= np.linalg.norm(verts, axis=1, keepdims=True)
+    faces = np.array([[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6],
+                      [7, 1, 8], [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+                      [8, 6, 7], [9, 8, 1]], np.int64)
+    return verts, faces
+
+
+def geodesic_mesh(freq, order="morton"):
+    """Global quasi-uniform mesh of ANY size class: every face of the icosahedron divided into freq^2 triangles (a class-I geodesic
+    grid) -> 10 * freq^2 + 2 cells, 12 pentagons, hexagons elsewhere -- freq = 2^level reproduces icosahedral_mesh's counts (not its
+    points: bisection re-projects at every level).  freq = 548: 3 003 042 cells, the "3 M-cell" global mesh of BASELINE configs[4]
+    (the bisection family jumps from 2.6 M to 10.5 M).  O(N log N) numpy."""
+    if freq < 1:
+        raise ValueError("freq >= 1")
+    iv, ifc = _icosahedron()
+    n = int(freq)
+    # lattice points of one face: (i, j) with i + j <= n  ->  (i * B + j * C + (n - i - j) * A) / n
+    ii, jj = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    keep = ii + jj <= n
+    ii, jj = ii[keep], jj[keep]
+    kk = n - ii - jj
+    local = -np.ones((n + 1, n + 1), np.int64)
+    local[ii, jj] = np.arange(ii.size)
+    # triangles of the face lattice: upward (i,j),(i+1,j),(i,j+1) and downward (i+1,j),(i+1,j+1),(i,j+1)
+    ui, uj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    up = ui + uj <= n - 1
+    dn = ui + uj <= n - 2
+    tri_l = np.concatenate([np.stack([local[ui[up], uj[up]], local[ui[up] + 1, uj[up]], local[ui[up], uj[up] + 1]], 1),
+                            np.stack([local[ui[dn] + 1, uj[dn]], local[ui[dn] + 1, uj[dn] + 1], local[ui[dn], uj[dn] + 1]], 1)])
+    pts, tris = [], []
+    npf = ii.size
+    for f, (a, b, c) in enumerate(ifc):
+        p = (kk[:, None] * iv[a] + ii[:, None] * iv[b] + jj[:, None] * iv[c]) / float(n)
+        pts.append(p / np.linalg.norm(p, axis=1, keepdims=True))
+        tris.append(tri_l + f * npf)
+    pts, tris = np.concatenate(pts), np.concatenate(tris)
+    # points on shared edges / corners come once per face: merge them (they agree to rounding; the lattice spacing is ~1 / freq)
+    key = np.round(pts * (1 << 26)).astype(np.int64)
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    verts = pts[first]
+    faces = inv.reshape(-1)[tris]
+    if verts.shape[0] != 10 * n * n + 2 or faces.shape[0] != 20 * n * n:
+        raise RuntimeError("geodesic_mesh: %d points / %d triangles, expected %d / %d" % (verts.shape[0], faces.shape[0], 10 * n * n + 2, 20 * n * n))
+    return _mesh_from_sphere_triangulation(verts, faces, order)
+
+
+def _mesh_from_sphere_triangulation(verts, faces, order):
+    """Delaunay triangulation of the sphere (points = cell centres, triangles) -> MpasMesh: Voronoi vertices = spherical circumcentres,
+    verticesOnCell counter-clockwise; order = 'morton' (cells and vertices along a space-filling curve) | 'native'."""
+    faces = faces.copy()
     a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
     n = np.cross(b - a, c - a)
     flip = np.einsum("ij,ij->i", n, a + b + c) < 0.0          # counter-clockwise seen from outside
@@ -283,6 +334,16 @@ def morton_cells(m, bits=12):
         code |= ((qx >> b) & 1) << (2 * b)
         code |= ((qy >> b) & 1) << (2 * b + 1)
     return renumber_cells(m, np.argsort(code, kind="stable"))
+
+
+def cutout_cells(m, bits=21):
+    """Cells renumbered as a LIMITED-AREA CUT-OUT of a global mesh numbers them: a regional MPAS mesh is made by cutting cells out of a
+    global parent (MPAS-Limited-Area), and the cut-out keeps the parent's relative order.  The parent here is numbered along a 3-D
+    Morton curve over the whole unit sphere (as icosahedral_mesh / geodesic_mesh number theirs): the regional cells inherit that
+    GLOBAL curve's order -- its cube octants, not the region's own extent, decide where the numbering jumps (morton_cells fits a 2-D
+    curve to the region itself: the friendlier case)."""
+    xyz = latlon_rad_to_xyz(m.latCell, m.lonCell)
+    return renumber_cells(m, _morton_order(xyz, bits=bits))
 
 
 def shuffle_cells(m, seed=SEED, block=1):

@@ -85,11 +85,23 @@ def workload(name, arrays=True):
     if name in ("c5_global_latlon", "c5_small"):
         # BASELINE config 5: global mesh -> global lat-lon grid (is_regional=.false.: 360/nx x 180/ny degrees, periodic in i,
         # poles closed, program_setup.F90:197-217 / model_grid.F90:684-696)
-        level, nx, ny = (9, 3601, 1801) if name == "c5_global_latlon" else (6, 361, 181)
+        # "3 M-cell mesh": the class-I geodesic grid of frequency 548 = 3 003 042 cells (round 6; until round 5 the bisection mesh of
+        # 2 621 442 cells stood in: the bisection family has nothing between 2.6 M and 10.5 M)
+        nx, ny = (3601, 1801) if name == "c5_global_latlon" else (361, 181)
         g = tg.define_target_grid_params("lat-lon", nx, ny, stand_lon=0.0, is_regional=False)
-        m = synth.icosahedral_mesh(level)
-        return m, g, 55, "%d-cell global icosahedral mesh x 55 levels -> %dx%d global lat-lon (%dx%d mass points)" % (
-            m.nCells, nx, ny, nx - 1, ny - 1)
+        m = synth.geodesic_mesh(548) if name == "c5_global_latlon" else synth.icosahedral_mesh(6)
+        return m, g, 55, "%d-cell global %s mesh x 55 levels -> %dx%d global lat-lon (%dx%d mass points)" % (
+            m.nCells, "geodesic (frequency 548)" if name == "c5_global_latlon" else "icosahedral", nx, ny, nx - 1, ny - 1)
+    if name == "c5_2p6m_bisection":      # rounds 1-5's stand-in for configuration 5 (kept for same-mesh comparisons with their records)
+        g = tg.define_target_grid_params("lat-lon", 3601, 1801, stand_lon=0.0, is_regional=False)
+        m = synth.icosahedral_mesh(9)
+        return m, g, 55, "%d-cell global icosahedral mesh x 55 levels -> 3601x1801 global lat-lon (3600x1800 mass points)" % m.nCells
+    if name == "c4_3m_cutout":
+        # configuration 4 numbered as a limited-area CUT-OUT of a global mesh: the regional cells in the order of a parent numbered along a
+        # space-filling curve over the whole sphere (synth.cutout_cells) -- how a regional MPAS mesh made by MPAS-Limited-Area is numbered
+        g = conus_lambert_grid()
+        m = synth.cutout_cells(synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000))
+        return m, g, 55, "3.0 M-cell regional hex mesh numbered as a cut-out of a Morton-numbered global mesh, x 55 levels -> 1801x1061 Lambert" 
     if name == "x_655k_global005":
         # extra workload (not a BASELINE config): a COARSE mesh under a FINE global grid -- 655 362 cells (30 km) -> 7200 x 3600 points (0.05 degrees):
         # 40 target points per cell, 94 % of the algorithmic bytes are stores.  The shape that showed the staged level-fast kernel's fixed row

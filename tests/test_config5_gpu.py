@@ -1,4 +1,4 @@
-"""BASELINE config 5 at full size: 2 621 442-cell global icosahedral mesh -> 3600 x 1800 global lat-lon grid
+"""BASELINE config 5 at full size: 3 003 042-cell global geodesic mesh ("3 M-cell", round 6) -> 3600 x 1800 global lat-lon grid
 (is_regional=.false.), wrf_mod_vars staggered winds.  Properties only a GLOBAL remap offers -- every target point is
 mapped (poles and date line included), the conservative remap preserves the global integral, the pole rows of V are
 zonal means, U wraps around the seam -- and the oracle itself at full size (test_c5_full_size_oracle_parity: the three
@@ -35,7 +35,7 @@ def _tri_area(a, b, c):
 def test_c5_bilinear_and_nearest(c5):
     from mpassit_amd import regrid as R
     torch, m, g = c5["torch"], c5["m"], c5["g"]
-    assert (g.nx, g.ny) == (3600, 1800) and m.nCells == 2_621_442
+    assert (g.nx, g.ny) == (3600, 1800) and m.nCells == 3_003_042 >= 3_000_000      # "3 M-cell mesh" (BASELINE configs[4])
     rh = R.regrid_store(c5["mesh"], c5["grid"], R.REGRIDMETHOD_BILINEAR)
     idx, w = rh.weights()
     assert (idx >= 0).all()                                # a closed sphere has no unmapped point
@@ -185,8 +185,8 @@ def test_c5_full_size_oracle_parity(c5, oracle):
 def test_c5_hundred_field_bundle_as_baseline_states_it(c5, oracle):
     """BASELINE configs[4] as written: "3 M-cell mesh -> 3600 x 1800 global lat-lon, 100+ 3-D fields" -- ONE bundle Regrid of
     100 float32 file-order fields x 55 levels (interp.F90:240-254 regrids every listed nz field in one FieldBundleRegrid):
-    57.7 GB of sources, 142.6 GB of results, 1.3 M workgroups.  (The mesh is the 2 621 442-cell icosahedral one, 10 * 4^9 + 2:
-    the nearest quasi-uniform global MPAS size to "3 M"; a 3.0 M-cell GLOBAL mesh does not exist in that family.)
+    66.1 GB of sources, 142.6 GB of results, 1.3 M workgroups.  (The mesh: the class-I geodesic grid of frequency 548, 3 003 042 cells;
+    until round 5 the 2 621 442-cell bisection mesh stood in.)
     What is checked: the first and the LAST field of the bundle -- where a 32-bit overflow in field * level * point offsets
     would land -- against the oracle's widen -> apply chain narrowed to float32 (equal except where the two float64 values,
     <= 1e-12 apart, straddle a float32 rounding boundary: one float32 ulp on a vanishing fraction of the points, the bar of
