@@ -806,6 +806,7 @@ static int store_mesh_entry(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst
 }
 
 int mpg_regrid_store(mpg_mesh src, int src_meshloc, mpg_grid dst, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+  MPG_CHECK_INIT();
   MPG_ARG(out, "mpg_regrid_store: NULL argument");
   return store_mesh_entry(src, src_meshloc, dst, dst_staggerloc, regridmethod, out, "mpg_regrid_store");
 }
@@ -880,6 +881,7 @@ static int store_grid_entry(mpg_grid grid, int src_staggerloc, int dst_staggerlo
   return store_common(key, out, store_grid_build, ctx);
 }
 int mpg_regrid_store_grid(mpg_grid grid, int src_staggerloc, int dst_staggerloc, int regridmethod, mpg_handle *out) {
+  MPG_CHECK_INIT();
   MPG_ARG(out, "mpg_regrid_store_grid: NULL argument");
   return store_grid_entry(grid, src_staggerloc, dst_staggerloc, regridmethod, out);
 }
