@@ -16,11 +16,11 @@ SOURCES = ["mpg_api.hip", "mpg_comm.hip", "mpg_hostpipe.hip", "mpg_fileio.hip", 
            "k_store_gridbil.hip", "k_apply.hip", "k_apply_lfu.hip", "k_apply_typed.hip", "k_wind.hip", "k_pole.hip", "k_post.hip", "k_halo.hip", "k_prims.hip", "k_sort.hip"]
 HEADERS = ["mpg_internal.h", "geom.h", os.path.join("..", "..", "include", "mpassit_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-STRIP = os.environ.get("MPASSIT_STRIP_DEVICE", "").split()   # e.g. "-Xoffload-linker --strip-all" (measured in round 5: see below)
-# -Xoffload-linker --strip-all: the device code objects keep their dynamic symbols (the kernels the runtime looks up) and lose the
-# static symbol table and its strings -- 1.2 MB of mangled template names per translation unit that instantiates library templates,
-# all of which the runtime reads when it loads the object (profiles/r05_init_breakdown.md)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"] + STRIP
+# (Round 5 carried an MPASSIT_STRIP_DEVICE switch here whose one documented setting, `-Xoffload-linker --strip-all`, drops the device objects'
+# .symtab and makes the first hipLaunchKernel of this runtime SEGFAULT after a successful mpg_init -- profiles/r05_init_breakdown.md,
+# gpurun_out/r05/strip_probe.txt.  A build option whose only known value crashes a process that holds the GPU is not an option: removed
+# in round 6; the 1.2 MB it saved are not worth a loader-dependent failure mode.)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 
 
 def _newer(a, deps):

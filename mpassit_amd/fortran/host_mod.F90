@@ -142,12 +142,14 @@ contains
     end if
     if (from_launcher("PMI_SIZE", "PMI_RANK", "MPI_LOCALRANKID")) then
       write (run_id, '(a,i0)') "hydra", c_getppid()
+      call node_local_tag_check("MPI_LOCALNRANKS")
     else if (from_launcher("OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_LOCAL_RANK")) then
       call get_environment_variable("PMIX_NAMESPACE", buf)
       if (len_trim(buf) > 0) then
         run_id = "ompi"//tag_of(buf)
       else
         write (run_id, '(a,i0)') "ompi", c_getppid()
+        call node_local_tag_check("OMPI_COMM_WORLD_LOCAL_SIZE")
       end if
     else
       call get_environment_variable("SLURM_STEP_ID", buf)
@@ -159,8 +161,29 @@ contains
         end if
       end if
     end if
+    ! MPASSIT_RUN_ID is the user's word on what belongs together: it overrides whatever tag the launcher's variables gave
+    ! (round-5 advisor: it was ignored on this path, so a multi-node hydra launch could not be given a job-wide tag at all)
+    call get_environment_variable("MPASSIT_RUN_ID", buf)
+    if (nranks > 1 .and. len_trim(buf) > 0) run_id = "user"//tag_of(buf)
     if (nranks > 1) print '(a,i0,a,i0,a,a)', " - LAUNCHED AS RANK ", myrank, " OF ", nranks, " BY AN MPI / SLURM LAUNCHER; RUN TAG ", trim(run_id)
   contains
+    !> The parent process id is the launcher's PER-NODE proxy (hydra_pmi_proxy, orted): images on different nodes would get different
+    !! tags, look for different marker files and wait MPASSIT_WAIT_S for images that are there all along.  When the launcher says that
+    !! fewer ranks share this node than the job has (v_local_size), a job-wide tag is needed: MPASSIT_RUN_ID, or stop now saying so.
+    subroutine node_local_tag_check(v_local_size)
+      character(len=*), intent(in) :: v_local_size
+      character(len=64) :: b, id
+      integer :: nloc, e
+      call get_environment_variable(v_local_size, b)
+      if (len_trim(b) == 0) return
+      read (b, *, iostat=e) nloc
+      if (e /= 0 .or. nloc < 1 .or. nloc >= nranks) return
+      call get_environment_variable("MPASSIT_RUN_ID", id)
+      if (len_trim(id) > 0) return
+      call fatal("this launch spans several nodes ("//trim(b)//" of its ranks on this one) and the launcher gives no job-wide name: "// &
+                 "set MPASSIT_RUN_ID to one value, unique per launch, for all ranks (e.g. mpiexec -genv MPASSIT_RUN_ID $$)", nranks)
+    end subroutine node_local_tag_check
+
     !> nranks / myrank / local_rank from a launcher's three variables; .false. (and nothing changed) unless the first two are there and sane
     logical function from_launcher(v_size, v_rank, v_local)
       character(len=*), intent(in) :: v_size, v_rank, v_local

@@ -468,6 +468,39 @@ def test_the_references_launch_line_works_mpiexec_starts_the_images(tmp_path, gp
     assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_srun.nc"), "rb").read()
 
 
+def test_a_multi_node_launch_needs_a_job_wide_tag_and_takes_mpassit_run_id(tmp_path, gpu_lib, regional_case):
+    """Round-5 advisor: under MPICH / hydra the run tag came from getppid(), the PER-NODE proxy, so images on different nodes waited for
+    markers that never appear -- and MPASSIT_RUN_ID was ignored on that path.  Two images started side by side with hydra's variables
+    saying "2 ranks, 1 on this node": without MPASSIT_RUN_ID both stop AT ONCE saying what to set; with it they run, tagged with it,
+    and write the single image's bytes."""
+    import time
+    m, _ = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc")
+    open(os.path.join(d, "namelist.one"), "w").write(nml)
+    open(os.path.join(d, "namelist.two"), "w").write(nml.replace("out.nc", "out_two.nc"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("MPASSIT_", "PMI_", "OMPI_", "SLURM_", "MPI_"))}
+    r = subprocess.run([_driver(), "namelist.one"], cwd=d, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    def start(extra):
+        return [subprocess.Popen([_driver(), "namelist.two"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                 env=dict(env, PMI_SIZE="2", PMI_RANK=str(k), MPI_LOCALRANKID="0", MPI_LOCALNRANKS="1", MPASSIT_WAIT_S="20", **extra))
+                for k in range(2)]
+    t0 = time.monotonic()
+    ps = start({})
+    outs = [p.communicate(timeout=120)[0] for p in ps]
+    assert all(p.returncode != 0 for p in ps) and time.monotonic() - t0 < 15, outs             # refused at start-up, not after the wait
+    assert all("spans several nodes" in o and "MPASSIT_RUN_ID" in o for o in outs), outs
+    assert not os.path.exists(os.path.join(d, "out_two.nc"))
+    ps = start({"MPASSIT_RUN_ID": "job-4711.a"})
+    outs = [p.communicate(timeout=600)[0] for p in ps]
+    assert all(p.returncode == 0 for p in ps), outs
+    assert all("RUN TAG userjob4711a" in o for o in outs), outs
+    assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_two.nc"), "rb").read()
+
+
 def test_an_image_whose_peers_never_come_stops_with_a_message(tmp_path, gpu_lib, regional_case):
     """Rank 1 of 2 by srun's variables, but nobody is rank 0 (a stray environment, a rank that died before its marker): the image waits
     MPASSIT_WAIT_S and stops saying how many images it expected -- it does not hang, and it writes nothing."""
