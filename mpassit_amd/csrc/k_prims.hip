@@ -64,8 +64,9 @@ __global__ __launch_bounds__(SCAN_NT) void k_scan_sums(int32_t *__restrict__ bsu
 
 // every block scans its own entries (thread t owns the SCAN_IPT consecutive entries t * SCAN_IPT ..: its running sum is local) and adds
 // the block's offset
-__global__ __launch_bounds__(SCAN_NT) void k_scan_apply(const int32_t *__restrict__ in, int64_t n, const int32_t *__restrict__ boff,
-                                                        int32_t *__restrict__ out) {
+// `in` and `out` may be the same array (mpg_scan_excl_i32 allows in == out): neither is __restrict__ -- every entry a thread writes it has
+// read into registers before, but the qualifier would let the compiler assume otherwise-impossible things about the two (round-5 advisor)
+__global__ __launch_bounds__(SCAN_NT) void k_scan_apply(const int32_t *in, int64_t n, const int32_t *__restrict__ boff, int32_t *out) {
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_IPT;
   int32_t v[SCAN_IPT];
   int32_t sum = 0;
