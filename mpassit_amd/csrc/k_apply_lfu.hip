@@ -369,7 +369,7 @@ static int lfu_build_shape(mpg_handle_s *h, int txu, int tyu, hipStream_t s, int
   // kernel is launched once per class with the row slots that class needs (round 5 chose the slots per HANDLE from its longest list: on a
   // global lat-lon grid the tiles at 60 degrees list half, at 80 degrees a fifth of the cells of a tile at the equator).
   for (int c = 0; c < 7; ++c) h->ut_cls_off[c] = 0;
-  if (txu == 64 && tyu == 8) {   // the tile shape of k_apply3_lfu (LFU_NT / 64 rows)
+  if (txu == 64 && (tyu == 8 || tyu == 16)) {   // the tile shapes of k_apply3_lfu (LFU_NT / 64 rows; 16: the -DLFU_NT=1024 experiment)
     const int ntx = mpg_tile_ntx(h->nx_dst, txu, h->ut_align);
     const int64_t ntile = (int64_t)ntx * nty;
     std::vector<int32_t> cnt((size_t)ntile), order((size_t)ntile);
@@ -675,8 +675,8 @@ static int launch_lfu_n(mpg_handle_s *h, const void *src, int nlev, int nfields,
 template <typename TS, typename TD, int NT, bool EPI>
 static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, void *dst, double scale, double offset, int sbe, int dbe,
                       hipStream_t s, const FieldTab &tab) {
-  constexpr int RPP = NT / 16;
-  static_assert(RPP * 2 == 64, "class c holds 64 << c rows");
+  constexpr int RPP = NT / 16, NPF0 = 64 / RPP;   // class c holds 64 << c rows = RPP * (NPF0 << c)
+  static_assert(RPP * NPF0 == 64, "class c holds 64 << c rows");
   if (h->ut_cls_off[6] > h->ut_cls_off[5] || !h->ut_order.p || h->ut_stride < 64 || (uint64_t)h->n_src * (uint64_t)nlev * sizeof(TS) >= 0xFFFFFFFFull ||
       (uint64_t)h->n_dst * sizeof(TD) >= 0xFFFFFFFFull)
     return MPG_ERR_UNSUPPORTED;   // a tile lists more than 1024 cells, or the 32-bit offsets do not reach
@@ -685,23 +685,25 @@ static int launch_lfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
     if (n_cls == 0) continue;
     if (h->ut_stride < (64 << c)) return MPG_ERR_UNSUPPORTED;
     const int32_t *order = h->ut_order.p + h->ut_cls_off[c];
-    int npf = 2 << c;
-    if (g_lfu_npf > npf) npf = g_lfu_npf;
-    if (h->ut_stride < RPP * npf) npf = 2 << c;   // (a forced value whose slab would read past the list's stride)
+    int cc = c;                                                       // the class whose row slots serve this one
+    while (cc < 4 && (NPF0 << cc) < g_lfu_npf && h->ut_stride >= (64 << (cc + 1))) ++cc;   // "lfu_npf": at least that many (A/B)
     int rc;
-    switch (npf) {
-      case 2: rc = launch_lfu_n<TS, TD, NT, EPI, 2>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
-      case 4: rc = launch_lfu_n<TS, TD, NT, EPI, 4>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
-      case 8: rc = launch_lfu_n<TS, TD, NT, EPI, 8>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
-      case 16: rc = launch_lfu_n<TS, TD, NT, EPI, 16>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
-      default: rc = launch_lfu_n<TS, TD, NT, EPI, 32>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+    switch (cc) {
+      case 0: rc = launch_lfu_n<TS, TD, NT, EPI, NPF0>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      case 1: rc = launch_lfu_n<TS, TD, NT, EPI, NPF0 * 2>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      case 2: rc = launch_lfu_n<TS, TD, NT, EPI, NPF0 * 4>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      case 3: rc = launch_lfu_n<TS, TD, NT, EPI, NPF0 * 8>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
+      default: rc = launch_lfu_n<TS, TD, NT, EPI, NPF0 * 16>(h, src, nlev, nfields, dst, scale, offset, sbe, dbe, s, tab, order, n_cls); break;
     }
     if (rc) return rc;
   }
   return MPG_SUCCESS;
 }
 
-#define LFU_NT 512   // 64 x 8-point tiles; float32 rows: 35 KB of LDS, four workgroups of eight waves per CU; float64: 70 KB, two
+#ifndef LFU_NT
+#define LFU_NT 512
+#endif
+// LFU_NT 512: 64 x 8-point tiles; float32 rows: 35 KB of LDS, four workgroups of eight waves per CU; float64: 70 KB, two
 
 // -> MPG_ERR_UNSUPPORTED when a tile's list does not fit the slab (the caller takes the row gather)
 int mpg_k_apply3_lfu_typed(mpg_handle_s *h, const void *src, int src_type, int nlev, int nfields, void *dst, int dst_type, double scale,
