@@ -89,7 +89,8 @@ def main():
         ref, _ = run(False)
         what = "case %d kind %d nlev %d nf %d %s->%s be %d layout %d mesh %d cells grid %dx%d" % (
             case, kind, nlev, nf, str(sdt)[-7:], str(ddt)[-7:], be, layout, m.nCells, g.nx, g.ny)
-        combos = [("a3_staged", v) for v in (-2, 0, 1, 2)] + [("lf_variant", v) for v in (0, 1, 2)] + [("field_band", v) for v in (0, 3, 64)]
+        combos = [("a3_staged", v) for v in (-2, 0, 1, 2)] + [("lf_variant", v) for v in (0, 1, 2)] + [("field_band", v) for v in (0, 3, 64)] + \
+                 [("lfu_npf", v) for v in (16, 32)]        # round 6: row slots per class of tiles (default) against one size for all
         for knob, v in combos:
             if _lib.load().mpg_tune(knob.encode(), int(v)) != 0:
                 continue
@@ -101,7 +102,7 @@ def main():
                     print("ERROR", what, knob, v, str(e)[:120], flush=True)
                     bad += 1
             finally:
-                _lib.tune(knob, -1)
+                _lib.tune(knob, 0 if knob == "lfu_npf" else -1)
             runs += 1
             if got is not None and (not ok or not torch.equal(got, ref)):
                 bad += 1
@@ -118,6 +119,42 @@ def main():
                     bad += 1
                     print("FAIL", what, "bundle field", f, flush=True)
         rh.release()
+        # round 6: the one-pass wind chain (mpg_wind_destagger_dev) against rotate_winds_cgrid + the two Grid -> Grid Regrids, on this grid
+        if rng.random() < 0.6:
+            nz = int(rng.choice([1, 2, 5, 16, 33]))
+            um = (torch.rand((nz, g.ny, g.nx), dtype=torch.float64, device="cuda", generator=gen) - 0.5) * 80.0
+            vm = (torch.rand((nz, g.ny, g.nx), dtype=torch.float64, device="cuda", generator=gen) - 0.5) * 80.0
+            rot = getattr(g, "cosa", None) is not None and rng.random() < 0.7
+            wdt, wbe = [(torch.float64, False), (torch.float32, True), (torch.float32, False)][int(rng.integers(3))]
+            which = ["uv", "uv", "u", "v"][int(rng.integers(4))] if not rot else "uv"
+            ru = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1) if "u" in which else None
+            rv = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2) if "v" in which else None
+            ca = torch.as_tensor(np.ascontiguousarray(g.cosa), device="cuda") if rot else None
+            sa = torch.as_tensor(np.ascontiguousarray(g.sina), device="cuda") if rot else None
+            a, b = um.clone(), vm.clone()
+            if rot:
+                R.rotate_winds_cgrid(ca, sa, a, b)
+            wit = torch.int32 if wdt == torch.float32 else torch.int64
+
+            def one(rh_s, mass):
+                if wdt == torch.float64 and not wbe:
+                    return rh_s.regrid(mass.reshape(-1), nlev=nz)[0]
+                return rh_s.regrid_typed(mass.reshape(-1), nlev=nz, out_dtype=wdt, dst_be=wbe)[0]
+            u0 = one(ru, a) if ru is not None else None
+            v0 = one(rv, b) if rv is not None else None
+            u1, v1, _, _ = R.wind_destagger(ru, rv, ca, sa, um if (ru is not None or rot) else None, vm if (rv is not None or rot) else None, nz,
+                                            out_dtype=wdt, dst_be=wbe)
+            torch.cuda.synchronize()
+            for nm, x0, x1 in (("U", u0, u1), ("V", v0, v1)):
+                if x0 is None:
+                    continue
+                runs += 1
+                if not torch.equal(x0.reshape(-1).view(wit), x1.reshape(-1).view(wit)):
+                    bad += 1
+                    print("FAIL", what, "wind chain", nm, "rot %d nz %d %s be %d which %s" % (rot, nz, str(wdt)[-7:], wbe, which), flush=True)
+            for r_ in (ru, rv):
+                if r_ is not None:
+                    r_.release()
         mesh.destroy()
         grid.destroy()
         if case % 25 == 24:
