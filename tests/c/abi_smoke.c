@@ -181,6 +181,64 @@ int main(void) {
       return 1;
     }
     CHECK(mpg_mesh_set_source_window(mesh, MPG_MESHLOC_ELEMENT, 0, 4));
+    /* ---- round 6: Stores begun in the background, and interp.F90:291-328 (rotate_winds_cgrid + UMASS -> U + VMASS -> V) in one pass ---- */
+    {
+      enum { WX = 40, WY = 24, WL = 3 };
+      mpg_proj pj;
+      memset(&pj, 0, sizeof pj);
+      pj.code = MPG_PROJ_LC;
+      pj.known_lat = 38.5; pj.known_lon = -97.5; pj.known_x = 0.5 * (WX + 1); pj.known_y = 0.5 * (WY + 1);
+      pj.dx_m = 30000.0; pj.stand_lon = -97.5; pj.truelat1 = 38.5; pj.truelat2 = 38.5;
+      mpg_grid wg;
+      CHECK(mpg_grid_create_proj(&pj, WX, WY, 0, &wg));
+      CHECK(mpg_regrid_store_grid_begin(wg, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, MPG_REGRIDMETHOD_BILINEAR));
+      CHECK(mpg_regrid_store_grid_begin(wg, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE2, MPG_REGRIDMETHOD_BILINEAR));
+      double um[WL][WY][WX], vm[WL][WY][WX];
+      for (int k = 0; k < WL; ++k)
+        for (int j = 0; j < WY; ++j)
+          for (int i = 0; i < WX; ++i) {
+            um[k][j][i] = 10.0 + k + 0.3 * i - 0.2 * j;
+            vm[k][j][i] = -4.0 + 0.5 * k + 0.1 * i * j;
+          }
+      mpg_handle ru, rv;
+      CHECK(mpg_regrid_store_grid(wg, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, MPG_REGRIDMETHOD_BILINEAR, &ru));   /* collects the begun Stores */
+      CHECK(mpg_regrid_store_grid(wg, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE2, MPG_REGRIDMETHOD_BILINEAR, &rv));
+      const double *ca, *sa;
+      CHECK(mpg_grid_rotang_dev(wg, &ca, &sa));
+      const size_t nm = sizeof um, nu = (size_t)WL * WY * (WX + 1) * 8, nv = (size_t)WL * (WY + 1) * WX * 8;
+      void *um_d, *vm_d, *ur_d, *vr_d, *u1_d, *v1_d, *u3_d, *v3_d;
+      CHECK(mpg_dev_alloc(nm, &um_d)); CHECK(mpg_dev_alloc(nm, &vm_d)); CHECK(mpg_dev_alloc(nm, &ur_d)); CHECK(mpg_dev_alloc(nm, &vr_d));
+      CHECK(mpg_dev_alloc(nu, &u1_d)); CHECK(mpg_dev_alloc(nv, &v1_d)); CHECK(mpg_dev_alloc(nu, &u3_d)); CHECK(mpg_dev_alloc(nv, &v3_d));
+      CHECK(mpg_dev_upload(um_d, um, nm)); CHECK(mpg_dev_upload(vm_d, vm, nm));
+      CHECK(mpg_dev_upload(ur_d, um, nm)); CHECK(mpg_dev_upload(vr_d, vm, nm));
+      /* one pass ... */
+      CHECK(mpg_wind_destagger_dev(ru, rv, ca, sa, (const double *)um_d, (const double *)vm_d, WL, u1_d, v1_d, MPG_TYPE_F64, NULL, NULL, NULL));
+      /* ... against the three calls of the reference's sequence */
+      CHECK(mpg_rotate_winds_dev((int64_t)WX * WY, WL, ca, sa, (double *)ur_d, (double *)vr_d, NULL));
+      CHECK(mpg_regrid_dev(ru, (const double *)ur_d, MPG_LAYOUT_CELL_FAST, WL, 1, (double *)u3_d, NULL));
+      CHECK(mpg_regrid_dev(rv, (const double *)vr_d, MPG_LAYOUT_CELL_FAST, WL, 1, (double *)v3_d, NULL));
+      static double u1[WL][WY][WX + 1], u3[WL][WY][WX + 1], v1[WL][WY + 1][WX], v3[WL][WY + 1][WX];
+      CHECK(mpg_dev_download(u1, u1_d, nu)); CHECK(mpg_dev_download(u3, u3_d, nu));
+      CHECK(mpg_dev_download(v1, v1_d, nv)); CHECK(mpg_dev_download(v3, v3_d, nv));
+      if (memcmp(u1, u3, nu) != 0 || memcmp(v1, v3, nv) != 0) {
+        fprintf(stderr, "FAIL: mpg_wind_destagger_dev differs from rotate_winds + two Regrids\n");
+        return 1;
+      }
+      if (u1[1][WY / 2][WX / 2] == 0.0 || u1[0][3][0] != 0.0 || v1[2][0][5] != 0.0) {   /* interior mapped, outer half-cell ring 0.0 */
+        fprintf(stderr, "FAIL: staggered winds: interior / hull values\n");
+        return 1;
+      }
+      if (mpg_wind_destagger_dev(ru, rv, ca, sa, (const double *)um_d, (const double *)vm_d, WL, u1_d, v1_d, MPG_TYPE_F64, (double *)um_d, NULL, NULL) !=
+          MPG_ERR_INVALID_ARG) {
+        fprintf(stderr, "FAIL: rotated mass winds over the inputs must be refused\n");
+        return 1;
+      }
+      CHECK(mpg_handle_release(ru)); CHECK(mpg_handle_release(rv));
+      CHECK(mpg_dev_free(um_d)); CHECK(mpg_dev_free(vm_d)); CHECK(mpg_dev_free(ur_d)); CHECK(mpg_dev_free(vr_d));
+      CHECK(mpg_dev_free(u1_d)); CHECK(mpg_dev_free(v1_d)); CHECK(mpg_dev_free(u3_d)); CHECK(mpg_dev_free(v3_d));
+      CHECK(mpg_grid_destroy(wg));
+      CHECK(mpg_regrid_store_begin(mesh, MPG_MESHLOC_ELEMENT, grid, MPG_STAGGERLOC_CENTER, MPG_REGRIDMETHOD_CONSERVE));   /* begun, collected by nobody: parked */
+    }
     /* ---- one rank of the multi-GPU verbs: communicator, halo schedule of this handle, exchange, row gather ---- */
     mpg_comm comm;
     mpg_halo halo;
