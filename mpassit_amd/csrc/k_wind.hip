@@ -61,7 +61,10 @@ __device__ __forceinline__ void wd_rotate(double uo, double vo, double ca, doubl
   vn = (vo - t2) / ca;
 }
 
-template <typename TD, bool ROT, bool TYPED>
+// KEEP: the rotated mass winds are written too (um_rot / vm_rot) -- a template parameter, because its per-lane condition is a divergent
+// branch around a store, and with one in the level loop the compiler waits for EVERY outstanding store before it consumes the next
+// level's loads (vmcnt(0)); without, it waits for the loads only (the four stores of the level stay in flight)
+template <typename TD, bool ROT, bool TYPED, bool KEEP>
 __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_wind_destagger(const WindArgs a) {
   __shared__ double lds[2 * 2 * WD_NW];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -180,10 +183,23 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     for (int r = 0; r < WD_WPT; ++r) {
       buf_load(fu[r], ru, gb[r], 0u);
       buf_load(fv[r], rv, gb[r], 0u);
+      __builtin_amdgcn_sched_barrier(0);   // program order, here and in the loop: see below
     }
   };
   fetch(0);
   TD *uplane = (TD *)a.u, *vplane = (TD *)a.v;
+  // gfx950 counts loads and stores in ONE in-order counter (vmcnt).  At the top of the level loop the compiler must wait for level k's
+  // loads; what it may leave in flight is the minimum over the two ways into the loop of "memory operations issued after the load".
+  // From the loop's own end those are the later loads and the level's four stores; from here, without the four (dropped: their lane
+  // offset is out of range) stores below, nothing -- and the wait became vmcnt(0): every level waited for the stores of the level
+  // before it to be acknowledged.  With the same six loads in the same order and four stores behind them on both ways in, the wait is
+  // "the loads, not the stores" (vmcnt(5) / (3) / (1) in the ISA).  Measured level on configuration 4's grid (0.79-0.80 ms either way,
+  // profiles/r06_wind_chain_probe.txt: the kernel runs at 91 % of the box's device-copy rate with two workgroups per CU); kept: it costs nothing.
+  {
+    const BufRsrc none = buf_rsrc(nullptr, 0u);
+#pragma unroll
+    for (int r = 0; r < 2 * WD_RPT; ++r) buf_store_nt((TD)0, none, MPG_BUF_NONE);
+  }
   for (int k = 0; k < nlev; ++k) {
     double *bu = lds + (k & 1) * 2 * WD_NW, *bv = bu + WD_NW;
 #pragma unroll
@@ -195,13 +211,13 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         bu[e] = un;
         bv[e] = vn;
       }
-      if constexpr (ROT) {
+      if constexpr (KEEP) {
         if (a.um_rot && wown[r]) __builtin_nontemporal_store(un, a.um_rot + (int64_t)k * NP + (gb[r] >> 3));
         if (a.vm_rot && wown[r]) __builtin_nontemporal_store(vn, a.vm_rot + (int64_t)k * NP + (gb[r] >> 3));
       }
     }
     __syncthreads();
-    if (k + 1 < nlev) fetch(k + 1);
+    fetch(min(k + 1, nlev - 1));   // no branch around the loads (the last level is fetched once more): the compiler can count what is in flight
     const BufRsrc ou = buf_rsrc(do_u ? uplane : nullptr, do_u ? u_bytes : 0u), ov = buf_rsrc(do_v ? vplane : nullptr, do_v ? v_bytes : 0u);
 #pragma unroll
     for (int r = 0; r < WD_RPT; ++r) {
@@ -268,8 +284,9 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 
 template <typename TD, bool TYPED>
 static int launch_wind(const WindArgs &a, bool rot, unsigned nwg, hipStream_t s) {
-  if (rot) k_wind_destagger<TD, true, TYPED><<<nwg, WD_NT, 0, s>>>(a);
-  else k_wind_destagger<TD, false, TYPED><<<nwg, WD_NT, 0, s>>>(a);
+  if (rot && (a.um_rot || a.vm_rot)) k_wind_destagger<TD, true, TYPED, true><<<nwg, WD_NT, 0, s>>>(a);
+  else if (rot) k_wind_destagger<TD, true, TYPED, false><<<nwg, WD_NT, 0, s>>>(a);
+  else k_wind_destagger<TD, false, TYPED, false><<<nwg, WD_NT, 0, s>>>(a);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -337,4 +354,4 @@ int mpg_k_wind_destagger(mpg_handle_s *h1, mpg_handle_s *h2, const double *cosa,
 }
 
 // mpg_init loads this translation unit's code object ahead of its first launch (mpg_api.hip: warm_modules)
-const void *mpg_anchor_k_wind() { return (const void *)&k_wind_destagger<double, true, false>; }
+const void *mpg_anchor_k_wind() { return (const void *)&k_wind_destagger<double, true, false, false>; }
