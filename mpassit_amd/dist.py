@@ -441,9 +441,11 @@ class ShardedInterp:
         self.mesh = R.Mesh.from_mpas(mpas_mesh, window_grid=self.grid if world > 1 else None)   # only what this row block can see
         self.grid_ext = R.Grid.from_target(target, rows=(self.e0, self.e1))
         self.target = copy.copy(target)               # rotation angles of the own rows
+        self.cosa_ext = self.sina_ext = None
         if target.cosa is not None:
             self.target.cosa = np.ascontiguousarray(target.cosa[self.j0:self.j1])
             self.target.sina = np.ascontiguousarray(target.sina[self.j0:self.j1])
+            self.cosa_ext, self.sina_ext = target.cosa[self.e0:self.e1], target.sina[self.e0:self.e1]   # ... and of the block with its halo rows
 
     def _halo_rows(self, mass):
         """mass [nz][rows][nx] of the own block -> [nz][e1-e0][nx] with the neighbours' boundary rows attached."""
@@ -486,9 +488,44 @@ class ShardedInterp:
             nrows += 1                                              # the last rank also owns the top V row
         return full[:, off:off + nrows]
 
+    def _winds(self, um, vm, rot, nz):
+        """interp.F90:291-328 in one pass on this rank's block: the halo rows that travel are those of the UNROTATED mass winds, the
+        rotation (pointwise) and both destaggerings happen in mpg_wind_destagger_dev on the block extended by them -- the same bits as
+        rotating first and exchanging rotated rows (the three-call route above).  None: not device-resident -> that route."""
+        import torch
+
+        from . import _lib as L, regrid as R
+        ref = um if um is not None else vm
+        if not (type(ref).__module__.startswith("torch") and ref.is_cuda and all(t is None or t.dtype == torch.float64 for t in (um, vm))):
+            return None
+        eu = self._halo_rows(um) if um is not None else None
+        ev = self._halo_rows(vm) if vm is not None else None
+        cosa = sina = None
+        if rot:
+            if getattr(self, "_rot_ext", None) is None or self._rot_ext[0].device != ref.device:
+                self._rot_ext = (torch.as_tensor(np.ascontiguousarray(self.cosa_ext), device=ref.device),
+                                 torch.as_tensor(np.ascontiguousarray(self.sina_ext), device=ref.device))
+            cosa, sina = self._rot_ext
+        rh_u = R.regrid_store_grid(self.grid_ext, R.STAGGERLOC_EDGE1) if eu is not None else None
+        rh_v = R.regrid_store_grid(self.grid_ext, R.STAGGERLOC_EDGE2) if ev is not None else None
+        try:
+            u, v, _, _ = R.wind_destagger(rh_u, rh_v, cosa, sina, eu.contiguous() if eu is not None else None,
+                                          ev.contiguous() if ev is not None else None, nz)
+        except L.MpgError as e:
+            if e.rc != L.MPG_ERR_UNSUPPORTED:
+                raise
+            return None
+        finally:
+            for rh in (rh_u, rh_v):
+                if rh is not None:
+                    rh.release()
+        off, nrows = self.j0 - self.e0, self.j1 - self.j0
+        return (u[:, off:off + nrows] if u is not None else None,
+                v[:, off:off + nrows + (1 if self.j1 == self.ny else 0)] if v is not None else None)       # the last rank also owns the top V row
+
     def interp_data(self, inp, cfg):
         from . import interp as I
-        return I.interp_data(self.mesh, self.grid, self.target, inp, cfg, destagger=self._destagger)
+        return I.interp_data(self.mesh, self.grid, self.target, inp, cfg, destagger=self._destagger, winds=self._winds)
 
     def destroy(self):
         self.mesh.destroy()

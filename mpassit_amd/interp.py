@@ -179,7 +179,7 @@ def _wind_chain_fused(grid, target, cfg, um, vm, rot, nz, out, destagger):
     return True
 
 
-def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
+def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None, winds=None):
     h = F.classify_hist(cfg.hist_2d, cfg.hist_3d, cfg.hist_soil, cfg.wrf_mod_vars)
     # `method` is only assigned inside `if (n_hist_fields_2d_patch>0)` in the reference (interp.F90:203-204) and
     # undefined otherwise; this build always uses BILINEAR for the blocks below.
@@ -196,7 +196,23 @@ def interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=None):
         vm = rh_patch.regrid(inp.hist["uReconstructMeridional"], nlev=inp.nz, layout=inp.layout, **_be_kw(inp.hist["uReconstructMeridional"]))[0]  # :274-289
     rot = h.do_u_interp and h.do_v_interp and cfg.proj_is_lambert                                                                         # :291
     if um is not None or vm is not None:
-        if not _wind_chain_fused(grid, target, cfg, um, vm, rot, inp.nz, out, destagger):
+        done = False
+        if winds is not None and cfg.fused_winds:         # the row-sharded driver's own one-pass chain (halo rows of the UNROTATED mass winds)
+            uv = winds(um, vm, rot, inp.nz)
+            if uv is not None:
+                done = True
+                if uv[0] is not None:
+                    out["U"] = uv[0]
+                if uv[1] is not None:
+                    out["V"] = uv[1]
+                if cfg.keep_mass_winds:                    # (asked for explicitly: rotated in place, as the three-call chain leaves them)
+                    if rot:
+                        rotate_winds_cgrid(target, um, vm, grid)
+                    if um is not None:
+                        out["UMASS"] = um
+                    if vm is not None:
+                        out["VMASS"] = vm
+        if not done and not _wind_chain_fused(grid, target, cfg, um, vm, rot, inp.nz, out, destagger):
             if rot:
                 rotate_winds_cgrid(target, um, vm, grid)              # :291-293
             ds = destagger or _destagger_local
@@ -260,16 +276,17 @@ def begin_stores(mesh, grid, cfg, local_destagger=True):
         R.regrid_store_begin(mesh, grid, R.REGRIDMETHOD_NEAREST_STOD)
 
 
-def interp_data(mesh, grid, target, inp, cfg, destagger=None):
+def interp_data(mesh, grid, target, inp, cfg, destagger=None, winds=None):
     """-> dict target_name -> array ([ny][nx], [nlev][ny][nx]; U on EDGE1, V on EDGE2).
-    `destagger` lets the row-sharded driver (dist.ShardedInterp) supply the CENTER -> EDGE step with its row halo."""
+    `destagger` lets the row-sharded driver (dist.ShardedInterp) supply the CENTER -> EDGE step with its row halo; `winds`
+    (um, vm, rotate, nz) -> (U, V) | None its one-pass form of the whole chain interp.F90:291-328."""
     out = {}
     if cfg.overlap_stores:
         begin_stores(mesh, grid, cfg, local_destagger=destagger is None)
     if cfg.interp_diag:
         interp_diag_data(mesh, grid, target, inp, cfg, out)
     if cfg.interp_hist:
-        interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=destagger)
+        interp_hist_data(mesh, grid, target, inp, cfg, out, destagger=destagger, winds=winds)
     return out
 
 

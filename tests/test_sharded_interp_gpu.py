@@ -34,7 +34,15 @@ def _inputs(m):
     return inp, cfg
 
 
-def _rank(rank, world, port, q):
+def _to_device(inp):
+    import torch
+    inp.hgt = torch.as_tensor(inp.hgt, device="cuda")
+    for k in list(inp.hist):
+        inp.hist[k] = torch.as_tensor(np.ascontiguousarray(inp.hist[k]), device="cuda")
+    return inp
+
+
+def _rank(rank, world, port, q, device=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import datetime
     import torch.distributed as dist
@@ -44,29 +52,38 @@ def _rank(rank, world, port, q):
         _lib.init(0)
         m, g, _, _ = workloads.workload("tiny")
         inp, cfg = _inputs(m)
+        if device:
+            inp = _to_device(inp)
         si = mdist.ShardedInterp(m, g, rank, world)
         out = si.interp_data(inp, cfg)
-        q.put((rank, si.j0, si.j1, {k: np.asarray(v) for k, v in out.items()}))
+        q.put((rank, si.j0, si.j1, {k: np.asarray(v.cpu() if device else v) for k, v in out.items()}))
         si.destroy()
         _lib.finalize()
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_interp_equals_single_gpu(gpu_lib):
+@pytest.mark.parametrize("device", [False, True], ids=["host_arrays", "device_resident"])
+def test_sharded_interp_equals_single_gpu(gpu_lib, device):
+    """device_resident (round 6): the sharded driver's one-pass wind chain -- halo rows of the UNROTATED mass winds, rotation and both
+    destaggerings in mpg_wind_destagger_dev on the extended block -- against the single GPU's; host arrays take the three-call route."""
     import torch.multiprocessing as mp
     from mpassit_amd import interp as I, regrid as R, workloads
     m, g, _, _ = workloads.workload("tiny")
     inp, cfg = _inputs(m)
+    if device:
+        inp = _to_device(inp)
     mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
     want = I.interp_data(mesh, grid, g, inp, cfg)
+    if device:
+        want = {k: v.cpu().numpy() for k, v in want.items()}
     mesh.destroy()
     grid.destroy()
     world = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, q, device)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda r: r[0])
