@@ -72,6 +72,7 @@ program mpassit
   no_window = len_trim(envbuf) > 0
   if (dev_flow .and. myrank == 0 .and. .not. no_reserve) call reserve_output()   ! the output file's pages are allocated while the inputs are read
   call mpg_check(mpg_init(int(gpu, c_int)), "INITIALIZING GPU RUNTIME")
+  call mpg_apply_tune_env()      ! MPASSIT_TUNE: a site's run-time choices (bilinear line type, fan apex, inside tolerance ...)
   call lap("SETUP + GPU RUNTIME")
   print *, "- DEFINE TARGET GRID"
   call define_target_grid()

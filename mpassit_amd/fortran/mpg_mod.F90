@@ -42,6 +42,14 @@ module mpg
       integer(c_int) :: rc
     end function mpg_init
 
+    !> a run-time choice of the library by name (include/mpassit_amd.h: bilinear_linetype, node_fan_origin, grid_inside_tol_exp, ...)
+    function mpg_tune_c(key, value) bind(C, name="mpg_tune") result(rc)
+      import :: c_int, c_char
+      character(kind=c_char), intent(in) :: key(*)
+      integer(c_int), value :: value
+      integer(c_int) :: rc
+    end function mpg_tune_c
+
     function mpg_device_count(n) bind(C, name="mpg_device_count") result(rc)
       import :: c_int
       integer(c_int), intent(out) :: n
@@ -490,6 +498,38 @@ contains
     type(c_ptr), intent(in) :: src_dev
     rc = mpg_dev_to_file_c(trim(path)//c_null_char, offset, nbytes, src_dev, c_null_ptr)
   end function mpg_dev_to_file
+
+  !> MPASSIT_TUNE="key=value[,key=value...]": the library's run-time choices for a site whose ESMF comparison (tools/esmf_pin.py compare)
+  !! named another setting than the default -- e.g. MPASSIT_TUNE="bilinear_linetype=1,node_fan_origin=-1".  Called once after mpg_init.
+  subroutine mpg_apply_tune_env()
+    character(len=512) :: txt
+    character(len=64) :: key
+    integer :: i, j, k, val, ios
+    call get_environment_variable("MPASSIT_TUNE", txt)
+    i = 1
+    do while (i <= len_trim(txt))
+      j = index(txt(i:), ",")
+      if (j == 0) then
+        j = len_trim(txt) + 1
+      else
+        j = i + j - 1
+      end if
+      k = index(txt(i:j - 1), "=")
+      if (k < 2) then
+        print *, "- FATAL ERROR: MPASSIT_TUNE wants key=value[,key=value...]: ", trim(txt)
+        error stop 998
+      end if
+      key = adjustl(txt(i:i + k - 2))
+      read (txt(i + k:j - 1), *, iostat=ios) val
+      if (ios /= 0) then
+        print *, "- FATAL ERROR: MPASSIT_TUNE: not an integer in ", txt(i:j - 1)
+        error stop 998
+      end if
+      call mpg_check(mpg_tune_c(trim(key)//c_null_char, int(val, c_int)), "MPASSIT_TUNE "//txt(i:j - 1))
+      print '(a,a,a,i0)', " - LIBRARY CHOICE ", trim(key), " = ", val
+      i = j + 1
+    end do
+  end subroutine mpg_apply_tune_env
 
   subroutine mpg_check(rc, where)
     integer(c_int), intent(in) :: rc

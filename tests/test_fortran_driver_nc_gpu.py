@@ -468,6 +468,31 @@ def test_the_references_launch_line_works_mpiexec_starts_the_images(tmp_path, gp
     assert open(os.path.join(d, "out.nc"), "rb").read() == open(os.path.join(d, "out_srun.nc"), "rb").read()
 
 
+def test_mpassit_tune_sets_the_librarys_choices_in_the_driver(tmp_path, gpu_lib, regional_case):
+    """MPASSIT_TUNE (round 6): what a site's `esmf_pin compare` named goes into the shipped driver without a rebuild.  The other bilinear line
+    type moves the bilinear fields by O(h^2) (tests/test_unpinned_bounds_gpu.py) and nothing else; an unknown key or a non-integer stops the run."""
+    from mpassit_amd import ncio
+    m, _ = regional_case
+    d = str(tmp_path)
+    _write_inputs(d, m, 6, 4)
+    nml = NAMELIST.format(d=d).replace(".raw", ".nc")
+    open(os.path.join(d, "namelist.a"), "w").write(nml)
+    open(os.path.join(d, "namelist.b"), "w").write(nml.replace("out.nc", "out_lt1.nc"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MPASSIT_")}
+    r = subprocess.run([_driver(), "namelist.a"], cwd=d, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "LIBRARY CHOICE" not in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([_driver(), "namelist.b"], cwd=d, capture_output=True, text=True, timeout=300,
+                       env=dict(env, MPASSIT_TUNE="bilinear_linetype=1,grid_inside_tol_exp=10"))
+    assert r.returncode == 0 and "LIBRARY CHOICE bilinear_linetype = 1" in r.stdout and "LIBRARY CHOICE grid_inside_tol_exp = 10" in r.stdout, r.stdout + r.stderr
+    with ncio.Reader(os.path.join(d, "out.nc")) as fa, ncio.Reader(os.path.join(d, "out_lt1.nc")) as fb:
+        ta, tb = fa.get("T", rec=0), fb.get("T", rec=0)
+        assert ta.shape == tb.shape and not np.array_equal(ta, tb) and np.abs(ta - tb).max() < 1e-2 * max(1.0, np.abs(ta).max())
+        assert np.array_equal(fa.get("XLAND", rec=0), fb.get("XLAND", rec=0))            # nearest-neighbour fields do not know about line types
+    for bad in ("no_such_knob=1", "bilinear_linetype=x", "bilinear_linetype"):
+        r = subprocess.run([_driver(), "namelist.b"], cwd=d, capture_output=True, text=True, timeout=300, env=dict(env, MPASSIT_TUNE=bad))
+        assert r.returncode != 0 and "MPASSIT_TUNE" in r.stdout + r.stderr, (bad, r.stdout[-500:], r.stderr[-500:])
+
+
 def test_a_multi_node_launch_needs_a_job_wide_tag_and_takes_mpassit_run_id(tmp_path, gpu_lib, regional_case):
     """Round-5 advisor: under MPICH / hydra the run tag came from getppid(), the PER-NODE proxy, so images on different nodes waited for
     markers that never appear -- and MPASSIT_RUN_ID was ignored on that path.  Two images started side by side with hydra's variables
