@@ -12,7 +12,10 @@
  * the HDF5 C library (hdf5.h, libhdf5, libhdf5_hl: the reference's own dependency under libnetcdf; mpassit_amd/build.py find_hdf5) the
  * same calls read them (ncio_open recognises the magic) and write them (ncio_create with format 4) following the "NetCDF-4 File
  * Format" appendix of the User's Guide -- hostio/nc4hdf5.h; such files offer no raw byte range (ncio_var_extent).  A build without
- * HDF5 reports NCIO_EHDF5 for them and says how to convert.  Host code, no GPU involved.
+ * HDF5 reports NCIO_EHDF5 for them and says how to convert.  One difference from a libnetcdf-written file: this writer sets no HDF5 fill value
+ * and writes no _FillValue attribute, so a record that was never written reads back as 0, not as libnetcdf's default fill (9.96921e+36 for
+ * NC_FLOAT) -- the driver writes every record of every variable it defines.  Checked against h5py, not against libnetcdf itself (absent here).
+ * Host code, no GPU involved.
  * All functions return 0 on success or a negative NCIO_E* code; ncio_strerror() explains the last failure. */
 #ifndef MPASSIT_NCIO_H
 #define MPASSIT_NCIO_H

@@ -172,6 +172,7 @@ static herr_t h5_att_cb(hid_t obj, const char *name, const H5A_info_t *info, voi
   if (!na) { free(out.data); L->bad = 1; return -1; }
   L->a = na;
   out.name = strdup(name);
+  if (!out.name) { free(out.data); L->bad = 1; return -1; }
   L->a[L->n++] = out;
   return 0;
 }
@@ -230,12 +231,12 @@ static int h5_add_dim(ncio_file *f, const char *name, int64_t len) {
   if (!nd) return -1;
   f->dims = nd;
   f->dims[f->ndims].name = strdup(name);
+  if (!f->dims[f->ndims].name) return -1;
   f->dims[f->ndims].len = len;
   return f->ndims++;
 }
 
 static int nc4_open_(const char *path, ncio_file **out) {
-  H5Eset_auto2(H5E_DEFAULT, NULL, NULL); /* failures are reported through ncio_strerror, not printed by the library */
   ncio_file *f = (ncio_file *)calloc(1, sizeof(*f));
   h5_t *h = (h5_t *)calloc(1, sizeof(*h));
   if (!f || !h) { free(f); free(h); return fail(NCIO_ENOMEM, "out of memory"); }
@@ -257,8 +258,12 @@ static int nc4_open_(const char *path, ncio_file **out) {
   /* pass 1: dimensions = the dimension scales, numbered by _Netcdf4Dimid where every scale carries one */
   int *is_scale = (int *)calloc((size_t)N.n + 1, sizeof(int)), *dim_only = (int *)calloc((size_t)N.n + 1, sizeof(int));
   int *dimid_att = (int *)calloc((size_t)N.n + 1, sizeof(int));
+  int *order = (int *)calloc((size_t)N.n + 1, sizeof(int)); /* scale datasets in dimension order */
+  if (!is_scale || !dim_only || !dimid_att || !order) rc = fail(NCIO_ENOMEM, "out of memory");
+  for (int i = 0; i < N.n && !rc; ++i)
+    if (!N.name[i]) rc = fail(NCIO_ENOMEM, "out of memory");   /* a strdup of the link walk came back empty */
   int nsc = 0, all_numbered = 1;
-  for (int i = 0; i < N.n; ++i) {
+  for (int i = 0; i < N.n && !rc; ++i) {
     if (H5DSis_scale(N.id[i]) <= 0) continue;
     is_scale[i] = 1;
     ++nsc;
@@ -274,15 +279,14 @@ static int nc4_open_(const char *path, ncio_file **out) {
     }
     if (dimid_att[i] < 0 || dimid_att[i] >= N.n) all_numbered = 0;
   }
-  int *order = (int *)calloc((size_t)N.n + 1, sizeof(int)); /* scale datasets in dimension order */
   int no = 0;
-  if (all_numbered && nsc > 0) {
+  if (!rc && all_numbered && nsc > 0) {
     for (int want = 0; want < N.n && no < nsc; ++want)
       for (int i = 0; i < N.n; ++i)
         if (is_scale[i] && dimid_att[i] == want) order[no++] = i;
     if (no != nsc) { no = 0; all_numbered = 0; }
   }
-  if (!all_numbered)
+  if (!rc && !all_numbered)
     for (int i = 0; i < N.n; ++i)
       if (is_scale[i]) order[no++] = i;
   for (int k = 0; k < no && !rc; ++k) {
@@ -299,9 +303,10 @@ static int nc4_open_(const char *path, ncio_file **out) {
   }
   /* pass 2: variables = every dataset that is not a dimension without a variable */
   int nvar = 0;
-  for (int i = 0; i < N.n; ++i) nvar += !(is_scale[i] && dim_only[i]);
+  for (int i = 0; i < N.n && !rc; ++i) nvar += !(is_scale[i] && dim_only[i]);
   f->vars = (var_t *)calloc((size_t)nvar + 1, sizeof(var_t));
   h->dset = (hid_t *)calloc((size_t)nvar + 1, sizeof(hid_t));
+  if (!rc && (!f->vars || !h->dset)) rc = fail(NCIO_ENOMEM, "out of memory");
   int phony = 0;
   for (int i = 0; i < N.n && !rc; ++i) {
     if (is_scale[i] && dim_only[i]) continue;
@@ -315,6 +320,7 @@ static int nc4_open_(const char *path, ncio_file **out) {
     if (!nct || nd > NCIO_MAX_DIMS) continue; /* a type or rank the classic model has no word for: not offered */
     var_t *x = &f->vars[f->nvars];
     x->name = strdup(N.name[i]);
+    if (!x->name) { rc = fail(NCIO_ENOMEM, "out of memory"); break; }
     x->type = nct;
     x->ndims = nd;
     for (int d = 0; d < nd; ++d) {
@@ -441,7 +447,6 @@ static int nc4_xfer_(ncio_file *f, int varid, int64_t rec, int mem_type, void *b
 
 /* ---- writing ---------------------------------------------------------------------------------------------------------- */
 static int nc4_create_(const char *path, ncio_file *f) {
-  H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
   h5_t *h = (h5_t *)calloc(1, sizeof(*h));
   if (!h) return fail(NCIO_ENOMEM, "out of memory");
   hid_t fcpl = H5Pcreate(H5P_FILE_CREATE); /* definition order survives: link and attribute creation order tracked, as libnetcdf sets it */
@@ -486,6 +491,7 @@ static int nc4_enddef_(ncio_file *f) {
   h->dset = (hid_t *)calloc((size_t)f->nvars + 1, sizeof(hid_t));
   h->scale = (hid_t *)calloc((size_t)f->ndims + 1, sizeof(hid_t));
   h->scale_own = (int *)calloc((size_t)f->ndims + 1, sizeof(int));
+  if (!h->dset || !h->scale || !h->scale_own) return fail(NCIO_ENOMEM, "out of memory");
   h->nscale = f->ndims;
   for (int v = 0; v < f->nvars; ++v) h->dset[v] = -1;
   for (int d = 0; d < f->ndims; ++d) h->scale[d] = -1;
@@ -494,6 +500,7 @@ static int nc4_enddef_(ncio_file *f) {
   /* a variable named like a dimension must BE its coordinate variable (one axis, that dimension): anything else needs libnetcdf's
    * renaming scheme ("_nc4_non_coord_"), which this writer does not speak */
   int *coord = (int *)calloc((size_t)f->ndims + 1, sizeof(int));
+  if (!coord) return fail(NCIO_ENOMEM, "out of memory");
   for (int d = 0; d < f->ndims; ++d) coord[d] = -1;
   for (int v = 0; v < f->nvars; ++v) {
     const int d = h5_find_dim(f, f->vars[v].name);
@@ -613,12 +620,19 @@ static int nc4_close_(ncio_file *f) {
 /* libhdf5 is not thread-safe in its usual build, and hosts do use two threads (io_nc.run_series reads the next file while the current one is
  * written): every entry into the library goes through one lock. */
 static pthread_mutex_t g_h5_lock = PTHREAD_MUTEX_INITIALIZER;
-#define NC4_LOCKED(call)                \
-  do {                                  \
-    pthread_mutex_lock(&g_h5_lock);     \
-    int rc_ = (call);                   \
-    pthread_mutex_unlock(&g_h5_lock);   \
-    return rc_;                         \
+/* Failures are reported through ncio_strerror, not printed by libhdf5 -- but only while THIS code is inside the library: the host process's
+ * own error handler (another HDF5 user's printing, a test harness's hook) is saved on entry and put back on the way out. */
+#define NC4_LOCKED(call)                                   \
+  do {                                                     \
+    pthread_mutex_lock(&g_h5_lock);                        \
+    H5E_auto2_t efn_ = NULL;                               \
+    void *edata_ = NULL;                                   \
+    H5Eget_auto2(H5E_DEFAULT, &efn_, &edata_);             \
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);                 \
+    int rc_ = (call);                                      \
+    H5Eset_auto2(H5E_DEFAULT, efn_, edata_);               \
+    pthread_mutex_unlock(&g_h5_lock);                      \
+    return rc_;                                            \
   } while (0)
 static int nc4_open(const char *path, ncio_file **out) { NC4_LOCKED(nc4_open_(path, out)); }
 static int nc4_xfer(ncio_file *f, int varid, int64_t rec, int mem_type, void *buf, int writing, const char *who) {

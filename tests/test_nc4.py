@@ -343,3 +343,37 @@ def test_two_threads_inside_the_hdf5_backend(ncio, tmp_path):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_the_hosts_hdf5_error_handler_survives_ncio_calls(tmp_path, ncio):
+    """Round-5 advisor: nc4_open_ / nc4_create_ switched libhdf5's automatic error printing off for the WHOLE process.  The handler a host
+    installed (another HDF5 user's printing, a harness's hook) is now saved on entry and put back on the way out of every ncio call --
+    asked of the very libhdf5 the library is linked against, around a failing open and a successful write."""
+    import ctypes
+    from mpassit_amd import build
+    h5 = build.find_hdf5()
+    lib = ctypes.CDLL(os.path.join(h5[1], "libhdf5.so"), mode=ctypes.RTLD_GLOBAL)
+    lib.H5open()
+    CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int64, ctypes.c_void_p)
+    calls = []
+    cb = CB(lambda stack, data: calls.append(1) or 0)
+    lib.H5Eset_auto2.argtypes = [ctypes.c_int64, CB, ctypes.c_void_p]
+    lib.H5Eget_auto2.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    tag = ctypes.c_void_p(0x5EED)
+    assert lib.H5Eset_auto2(0, cb, tag) >= 0                      # H5E_DEFAULT = 0
+    try:
+        bad = str(tmp_path / "bad.nc")
+        open(bad, "wb").write(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)   # the magic, then nothing libhdf5 can use
+        with pytest.raises(Exception):
+            ncio.Reader(bad)
+        good = str(tmp_path / "good.nc")
+        with ncio.Writer(good, format=4) as w:
+            w.def_dim("x", 3)
+            w.def_var("v", ncio.FLOAT, ("x",))
+            w.put("v", np.arange(3, dtype=np.float32))
+        fn, data = ctypes.c_void_p(), ctypes.c_void_p()
+        assert lib.H5Eget_auto2(0, ctypes.byref(fn), ctypes.byref(data)) >= 0
+        assert fn.value == ctypes.cast(cb, ctypes.c_void_p).value and data.value == 0x5EED
+        assert not calls                                           # and the library's own failures stayed silent
+    finally:
+        lib.H5Eset_auto2(0, CB(0), None)
