@@ -7,7 +7,7 @@
 // The reference (and this library until round 5: k_rotate + 2 x k_applyN<4>) makes three passes: the rotation reads and
 // rewrites both mass fields, each destaggering reads one of them again.  u/v_target_grid_nostag are intermediates the
 // reference never writes to its file (write_data.F90 has no `nostag`), so here the earth-relative mass winds are read ONCE:
-// a workgroup owns 64 x 16 points of the (i, j) index space, stages the (64 + 2 + 15) x (16 + 2) window of mass points
+// a workgroup owns 64 x 16 points of the (i, j) index space, stages the (64 + 2 + WD_A - 1) x (16 + 2) window of mass points
 // around them in LDS -- rotated on the way in, with the operation sequence of interp.F90:737-748 (no contraction, as
 // k_rotate: bit-identical) -- and combines every U point (EDGE1, nx + 1 columns) and every V point (EDGE2, ny + 1 rows) of
 // its tile from there with the 4-point weights of the two Grid -> Grid handles, in k_applyN's accumulation order (the same
@@ -15,8 +15,8 @@
 // of indices and weights and 16 B of rotation angles per point, once per launch) against 4 x 8 + 2 x (8 + e_dst) before.
 //
 // Store segments: a wave stores 64 consecutive points of ONE output row, and each row's segment is shifted left so that it
-// starts on a multiple of 16 elements in memory whatever the row length (U rows are nx + 1 = 1801 wide on the README's
-// grid: unshifted, every segment would straddle one more line and leave two partial lines to another workgroup); the 15
+// starts on a multiple of WD_A = 8 elements in memory whatever the row length (U rows are nx + 1 = 1801 wide on the README's
+// grid: unshifted, every segment would straddle one more line and leave two partial lines to another workgroup); the 7
 // extra window columns pay for that.  The window is double-buffered (one barrier per level) and level k + 1 is in flight
 // in registers while level k is combined.
 // Generality: the handles are ordinary Grid -> Grid handles (k_store_gridbil.hip); a point whose four sources do not all
@@ -35,7 +35,7 @@
 #ifndef WD_A
 #define WD_A 8                          // store segments start on multiples of 8 elements (A/B r06: 1, 8, 16, 32 within 4 %, 8 ahead)
 #endif
-#define WD_WW (WD_TX + 2 + WD_A - 1)    // 81 window columns: i0 - 16 .. i0 + 64
+#define WD_WW (WD_TX + 2 + WD_A - 1)    // 73 window columns: i0 - WD_A .. i0 + 64
 #define WD_WH (WD_TY + 2)               // 18 window rows:    j0 - 1  .. j0 + 16
 #define WD_NW (WD_WW * WD_WH)
 #define WD_WPT ((WD_NW + WD_NT - 1) / WD_NT)

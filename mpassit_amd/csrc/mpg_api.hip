@@ -658,7 +658,9 @@ static int store_build_now(StoreJob &job, hipStream_t s) {
 }
 
 static void store_worker_main(int device) {
-  if (hipSetDevice(device) != hipSuccess) return;
+  // a worker that cannot bind its device keeps serving the queue -- with the error: a thread that simply left would make every later
+  // RegridStore wait for ever on a job nobody runs
+  const hipError_t dev_err = hipSetDevice(device);
   for (;;) {
     std::shared_ptr<StoreJob> job;
     {
@@ -669,8 +671,14 @@ static void store_worker_main(int device) {
       SW().queue.pop_front();
     }
     g_err[0] = 0;
-    if (job->ready) (void)hipStreamWaitEvent(SW().stream, job->ready, 0);
-    const int rc = store_build_now(*job, SW().stream);
+    int rc;
+    if (dev_err != hipSuccess) {
+      mpg_set_error("RegridStore: the Store worker could not bind device %d: %s", device, hipGetErrorString(dev_err));
+      rc = MPG_ERR_HIP;
+    } else {
+      if (job->ready) (void)hipStreamWaitEvent(SW().stream, job->ready, 0);
+      rc = store_build_now(*job, SW().stream);
+    }
     {
       std::lock_guard<std::mutex> lk(SW().mu);
       job->rc = rc;
