@@ -178,11 +178,21 @@ typedef unsigned buf_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ BufRsrc buf_rsrc(const void *base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
+// -DMPG_SRC_NT (A/B builds only, mpassit_amd.build.build_alt): the staged kernels' source loads carry the "nt" bit -- every cell is
+// loaded once per tile, L1 has nothing to give them.  Measured 16-55 % SLOWER (profiles/r06_src_nt_loads.txt: the bit also makes the lines evict-first
+// in L2, and a row's next 64-byte chunk and the neighbour tile's ring are then fetched again): not in the product build.
+#ifdef MPG_SRC_NT
+#define MPG_SRC_AUX 2
+#define MPG_LDG(p) __builtin_nontemporal_load(p)
+#else
+#define MPG_SRC_AUX 0
+#define MPG_LDG(p) (*(p))
+#endif
 __device__ __forceinline__ void buf_load(float &v, BufRsrc r, uint32_t lane_off, uint32_t wave_off) {
-  v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)wave_off, 0));
+  v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)wave_off, MPG_SRC_AUX));
 }
 __device__ __forceinline__ void buf_load(double &v, BufRsrc r, uint32_t lane_off, uint32_t wave_off) {
-  v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)wave_off, 0));
+  v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)wave_off, MPG_SRC_AUX));
 }
 // non-temporal (aux = 2: the "nt" bit of gfx94x / gfx950)
 __device__ __forceinline__ void buf_store_nt(float v, BufRsrc r, uint32_t lane_off) {

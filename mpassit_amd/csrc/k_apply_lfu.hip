@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ u
 #pragma unroll
   for (int lv = 0; lv < LC; ++lv)
 #pragma unroll
-    for (int u = 0; u < UPT; ++u) pf[lv * UPT + u] = (cell[u] >= 0 && lv < nlev) ? sf[(int64_t)lv * nsrc + cell[u]] : (TS)0;
+    for (int u = 0; u < UPT; ++u) pf[lv * UPT + u] = (cell[u] >= 0 && lv < nlev) ? MPG_LDG(sf + ((int64_t)lv * nsrc + cell[u])) : (TS)0;
   for (int k0 = 0; k0 < nlev; k0 += LC) {
 #pragma unroll
     for (int lv = 0; lv < LC; ++lv)
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ u
       for (int lv = 0; lv < LC; ++lv)
 #pragma unroll
         for (int u = 0; u < UPT; ++u)
-          pf[lv * UPT + u] = (cell[u] >= 0 && kn1 + lv < nlev) ? sf[(int64_t)(kn1 + lv) * nsrc + cell[u]] : (TS)0;
+          pf[lv * UPT + u] = (cell[u] >= 0 && kn1 + lv < nlev) ? MPG_LDG(sf + ((int64_t)(kn1 + lv) * nsrc + cell[u])) : (TS)0;
     }
     const int kn = min(LC, nlev - k0);
     for (int kk = 0; kk < kn; ++kk) {
