@@ -320,6 +320,11 @@ int mpg_k_tune(const char *key, int value) {
     mpg_lfu_set_npf(value);
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "staged_lds_pad_kb")) {   // A/B only: extra dynamic LDS (KB) for the staged Regrid kernels = fewer workgroups per CU (the kernels live on L2 keeping what
+    if (value < -1 || value > 128) return MPG_ERR_INVALID_ARG;   // they stream, profiles/r06_src_nt_loads.txt: does a smaller in-flight working set pay for the latency hiding it costs?)
+    mpg_set_staged_lds_pad_kb(value < 0 ? 0 : value);
+    return MPG_SUCCESS;
+  }
   if (!strcmp(key, "lfu_min_reuse_x10")) {
     if (value < 0 || value > 1000) return MPG_ERR_INVALID_ARG;
     mpg_lfu_set_min_reuse_x10(value);

@@ -27,6 +27,7 @@
 #include <limits.h>
 #include <string.h>
 
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -34,6 +35,8 @@
 #include "mpg_internal.h"
 
 int mpg_field_band(int kernel_default);
+static int g_staged_lds_pad_kb = 0;   // "staged_lds_pad_kb" knob (A/B): extra dynamic LDS per workgroup of k_apply3_cfu / k_apply3_lfu
+void mpg_set_staged_lds_pad_kb(int v) { g_staged_lds_pad_kb = v; }
 #define LFU_THREADS 256
 #define LFU_LIST_PAD 1024  // a tile's list is padded with its last cell up to the row count of its class: 64, 128 ... this many (min stride)
 #define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two
@@ -507,6 +510,7 @@ static int launch_cfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align), nty = (h->ny_dst + TYU - 1) / TYU;
   const size_t um = h->ut_max > 0 ? h->ut_max : 1;   // unmapped points read slot 0
   size_t lds = sizeof(double) * um * 4 + 16;
+  lds = std::min<size_t>(lds + (size_t)g_staged_lds_pad_kb * 1024, std::max<size_t>(lds, 160 * 1024));
   if (lds > 160 * 1024) {
     mpg_set_error("Regrid(CELL_FAST, staged): %d unique cells per tile exceed the LDS", h->ut_max);
     return MPG_ERR_UNSUPPORTED;
@@ -661,7 +665,8 @@ static int launch_lfu_n(mpg_handle_s *h, const void *src, int nlev, int nfields,
   if (n_cls == 0) return MPG_SUCCESS;
   const int ntx = mpg_tile_ntx(h->nx_dst, 64, h->ut_align);
   constexpr int ROWS = NT / 16 * NPF;   // rows of the slab
-  const size_t lds = sizeof(TS) * (ROWS + 1) * 17;
+  size_t lds = sizeof(TS) * (ROWS + 1) * 17;
+  lds = std::min<size_t>(lds + (size_t)g_staged_lds_pad_kb * 1024, std::max<size_t>(lds, 160 * 1024));
   static_assert(ROWS <= LFU_LIST_PAD, "the kernel reads ROWS list entries of every tile");
   auto fn = (sbe || dbe) ? k_apply3_lfu<TS, TD, NT, EPI, true, NPF> : k_apply3_lfu<TS, TD, NT, EPI, false, NPF>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
