@@ -244,6 +244,16 @@ int mpg_rotate_winds_dev(int64_t npts, int nlev, const double *cosa_dev, const d
 int mpg_wind_destagger_dev(mpg_handle rh_edge1, mpg_handle rh_edge2, const double *cosa_dev, const double *sina_dev,
                            const double *umass_dev, const double *vmass_dev, int nlev, void *u_dev, void *v_dev, int dst_type,
                            double *umass_rot_dev, double *vmass_rot_dev, void *hip_stream);
+/* The same chain for a host that keeps its fields in HOST arrays, as the reference does (farrayPtr in, farrayPtr out: interp.F90:702-735
+ * fetches the pointers, :291-328 runs the chain).  The three separate host calls -- mpg_rotate_winds, then mpg_regrid on each handle --
+ * move 4 fields up and 4 down over the link; this one moves the earth-relative mass winds up ONCE in chunks of levels and only U and V
+ * down, both directions at once (2 up, 2 down: the chain is link-bound, so about half the time).  Same bits as mpg_wind_destagger_dev.
+ * All pointers are host pointers; cosa_host / sina_host [ny][nx] or both NULL; umass_rot_host / vmass_rot_host optional (NULL) and --
+ * unlike the device form -- MAY be the input arrays themselves: rotate_winds_cgrid's in-place result (a level's rotated winds come
+ * down after that level went up).  Blocks until every destination is complete. */
+int mpg_wind_destagger(mpg_handle rh_edge1, mpg_handle rh_edge2, const double *cosa_host, const double *sina_host,
+                       const double *umass_host, const double *vmass_host, int nlev, void *u_host, void *v_host, int dst_type,
+                       double *umass_rot_host, double *vmass_rot_host);
 
 /* ---- output epilogues: what write_data.F90 computes on rank 0 between ESMF_FieldGather and nf90_put_var, done on
  * the device-resident regridded fields so that only final float32 arrays leave the GPU.

@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("MPASSIT_AMD_LIB") or os.path.join(_HERE, "libmpassit_a
 SYMBOLS = [
     "mpg_init", "mpg_finalize", "mpg_last_error", "mpg_device_info", "mpg_mesh_create", "mpg_mesh_create_window", "mpg_mesh_window_info", "mpg_mesh_destroy",
     "mpg_grid_create", "mpg_grid_attach_proj", "mpg_grid_destroy", "mpg_regrid_store", "mpg_regrid_store_grid", "mpg_regrid_store_begin", "mpg_regrid_store_grid_begin", "mpg_regrid",
-    "mpg_regrid_dev", "mpg_regrid_typed_dev", "mpg_regrid_typed", "mpg_handle_release", "mpg_rotate_winds", "mpg_rotate_winds_dev", "mpg_wind_destagger_dev", "mpg_handle_info",
+    "mpg_regrid_dev", "mpg_regrid_typed_dev", "mpg_regrid_typed", "mpg_handle_release", "mpg_rotate_winds", "mpg_rotate_winds_dev", "mpg_wind_destagger_dev", "mpg_wind_destagger", "mpg_handle_info",
     "mpg_handle_from_weights", "mpg_handle_get_weights", "mpg_handle_get_csr", "mpg_mesh_get_triangles", "mpg_handle_unique_sources",
     "mpg_handle_localize", "mpg_handle_rebase", "mpg_pack_dev", "mpg_handle_store_ms", "mpg_regrid_bundle_typed_dev", "mpg_regrid_bundle_typed", "mpg_handle_store_path", "mpg_tune", "mpg_handle_pole_count", "mpg_handle_kernel_choice", "mpg_handle_tile_stats",
     "mpg_handle_get_pole", "mpg_bswap_dev", "mpg_file_to_dev", "mpg_dev_to_file", "mpg_dev_alloc", "mpg_dev_free", "mpg_dev_upload", "mpg_dev_download", "mpg_post_cast_dev", "mpg_post_layer_mean_dev", "mpg_post_ptop_dev", "mpg_post_ptop_parts_dev", "mpg_grid_create_proj", "mpg_grid_get_coords",

@@ -17,6 +17,7 @@
 // runtime pins a pageable range on first use and remembers it, repeated calls on the same buffers run at the pinned rate.
 // hipMalloc is expensive too (55-145 ms for the 2.2 GB of one float64 field), so the device slots, streams and the
 // download thread's stream are created once per process and reused by every call (released by mpg_finalize).
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -225,5 +226,105 @@ static int run_plan(mpg_handle h, const std::vector<Chunk> &plan, int src_f32, i
   (void)hipStreamSynchronize(s_up);
   (void)hipStreamSynchronize(s_down);
   if (rc == MPG_ERR_HIP) mpg_set_error("mpg_regrid_typed: a HIP call of the transfer pipeline failed: %s", hipGetErrorString(hipGetLastError()));
+  return rc;
+}
+
+// ---- the wind chain for a host that holds its fields in HOST arrays (interp.F90:291-328 as the reference runs it: farrayPtr
+// in, farrayPtr out).  The three separate calls (mpg_rotate_winds + two mpg_regrid) move the mass winds over the link twice in
+// each direction -- up and down for the in-place rotation, up again for each destaggering -- and the staggered winds down once:
+// 4 fields up, 4 down.  Here the earth-relative mass winds go up ONCE in chunks of levels, k_wind_destagger runs on each chunk,
+// and only U and V (plus, on request, the rotated mass winds) come down: 2 up, 2 down, both directions busy at once (the pipeline
+// of run_plan above: upload of chunk c + 1 and its kernel on the calling thread, download of chunk c - 1 on a helper thread).
+extern "C" int mpg_wind_destagger(mpg_handle h1, mpg_handle h2, const double *cosa_host, const double *sina_host, const double *umass_host,
+                                  const double *vmass_host, int nlev, void *u_host, void *v_host, int dst_type, double *umass_rot_host,
+                                  double *vmass_rot_host) {
+  MPG_CHECK_INIT();
+  MPG_ARG(h1 || h2, "mpg_wind_destagger: no handle");
+  MPG_ARG((cosa_host == nullptr) == (sina_host == nullptr), "mpg_wind_destagger: cosa and sina come together");
+  const bool rot = cosa_host != nullptr;
+  MPG_ARG(!rot || (h1 && h2), "mpg_wind_destagger: the rotation needs both components (interp.F90:291)");
+  MPG_ARG((!h1 || u_host) && (!h2 || v_host), "mpg_wind_destagger: NULL destination");
+  MPG_ARG((!(h1 || rot) || umass_host) && (!(h2 || rot) || vmass_host), "mpg_wind_destagger: NULL mass field");
+  MPG_ARG(nlev >= 1, "mpg_wind_destagger: nlev must be >= 1");
+  MPG_ARG(dst_type >= 0 && dst_type <= 3, "mpg_wind_destagger: dst_type must be MPG_TYPE_F64 or MPG_TYPE_F32, optionally | MPG_TYPE_BE");
+  MPG_ARG(rot || (!umass_rot_host && !vmass_rot_host), "mpg_wind_destagger: rotated mass winds asked for without a rotation");
+  const int nx = h2 ? h2->nx_dst : h1->nx_dst - 1, ny = h2 ? h2->ny_dst - 1 : h1->ny_dst;
+  MPG_ARG(nx >= 1 && ny >= 1, "mpg_wind_destagger: the handles are not the CENTER -> EDGE1 / EDGE2 pair of one grid");
+  const size_t NP = (size_t)nx * ny, P1 = (size_t)(nx + 1) * ny, P2 = (size_t)nx * (ny + 1), ed = (dst_type & MPG_TYPE_F32) ? 4 : 8;
+  const bool src_u = rot || h1, src_v = rot || h2;
+  int lch = (int)((96u << 20) / (2 * NP * 8));
+  lch = lch < 1 ? 1 : (lch > nlev ? nlev : lch);
+  const int nchunk = (nlev + lch - 1) / lch;
+  // slot layout: source  um[lch][NP] | vm[lch][NP];  result  u[lch][P1] | v[lch][P2] | um_rot[lch][NP] | vm_rot[lch][NP]  (8-byte aligned parts)
+  const size_t so_v = (size_t)lch * NP * 8, s_bytes = 2 * so_v;
+  const size_t do_v = ((size_t)lch * P1 * ed + 7) & ~(size_t)7, do_ur = do_v + (((size_t)lch * P2 * ed + 7) & ~(size_t)7), do_vr = do_ur + so_v,
+               d_bytes = do_vr + so_v;
+  std::lock_guard<std::mutex> pipe_lock(g_pipe.mu);
+  int rc = g_pipe.ensure(s_bytes + 16, d_bytes + 16);
+  if (rc) return rc;
+  hipStream_t s_up = g_pipe.s_up, s_k = g_pipe.s_k, s_down = g_pipe.s_down;
+  TmpBuf<double> cs;
+  if (rot) {
+    if ((rc = cs.alloc(2 * NP, s_up))) return rc;
+    MPG_HIP(hipMemcpyAsync(cs.p, cosa_host, 8 * NP, hipMemcpyHostToDevice, s_up));
+    MPG_HIP(hipMemcpyAsync(cs.p + NP, sina_host, 8 * NP, hipMemcpyHostToDevice, s_up));
+  }
+  struct Res {
+    std::vector<hipEvent_t> up, done;
+    ~Res() {
+      for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
+      for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+    }
+  } res;
+  res.up.assign((size_t)nchunk, nullptr);
+  res.done.assign((size_t)nchunk, nullptr);
+  for (int c = 0; c < nchunk; ++c) {
+    MPG_HIP(hipEventCreateWithFlags(&res.up[(size_t)c], hipEventDisableTiming));
+    MPG_HIP(hipEventCreateWithFlags(&res.done[(size_t)c], hipEventDisableTiming));
+  }
+  std::atomic<int> produced{0}, consumed{0}, err{0};
+  const int dev = mpg_device_index();
+  char *const *dsrc = g_pipe.dsrc, *const *ddst = g_pipe.ddst;
+  std::thread down([&]() {
+    if (hipSetDevice(dev) != hipSuccess) { err = MPG_ERR_HIP; return; }
+    for (int c = 0; c < nchunk; ++c) {
+      while (produced.load(std::memory_order_acquire) <= c) {
+        if (err.load()) return;
+        std::this_thread::yield();
+      }
+      const int q = c % NSLOT, l0 = c * lch, nl = std::min(lch, nlev - l0);
+      bool ok = hipStreamWaitEvent(s_down, res.done[(size_t)c], 0) == hipSuccess;
+      if (ok && h1) ok = hipMemcpyAsync((char *)u_host + (size_t)l0 * P1 * ed, ddst[q], (size_t)nl * P1 * ed, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+      if (ok && h2) ok = hipMemcpyAsync((char *)v_host + (size_t)l0 * P2 * ed, ddst[q] + do_v, (size_t)nl * P2 * ed, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+      if (ok && umass_rot_host) ok = hipMemcpyAsync(umass_rot_host + (size_t)l0 * NP, ddst[q] + do_ur, (size_t)nl * NP * 8, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+      if (ok && vmass_rot_host) ok = hipMemcpyAsync(vmass_rot_host + (size_t)l0 * NP, ddst[q] + do_vr, (size_t)nl * NP * 8, hipMemcpyDeviceToHost, s_down) == hipSuccess;
+      if (ok) ok = hipStreamSynchronize(s_down) == hipSuccess;
+      if (!ok) { err = MPG_ERR_HIP; return; }
+      consumed.store(c + 1, std::memory_order_release);
+    }
+  });
+  rc = MPG_SUCCESS;
+  for (int c = 0; c < nchunk && !rc && !err.load(); ++c) {
+    const int q = c % NSLOT, l0 = c * lch, nl = std::min(lch, nlev - l0);
+    while (c >= NSLOT && consumed.load(std::memory_order_acquire) <= c - NSLOT && !err.load()) std::this_thread::yield();
+    if (src_u && hipMemcpyAsync(dsrc[q], umass_host + (size_t)l0 * NP, (size_t)nl * NP * 8, hipMemcpyHostToDevice, s_up) != hipSuccess) rc = MPG_ERR_HIP;
+    if (!rc && src_v && hipMemcpyAsync(dsrc[q] + so_v, vmass_host + (size_t)l0 * NP, (size_t)nl * NP * 8, hipMemcpyHostToDevice, s_up) != hipSuccess) rc = MPG_ERR_HIP;
+    if (!rc && (hipEventRecord(res.up[(size_t)c], s_up) != hipSuccess || hipStreamWaitEvent(s_k, res.up[(size_t)c], 0) != hipSuccess)) rc = MPG_ERR_HIP;
+    if (!rc)
+      rc = mpg_k_wind_destagger(h1, h2, rot ? cs.p : nullptr, rot ? cs.p + NP : nullptr, (const double *)dsrc[q], (const double *)(dsrc[q] + so_v), nl, ddst[q],
+                                ddst[q] + do_v, dst_type, umass_rot_host ? (double *)(ddst[q] + do_ur) : nullptr,
+                                vmass_rot_host ? (double *)(ddst[q] + do_vr) : nullptr, s_k);
+    if (!rc && hipEventRecord(res.done[(size_t)c], s_k) != hipSuccess) rc = MPG_ERR_HIP;
+    if (!rc) produced.store(c + 1, std::memory_order_release);
+  }
+  if (rc) err = rc;
+  down.join();
+  if (!rc && err.load()) rc = err.load();
+  (void)hipStreamSynchronize(s_k);
+  (void)hipStreamSynchronize(s_up);
+  (void)hipStreamSynchronize(s_down);
+  cs.free();
+  if (rc == MPG_ERR_UNSUPPORTED) mpg_set_error("mpg_wind_destagger: the handles are not the CENTER -> EDGE1 / EDGE2 pair of one grid");
+  else if (rc == MPG_ERR_HIP) mpg_set_error("mpg_wind_destagger: a HIP call of the transfer pipeline failed: %s", hipGetErrorString(hipGetLastError()));
   return rc;
 }

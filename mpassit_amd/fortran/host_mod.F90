@@ -378,7 +378,7 @@ module target_grid
   implicit none
   public
   real(dp), allocatable :: lat_m(:, :), lon_m(:, :), lat_u(:, :), lon_u(:, :), lat_v(:, :), lon_v(:, :)
-  real(dp), allocatable :: cosa(:, :), sina(:, :), mapfac_m(:, :), mapfac_u(:, :), mapfac_v(:, :)
+  real(dp), allocatable, target :: cosa(:, :), sina(:, :), mapfac_m(:, :), mapfac_u(:, :), mapfac_v(:, :)
 contains
   subroutine define_target_grid_params(grid_h)
     type(c_ptr), intent(out) :: grid_h

@@ -325,6 +325,10 @@ contains
       ! device-resident fields: rotation and both destaggerings in ONE pass over the mass winds (mpg_wind_destagger_dev); a pair of
       ! handles it does not take (MPG_ERR_UNSUPPORTED) leaves the three calls below to do the work
       if (wind_chain_fused()) go to 100
+    else if (do_u_interp == 1 .or. do_v_interp == 1) then
+      ! host arrays: the same chain through ONE upload of the mass winds (mpg_wind_destagger) instead of three calls that move them
+      ! up twice and down once more
+      if (wind_chain_fused_host()) go to 100
     end if
     if (do_u_interp == 1 .and. do_v_interp == 1 .and. proj_code == PROJ_LC) call rotate_winds_cgrid(umass, vmass)
     if (do_u_interp == 1) then          ! UMASS(CENTER) -> U(EDGE1), interp.F90:295-311
@@ -450,6 +454,66 @@ contains
     call mpg_check(rc, "IN wind_destagger")
     wind_chain_fused = .true.
   end function wind_chain_fused
+
+  !> interp.F90:291-328 on HOST arrays (the NetCDF-4 / raw-file flows): mpg_wind_destagger uploads the float64 mass winds once in chunks of
+  !! levels and brings back U and V as the output holds them (NF90_FLOAT for a NetCDF file, float64 else); the rotated mass winds come
+  !! back into umass / vmass only where they are output variables (the raw format: not f32_out).  Bit-identical to the three calls.
+  !! .false.: the library does not take this pair of handles, or the mass winds are not float64 host arrays -- nothing has been done.
+  logical function wind_chain_fused_host()
+    type(c_ptr) :: rh_u, rh_v, ca, sa, pum, pvm, pu, pv, pur, pvr
+    integer(c_int64_t) :: n_src, n_dst, nnz
+    integer(c_int) :: nxd, nyd, npr, rc, nlev
+    logical :: rot
+    wind_chain_fused_host = .false.
+    rh_u = c_null_ptr; rh_v = c_null_ptr; ca = c_null_ptr; sa = c_null_ptr
+    pum = c_null_ptr; pvm = c_null_ptr; pu = c_null_ptr; pv = c_null_ptr; pur = c_null_ptr; pvr = c_null_ptr
+    rot = do_u_interp == 1 .and. do_v_interp == 1 .and. proj_code == PROJ_LC
+    nlev = int(merge(umass%nlev, vmass%nlev, do_u_interp == 1), c_int)
+    if (do_u_interp == 1) then
+      if (.not. allocated(umass%dst)) return
+    end if
+    if (do_v_interp == 1) then
+      if (.not. allocated(vmass%dst)) return
+    end if
+    if (do_u_interp == 1) then
+      call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE1, MPG_REGRIDMETHOD_BILINEAR, rh_u), &
+                     "IN FieldRegridStore")
+      call mpg_check(mpg_handle_info(rh_u, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+      if (allocated(u_field%dst)) deallocate (u_field%dst)
+      if (allocated(u_field%dst4)) deallocate (u_field%dst4)
+      if (f32_out) then
+        allocate (u_field%dst4(n_dst*nlev)); pu = c_loc(u_field%dst4)
+      else
+        allocate (u_field%dst(n_dst*nlev)); pu = c_loc(u_field%dst)
+      end if
+      pum = c_loc(umass%dst)
+    end if
+    if (do_v_interp == 1) then
+      call mpg_check(mpg_regrid_store_grid(target_grid_h, MPG_STAGGERLOC_CENTER, MPG_STAGGERLOC_EDGE2, MPG_REGRIDMETHOD_BILINEAR, rh_v), &
+                     "IN FieldRegridStore")
+      call mpg_check(mpg_handle_info(rh_v, n_src, n_dst, nxd, nyd, npr, nnz), "IN HandleInfo")
+      if (allocated(v_field%dst)) deallocate (v_field%dst)
+      if (allocated(v_field%dst4)) deallocate (v_field%dst4)
+      if (f32_out) then
+        allocate (v_field%dst4(n_dst*nlev)); pv = c_loc(v_field%dst4)
+      else
+        allocate (v_field%dst(n_dst*nlev)); pv = c_loc(v_field%dst)
+      end if
+      pvm = c_loc(vmass%dst)
+    end if
+    if (rot) then
+      ca = c_loc(cosa); sa = c_loc(sina)
+      if (.not. f32_out) then        ! UMASS / VMASS are output variables of the raw format: rotated in place, as rotate_winds_cgrid leaves them
+        pur = pum; pvr = pvm
+      end if
+    end if
+    rc = mpg_wind_destagger(rh_u, rh_v, ca, sa, pum, pvm, nlev, pu, pv, merge(MPG_TYPE_F32, MPG_TYPE_F64, f32_out), pur, pvr)
+    if (c_associated(rh_u)) call mpg_check(mpg_handle_release(rh_u), "IN FieldRegridRelease")
+    if (c_associated(rh_v)) call mpg_check(mpg_handle_release(rh_v), "IN FieldRegridRelease")
+    if (rc == MPG_ERR_UNSUPPORTED) return
+    call mpg_check(rc, "IN wind_destagger")
+    wind_chain_fused_host = .true.
+  end function wind_chain_fused_host
 
   !> mesh field `src` -> CENTER-stagger field `dst` (uReconstructZonal -> UMASS, interp.F90:256-289)
   subroutine regrid_to(rh, src, dst)

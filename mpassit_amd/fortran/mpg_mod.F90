@@ -225,6 +225,15 @@ module mpg
       integer(c_int), value :: nlev, dst_type
       integer(c_int) :: rc
     end function mpg_wind_destagger_dev
+    !> the same chain on HOST arrays: the mass winds cross the link once, only U and V (and, on request, the rotated mass winds -- which
+    !! may be the input arrays: rotate_winds_cgrid's in-place result) come back (include/mpassit_amd.h)
+    function mpg_wind_destagger(rh_edge1, rh_edge2, cosa, sina, umass, vmass, nlev, u, v, dst_type, umass_rot, vmass_rot) &
+      bind(C, name="mpg_wind_destagger") result(rc)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: rh_edge1, rh_edge2, cosa, sina, umass, vmass, u, v, umass_rot, vmass_rot
+      integer(c_int), value :: nlev, dst_type
+      integer(c_int) :: rc
+    end function mpg_wind_destagger
 
     !> device buffers for fields that stay in HBM between the input and the output file
     function mpg_dev_alloc(nbytes, dev) bind(C, name="mpg_dev_alloc") result(rc)

@@ -144,19 +144,27 @@ def _destagger_local(grid, staggerloc, mass, nz):
 
 
 def _wind_chain_fused(grid, target, cfg, um, vm, rot, nz, out, destagger):
-    """interp.F90:291-328 through mpg_wind_destagger_dev when the mass winds are device-resident and the destaggering is this
-    grid's own (no row halo supplied by a sharded driver): one pass instead of three, the same bits.  -> False: the caller
-    takes the three-call chain."""
+    """interp.F90:291-328 through mpg_wind_destagger_dev (device-resident mass winds) or mpg_wind_destagger (host arrays) when the
+    destaggering is this grid's own (no row halo supplied by a sharded driver): one pass instead of three, the same bits.
+    -> False: the caller takes the three-call chain."""
     ref = um if um is not None else vm
-    if destagger is not None or not cfg.fused_winds or not _is_torch(ref) or not ref.is_cuda:
+    if destagger is not None or not cfg.fused_winds:
         return False
-    import torch
-    if any(t is not None and t.dtype != torch.float64 for t in (um, vm)):
-        return False
+    host = not _is_torch(ref)
+    if host:                                   # HOST arrays (mpg_wind_destagger): the mass winds go up once, only U and V come down
+        if any(t is not None and (not isinstance(t, np.ndarray) or t.dtype != np.float64) for t in (um, vm)):
+            return False
+    else:
+        import torch
+        if not ref.is_cuda or any(t is not None and t.dtype != torch.float64 for t in (um, vm)):
+            return False
     rh_u = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1) if um is not None else None      # :298
     rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2) if vm is not None else None      # :316
     try:
-        cosa, sina = _rot_angles_dev(target, ref.device, grid) if rot else (None, None)
+        if host:
+            cosa, sina = (target.cosa, target.sina) if rot else (None, None)
+        else:
+            cosa, sina = _rot_angles_dev(target, ref.device, grid) if rot else (None, None)
         try:
             u, v, ur, vr = R.wind_destagger(rh_u, rh_v, cosa, sina, um, vm, nz, keep_mass=cfg.keep_mass_winds)
         except R.L.MpgError as e:

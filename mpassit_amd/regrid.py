@@ -527,15 +527,34 @@ def rotate_winds_cgrid(cosa, sina, u, v):
 
 
 def wind_destagger(rh_u, rh_v, cosa, sina, umass, vmass, nlev, out_dtype=None, dst_be=False, keep_mass=False):
-    """interp.F90:291-328 in one pass (mpg_wind_destagger_dev): rotate_winds_cgrid on the CENTER-stagger winds (cosa / sina
+    """interp.F90:291-328 in one pass (mpg_wind_destagger_dev; numpy arrays: mpg_wind_destagger): rotate_winds_cgrid on the CENTER-stagger winds (cosa / sina
     None: no rotation) + UMASS -> U(EDGE1) + VMASS -> V(EDGE2).  rh_u / rh_v: the regrid_store_grid handles of ONE grid (either
-    may be None); umass / vmass: float64 CUDA tensors [nlev][ny][nx], not modified.  Returns (U, V, UMASS', VMASS'): U
+    may be None); umass / vmass: float64 CUDA tensors (or numpy arrays) [nlev][ny][nx], not modified.  Returns (U, V, UMASS', VMASS'): U
     [nlev][ny][nx+1], V [nlev][ny+1][nx] of out_dtype (float64), the rotated mass winds only with keep_mass (else None).
     Bit-identical to rotate_winds_cgrid followed by the two handles' regrid().  Raises MpgError(rc = MPG_ERR_UNSUPPORTED) for
     handles that are not such a pair (re-indexed ones)."""
-    import torch
     ref = umass if umass is not None else vmass
     rot = cosa is not None
+    if not _is_torch(ref):
+        # HOST arrays (mpg_wind_destagger): the mass winds cross the link once, U and V come back -- 2 fields up, 2 down, where
+        # rotate_winds_cgrid + two regrid() calls move 4 up and 4 down.  keep_mass: the rotated mass winds are returned as new arrays.
+        out_np = np.dtype(out_dtype or np.float64)
+        if out_np not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("wind_destagger: out_dtype must be float64 or float32")
+        um = _f64(umass) if umass is not None else None
+        vm = _f64(vmass) if vmass is not None else None
+        ca, sa = (_f64(cosa), _f64(sina)) if rot else (None, None)
+        u = np.empty((nlev, rh_u.ny_dst, rh_u.nx_dst), dtype=out_np) if rh_u is not None else None
+        v = np.empty((nlev, rh_v.ny_dst, rh_v.nx_dst), dtype=out_np) if rh_v is not None else None
+        ur = np.empty_like(um) if (keep_mass and rot) else None
+        vr = np.empty_like(vm) if (keep_mass and rot) else None
+
+        def hp(a):
+            return _ptr(a) if a is not None else None
+        check(L.load().mpg_wind_destagger(rh_u._h if rh_u is not None else None, rh_v._h if rh_v is not None else None, hp(ca), hp(sa), hp(um), hp(vm),
+                                          C.c_int(nlev), hp(u), hp(v), C.c_int(int(out_np == np.dtype(np.float32)) | (2 if dst_be else 0)), hp(ur), hp(vr)))
+        return u, v, ur, vr
+    import torch
     out_dtype = out_dtype or torch.float64
     for t in (umass, vmass):
         if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float64):

@@ -233,6 +233,19 @@ int main(void) {
         fprintf(stderr, "FAIL: rotated mass winds over the inputs must be refused\n");
         return 1;
       }
+      /* the same chain on HOST arrays (the reference's own shape): one call, the rotated mass winds back into the arrays that held them */
+      {
+        static double cah[WY][WX], sah[WY][WX], uh[WL][WY][WX + 1], vh[WL][WY + 1][WX], umh[WL][WY][WX], vmh[WL][WY][WX], urh[WL][WY][WX];
+        CHECK(mpg_grid_get_rotang(wg, &cah[0][0], &sah[0][0]));
+        memcpy(umh, um, nm);
+        memcpy(vmh, vm, nm);
+        CHECK(mpg_wind_destagger(ru, rv, &cah[0][0], &sah[0][0], &umh[0][0][0], &vmh[0][0][0], WL, uh, vh, MPG_TYPE_F64, &umh[0][0][0], &vmh[0][0][0]));
+        CHECK(mpg_dev_download(urh, ur_d, nm));   /* what mpg_rotate_winds_dev left in place above */
+        if (memcmp(uh, u3, nu) != 0 || memcmp(vh, v3, nv) != 0 || memcmp(umh, urh, nm) != 0) {
+          fprintf(stderr, "FAIL: mpg_wind_destagger (host arrays) differs from rotate_winds + two Regrids\n");
+          return 1;
+        }
+      }
       CHECK(mpg_handle_release(ru)); CHECK(mpg_handle_release(rv));
       CHECK(mpg_dev_free(um_d)); CHECK(mpg_dev_free(vm_d)); CHECK(mpg_dev_free(ur_d)); CHECK(mpg_dev_free(vr_d));
       CHECK(mpg_dev_free(u1_d)); CHECK(mpg_dev_free(v1_d)); CHECK(mpg_dev_free(u3_d)); CHECK(mpg_dev_free(v3_d));

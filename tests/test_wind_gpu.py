@@ -215,3 +215,72 @@ def test_interp_data_fused_equals_three_calls(gpu_lib, global_mesh, conus_grid_3
     assert _same_bits(torch, out["U"], outs[False]["U"]) and _same_bits(torch, out["V"], outs[False]["V"])
     mesh.destroy()
     grid.destroy()
+
+
+# ---- host arrays: mpg_wind_destagger (the reference's own shape: farrayPtr in, farrayPtr out) ---------------------------------
+@pytest.mark.parametrize("nx,ny,nlev,rot,dtype,be", [(180, 106, 5, True, "float64", False), (150, 90, 3, False, "float64", False), (203, 35, 7, True, "float32", True),
+                                                     (65, 17, 1, True, "float32", False), (1800, 1060, 9, True, "float64", False)])
+def test_host_arrays_same_bits_as_the_device_form(gpu_lib, nx, ny, nlev, rot, dtype, be):
+    """The host-array chain (mass winds up once in chunks of levels, only U and V down) gives the bits of mpg_wind_destagger_dev and so of the
+    three-call chain; the 1800 x 1060 case takes several chunks (three levels of two fields per 96 MB), the last one short."""
+    import torch
+    from mpassit_amd import regrid as R
+    t, grid = _grid(nx, ny)
+    um, vm = _winds(torch, t, nlev, 300 + nx)
+    dt = getattr(torch, dtype)
+    u0, v0, ur0, vr0 = _fused(torch, R, t, grid, um, vm, nlev, rot, out_dtype=dt, dst_be=be, keep=rot)
+    rh_u, rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1), R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2)
+    umh, vmh = um.cpu().numpy(), vm.cpu().numpy()
+    um_in, vm_in = umh.copy(), vmh.copy()
+    u, v, ur, vr = R.wind_destagger(rh_u, rh_v, t.cosa if rot else None, t.sina if rot else None, umh, vmh, nlev, out_dtype=getattr(np, dtype), dst_be=be,
+                                    keep_mass=rot)
+    assert np.array_equal(umh, um_in) and np.array_equal(vmh, vm_in), "the mass winds are inputs"
+    it = {"float64": np.int64, "float32": np.int32}[dtype]
+    assert u.shape == tuple(u0.shape) and np.array_equal(u.view(it), u0.cpu().numpy().view(it))
+    assert v.shape == tuple(v0.shape) and np.array_equal(v.view(it), v0.cpu().numpy().view(it))
+    if rot:
+        assert np.array_equal(ur.view(np.int64), ur0.cpu().numpy().view(np.int64)) and np.array_equal(vr.view(np.int64), vr0.cpu().numpy().view(np.int64))
+    else:
+        assert ur is None and vr is None
+    # one component only (do_u_interp or do_v_interp alone, interp.F90:295,313)
+    if not rot:
+        u1, v1, _, _ = R.wind_destagger(rh_u, None, None, None, umh, None, nlev, out_dtype=getattr(np, dtype), dst_be=be)
+        assert v1 is None and np.array_equal(u1.view(it), u.view(it))
+        u2, v2, _, _ = R.wind_destagger(None, rh_v, None, None, None, vmh, nlev, out_dtype=getattr(np, dtype), dst_be=be)
+        assert u2 is None and np.array_equal(v2.view(it), v.view(it))
+    rh_u.release()
+    rh_v.release()
+    grid.destroy()
+
+
+def test_host_arrays_rotated_in_place_like_the_reference(gpu_lib):
+    """rotate_winds_cgrid works in place (interp.F90:702-748): with host arrays the rotated mass winds may come back into the arrays that
+    held the earth-relative ones (a level's result comes down after that level went up); arguments are checked as in the device form."""
+    import ctypes as C
+    import torch
+    from mpassit_amd import _lib as L, regrid as R
+    t, grid = _grid(150, 90)
+    um, vm = _winds(torch, t, 6, 11)
+    u0, v0, ur0, vr0 = _fused(torch, R, t, grid, um, vm, 6, True, keep=True)
+    rh_u, rh_v = R.regrid_store_grid(grid, R.STAGGERLOC_EDGE1), R.regrid_store_grid(grid, R.STAGGERLOC_EDGE2)
+    umh, vmh = um.cpu().numpy().copy(), vm.cpu().numpy().copy()
+    u, v = np.empty(tuple(u0.shape)), np.empty(tuple(v0.shape))
+    cosa, sina = np.ascontiguousarray(t.cosa, dtype=np.float64), np.ascontiguousarray(t.sina, dtype=np.float64)
+    lib = L.load()
+
+    def p(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    assert lib.mpg_wind_destagger(rh_u._h, rh_v._h, p(cosa), p(sina), p(umh), p(vmh), 6, p(u), p(v), 0, p(umh), p(vmh)) == 0, lib.mpg_last_error()
+    assert np.array_equal(u, u0.cpu().numpy()) and np.array_equal(v, v0.cpu().numpy())
+    assert np.array_equal(umh, ur0.cpu().numpy()) and np.array_equal(vmh, vr0.cpu().numpy())
+    bad = L.MPG_ERR_INVALID_ARG
+    assert lib.mpg_wind_destagger(None, None, None, None, p(umh), p(vmh), 6, p(u), p(v), 0, None, None) == bad
+    assert lib.mpg_wind_destagger(rh_u._h, rh_v._h, p(cosa), None, p(umh), p(vmh), 6, p(u), p(v), 0, None, None) == bad
+    assert lib.mpg_wind_destagger(rh_u._h, None, p(cosa), p(sina), p(umh), p(vmh), 6, p(u), None, 0, None, None) == bad       # the rotation needs both
+    assert lib.mpg_wind_destagger(rh_u._h, rh_v._h, None, None, p(umh), p(vmh), 6, None, p(v), 0, None, None) == bad
+    assert lib.mpg_wind_destagger(rh_u._h, rh_v._h, None, None, p(umh), p(vmh), 0, p(u), p(v), 0, None, None) == bad
+    assert lib.mpg_wind_destagger(rh_u._h, rh_v._h, None, None, p(umh), p(vmh), 6, p(u), p(v), 0, p(umh), None) == bad       # rotated winds without a rotation
+    assert lib.mpg_wind_destagger(rh_v._h, rh_u._h, None, None, p(umh), p(vmh), 6, p(u), p(v), 0, None, None) == L.MPG_ERR_UNSUPPORTED
+    rh_u.release()
+    rh_v.release()
+    grid.destroy()

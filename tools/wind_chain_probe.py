@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--f32", action="store_true", help="U / V as NF90_FLOAT big-endian (what the Fortran driver's device flow stores)")
     ap.add_argument("--latlon", action="store_true", help="global lat-lon grid (periodic, pole caps, no rotation)")
+    ap.add_argument("--host", action="store_true", help="HOST arrays in and out: mpg_rotate_winds + two mpg_regrid against mpg_wind_destagger (wall clock, link included)")
     args = ap.parse_args()
     import torch
     from mpassit_amd import _lib, regrid as R, target_grid as T
@@ -70,6 +71,42 @@ def main():
             ts.append(e0.elapsed_time(e1))
         ts.sort()
         return ts[len(ts) // 2], ts[0]
+    if args.host:
+        import time
+        umh, vmh = um.cpu().numpy(), vm.cpu().numpy()
+        ca, sa = (np.ascontiguousarray(t.cosa), np.ascontiguousarray(t.sina)) if rot else (None, None)
+        odn = np.float32 if args.f32 else np.float64
+
+        def chain_h():
+            a, b = umh.copy(), vmh.copy()
+            t0 = time.perf_counter()
+            if rot:
+                R.rotate_winds_cgrid(ca, sa, a, b)
+            if args.f32:
+                r = rh_u.regrid_typed_host(a.reshape(-1), nlev=nlev, out_dtype=odn)[0], rh_v.regrid_typed_host(b.reshape(-1), nlev=nlev, out_dtype=odn)[0]
+            else:
+                r = rh_u.regrid(a.reshape(-1), nlev=nlev)[0], rh_v.regrid(b.reshape(-1), nlev=nlev)[0]
+            return r, time.perf_counter() - t0
+
+        def fused_h():
+            t0 = time.perf_counter()
+            u, v, _, _ = R.wind_destagger(rh_u, rh_v, ca, sa, umh, vmh, nlev, out_dtype=odn)
+            return (u, v), time.perf_counter() - t0
+        (uc, vc), _ = chain_h()
+        (uf, vf), _ = fused_h()
+        same = np.array_equal(uc.view(np.uint8), np.asarray(uf).view(np.uint8)) and np.array_equal(vc.view(np.uint8), np.asarray(vf).view(np.uint8))
+        tc = sorted(chain_h()[1] for _ in range(max(3, args.reps // 4)))
+        tf = sorted(fused_h()[1] for _ in range(max(3, args.reps // 4)))
+        up_c, dn_c = nlev * P * 8 * (4 if rot else 2), nlev * (P * 16 if rot else 0) + nlev * (rh_u.n_dst + rh_v.n_dst) * es
+        up_f, dn_f = nlev * P * 16, nlev * (rh_u.n_dst + rh_v.n_dst) * es
+        print(json.dumps({"grid": "%dx%d" % (t.nx, t.ny), "nlev": nlev, "dst": "f32" if args.f32 else "f64", "host_arrays": True, "bits_equal": bool(same),
+                          "chain_ms": round(tc[len(tc) // 2] * 1e3, 1), "fused_ms": round(tf[len(tf) // 2] * 1e3, 1), "speedup": round(tc[len(tc) // 2] / tf[len(tf) // 2], 2),
+                          "chain_GB_up_down": [round(up_c / 1e9, 2), round(dn_c / 1e9, 2)], "fused_GB_up_down": [round(up_f / 1e9, 2), round(dn_f / 1e9, 2)]}))
+        for rh in (rh_u, rh_v):
+            rh.release()
+        grid.destroy()
+        _lib.finalize()
+        return
     uc, vc = chain()
     uf, vf = fused()
     torch.cuda.synchronize()
