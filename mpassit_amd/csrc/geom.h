@@ -105,6 +105,42 @@ __device__ __forceinline__ double sph_tri_area(dv3 a, dv3 b, dv3 c) {
   return 2.0 * atan2(num, den);
 }
 
+// ---- streaming stores of results ---------------------------------------------------------------------------------------
+// Results are written once and never read by the kernel, so a wavefront's run of consecutive result elements that covers whole
+// 128-byte lines goes out non-temporal (2-6 % on the Regrid kernels: the lines do not displace the source rows the kernel lives
+// on in L2).  A run that STARTS inside a line leaves a partial line at either end, whose other part a neighbouring workgroup
+// writes a little later; for float32 results in 256-byte runs that is half of all lines, and plain write-back stores, which let
+// the two parts meet in L2, were measured up to 14 % faster there (profiles/r06_plane_alignment.md; float64 results in 512-byte
+// runs stay better off non-temporal even 64 bytes off).  Whether runs start on a line is a property of the level's PLANE: tiles
+// start at multiples of 64 points of the plane, so level k's runs are aligned iff its plane is -- and plane k of a
+// [nlev][ny][nx] result starts k * ny * nx * sizeof(T) bytes after plane 0: on a line for every k only when ny * nx is a
+// multiple of 32 (float32) points.  The headline grid (1800 x 1060) is; its staggers (1801 x 1060, 1800 x 1061), a rank's row
+// block of it (1800 x 133) and most grids a user brings are not.
+//   stream_nt(plane)          wave-uniform: this level's plane starts on a line
+//   stream_store(v, p, nt)    the store, non-temporal or plain.  ONLY for stores in a kernel's final phase: a branch around stores
+//                             inside a loop that also loads makes the compiler wait for every outstanding store (one in-order
+//                             counter on gfx950) -- the pipelined kernels choose per LAUNCH or keep their non-temporal stores.
+// The empty asm statements keep LLVM from merging the two branches into ONE plain store (it sinks / hoists stores that differ
+// only in their !nontemporal hint and drops the hint: found in the ISA, round 6).
+// -DMPG_STREAM_STORE_MODE=1 / 2 (A/B builds, mpassit_amd.build.build_alt): every plane plain / non-temporal (2 = rounds 2-6a).
+#ifndef MPG_STREAM_STORE_MODE
+#define MPG_STREAM_STORE_MODE 0
+#endif
+__device__ __forceinline__ bool stream_nt(const void *plane, int mode = MPG_STREAM_STORE_MODE) {
+  if (mode) return mode == 2;
+  return __builtin_amdgcn_readfirstlane((int)((uintptr_t)plane & 127u)) == 0;   // all lanes of a workgroup work on one level of one field
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T v, T *addr, bool nt) {
+  if (nt) {
+    asm volatile("" ::: "memory");
+    __builtin_nontemporal_store(v, addr);
+    asm volatile("" ::: "memory");
+  } else {
+    *addr = v;
+  }
+}
+
 // Bijective XCD swizzle (cdna_hip_programming.md s5 "XCD swizzle must be bijective"): the hardware deals workgroups b,
 // b+8, b+16, ... to the same XCD, so give each of the 8 XCDs one contiguous range of the linear work space -- tiles that
 // are neighbours in the work space then share an L2.
@@ -200,4 +236,17 @@ __device__ __forceinline__ void buf_store_nt(float v, BufRsrc r, uint32_t lane_o
 }
 __device__ __forceinline__ void buf_store_nt(double v, BufRsrc r, uint32_t lane_off) {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u32x2, v), r, (int)lane_off, 0, 2);
+}
+// plain (write-back), and the choice between the two at COMPILE time (a kernel whose stores sit in a loop that also loads picks per
+// instantiation: see stream_store above)
+__device__ __forceinline__ void buf_store_wb(float v, BufRsrc r, uint32_t lane_off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)lane_off, 0, 0);
+}
+__device__ __forceinline__ void buf_store_wb(double v, BufRsrc r, uint32_t lane_off) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(buf_u32x2, v), r, (int)lane_off, 0, 0);
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void buf_store_pick(T v, BufRsrc r, uint32_t lane_off) {
+  if constexpr (NT) buf_store_nt(v, r, lane_off);
+  else buf_store_wb(v, r, lane_off);
 }

@@ -325,6 +325,11 @@ int mpg_k_tune(const char *key, int value) {
     mpg_set_staged_lds_pad_kb(value < 0 ? 0 : value);
     return MPG_SUCCESS;
   }
+  if (!strcmp(key, "lf_rows_store")) {   // store policy of the level-fast row gather's float32 results: 0 = per level by the alignment of its plane (geom.h stream_nt), 1 = plain, 2 = non-temporal (A/B)
+    if (value < 0 || value > 2) return MPG_ERR_INVALID_ARG;
+    mpg_set_lf_rows_store(value);
+    return MPG_SUCCESS;
+  }
   if (!strcmp(key, "lfu_min_reuse_x10")) {
     if (value < 0 || value > 1000) return MPG_ERR_INVALID_ARG;
     mpg_lfu_set_min_reuse_x10(value);

@@ -182,14 +182,18 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
   int j = ty, i = tx * 64 + lane - mpg_tile_shift(j, nx);
   if (i >= 0 && i < nx && j < ny) {
     int64_t p = (int64_t)j * nx + i;
-    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + p);
+    for (int k = wave; k < nlev; k += 4)   // float32 results: per level, by the alignment of its plane (geom.h); float64: non-temporal
+      stream_store(tile[k * 65 + lane], df + (int64_t)k * P + p, sizeof(TD) == 8 || (mpg_tile_align(nx) == 32 && stream_nt(df + (int64_t)k * P)));
   }
 }
 
 // The level-fast row gather on LINEAR tiles.  A tile is 64 consecutive target points of the flattened [ny][nx] plane
-// starting at a multiple of 64, so every store of a level is one naturally aligned 256-byte (float32) / 512-byte
-// (float64) segment whatever nx is (64 x 1 tiles of a 1800-wide grid start 32 bytes off a line in three rows of four:
-// 10 % more bytes written, PMC, and two partial lines per store).  Phase 0 stages the tile's three cell offsets
+// starting at a multiple of 64, so every store of a level is one 256-byte (float32) / 512-byte (float64) segment that is
+// naturally aligned whatever nx is (64 x 1 tiles of a 1800-wide grid start 32 bytes off a line in three rows of four:
+// 10 % more bytes written, PMC, and two partial lines per store) -- IF the level's plane starts on a line, which only
+// planes of a multiple of 32 (16) points do: the row block of a sharded job (133 x 1800), a stagger (1801 x 1060) or any
+// odd grid puts level k's plane k * P * sizeof(TD) mod 128 bytes into one, and non-temporal stores of such float32 segments
+// cost up to 14 % of the kernel (profiles/r06_plane_alignment.md).  stream_store (geom.h) decides per level.  Phase 0 stages the tile's three cell offsets
 // (premultiplied by nlev, 32 bit, added to a scalar field base: no 64-bit address arithmetic per load) and weights in
 // LDS; phase 1: a half-wave covers 64 levels of one point with ONE load per row, two levels per lane (8 bytes of a
 // float32 row, 16 of a float64 row; rows are only element-aligned -- 55 float32 levels are 220 bytes -- which the
@@ -207,7 +211,7 @@ template <> struct Row2<double> { typedef f64x2_u type; };
 template <typename TS, typename TD, int UNR, bool EPI, bool SWZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_apply3_lf_rows(
     const int32_t *__restrict__ idx, const double *__restrict__ w, const TS *__restrict__ src, TD *__restrict__ dst, int64_t P, int64_t nsrc,
-    int nlev, unsigned ntile, double scale, double offset, int sbe, int dbe, int band, FieldTab tab) {
+    int nlev, unsigned ntile, double scale, double offset, int sbe, int dbe, int band, int st_mode, FieldTab tab) {
   typedef typename Row2<TS>::type row2;
   extern __shared__ double sw[];                    // sw[3][64] | soff[3][64] | tile[nlev][65] in the destination type
   uint32_t *soff = (uint32_t *)(sw + 192);
@@ -279,7 +283,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   __syncthreads();
   TD *df = mpg_field_dst(tab, dst, f, (int64_t)nlev * P) + p0;
   if (p0 + lane < P)
-    for (int k = wave; k < nlev; k += 4) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + lane);
+    for (int k = wave; k < nlev; k += 4) {
+      TD *row = df + (int64_t)k * P;   // wave-uniform; st_mode: the "lf_rows_store" knob (0: float64 results non-temporal, float32 by the plane's alignment)
+      stream_store(tile[k * 65 + lane], row + lane, st_mode ? st_mode == 2 : (sizeof(TD) == 8 || stream_nt(row)));
+    }
 }
 
 // nearest (NNZ = 1, weights implicit), 4-point destagger (NNZ = 4) and CSR (NNZ = 0): one thread per target point.  The
@@ -372,6 +379,8 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
 // the (field, tile) order of the row gather: bands of 1024 tiles (64 K points, 2.4 MB of indices + weights: they stay in the
 // XCD's L2 from one field of the bundle to the next), all fields of a band before the next band -- 4 % on configuration 4
 #define LF_ROWS_BAND 1024
+static int g_lf_rows_store = 0;   // "lf_rows_store" knob: 0 = float32 results per level by the alignment of its plane (geom.h stream_nt), float64 non-temporal; 1 = plain, 2 = non-temporal (A/B)
+void mpg_set_lf_rows_store(int v) { g_lf_rows_store = v; }
 static size_t lf_rows_lds(size_t dst_size, int nlev) { return dst_size * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192; }
 static bool lf_rows_fits(const mpg_handle_s *h, size_t dst_size, int nlev) {
   return nlev >= 2 && (uint64_t)h->n_src * (uint64_t)nlev < 0xFFFFFFFFull && lf_rows_lds(dst_size, nlev) <= 160 * 1024;
@@ -388,7 +397,7 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
       const unsigned ntile = (unsigned)((P + 63) / 64);
       auto fn = k_apply3_lf_rows<TS, TD, sizeof(TS) == 4 ? 2 : 1, true, SWZ>;   // measured: unroll 2 for float32 rows, 1 for float64
       if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, scale, offset, sbe, dbe, mpg_field_band(LF_ROWS_BAND), tab);
+      fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, (const TS *)src, (TD *)dst, P, h->n_src, nlev, ntile, scale, offset, sbe, dbe, mpg_field_band(LF_ROWS_BAND), g_lf_rows_store, tab);
     } else if (lev_fast) {
       size_t lds = sizeof(TD) * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192;
       if (lds > 160 * 1024) {
@@ -430,7 +439,7 @@ int mpg_k_apply3_lf_rows(mpg_handle_s *h, const double *src, int nlev, int nfiel
   const unsigned ntile = (unsigned)((P + 63) / 64);
   auto fn = k_apply3_lf_rows<double, double, 1, false, false>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, 1.0, 0.0, 0, 0, mpg_field_band(LF_ROWS_BAND), FieldTab());
+  fn<<<ntile * (unsigned)nfields, 256, lds, s>>>(h->idx.p, h->w.p, src, dst, P, h->n_src, nlev, ntile, 1.0, 0.0, 0, 0, mpg_field_band(LF_ROWS_BAND), g_lf_rows_store, FieldTab());
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }

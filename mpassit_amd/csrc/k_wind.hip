@@ -76,6 +76,11 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   const bool per = a.periodic != 0, do_u = (a.mode & 1) != 0, do_v = (a.mode & 2) != 0;
   const bool src_u = ROT || do_u, src_v = ROT || do_v;
   const Swz zd = make_swz(a.dbe);
+  // U / V segments start on multiples of WD_A = 8 elements: 64 bytes of a float64 row (non-temporal stores: level with plain ones on the
+  // README's grid), 32 bytes of a float32 row -- three segments of four then start inside a 128-byte line, and the partial lines of
+  // neighbouring workgroups only meet in L2 under write-back stores (0.678 against 0.722 ms, profiles/r06_plane_alignment.md).  Chosen
+  // per instantiation, not per level: a branch around stores in this loop would make every level wait for the stores before it (below).
+  constexpr bool ST_NT = MPG_STREAM_STORE_MODE ? MPG_STREAM_STORE_MODE == 2 : sizeof(TD) == 8;
 
   // ---- this thread's window points: byte offset inside a level plane (MPG_BUF_NONE: outside the grid -> loads 0) ----
   uint32_t gb[WD_WPT];
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   {
     const BufRsrc none = buf_rsrc(nullptr, 0u);
 #pragma unroll
-    for (int r = 0; r < 2 * WD_RPT; ++r) buf_store_nt((TD)0, none, MPG_BUF_NONE);
+    for (int r = 0; r < 2 * WD_RPT; ++r) buf_store_pick<ST_NT>((TD)0, none, MPG_BUF_NONE);
   }
   for (int k = 0; k < nlev; ++k) {
     double *bu = lds + (k & 1) * 2 * WD_NW, *bv = bu + WD_NW;
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         acc = fma(wu[r][1], q[1], acc);
         acc = fma(wu[r][2], q[WD_WW + 1], acc);
         acc = fma(wu[r][3], q[WD_WW], acc);
-        buf_store_nt(finish(acc, mapu[r]), ou, pu[r]);
+        buf_store_pick<ST_NT>(finish(acc, mapu[r]), ou, pu[r]);
       }
       {
         const double *q = bv + lv[r];
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         acc = fma(wv[r][1], q[1], acc);
         acc = fma(wv[r][2], q[WD_WW + 1], acc);
         acc = fma(wv[r][3], q[WD_WW], acc);
-        buf_store_nt(finish(acc, mapv[r]), ov, pv[r]);
+        buf_store_pick<ST_NT>(finish(acc, mapv[r]), ov, pv[r]);
       }
     }
     uplane += P1;

@@ -31,8 +31,25 @@ def para_range(n1, n2, nprocs, irank):
     return ista, iend
 
 
-def row_block(ny, world, rank):
-    """0-based half-open mass-row block [j0, j1) of `rank`."""
+def row_quantum(nx, ny, world):
+    """Rows per alignment quantum of a row split of an nx-wide grid, or 1: a rank's result is [nlev][rows][nx], and level k's plane
+    starts on a 128-byte line for every k only when rows * nx is a multiple of 32 points (float32; 16 for float64) -- the Regrid
+    kernels' stores of a plane that does not are partial lines at both ends of every run (csrc/geom.h stream_nt,
+    profiles/r06_plane_alignment.md: 13 % on float32 results).  Block boundaries on multiples of q = 32 / gcd(nx, 32) rows give every
+    rank but possibly the last such planes; taken only where half a quantum is at most 3 % of a block (nx = 1800: q = 4; an odd nx
+    would need q = 32: the split stays para_range's)."""
+    from math import gcd
+    q = 32 // gcd(int(nx), 32)
+    return q if q > 1 and 16 * q * world <= ny else 1
+
+
+def row_block(ny, world, rank, nx=None):
+    """0-based half-open mass-row block [j0, j1) of `rank`: para_range's split (model_grid.F90:2428-2441), or -- given the grid's
+    width -- the same blocks with their boundaries rounded to whole alignment quanta (row_quantum)."""
+    q = row_quantum(nx, ny, world) if nx else 1
+    if q > 1:
+        bnd = lambda r: ny if r >= world else q * ((2 * r * ny + world * q) // (2 * world * q))   # noqa: E731
+        return bnd(rank), bnd(rank + 1)
     a, b = para_range(1, ny, world, rank)
     return a - 1, b
 
@@ -307,7 +324,7 @@ class ShardedRegrid:
         directly, what a C or Fortran host uses); the ranks meet through `id_file`."""
         from . import regrid as R
         self.rank, self.world = rank, world
-        self.j0, self.j1 = row_block(target.ny, world, rank)
+        self.j0, self.j1 = row_block(target.ny, world, rank, nx=target.nx)
         self.grid = R.Grid.from_target(target, rows=(self.j0, self.j1))
         # with several ranks a rank's mesh holds only what its row block can see (mpg_mesh_create_window: same weights, geometry
         # ingest and Stores that shrink with the block; the reference gives every rank 1/N of the cells, model_grid.F90:423-438)
@@ -435,7 +452,7 @@ class ShardedInterp:
 
         from . import regrid as R
         self.rank, self.world, self.ny = rank, world, target.ny
-        self.j0, self.j1 = row_block(target.ny, world, rank)
+        self.j0, self.j1 = row_block(target.ny, world, rank, nx=target.nx)
         self.e0, self.e1 = max(self.j0 - 1, 0), min(self.j1 + 1, target.ny)
         self.grid = R.Grid.from_target(target, rows=(self.j0, self.j1))
         self.mesh = R.Mesh.from_mpas(mpas_mesh, window_grid=self.grid if world > 1 else None)   # only what this row block can see

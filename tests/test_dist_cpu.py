@@ -252,3 +252,25 @@ def test_row_and_cell_blocks():
     assert mdist.row_block(1060, 8, 7) == (928, 1060)
     blocks = [mdist.cell_block(10, 4, r) for r in range(4)]
     assert blocks == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_row_blocks_on_alignment_quanta():
+    """Given the grid's width the split keeps para_range's blocks but puts their boundaries on whole alignment quanta (every level plane
+    of a rank's [nlev][rows][nx] result then starts on a 128-byte line: csrc/geom.h stream_nt) -- where that costs at most 3 % of balance."""
+    from math import gcd
+
+    from mpassit_amd import dist as mdist
+    assert mdist.row_quantum(1800, 1060, 8) == 4 and mdist.row_quantum(3600, 1800, 8) == 2
+    assert mdist.row_quantum(1801, 1060, 8) == 1          # an odd width would need 32-row quanta: not worth a quarter of a block
+    assert mdist.row_quantum(1800, 100, 8) == 1           # blocks of 12 rows: half a quantum is too much of one
+    assert [mdist.row_block(1060, 8, r, nx=1801) for r in range(8)] == [mdist.row_block(1060, 8, r) for r in range(8)]
+    for ny, nx, world in [(1060, 1800, 8), (1060, 1800, 4), (1060, 1800, 2), (1060, 1800, 3), (1061, 1800, 8), (1800, 3600, 8), (1800, 3600, 6), (777, 808, 5)]:
+        q = mdist.row_quantum(nx, ny, world)
+        b = [mdist.row_block(ny, world, r, nx=nx) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == ny and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        assert all(j1 > j0 for j0, j1 in b)
+        assert all(j1 % q == 0 for _, j1 in b[:-1])                                    # every boundary on a quantum
+        assert all(((j1 - j0) * nx) % 32 == 0 for j0, j1 in b[:-1]) or q == 1         # planes of whole lines (float32; float64 a fortiori)
+        assert q == 1 or q == 32 // gcd(nx, 32)
+        assert max(j1 - j0 for j0, j1 in b) <= (ny / world) * 1.035 + 1                # balance within the 3 % the rule allows
+    assert [j1 - j0 for j0, j1 in (mdist.row_block(1060, 8, r, nx=1800) for r in range(8))] == [132, 132, 132, 136, 132, 132, 132, 132]
