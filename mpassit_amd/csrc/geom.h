@@ -106,29 +106,42 @@ __device__ __forceinline__ double sph_tri_area(dv3 a, dv3 b, dv3 c) {
 }
 
 // ---- streaming stores of results ---------------------------------------------------------------------------------------
-// Results are written once and never read by the kernel, so a wavefront's run of consecutive result elements that covers whole
-// 128-byte lines goes out non-temporal (2-6 % on the Regrid kernels: the lines do not displace the source rows the kernel lives
-// on in L2).  A run that STARTS inside a line leaves a partial line at either end, whose other part a neighbouring workgroup
-// writes a little later; for float32 results in 256-byte runs that is half of all lines, and plain write-back stores, which let
-// the two parts meet in L2, were measured up to 14 % faster there (profiles/r06_plane_alignment.md; float64 results in 512-byte
-// runs stay better off non-temporal even 64 bytes off).  Whether runs start on a line is a property of the level's PLANE: tiles
-// start at multiples of 64 points of the plane, so level k's runs are aligned iff its plane is -- and plane k of a
-// [nlev][ny][nx] result starts k * ny * nx * sizeof(T) bytes after plane 0: on a line for every k only when ny * nx is a
-// multiple of 32 (float32) points.  The headline grid (1800 x 1060) is; its staggers (1801 x 1060, 1800 x 1061), a rank's row
-// block of it (1800 x 133) and most grids a user brings are not.
-//   stream_nt(plane)          wave-uniform: this level's plane starts on a line
-//   stream_store(v, p, nt)    the store, non-temporal or plain.  ONLY for stores in a kernel's final phase: a branch around stores
-//                             inside a loop that also loads makes the compiler wait for every outstanding store (one in-order
-//                             counter on gfx950) -- the pipelined kernels choose per LAUNCH or keep their non-temporal stores.
+// Results are written once and never read by the kernel, so a wavefront's run of 64 consecutive result elements goes out
+// non-temporal (2-6 % on the Regrid kernels: the lines do not displace the source rows the kernel lives on in L2) -- where it
+// covers whole 128-byte lines.  A run that STARTS inside a line leaves a partial line at either end, whose other part a
+// neighbouring workgroup writes a little later: non-temporal, the first part has left L2 by then and HBM sees two masked writes
+// per line; write-back, the parts meet in L2.  Whether runs start on a line is a property of the level's PLANE: tiles start at
+// multiples of 64 points of the plane, so level k's runs are aligned iff its plane is -- and plane k of a [nlev][ny][nx] result
+// starts k * ny * nx * sizeof(T) bytes after plane 0: on a line for every k only when ny * nx is a multiple of 32 (float32) / 16
+// (float64) points.  The headline grid (1800 x 1060) is -- which hid all this for five rounds; its staggers (1801 x 1060, 1800 x
+// 1061), a rank's row block of it (1800 x 133), HRRR's own 1799 x 1059 and most grids a user brings are not: as shipped until
+// round 6a they cost 14 % (float64 cell-fast) to 29 % (float32 file order) of the kernel (profiles/r06_plane_alignment.md).
+//   stream_store_lane(v, p, lane_bytes)   per LANE, the general form (below): whole lines non-temporal, the run's two end lines
+//                                         write-back; no branch, safe inside pipelined loops
+//   stream_nt(plane), stream_store(v, p, nt)   per LEVEL (wave-uniform: this level's plane starts on a line).  ONLY for stores in a
+//                             kernel's final phase: a uniform branch around stores inside a loop that also loads makes the compiler
+//                             wait for every outstanding store (one in-order counter on gfx950; measured: 10 % of k_wind_destagger)
 // The empty asm statements keep LLVM from merging the two branches into ONE plain store (it sinks / hoists stores that differ
 // only in their !nontemporal hint and drops the hint: found in the ISA, round 6).
-// -DMPG_STREAM_STORE_MODE=1 / 2 (A/B builds, mpassit_amd.build.build_alt): every plane plain / non-temporal (2 = rounds 2-6a).
+// -DMPG_STREAM_STORE_MODE=1 / 2 (A/B builds, mpassit_amd.build.build_alt): everything plain / non-temporal (2 = rounds 2-6a).
 #ifndef MPG_STREAM_STORE_MODE
 #define MPG_STREAM_STORE_MODE 0
 #endif
 __device__ __forceinline__ bool stream_nt(const void *plane, int mode = MPG_STREAM_STORE_MODE) {
   if (mode) return mode == 2;
   return __builtin_amdgcn_readfirstlane((int)((uintptr_t)plane & 127u)) == 0;   // all lanes of a workgroup work on one level of one field
+}
+// Per LANE (round 6, the general form): a lane whose 128-byte line lies wholly inside its wavefront's run of 64 consecutive
+// elements stores non-temporal, the lanes on the partial lines at the run's two ends store write-back, so that the other part --
+// the neighbouring run's -- meets them in L2.  No wave-uniform branch: both stores are straight-line code under complementary
+// lane masks, so the compiler's count of what is in flight stays static and the form is safe inside pipelined level loops
+// (same s_waitcnt pattern in the ISA; k_apply3_cfu float64 on planes 8 / 24 / 104 bytes off a line: 0.57 -> 0.62-0.64 of the
+// peak, planes on a line or 64 bytes off unchanged, profiles/r06_plane_alignment.md).  lane_bytes = (lane of the run) * sizeof(T);
+// a run cut short by the end of a grid row may send one partial line non-temporal: rare, and only a matter of speed.
+template <typename T>
+__device__ __forceinline__ bool stream_lane_full(const T *addr, unsigned lane_bytes) {
+  const unsigned a = (unsigned)(uintptr_t)addr & 127u;
+  return a <= lane_bytes && lane_bytes - a <= 64u * (unsigned)sizeof(T) - 128u;
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T v, T *addr, bool nt) {
@@ -139,6 +152,11 @@ __device__ __forceinline__ void stream_store(T v, T *addr, bool nt) {
   } else {
     *addr = v;
   }
+}
+// all_nt (wave-uniform, a run-time A/B knob): OR-ed into the lane predicate, no branch -- the write-back store then runs with no lane
+template <typename T>
+__device__ __forceinline__ void stream_store_lane(T v, T *addr, unsigned lane_bytes, bool all_nt = false) {
+  stream_store(v, addr, MPG_STREAM_STORE_MODE ? MPG_STREAM_STORE_MODE == 2 : (all_nt | stream_lane_full(addr, lane_bytes)));
 }
 
 // Bijective XCD swizzle (cdna_hip_programming.md s5 "XCD swizzle must be bijective"): the hardware deals workgroups b,
@@ -248,5 +266,14 @@ __device__ __forceinline__ void buf_store_wb(double v, BufRsrc r, uint32_t lane_
 template <bool NT, typename T>
 __device__ __forceinline__ void buf_store_pick(T v, BufRsrc r, uint32_t lane_off) {
   if constexpr (NT) buf_store_nt(v, r, lane_off);
+  else buf_store_wb(v, r, lane_off);
+}
+// stream_store_lane for buffer addressing: `plane` = the descriptor's base, lane_off = the lane's byte offset inside it (MPG_BUF_NONE:
+// no store either way).  Two stores under complementary lane masks, distinct cache-policy immediates: nothing for the compiler to merge.
+template <typename T>
+__device__ __forceinline__ void buf_store_lane(T v, BufRsrc r, const void *plane, uint32_t lane_off, unsigned lane_bytes) {
+  const unsigned a = ((unsigned)(uintptr_t)plane + lane_off) & 127u;
+  const bool full = MPG_STREAM_STORE_MODE ? MPG_STREAM_STORE_MODE == 2 : (a <= lane_bytes && lane_bytes - a <= 64u * (unsigned)sizeof(T) - 128u);
+  if (full) buf_store_nt(v, r, lane_off);
   else buf_store_wb(v, r, lane_off);
 }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf(const int32_t *__restrict__ i
     }
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
-      if (act[r]) __builtin_nontemporal_store(mapped[r] ? v[r] : 0.0, d + po[r]);
+      if (act[r]) stream_store_lane(mapped[r] ? v[r] : 0.0, d + po[r], (unsigned)(threadIdx.x & 63) * 8u);   // geom.h: per lane
     s += nsrc;
     d += P;
   }
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(512) void k_apply3_lf(const int32_t *__restrict__ i
   __syncthreads();
   double *df = dst + (int64_t)fld * nlev * P;
   if (oact)
-    for (int k = wave; k < nlev; k += WAVES) __builtin_nontemporal_store(tile[k * 65 + lane], df + (int64_t)k * P + op);
+    for (int k = wave; k < nlev; k += WAVES) stream_store_lane(tile[k * 65 + lane], df + (int64_t)k * P + op, (unsigned)lane * 8u);
 }
 // "lf_variant" knob: -1 per-handle choice (default) between 0 and 1; 0 row gather on linear aligned tiles
 // (k_apply3_lf_rows), 1 level-chunked LDS-staged kernel (k_apply_lfu.hip), 2 row gather on grid-row tiles (k_apply3_lf /
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_apply1(const int32_t *__restrict__ idx,
   for (int k = 0; k < nlev; ++k) {
     double v = 0.0;
     if (c >= 0) v = sf[k * step];
-    __builtin_nontemporal_store(v, df + (int64_t)k * P);
+    stream_store_lane(v, df + (int64_t)k * P, (unsigned)(threadIdx.x & 63) * 8u);
   }
 }
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_applyN(const int32_t *__restrict__ idx,
 #pragma unroll
       for (int q = 0; q < NNZ; ++q) acc = fma(ww[q], sf[c[q] + k * step], acc);
     }
-    __builtin_nontemporal_store(acc, df + (int64_t)k * P);
+    stream_store_lane(acc, df + (int64_t)k * P, (unsigned)(threadIdx.x & 63) * 8u);
   }
 }
 
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_apply_csr(const int32_t *__restrict__ r
       int32_t c = col[q];
       acc = fma(val[q], LEVF ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], acc);
     }
-    __builtin_nontemporal_store(acc, df + (int64_t)k * P);
+    stream_store_lane(acc, df + (int64_t)k * P, (unsigned)(threadIdx.x & 63) * 8u);
   }
 }
 
@@ -325,8 +325,13 @@ int mpg_k_tune(const char *key, int value) {
     mpg_set_staged_lds_pad_kb(value < 0 ? 0 : value);
     return MPG_SUCCESS;
   }
-  if (!strcmp(key, "lf_rows_store")) {   // store policy of the level-fast row gather's float32 results: 0 = per level by the alignment of its plane (geom.h stream_nt), 1 = plain, 2 = non-temporal (A/B)
-    if (value < 0 || value > 2) return MPG_ERR_INVALID_ARG;
+  if (!strcmp(key, "staged_store")) {   // A/B only: stores of the staged cell-fast kernel: 0 = per lane (geom.h stream_store_lane), 2 = every lane non-temporal
+    if (value != 0 && value != 2) return MPG_ERR_INVALID_ARG;
+    mpg_set_staged_store(value);
+    return MPG_SUCCESS;
+  }
+  if (!strcmp(key, "lf_rows_store")) {   // store policy of the level-fast row gather: 0 = float32 results per level by the alignment of its plane, float64 per lane (geom.h); 1 = plain, 2 = non-temporal, 3 = per lane (A/B)
+    if (value < 0 || value > 3) return MPG_ERR_INVALID_ARG;
     mpg_set_lf_rows_store(value);
     return MPG_SUCCESS;
   }

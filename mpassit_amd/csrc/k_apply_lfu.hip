@@ -187,7 +187,7 @@ template <typename TS, typename TD, int RPT, int NT, bool EPI>
 __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ ut_cnt, const int32_t *__restrict__ ut_cells, int stride,
                                                    const uint16_t *__restrict__ lidx, const double *__restrict__ w,
                                                    const TS *__restrict__ src, TD *__restrict__ dst, int nx, int ny, int talign, int64_t nsrc,
-                                                   int nlev, int ntx, int nty, int ut_max, double scale, double offset, int band, FieldTab tab) {
+                                                   int nlev, int ntx, int nty, int ut_max, double scale, double offset, int band, int st_all_nt, FieldTab tab) {
   constexpr int LC = 4, UPT = 4, NPF = LC * UPT;
   extern __shared__ double lds[];  // [LC][nup]
   const int nup = ut_max;
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ u
   const TS *sf = mpg_field_src(tab, src, f, (int64_t)nlev * nsrc);
   TD *df = mpg_field_dst(tab, dst, f, (int64_t)nlev * P);
   if constexpr (EPI) offset = mpg_field_off(tab, f, offset);
+  const unsigned lane_bytes = (unsigned)(t & 63) * (unsigned)sizeof(TD);   // geom.h stream_store_lane
   int32_t cell[UPT];
 #pragma unroll
   for (int u = 0; u < UPT; ++u) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(NT) void k_apply3_cfu(const int32_t *__restrict__ u
         double val = wsum3(pts.ww[r][0], a, pts.ww[r][1], b, pts.ww[r][2], e);
         val = pts.mapped[r] ? val : 0.0;
         if constexpr (EPI) val = fma(val, scale, offset);
-        if (pts.act[r]) __builtin_nontemporal_store((TD)val, df + (int64_t)(k0 + kk) * P + pts.off[r]);
+        if (pts.act[r]) stream_store_lane((TD)val, df + (int64_t)(k0 + kk) * P + pts.off[r], lane_bytes, st_all_nt != 0);
       }
     }
     __syncthreads();
@@ -440,6 +441,8 @@ void mpg_lfu_set_min_reuse_x10(int v) { g_lfu_min_reuse = 0.1f * (float)v; }
 // indices and weights per point are 7 % of its traffic and a band's 2.4 MB stay in the XCD's L2 from one field to the
 // next); the staged kernels LOSE 12-17 % on configuration 5 (thirteen fields' source rows then compete for the L2 that
 // serves the re-read ring of neighbouring tiles) and are level on configuration 4: they stay field-major.
+static int g_staged_store = 0;   // "staged_store" knob (A/B): 0 = per lane (geom.h stream_store_lane), 2 = every lane non-temporal (rounds 2-6a)
+void mpg_set_staged_store(int v) { g_staged_store = v; }
 static int g_field_band = -1;
 int mpg_field_band(int kernel_default) { return g_field_band < 0 ? kernel_default : g_field_band; }
 void mpg_set_field_band(int v) { g_field_band = v; }
@@ -518,7 +521,7 @@ static int launch_cfu(mpg_handle_s *h, const void *src, int nlev, int nfields, v
   auto fn = k_apply3_cfu<TS, TD, RPT, NT, EPI>;
   if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   fn<<<(unsigned)ntx * nty * nfields, NT, lds, s>>>(h->ut_cnt.p, h->ut_cells.p, h->ut_stride, h->lidx.p, h->w.p, (const TS *)src, (TD *)dst, h->nx_dst,
-                                                   h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset, mpg_field_band(0), tab);
+                                                   h->ny_dst, h->ut_align, h->n_src, nlev, ntx, nty, (int)um, scale, offset, mpg_field_band(0), g_staged_store == 2, tab);
   MPG_HIP(hipGetLastError());
   return MPG_SUCCESS;
 }
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(NT) void k_apply3_lfu(const int32_t *__restrict__ u
     const double a = (double)slab[l0 + col], b = (double)slab[l1 + col], e = (double)slab[l2 + col];
     double val = wsum3(w0, a, w1, b, w2, e);
     if constexpr (EPI) val = fma(val, scale, offset);
-    buf_store_nt(swz<SWZ>((TD)val, zd), buf_rsrc(dlev, plane), pb);
+    buf_store_nt(swz<SWZ>((TD)val, zd), buf_rsrc(dlev, plane), pb);   // every lane non-temporal: the per-lane form of geom.h cost this 16-times unrolled body 16 % on configuration 5's (aligned) planes, profiles/r06_plane_alignment.md
     dlev += P;
   };
   fetch(nch > 1 ? 0 : k0_last);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf_t(const int32_t *__restrict__
     }
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
-      if (act[r]) __builtin_nontemporal_store(swz<SWZ>((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), zd), d + po[r]);
+      if (act[r]) stream_store_lane(swz<SWZ>((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), zd), d + po[r], (unsigned)lane * (unsigned)sizeof(TD));   // geom.h: per lane
     s += nsrc;
     d += P;
   }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_apply3_cf_fields(const int32_t *__restr
     }
 #pragma unroll
     for (int r = 0; r < RPT; ++r)
-      if (act[r]) __builtin_nontemporal_store(swz<SWZ>((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), zd), d + po[r]);
+      if (act[r]) stream_store_lane(swz<SWZ>((TD)fma(mapped[r] ? v[r] : 0.0, scale, offset), zd), d + po[r], (unsigned)lane * (unsigned)sizeof(TD));   // geom.h: per lane
   }
 }
 
@@ -182,8 +182,7 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
   int j = ty, i = tx * 64 + lane - mpg_tile_shift(j, nx);
   if (i >= 0 && i < nx && j < ny) {
     int64_t p = (int64_t)j * nx + i;
-    for (int k = wave; k < nlev; k += 4)   // float32 results: per level, by the alignment of its plane (geom.h); float64: non-temporal
-      stream_store(tile[k * 65 + lane], df + (int64_t)k * P + p, sizeof(TD) == 8 || (mpg_tile_align(nx) == 32 && stream_nt(df + (int64_t)k * P)));
+    for (int k = wave; k < nlev; k += 4) stream_store_lane(tile[k * 65 + lane], df + (int64_t)k * P + p, (unsigned)lane * (unsigned)sizeof(TD));   // geom.h: per lane
   }
 }
 
@@ -192,8 +191,8 @@ __global__ __launch_bounds__(256) void k_apply3_lf_t(const int32_t *__restrict__
 // naturally aligned whatever nx is (64 x 1 tiles of a 1800-wide grid start 32 bytes off a line in three rows of four:
 // 10 % more bytes written, PMC, and two partial lines per store) -- IF the level's plane starts on a line, which only
 // planes of a multiple of 32 (16) points do: the row block of a sharded job (133 x 1800), a stagger (1801 x 1060) or any
-// odd grid puts level k's plane k * P * sizeof(TD) mod 128 bytes into one, and non-temporal stores of such float32 segments
-// cost up to 14 % of the kernel (profiles/r06_plane_alignment.md).  stream_store (geom.h) decides per level.  Phase 0 stages the tile's three cell offsets
+// odd grid puts level k's plane k * P * sizeof(TD) mod 128 bytes into one, and non-temporal stores of such segments cost 14-29 %
+// of the kernel (profiles/r06_plane_alignment.md).  geom.h decides: float32 results per level, float64 results per lane.  Phase 0 stages the tile's three cell offsets
 // (premultiplied by nlev, 32 bit, added to a scalar field base: no 64-bit address arithmetic per load) and weights in
 // LDS; phase 1: a half-wave covers 64 levels of one point with ONE load per row, two levels per lane (8 bytes of a
 // float32 row, 16 of a float64 row; rows are only element-aligned -- 55 float32 levels are 220 bytes -- which the
@@ -284,8 +283,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   TD *df = mpg_field_dst(tab, dst, f, (int64_t)nlev * P) + p0;
   if (p0 + lane < P)
     for (int k = wave; k < nlev; k += 4) {
-      TD *row = df + (int64_t)k * P;   // wave-uniform; st_mode: the "lf_rows_store" knob (0: float64 results non-temporal, float32 by the plane's alignment)
-      stream_store(tile[k * 65 + lane], row + lane, st_mode ? st_mode == 2 : (sizeof(TD) == 8 || stream_nt(row)));
+      TD *row = df + (int64_t)k * P;   // wave-uniform.  st_mode: the "lf_rows_store" knob -- 0: float64 results per lane (+22 % on planes 8 / 24 bytes off a line), float32 per level
+      // (their 256-byte runs hold one whole line at most: per lane and per level measured equal); 1 plain, 2 non-temporal, 3 per lane (A/B)
+      const bool per_lane = st_mode == 3 || (st_mode == 0 && sizeof(TD) == 8);
+      stream_store(tile[k * 65 + lane], row + lane, per_lane ? stream_lane_full(row + lane, (unsigned)lane * (unsigned)sizeof(TD)) : st_mode ? st_mode == 2 : stream_nt(row));
     }
 }
 
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
         int32_t c = col[q];
         acc = fma(val[q], (double)swz<SWZ>(lev_fast ? sf[(int64_t)c * nlev + k] : sf[(int64_t)k * nsrc + c], zs), acc);
       }
-      __builtin_nontemporal_store(swz<SWZ>((TD)fma(acc, scale, offset), zd), df + (int64_t)k * P + p);
+      stream_store_lane(swz<SWZ>((TD)fma(acc, scale, offset), zd), df + (int64_t)k * P + p, (unsigned)(threadIdx.x & 63) * (unsigned)sizeof(TD));
     }
   } else {
     int32_t c[NNZ];
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
     // share one in-order counter on gfx950, so a load issued after a store cannot be consumed before that store has been
     // acknowledged -- with the loads in front, a step waits for its own data only (s_waitcnt vmcnt(2): the two stores stay
     // in flight).
-    auto put = [&](int k, const double *v) { __builtin_nontemporal_store(swz<SWZ>((TD)fma(combine(v), scale, offset), zd), df + (int64_t)k * P + p); };
+    auto put = [&](int k, const double *v) { stream_store_lane(swz<SWZ>((TD)fma(combine(v), scale, offset), zd), df + (int64_t)k * P + p, (unsigned)(threadIdx.x & 63) * (unsigned)sizeof(TD)); };
     double a0[NNZ], a1[NNZ];
     level(0, a0);
     level(nlev > 1 ? 1 : 0, a1);
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void k_apply_generic_t(const int32_t *__restri
 // the (field, tile) order of the row gather: bands of 1024 tiles (64 K points, 2.4 MB of indices + weights: they stay in the
 // XCD's L2 from one field of the bundle to the next), all fields of a band before the next band -- 4 % on configuration 4
 #define LF_ROWS_BAND 1024
-static int g_lf_rows_store = 0;   // "lf_rows_store" knob: 0 = float32 results per level by the alignment of its plane (geom.h stream_nt), float64 non-temporal; 1 = plain, 2 = non-temporal (A/B)
+static int g_lf_rows_store = 0;   // "lf_rows_store" knob: 0 = float32 results per level by the alignment of its plane (geom.h stream_nt), float64 per lane (stream_lane_full); 1 = plain, 2 = non-temporal, 3 = per lane (A/B)
 void mpg_set_lf_rows_store(int v) { g_lf_rows_store = v; }
 static size_t lf_rows_lds(size_t dst_size, int nlev) { return dst_size * 65 * (size_t)nlev + sizeof(double) * 192 + sizeof(int32_t) * 192; }
 static bool lf_rows_fits(const mpg_handle_s *h, size_t dst_size, int nlev) {

@@ -76,11 +76,12 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   const bool per = a.periodic != 0, do_u = (a.mode & 1) != 0, do_v = (a.mode & 2) != 0;
   const bool src_u = ROT || do_u, src_v = ROT || do_v;
   const Swz zd = make_swz(a.dbe);
-  // U / V segments start on multiples of WD_A = 8 elements: 64 bytes of a float64 row (non-temporal stores: level with plain ones on the
-  // README's grid), 32 bytes of a float32 row -- three segments of four then start inside a 128-byte line, and the partial lines of
-  // neighbouring workgroups only meet in L2 under write-back stores (0.678 against 0.722 ms, profiles/r06_plane_alignment.md).  Chosen
-  // per instantiation, not per level: a branch around stores in this loop would make every level wait for the stores before it (below).
-  constexpr bool ST_NT = MPG_STREAM_STORE_MODE ? MPG_STREAM_STORE_MODE == 2 : sizeof(TD) == 8;
+  // U / V segments start on multiples of WD_A = 8 elements of a row -- 64 bytes (float64) / 32 bytes (float32) into a 128-byte line at
+  // best, and U / V planes are not whole numbers of lines (1801 x 1060, 1800 x 1061): every level's runs have partial lines at their
+  // ends.  Stored per LANE (geom.h buf_store_lane: whole lines non-temporal, the ends write-back so that the neighbour's part meets
+  // them in L2): no branch, both stores under complementary lane masks -- a branch around stores in this loop would make every level
+  // wait for the stores before it (below).
+  const unsigned lane_bytes = (unsigned)lane * (unsigned)sizeof(TD);
 
   // ---- this thread's window points: byte offset inside a level plane (MPG_BUF_NONE: outside the grid -> loads 0) ----
   uint32_t gb[WD_WPT];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
   {
     const BufRsrc none = buf_rsrc(nullptr, 0u);
 #pragma unroll
-    for (int r = 0; r < 2 * WD_RPT; ++r) buf_store_pick<ST_NT>((TD)0, none, MPG_BUF_NONE);
+    for (int r = 0; r < 2 * WD_RPT; ++r) buf_store_lane((TD)0, none, nullptr, MPG_BUF_NONE, lane_bytes);
   }
   for (int k = 0; k < nlev; ++k) {
     double *bu = lds + (k & 1) * 2 * WD_NW, *bv = bu + WD_NW;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         acc = fma(wu[r][1], q[1], acc);
         acc = fma(wu[r][2], q[WD_WW + 1], acc);
         acc = fma(wu[r][3], q[WD_WW], acc);
-        buf_store_pick<ST_NT>(finish(acc, mapu[r]), ou, pu[r]);
+        buf_store_lane(finish(acc, mapu[r]), ou, uplane, pu[r], lane_bytes);
       }
       {
         const double *q = bv + lv[r];
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(WD_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         acc = fma(wv[r][1], q[1], acc);
         acc = fma(wv[r][2], q[WD_WW + 1], acc);
         acc = fma(wv[r][3], q[WD_WW], acc);
-        buf_store_pick<ST_NT>(finish(acc, mapv[r]), ov, pv[r]);
+        buf_store_lane(finish(acc, mapv[r]), ov, vplane, pv[r], lane_bytes);
       }
     }
     uplane += P1;

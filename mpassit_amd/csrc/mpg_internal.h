@@ -323,6 +323,7 @@ void mpg_lfu_set_min_reuse_x10(int v);  // k_apply_lfu.hip
 int mpg_field_band(int kernel_default);   // "field_band" knob, or the calling kernel's default when the knob is -1
 void mpg_set_field_band(int v);
 void mpg_lfu_set_npf(int v);                // "lfu_npf" knob (k_apply_lfu.hip)
+void mpg_set_staged_store(int v);            // "staged_store" knob (k_apply_lfu.hip; A/B only)
 void mpg_set_lf_rows_store(int v);          // "lf_rows_store" knob (k_apply_typed.hip; A/B only)
 void mpg_set_staged_lds_pad_kb(int v);      // "staged_lds_pad_kb" knob (k_apply_lfu.hip; A/B only)
 bool mpg_handle_is_windowed(const mpg_handle_s *h);   // mpg_api.hip: its mesh carries a source window (indices are window-relative)

@@ -48,6 +48,12 @@ def workload(name, arrays=True):
         g = conus_lambert_grid(nx=1793)
         m = synth.regional_mesh_for_lambert(g.proj, 1801, 1061, 3_000_000)
         return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1793x1061 Lambert (1792x1060 mass points)"
+    if name == "x_c4_1799x1059":
+        # extra (round 6, plane alignment): configuration 4's mesh under HRRR's own grid size -- 1799 x 1059 mass points, an odd
+        # number of points per level: plane k of every result starts k * 84 (float32) / k * 40 (float64) bytes (mod 128) into a line
+        g = conus_lambert_grid(nx=1800, ny=1060)
+        m = synth.regional_mesh_for_lambert(conus_lambert_grid().proj, 1801, 1061, 3_000_000)
+        return m, g, 55, "3.0 M-cell regional hex mesh x 55 levels -> 1800x1060 Lambert (1799x1059 mass points: planes of an odd number of points)"
     if name.startswith("x_c4_rows"):
         # extra (strong-scaling rehearsal on one GPU): one rank's share of configuration 4 at N ranks = a block of
         # 1060 / N grid rows of the same 1800-wide grid over the same mesh, e.g. x_c4_rows133 for N = 8

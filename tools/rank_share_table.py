@@ -50,6 +50,7 @@ def main():
     es = 4 if args.io == "f32" else 8
     table = []
     t1 = None
+    warm = False
     for N in [int(x) for x in args.ranks.split(",")]:
         objs, needed = [], []
         for q in range(N):
@@ -78,8 +79,9 @@ def main():
                     rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
                 else:
                     rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
-            for _ in range(3):
+            for _ in range(3 if warm else 40):   # the first measurement of a process is slow by up to 10 % (clocks, first-touch): N = 1 is everybody's yardstick
                 launch()
+            warm = True
             torch.cuda.synchronize()
             ms = []
             for _ in range(args.reps):
