@@ -539,7 +539,9 @@ def main():
             flat.update({k: c3[k] for k in ("c3_conserve_ms", "c3_conserve_frac", "c3_nearest_soil_ms", "c3_nearest_soil_frac", "c3_store_conserve_first_ms",
                                             "c3_store_nearest_first_ms", "c3_job_cold_first_ms", "c3_job_warm_ms", "c3_job_warm_frac")})
         if numbering:                  # the headline's kernel on the same cells numbered as production meshes are
-            flat.update(morton_numbering_frac=round(numbering["roofline_frac"], 4), cutout_numbering_frac=round(numbering["cutout"]["roofline_frac"], 4))
+            flat.update(morton_numbering_frac=round(numbering["roofline_frac"], 4), cutout_numbering_frac=round(numbering["cutout"]["roofline_frac"], 4),
+                        odd_grid_1799x1059_frac=round(numbering["odd_grid"]["roofline_frac"], 4),
+                        odd_grid_1799x1059_f32_lev_fast_frac=round(numbering["odd_grid_f32_lev_fast"]["roofline_frac"], 4))
         if traffic:
             flat["traffic_ratio"] = round(traffic / alg_bytes, 3)
         rec = {
@@ -583,29 +585,41 @@ def realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, rh_r
     """The same step on the same 3.0 M cells numbered as production meshes are -- c4_3m_morton: along a Morton curve over the region itself;
     c4_3m_cutout (round 6): as a limited-area CUT-OUT of a global mesh numbered along a space-filling curve over the whole sphere (how
     MPAS-Limited-Area leaves a regional mesh) -- fields/s, roofline fraction, the kernel the library picked and its tile-list locality
-    statistics next to those of the row-numbered headline mesh.  The Morton leg's keys stay at the top level; `cutout` holds the other."""
-    def one(name):
+    statistics next to those of the row-numbered headline mesh.  The Morton leg's keys stay at the top level; `cutout` holds the other.
+    `odd_grid` (round 6): the headline's mesh under HRRR's own grid size, 1799 x 1059 mass points -- an odd number of points per level, so
+    every level plane of the result starts somewhere else inside a 128-byte line (profiles/r06_plane_alignment.md); `odd_grid_f32_lev_fast`:
+    the same in float32 file order, what the driver issues."""
+    def one(name, f32_file_order=False):
         m, g, nlev, desc = workloads.workload(name)
         mesh, grid = R.Mesh.from_mpas(m), R.Grid.from_target(g)
         rh = R.regrid_store(mesh, grid, R.REGRIDMETHOD_BILINEAR)
         U = rh.unique_sources().size
         src = torch.empty((F * nlev, m.nCells), dtype=torch.float64, device=dev)
         synth_fields_device(torch, m.latCell, m.lonCell, nlev, F, src)
-        if layout == R.LAYOUT_LEV_FAST:
-            src = src.view(F, nlev, -1).permute(0, 2, 1).contiguous()
+        lay, es = layout, 8.0
+        if f32_file_order:
+            lay, es = R.LAYOUT_LEV_FAST, 4.0
+            src = src.view(F, nlev, -1).permute(0, 2, 1).to(torch.float32).contiguous()
+            o = out.view(-1).view(torch.float32)[:F * nlev * rh.n_dst].view(F, nlev, g.ny, g.nx)
+            launch = lambda: rh.regrid_typed(src.view(-1), nlev=nlev, nfields=F, layout=lay, out=o)   # noqa: E731
+        else:
+            if layout == R.LAYOUT_LEV_FAST:
+                src = src.view(F, nlev, -1).permute(0, 2, 1).contiguous()
+            o = out.view(-1)[:F * nlev * rh.n_dst].view(F, nlev, g.ny, g.nx)   # the headline's result buffer: starts on a line
+            launch = lambda: rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=lay, out=o)   # noqa: E731
         steps = max(3, min(args.steps, 10))
         for _ in range(2):
-            rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(steps):
-            rh.regrid(src.view(-1), nlev=nlev, nfields=F, layout=layout, out=out)
+            launch()
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
-        alg = F * nlev * 8.0 * (U + rh.n_dst) + rh.n_dst * 36.0
-        res = {"workload": name, "fields_per_s": F / ms * 1e3, "kernel_ms": ms, "steps": steps,
-               "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel_label(rh, layout, R),
+        alg = F * nlev * es * (U + rh.n_dst) + rh.n_dst * 36.0
+        res = {"workload": name, "fields_per_s": F / ms * 1e3, "kernel_ms": ms, "steps": steps, "target_points": int(rh.n_dst),
+               "roofline_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel_label(rh, lay, R),
                "tile_stats": dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh.tile_stats() or ()))}
         rh.release()
         mesh.destroy()
@@ -615,6 +629,8 @@ def realistic_numbering_leg(torch, R, workloads, args, F, layout, dev, out, rh_r
     res = one("c4_3m_morton")
     res["tile_stats_row_numbered"] = dict(zip(("tile_nx", "tile_ny", "reuse", "line_fill"), rh_rows.tile_stats() or ()))
     res["cutout"] = one("c4_3m_cutout")
+    res["odd_grid"] = one("x_c4_1799x1059")
+    res["odd_grid_f32_lev_fast"] = one("x_c4_1799x1059", f32_file_order=True)
     return res
 
 
