@@ -37,6 +37,7 @@
 int mpg_field_band(int kernel_default);
 static int g_staged_lds_pad_kb = 0;   // "staged_lds_pad_kb" knob (A/B): extra dynamic LDS per workgroup of k_apply3_cfu / k_apply3_lfu
 void mpg_set_staged_lds_pad_kb(int v) { g_staged_lds_pad_kb = v; }
+int mpg_staged_lds_pad_kb() { return g_staged_lds_pad_kb; }
 #define LFU_THREADS 256
 #define LFU_LIST_PAD 1024  // a tile's list is padded with its last cell up to the row count of its class: 64, 128 ... this many (min stride)
 #define LFU_SORT 4096   // sort buffer: 3 ids x (at most) 1024 points, padded to a power of two

@@ -394,7 +394,7 @@ static int launch_typed(mpg_handle_s *h, const void *src, int layout, int nlev, 
   int lev_fast = layout == MPG_LAYOUT_LEV_FAST && nlev > 1;
   if (h->kind == MPG_KIND_FIXED && h->nnz_per_row == 3) {
     if (lev_fast && mpg_lf_variant() != MPG_LF_ROWTILES && lf_rows_fits(h, sizeof(TD), nlev)) {
-      const size_t lds = lf_rows_lds(sizeof(TD), nlev);
+      const size_t lds = std::min<size_t>(lf_rows_lds(sizeof(TD), nlev) + (size_t)mpg_staged_lds_pad_kb() * 1024, 160 * 1024);   // the pad: A/B knob, 0 in production
       const unsigned ntile = (unsigned)((P + 63) / 64);
       auto fn = k_apply3_lf_rows<TS, TD, sizeof(TS) == 4 ? 2 : 1, true, SWZ>;   // measured: unroll 2 for float32 rows, 1 for float64
       if (lds > 48 * 1024) MPG_HIP(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -326,6 +326,7 @@ void mpg_lfu_set_npf(int v);                // "lfu_npf" knob (k_apply_lfu.hip)
 void mpg_set_staged_store(int v);            // "staged_store" knob (k_apply_lfu.hip; A/B only)
 void mpg_set_lf_rows_store(int v);          // "lf_rows_store" knob (k_apply_typed.hip; A/B only)
 void mpg_set_staged_lds_pad_kb(int v);      // "staged_lds_pad_kb" knob (k_apply_lfu.hip; A/B only)
+int mpg_staged_lds_pad_kb();
 bool mpg_handle_is_windowed(const mpg_handle_s *h);   // mpg_api.hip: its mesh carries a source window (indices are window-relative)
 void mpg_cache_detach(mpg_handle_s *h);  // mpg_api.hip: a handle about to be re-indexed in place leaves the Store cache
 void mpg_hostpipe_release();  // mpg_hostpipe.hip: device slots / streams of the host-pointer Regrid pipeline, dropped by mpg_finalize
