@@ -553,6 +553,8 @@ def main():
                        "target_points": int(g.nx * g.ny), "method": "bilinear", "src_layout": args.layout,
                        "io_dtype": "f32 (fused ingest/egress, f64 arithmetic)" if io32 else "f64",
                        "parallelism": "rows%d+halo(%s,%s)" % (world, primary.mode, "c-abi rccl" if transport == "cabi" else "torch " + backend) if world > 1 else "single-gpu",
+                       "row_split": ("para_range" if mdist.row_quantum(g.nx, g.ny, world) == 1 else "block boundaries on multiples of %d rows (planes of whole 128-byte lines)"
+                                     % mdist.row_quantum(g.nx, g.ny, world)) if world > 1 else None,
                        "unmapped_points_rank0": n_unmapped, "bundle_ends_equal_single": bundle_check},
             "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": traffic, "traffic_source": traffic_source, "kernel": primary.kernel,
