@@ -473,6 +473,12 @@ int mpg_halo_plan_owned_host(int rank, int nranks, const int64_t *n_needed, cons
  *   "lfu_min_reuse_x10"   threshold (x10) of the per-handle level-fast choice (default 35)
  *   "lfu_npf"     row slots per thread of the staged level-fast kernel: 0 (default) = by the handle's longest tile list (2 / 4 / 8 / 16),
  *                 16 = the fixed shape of rounds 1-4 (A/B measurements; the results are the same bits)
+ *   "lf_rows_store", "staged_store"   how results are STORED (never what: the same bits).  A result is [nlev][ny][nx]; level k's plane starts on a
+ *                 128-byte line only when ny * nx is a multiple of 32 (float32) / 16 (float64) points, and the kernels' runs of 64 points of a plane
+ *                 that does not have a partial line at either end.  Default 0: whole lines non-temporal, partial lines write-back (per lane;
+ *                 the row gather's float32 results per level).  "lf_rows_store" 1 / 2 / 3: the file-order row gather plain / non-temporal / per lane;
+ *                 "staged_store" 2: the staged cell-fast kernel non-temporal on every lane (what rounds 2-6a shipped).  A/B only
+ *                 (profiles/r06_plane_alignment.md: 14-29 % on grids with an odd number of points per level)
  * Unknown keys and out-of-range values return MPG_ERR_INVALID_ARG. */
 int mpg_tune(const char *key, int value);
 
